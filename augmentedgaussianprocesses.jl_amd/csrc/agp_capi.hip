@@ -1,0 +1,1267 @@
+// agp_capi.hip -- C ABI of libagp_hip.so (see include/agp_hip.h).  Host-side orchestration of the gfx950 kernels in
+// agp_linalg.h / agp_cavi.h: one process per GPU, everything enqueued on the caller's HIP stream.
+#include "../../include/agp_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "agp_cavi.h"
+#include "agp_linalg.h"
+
+using namespace agp;
+
+struct agp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+};
+
+#define HIPCHK(ctx, expr)                                                                       \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess) {                                                                     \
+      (ctx)->err = std::string(#expr) + " : " + hipGetErrorString(_e);                          \
+      return AGP_ERR_HIP;                                                                       \
+    }                                                                                           \
+  } while (0)
+
+#define LAUNCHCHK(ctx)                                                                          \
+  do {                                                                                          \
+    hipError_t _e = hipGetLastError();                                                          \
+    if (_e != hipSuccess) {                                                                     \
+      (ctx)->err = std::string("kernel launch : ") + hipGetErrorString(_e) + " @" + std::to_string(__LINE__); \
+      return AGP_ERR_HIP;                                                                       \
+    }                                                                                           \
+  } while (0)
+
+#define AGPCHK(expr)                   \
+  do {                                 \
+    agp_status _s = (expr);            \
+    if (_s != AGP_OK) return _s;       \
+  } while (0)
+
+static inline int64_t rup64(int64_t x) { return (x + 63) / 64 * 64; }
+static inline dim3 grid1(int64_t n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
+static inline dim3 grid2(int64_t rows, int64_t cols) { return dim3((unsigned)((cols + 15) / 16), (unsigned)((rows + 15) / 16)); }
+static const dim3 blk2(16, 16);
+
+template <typename T>
+static agp_status dmalloc(agp_ctx* c, T** p, int64_t n) {
+  *p = nullptr;
+  if (n <= 0) n = 1;
+  hipError_t e = hipMalloc((void**)p, (size_t)n * sizeof(T));
+  if (e != hipSuccess) {
+    c->err = std::string("hipMalloc : ") + hipGetErrorString(e);
+    return AGP_ERR_NOMEM;
+  }
+  return AGP_OK;
+}
+
+// ---- linear-algebra drivers on padded matrices ---------------------------------------------------------------
+// Cholesky in place (lower) of the n x n (n = nt*64) matrix A; writes the inverses of the diagonal blocks into X.
+template <typename T>
+static agp_status potrf_padded(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int64_t ldx, int32_t* info_dev,
+                               int64_t nvalid) {
+  const int64_t nt = n / TILE;
+  for (int64_t k = 0; k < nt; ++k) {
+    hipLaunchKernelGGL((k_potrf_panel<T>), dim3((unsigned)(nt - k)), dim3(NTHREADS), 0, c->stream, A, ld, k, X, ldx,
+                       info_dev, nvalid);
+    const int64_t nr = nt - k - 1;
+    if (nr > 0)
+      hipLaunchKernelGGL((k_potrf_update<T>), dim3((unsigned)(nr * (nr + 1) / 2)), dim3(NTHREADS), 0, c->stream, A, ld,
+                         k);
+  }
+  LAUNCHCHK(c);
+  return AGP_OK;
+}
+
+// X = L^-1 (diagonal blocks already in X); Tw is an n x n scratch
+template <typename T>
+static agp_status trtri_padded(agp_ctx* c, const T* L, int64_t ld, int64_t n, T* X, int64_t ldx, T* Tw, int64_t ldt) {
+  for (int64_t h = TILE; h < n; h *= 2) {
+    const int64_t pairs = (n + 2 * h - 1) / (2 * h);
+    dim3 g((unsigned)(h / TILE), (unsigned)(h / TILE), (unsigned)pairs);
+    hipLaunchKernelGGL((k_trtri_step<T>), g, dim3(NTHREADS), 0, c->stream, L, ld, X, ldx, Tw, ldt, n, h, 0);
+    hipLaunchKernelGGL((k_trtri_step<T>), g, dim3(NTHREADS), 0, c->stream, L, ld, X, ldx, Tw, ldt, n, h, 1);
+  }
+  LAUNCHCHK(c);
+  return AGP_OK;
+}
+
+// out = X' X for lower-triangular X  (A^-1 from its inverse Cholesky factor)
+template <typename T>
+static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* out, int64_t ldo) {
+  const int64_t nt = n / TILE;
+  hipLaunchKernelGGL((k_syrk_tn<T, SY_STORE>), dim3((unsigned)(nt * (nt + 1) / 2)), dim3(NTHREADS), 0, c->stream, X, ld,
+                     n, (const T*)nullptr, 1, out, ldo, (T*)nullptr, (const T*)nullptr, (int64_t)0, (const T*)nullptr);
+  LAUNCHCHK(c);
+  return AGP_OK;
+}
+
+template <typename T, int EPI>
+static agp_status gemm_nt(agp_ctx* c, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                          int tri_b, T* C, int64_t ldc, const T* E, int64_t lde, const T* v, T* p0, T* p1,
+                          int64_t ldp) {
+  dim3 g((unsigned)(N / TILE), (unsigned)(M / TILE));
+  hipLaunchKernelGGL((k_gemm_nt<T, EPI>), g, dim3(NTHREADS), 0, c->stream, A, lda, B, ldb, K, tri_b, C, ldc, E, lde, v,
+                     p0, p1, ldp);
+  LAUNCHCHK(c);
+  return AGP_OK;
+}
+
+// ---- model ---------------------------------------------------------------------------------------------------
+struct KernelHost {
+  int kind = AGP_K_SQEXP;
+  double variance = 1.0;
+  std::vector<double> scales;  // length D
+};
+
+struct SvgpBase {
+  agp_ctx* ctx = nullptr;
+  agp_svgp_desc desc{};
+  virtual ~SvgpBase() {}
+  virtual agp_status init() = 0;
+  virtual agp_status set_kernel(int l, const agp_kernel_desc* k) = 0;
+  virtual agp_status set_Z(int l, const void* z, int64_t ldz) = 0;
+  virtual agp_status get_Z(int l, void* z, int64_t ldz) = 0;
+  virtual agp_status set_mu0(int l, const void* mu0) = 0;
+  virtual agp_status refresh_K() = 0;
+  virtual agp_status step_local(const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B, double rho,
+                                bool fresh) = 0;
+  virtual agp_status lsm_gamma() = 0;
+  virtual agp_status lsm_alpha() = 0;
+  virtual agp_status lsm_gsum_ptr(void** p, int64_t* n) = 0;
+  virtual agp_status step_stats(bool fused) = 0;
+  virtual agp_status stats_ptr(void** p, int64_t* n) = 0;
+  virtual agp_status step_global(bool fused) = 0;
+  virtual agp_status check_status() = 0;
+  virtual agp_status elbo(const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B, double rho,
+                          int fresh, double* out) = 0;
+  virtual agp_status get_state(int l, void* mu, void* sigma, void* eta1, void* eta2) = 0;
+  virtual agp_status set_state(int l, const void* eta1, const void* eta2) = 0;
+  virtual agp_status get_matrix(int l, int which, void* out, int64_t ldo) = 0;
+  virtual agp_status predict_f(const void* xt, int64_t ldx, int64_t nt, void* mu, void* var) = 0;
+  virtual agp_status predict_y(const void* xt, int64_t ldx, int64_t nt, void* out) = 0;
+  virtual agp_status proba_y(const void* xt, int64_t ldx, int64_t nt, const double* nodes, const double* weights,
+                             int nn, void* o0, void* o1) = 0;
+  int64_t n_opt = 1;  // RobbinsMonro counter (optimisers.jl:12)
+};
+
+struct agp_svgp {
+  SvgpBase* impl;
+};
+
+template <typename T>
+struct Svgp : SvgpBase {
+  struct Latent {
+    KernelHost k;
+    T* scales = nullptr;  // device, D
+    T* Z = nullptr;       // m x D
+    T* L = nullptr;       // mp x mp : K then chol(K) (lower)
+    T* Xk = nullptr;      // L^-1
+    T* Kinv = nullptr;
+    T* mu0 = nullptr;
+    T* kinv_mu0 = nullptr;
+    T* eta1 = nullptr;
+    T* eta2 = nullptr;
+    T* La = nullptr;      // -2*eta2 then its Cholesky factor
+    T* Xa = nullptr;      // La^-1   (Sigma = Xa' Xa)
+    T* v = nullptr;       // Xa eta1 (mu = Xa' v)
+    T* Sigma = nullptr;
+    T* mu = nullptr;
+    T* Knm = nullptr;
+    T* kappa = nullptr;
+    T* Apred = nullptr;   // K^-1 - K^-1 Sigma K^-1
+    T* apred = nullptr;   // K^-1 mu
+    bool K_stale = true, post_valid = false, pred_valid = false, predvar_valid = false, kappa_valid = false;
+    double half_logdetK = 0.0;
+  };
+  std::vector<Latent> lat;
+  int64_t m = 0, mp = 0, D = 0, Bmax = 0, Bp = 0;  // Bp = padded max batch
+  int nl = 0;
+  double jitter = 1e-4;
+  LikParams<T> lp{};
+  // shared batch buffers
+  T *pk = nullptr, *pw0 = nullptr, *pw1 = nullptr;  // partial slices [2*mp/64][ldp]
+  int64_t ldp = 0;
+  T *Kt = nullptr, *muf = nullptr, *varf = nullptr, *cbuf = nullptr, *theta = nullptr, *gamma = nullptr,
+    *rbuf = nullptr, *wbuf = nullptr;              // [nl][Bp]
+  T *alpha = nullptr, *beta = nullptr, *gsum = nullptr, *alpha_save = nullptr;  // [Bp]
+  T *emuf = nullptr, *evarf = nullptr;             // ELBO-time mean_f / var_f [nl][Bp]
+  T* cpart = nullptr;                              // [Bp/64][mp]
+  T* stats = nullptr;                              // [nl][mp + mp*mp]
+  T* Tw = nullptr;                                 // mp x mp scratch
+  T* Tw2 = nullptr;                                // mp x mp scratch (predict)
+  T* tmpv = nullptr;                               // mp
+  T* lr_dev = nullptr;
+  int32_t* info_dev = nullptr;
+  int* flags_dev = nullptr;
+  double* scal_dev = nullptr;                      // 16 doubles
+  // prediction workspace
+  T *Kstar = nullptr, *ppm = nullptr, *ppv = nullptr, *pmu = nullptr, *pvar = nullptr;
+  int64_t pred_chunk = 0, pred_nt_cap = 0;
+  double* gh_dev = nullptr;
+  int gh_cap = 0;
+  // last step
+  const void* x_last = nullptr;
+  const void* y_last = nullptr;
+  const int64_t* idx_last = nullptr;
+  int64_t B_last = 0, ldx_last = 0;
+  double rho_last = 1.0;
+
+  hipStream_t st() { return ctx->stream; }
+
+  agp_status init() override {
+    m = desc.m;
+    D = desc.D;
+    nl = desc.n_latent;
+    Bmax = desc.max_batch;
+    if (m <= 0 || D <= 0 || nl <= 0 || Bmax <= 0) {
+      ctx->err = "agp_svgp_create: m, D, n_latent, max_batch must be positive";
+      return AGP_ERR_INVALID;
+    }
+    mp = rup64(m);
+    Bp = rup64(Bmax);
+    jitter = desc.jitter > 0 ? desc.jitter : (sizeof(T) == 8 ? 1e-4 : 1e-3);
+    lp.kind = desc.lik.kind;
+    lp.p0 = (T)desc.lik.p0;
+    lp.p1 = (T)desc.lik.p1;
+    if (lp.kind < 0 || lp.kind > AGP_LIK_LOGISTICSOFTMAX) {
+      ctx->err = "likelihood not implemented for AnalyticVI on this path";
+      return AGP_ERR_UNSUPPORTED;
+    }
+    if (lp.kind == AGP_LIK_GAUSSIAN && !(desc.lik.p0 > 0)) return AGP_ERR_INVALID;
+    if (lp.kind == AGP_LIK_STUDENTT && !(desc.lik.p0 > 0.5)) {
+      ctx->err = "nu should be greater than 0.5";  // studentt.jl:28
+      return AGP_ERR_INVALID;
+    }
+    if (lp.kind != AGP_LIK_LOGISTICSOFTMAX && nl != 1) return AGP_ERR_INVALID;
+    if (desc.stochastic && !(desc.rm_kappa > 0.5 && desc.rm_kappa <= 1.0 && desc.rm_tau > 0)) {
+      ctx->err = "RobbinsMonro: kappa in (0.5,1], tau > 0";  // optimisers.jl:7-8
+      return AGP_ERR_INVALID;
+    }
+    lat.resize(nl);
+    const int64_t mm = mp * mp;
+    for (auto& g : lat) {
+      g.k.scales.assign(D, 1.0);
+      AGPCHK(dmalloc(ctx, &g.scales, D));
+      AGPCHK(dmalloc(ctx, &g.Z, m * D));
+      AGPCHK(dmalloc(ctx, &g.L, mm));
+      AGPCHK(dmalloc(ctx, &g.Xk, mm));
+      AGPCHK(dmalloc(ctx, &g.Kinv, mm));
+      AGPCHK(dmalloc(ctx, &g.eta1, mp));
+      AGPCHK(dmalloc(ctx, &g.eta2, mm));
+      AGPCHK(dmalloc(ctx, &g.La, mm));
+      AGPCHK(dmalloc(ctx, &g.Xa, mm));
+      AGPCHK(dmalloc(ctx, &g.v, mp));
+      AGPCHK(dmalloc(ctx, &g.Sigma, mm));
+      AGPCHK(dmalloc(ctx, &g.mu, mp));
+      AGPCHK(dmalloc(ctx, &g.Knm, Bp * mp));
+      AGPCHK(dmalloc(ctx, &g.kappa, Bp * mp));
+      AGPCHK(upload_scales(g));
+      AGPCHK(reset_posterior(g));
+    }
+    ldp = Bp;
+    const int ns = (int)(2 * mp / TILE);
+    AGPCHK(dmalloc(ctx, &pk, ns * ldp));
+    AGPCHK(dmalloc(ctx, &pw0, ns * ldp));
+    AGPCHK(dmalloc(ctx, &pw1, ns * ldp));
+    T** bv[] = {&Kt, &muf, &varf, &cbuf, &theta, &gamma, &rbuf, &wbuf, &emuf, &evarf};
+    for (auto p : bv) {
+      AGPCHK(dmalloc(ctx, p, nl * Bp));
+      HIPCHK(ctx, hipMemsetAsync(*p, 0, sizeof(T) * nl * Bp, st()));
+    }
+    AGPCHK(dmalloc(ctx, &alpha, Bp));
+    AGPCHK(dmalloc(ctx, &beta, Bp));
+    AGPCHK(dmalloc(ctx, &gsum, Bp));
+    AGPCHK(dmalloc(ctx, &alpha_save, Bp));
+    AGPCHK(dmalloc(ctx, &cpart, (Bp / TILE) * mp));
+    AGPCHK(dmalloc(ctx, &stats, nl * (mp + mm)));
+    AGPCHK(dmalloc(ctx, &Tw, mm));
+    AGPCHK(dmalloc(ctx, &Tw2, mm));
+    AGPCHK(dmalloc(ctx, &tmpv, mp));
+    AGPCHK(dmalloc(ctx, &lr_dev, 1));
+    AGPCHK(dmalloc(ctx, &info_dev, 1));
+    AGPCHK(dmalloc(ctx, &flags_dev, 1));
+    AGPCHK(dmalloc(ctx, &scal_dev, 16));
+    HIPCHK(ctx, hipMemsetAsync(info_dev, 0, sizeof(int32_t), st()));
+    HIPCHK(ctx, hipMemsetAsync(flags_dev, 0, sizeof(int), st()));
+    // LogisticSoftMax state: alpha = beta = K (total classes)  logisticsoftmax.jl:43-53
+    const T kk = (T)(lp.kind == AGP_LIK_LOGISTICSOFTMAX ? desc.lik.n_class : 1);
+    hipLaunchKernelGGL((k_fill<T>), grid1(Bp), dim3(256), 0, st(), alpha, Bp, kk);
+    hipLaunchKernelGGL((k_fill<T>), grid1(Bp), dim3(256), 0, st(), beta, Bp, kk);
+    LAUNCHCHK(ctx);
+    n_opt = 1;
+    return AGP_OK;
+  }
+
+  ~Svgp() override {
+    for (auto& g : lat) {
+      T* ps[] = {g.scales, g.Z, g.L, g.Xk, g.Kinv, g.mu0, g.kinv_mu0, g.eta1, g.eta2, g.La, g.Xa, g.v,
+                 g.Sigma, g.mu, g.Knm, g.kappa, g.Apred, g.apred};
+      for (T* p : ps)
+        if (p) (void)hipFree(p);
+    }
+    T* ps[] = {pk, pw0, pw1, Kt, muf, varf, cbuf, theta, gamma, rbuf, wbuf, alpha, beta, gsum, alpha_save, emuf,
+               evarf, cpart, stats, Tw, Tw2, tmpv, lr_dev, Kstar, ppm, ppv, pmu, pvar};
+    for (T* p : ps)
+      if (p) (void)hipFree(p);
+    if (info_dev) (void)hipFree(info_dev);
+    if (flags_dev) (void)hipFree(flags_dev);
+    if (scal_dev) (void)hipFree(scal_dev);
+    if (gh_dev) (void)hipFree(gh_dev);
+  }
+
+  agp_status upload_scales(Latent& g) {
+    std::vector<T> h(D);
+    for (int64_t d = 0; d < D; ++d) h[d] = (T)g.k.scales[d];
+    HIPCHK(ctx, hipMemcpyAsync(g.scales, h.data(), sizeof(T) * D, hipMemcpyHostToDevice, st()));
+    HIPCHK(ctx, hipStreamSynchronize(st()));  // h goes out of scope
+    return AGP_OK;
+  }
+
+  // VarPosterior{T}(dim): mu = 0, Sigma = I, eta1 = 0, eta2 = -I/2   (posterior.jl:29-37)
+  agp_status reset_posterior(Latent& g) {
+    HIPCHK(ctx, hipMemsetAsync(g.eta1, 0, sizeof(T) * mp, st()));
+    HIPCHK(ctx, hipMemsetAsync(g.v, 0, sizeof(T) * mp, st()));
+    hipLaunchKernelGGL((k_set_identity<T>), grid2(mp, mp), blk2, 0, st(), g.eta2, mp, mp, T(-0.5));
+    hipLaunchKernelGGL((k_set_identity<T>), grid2(mp, mp), blk2, 0, st(), g.La, mp, mp, T(1));
+    hipLaunchKernelGGL((k_set_identity<T>), grid2(mp, mp), blk2, 0, st(), g.Xa, mp, mp, T(1));
+    LAUNCHCHK(ctx);
+    g.post_valid = false;
+    g.pred_valid = g.predvar_valid = false;
+    return AGP_OK;
+  }
+
+  agp_status set_kernel(int l, const agp_kernel_desc* k) override {
+    if (l < 0 || l >= nl || !k) return AGP_ERR_INVALID;
+    if (k->kind < 0 || k->kind > AGP_K_EXPONENTIAL || !(k->variance > 0)) return AGP_ERR_INVALID;
+    Latent& g = lat[l];
+    g.k.kind = k->kind;
+    g.k.variance = k->variance;
+    for (int64_t d = 0; d < D; ++d) g.k.scales[d] = k->ard ? k->ard_scales_host[d] : k->scale;
+    g.K_stale = true;
+    g.kappa_valid = false;
+    g.pred_valid = g.predvar_valid = false;
+    return upload_scales(g);
+  }
+
+  agp_status set_Z(int l, const void* z, int64_t ldz) override {
+    if (l < 0 || l >= nl || !z || ldz < D) return AGP_ERR_INVALID;
+    Latent& g = lat[l];
+    HIPCHK(ctx, hipMemcpy2DAsync(g.Z, sizeof(T) * D, z, sizeof(T) * ldz, sizeof(T) * D, m, hipMemcpyDeviceToDevice,
+                                 st()));
+    g.K_stale = true;
+    g.kappa_valid = false;
+    g.pred_valid = g.predvar_valid = false;
+    return AGP_OK;
+  }
+
+  agp_status get_Z(int l, void* z, int64_t ldz) override {
+    if (l < 0 || l >= nl || !z || ldz < D) return AGP_ERR_INVALID;
+    HIPCHK(ctx, hipMemcpy2DAsync(z, sizeof(T) * ldz, lat[l].Z, sizeof(T) * D, sizeof(T) * D, m,
+                                 hipMemcpyDeviceToDevice, st()));
+    return AGP_OK;
+  }
+
+  agp_status set_mu0(int l, const void* mu0) override {
+    if (l < 0 || l >= nl) return AGP_ERR_INVALID;
+    Latent& g = lat[l];
+    if (!mu0) {
+      if (g.mu0) (void)hipFree(g.mu0);
+      if (g.kinv_mu0) (void)hipFree(g.kinv_mu0);
+      g.mu0 = g.kinv_mu0 = nullptr;
+      return AGP_OK;
+    }
+    if (!g.mu0) {
+      AGPCHK(dmalloc(ctx, &g.mu0, mp));
+      AGPCHK(dmalloc(ctx, &g.kinv_mu0, mp));
+    }
+    HIPCHK(ctx, hipMemsetAsync(g.mu0, 0, sizeof(T) * mp, st()));
+    HIPCHK(ctx, hipMemcpyAsync(g.mu0, mu0, sizeof(T) * m, hipMemcpyDeviceToDevice, st()));
+    g.K_stale = true;  // K^-1 mu0 must be refreshed
+    return AGP_OK;
+  }
+
+  // compute_K : cholesky(kernelmatrix(k, Z) + jitt*I) ; inv(K)      latentgp.jl:205-207, analyticVI.jl:179
+  agp_status refresh_K() override {
+    bool any = false;
+    for (auto& g : lat) {
+      if (!g.K_stale) continue;
+      any = true;
+      dim3 gk((unsigned)(mp / TILE), (unsigned)(mp / TILE));
+      hipLaunchKernelGGL((k_kernelmatrix<T>), gk, dim3(NTHREADS), 0, st(), (const T*)g.Z, D, (const int64_t*)nullptr, m,
+                         (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.L, mp, mp, mp, 1,
+                         (T)jitter, (const T*)nullptr, (T*)nullptr, (int64_t)0);
+      LAUNCHCHK(ctx);
+      AGPCHK(potrf_padded<T>(ctx, g.L, mp, mp, g.Xk, mp, info_dev, m));
+      AGPCHK(trtri_padded<T>(ctx, g.L, mp, mp, g.Xk, mp, Tw, mp));
+      AGPCHK(xtx_padded<T>(ctx, g.Xk, mp, mp, g.Kinv, mp));
+      hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.L, mp, m, scal_dev);
+      LAUNCHCHK(ctx);
+      double hl = 0;
+      HIPCHK(ctx, hipMemcpyAsync(&hl, scal_dev, sizeof(double), hipMemcpyDeviceToHost, st()));
+      HIPCHK(ctx, hipStreamSynchronize(st()));
+      g.half_logdetK = hl;
+      if (g.mu0) {
+        hipLaunchKernelGGL((k_symv<T>), grid1(mp * 64), dim3(256), 0, st(), (const T*)g.Kinv, mp, mp, (const T*)g.mu0,
+                           g.kinv_mu0);
+        LAUNCHCHK(ctx);
+      }
+      g.K_stale = false;
+      g.kappa_valid = false;
+      g.pred_valid = g.predvar_valid = false;
+    }
+    if (any) {
+      int32_t info = 0;
+      HIPCHK(ctx, hipMemcpyAsync(&info, info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st()));
+      HIPCHK(ctx, hipStreamSynchronize(st()));
+      if (info != 0) {
+        HIPCHK(ctx, hipMemsetAsync(info_dev, 0, sizeof(int32_t), st()));
+        for (auto& g : lat) g.K_stale = true;
+        ctx->err = "PosDefException: K_ZZ + jitter*I is not positive definite; leading minor " + std::to_string(info);
+        return AGP_ERR_NOT_POSDEF;
+      }
+    }
+    return AGP_OK;
+  }
+
+  agp_status check_batch(int64_t B) {
+    if (B <= 0 || B > Bmax) {  // training.jl:27-29
+      ctx->err = "The size of mini-batch " + std::to_string(B) + " is incorrect (negative or bigger than max_batch)";
+      return AGP_ERR_BAD_BATCH;
+    }
+    return AGP_OK;
+  }
+
+  // compute_kappa + mean_f/var_f + local update
+  agp_status step_local(const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B, double rho,
+                        bool fresh) override {
+    AGPCHK(check_batch(B));
+    if (!x || !y || ldx < D) return AGP_ERR_INVALID;
+    AGPCHK(refresh_K());
+    const int64_t Bq = rup64(B);
+    const int ns = (int)(2 * mp / TILE);
+    const bool reuse = !desc.stochastic && !fresh && x == x_last && idx == idx_last && B == B_last && ldx == ldx_last;
+    for (int l = 0; l < nl; ++l) {
+      Latent& g = lat[l];
+      const bool keep = reuse && g.kappa_valid;
+      if (!keep) {
+        dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
+        hipLaunchKernelGGL((k_kernelmatrix<T>), gk, dim3(NTHREADS), 0, st(), (const T*)x, ldx, idx, B, (const T*)g.Z,
+                           D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Knm, mp, Bq, mp, 0, T(0),
+                           (const T*)nullptr, (T*)nullptr, (int64_t)0);
+        LAUNCHCHK(ctx);
+        AGPCHK((gemm_nt<T, EPI_KAPPA>(ctx, g.Knm, mp, g.Kinv, mp, Bq, mp, mp, 0, g.kappa, mp, g.Knm, mp, nullptr, pk,
+                                      nullptr, ldp)));
+        g.kappa_valid = !desc.stochastic && !fresh;
+      }
+      AGPCHK((gemm_nt<T, EPI_W>(ctx, g.kappa, mp, g.Xa, mp, Bq, mp, mp, 1, nullptr, 0, nullptr, 0, g.v, pw0, pw1, ldp)));
+      hipLaunchKernelGGL((k_local_update<T>), grid1(B), dim3(256), 0, st(), B, ns, (const T*)pk, (const T*)pw0,
+                         (const T*)pw1, ldp, (T)g.k.variance, (T)jitter, (T)rho, lp, (const T*)y, idx, Kt + l * Bp,
+                         muf + l * Bp, varf + l * Bp, cbuf + l * Bp, theta + l * Bp, rbuf + l * Bp, wbuf + l * Bp,
+                         flags_dev, (int)keep);
+      LAUNCHCHK(ctx);
+    }
+    x_last = x;
+    y_last = y;
+    idx_last = idx;
+    B_last = B;
+    ldx_last = ldx;
+    rho_last = rho;
+    return AGP_OK;
+  }
+
+  agp_status lsm_gamma() override {
+    if (lp.kind != AGP_LIK_LOGISTICSOFTMAX) return AGP_OK;
+    hipLaunchKernelGGL((k_lsm_gamma<T>), grid1(B_last), dim3(256), 0, st(), B_last, nl, Bp, (const T*)muf,
+                       (const T*)cbuf, (const T*)alpha, (const T*)beta, gamma, gsum);
+    LAUNCHCHK(ctx);
+    return AGP_OK;
+  }
+  agp_status lsm_alpha() override {
+    if (lp.kind != AGP_LIK_LOGISTICSOFTMAX) return AGP_OK;
+    hipLaunchKernelGGL((k_lsm_alpha<T>), grid1(B_last), dim3(256), 0, st(), B_last, (const T*)gsum, alpha);
+    LAUNCHCHK(ctx);
+    return AGP_OK;
+  }
+  agp_status lsm_gsum_ptr(void** p, int64_t* n) override {
+    *p = gsum;
+    *n = B_last;
+    return AGP_OK;
+  }
+  agp_status lsm_finish() {
+    if (lp.kind != AGP_LIK_LOGISTICSOFTMAX) return AGP_OK;
+    hipLaunchKernelGGL((k_lsm_finish<T>), grid1(B_last), dim3(256), 0, st(), B_last, nl, Bp, desc.latent_offset,
+                       (T)rho_last, (const int32_t*)y_last, idx_last, (const T*)cbuf, (const T*)gamma, theta, rbuf,
+                       wbuf);
+    LAUNCHCHK(ctx);
+    return AGP_OK;
+  }
+
+  agp_status set_lr() {
+    double lr = desc.stochastic ? 1.0 / std::pow(desc.rm_tau + (double)n_opt, desc.rm_kappa) : 1.0;  // optimisers.jl:14-19
+    hipLaunchKernelGGL((k_set_scalar<T>), dim3(1), dim3(64), 0, st(), lr_dev, (T)lr);
+    LAUNCHCHK(ctx);
+    return AGP_OK;
+  }
+
+  // batch statistics ; fused: eta1/eta2 are stepped directly, otherwise stats = [t | S] for an all-reduce
+  agp_status step_stats(bool fused) override {
+    AGPCHK(lsm_finish());
+    const int64_t Bq = rup64(B_last);
+    const int64_t nt = mp / TILE;
+    if (fused) AGPCHK(set_lr());
+    for (int l = 0; l < nl; ++l) {
+      Latent& g = lat[l];
+      dim3 gc((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
+      hipLaunchKernelGGL((k_colsum_partial<T>), gc, dim3(NTHREADS), 0, st(), (const T*)g.kappa, mp,
+                         (const T*)(rbuf + l * Bp), cpart, mp);
+      T* sl = stats + l * (mp + mp * mp);
+      if (fused) {
+        hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, (int)(Bq / TILE), (const T*)cpart, mp,
+                           (const T*)nullptr, (const T*)g.kinv_mu0, g.eta1, (const T*)lr_dev, (T*)nullptr);
+        hipLaunchKernelGGL((k_syrk_tn<T, SY_ETA2>), dim3((unsigned)(nt * (nt + 1) / 2)), dim3(NTHREADS), 0, st(),
+                           (const T*)g.kappa, mp, Bq, (const T*)(wbuf + l * Bp), 0, g.La, mp, g.eta2, (const T*)g.Kinv,
+                           mp, (const T*)lr_dev);
+      } else {
+        hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, (int)(Bq / TILE), (const T*)cpart, mp,
+                           (const T*)nullptr, (const T*)nullptr, (T*)nullptr, (const T*)lr_dev, sl);
+        hipLaunchKernelGGL((k_syrk_tn<T, SY_STORE>), dim3((unsigned)(nt * (nt + 1) / 2)), dim3(NTHREADS), 0, st(),
+                           (const T*)g.kappa, mp, Bq, (const T*)(wbuf + l * Bp), 0, sl + mp, mp, (T*)nullptr,
+                           (const T*)nullptr, (int64_t)0, (const T*)nullptr);
+      }
+      LAUNCHCHK(ctx);
+    }
+    return AGP_OK;
+  }
+  agp_status stats_ptr(void** p, int64_t* n) override {
+    *p = stats;
+    *n = (int64_t)nl * (mp + mp * mp);
+    return AGP_OK;
+  }
+
+  // Sigma-side refresh after eta changed: La = chol(-2 eta2), Xa = La^-1, v = Xa eta1   (inference.jl:25-28)
+  agp_status refactor(Latent& g) {
+    AGPCHK(potrf_padded<T>(ctx, g.La, mp, mp, g.Xa, mp, info_dev, m));
+    AGPCHK(trtri_padded<T>(ctx, g.La, mp, mp, g.Xa, mp, Tw, mp));
+    hipLaunchKernelGGL((k_trmv_lower<T>), grid1(mp * 64), dim3(256), 0, st(), (const T*)g.Xa, mp, mp, (const T*)g.eta1,
+                       g.v);
+    LAUNCHCHK(ctx);
+    g.post_valid = false;
+    g.pred_valid = g.predvar_valid = false;
+    return AGP_OK;
+  }
+
+  agp_status step_global(bool fused) override {
+    if (!fused) AGPCHK(set_lr());
+    for (int l = 0; l < nl; ++l) {
+      Latent& g = lat[l];
+      if (!fused) {
+        const T* sl = stats + l * (mp + mp * mp);
+        hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, 0, (const T*)nullptr, (int64_t)0, sl,
+                           (const T*)g.kinv_mu0, g.eta1, (const T*)lr_dev, (T*)nullptr);
+        hipLaunchKernelGGL((k_eta2_from_stats<T>), grid1(mp * mp), dim3(256), 0, st(), sl + mp, mp, g.eta2,
+                           (const T*)g.Kinv, g.La, (const T*)lr_dev);
+        LAUNCHCHK(ctx);
+      }
+      AGPCHK(refactor(g));
+    }
+    n_opt += 1;
+    return AGP_OK;
+  }
+
+  agp_status check_status() override {
+    int32_t info = 0;
+    int flags = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&info, info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st()));
+    HIPCHK(ctx, hipMemcpyAsync(&flags, flags_dev, sizeof(int), hipMemcpyDeviceToHost, st()));
+    HIPCHK(ctx, hipStreamSynchronize(st()));
+    if (info != 0 || flags != 0) {
+      HIPCHK(ctx, hipMemsetAsync(info_dev, 0, sizeof(int32_t), st()));
+      HIPCHK(ctx, hipMemsetAsync(flags_dev, 0, sizeof(int), st()));
+    }
+    if (flags & FLAG_NEG_KTILDE) {
+      ctx->err = "K~ has negative values";  // latentgp.jl:213
+      return AGP_ERR_NEG_KTILDE;
+    }
+    if (info != 0) {
+      ctx->err = "PosDefException: -2*eta2 is not positive definite; leading minor " + std::to_string(info);
+      return AGP_ERR_NOT_POSDEF;
+    }
+    return AGP_OK;
+  }
+
+  // Sigma = Xa' Xa ; mu = Xa' v
+  agp_status materialize(Latent& g) {
+    if (g.post_valid) return AGP_OK;
+    AGPCHK(xtx_padded<T>(ctx, g.Xa, mp, mp, g.Sigma, mp));
+    hipLaunchKernelGGL((k_trmv_lower_t<T>), grid1(mp), dim3(256), 0, st(), (const T*)g.Xa, mp, mp, (const T*)g.v, g.mu);
+    LAUNCHCHK(ctx);
+    g.post_valid = true;
+    return AGP_OK;
+  }
+
+  agp_status elbo(const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B, double rho, int fresh,
+                  double* out) override {
+    AGPCHK(check_batch(B));
+    const int ns = (int)(2 * mp / TILE);
+    const bool lsm = lp.kind == AGP_LIK_LOGISTICSOFTMAX;
+    const T* mf;
+    const T* vf;
+    if (fresh) {
+      // ELBO.jl:32-47 : recompute kernel matrices on (x, y), fresh local variables, one local update
+      if (lsm) {
+        HIPCHK(ctx, hipMemcpyAsync(alpha_save, alpha, sizeof(T) * Bp, hipMemcpyDeviceToDevice, st()));
+        hipLaunchKernelGGL((k_fill<T>), grid1(Bp), dim3(256), 0, st(), alpha, Bp, (T)desc.lik.n_class);
+      }
+      AGPCHK(step_local(x, ldx, y, idx, B, rho, true));
+      if (lsm) {
+        for (int it = 0; it < 2; ++it) {
+          AGPCHK(lsm_gamma());
+          AGPCHK(lsm_alpha());
+        }
+        AGPCHK(lsm_finish());
+      }
+      for (auto& g : lat) g.kappa_valid = false;
+      mf = muf;
+      vf = varf;
+    } else {
+      if (B != B_last) {
+        ctx->err = "agp_svgp_elbo(fresh_local=0) must be called with the batch of the last cavi_step";
+        return AGP_ERR_INVALID;
+      }
+      // mean_f / var_f with the UPDATED posterior, local variables from the step (analyticVI.jl:260-266)
+      const int64_t Bq = rup64(B);
+      for (int l = 0; l < nl; ++l) {
+        Latent& g = lat[l];
+        AGPCHK((gemm_nt<T, EPI_W>(ctx, g.kappa, mp, g.Xa, mp, Bq, mp, mp, 1, nullptr, 0, nullptr, 0, g.v, pw0, pw1,
+                                  ldp)));
+        hipLaunchKernelGGL((k_meanvar_finish<T>), grid1(B), dim3(256), 0, st(), B, ns, (const T*)pw0, (const T*)pw1, ldp,
+                           (const T*)(Kt + l * Bp), emuf + l * Bp, evarf + l * Bp);
+        LAUNCHCHK(ctx);
+      }
+      mf = emuf;
+      vf = evarf;
+    }
+    hipLaunchKernelGGL((k_elbo_terms<T>), dim3(1), dim3(1024), 0, st(), B, nl, Bp, lp, desc.elbo_mode, desc.latent_offset,
+                       (int)(desc.latent_offset == 0), (const T*)y, (const int32_t*)y, idx, mf, vf, (const T*)cbuf,
+                       (const T*)theta, (const T*)gamma, (const T*)alpha, (const T*)beta, scal_dev);
+    LAUNCHCHK(ctx);
+    if (fresh && lsm)
+      HIPCHK(ctx, hipMemcpyAsync(alpha, alpha_save, sizeof(T) * Bp, hipMemcpyDeviceToDevice, st()));
+    // GaussianKL per latent (KLdivergences.jl:11-18)
+    double kl_gauss = 0.0;
+    for (int l = 0; l < nl; ++l) {
+      Latent& g = lat[l];
+      AGPCHK(materialize(g));
+      hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.La, mp, m, scal_dev + 2);
+      hipLaunchKernelGGL((k_frob_dot<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.Kinv, (const T*)g.Sigma, mp, m,
+                         scal_dev + 3);
+      hipLaunchKernelGGL((k_axpby<T>), grid1(mp), dim3(256), 0, st(), mp, T(1), (const T*)g.mu, T(-1), (const T*)g.mu0,
+                         tmpv);
+      hipLaunchKernelGGL((k_trmv_lower<T>), grid1(mp * 64), dim3(256), 0, st(), (const T*)g.Xk, mp, mp, (const T*)tmpv,
+                         pw0);
+      hipLaunchKernelGGL((k_sumsq<T>), dim3(1), dim3(1024), 0, st(), (const T*)pw0, mp, scal_dev + 4);
+      LAUNCHCHK(ctx);
+      double h[5];
+      HIPCHK(ctx, hipMemcpyAsync(h, scal_dev, sizeof(double) * 5, hipMemcpyDeviceToHost, st()));
+      HIPCHK(ctx, hipStreamSynchronize(st()));
+      if (l == 0) {
+        e_data = h[0];
+        kl_aug = h[1];
+      }
+      const double logdetK = 2.0 * g.half_logdetK, logdetS = -2.0 * h[2];
+      kl_gauss += 0.5 * (logdetK - logdetS + h[3] + h[4] - (double)m);
+    }
+    *out = rho * e_data - kl_gauss - rho * kl_aug;
+    return AGP_OK;
+  }
+  double e_data = 0, kl_aug = 0;
+
+  agp_status get_state(int l, void* mu, void* sigma, void* eta1, void* eta2) override {
+    if (l < 0 || l >= nl) return AGP_ERR_INVALID;
+    Latent& g = lat[l];
+    if (mu || sigma) AGPCHK(materialize(g));
+    if (mu) HIPCHK(ctx, hipMemcpyAsync(mu, g.mu, sizeof(T) * m, hipMemcpyDeviceToDevice, st()));
+    if (eta1) HIPCHK(ctx, hipMemcpyAsync(eta1, g.eta1, sizeof(T) * m, hipMemcpyDeviceToDevice, st()));
+    if (sigma)
+      HIPCHK(ctx, hipMemcpy2DAsync(sigma, sizeof(T) * m, g.Sigma, sizeof(T) * mp, sizeof(T) * m, m,
+                                   hipMemcpyDeviceToDevice, st()));
+    if (eta2)
+      HIPCHK(ctx, hipMemcpy2DAsync(eta2, sizeof(T) * m, g.eta2, sizeof(T) * mp, sizeof(T) * m, m,
+                                   hipMemcpyDeviceToDevice, st()));
+    return AGP_OK;
+  }
+
+  agp_status set_state(int l, const void* eta1, const void* eta2) override {
+    if (l < 0 || l >= nl || !eta1 || !eta2) return AGP_ERR_INVALID;
+    Latent& g = lat[l];
+    HIPCHK(ctx, hipMemsetAsync(g.eta1, 0, sizeof(T) * mp, st()));
+    HIPCHK(ctx, hipMemcpyAsync(g.eta1, eta1, sizeof(T) * m, hipMemcpyDeviceToDevice, st()));
+    hipLaunchKernelGGL((k_copy2d<T>), grid2(mp, mp), blk2, 0, st(), (const T*)eta2, m, m, m, g.eta2, mp, mp, mp,
+                       T(-0.5), T(1));
+    hipLaunchKernelGGL((k_copy2d<T>), grid2(mp, mp), blk2, 0, st(), (const T*)eta2, m, m, m, g.La, mp, mp, mp, T(1),
+                       T(-2));
+    LAUNCHCHK(ctx);
+    return refactor(g);
+  }
+
+  agp_status get_matrix(int l, int which, void* out, int64_t ldo) override {
+    if (l < 0 || l >= nl || !out) return AGP_ERR_INVALID;
+    Latent& g = lat[l];
+    const int64_t B = B_last;
+    auto copy2 = [&](const T* src, int64_t lds, int64_t rows, int64_t cols) -> agp_status {
+      if (ldo < cols) return AGP_ERR_INVALID;
+      HIPCHK(ctx, hipMemcpy2DAsync(out, sizeof(T) * ldo, src, sizeof(T) * lds, sizeof(T) * cols, rows,
+                                   hipMemcpyDeviceToDevice, st()));
+      return AGP_OK;
+    };
+    auto copy1 = [&](const T* src, int64_t n) -> agp_status {
+      HIPCHK(ctx, hipMemcpyAsync(out, src, sizeof(T) * n, hipMemcpyDeviceToDevice, st()));
+      return AGP_OK;
+    };
+    switch (which) {
+      case AGP_MAT_L: {
+        AGPCHK(refresh_K());
+        AGPCHK(copy2(g.L, mp, m, m));
+        // strict upper part of the stored factor is not maintained outside the diagonal tiles: zero it in the copy
+        hipLaunchKernelGGL((k_zero_strict_upper<T>), grid2(m, m), blk2, 0, st(), (T*)out, ldo, m);
+        LAUNCHCHK(ctx);
+        return AGP_OK;
+      }
+      case AGP_MAT_KINV:
+        AGPCHK(refresh_K());
+        return copy2(g.Kinv, mp, m, m);
+      case AGP_MAT_KNM:
+        return copy2(g.Knm, mp, B, m);
+      case AGP_MAT_KAPPA:
+        return copy2(g.kappa, mp, B, m);
+      case AGP_VEC_KTILDE:
+        return copy1(Kt + l * Bp, B);
+      case AGP_VEC_MEAN_F:
+        return copy1(muf + l * Bp, B);
+      case AGP_VEC_VAR_F:
+        return copy1(varf + l * Bp, B);
+      case AGP_VEC_THETA:
+        return copy1(theta + l * Bp, B);
+      case AGP_VEC_C:
+        return copy1(cbuf + l * Bp, B);
+      case AGP_VEC_GAMMA:
+        return copy1(gamma + l * Bp, B);
+      case AGP_VEC_ALPHA:
+        return copy1(alpha, B);
+      default:
+        return AGP_ERR_INVALID;
+    }
+  }
+
+  // ---- prediction (predictions.jl:25-50) -------------------------------------------------------------------
+  agp_status ensure_pred(Latent& g, bool need_var) {
+    AGPCHK(refresh_K());
+    AGPCHK(materialize(g));
+    if (!g.apred) {
+      AGPCHK(dmalloc(ctx, &g.apred, mp));
+    }
+    if (need_var && !g.Apred) AGPCHK(dmalloc(ctx, &g.Apred, mp * mp));
+    if (!g.pred_valid) {
+      // K \ mu
+      hipLaunchKernelGGL((k_symv<T>), grid1(mp * 64), dim3(256), 0, st(), (const T*)g.Kinv, mp, mp, (const T*)g.mu,
+                         g.apred);
+      LAUNCHCHK(ctx);
+      g.pred_valid = true;
+    }
+    if (need_var && !g.predvar_valid) {
+      // A = K \ (I - Sigma / K) = Kinv - Kinv Sigma Kinv :  T2 = Kinv Sigma (NT, both symmetric) ; A = Kinv - Kinv T2'
+      AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.Kinv, mp, g.Sigma, mp, mp, mp, mp, 0, Tw2, mp, nullptr, 0, nullptr, nullptr,
+                                    nullptr, 0)));
+      AGPCHK((gemm_nt<T, EPI_EMINUS>(ctx, g.Kinv, mp, Tw2, mp, mp, mp, mp, 0, g.Apred, mp, g.Kinv, mp, nullptr,
+                                     nullptr, nullptr, 0)));
+      g.predvar_valid = true;
+    }
+    return AGP_OK;
+  }
+
+  agp_status ensure_pred_ws(int64_t nt, bool need_var) {
+    const int64_t CH = 4096;
+    if (pred_chunk == 0) {
+      pred_chunk = CH;
+      AGPCHK(dmalloc(ctx, &ppm, (mp / TILE) * CH));
+      AGPCHK(dmalloc(ctx, &ppv, (2 * mp / TILE) * CH));
+    }
+    if (need_var && !Kstar) AGPCHK(dmalloc(ctx, &Kstar, CH * mp));
+    if (nt > pred_nt_cap) {
+      if (pmu) (void)hipFree(pmu);
+      if (pvar) (void)hipFree(pvar);
+      AGPCHK(dmalloc(ctx, &pmu, nl * nt));
+      AGPCHK(dmalloc(ctx, &pvar, nl * nt));
+      pred_nt_cap = nt;
+    }
+    return AGP_OK;
+  }
+
+  agp_status predict_f(const void* xt, int64_t ldx, int64_t nt, void* mu_out, void* var_out) override {
+    if (!xt || nt <= 0 || ldx < D || !mu_out) return AGP_ERR_INVALID;
+    const bool need_var = var_out != nullptr;
+    AGPCHK(ensure_pred_ws(0, need_var));
+    for (auto& g : lat) AGPCHK(ensure_pred(g, need_var));
+    const int64_t CH = pred_chunk;
+    for (int l = 0; l < nl; ++l) {
+      Latent& g = lat[l];
+      for (int64_t s = 0; s < nt; s += CH) {
+        const int64_t nc = (nt - s) < CH ? (nt - s) : CH;
+        const int64_t nq = rup64(nc);
+        const T* xs = (const T*)xt + s * ldx;
+        dim3 gk((unsigned)(mp / TILE), (unsigned)(nq / TILE));
+        hipLaunchKernelGGL((k_kernelmatrix<T>), gk, dim3(NTHREADS), 0, st(), xs, ldx, (const int64_t*)nullptr, nc,
+                           (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance,
+                           need_var ? Kstar : (T*)nullptr, mp, nq, mp, 0, T(0), (const T*)g.apred, ppm, CH);
+        LAUNCHCHK(ctx);
+        if (need_var)
+          AGPCHK((gemm_nt<T, EPI_ROWDOT>(ctx, Kstar, mp, g.Apred, mp, nq, mp, mp, 0, nullptr, 0, Kstar, mp, nullptr, ppv,
+                                         nullptr, CH)));
+        hipLaunchKernelGGL((k_predict_finish<T>), grid1(nc), dim3(256), 0, st(), nc, (int)(mp / TILE), (const T*)ppm,
+                           (int)(2 * mp / TILE), (const T*)ppv, CH, (T)g.k.variance, (T)jitter,
+                           (T*)mu_out + (int64_t)l * nt + s, need_var ? (T*)var_out + (int64_t)l * nt + s : (T*)nullptr);
+        LAUNCHCHK(ctx);
+      }
+    }
+    return AGP_OK;
+  }
+
+  agp_status predict_y(const void* xt, int64_t ldx, int64_t nt, void* out) override {
+    if (!out) return AGP_ERR_INVALID;
+    if (lp.kind == AGP_LIK_GAUSSIAN || lp.kind == AGP_LIK_STUDENTT) return predict_f(xt, ldx, nt, out, nullptr);
+    AGPCHK(ensure_pred_ws(nt, false));
+    AGPCHK(predict_f(xt, ldx, nt, pmu, nullptr));
+    hipLaunchKernelGGL((k_predict_label<T>), grid1(nt), dim3(256), 0, st(), nt, nl, nt, desc.latent_offset,
+                       (const T*)pmu, (int32_t*)out, (int)(lp.kind == AGP_LIK_LOGISTIC));
+    LAUNCHCHK(ctx);
+    return AGP_OK;
+  }
+
+  agp_status proba_y(const void* xt, int64_t ldx, int64_t nt, const double* nodes, const double* weights, int nn,
+                     void* o0, void* o1) override {
+    if (!o0) return AGP_ERR_INVALID;
+    AGPCHK(ensure_pred_ws(nt, true));
+    AGPCHK(predict_f(xt, ldx, nt, pmu, pvar));
+    if (lp.kind == AGP_LIK_GAUSSIAN) {
+      if (!o1) return AGP_ERR_INVALID;
+      hipLaunchKernelGGL((k_proba_regression<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)pmu, (const T*)pvar,
+                         lp.p0, 0, (T*)o0, (T*)o1);
+    } else if (lp.kind == AGP_LIK_STUDENTT) {
+      if (!o1) return AGP_ERR_INVALID;
+      const double nu = desc.lik.p0, sg = desc.lik.p1;
+      hipLaunchKernelGGL((k_proba_regression<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)pmu, (const T*)pvar,
+                         (T)(nu * sg * sg / (2.0 * (nu / 2.0 - 1.0))), 1, (T*)o0, (T*)o1);
+    } else if (lp.kind == AGP_LIK_LOGISTIC) {
+      if (!o1 || !nodes || !weights || nn <= 0) return AGP_ERR_INVALID;
+      if (nn > gh_cap) {
+        if (gh_dev) (void)hipFree(gh_dev);
+        AGPCHK(dmalloc(ctx, &gh_dev, 2 * nn));
+        gh_cap = nn;
+      }
+      HIPCHK(ctx, hipMemcpyAsync(gh_dev, nodes, sizeof(double) * nn, hipMemcpyHostToDevice, st()));
+      HIPCHK(ctx, hipMemcpyAsync(gh_dev + nn, weights, sizeof(double) * nn, hipMemcpyHostToDevice, st()));
+      HIPCHK(ctx, hipStreamSynchronize(st()));
+      hipLaunchKernelGGL((k_proba_logistic<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)pmu, (const T*)pvar, nn,
+                         (const double*)gh_dev, (const double*)(gh_dev + nn), (T*)o0, (T*)o1);
+    } else {
+      hipLaunchKernelGGL((k_proba_lsm<T>), grid1(nt), dim3(256), 0, st(), nt, nl, nt, (const T*)pmu, (T*)o0);
+    }
+    LAUNCHCHK(ctx);
+    return AGP_OK;
+  }
+};
+
+// ================================================================================================================
+// C entry points
+// ================================================================================================================
+extern "C" {
+
+int32_t agp_version(void) { return 100; }
+
+agp_status agp_ctx_create(int32_t device, void* hip_stream, agp_ctx** out) {
+  if (!out) return AGP_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return AGP_ERR_HIP;
+  if (hipSetDevice(device) != hipSuccess) return AGP_ERR_HIP;
+  agp_ctx* c = new agp_ctx();
+  c->device = device;
+  c->stream = (hipStream_t)hip_stream;
+  *out = c;
+  return AGP_OK;
+}
+
+agp_status agp_ctx_destroy(agp_ctx* ctx) {
+  delete ctx;
+  return AGP_OK;
+}
+
+agp_status agp_ctx_sync(agp_ctx* ctx) {
+  if (!ctx) return AGP_ERR_INVALID;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return AGP_OK;
+}
+
+const char* agp_last_error(agp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+}  // extern "C"
+
+// ---- building blocks ---------------------------------------------------------------------------------------------
+template <typename T>
+static agp_status bb_kernelmatrix(agp_ctx* ctx, const agp_kernel_desc* k, const void* x, int64_t n, int64_t ldx,
+                                  const int64_t* idx, const void* y, int64_t p, int64_t ldy, int64_t D, void* out,
+                                  int64_t ldo) {
+  std::vector<T> hs(D);
+  for (int64_t d = 0; d < D; ++d) hs[d] = (T)(k->ard ? k->ard_scales_host[d] : k->scale);
+  T* ds = nullptr;
+  AGPCHK(dmalloc(ctx, &ds, D));
+  HIPCHK(ctx, hipMemcpyAsync(ds, hs.data(), sizeof(T) * D, hipMemcpyHostToDevice, ctx->stream));
+  const bool sym = (y == nullptr);
+  const void* yy = sym ? x : y;
+  const int64_t pp = sym ? n : p, ldyy = sym ? ldx : ldy;
+  dim3 g((unsigned)((pp + TILE - 1) / TILE), (unsigned)((n + TILE - 1) / TILE));
+  hipLaunchKernelGGL((k_kernelmatrix<T>), g, dim3(NTHREADS), 0, ctx->stream, (const T*)x, ldx, idx, n, (const T*)yy, ldyy,
+                     pp, D, (const T*)ds, k->kind, (T)k->variance, (T*)out, ldo, n, pp, 0, T(0), (const T*)nullptr,
+                     (T*)nullptr, (int64_t)0);
+  hipError_t e = hipGetLastError();
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(ds);
+  if (e != hipSuccess) {
+    ctx->err = hipGetErrorString(e);
+    return AGP_ERR_HIP;
+  }
+  return AGP_OK;
+}
+
+// copy A (n x n, lda) into a padded np x np buffer (identity padding), add jitter on the diagonal
+template <typename T>
+static agp_status pad_spd(agp_ctx* ctx, const void* a, int64_t lda, int64_t n, double jitter, T** Ap, int64_t* np) {
+  *np = rup64(n);
+  AGPCHK(dmalloc(ctx, Ap, (*np) * (*np)));
+  hipLaunchKernelGGL((k_copy2d<T>), grid2(*np, *np), blk2, 0, ctx->stream, (const T*)a, lda, n, n, *Ap, *np, *np, *np,
+                     T(1), T(1));
+  if (jitter != 0.0)
+    hipLaunchKernelGGL((k_add_diag<T>), grid1(n), dim3(256), 0, ctx->stream, *Ap, *np, n, (T)jitter);
+  LAUNCHCHK(ctx);
+  return AGP_OK;
+}
+
+template <typename T>
+static agp_status bb_potrf(agp_ctx* ctx, void* a, int64_t lda, int64_t n, double jitter, int32_t* info_host) {
+  T *Ap = nullptr, *X = nullptr;
+  int32_t* info = nullptr;
+  int64_t np;
+  AGPCHK(pad_spd<T>(ctx, a, lda, n, jitter, &Ap, &np));
+  AGPCHK(dmalloc(ctx, &X, np * np));
+  AGPCHK(dmalloc(ctx, &info, 1));
+  HIPCHK(ctx, hipMemsetAsync(info, 0, sizeof(int32_t), ctx->stream));
+  AGPCHK(potrf_padded<T>(ctx, Ap, np, np, X, np, info, n));
+  HIPCHK(ctx, hipMemcpy2DAsync(a, sizeof(T) * lda, Ap, sizeof(T) * np, sizeof(T) * n, n, hipMemcpyDeviceToDevice,
+                               ctx->stream));
+  hipLaunchKernelGGL((k_zero_strict_upper<T>), grid2(n, n), blk2, 0, ctx->stream, (T*)a, lda, n);
+  int32_t hinfo = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&hinfo, info, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (info_host) *info_host = hinfo;
+  (void)hipFree(Ap);
+  (void)hipFree(X);
+  (void)hipFree(info);
+  if (hinfo != 0) {
+    ctx->err = "PosDefException: matrix is not positive definite; leading minor " + std::to_string(hinfo);
+    return AGP_ERR_NOT_POSDEF;
+  }
+  return AGP_OK;
+}
+
+template <typename T>
+static agp_status bb_spd_inverse(agp_ctx* ctx, const void* a, int64_t lda, int64_t n, void* ainv, int64_t ldi,
+                                 double* logdet_host, int32_t* info_host, T** keep_inv_padded, int64_t* np_out) {
+  T *Ap = nullptr, *X = nullptr, *Tw = nullptr, *Inv = nullptr;
+  int32_t* info = nullptr;
+  double* sc = nullptr;
+  int64_t np;
+  AGPCHK(pad_spd<T>(ctx, a, lda, n, 0.0, &Ap, &np));
+  AGPCHK(dmalloc(ctx, &X, np * np));
+  AGPCHK(dmalloc(ctx, &Tw, np * np));
+  AGPCHK(dmalloc(ctx, &Inv, np * np));
+  AGPCHK(dmalloc(ctx, &info, 1));
+  AGPCHK(dmalloc(ctx, &sc, 1));
+  HIPCHK(ctx, hipMemsetAsync(info, 0, sizeof(int32_t), ctx->stream));
+  AGPCHK(potrf_padded<T>(ctx, Ap, np, np, X, np, info, n));
+  AGPCHK(trtri_padded<T>(ctx, Ap, np, np, X, np, Tw, np));
+  AGPCHK(xtx_padded<T>(ctx, X, np, np, Inv, np));
+  hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, ctx->stream, (const T*)Ap, np, n, sc);
+  LAUNCHCHK(ctx);
+  if (ainv)
+    HIPCHK(ctx, hipMemcpy2DAsync(ainv, sizeof(T) * ldi, Inv, sizeof(T) * np, sizeof(T) * n, n, hipMemcpyDeviceToDevice,
+                                 ctx->stream));
+  int32_t hinfo = 0;
+  double hl = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&hinfo, info, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(&hl, sc, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (info_host) *info_host = hinfo;
+  if (logdet_host) *logdet_host = 2.0 * hl;
+  (void)hipFree(Ap);
+  (void)hipFree(X);
+  (void)hipFree(Tw);
+  (void)hipFree(info);
+  (void)hipFree(sc);
+  if (keep_inv_padded) {
+    *keep_inv_padded = Inv;
+    *np_out = np;
+  } else {
+    (void)hipFree(Inv);
+  }
+  if (hinfo != 0) {
+    ctx->err = "PosDefException: matrix is not positive definite; leading minor " + std::to_string(hinfo);
+    return AGP_ERR_NOT_POSDEF;
+  }
+  return AGP_OK;
+}
+
+template <typename T>
+static agp_status bb_solve_right(agp_ctx* ctx, const void* a, int64_t lda, int64_t n, const void* b, int64_t ldb,
+                                 int64_t r, void* x, int64_t ldx, int32_t* info_host) {
+  T* Inv = nullptr;
+  int64_t np = 0;
+  agp_status s = bb_spd_inverse<T>(ctx, a, lda, n, nullptr, 0, nullptr, info_host, &Inv, &np);
+  if (s != AGP_OK) {
+    if (Inv) (void)hipFree(Inv);
+    return s;
+  }
+  const int64_t rp = rup64(r);
+  T *Bp = nullptr, *Xp = nullptr;
+  AGPCHK(dmalloc(ctx, &Bp, rp * np));
+  AGPCHK(dmalloc(ctx, &Xp, rp * np));
+  // zero the padded rows/cols of B (pad_diag = 0) ; padded block of Inv is the identity
+  hipLaunchKernelGGL((k_copy2d_zero<T>), grid2(rp, np), blk2, 0, ctx->stream, (const T*)b, ldb, r, n, Bp, np, rp, np);
+  LAUNCHCHK(ctx);
+  AGPCHK((gemm_nt<T, EPI_STORE>(ctx, Bp, np, Inv, np, rp, np, np, 0, Xp, np, nullptr, 0, nullptr, nullptr, nullptr, 0)));
+  HIPCHK(ctx, hipMemcpy2DAsync(x, sizeof(T) * ldx, Xp, sizeof(T) * np, sizeof(T) * n, r, hipMemcpyDeviceToDevice,
+                               ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(Inv);
+  (void)hipFree(Bp);
+  (void)hipFree(Xp);
+  return AGP_OK;
+}
+
+template <typename T>
+static agp_status bb_mfma_peak(agp_ctx* ctx, double* tflops) {
+  const int blocks = 256 * 8, iters = 4096;
+  T* out = nullptr;
+  AGPCHK(dmalloc(ctx, &out, (int64_t)blocks * NTHREADS));
+  hipEvent_t e0, e1;
+  HIPCHK(ctx, hipEventCreate(&e0));
+  HIPCHK(ctx, hipEventCreate(&e1));
+  hipLaunchKernelGGL((k_mfma_peak<T>), dim3(blocks), dim3(NTHREADS), 0, ctx->stream, out, 64);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+  hipLaunchKernelGGL((k_mfma_peak<T>), dim3(blocks), dim3(NTHREADS), 0, ctx->stream, out, iters);
+  HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+  HIPCHK(ctx, hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)blocks * (NTHREADS / 64) * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(out);
+  return AGP_OK;
+}
+
+#define DISPATCH(dtype, call_f64, call_f32)        \
+  do {                                             \
+    if ((dtype) == AGP_F64) return call_f64;       \
+    if ((dtype) == AGP_F32) return call_f32;       \
+    return AGP_ERR_INVALID;                        \
+  } while (0)
+
+extern "C" {
+
+agp_status agp_kernelmatrix(agp_ctx* ctx, int32_t dtype, const agp_kernel_desc* k, const void* x, int64_t n, int64_t ldx,
+                            const int64_t* idx, const void* y, int64_t p, int64_t ldy, int64_t D, void* out,
+                            int64_t ldo) {
+  if (!ctx || !k || !x || !out || n <= 0 || D <= 0) return AGP_ERR_INVALID;
+  DISPATCH(dtype, bb_kernelmatrix<double>(ctx, k, x, n, ldx, idx, y, p, ldy, D, out, ldo),
+           bb_kernelmatrix<float>(ctx, k, x, n, ldx, idx, y, p, ldy, D, out, ldo));
+}
+
+agp_status agp_potrf_jitter(agp_ctx* ctx, int32_t dtype, void* a, int64_t lda, int64_t n, double jitter,
+                            int32_t* info_host) {
+  if (!ctx || !a || n <= 0 || lda < n) return AGP_ERR_INVALID;
+  DISPATCH(dtype, bb_potrf<double>(ctx, a, lda, n, jitter, info_host), bb_potrf<float>(ctx, a, lda, n, jitter, info_host));
+}
+
+agp_status agp_spd_inverse(agp_ctx* ctx, int32_t dtype, const void* a, int64_t lda, int64_t n, void* ainv, int64_t ldi,
+                           double* logdet_host, int32_t* info_host) {
+  if (!ctx || !a || !ainv || n <= 0 || lda < n || ldi < n) return AGP_ERR_INVALID;
+  DISPATCH(dtype, bb_spd_inverse<double>(ctx, a, lda, n, ainv, ldi, logdet_host, info_host, nullptr, nullptr),
+           bb_spd_inverse<float>(ctx, a, lda, n, ainv, ldi, logdet_host, info_host, nullptr, nullptr));
+}
+
+agp_status agp_solve_right_spd(agp_ctx* ctx, int32_t dtype, const void* a, int64_t lda, int64_t n, const void* b,
+                               int64_t ldb, int64_t r, void* x, int64_t ldx, int32_t* info_host) {
+  if (!ctx || !a || !b || !x || n <= 0 || r <= 0) return AGP_ERR_INVALID;
+  DISPATCH(dtype, bb_solve_right<double>(ctx, a, lda, n, b, ldb, r, x, ldx, info_host),
+           bb_solve_right<float>(ctx, a, lda, n, b, ldb, r, x, ldx, info_host));
+}
+
+agp_status agp_mfma_peak(agp_ctx* ctx, int32_t dtype, double* tflops_host) {
+  if (!ctx || !tflops_host) return AGP_ERR_INVALID;
+  DISPATCH(dtype, bb_mfma_peak<double>(ctx, tflops_host), bb_mfma_peak<float>(ctx, tflops_host));
+}
+
+agp_status agp_svgp_create(agp_ctx* ctx, const agp_svgp_desc* desc, agp_svgp** out) {
+  if (!ctx || !desc || !out) return AGP_ERR_INVALID;
+  *out = nullptr;
+  SvgpBase* impl = nullptr;
+  if (desc->dtype == AGP_F64) impl = new Svgp<double>();
+  else if (desc->dtype == AGP_F32) impl = new Svgp<float>();
+  else return AGP_ERR_INVALID;
+  impl->ctx = ctx;
+  impl->desc = *desc;
+  agp_status s = impl->init();
+  if (s != AGP_OK) {
+    delete impl;
+    return s;
+  }
+  agp_svgp* h = new agp_svgp();
+  h->impl = impl;
+  *out = h;
+  return AGP_OK;
+}
+
+agp_status agp_svgp_destroy(agp_svgp* h) {
+  if (!h) return AGP_OK;
+  (void)hipStreamSynchronize(h->impl->ctx->stream);
+  delete h->impl;
+  delete h;
+  return AGP_OK;
+}
+
+#define HCHK(h) \
+  if (!(h) || !(h)->impl) return AGP_ERR_INVALID
+
+agp_status agp_svgp_set_kernel(agp_svgp* h, int32_t latent, const agp_kernel_desc* k) {
+  HCHK(h);
+  return h->impl->set_kernel(latent, k);
+}
+agp_status agp_svgp_set_Z(agp_svgp* h, int32_t latent, const void* z, int64_t ldz) {
+  HCHK(h);
+  return h->impl->set_Z(latent, z, ldz);
+}
+agp_status agp_svgp_get_Z(agp_svgp* h, int32_t latent, void* z, int64_t ldz) {
+  HCHK(h);
+  return h->impl->get_Z(latent, z, ldz);
+}
+agp_status agp_svgp_set_prior_mean(agp_svgp* h, int32_t latent, const void* mu0) {
+  HCHK(h);
+  return h->impl->set_mu0(latent, mu0);
+}
+agp_status agp_svgp_refresh_K(agp_svgp* h) {
+  HCHK(h);
+  return h->impl->refresh_K();
+}
+agp_status agp_svgp_set_opt_state(agp_svgp* h, int64_t n) {
+  HCHK(h);
+  if (n < 1) return AGP_ERR_INVALID;
+  h->impl->n_opt = n;
+  return AGP_OK;
+}
+agp_status agp_svgp_get_opt_state(agp_svgp* h, int64_t* n_host) {
+  HCHK(h);
+  *n_host = h->impl->n_opt;
+  return AGP_OK;
+}
+
+agp_status agp_svgp_cavi_step(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B,
+                              double rho) {
+  HCHK(h);
+  SvgpBase* s = h->impl;
+  AGPCHK(s->step_local(x, ldx, y, idx, B, rho, false));
+  if (s->desc.lik.kind == AGP_LIK_LOGISTICSOFTMAX) {
+    for (int it = 0; it < 2; ++it) {  // logisticsoftmax.jl:65
+      AGPCHK(s->lsm_gamma());
+      AGPCHK(s->lsm_alpha());
+    }
+  }
+  AGPCHK(s->step_stats(true));
+  return s->step_global(true);
+}
+
+agp_status agp_svgp_step_local(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B,
+                               double rho) {
+  HCHK(h);
+  return h->impl->step_local(x, ldx, y, idx, B, rho, false);
+}
+agp_status agp_svgp_lsm_gamma(agp_svgp* h) {
+  HCHK(h);
+  return h->impl->lsm_gamma();
+}
+agp_status agp_svgp_lsm_alpha(agp_svgp* h) {
+  HCHK(h);
+  return h->impl->lsm_alpha();
+}
+agp_status agp_svgp_lsm_gsum_ptr(agp_svgp* h, void** ptr, int64_t* count) {
+  HCHK(h);
+  return h->impl->lsm_gsum_ptr(ptr, count);
+}
+agp_status agp_svgp_step_stats(agp_svgp* h) {
+  HCHK(h);
+  return h->impl->step_stats(false);
+}
+agp_status agp_svgp_stats_ptr(agp_svgp* h, void** ptr, int64_t* count) {
+  HCHK(h);
+  return h->impl->stats_ptr(ptr, count);
+}
+agp_status agp_svgp_step_global(agp_svgp* h) {
+  HCHK(h);
+  return h->impl->step_global(false);
+}
+agp_status agp_svgp_check_status(agp_svgp* h) {
+  HCHK(h);
+  return h->impl->check_status();
+}
+agp_status agp_svgp_elbo(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B,
+                         double rho, int32_t fresh_local, double* elbo_host) {
+  HCHK(h);
+  if (!elbo_host) return AGP_ERR_INVALID;
+  return h->impl->elbo(x, ldx, y, idx, B, rho, fresh_local, elbo_host);
+}
+agp_status agp_svgp_get_state(agp_svgp* h, int32_t latent, void* mu, void* sigma, void* eta1, void* eta2) {
+  HCHK(h);
+  return h->impl->get_state(latent, mu, sigma, eta1, eta2);
+}
+agp_status agp_svgp_set_state(agp_svgp* h, int32_t latent, const void* eta1, const void* eta2) {
+  HCHK(h);
+  return h->impl->set_state(latent, eta1, eta2);
+}
+agp_status agp_svgp_get_matrix(agp_svgp* h, int32_t latent, int32_t which, void* out, int64_t ldo) {
+  HCHK(h);
+  return h->impl->get_matrix(latent, which, out, ldo);
+}
+agp_status agp_svgp_predict_f(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* mu_out, void* var_out) {
+  HCHK(h);
+  return h->impl->predict_f(xt, ldx, n_t, mu_out, var_out);
+}
+agp_status agp_svgp_predict_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* y_out) {
+  HCHK(h);
+  return h->impl->predict_y(xt, ldx, n_t, y_out);
+}
+agp_status agp_svgp_proba_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, const double* gh_nodes_host,
+                            const double* gh_weights_host, int32_t n_nodes, void* out0, void* out1) {
+  HCHK(h);
+  return h->impl->proba_y(xt, ldx, n_t, gh_nodes_host, gh_weights_host, n_nodes, out0, out1);
+}
+
+}  // extern "C"

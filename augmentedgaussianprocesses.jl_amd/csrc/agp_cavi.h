@@ -1,0 +1,558 @@
+// agp_cavi.h -- kernel-matrix evaluation, per-likelihood local updates, natural-parameter vector updates, ELBO
+// reductions and prediction post-processing for the SVGP / AnalyticVI path on gfx950.
+// Reference: src/gpblocks/latentgp.jl:171-215, src/likelihood/{gaussian,logistic,studentt,logisticsoftmax}.jl,
+// src/inference/analyticVI.jl:143-274, src/functions/KLdivergences.jl, src/training/predictions.jl.
+#pragma once
+#include "agp_device.h"
+
+namespace agp {
+
+enum { K_SQEXP = 0, K_MATERN52 = 1, K_MATERN32 = 2, K_EXPONENTIAL = 3 };
+enum { LIK_GAUSSIAN = 0, LIK_LOGISTIC = 1, LIK_STUDENTT = 2, LIK_LSM = 3 };
+enum { FLAG_NEG_KTILDE = 1 };
+
+template <typename T>
+__device__ __forceinline__ T kernel_base(int kind, T d2) {
+  d2 = d2 > T(0) ? d2 : T(0);
+  if (kind == K_SQEXP) return exp(T(-0.5) * d2);
+  T d = sqrt(d2);
+  if (kind == K_MATERN52) {
+    const T s5 = T(2.23606797749978969641);
+    return (T(1) + s5 * d + T(5) * d2 / T(3)) * exp(-s5 * d);
+  }
+  if (kind == K_MATERN32) {
+    const T s3 = T(1.73205080756887729353);
+    return (T(1) + s3 * d) * exp(-s3 * d);
+  }
+  return exp(-d);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kernelmatrix(k, X[idx], Y)  (src/gpblocks/latentgp.jl:206,210 ; KernelFunctions.jl semantics):
+//   out[i][j] = variance * base( || scales .* (x_i - y_j) ||^2 )     direct squared differences, no GEMM trick.
+// 64x64 output tile per workgroup, 4x4 outputs per thread, operands staged through LDS in chunks of 32 dims with
+// the minibatch gather (x row = X[idx[i]]) fused into the staging loads (256-byte coalesced rows at D = 32 f64).
+//   rows >= n or cols >= p (padding up to n_out x p_out) are written as 0 ;
+//   sym != 0 : self matrix -> adds diag_add (jitter) on the diagonal and 1 on the padded diagonal.
+//   alpha != nullptr : fused row-dot  part[blockIdx.x][i] = sum_j out[i][j] alpha[j]  (predict mean without K_*m)
+//   out == nullptr : nothing stored (mean-only prediction)
+// ---------------------------------------------------------------------------------------------------
+constexpr int KM_DC = 32;
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_kernelmatrix(const T* __restrict__ X, int64_t ldx,
+                                                           const int64_t* __restrict__ idx, int64_t n,
+                                                           const T* __restrict__ Y, int64_t ldy, int64_t p, int64_t D,
+                                                           const T* __restrict__ scales, int kind, T variance,
+                                                           T* __restrict__ out, int64_t ldo, int64_t n_out,
+                                                           int64_t p_out, int sym, T diag_add,
+                                                           const T* __restrict__ alpha, T* __restrict__ part,
+                                                           int64_t ldp) {
+  __shared__ T xs[TILE][KM_DC + 1];
+  __shared__ T ys[TILE][KM_DC + 1];
+  const int tid = threadIdx.x;
+  const int ty = tid >> 4, tx = tid & 15;
+  const int64_t i0 = blockIdx.y * (int64_t)TILE, j0 = blockIdx.x * (int64_t)TILE;
+  T acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = T(0);
+  for (int64_t d0 = 0; d0 < D; d0 += KM_DC) {
+    for (int e = tid; e < TILE * KM_DC; e += NTHREADS) {
+      int r = e / KM_DC, d = e % KM_DC;
+      int64_t gd = d0 + d;
+      T sc = (scales && gd < D) ? scales[gd] : T(1);
+      int64_t gi = i0 + r, gj = j0 + r;
+      T xv = T(0), yv = T(0);
+      if (gd < D) {
+        if (gi < n) {
+          int64_t src = idx ? idx[gi] : gi;
+          xv = X[src * ldx + gd] * sc;
+        }
+        if (gj < p) yv = Y[gj * ldy + gd] * sc;
+      }
+      xs[r][d] = xv;
+      ys[r][d] = yv;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int d = 0; d < KM_DC; ++d) {
+      T xv[4], yv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) xv[a] = xs[ty + 16 * a][d];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) yv[b] = ys[tx + 16 * b][d];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          T df = xv[a] - yv[b];
+          acc[a][b] += df * df;
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    int64_t gi = i0 + ty + 16 * a;
+    T rsum = T(0);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      int64_t gj = j0 + tx + 16 * b;
+      T val = T(0);
+      if (gi < n && gj < p) {
+        val = variance * kernel_base<T>(kind, acc[a][b]);
+        if (sym && gi == gj) val += diag_add;
+      } else if (sym && gi == gj) {
+        val = T(1);
+      }
+      if (out && gi < n_out && gj < p_out) out[gi * ldo + gj] = val;
+      if (alpha && gj < p) rsum += val * alpha[gj];
+    }
+    if (alpha) {
+      rsum = row16_sum(rsum);
+      if (tx == 0 && gi < n_out) part[blockIdx.x * ldp + gi] = rsum;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// special functions
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double digamma_d(double x) {
+  // psi(x), x > 0 : upward recurrence to x >= 10, then the asymptotic series (|err| < 1e-15 relative)
+  double r = 0.0;
+  while (x < 10.0) {
+    r -= 1.0 / x;
+    x += 1.0;
+  }
+  double f = 1.0 / (x * x);
+  double t = f * (-1.0 / 12.0 +
+                  f * (1.0 / 120.0 +
+                       f * (-1.0 / 252.0 +
+                            f * (1.0 / 240.0 + f * (-1.0 / 132.0 + f * (691.0 / 32760.0 + f * (-1.0 / 12.0)))))));
+  return r + log(x) - 0.5 / x + t;
+}
+
+// E[omega] for PG(1, c): tanh(c/2)/(2c), series 1/4 - c^2/48 near 0   (src/likelihood/logistic.jl:47-49)
+template <typename T>
+__device__ __forceinline__ T theta_pg(T c) {
+  T ac = fabs(c);
+  const T small = sizeof(T) == 8 ? T(1e-6) : T(1e-2);
+  if (ac < small) return T(0.25) - c * c / T(48) + c * c * c * c / T(480);
+  return tanh(c / T(2)) / (T(2) * c);
+}
+
+// log(cosh(x)) = log(exp(-2x)+1) + x - log 2   (src/functions/utils.jl:89-91)
+__device__ __forceinline__ double logcosh_d(double x) { return log(exp(-2.0 * x) + 1.0) + x - 0.69314718055994530942; }
+
+// exp(mu)/cosh(c) with the reference's overflow fallback (src/functions/utils.jl:84-86)
+__device__ __forceinline__ double safe_expcosh_d(double mu, double c) {
+  double r = exp(mu) / cosh(c);
+  if (isfinite(r)) return r;
+  double z = 2.0 * (mu > c ? mu : c);
+  return 2.0 / (1.0 + exp(-z));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Local step: finish K~, mean_f, var_f from the GEMM partial slices and run the likelihood's local_updates! +
+// grad_E_mu / grad_E_Sigma (Appendix B of SURVEY.md):
+//   K~   = kdiag + jitter - sum_s pk[s][i]          latentgp.jl:212
+//   varf = sum_s pw0[s][i] + K~ ; muf = sum_s pw1[s][i]   latentgp.jl:179,189
+//   r = rho * grad_E_mu , w = rho * grad_E_Sigma  (what the batch statistics consume, analyticVI.jl:168,179)
+// For LogisticSoftMax only c_k is produced here; gamma/alpha/theta follow in the k_lsm_* kernels.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+struct LikParams {
+  int kind;
+  T p0;  // gaussian sigma2 / studentt nu
+  T p1;  // studentt sigma
+};
+
+template <typename T>
+__global__ void k_local_update(int64_t B, int nslices, const T* __restrict__ pk, const T* __restrict__ pw0,
+                               const T* __restrict__ pw1, int64_t ldp, T kdiag, T jitter, T rho, LikParams<T> lp,
+                               const T* __restrict__ y, const int64_t* __restrict__ idx, T* __restrict__ Kt,
+                               T* __restrict__ muf, T* __restrict__ varf, T* __restrict__ c, T* __restrict__ theta,
+                               T* __restrict__ r, T* __restrict__ w, int* __restrict__ flags, int use_kt) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  T sk = T(0), s0 = T(0), s1 = T(0);
+  for (int s = 0; s < nslices; ++s) {
+    if (!use_kt) sk += pk[s * ldp + i];
+    s0 += pw0[s * ldp + i];
+    s1 += pw1[s * ldp + i];
+  }
+  // use_kt: kappa (hence K~) was kept from the previous full-batch step (training.jl:199-205)
+  T kt = use_kt ? Kt[i] : kdiag + jitter - sk;
+  if (!(kt > T(0))) atomicOr(flags, FLAG_NEG_KTILDE);
+  T var = s0 + kt, mu = s1;
+  Kt[i] = kt;
+  muf[i] = mu;
+  varf[i] = var;
+  if (lp.kind == LIK_LSM) {
+    c[i] = sqrt(mu * mu + var);  // logisticsoftmax.jl:62-64
+    return;
+  }
+  T yi = y[idx ? idx[i] : i];
+  T th, cc = T(0), g1;
+  if (lp.kind == LIK_GAUSSIAN) {  // gaussian.jl:70-80
+    th = T(1) / lp.p0;
+    g1 = yi / lp.p0;
+  } else if (lp.kind == LIK_LOGISTIC) {  // logistic.jl:39-51,64-69
+    cc = sqrt(mu * mu + var);
+    th = theta_pg<T>(cc);
+    g1 = yi / T(2);
+  } else {  // studentt.jl:68-82,96-99
+    T alpha = (lp.p0 + T(1)) / T(2);
+    cc = ((mu - yi) * (mu - yi) + var + lp.p1 * lp.p1 * lp.p0) / T(2);
+    th = alpha / cc;
+    g1 = th * yi;
+  }
+  c[i] = cc;
+  theta[i] = th;
+  r[i] = rho * g1;
+  w[i] = rho * th / T(2);
+}
+
+// LogisticSoftMax fixed point (logisticsoftmax.jl:65-72), arrays are [nl][ldb] per local latent:
+//   gamma_k = exp(psi(alpha)) * safe_expcosh(-mu_k/2, c_k/2) / (2 beta) ; gsum = sum_k gamma_k (local latents)
+template <typename T>
+__global__ void k_lsm_gamma(int64_t B, int nl, int64_t ldb, const T* __restrict__ muf, const T* __restrict__ c,
+                            const T* __restrict__ alpha, const T* __restrict__ beta, T* __restrict__ gamma,
+                            T* __restrict__ gsum) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  double epsi = exp(digamma_d((double)alpha[i]));
+  double b2 = 2.0 * (double)beta[i];
+  double s = 0.0;
+  for (int k = 0; k < nl; ++k) {
+    double g = epsi * safe_expcosh_d(-0.5 * (double)muf[k * ldb + i], 0.5 * (double)c[k * ldb + i]) / b2;
+    gamma[k * ldb + i] = (T)g;
+    s += g;
+  }
+  gsum[i] = (T)s;
+}
+
+template <typename T>
+__global__ void k_lsm_alpha(int64_t B, const T* __restrict__ gsum, T* __restrict__ alpha) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < B) alpha[i] = T(1) + gsum[i];
+}
+
+// theta_k = (Y_k + gamma_k) tanh(c_k/2)/(2 c_k) ; r_k = rho (Y_k - gamma_k)/2 ; w_k = rho theta_k/2
+// (logisticsoftmax.jl:73-77, 98-103) ; ycls = 0-based class index, Y_k = (ycls == latent_offset + k)
+template <typename T>
+__global__ void k_lsm_finish(int64_t B, int nl, int64_t ldb, int latent_offset, T rho,
+                             const int32_t* __restrict__ ycls, const int64_t* __restrict__ idx,
+                             const T* __restrict__ c, const T* __restrict__ gamma, T* __restrict__ theta,
+                             T* __restrict__ r, T* __restrict__ w) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  int cls = ycls[idx ? idx[i] : i];
+  for (int k = 0; k < nl; ++k) {
+    T yk = (cls == latent_offset + k) ? T(1) : T(0);
+    T g = gamma[k * ldb + i];
+    T th = (yk + g) * theta_pg<T>(c[k * ldb + i]);
+    theta[k * ldb + i] = th;
+    r[k * ldb + i] = rho * (yk - g) / T(2);
+    w[k * ldb + i] = rho * th / T(2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// t = kappa' r  (analyticVI.jl:168): column sums in two deterministic stages.
+// stage 1: grid (mp/64, Bp/64): part[by][col] = sum over the 64 rows of this row block
+// stage 2 lives in k_eta1_update / k_stats_t.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_colsum_partial(const T* __restrict__ kappa, int64_t ld,
+                                                             const T* __restrict__ r, T* __restrict__ part,
+                                                             int64_t ldp) {
+  __shared__ T red[4][TILE];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t c0 = blockIdx.x * (int64_t)TILE, r0 = blockIdx.y * (int64_t)TILE;
+  T s = T(0);
+#pragma unroll 4
+  for (int q = 0; q < 16; ++q) {
+    int64_t row = r0 + grp * 16 + q;
+    s += kappa[row * ld + c0 + col] * r[row];
+  }
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0) part[blockIdx.y * ldp + c0 + col] = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+}
+
+// eta1 += lr * ( sum_parts t + K^-1 mu0 - eta1 )    (analyticVI.jl:160-169, 229-246)
+// t_in != nullptr: t already reduced (multi-GPU stats path) ; else sum nparts slices of part.
+template <typename T>
+__global__ void k_eta1_update(int64_t mp, int nparts, const T* __restrict__ part, int64_t ldp,
+                              const T* __restrict__ t_in, const T* __restrict__ kinv_mu0, T* __restrict__ eta1,
+                              const T* __restrict__ lr_dev, T* __restrict__ t_out) {
+  int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (a >= mp) return;
+  T t = T(0);
+  if (t_in) t = t_in[a];
+  else
+    for (int s = 0; s < nparts; ++s) t += part[s * ldp + a];
+  if (t_out) {
+    t_out[a] = t;
+    return;
+  }
+  T e = eta1[a];
+  T g = t + (kinv_mu0 ? kinv_mu0[a] : T(0)) - e;
+  eta1[a] = e + (*lr_dev) * g;
+}
+
+// mean_f / var_f only (ELBO with the updated posterior): mu = sum pw1 ; var = sum pw0 + K~
+template <typename T>
+__global__ void k_meanvar_finish(int64_t B, int nslices, const T* __restrict__ pw0, const T* __restrict__ pw1,
+                                 int64_t ldp, const T* __restrict__ Kt, T* __restrict__ muf, T* __restrict__ varf) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  T s0 = T(0), s1 = T(0);
+  for (int s = 0; s < nslices; ++s) {
+    s0 += pw0[s * ldp + i];
+    s1 += pw1[s * ldp + i];
+  }
+  muf[i] = s1;
+  varf[i] = s0 + Kt[i];
+}
+
+template <typename T>
+__global__ void k_zero_strict_upper(T* __restrict__ A, int64_t ld, int64_t n) {
+  int64_t i = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
+  int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n && j < n && j > i) A[i * ld + j] = T(0);
+}
+
+template <typename T>
+__global__ void k_add_diag(T* __restrict__ A, int64_t ld, int64_t n, T v) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) A[i * ld + i] += v;
+}
+
+// dst (rd x cd) = src (rs x cs) zero-padded
+template <typename T>
+__global__ void k_copy2d_zero(const T* __restrict__ src, int64_t lds, int64_t rs, int64_t cs, T* __restrict__ dst,
+                              int64_t ldd, int64_t rd, int64_t cd) {
+  int64_t r = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= rd || c >= cd) return;
+  dst[r * ldd + c] = (r < rs && c < cs) ? src[r * lds + c] : T(0);
+}
+
+template <typename T>
+__global__ void k_set_scalar(T* p, T v) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *p = v;
+}
+
+template <typename T>
+__global__ void k_fill(T* p, int64_t n, T v) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// dst(n x n, ld) = diag value on the diagonal, 0 elsewhere
+template <typename T>
+__global__ void k_set_identity(T* p, int64_t n, int64_t ld, T diag) {
+  int64_t i = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
+  int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n && j < n) p[i * ld + j] = (i == j) ? diag : T(0);
+}
+
+// strided 2-D copy with optional padding: dst[r][c] = (r < rs && c < cs) ? src[r][c] : padval(r,c)
+template <typename T>
+__global__ void k_copy2d(const T* __restrict__ src, int64_t lds, int64_t rs, int64_t cs, T* __restrict__ dst,
+                         int64_t ldd, int64_t rd, int64_t cd, T pad_diag, T scale) {
+  int64_t r = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= rd || c >= cd) return;
+  T v = (r < rs && c < cs) ? src[r * lds + c] * scale : ((r == c) ? pad_diag : T(0));
+  dst[r * ldd + c] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ELBO data terms (analyticVI.jl:255-274): one workgroup, double accumulation, deterministic.
+//   out[0] = expec_loglikelihood (gaussian.jl:82-93, logistic.jl:73-84, studentt.jl:103-119, logisticsoftmax.jl:106-115)
+//   out[1] = AugmentedKL          (logistic.jl:86-92, studentt.jl:121-127, logisticsoftmax.jl:117-140)
+// LogisticSoftMax: sums over the nl local latents; the GammaEntropy term and nothing else is global and is added
+// only when add_global != 0 (latent_offset == 0 rank).  elbo_ref != 0 reproduces logistic.jl:82 (dot(theta, mu)).
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_elbo_terms(int64_t B, int nl, int64_t ldb, LikParams<T> lp, int elbo_ref, int latent_offset,
+                             int add_global, const T* __restrict__ y, const int32_t* __restrict__ ycls,
+                             const int64_t* __restrict__ idx, const T* __restrict__ muf, const T* __restrict__ varf,
+                             const T* __restrict__ c, const T* __restrict__ theta, const T* __restrict__ gamma,
+                             const T* __restrict__ alpha, const T* __restrict__ beta, double* __restrict__ out) {
+  __shared__ double red[16];
+  double e = 0.0, kl = 0.0;
+  const double LOG2 = 0.69314718055994530942, LOG2PI = 1.83787706640934548356;
+  for (int64_t i = threadIdx.x; i < B; i += blockDim.x) {
+    if (lp.kind == LIK_LSM) {
+      int cls = ycls[idx ? idx[i] : i];
+      double a = (double)alpha[i], b = (double)beta[i];
+      double psi = digamma_d(a);
+      double lam0 = a / b, psil = psi - log(b);
+      for (int k = 0; k < nl; ++k) {
+        double yk = (cls == latent_offset + k) ? 1.0 : 0.0;
+        double g = (double)gamma[k * ldb + i], th = (double)theta[k * ldb + i];
+        double mu = (double)muf[k * ldb + i], s = (double)varf[k * ldb + i], cc = (double)c[k * ldb + i];
+        e += -LOG2 - (g + yk) * LOG2 + 0.5 * (mu * (yk - g) - th * mu * mu - th * s);
+        kl += (yk + g) * logcosh_d(0.5 * cc) - 0.5 * cc * cc * th;          // PolyaGammaKL
+        kl += lam0 - g + (g > 0.0 ? g * log(g) : 0.0) - g * psil;           // PoissonKL
+      }
+      if (add_global) kl += -a - lgamma(a) - (1.0 - a) * psi;               // GammaEntropy (sum parts)
+    } else {
+      double yi = (double)y[idx ? idx[i] : i];
+      double mu = (double)muf[i], s = (double)varf[i];
+      if (lp.kind == LIK_GAUSSIAN) {
+        double s2 = (double)lp.p0;
+        e += -0.5 * (LOG2PI + log(s2) + ((yi - mu) * (yi - mu) + s) / s2);
+      } else if (lp.kind == LIK_LOGISTIC) {
+        double th = (double)theta[i], cc = (double)c[i];
+        double quad = elbo_ref ? th * mu : th * mu * mu;
+        e += -0.5 * LOG2 + 0.5 * (mu * yi - th * s - quad);
+        kl += logcosh_d(0.5 * cc) - 0.5 * cc * cc * th;
+      } else {
+        double nu = (double)lp.p0, sig = (double)lp.p1;
+        double al = 0.5 * (nu + 1.0), alp = 0.5 * nu, bp = alp * sig * sig;
+        double th = (double)theta[i], cc = (double)c[i];
+        e += -0.5 * log(2.0 * 3.14159265358979323846 * sig * sig) - (log(cc) - digamma_d(al)) -
+             0.5 * (th * s + th * mu * mu - 2.0 * th * mu * yi + th * yi * yi);
+        kl += (al - alp) * digamma_d(al) - lgamma(al) + lgamma(alp) + alp * (log(cc) - log(bp)) + al * (bp - cc) / cc;
+      }
+    }
+  }
+  e = block_sum<double>(e, red);
+  kl = block_sum<double>(kl, red);
+  if (threadIdx.x == 0) {
+    if (lp.kind == LIK_LSM && add_global) kl += log((double)beta[0]);  // sum(log, first(beta)) (Q16)
+    out[0] = e;
+    out[1] = kl;
+  }
+}
+
+// sum_{a,b < m} A[a][b]*Bm[a][b]  -> out[0]   (tr(K^-1 Sigma) as a Frobenius dot, KLdivergences.jl:17)
+template <typename T>
+__global__ void k_frob_dot(const T* __restrict__ A, const T* __restrict__ Bm, int64_t ld, int64_t m,
+                           double* __restrict__ out) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int64_t e = threadIdx.x; e < m * m; e += blockDim.x) {
+    int64_t a = e / m, b = e % m;
+    s += (double)A[a * ld + b] * (double)Bm[a * ld + b];
+  }
+  s = block_sum<double>(s, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+// out[0] = sum_{i<n} x[i]^2
+template <typename T>
+__global__ void k_sumsq(const T* __restrict__ x, int64_t n, double* __restrict__ out) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += (double)x[i] * (double)x[i];
+  s = block_sum<double>(s, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+template <typename T>
+__global__ void k_axpby(int64_t n, T a, const T* __restrict__ x, T b, const T* __restrict__ y, T* __restrict__ z) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) z[i] = a * (x ? x[i] : T(0)) + b * (y ? y[i] : T(0));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// prediction post-processing (src/training/predictions.jl:25-50,178-247)
+// ---------------------------------------------------------------------------------------------------
+// mu[i] = sum_s pm[s][i] ; var[i] = kdiag + jitter - sum_s pv[s][i]
+template <typename T>
+__global__ void k_predict_finish(int64_t n, int nsm, const T* __restrict__ pm, int nsv, const T* __restrict__ pv,
+                                 int64_t ldp, T kdiag, T jitter, T* __restrict__ mu, T* __restrict__ var) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T s = T(0);
+  for (int q = 0; q < nsm; ++q) s += pm[q * ldp + i];
+  mu[i] = s;
+  if (var) {
+    T v = T(0);
+    for (int q = 0; q < nsv; ++q) v += pv[q * ldp + i];
+    var[i] = kdiag + jitter - v;
+  }
+}
+
+// predict_y: logistic -> mu > 0 ; LogisticSoftMax -> argmax_k (first maximum, like Julia argmax)
+template <typename T>
+__global__ void k_predict_label(int64_t n, int nl, int64_t ldm, int latent_offset, const T* __restrict__ mu,
+                                int32_t* __restrict__ out, int binary) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (binary) {
+    out[i] = mu[i] > T(0) ? 1 : 0;
+    return;
+  }
+  int best = 0;
+  T bv = mu[i];
+  for (int k = 1; k < nl; ++k) {
+    T v = mu[k * ldm + i];
+    if (v > bv) {
+      bv = v;
+      best = k;
+    }
+  }
+  out[i] = best + latent_offset;
+}
+
+// compute_proba for BernoulliLikelihood{LogisticLink} (classification.jl:14-26): Gauss-Hermite expectation of
+// sigma(f) and sigma(f)^2 with f ~ N(mu, max(var,0)) ; nodes/weights in device memory (already x*sqrt2, w/sqrt(pi)).
+template <typename T>
+__global__ void k_proba_logistic(int64_t n, const T* __restrict__ mu, const T* __restrict__ var, int nn,
+                                 const double* __restrict__ nodes, const double* __restrict__ weights,
+                                 T* __restrict__ p, T* __restrict__ pv) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double m = (double)mu[i], sd = sqrt(fmax((double)var[i], 0.0));
+  double s1 = 0.0, s2 = 0.0;
+  for (int q = 0; q < nn; ++q) {
+    double x = nodes[q] * sd + m;
+    double sg = x >= 0.0 ? 1.0 / (1.0 + exp(-x)) : exp(x) / (1.0 + exp(x));
+    s1 += weights[q] * sg;
+    s2 += weights[q] * sg * sg;
+  }
+  p[i] = (T)s1;
+  pv[i] = (T)fmax(s2 - s1 * s1, 0.0);
+}
+
+// (mu, var + add) for Gaussian (gaussian.jl:41-45) ; (mu, max(var,0) + add) for StudentT (studentt.jl:57-61)
+template <typename T>
+__global__ void k_proba_regression(int64_t n, const T* __restrict__ mu, const T* __restrict__ var, T add, int clamp,
+                                   T* __restrict__ o0, T* __restrict__ o1) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  o0[i] = mu[i];
+  T v = var[i];
+  if (clamp) v = v > T(0) ? v : T(0);
+  o1[i] = v + add;
+}
+
+// LogisticSoftMax link on the means only (multiclass.jl:96-117, logisticsoftmax.jl:29-31): out[i][k] row-major n x nl
+template <typename T>
+__global__ void k_proba_lsm(int64_t n, int nl, int64_t ldm, const T* __restrict__ mu, T* __restrict__ out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int k = 0; k < nl; ++k) {
+    double x = (double)mu[k * ldm + i];
+    double sg = x >= 0.0 ? 1.0 / (1.0 + exp(-x)) : exp(x) / (1.0 + exp(x));
+    s += sg;
+  }
+  for (int k = 0; k < nl; ++k) {
+    double x = (double)mu[k * ldm + i];
+    double sg = x >= 0.0 ? 1.0 / (1.0 + exp(-x)) : exp(x) / (1.0 + exp(x));
+    out[i * nl + k] = (T)(sg / s);
+  }
+}
+
+}  // namespace agp

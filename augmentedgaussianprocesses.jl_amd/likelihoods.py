@@ -1,0 +1,177 @@
+"""Likelihood descriptors + label handling (host logic, no numerics).
+
+Mirrors src/likelihood/{gaussian,logistic,classification,studentt,regression,logisticsoftmax,multiclass}.jl:
+constructors, `implemented`, `n_latent`, `treat_labels!`, class mapping / one-hot.  The local updates, gradients,
+ELBO terms and compute_proba run on the GPU (csrc/agp_cavi.h).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import capi
+
+
+class AbstractLikelihood:
+    kind = None
+    n_latent = 1
+
+    def lik_desc(self):
+        raise NotImplementedError
+
+
+class GaussianLikelihood(AbstractLikelihood):
+    """GaussianLikelihood(σ²=1e-3)  src/likelihood/gaussian.jl:10-24 (opt_noise is not on this path)."""
+
+    kind = capi.LIK_GAUSSIAN
+
+    def __init__(self, sigma2: float = 1e-3, opt_noise=False):
+        if opt_noise:
+            raise NotImplementedError("opt_noise uses a removed Optimisers API in the reference (gaussian.jl:63-69)")
+        if not sigma2 > 0:
+            raise ValueError("σ² must be positive")
+        self.sigma2 = float(sigma2)
+
+    def lik_desc(self):
+        return capi.LikDesc(self.kind, 1, self.sigma2, 0.0)
+
+    def __repr__(self):
+        return f"Gaussian likelihood (σ² = {self.sigma2})"
+
+
+class LogisticLikelihood(AbstractLikelihood):
+    """LogisticLikelihood() -> BernoulliLikelihood(LogisticLink())  src/likelihood/logistic.jl:19."""
+
+    kind = capi.LIK_LOGISTIC
+
+    def lik_desc(self):
+        return capi.LikDesc(self.kind, 1, 0.0, 0.0)
+
+    def __repr__(self):
+        return "Bernoulli Likelihood with Logistic Link"
+
+
+class StudentTLikelihood(AbstractLikelihood):
+    """StudentTLikelihood(ν, σ=1)  src/likelihood/studentt.jl:23-35."""
+
+    kind = capi.LIK_STUDENTT
+
+    def __init__(self, nu: float, sigma: float = 1.0):
+        if not nu > 0.5:
+            raise ValueError("ν should be greater than 0.5")  # studentt.jl:28
+        self.nu = float(nu)
+        self.sigma = float(sigma)
+        self.alpha = (self.nu + 1.0) / 2.0
+
+    def lik_desc(self):
+        return capi.LikDesc(self.kind, 1, self.nu, self.sigma)
+
+    def __repr__(self):
+        return f"Student-t likelihood (ν={self.nu}, σ={self.sigma})"
+
+
+class LogisticSoftMaxLikelihood(AbstractLikelihood):
+    """LogisticSoftMaxLikelihood(num_class | labels)  src/likelihood/logisticsoftmax.jl:24, multiclass.jl:1-25."""
+
+    kind = capi.LIK_LOGISTICSOFTMAX
+
+    def __init__(self, x):
+        if isinstance(x, (int, np.integer)):
+            self.n_class = int(x)
+            self.class_mapping = None
+            self.ind_mapping = None
+        else:
+            labels = list(x)
+            self.n_class = len(labels)
+            self.class_mapping = labels
+            self.ind_mapping = {v: i + 1 for i, v in enumerate(labels)}
+        if self.n_class < 2:
+            raise ValueError("need at least two classes")
+
+    @property
+    def n_latent(self):  # multiclass.jl:27
+        return self.n_class
+
+    def lik_desc(self):
+        return capi.LikDesc(self.kind, self.n_class, 0.0, 0.0)
+
+    def __repr__(self):
+        return f"Multiclass Likelihood ({self.n_class} classes, Logistic-SoftMax Link )"
+
+
+def _unique_in_order(y):
+    seen = []
+    for v in y:
+        if v not in seen:
+            seen.append(v)
+    return seen
+
+
+def create_mapping(l: LogisticSoftMaxLikelihood, y):
+    """create_mapping!  src/likelihood/multiclass.jl:60-78."""
+    K = l.n_latent
+    if l.class_mapping is None:
+        cm = _unique_in_order(y)
+        if len(cm) <= K and all(isinstance(v, (int, np.integer)) and 1 <= v <= K for v in cm):
+            cm = list(range(1, K + 1))
+        elif len(cm) > K:
+            raise RuntimeError(
+                f"The number of unique labels in the data : {cm} is not of the same size then the predefined class "
+                f"number ; {K}"
+            )
+        l.class_mapping = cm
+    l.ind_mapping = {v: i + 1 for i, v in enumerate(l.class_mapping)}
+    return l.ind_mapping
+
+
+def create_one_hot(l: LogisticSoftMaxLikelihood, y):
+    """create_one_hot  src/likelihood/multiclass.jl:81-94 (bool matrix N x K)."""
+    for v in _unique_in_order(y):
+        if v not in l.class_mapping:
+            raise RuntimeError("Some labels of y are not part of the expect labels")
+    Y = np.zeros((len(y), l.n_class), dtype=bool)
+    for i, v in enumerate(y):
+        for j in range(l.n_class):
+            if v == l.class_mapping[j]:
+                Y[i, j] = True
+                break
+    return Y
+
+
+def _as_list(y):
+    return y.tolist() if isinstance(y, np.ndarray) else list(y)
+
+
+def treat_labels(y, l: AbstractLikelihood):
+    """treat_labels!  regression.jl:10-15, classification.jl:29-44, multiclass.jl:40-44.
+
+    Returns what view_y hands to the inference: real vector (regression), ±1 vector (Bernoulli), one-hot bool
+    matrix (multiclass)."""
+    if isinstance(l, (GaussianLikelihood, StudentTLikelihood)):
+        arr = np.asarray(y)
+        if not (np.issubdtype(arr.dtype, np.floating) or np.issubdtype(arr.dtype, np.integer)):
+            raise ValueError("For regression target(s) should be real valued")
+        return arr.astype(np.float64)
+    if isinstance(l, LogisticLikelihood):
+        arr = np.asarray(y)
+        if not (np.issubdtype(arr.dtype, np.floating) or np.issubdtype(arr.dtype, np.integer)
+                or arr.dtype == bool):
+            raise TypeError("For classification target(s) should be real valued (Bool, Integer or Float)")
+        labels = sorted(int(v) for v in np.unique(arr))
+        if labels == [0, 1]:
+            return np.sign(arr.astype(np.float64) - 0.5)
+        if labels == [-1, 1]:
+            return arr.astype(np.float64)
+        raise ValueError("Labels of y should be binary {-1,1} or {0,1}")
+    if isinstance(l, LogisticSoftMaxLikelihood):
+        arr = np.asarray(y) if not isinstance(y, list) else None
+        if arr is not None and arr.ndim > 1:
+            raise ValueError("Target should be a vector of labels")
+        yl = _as_list(y)
+        create_mapping(l, yl)
+        return create_one_hot(l, yl)
+    raise TypeError(f"likelihood {l} is not implemented on this path")
+
+
+def class_indices(Y_onehot: np.ndarray) -> np.ndarray:
+    """0-based class index per row of a one-hot matrix (device representation of the BitMatrix)."""
+    return np.argmax(Y_onehot, axis=1).astype(np.int32)

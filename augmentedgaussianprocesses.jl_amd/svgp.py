@@ -1,0 +1,482 @@
+"""Host-side mirror of the reference's SVGP / AnalyticVI / train! / predict API.
+
+Reference                                                         here
+  SVGP(kernel, likelihood, inference, Z; ...)   SVGP.jl:33-80       SVGP(kernel, likelihood, inference, Z, ...)
+  AnalyticVI(; ϵ) / AnalyticSVI(B; ϵ, optimiser) analyticVI.jl:44-52 AnalyticVI(eps) / AnalyticSVI(B, eps, optimiser)
+  train!(model, X, y, iterations; callback, state, obsdim)          train_(model, X, y, iterations, callback=..., state=..., obsdim=1)
+  predict_f / predict_y / proba_y                predictions.jl      predict_f / predict_y / proba_y
+  ELBO(model, X, y) / objective(model, state, y) ELBO.jl, SVGP.jl:90 ELBO / objective
+
+Everything numeric is a call through the C ABI (capi.py -> libagp_hip.so).  torch supplies device buffers and the
+HIP stream.  There is no CPU path: constructing a device handle without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+from . import capi
+from .kernels import Kernel
+from .likelihoods import (
+    AbstractLikelihood,
+    GaussianLikelihood,
+    LogisticLikelihood,
+    LogisticSoftMaxLikelihood,
+    StudentTLikelihood,
+    class_indices,
+    treat_labels,
+)
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+class RobbinsMonro:
+    """RobbinsMonro(κ=0.51, τ=1)  src/inference/optimisers.jl:1-19."""
+
+    def __init__(self, kappa: float = 0.51, tau: float = 1.0):
+        if not (0.5 < kappa <= 1):
+            raise ValueError("κ should be in the interval (0.5,1]")
+        if not tau > 0:
+            raise ValueError("τ should be positive")
+        self.kappa = float(kappa)
+        self.tau = float(tau)
+
+
+class AnalyticVI:
+    """AnalyticVI(; ϵ=1e-5) -- full-batch CAVI, Descent(1.0) on the natural parameters (analyticVI.jl:44-46)."""
+
+    def __init__(self, eps: float = 1e-5, *, _stoch=False, _batchsize=0, _optimiser=None):
+        self.eps = float(eps)
+        self.n_iter = 0
+        self.stoch = _stoch
+        self.batchsize = int(_batchsize)
+        self.rho = 1.0
+        self.HyperParametersUpdated = True
+        self.optimiser = _optimiser
+
+    def __repr__(self):
+        return f"Analytic{' Stochastic' if self.stoch else ''} Variational Inference"
+
+
+def AnalyticSVI(nMinibatch: int, eps: float = 1e-5, optimiser: Optional[RobbinsMonro] = None) -> AnalyticVI:
+    """AnalyticSVI(nMinibatch; ϵ=1e-5, optimiser=RobbinsMonro())  analyticVI.jl:48-52."""
+    opt = optimiser if optimiser is not None else RobbinsMonro()
+    if not isinstance(opt, RobbinsMonro):
+        raise NotImplementedError("only RobbinsMonro is wired on this path (ALRSVI is dead code in the reference)")
+    return AnalyticVI(eps, _stoch=True, _batchsize=int(nMinibatch), _optimiser=opt)
+
+
+class State:
+    """What train! returns next to the model (states.jl:1-9): a reference to the device-resident state."""
+
+    def __init__(self, model):
+        self.model = model
+
+
+class SVGP:
+    """Sparse Variational GP (src/models/SVGP.jl:22-80).  Z: (m, D) array of inducing points (rows = points).
+
+    Keyword arguments follow the reference; hyper-parameter optimisation (`optimiser`, `Zoptimiser`) is the
+    next-tier row of SURVEY.md §8f and is not wired yet: pass optimiser=False (as every docs example does).
+    """
+
+    def __init__(self, kernel, likelihood, inference, Z, *, verbose: int = 0, optimiser=False, atfrequency: int = 1,
+                 mean=None, Zoptimiser=False, T=np.float64, device: Optional[int] = None, seed: Optional[int] = None,
+                 elbo_mode: str = "corrected", latent_slice: Optional[tuple] = None):
+        if not isinstance(inference, AnalyticVI):
+            raise TypeError("The inference object should be of type `VariationalInference` : either `AnalyticVI` or "
+                            "`NumericalVI`")  # SVGP.jl:45-47 (only AnalyticVI exists on this path)
+        if not isinstance(likelihood, (GaussianLikelihood, LogisticLikelihood, StudentTLikelihood,
+                                       LogisticSoftMaxLikelihood)):
+            raise RuntimeError(f"The {likelihood} is not compatible or implemented with the {inference}")  # :48-49
+        if optimiser or Zoptimiser:
+            raise NotImplementedError("hyper-parameter / inducing-point optimisation is the next-tier row "
+                                      "(SURVEY.md §8f-1); pass optimiser=False, Zoptimiser=False")
+        if mean is not None and not (np.isscalar(mean) or isinstance(mean, (list, np.ndarray))):
+            raise TypeError("mean must be None (ZeroMean), a Real (ConstantMean) or a vector (EmpiricalMean)")
+        self.likelihood = likelihood
+        self.inference = inference
+        self.verbose = verbose
+        self.atfrequency = atfrequency
+        self.trained = False
+        self.T = np.dtype(T)
+        if self.T not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise TypeError("T must be Float64 or Float32")
+        Z = np.asarray(Z, dtype=np.float64)
+        if Z.ndim != 2:
+            raise ValueError("Z must be an (m, D) array of inducing points")
+        self.n_latent_total = likelihood.n_latent
+        # latent-parallel runs hold a slice [lo, hi) of the latents on this rank
+        lo, hi = latent_slice if latent_slice is not None else (0, self.n_latent_total)
+        self.latent_offset, self.n_latent = lo, hi - lo
+        kernels = kernel if isinstance(kernel, (list, tuple)) else [kernel] * self.n_latent_total
+        for k in kernels:
+            if not isinstance(k, Kernel):
+                raise TypeError("kernel must be a KernelFunctions-style kernel object")
+        import copy
+
+        # each latent owns a deep copy of kernel and Z (latentgp.jl:63-68)
+        self.kernels = [copy.deepcopy(kernels[lo + i]) for i in range(self.n_latent)]
+        self.Zs = [Z.copy() for _ in range(self.n_latent)]
+        self.mean = mean
+        self.m, self.D = Z.shape
+        self.elbo_mode = elbo_mode
+        self.device = device
+        self.rng = np.random.default_rng(seed)
+        self._ctx = None
+        self._h = None
+        self._max_batch = 0
+        self._keep = []
+        self._data = None  # (X_dev, y_dev, N)
+
+    # ---- device handle management ---------------------------------------------------------------------------
+    @property
+    def tdtype(self):
+        torch = _torch()
+        return torch.float64 if self.T == np.dtype(np.float64) else torch.float32
+
+    def _dev(self):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: augmentedgaussianprocesses.jl_amd has no CPU fallback")
+        d = self.device if self.device is not None else torch.cuda.current_device()
+        return torch.device("cuda", d)
+
+    def _ensure_ctx(self):
+        if self._ctx is None:
+            torch = _torch()
+            dev = self._dev()
+            L = capi.lib()
+            ctx = C.c_void_p()
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            st = L.agp_ctx_create(dev.index, C.c_void_p(stream), C.byref(ctx))
+            if st != capi.AGP_OK:
+                raise capi.AGPError(st, "agp_ctx_create failed")
+            self._ctx = ctx
+        return self._ctx
+
+    def _chk(self, st):
+        capi.check(self._ctx, st)
+
+    def _ensure_handle(self, max_batch: int):
+        """(Re)create the device handle when a larger batch than ever before is requested; state is carried."""
+        torch = _torch()
+        L = capi.lib()
+        ctx = self._ensure_ctx()
+        if self._h is not None and max_batch <= self._max_batch:
+            return self._h
+        old = None
+        if self._h is not None:
+            old = [self.get_state(i) for i in range(self.n_latent)]
+            n_opt = C.c_int64()
+            self._chk(L.agp_svgp_get_opt_state(self._h, C.byref(n_opt)))
+            L.agp_svgp_destroy(self._h)
+            self._h = None
+        d = capi.SvgpDesc()
+        d.dtype = capi.F64 if self.T == np.dtype(np.float64) else capi.F32
+        d.n_latent = self.n_latent
+        d.latent_offset = self.latent_offset
+        d.stochastic = 1 if self.inference.stoch else 0
+        d.m, d.D, d.max_batch = self.m, self.D, int(max_batch)
+        d.lik = self.likelihood.lik_desc()
+        d.jitter = 0.0
+        opt = self.inference.optimiser or RobbinsMonro()
+        d.rm_kappa, d.rm_tau = opt.kappa, opt.tau
+        d.elbo_mode = capi.ELBO_REFERENCE if self.elbo_mode == "reference" else capi.ELBO_CORRECTED
+        h = C.c_void_p()
+        self._chk(L.agp_svgp_create(ctx, C.byref(d), C.byref(h)))
+        self._h = h
+        self._max_batch = int(max_batch)
+        dev = self._dev()
+        for i in range(self.n_latent):
+            kd, keep = self.kernels[i].desc(self.D)
+            self._chk(L.agp_svgp_set_kernel(h, i, C.byref(kd)))
+            z = torch.as_tensor(self.Zs[i], dtype=self.tdtype, device=dev).contiguous()
+            self._chk(L.agp_svgp_set_Z(h, i, C.c_void_p(z.data_ptr()), self.D))
+            if self.mean is not None:
+                mu0 = np.full(self.m, float(self.mean)) if np.isscalar(self.mean) else np.asarray(self.mean, float)
+                t = torch.as_tensor(mu0, dtype=self.tdtype, device=dev)
+                self._chk(L.agp_svgp_set_prior_mean(h, i, C.c_void_p(t.data_ptr())))
+            torch.cuda.synchronize(dev)
+        if old is not None:
+            for i, (mu, Sig, e1, e2) in enumerate(old):
+                self.set_state(i, e1, e2)
+            self._chk(L.agp_svgp_set_opt_state(h, n_opt.value))
+        return h
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                capi.lib().agp_svgp_destroy(self._h)
+            if self._ctx is not None:
+                capi.lib().agp_ctx_destroy(self._ctx)
+        except Exception:
+            pass
+
+    # ---- data ---------------------------------------------------------------------------------------------
+    def _upload(self, X, obsdim=1):
+        """wrap_X (datacontainer.jl:64-74): N x D (obsdim=1) or D x N (obsdim=2) -> point-major device tensor."""
+        torch = _torch()
+        dev = self._dev()
+        if isinstance(X, torch.Tensor):
+            Xt = X.to(device=dev, dtype=self.tdtype)
+        else:
+            Xt = torch.as_tensor(np.asarray(X), dtype=self.tdtype, device=dev)
+        if Xt.ndim == 1:
+            Xt = Xt[:, None]
+        if obsdim == 2:
+            Xt = Xt.t()
+        Xt = Xt.contiguous()
+        if Xt.shape[1] != self.D:
+            raise ValueError(f"data has {Xt.shape[1]} features, inducing points have {self.D}")
+        return Xt
+
+    def _upload_y(self, y_treated):
+        torch = _torch()
+        dev = self._dev()
+        if isinstance(self.likelihood, LogisticSoftMaxLikelihood):
+            return torch.as_tensor(class_indices(y_treated), dtype=torch.int32, device=dev)
+        return torch.as_tensor(y_treated, dtype=self.tdtype, device=dev)
+
+    # ---- state export / import ----------------------------------------------------------------------------
+    def get_state(self, latent: int = 0):
+        """(μ, Σ, η₁, η₂) of one latent as numpy arrays (VarPosterior, posterior.jl:21-27)."""
+        torch = _torch()
+        dev = self._dev()
+        m = self.m
+        mu = torch.empty(m, dtype=self.tdtype, device=dev)
+        e1 = torch.empty(m, dtype=self.tdtype, device=dev)
+        Sig = torch.empty(m, m, dtype=self.tdtype, device=dev)
+        e2 = torch.empty(m, m, dtype=self.tdtype, device=dev)
+        self._chk(capi.lib().agp_svgp_get_state(self._h, latent, C.c_void_p(mu.data_ptr()), C.c_void_p(Sig.data_ptr()),
+                                                C.c_void_p(e1.data_ptr()), C.c_void_p(e2.data_ptr())))
+        self._chk(capi.lib().agp_ctx_sync(self._ctx))
+        return mu.cpu().numpy(), Sig.cpu().numpy(), e1.cpu().numpy(), e2.cpu().numpy()
+
+    def set_state(self, latent: int, eta1, eta2):
+        torch = _torch()
+        dev = self._dev()
+        e1 = torch.as_tensor(np.asarray(eta1), dtype=self.tdtype, device=dev).contiguous()
+        e2 = torch.as_tensor(np.asarray(eta2), dtype=self.tdtype, device=dev).contiguous()
+        self._chk(capi.lib().agp_svgp_set_state(self._h, latent, C.c_void_p(e1.data_ptr()), C.c_void_p(e2.data_ptr())))
+        self._chk(capi.lib().agp_svgp_check_status(self._h))
+
+    def get_matrix(self, which: int, latent: int = 0, rows: Optional[int] = None):
+        torch = _torch()
+        dev = self._dev()
+        m = self.m
+        if which in (capi.MAT_L, capi.MAT_KINV):
+            out = torch.empty(m, m, dtype=self.tdtype, device=dev)
+            ld = m
+        elif which in (capi.MAT_KNM, capi.MAT_KAPPA):
+            out = torch.empty(rows, m, dtype=self.tdtype, device=dev)
+            ld = m
+        else:
+            out = torch.empty(rows, dtype=self.tdtype, device=dev)
+            ld = 1
+        self._chk(capi.lib().agp_svgp_get_matrix(self._h, latent, which, C.c_void_p(out.data_ptr()), ld))
+        self._chk(capi.lib().agp_ctx_sync(self._ctx))
+        return out.cpu().numpy()
+
+    def __repr__(self):
+        return f"Sparse Variational Gaussian Process with a {self.likelihood} infered by {self.inference} "
+
+
+# ---- training (src/training/training.jl:13-111) ------------------------------------------------------------------
+def train_(model: SVGP, X, y, iterations: int = 100, *, callback: Optional[Callable] = None, convergence=None,
+           state: Optional[State] = None, obsdim: int = 1, idx_stream: Optional[Sequence] = None):
+    """train!(model, X, y, iterations; callback, state, obsdim).  Runs a FIXED number of iterations like the
+    reference (ϵ / convergence are never read there, training.jl:48,93-94).
+
+    idx_stream: optional pre-generated minibatch indices (one int array per iteration) replacing
+    StatsBase.sample(1:N, B; replace=false) (training.jl:51-53) so runs are reproducible across back-ends.
+    """
+    torch = _torch()
+    L = capi.lib()
+    if not iterations > 0:
+        raise ValueError("Number of iterations should be positive")
+    Xd = model._upload(X, obsdim)
+    yt = treat_labels(y, model.likelihood)
+    N = Xd.shape[0]
+    if len(yt) != N:
+        raise ValueError(f"There is not the same number of samples in X ({N}) and y ({len(yt)})")
+    inf = model.inference
+    if inf.stoch:
+        if not (0 < inf.batchsize <= N):
+            raise ValueError(f"The size of mini-batch {inf.batchsize} is incorrect (negative or bigger than number "
+                             "of samples), please set `batchsize` correctly in the inference object")
+        inf.rho = N / inf.batchsize
+    else:
+        inf.batchsize = N
+        inf.rho = 1.0
+    B = inf.batchsize
+    yd = model._upload_y(yt)
+    h = model._ensure_handle(B)
+    model._data = (Xd, yd, N)
+    dev = model._dev()
+    if state is None:
+        inf.HyperParametersUpdated = True
+    model._chk(L.agp_svgp_refresh_K(h))
+    local_iter = 1
+    while True:
+        if inf.stoch:
+            if idx_stream is not None:
+                idx_np = np.asarray(idx_stream[local_iter - 1], dtype=np.int64)
+                if idx_np.shape != (B,):
+                    raise ValueError("idx_stream entries must have length batchsize")
+            else:
+                idx_np = model.rng.choice(N, B, replace=False).astype(np.int64)
+            idx = torch.as_tensor(idx_np, device=dev)
+            idx_ptr = C.c_void_p(idx.data_ptr())
+            model._keep = [idx]
+        else:
+            idx_ptr = None
+        model._chk(L.agp_svgp_cavi_step(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(yd.data_ptr()),
+                                        idx_ptr, B, inf.rho))
+        model.trained = True
+        model._last_idx = idx_ptr
+        if callback is not None:
+            callback(model, State(model), inf.n_iter)
+        if model.verbose > 2 or (model.verbose > 1 and local_iter % 10 == 0):
+            print(f"iter {local_iter}  ELBO {objective(model, State(model), None):.6f}")
+        local_iter += 1
+        inf.n_iter += 1
+        if local_iter > iterations:
+            break
+    model._chk(L.agp_svgp_check_status(h))
+    return model, State(model)
+
+
+def objective(model: SVGP, state: Optional[State] = None, y=None) -> float:
+    """objective(model, state, y) = ELBO(model, state, y) on the last minibatch (SVGP.jl:90, analyticVI.jl:255-274)."""
+    L = capi.lib()
+    Xd, yd, N = model._data
+    out = C.c_double()
+    idx_ptr = getattr(model, "_last_idx", None)
+    model._chk(L.agp_svgp_elbo(model._h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(yd.data_ptr()), idx_ptr,
+                               model.inference.batchsize, model.inference.rho, 0, C.byref(out)))
+    return out.value
+
+
+def ELBO(model: SVGP, X, y, *, obsdim: int = 1, rho: Optional[float] = None) -> float:
+    """External ELBO(model, X, y) (src/functions/ELBO.jl:28-47): fresh local variables on (X, y), one local update.
+    rho defaults to the reference's behaviour (the ρ left by the last train!, Appendix A Q13); pass rho=1 for the
+    properly scaled full-data ELBO."""
+    L = capi.lib()
+    Xd = model._upload(X, obsdim)
+    yt = treat_labels(y, model.likelihood)
+    yd = model._upload_y(yt)
+    n = Xd.shape[0]
+    h = model._ensure_handle(max(n, model._max_batch))
+    r = model.inference.rho if rho is None else float(rho)
+    out = C.c_double()
+    model._chk(L.agp_svgp_elbo(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(yd.data_ptr()), None, n, r, 1,
+                               C.byref(out)))
+    return out.value
+
+
+# ---- prediction (src/training/predictions.jl) -----------------------------------------------------------------------
+def _predict_f(model: SVGP, X_test, cov: bool, obsdim: int = 1):
+    torch = _torch()
+    L = capi.lib()
+    Xd = model._upload(X_test, obsdim)
+    nt = Xd.shape[0]
+    h = model._ensure_handle(max(model._max_batch, 1))
+    dev = model._dev()
+    mu = torch.empty(model.n_latent, nt, dtype=model.tdtype, device=dev)
+    var = torch.empty(model.n_latent, nt, dtype=model.tdtype, device=dev) if cov else None
+    model._chk(L.agp_svgp_predict_f(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), nt, C.c_void_p(mu.data_ptr()),
+                                    C.c_void_p(var.data_ptr()) if cov else None))
+    model._chk(L.agp_ctx_sync(model._ctx))
+    return mu, var
+
+
+def predict_f(model: SVGP, X_test, state: Optional[State] = None, *, cov: bool = False, diag: bool = True,
+              obsdim: int = 1):
+    """predict_f(model, X_test; cov=false, diag=true)  predictions.jl:141-164.  Full covariances (diag=false) are
+    not on the streaming path."""
+    if cov and not diag:
+        raise NotImplementedError("full predictive covariance (diag=false) is not on the streaming path")
+    mu, var = _predict_f(model, X_test, cov, obsdim)
+    mu_np = mu.cpu().numpy()
+    if model.n_latent > 1:
+        m_out = tuple(mu_np[k] for k in range(model.n_latent))
+        if not cov:
+            return m_out
+        v_np = var.cpu().numpy()
+        return m_out, tuple(v_np[k] for k in range(model.n_latent))
+    if not cov:
+        return mu_np[0]
+    return mu_np[0], var.cpu().numpy()[0]
+
+
+def predict_y(model: SVGP, X_test, state: Optional[State] = None, *, obsdim: int = 1):
+    """predict_y  predictions.jl:178-198: regression mean / Bool (μ_f > 0) / most likely class label."""
+    torch = _torch()
+    L = capi.lib()
+    Xd = model._upload(X_test, obsdim)
+    nt = Xd.shape[0]
+    h = model._ensure_handle(max(model._max_batch, 1))
+    dev = model._dev()
+    lik = model.likelihood
+    if isinstance(lik, (GaussianLikelihood, StudentTLikelihood)):
+        out = torch.empty(nt, dtype=model.tdtype, device=dev)
+    else:
+        out = torch.empty(nt, dtype=torch.int32, device=dev)
+    model._chk(L.agp_svgp_predict_y(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), nt, C.c_void_p(out.data_ptr())))
+    model._chk(L.agp_ctx_sync(model._ctx))
+    o = out.cpu().numpy()
+    if isinstance(lik, LogisticLikelihood):
+        return o.astype(bool)
+    if isinstance(lik, LogisticSoftMaxLikelihood):
+        cm = lik.class_mapping or list(range(1, lik.n_class + 1))
+        return np.array([cm[i] for i in o])
+    return o
+
+
+_GH = None
+
+
+def _gauss_hermite():
+    """pred_nodes, pred_weights = (x*√2, w/√π) of gausshermite(100)   predictions.jl:4."""
+    global _GH
+    if _GH is None:
+        x, w = np.polynomial.hermite.hermgauss(100)
+        _GH = (np.ascontiguousarray(x * math.sqrt(2.0)), np.ascontiguousarray(w / math.sqrt(math.pi)))
+    return _GH
+
+
+def proba_y(model: SVGP, X_test, state: Optional[State] = None, *, obsdim: int = 1):
+    """proba_y  predictions.jl:225-247: (mean, var) for regression, (p, var) for Bernoulli, dict class -> p for
+    multi-class."""
+    torch = _torch()
+    L = capi.lib()
+    Xd = model._upload(X_test, obsdim)
+    nt = Xd.shape[0]
+    h = model._ensure_handle(max(model._max_batch, 1))
+    dev = model._dev()
+    lik = model.likelihood
+    nodes, weights = _gauss_hermite()
+    if isinstance(lik, LogisticSoftMaxLikelihood):
+        o0 = torch.empty(nt, model.n_latent, dtype=model.tdtype, device=dev)
+        o1 = None
+    else:
+        o0 = torch.empty(nt, dtype=model.tdtype, device=dev)
+        o1 = torch.empty(nt, dtype=model.tdtype, device=dev)
+    model._chk(L.agp_svgp_proba_y(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), nt,
+                                  nodes.ctypes.data_as(C.POINTER(C.c_double)),
+                                  weights.ctypes.data_as(C.POINTER(C.c_double)), len(nodes),
+                                  C.c_void_p(o0.data_ptr()), C.c_void_p(o1.data_ptr()) if o1 is not None else None))
+    model._chk(L.agp_ctx_sync(model._ctx))
+    if isinstance(lik, LogisticSoftMaxLikelihood):
+        p = o0.cpu().numpy()
+        cm = lik.class_mapping or list(range(1, lik.n_class + 1))
+        return {cm[model.latent_offset + k]: p[:, k] for k in range(model.n_latent)}
+    return o0.cpu().numpy(), o1.cpu().numpy()

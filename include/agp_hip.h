@@ -1,0 +1,207 @@
+/*
+ * agp_hip.h -- C ABI of libagp_hip.so : MI355X (gfx950) engine for the SVGP + AnalyticVI/AnalyticSVI
+ * hot path of AugmentedGaussianProcesses.jl (reference paths are relative to /root/reference).
+ *
+ * The reference has no FFI; this header is what a `ccall` shim binds (see INTEGRATION.md and
+ * julia/AGPHip.jl).  Every entry point names the reference method(s) it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no exceptions cross the boundary; every call returns agp_status.
+ *   - all data pointers are DEVICE pointers unless the parameter name ends in `_host`.
+ *   - element type T is double (AGP_F64) or float (AGP_F32), fixed per handle / per call.
+ *   - inputs X, Z are POINT-MAJOR: point i occupies X[i*ldx .. i*ldx+D) (Julia `ColVecs` memory order;
+ *     a `RowVecs` N x D column-major matrix is permuted once by the shim at upload).
+ *   - m x m outputs are dense row-major with leading dimension m (all are symmetric or explicitly
+ *     lower-triangular, so Julia column-major readers see the transpose == the same matrix / upper factor).
+ *   - caller owns all data buffers; the library owns the opaque handles and their device workspaces.
+ *   - work is enqueued asynchronously on the ctx stream; calls that return host scalars or a
+ *     data-dependent status (refresh_K, elbo, check_status, ctx_sync) synchronise that stream.
+ */
+#ifndef AGP_HIP_H
+#define AGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t agp_status;
+enum {
+  AGP_OK = 0,
+  AGP_ERR_INVALID = 1,     /* bad argument */
+  AGP_ERR_NOT_POSDEF = 2,  /* Julia PosDefException from cholesky(K + jitt*I)   src/gpblocks/latentgp.jl:206 */
+  AGP_ERR_NEG_KTILDE = 3,  /* error("K~ has negative values")                   src/gpblocks/latentgp.jl:213 */
+  AGP_ERR_BAD_BATCH = 4,   /* batch-size check                                  src/training/training.jl:27-29 */
+  AGP_ERR_UNSUPPORTED = 5, /* implemented(likelihood, inference) == false       src/models/SVGP.jl:48-49 */
+  AGP_ERR_LABELS = 6,      /* treat_labels! ArgumentError                       src/likelihood/classification.jl:36-44 */
+  AGP_ERR_HIP = 7,         /* HIP runtime failure (message in agp_last_error) */
+  AGP_ERR_NOMEM = 8
+};
+
+enum { AGP_F64 = 0, AGP_F32 = 1 };
+
+/* KernelFunctions.jl kernels (call sites src/gpblocks/latentgp.jl:202-212): sigma2 * base(||s .* (x-y)||) */
+enum { AGP_K_SQEXP = 0, AGP_K_MATERN52 = 1, AGP_K_MATERN32 = 2, AGP_K_EXPONENTIAL = 3 };
+
+/* likelihoods with closed-form augmented updates on this path (src/likelihood/{gaussian,logistic,studentt,logisticsoftmax}.jl) */
+enum { AGP_LIK_GAUSSIAN = 0, AGP_LIK_LOGISTIC = 1, AGP_LIK_STUDENTT = 2, AGP_LIK_LOGISTICSOFTMAX = 3 };
+
+/* ELBO variants: Appendix-A Q2 of SURVEY.md (src/likelihood/logistic.jl:82 uses dot(theta, mu)) */
+enum { AGP_ELBO_CORRECTED = 0, AGP_ELBO_REFERENCE = 1 };
+
+/* matrices readable through agp_svgp_get_matrix (for parity tests and the shim's state export) */
+enum {
+  AGP_MAT_L = 0,      /* m x m lower Cholesky factor of K_ZZ + jitter I          (state.kernel_matrices.K) */
+  AGP_MAT_KINV = 1,   /* m x m inv(K)                                             (analyticVI.jl:179) */
+  AGP_MAT_KNM = 2,    /* B x m                                                    (latentgp.jl:210) */
+  AGP_MAT_KAPPA = 3,  /* B x m                                                    (latentgp.jl:211) */
+  AGP_VEC_KTILDE = 4, /* B                                                        (latentgp.jl:212) */
+  AGP_VEC_MEAN_F = 5, /* B   kappa*mu   (value used by the last local update)     (latentgp.jl:179) */
+  AGP_VEC_VAR_F = 6,  /* B                                                        (latentgp.jl:189) */
+  AGP_VEC_THETA = 7,  /* B   local variable theta                                 (likelihood local_updates!) */
+  AGP_VEC_C = 8,      /* B   local variable c */
+  AGP_VEC_GAMMA = 9,  /* B   LogisticSoftMax gamma_k */
+  AGP_VEC_ALPHA = 10  /* B   LogisticSoftMax alpha (shared by all latents) */
+};
+
+typedef struct agp_ctx agp_ctx;
+typedef struct agp_svgp agp_svgp;
+
+typedef struct {
+  int32_t kind;                /* AGP_K_* */
+  int32_t ard;                 /* 0: ScaleTransform(scale)   1: ARDTransform(ard_scales_host[0..D)) */
+  double variance;             /* sigma2 of `sigma2 * k` (1 if none) */
+  double scale;                /* s of ScaleTransform(s) ; with_lengthscale(k, l) == scale 1/l */
+  const double* ard_scales_host; /* host pointer, length D, read at call time (only if ard) */
+} agp_kernel_desc;
+
+typedef struct {
+  int32_t kind;    /* AGP_LIK_* */
+  int32_t n_class; /* LogisticSoftMax: K (= number of latent GPs); else 1 */
+  double p0;       /* Gaussian: sigma2 ; StudentT: nu */
+  double p1;       /* StudentT: sigma */
+} agp_lik_desc;
+
+typedef struct {
+  int32_t dtype;       /* AGP_F64 / AGP_F32  (SVGP(...; T=Float64) src/models/SVGP.jl:43) */
+  int32_t n_latent;    /* latents held by THIS handle (latent-parallel ranks hold a slice) */
+  int32_t latent_offset; /* global index of this handle's first latent (class index for LogisticSoftMax) */
+  int32_t stochastic;  /* 0 AnalyticVI (Descent(1)) ; 1 AnalyticSVI (RobbinsMonro) analyticVI.jl:44-52 */
+  int64_t m;           /* inducing points per latent */
+  int64_t D;           /* input dimension */
+  int64_t max_batch;   /* largest B ever passed to step / elbo */
+  agp_lik_desc lik;
+  double jitter;       /* <= 0 : reference default 1e-4 (f64) / 1e-3 (f32)  src/functions/utils.jl:8-9 */
+  double rm_kappa;     /* RobbinsMonro kappa (0.51)  src/inference/optimisers.jl:6 */
+  double rm_tau;       /* RobbinsMonro tau   (1)     */
+  int32_t elbo_mode;   /* AGP_ELBO_* */
+  int32_t reserved;
+} agp_svgp_desc;
+
+/* ---- context ------------------------------------------------------------------------------------- */
+int32_t agp_version(void);
+/* hip_stream: a hipStream_t shared with the caller (AMDGPU.jl / torch) or NULL for the default stream */
+agp_status agp_ctx_create(int32_t device, void* hip_stream, agp_ctx** out);
+agp_status agp_ctx_destroy(agp_ctx* ctx);
+agp_status agp_ctx_sync(agp_ctx* ctx);
+const char* agp_last_error(agp_ctx* ctx);
+
+/* ---- building blocks (unit parity) ---------------------------------------------------------------- */
+/* kernelmatrix(k, X, Y) / kernelmatrix(k, X) (y == NULL -> symmetric)   src/gpblocks/latentgp.jl:206,210
+ * idx (nullable, int64[n]) gathers rows of X: row i of the result uses X[idx[i]] (the view(X, minibatch) of
+ * src/training/training.jl:54).  out is n x p row-major with leading dimension ldo. */
+agp_status agp_kernelmatrix(agp_ctx* ctx, int32_t dtype, const agp_kernel_desc* k, const void* x, int64_t n,
+                            int64_t ldx, const int64_t* idx, const void* y, int64_t p, int64_t ldy, int64_t D,
+                            void* out, int64_t ldo);
+/* cholesky(A + jitter*I) in place, lower factor (strict upper zeroed).  *info_host = 0 ok, k>0: leading minor
+ * k not positive definite (LAPACK potrf convention == Julia PosDefException.info).  src/gpblocks/latentgp.jl:206 */
+agp_status agp_potrf_jitter(agp_ctx* ctx, int32_t dtype, void* a, int64_t lda, int64_t n, double jitter,
+                            int32_t* info_host);
+/* inv(A) for SPD A via Cholesky (inv(K::Cholesky) analyticVI.jl:179 ; -inv(eta2)/2 inference.jl:26) */
+agp_status agp_spd_inverse(agp_ctx* ctx, int32_t dtype, const void* a, int64_t lda, int64_t n, void* ainv,
+                           int64_t ldi, double* logdet_host, int32_t* info_host);
+/* X = B / cholesky(A)  (Knm / K, two triangular solves in the reference, latentgp.jl:211); b is r x n */
+agp_status agp_solve_right_spd(agp_ctx* ctx, int32_t dtype, const void* a, int64_t lda, int64_t n, const void* b,
+                               int64_t ldb, int64_t r, void* x, int64_t ldx, int32_t* info_host);
+/* MFMA microbenchmark: TFLOP/s of back-to-back v_mfma_{f64,f32}_16x16x4 (roofline ceiling measurement) */
+agp_status agp_mfma_peak(agp_ctx* ctx, int32_t dtype, double* tflops_host);
+
+/* ---- SVGP model handle ---------------------------------------------------------------------------- */
+/* SVGP(kernel, likelihood, AnalyticVI()/AnalyticSVI(B), Z)  src/models/SVGP.jl:33-80 ;
+ * posterior init mu=0, Sigma=I, eta1=0, eta2=-I/2            src/gpblocks/posterior.jl:29-37 */
+agp_status agp_svgp_create(agp_ctx* ctx, const agp_svgp_desc* desc, agp_svgp** out);
+agp_status agp_svgp_destroy(agp_svgp* h);
+/* per-latent kernel and inducing points (each latent owns a copy, latentgp.jl:63-68); marks K stale */
+agp_status agp_svgp_set_kernel(agp_svgp* h, int32_t latent, const agp_kernel_desc* k);
+agp_status agp_svgp_set_Z(agp_svgp* h, int32_t latent, const void* z, int64_t ldz);
+agp_status agp_svgp_get_Z(agp_svgp* h, int32_t latent, void* z, int64_t ldz);
+/* prior mean values at Z (NULL == ZeroMean, src/mean/zeromean.jl:17) */
+agp_status agp_svgp_set_prior_mean(agp_svgp* h, int32_t latent, const void* mu0);
+/* compute_K for every latent with a stale K: K = k(Z,Z)+jitt I = L L', inv(K)   latentgp.jl:205-207.
+ * Synchronises; AGP_ERR_NOT_POSDEF if any factorisation failed. */
+agp_status agp_svgp_refresh_K(agp_svgp* h);
+/* RobbinsMonro counters (state_eta1/state_eta2, src/training/states.jl:63-70); n starts at 1 */
+agp_status agp_svgp_set_opt_state(agp_svgp* h, int64_t n);
+agp_status agp_svgp_get_opt_state(agp_svgp* h, int64_t* n_host);
+
+/* update_parameters!(model::SVGP, state, x, y)  src/training/training.jl:140-144 : one CAVI step on the
+ * minibatch X[idx[0..B)] for all latents of this handle.
+ *   y   : T[N] (+-1 labels / real targets) ; LogisticSoftMax: int32[N] 0-based class index
+ *   idx : int64[B] device, or NULL for rows 0..B-1 (full batch)
+ *   rho : N / B   (training.jl:30)
+ * Asynchronous; data-dependent failures (K~ <= 0, non-SPD -2*eta2) are latched and reported by
+ * agp_svgp_check_status / the next synchronising call. */
+agp_status agp_svgp_cavi_step(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx,
+                              int64_t B, double rho);
+/* The same step in phases, for multi-GPU runs:
+ *   step_local  : compute_kappa + mean_f/var_f (+ c_k for LogisticSoftMax)   latentgp.jl:209-215,171-189
+ *   lsm_*       : LogisticSoftMax cross-latent fixed point, logisticsoftmax.jl:65-72:
+ *                 lsm_gamma writes gamma_k for local latents and their sum into the `gsum` buffer (T[B]);
+ *                 the caller all-reduces gsum across latent-parallel ranks; lsm_alpha sets alpha = 1 + gsum.
+ *                 (called twice, as the reference loops twice)
+ *   step_stats  : theta, grad_E_mu, grad_E_Sigma and the batch statistics
+ *                 stats = [ kappa'(rho g1) (mp) | rho kappa' diag(g2) kappa (mp x mp) ] per latent
+ *                 -- the buffer a batch-parallel run all-reduces (analyticVI.jl:168,179)
+ *   step_global : natural-gradient step + (mu, Sigma) refresh      analyticVI.jl:229-246, inference.jl:25-28 */
+agp_status agp_svgp_step_local(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx,
+                               int64_t B, double rho);
+agp_status agp_svgp_lsm_gamma(agp_svgp* h);
+agp_status agp_svgp_lsm_alpha(agp_svgp* h);
+agp_status agp_svgp_lsm_gsum_ptr(agp_svgp* h, void** ptr, int64_t* count);
+agp_status agp_svgp_step_stats(agp_svgp* h);
+agp_status agp_svgp_stats_ptr(agp_svgp* h, void** ptr, int64_t* count);
+agp_status agp_svgp_step_global(agp_svgp* h);
+/* returns and clears the latched asynchronous failure (synchronises) */
+agp_status agp_svgp_check_status(agp_svgp* h);
+
+/* ELBO(model, state, y)  src/inference/analyticVI.jl:255-274
+ *   fresh_local = 0 : on the kernel matrices and local variables left by the last cavi_step (x, y, idx, B
+ *                     must be that step's) -- `objective(model, state, y)` of training.jl:76
+ *   fresh_local = 1 : external ELBO(model, X, y) of src/functions/ELBO.jl:32-47 : recompute kappa on this
+ *                     batch, re-initialise local variables, one local update, then the ELBO; rho explicit. */
+agp_status agp_svgp_elbo(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B,
+                         double rho, int32_t fresh_local, double* elbo_host);
+
+/* state export / import : VarPosterior(mu, Sigma, eta1, eta2)  src/gpblocks/posterior.jl:21-27 ; any pointer
+ * may be NULL.  set_state installs (eta1, eta2) and re-derives (mu, Sigma) (inference.jl:25-28). */
+agp_status agp_svgp_get_state(agp_svgp* h, int32_t latent, void* mu, void* sigma, void* eta1, void* eta2);
+agp_status agp_svgp_set_state(agp_svgp* h, int32_t latent, const void* eta1, const void* eta2);
+agp_status agp_svgp_get_matrix(agp_svgp* h, int32_t latent, int32_t which, void* out, int64_t ldo);
+
+/* _predict_f (sparse)  src/training/predictions.jl:25-50 : streams over n_t test points without materialising
+ * K_*m.  mu_out / var_out : T[n_latent][n_t] (var_out NULL -> cov=false). */
+agp_status agp_svgp_predict_f(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* mu_out, void* var_out);
+/* predict_y  predictions.jl:178-198 : regression -> T[n_t] mean ; logistic -> int32[n_t] (mu_f > 0) ;
+ * LogisticSoftMax -> int32[n_t] argmax_k mu_f,k (0-based LOCAL latent index + latent_offset) */
+agp_status agp_svgp_predict_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* y_out);
+/* proba_y  predictions.jl:225-247 + compute_proba : Gaussian / StudentT -> (mean, var) ; logistic -> (p, var) by
+ * Gauss-Hermite with the caller's nodes/weights (predictions.jl:4 : x*sqrt2, w/sqrt(pi), 100 nodes) ;
+ * LogisticSoftMax -> out0 = T[n_t][K] normalised logistic(mu_f) (multiclass.jl:96-117), out1 unused. */
+agp_status agp_svgp_proba_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, const double* gh_nodes_host,
+                            const double* gh_weights_host, int32_t n_nodes, void* out0, void* out1);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGP_HIP_H */

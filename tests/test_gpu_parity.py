@@ -1,0 +1,275 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the NumPy oracle on identical seeded inputs.
+
+Tolerances (fp64): single operations <= 1e-11 relative; posterior / predictive quantities after several CAVI steps
+<= 1e-8 relative (jitter 1e-4 bounds cond(K)).  fp32: 2e-3 relative on mu_f (Q6).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def env(built):
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import agp_amd as AGP
+    from agp_amd import capi
+    from oracle import agp_ref as R
+
+    L = capi.lib()
+    ctx = C.c_void_p()
+    st = L.agp_ctx_create(0, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ctx))
+    assert st == 0
+    yield dict(torch=torch, AGP=AGP, capi=capi, R=R, L=L, ctx=ctx)
+    L.agp_ctx_destroy(ctx)
+
+
+def _kdesc(capi, kind, variance, scale, ard=None):
+    d = capi.KernelDesc()
+    d.kind, d.variance = kind, variance
+    keep = None
+    if ard is not None:
+        keep = (C.c_double * len(ard))(*ard)
+        d.ard, d.scale, d.ard_scales_host = 1, 1.0, C.cast(keep, C.POINTER(C.c_double))
+    else:
+        d.ard, d.scale, d.ard_scales_host = 0, scale, None
+    return d, keep
+
+
+KINDS = [("sqexponential", 0), ("matern52", 1), ("matern32", 2), ("exponential", 3)]
+
+
+@pytest.mark.parametrize("kname,kid", KINDS)
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_kernelmatrix(env, kname, kid, dtype):
+    torch, capi, R, L, ctx = env["torch"], env["capi"], env["R"], env["L"], env["ctx"]
+    rng = np.random.default_rng(1)
+    n, p, D = 150, 77, 11  # ragged on purpose: nothing is a multiple of 64 / 32
+    X, Y = rng.random((n, D)), rng.random((p, D))
+    ard = rng.random(D) + 0.5
+    td = torch.float64 if dtype == "f64" else torch.float32
+    tol = 1e-12 if dtype == "f64" else 2e-5
+    for scale, a in [(1.7, None), (1.0, ard)]:
+        ref = R.Kernel(kname, a if a is not None else scale, 1.3).matrix(X, Y)
+        kd, keep = _kdesc(capi, kid, 1.3, scale, a)
+        xd = torch.tensor(X, dtype=td, device="cuda")
+        yd = torch.tensor(Y, dtype=td, device="cuda")
+        out = torch.empty(n, p, dtype=td, device="cuda")
+        st = L.agp_kernelmatrix(ctx, 0 if dtype == "f64" else 1, C.byref(kd), xd.data_ptr(), n, D, None,
+                                yd.data_ptr(), p, D, D, out.data_ptr(), p)
+        assert st == 0, L.agp_last_error(ctx)
+        assert _rel(out.cpu().numpy(), ref) < tol
+    # gathered rows + symmetric form
+    idx = rng.choice(n, 40, replace=False)
+    kd, keep = _kdesc(capi, kid, 1.0, 2.0)
+    xd = torch.tensor(X, dtype=td, device="cuda")
+    idd = torch.tensor(idx, dtype=torch.int64, device="cuda")
+    out = torch.empty(40, 40, dtype=td, device="cuda")
+    st = L.agp_kernelmatrix(ctx, 0 if dtype == "f64" else 1, C.byref(kd), xd.data_ptr(), 40, D, idd.data_ptr(), None,
+                            0, 0, D, out.data_ptr(), 40)
+    assert st == 0
+    # symmetric call with idx: rows gathered, columns are x[0:40] -> compare accordingly
+    ref = R.Kernel(kname, 2.0, 1.0).matrix(X[idx], X[:40])
+    assert _rel(out.cpu().numpy(), ref) < tol
+
+
+@pytest.mark.parametrize("n", [5, 64, 100, 257, 1024])
+def test_potrf_and_inverse(env, n):
+    torch, L, ctx = env["torch"], env["L"], env["ctx"]
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n, n + 3))
+    A = G @ G.T / n + 0.5 * np.eye(n)
+    ad = torch.tensor(A, dtype=torch.float64, device="cuda")
+    info = C.c_int32(-1)
+    st = L.agp_potrf_jitter(ctx, 0, ad.data_ptr(), n, n, 1e-4, C.byref(info))
+    assert st == 0 and info.value == 0, L.agp_last_error(ctx)
+    Lref = np.linalg.cholesky(A + 1e-4 * np.eye(n))
+    assert _rel(ad.cpu().numpy(), Lref) < 1e-11
+    a2 = torch.tensor(A, dtype=torch.float64, device="cuda")
+    inv = torch.empty(n, n, dtype=torch.float64, device="cuda")
+    ld = C.c_double()
+    st = L.agp_spd_inverse(ctx, 0, a2.data_ptr(), n, n, inv.data_ptr(), n, C.byref(ld), C.byref(info))
+    assert st == 0 and info.value == 0
+    assert _rel(inv.cpu().numpy(), np.linalg.inv(A)) < 1e-10
+    assert abs(ld.value - np.linalg.slogdet(A)[1]) < 1e-9 * max(1.0, abs(ld.value))
+    # X = B / A
+    r = 37
+    Bm = rng.standard_normal((r, n))
+    bd = torch.tensor(Bm, dtype=torch.float64, device="cuda")
+    xd = torch.empty(r, n, dtype=torch.float64, device="cuda")
+    st = L.agp_solve_right_spd(ctx, 0, a2.data_ptr(), n, n, bd.data_ptr(), n, r, xd.data_ptr(), n, C.byref(info))
+    assert st == 0
+    assert _rel(xd.cpu().numpy(), np.linalg.solve(A, Bm.T).T) < 1e-10
+
+
+def test_potrf_not_posdef(env):
+    torch, L, ctx, capi = env["torch"], env["L"], env["ctx"], env["capi"]
+    n = 130
+    A = np.eye(n)
+    A[100, 100] = -1.0  # leading minor 101 fails, like LAPACK info = 101
+    ad = torch.tensor(A, dtype=torch.float64, device="cuda")
+    info = C.c_int32(0)
+    st = L.agp_potrf_jitter(ctx, 0, ad.data_ptr(), n, n, 0.0, C.byref(info))
+    assert st == 2 and info.value == 101  # AGP_ERR_NOT_POSDEF
+
+
+def _toy(rng, N=300, D=3, m=20):
+    X = rng.random((N, D))
+    f = np.sin(3 * X[:, 0]) + X[:, 1] ** 2 - 0.7
+    Z = X[rng.permutation(N)[:m]].copy()
+    return X, f, Z
+
+
+def _models(env, likname, rng, stochastic, B=64, T=np.float64, m=20, N=300):
+    AGP, R = env["AGP"], env["R"]
+    X, f, Z = _toy(rng, N=N, m=m)
+    if likname == "gaussian":
+        y = f + 0.1 * rng.standard_normal(len(f))
+        la, lr = AGP.GaussianLikelihood(0.01), R.GaussianLikelihood(0.01)
+    elif likname == "logistic":
+        y = (f + 0.2 * rng.standard_normal(len(f)) > 0).astype(int)
+        la, lr = AGP.LogisticLikelihood(), R.LogisticLikelihood()
+    elif likname == "studentt":
+        y = f + 0.1 * rng.standard_t(3, len(f))
+        la, lr = AGP.StudentTLikelihood(3.0), R.StudentTLikelihood(3.0)
+    else:
+        y = 1 + np.digitize(f, np.quantile(f, [0.33, 0.66]))
+        la, lr = AGP.LogisticSoftMaxLikelihood(3), R.LogisticSoftMaxLikelihood(3)
+    ka = 1.5 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0))
+    kr = R.Kernel("sqexponential", 2.0, 1.5)
+    inf = AGP.AnalyticSVI(B) if stochastic else AGP.AnalyticVI()
+    ma = AGP.SVGP(ka, la, inf, Z, optimiser=False, T=T)
+    mr = R.SVGP(kr, lr, Z, stochastic=stochastic, batchsize=B, jitter=1e-4 if T == np.float64 else 1e-3)
+    return X, y, ma, mr
+
+
+@pytest.mark.parametrize("likname", ["gaussian", "logistic", "studentt", "logisticsoftmax"])
+@pytest.mark.parametrize("stochastic", [False, True])
+def test_cavi_trajectory_fp64(env, likname, stochastic):
+    AGP, R, capi = env["AGP"], env["R"], env["capi"]
+    rng = np.random.default_rng(7)
+    B, iters = 64, 6
+    X, y, ma, mr = _models(env, likname, rng, stochastic, B)
+    idx = [rng.choice(len(X), B, replace=False) for _ in range(iters)]
+    elbos_a, elbos_r = [], []
+    AGP.train_(ma, X, y, iters, idx_stream=idx, callback=lambda m, s, i: elbos_a.append(AGP.objective(m, s)))
+    yt = R.treat_labels(y, mr.likelihood)
+    mr.train(X, yt, iters, idx_stream=idx, labels_treated=True, callback=lambda M, it, xb, yb: elbos_r.append(M.elbo(yb)))
+    for k in range(ma.n_latent):
+        mu, Sig, e1, e2 = ma.get_state(k)
+        g = mr.latents[k]
+        assert _rel(e1, g.eta1) < 1e-9
+        assert _rel(e2, g.eta2) < 1e-9
+        assert _rel(mu, g.mu) < 1e-8
+        assert _rel(Sig, g.Sigma) < 1e-8
+    assert np.allclose(elbos_a, elbos_r, rtol=1e-8, atol=1e-7), (elbos_a, elbos_r)
+    # last-step intermediates
+    nb = B if stochastic else len(X)
+    g = mr.latents[0]
+    assert _rel(ma.get_matrix(capi.MAT_KAPPA, 0, nb), g.kappa) < 1e-9
+    assert _rel(ma.get_matrix(capi.VEC_KTILDE, 0, nb), g.Kt) < 1e-8
+    # predictions
+    Xt = rng.random((131, X.shape[1]))
+    if ma.n_latent == 1:
+        mf, vf = AGP.predict_f(ma, Xt, cov=True)
+        mfr, vfr = mr.predict_f(Xt, cov=True)
+        assert _rel(mf, mfr[0]) < 1e-8 and _rel(vf, vfr[0]) < 1e-7
+        pa = AGP.proba_y(ma, Xt)
+        pr = mr.proba_y(Xt)
+        assert _rel(pa[0], pr[0]) < 1e-8 and _rel(pa[1], pr[1]) < 1e-6
+        assert np.array_equal(np.asarray(AGP.predict_y(ma, Xt)), np.asarray(mr.predict_y(Xt))) or likname in (
+            "gaussian", "studentt")
+    else:
+        mf = AGP.predict_f(ma, Xt)
+        mfr = mr.predict_f(Xt)
+        for k in range(ma.n_latent):
+            assert _rel(mf[k], mfr[k]) < 1e-8
+        assert np.array_equal(AGP.predict_y(ma, Xt), mr.predict_y(Xt))
+        pa, pr = AGP.proba_y(ma, Xt), mr.proba_y(Xt)
+        for k, lab in enumerate([1, 2, 3]):
+            assert _rel(pa[lab], pr[:, k]) < 1e-8
+    # external ELBO with fresh local variables
+    ea = AGP.ELBO(ma, X, y, rho=1.0)
+    er = mr.elbo_fresh(X, yt, 1.0)
+    assert abs(ea - er) < 1e-7 * max(1.0, abs(er))
+
+
+def test_titsias_optimum_gaussian(env):
+    """KAT-1: Gaussian likelihood, full batch: after ONE step eta1 = kappa' y / s2, eta2 = -(kappa'kappa/s2 + Kinv)/2
+    and a second step is a fixed point."""
+    AGP, R, capi = env["AGP"], env["R"], env["capi"]
+    rng = np.random.default_rng(3)
+    X, y, ma, mr = _models(env, "gaussian", rng, False)
+    AGP.train_(ma, X, y, 1)
+    mu1, S1, e1, e2 = ma.get_state(0)
+    kern = R.Kernel("sqexponential", 2.0, 1.5)
+    K, Lk = R.compute_K(kern, ma.Zs[0], 1e-4)
+    _, kappa, _ = R.compute_kappa(kern, X, ma.Zs[0], Lk, 1e-4)
+    Kinv = np.linalg.inv(K)
+    assert _rel(e1, kappa.T @ y / 0.01) < 1e-9
+    assert _rel(e2, -0.5 * (kappa.T @ kappa / 0.01 + Kinv)) < 1e-9
+    AGP.train_(ma, X, y, 1, state=True)
+    mu2, S2, _, _ = ma.get_state(0)
+    assert _rel(mu2, mu1) < 1e-9 and _rel(S2, S1) < 1e-9
+
+
+def test_fp32_mode(env):
+    AGP, R = env["AGP"], env["R"]
+    rng = np.random.default_rng(11)
+    B, iters = 64, 5
+    X, y, ma, mr = _models(env, "studentt", rng, True, B, T=np.float32)
+    idx = [rng.choice(len(X), B, replace=False) for _ in range(iters)]
+    AGP.train_(ma, X, y, iters, idx_stream=idx)
+    mr.train(X, y, iters, idx_stream=idx)
+    Xt = rng.random((50, X.shape[1]))
+    mf = AGP.predict_f(ma, Xt)
+    assert _rel(mf, mr.predict_f(Xt)[0]) < 2e-3
+
+
+def test_error_mapping(env):
+    AGP, capi = env["AGP"], env["capi"]
+    rng = np.random.default_rng(0)
+    X, f, Z = _toy(rng)
+    # duplicate inducing points with zero jitter-resistance: K is singular beyond jitter? -> still SPD with jitter;
+    # force NOT_POSDEF through a state whose -2*eta2 is indefinite
+    m = AGP.SVGP(AGP.SqExponentialKernel(), AGP.GaussianLikelihood(0.1), AGP.AnalyticVI(), Z, optimiser=False)
+    AGP.train_(m, X, f, 1)
+    mu, S, e1, e2 = m.get_state(0)
+    bad = e2.copy()
+    bad[0, 0] = +1.0
+    with pytest.raises(capi.AGPError) as ei:
+        m.set_state(0, e1, bad)
+    assert ei.value.status == 2
+    with pytest.raises(ValueError):
+        AGP.train_(AGP.SVGP(AGP.SqExponentialKernel(), AGP.GaussianLikelihood(0.1), AGP.AnalyticSVI(10 ** 6), Z,
+                            optimiser=False), X, f, 1)
+
+
+def test_large_m1024_step_matches_oracle(env):
+    """One C2-shaped step (m = 1024, B = 1024, D = 32, logistic) against the oracle."""
+    AGP, R = env["AGP"], env["R"]
+    rng = np.random.default_rng(5)
+    N, D, m, B = 4096, 32, 1024, 1024
+    X = rng.random((N, D))
+    w = rng.standard_normal(D)
+    y = np.sign(np.sin(X @ w) + 0.1 * rng.standard_normal(N))
+    Z = X[rng.permutation(N)[:m]].copy()
+    ell = np.sqrt(D) / 4
+    idx = [rng.choice(N, B, replace=False) for _ in range(3)]
+    ma = AGP.SVGP(AGP.with_lengthscale(AGP.SqExponentialKernel(), ell), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z,
+                  optimiser=False)
+    AGP.train_(ma, X, y, 3, idx_stream=idx)
+    mr = R.SVGP(R.Kernel("sqexponential", 1 / ell, 1.0), R.LogisticLikelihood(), Z, stochastic=True, batchsize=B)
+    mr.train(X, y, 3, idx_stream=idx)
+    mu, Sig, e1, e2 = ma.get_state(0)
+    g = mr.latents[0]
+    assert _rel(e2, g.eta2) < 1e-9 and _rel(mu, g.mu) < 1e-8 and _rel(np.diag(Sig), np.diag(g.Sigma)) < 1e-8

@@ -121,6 +121,10 @@ def lib():
                 f"{LIB_PATH} not found: the HIP extension is not built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
             )
+        # torch (device memory / streams / RCCL plumbing) bundles its own libamdhip64: import it FIRST so that this
+        # library binds to the same HIP runtime instance instead of loading a second one from /opt/rocm.
+        import torch  # noqa: F401
+
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol

@@ -63,31 +63,21 @@ static agp_status dmalloc(agp_ctx* c, T** p, int64_t n) {
 }
 
 // ---- linear-algebra drivers on padded matrices ---------------------------------------------------------------
-// Cholesky in place (lower) of the n x n (n = nt*64) matrix A; writes the inverses of the diagonal blocks into X.
+// Cholesky (lower, in place; diagonal factors in Dg) of the n x n (n = nt*64) matrix A, optionally fused with
+// X = L^-1 (do_x) and with `ne` extension row blocks E <- E L^-T (augmented Cholesky).  nt (+1 if do_x) launches.
 template <typename T>
-static agp_status potrf_padded(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int64_t ldx, int32_t* info_dev,
-                               int64_t nvalid) {
+static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int64_t ldx, T* Dg, T* E, int64_t lde,
+                              int64_t ne, int do_x, int32_t* info_dev, int64_t nvalid) {
   const int64_t nt = n / TILE;
-  for (int64_t k = 0; k < nt; ++k) {
-    hipLaunchKernelGGL((k_potrf_panel<T>), dim3((unsigned)(nt - k)), dim3(NTHREADS), 0, c->stream, A, ld, k, X, ldx,
-                       info_dev, nvalid);
+  for (int64_t k = 0; k <= nt; ++k) {
+    const int64_t nP = (k < nt) ? (nt - k + ne) : 0;
     const int64_t nr = nt - k - 1;
-    if (nr > 0)
-      hipLaunchKernelGGL((k_potrf_update<T>), dim3((unsigned)(nr * (nr + 1) / 2)), dim3(NTHREADS), 0, c->stream, A, ld,
-                         k);
-  }
-  LAUNCHCHK(c);
-  return AGP_OK;
-}
-
-// X = L^-1 (diagonal blocks already in X); Tw is an n x n scratch
-template <typename T>
-static agp_status trtri_padded(agp_ctx* c, const T* L, int64_t ld, int64_t n, T* X, int64_t ldx, T* Tw, int64_t ldt) {
-  for (int64_t h = TILE; h < n; h *= 2) {
-    const int64_t pairs = (n + 2 * h - 1) / (2 * h);
-    dim3 g((unsigned)(h / TILE), (unsigned)(h / TILE), (unsigned)pairs);
-    hipLaunchKernelGGL((k_trtri_step<T>), g, dim3(NTHREADS), 0, c->stream, L, ld, X, ldx, Tw, ldt, n, h, 0);
-    hipLaunchKernelGGL((k_trtri_step<T>), g, dim3(NTHREADS), 0, c->stream, L, ld, X, ldx, Tw, ldt, n, h, 1);
+    const int64_t nU = (k >= 1 && k < nt && nr > 0) ? nr * (nr + 1) / 2 + ne * nr : 0;
+    const int64_t nX = (do_x && k >= 2) ? (k - 1) : 0;
+    const int64_t grid = nP + nU + nX;
+    if (grid == 0) continue;
+    hipLaunchKernelGGL((k_potrf_trtri_step<T>), dim3((unsigned)grid), dim3(NTHREADS), 0, c->stream, A, ld, X, ldx, Dg, E,
+                       lde, ne, do_x, k, nt, info_dev, nvalid);
   }
   LAUNCHCHK(c);
   return AGP_OK;
@@ -176,9 +166,15 @@ struct Svgp : SvgpBase {
     T* mu = nullptr;
     T* Knm = nullptr;
     T* kappa = nullptr;
+    T* Wbuf = nullptr;    // (Bp + 64) x mp : [kappa ; eta1'] -> [W ; v'] by the augmented Cholesky
+    T* DgK = nullptr;     // diagonal 64x64 factors of chol(K)      (mp x 64)
+    T* DgA = nullptr;     // diagonal 64x64 factors of chol(-2 eta2)
     T* Apred = nullptr;   // K^-1 - K^-1 Sigma K^-1
     T* apred = nullptr;   // K^-1 mu
     bool K_stale = true, post_valid = false, pred_valid = false, predvar_valid = false, kappa_valid = false;
+    // La holds: 0 = -2*eta2 (unfactored), 1 = its Cholesky factor ; xa_valid: Xa = La^-1 is current
+    int la_state = 0;
+    bool xa_valid = false;
     double half_logdetK = 0.0;
   };
   std::vector<Latent> lat;
@@ -263,6 +259,9 @@ struct Svgp : SvgpBase {
       AGPCHK(dmalloc(ctx, &g.mu, mp));
       AGPCHK(dmalloc(ctx, &g.Knm, Bp * mp));
       AGPCHK(dmalloc(ctx, &g.kappa, Bp * mp));
+      AGPCHK(dmalloc(ctx, &g.Wbuf, (Bp + TILE) * mp));
+      AGPCHK(dmalloc(ctx, &g.DgK, mp * TILE));
+      AGPCHK(dmalloc(ctx, &g.DgA, mp * TILE));
       AGPCHK(upload_scales(g));
       AGPCHK(reset_posterior(g));
     }
@@ -303,7 +302,7 @@ struct Svgp : SvgpBase {
   ~Svgp() override {
     for (auto& g : lat) {
       T* ps[] = {g.scales, g.Z, g.L, g.Xk, g.Kinv, g.mu0, g.kinv_mu0, g.eta1, g.eta2, g.La, g.Xa, g.v,
-                 g.Sigma, g.mu, g.Knm, g.kappa, g.Apred, g.apred};
+                 g.Sigma, g.mu, g.Knm, g.kappa, g.Apred, g.apred, g.Wbuf, g.DgK, g.DgA};
       for (T* p : ps)
         if (p) (void)hipFree(p);
     }
@@ -335,6 +334,8 @@ struct Svgp : SvgpBase {
     LAUNCHCHK(ctx);
     g.post_valid = false;
     g.pred_valid = g.predvar_valid = false;
+    g.la_state = 0;
+    g.xa_valid = false;
     return AGP_OK;
   }
 
@@ -399,10 +400,9 @@ struct Svgp : SvgpBase {
                          (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.L, mp, mp, mp, 1,
                          (T)jitter, (const T*)nullptr, (T*)nullptr, (int64_t)0);
       LAUNCHCHK(ctx);
-      AGPCHK(potrf_padded<T>(ctx, g.L, mp, mp, g.Xk, mp, info_dev, m));
-      AGPCHK(trtri_padded<T>(ctx, g.L, mp, mp, g.Xk, mp, Tw, mp));
+      AGPCHK(potrf_fused<T>(ctx, g.L, mp, mp, g.Xk, mp, g.DgK, (T*)nullptr, 0, 0, 1, info_dev, m));
       AGPCHK(xtx_padded<T>(ctx, g.Xk, mp, mp, g.Kinv, mp));
-      hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.L, mp, m, scal_dev);
+      hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.DgK, m, scal_dev);
       LAUNCHCHK(ctx);
       double hl = 0;
       HIPCHK(ctx, hipMemcpyAsync(&hl, scal_dev, sizeof(double), hipMemcpyDeviceToHost, st()));
@@ -458,11 +458,15 @@ struct Svgp : SvgpBase {
                            (const T*)nullptr, (T*)nullptr, (int64_t)0);
         LAUNCHCHK(ctx);
         AGPCHK((gemm_nt<T, EPI_KAPPA>(ctx, g.Knm, mp, g.Kinv, mp, Bq, mp, mp, 0, g.kappa, mp, g.Knm, mp, nullptr, pk,
-                                      nullptr, ldp)));
+                                      g.Wbuf, ldp)));
         g.kappa_valid = !desc.stochastic && !fresh;
+      } else {
+        HIPCHK(ctx, hipMemcpyAsync(g.Wbuf, g.kappa, sizeof(T) * Bq * mp, hipMemcpyDeviceToDevice, st()));
       }
-      AGPCHK((gemm_nt<T, EPI_W>(ctx, g.kappa, mp, g.Xa, mp, Bq, mp, mp, 1, nullptr, 0, nullptr, 0, g.v, pw0, pw1, ldp)));
-      hipLaunchKernelGGL((k_local_update<T>), grid1(B), dim3(256), 0, st(), B, ns, (const T*)pk, (const T*)pw0,
+      AGPCHK(aug_factor(g, Bq, 0));
+      hipLaunchKernelGGL((k_w_rowstats<T>), grid1(B * 64), dim3(256), 0, st(), (const T*)g.Wbuf, mp, B, mp,
+                         (const T*)(g.Wbuf + Bq * mp), pw0, pw1);
+      hipLaunchKernelGGL((k_local_update<T>), grid1(B), dim3(256), 0, st(), B, ns, 1, (const T*)pk, (const T*)pw0,
                          (const T*)pw1, ldp, (T)g.k.variance, (T)jitter, (T)rho, lp, (const T*)y, idx, Kt + l * Bp,
                          muf + l * Bp, varf + l * Bp, cbuf + l * Bp, theta + l * Bp, rbuf + l * Bp, wbuf + l * Bp,
                          flags_dev, (int)keep);
@@ -546,15 +550,31 @@ struct Svgp : SvgpBase {
     return AGP_OK;
   }
 
-  // Sigma-side refresh after eta changed: La = chol(-2 eta2), Xa = La^-1, v = Xa eta1   (inference.jl:25-28)
+  // Augmented Cholesky of -2*eta2 with the extension rows [kappa (Bq rows, already in Wbuf) ; eta1'] :
+  //   Wbuf <- [kappa L^-T ; (L^-1 eta1)']   i.e. W and v of mean_f = W v, var_f = rowsum(W^2) + K~.
+  // with_x additionally forms Xa = L^-1 (needed only for Sigma / mu export, ELBO and prediction).
+  agp_status aug_factor(Latent& g, int64_t Bq, int with_x) {
+    if (g.la_state != 0) {  // La holds a factor: rebuild -2*eta2
+      hipLaunchKernelGGL((k_copy2d<T>), grid2(mp, mp), blk2, 0, st(), (const T*)g.eta2, mp, mp, mp, g.La, mp, mp, mp,
+                         T(1), T(-2));
+      LAUNCHCHK(ctx);
+    }
+    T* ext = g.Wbuf + Bq * mp;
+    HIPCHK(ctx, hipMemsetAsync(ext, 0, sizeof(T) * TILE * mp, st()));
+    HIPCHK(ctx, hipMemcpyAsync(ext, g.eta1, sizeof(T) * mp, hipMemcpyDeviceToDevice, st()));
+    AGPCHK(potrf_fused<T>(ctx, g.La, mp, mp, g.Xa, mp, g.DgA, g.Wbuf, mp, Bq / TILE + 1, with_x, info_dev, m));
+    g.la_state = 1;
+    g.xa_valid = with_x != 0;
+    return AGP_OK;
+  }
+
+  // after eta changed outside a step (set_state): La = -2*eta2 is (re)built lazily; validate it is SPD now
   agp_status refactor(Latent& g) {
-    AGPCHK(potrf_padded<T>(ctx, g.La, mp, mp, g.Xa, mp, info_dev, m));
-    AGPCHK(trtri_padded<T>(ctx, g.La, mp, mp, g.Xa, mp, Tw, mp));
-    hipLaunchKernelGGL((k_trmv_lower<T>), grid1(mp * 64), dim3(256), 0, st(), (const T*)g.Xa, mp, mp, (const T*)g.eta1,
-                       g.v);
-    LAUNCHCHK(ctx);
+    g.la_state = 1;  // force the rebuild from eta2
     g.post_valid = false;
     g.pred_valid = g.predvar_valid = false;
+    AGPCHK(aug_factor(g, 0, 1));
+    HIPCHK(ctx, hipMemcpyAsync(g.v, g.Wbuf, sizeof(T) * mp, hipMemcpyDeviceToDevice, st()));
     return AGP_OK;
   }
 
@@ -570,7 +590,10 @@ struct Svgp : SvgpBase {
                            (const T*)g.Kinv, g.La, (const T*)lr_dev);
         LAUNCHCHK(ctx);
       }
-      AGPCHK(refactor(g));
+      g.la_state = 0;  // La now holds the new -2*eta2 (unfactored); it is factored inside the next local phase
+      g.xa_valid = false;
+      g.post_valid = false;
+      g.pred_valid = g.predvar_valid = false;
     }
     n_opt += 1;
     return AGP_OK;
@@ -597,9 +620,13 @@ struct Svgp : SvgpBase {
     return AGP_OK;
   }
 
-  // Sigma = Xa' Xa ; mu = Xa' v
+  // Sigma = Xa' Xa ; mu = Xa' v   with Xa = chol(-2 eta2)^-1, v = Xa eta1     (inference.jl:25-28)
   agp_status materialize(Latent& g) {
     if (g.post_valid) return AGP_OK;
+    if (!(g.la_state == 1 && g.xa_valid)) {
+      AGPCHK(aug_factor(g, 0, 1));
+      HIPCHK(ctx, hipMemcpyAsync(g.v, g.Wbuf, sizeof(T) * mp, hipMemcpyDeviceToDevice, st()));
+    }
     AGPCHK(xtx_padded<T>(ctx, g.Xa, mp, mp, g.Sigma, mp));
     hipLaunchKernelGGL((k_trmv_lower_t<T>), grid1(mp), dim3(256), 0, st(), (const T*)g.Xa, mp, mp, (const T*)g.v, g.mu);
     LAUNCHCHK(ctx);
@@ -640,9 +667,12 @@ struct Svgp : SvgpBase {
       const int64_t Bq = rup64(B);
       for (int l = 0; l < nl; ++l) {
         Latent& g = lat[l];
-        AGPCHK((gemm_nt<T, EPI_W>(ctx, g.kappa, mp, g.Xa, mp, Bq, mp, mp, 1, nullptr, 0, nullptr, 0, g.v, pw0, pw1,
-                                  ldp)));
-        hipLaunchKernelGGL((k_meanvar_finish<T>), grid1(B), dim3(256), 0, st(), B, ns, (const T*)pw0, (const T*)pw1, ldp,
+        HIPCHK(ctx, hipMemcpyAsync(g.Wbuf, g.kappa, sizeof(T) * Bq * mp, hipMemcpyDeviceToDevice, st()));
+        AGPCHK(aug_factor(g, Bq, 1));
+        HIPCHK(ctx, hipMemcpyAsync(g.v, g.Wbuf + Bq * mp, sizeof(T) * mp, hipMemcpyDeviceToDevice, st()));
+        hipLaunchKernelGGL((k_w_rowstats<T>), grid1(B * 64), dim3(256), 0, st(), (const T*)g.Wbuf, mp, B, mp,
+                           (const T*)g.v, pw0, pw1);
+        hipLaunchKernelGGL((k_meanvar_finish<T>), grid1(B), dim3(256), 0, st(), B, 1, (const T*)pw0, (const T*)pw1, ldp,
                            (const T*)(Kt + l * Bp), emuf + l * Bp, evarf + l * Bp);
         LAUNCHCHK(ctx);
       }
@@ -660,7 +690,7 @@ struct Svgp : SvgpBase {
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
       AGPCHK(materialize(g));
-      hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.La, mp, m, scal_dev + 2);
+      hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.DgA, m, scal_dev + 2);
       hipLaunchKernelGGL((k_frob_dot<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.Kinv, (const T*)g.Sigma, mp, m,
                          scal_dev + 3);
       hipLaunchKernelGGL((k_axpby<T>), grid1(mp), dim3(256), 0, st(), mp, T(1), (const T*)g.mu, T(-1), (const T*)g.mu0,
@@ -729,6 +759,8 @@ struct Svgp : SvgpBase {
     switch (which) {
       case AGP_MAT_L: {
         AGPCHK(refresh_K());
+        hipLaunchKernelGGL((k_publish_diag<T>), dim3((unsigned)(mp / TILE)), dim3(256), 0, st(), g.L, mp, (const T*)g.DgK);
+        LAUNCHCHK(ctx);
         AGPCHK(copy2(g.L, mp, m, m));
         // strict upper part of the stored factor is not maintained outside the diagonal tiles: zero it in the copy
         hipLaunchKernelGGL((k_zero_strict_upper<T>), grid2(m, m), blk2, 0, st(), (T*)out, ldo, m);
@@ -963,7 +995,10 @@ static agp_status bb_potrf(agp_ctx* ctx, void* a, int64_t lda, int64_t n, double
   AGPCHK(dmalloc(ctx, &X, np * np));
   AGPCHK(dmalloc(ctx, &info, 1));
   HIPCHK(ctx, hipMemsetAsync(info, 0, sizeof(int32_t), ctx->stream));
-  AGPCHK(potrf_padded<T>(ctx, Ap, np, np, X, np, info, n));
+  T* Dg = nullptr;
+  AGPCHK(dmalloc(ctx, &Dg, np * TILE));
+  AGPCHK(potrf_fused<T>(ctx, Ap, np, np, X, np, Dg, (T*)nullptr, 0, 0, 0, info, n));
+  hipLaunchKernelGGL((k_publish_diag<T>), dim3((unsigned)(np / TILE)), dim3(256), 0, ctx->stream, Ap, np, (const T*)Dg);
   HIPCHK(ctx, hipMemcpy2DAsync(a, sizeof(T) * lda, Ap, sizeof(T) * np, sizeof(T) * n, n, hipMemcpyDeviceToDevice,
                                ctx->stream));
   hipLaunchKernelGGL((k_zero_strict_upper<T>), grid2(n, n), blk2, 0, ctx->stream, (T*)a, lda, n);
@@ -973,6 +1008,7 @@ static agp_status bb_potrf(agp_ctx* ctx, void* a, int64_t lda, int64_t n, double
   if (info_host) *info_host = hinfo;
   (void)hipFree(Ap);
   (void)hipFree(X);
+  (void)hipFree(Dg);
   (void)hipFree(info);
   if (hinfo != 0) {
     ctx->err = "PosDefException: matrix is not positive definite; leading minor " + std::to_string(hinfo);
@@ -995,10 +1031,9 @@ static agp_status bb_spd_inverse(agp_ctx* ctx, const void* a, int64_t lda, int64
   AGPCHK(dmalloc(ctx, &info, 1));
   AGPCHK(dmalloc(ctx, &sc, 1));
   HIPCHK(ctx, hipMemsetAsync(info, 0, sizeof(int32_t), ctx->stream));
-  AGPCHK(potrf_padded<T>(ctx, Ap, np, np, X, np, info, n));
-  AGPCHK(trtri_padded<T>(ctx, Ap, np, np, X, np, Tw, np));
+  AGPCHK(potrf_fused<T>(ctx, Ap, np, np, X, np, Tw, (T*)nullptr, 0, 0, 1, info, n));
   AGPCHK(xtx_padded<T>(ctx, X, np, np, Inv, np));
-  hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, ctx->stream, (const T*)Ap, np, n, sc);
+  hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, ctx->stream, (const T*)Tw, n, sc);
   LAUNCHCHK(ctx);
   if (ainv)
     HIPCHK(ctx, hipMemcpy2DAsync(ainv, sizeof(T) * ldi, Inv, sizeof(T) * np, sizeof(T) * n, n, hipMemcpyDeviceToDevice,
@@ -1079,6 +1114,36 @@ static agp_status bb_mfma_peak(agp_ctx* ctx, double* tflops) {
   return AGP_OK;
 }
 
+template <typename T, int VAR>
+static agp_status bb_diag_bench(agp_ctx* ctx, int blocks, int reps, double* us) {
+  T *A = nullptr, *out = nullptr;
+  int32_t* info = nullptr;
+  AGPCHK(dmalloc(ctx, &A, TILE * TILE));
+  AGPCHK(dmalloc(ctx, &out, (int64_t)blocks * 2 * TILE * TILE));
+  AGPCHK(dmalloc(ctx, &info, 1));
+  std::vector<T> h(TILE * TILE);
+  for (int i = 0; i < TILE; ++i)
+    for (int j = 0; j < TILE; ++j) h[i * TILE + j] = (T)((i == j ? 2.0 : 0.0) + 0.5 / (1.0 + std::abs(i - j)));
+  HIPCHK(ctx, hipMemcpy(A, h.data(), sizeof(T) * TILE * TILE, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemset(info, 0, 4));
+  hipEvent_t e0, e1;
+  HIPCHK(ctx, hipEventCreate(&e0));
+  HIPCHK(ctx, hipEventCreate(&e1));
+  hipLaunchKernelGGL((k_diag_bench<T, VAR>), dim3(blocks), dim3(NTHREADS), 0, ctx->stream, (const T*)A, out, 2, info);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+  hipLaunchKernelGGL((k_diag_bench<T, VAR>), dim3(blocks), dim3(NTHREADS), 0, ctx->stream, (const T*)A, out, reps, info);
+  HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+  HIPCHK(ctx, hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+  *us = ms * 1e3 / reps;
+  (void)hipFree(A);
+  (void)hipFree(out);
+  (void)hipFree(info);
+  return AGP_OK;
+}
+
 #define DISPATCH(dtype, call_f64, call_f32)        \
   do {                                             \
     if ((dtype) == AGP_F64) return call_f64;       \
@@ -1119,6 +1184,27 @@ agp_status agp_solve_right_spd(agp_ctx* ctx, int32_t dtype, const void* a, int64
 agp_status agp_mfma_peak(agp_ctx* ctx, int32_t dtype, double* tflops_host) {
   if (!ctx || !tflops_host) return AGP_ERR_INVALID;
   DISPATCH(dtype, bb_mfma_peak<double>(ctx, tflops_host), bb_mfma_peak<float>(ctx, tflops_host));
+}
+
+// development micro-benchmark (not part of include/agp_hip.h): microseconds per 64x64 diagonal-tile factorisation
+agp_status agp_dev_diag_bench(agp_ctx* ctx, int32_t dtype, int32_t variant, int32_t blocks, int32_t reps, double* us) {
+  if (!ctx || !us) return AGP_ERR_INVALID;
+  if (dtype == AGP_F64) {
+    switch (variant) {
+      case 0: return bb_diag_bench<double, 0>(ctx, blocks, reps, us);
+      case 1: return bb_diag_bench<double, 1>(ctx, blocks, reps, us);
+      case 2: return bb_diag_bench<double, 2>(ctx, blocks, reps, us);
+      case 3: return bb_diag_bench<double, 3>(ctx, blocks, reps, us);
+    }
+  } else {
+    switch (variant) {
+      case 0: return bb_diag_bench<float, 0>(ctx, blocks, reps, us);
+      case 1: return bb_diag_bench<float, 1>(ctx, blocks, reps, us);
+      case 2: return bb_diag_bench<float, 2>(ctx, blocks, reps, us);
+      case 3: return bb_diag_bench<float, 3>(ctx, blocks, reps, us);
+    }
+  }
+  return AGP_ERR_INVALID;
 }
 
 agp_status agp_svgp_create(agp_ctx* ctx, const agp_svgp_desc* desc, agp_svgp** out) {

@@ -171,7 +171,7 @@ struct LikParams {
 };
 
 template <typename T>
-__global__ void k_local_update(int64_t B, int nslices, const T* __restrict__ pk, const T* __restrict__ pw0,
+__global__ void k_local_update(int64_t B, int nslices, int nslices_w, const T* __restrict__ pk, const T* __restrict__ pw0,
                                const T* __restrict__ pw1, int64_t ldp, T kdiag, T jitter, T rho, LikParams<T> lp,
                                const T* __restrict__ y, const int64_t* __restrict__ idx, T* __restrict__ Kt,
                                T* __restrict__ muf, T* __restrict__ varf, T* __restrict__ c, T* __restrict__ theta,
@@ -179,8 +179,9 @@ __global__ void k_local_update(int64_t B, int nslices, const T* __restrict__ pk,
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= B) return;
   T sk = T(0), s0 = T(0), s1 = T(0);
-  for (int s = 0; s < nslices; ++s) {
-    if (!use_kt) sk += pk[s * ldp + i];
+  if (!use_kt)
+    for (int s = 0; s < nslices; ++s) sk += pk[s * ldp + i];
+  for (int s = 0; s < nslices_w; ++s) {
     s0 += pw0[s * ldp + i];
     s1 += pw1[s * ldp + i];
   }

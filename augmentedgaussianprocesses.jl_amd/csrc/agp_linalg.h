@@ -38,8 +38,14 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_nt(const T* __restrict__ A, i
   acc.zero();
   int64_t kEnd = tri_b ? ((c0 + TILE) < K ? (c0 + TILE) : K) : K;
   gemm_tile<T, KC, KC>(A + r0 * lda, lda, B + c0 * ldb, ldb, 0, kEnd, nullptr, acc, smem);
-  if (EPI == EPI_STORE || EPI == EPI_KAPPA) {
+  if (EPI == EPI_STORE) {
     acc_foreach<T>(acc, [&](int r, int c, T val) { C[(r0 + r) * ldc + c0 + c] = val; });
+  }
+  if (EPI == EPI_KAPPA) {  // kappa goes to C and to the augmented-Cholesky workspace (part1, same ldc)
+    acc_foreach<T>(acc, [&](int r, int c, T val) {
+      C[(r0 + r) * ldc + c0 + c] = val;
+      if (part1) part1[(r0 + r) * ldc + c0 + c] = val;
+    });
   }
   if (EPI == EPI_EMINUS) {
     acc_foreach<T>(acc, [&](int r, int c, T val) { C[(r0 + r) * ldc + c0 + c] = E[(r0 + r) * lde + c0 + c] - val; });
@@ -140,54 +146,124 @@ __global__ void k_eta2_from_stats(const T* __restrict__ S, int64_t n, T* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Blocked right-looking Cholesky, nb = 64, in place on the lower triangle of A (n = nt*64).
+// Cholesky A = L L' (in place, lower, nb = 64) fused with the triangular inverse X = L^-1, one launch per
+// block column.  Launch S(k), k = 0..nt, has three kinds of workgroups:
+//   P (blockIdx < nt-k, k < nt)   panel of block column k: applies the pending rank-64 update from column k-1 to
+//       its own tile and (redundantly, every P workgroup) to the diagonal tile, factors the diagonal tile, then
+//       b == 0 stores L_kk (into Dg[k]) and X_kk = L_kk^-1, b > 0 forms L_ik = A_ik L_kk^-T with MFMA.
+//   U (k >= 1)                    trailing update from column k-1 for tiles (i, j), j > k: A_ij -= L_i,k-1 L_j,k-1'
+//   X (k >= 2)                    row q = k-1 of the inverse: X_qj = -X_qq sum_{i=j}^{q-1} L_qi X_ij   (j < q)
+// so the whole potrf + trtri of an m x m matrix costs nt+1 dependent launches (17 at m = 1024).
 //
-// k_potrf_panel (step k, grid = nt-k): EVERY workgroup factors the 64x64 diagonal block redundantly (it is the
-//   critical path; redundancy costs nothing and removes a launch): 256 threads hold the block as 4x4 register
-//   sub-blocks and eliminate column by column with ONE barrier per column, applying the same row operations to an
-//   identity so that L_kk and L_kk^-1 come out together (Gauss-Jordan on [A | I]).  Workgroup 0 stores L_kk and
-//   L_kk^-1 (the latter straight into the diagonal block of X = L^-1); workgroup b>0 forms the panel block
-//   L_ik = A_ik L_kk^-T with MFMA from LDS.
-// k_potrf_update (step k): A_ij -= L_ik L_jk^T for k < j <= i (MFMA, K = 64).
-// info: first non-positive pivot (1-based global column) is recorded with atomicMin-style CAS; 0 = success.
+// Diagonal-tile factorisation (the critical path): 256 threads hold the tile as 4x4 register sub-blocks of A and
+// of an identity M; column j is eliminated from BOTH with the same multipliers (Gauss-Jordan on [A | I]), ONE
+// barrier per column, no data-dependent branches: owners publish u_j (column j below the diagonal, zeros above)
+// and row j of M to LDS, everybody applies  a -= (u_j[R]/p_j) u_j[C],  g -= (u_j[R]/p_j) M_j[C].
+// After 64 steps L = a diag(p)^-1/2 (lower part) and L^-1 = diag(p)^-1/2 g.
+// L_kk goes to the side buffer Dg (nobody may overwrite A_kk while other P workgroups still read it); the P
+// workgroup 0 of the NEXT launch copies it into A.
+// info: first non-positive pivot (1-based global column), 0 = success.
 // ---------------------------------------------------------------------------------------------------
 constexpr int LDP = TILE + 2;  // 66: KC-style stride for 64-deep LDS tiles (conflict-free fragment reads)
 
-template <typename T>
-__device__ __forceinline__ T precise_rcp(T x) {
-  return T(1) / x;
+__device__ __forceinline__ double fast_rcp(double p) {
+  double r = __builtin_amdgcn_rcp(p);
+  double e = fma(-p, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-p, r, 1.0);
+  return fma(r, e, r);
+}
+__device__ __forceinline__ float fast_rcp(float p) {
+  float r = __builtin_amdgcn_rcpf(p);
+  float e = fmaf(-p, r, 1.0f);
+  return fmaf(r, e, r);
 }
 
+// acc += As(64 x 64, [r][k] stride LDP) * Bs(64 x 64 given as [c][k] stride LDP)^T
 template <typename T>
-__device__ __forceinline__ void factor_diag_block(T (&a)[4][4], T* colA, T* rowM, T* Ls, T* Linvs, int32_t* info,
-                                                  int64_t col0, int64_t nvalid) {
+__device__ __forceinline__ void mma_lds64(const T* As, const T* Bs, Acc<T>& acc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+#pragma unroll 4
+  for (int kk = 0; kk < TILE / 4; ++kk) {
+    T a0 = As[(wm * 32 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    T a1 = As[(wm * 32 + 16 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    T b0 = Bs[(wn * 32 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    T b1 = Bs[(wn * 32 + 16 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    acc.a[0][0] = Mfma<T>::mma(a0, b0, acc.a[0][0]);
+    acc.a[0][1] = Mfma<T>::mma(a0, b1, acc.a[0][1]);
+    acc.a[1][0] = Mfma<T>::mma(a1, b0, acc.a[1][0]);
+    acc.a[1][1] = Mfma<T>::mma(a1, b1, acc.a[1][1]);
+  }
+}
+
+// One 16-column group (J = j/16) of the elimination.  Thread (ti, tj) owns the CYCLIC 4x4 sub-blocks
+// rows R = ti + 16 r, cols C = tj + 16 c, so "row/col block still alive" is a compile-time property of (r, c, J):
+// A side only touches lower blocks J <= c <= r, M side blocks r >= J, c <= J -- about a third of the dense work,
+// with no lane-divergent branches.
+template <typename T, int J, int VAR = 0>
+__device__ __forceinline__ void eliminate_group(T (&a)[4][4], T (&g)[4][4], T* U, T* MR, T* piv, int ti, int tj) {
+  for (int jj = 0; jj < 16; ++jj) {
+    const int j = J * 16 + jj;
+    if (tj == jj) {  // owners of column j publish u_j (zero on and above the diagonal)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        T v = (r < J) ? T(0) : ((r > J) ? a[r][J] : (ti > jj ? a[r][J] : T(0)));
+        U[j * TILE + ti + 16 * r] = v;
+      }
+      if (ti == jj) piv[j] = a[J][J];
+    }
+    if (ti == jj) {  // owners of row j of M publish it (columns beyond block J are zero and never read)
+#pragma unroll
+      for (int c = 0; c <= J; ++c) MR[j * TILE + tj + 16 * c] = g[J][c];
+    }
+    if (VAR != 1) __syncthreads();
+    const T rinv = (VAR == 2) ? T(0.5) : fast_rcp(piv[j]);
+    T f[4], uC[4], mC[4];
+#pragma unroll
+    for (int r = J; r < 4; ++r) f[r] = U[j * TILE + ti + 16 * r] * rinv;
+#pragma unroll
+    for (int c = J; c < 4; ++c) uC[c] = U[j * TILE + tj + 16 * c];
+#pragma unroll
+    for (int c = 0; c <= J; ++c) mC[c] = MR[j * TILE + tj + 16 * c];
+    if (VAR != 3)
+#pragma unroll
+    for (int r = J; r < 4; ++r) {
+#pragma unroll
+      for (int c = J; c <= r; ++c) a[r][c] = fma(-f[r], uC[c], a[r][c]);
+#pragma unroll
+      for (int c = 0; c <= J; ++c) g[r][c] = fma(-f[r], mC[c], g[r][c]);
+    }
+  }
+}
+
+// In: bufA holds the SPD tile as [R*LDP + C] (lower triangle valid).  Out: bufA = L (upper zero), bufB = L^-1.
+template <typename T, int VAR = 0>
+__device__ __forceinline__ void factor_diag_tile(T* bufA, T* bufB, T* piv, int32_t* info, int64_t col0,
+                                                 int64_t nvalid) {
   const int tid = threadIdx.x;
   const int ti = tid >> 4, tj = tid & 15;
-  T g[4][4];
+  T a[4][4], g[4][4];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) g[r][c] = (ti == tj && r == c) ? T(1) : T(0);
-  const bool active = (tj <= ti);
-  // outer loop dynamic (jb), inner 4 columns unrolled so that register sub-block indices (jr) stay static
-  for (int jb = 0; jb < TILE / 4; ++jb)
-#pragma unroll
-  for (int jr = 0; jr < 4; ++jr) {
-    const int j = jb * 4 + jr;
-    T* cA = colA + (j & 1) * TILE;
-    T* rM = rowM + (j & 1) * TILE;
-    if (tj == jb) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cA[4 * ti + r] = a[r][jr];
+    for (int c = 0; c < 4; ++c) {
+      int R = ti + 16 * r, Cc = tj + 16 * c;
+      int lo = R >= Cc ? R : Cc, hi = R >= Cc ? Cc : R;
+      a[r][c] = bufA[lo * LDP + hi];
+      g[r][c] = (R == Cc) ? T(1) : T(0);
     }
-    if (ti == jb) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) rM[4 * tj + c] = g[jr][c];
-    }
-    __syncthreads();
-    T p = cA[j];
-    if (tid == 0 && !(p > T(0)) && (col0 + j) < nvalid) {
-      int32_t want = (int32_t)(col0 + j + 1);
+  __syncthreads();  // bufA / bufB are reused as the u_j / M-row stores from here on
+  eliminate_group<T, 0, VAR>(a, g, bufA, bufB, piv, ti, tj);
+  eliminate_group<T, 1, VAR>(a, g, bufA, bufB, piv, ti, tj);
+  eliminate_group<T, 2, VAR>(a, g, bufA, bufB, piv, ti, tj);
+  eliminate_group<T, 3, VAR>(a, g, bufA, bufB, piv, ti, tj);
+  __syncthreads();  // all reads of U / MR done; piv complete
+  if (tid < TILE) {
+    const T p = piv[tid];
+    const bool bad = !(p > T(0)) && (col0 + tid) < nvalid;
+    const unsigned long long mask = __ballot(bad);
+    if (mask != 0ull && tid == 0) {
+      int32_t want = (int32_t)(col0 + (__ffsll((long long)mask) - 1) + 1);
       int32_t old = atomicCAS(info, 0, want);
       while (old != 0 && old > want) {
         int32_t prev = atomicCAS(info, old, want);
@@ -195,149 +271,183 @@ __device__ __forceinline__ void factor_diag_block(T (&a)[4][4], T* colA, T* rowM
         old = prev;
       }
     }
-    if (!(p > T(0))) p = T(1);  // keep going with finite garbage; host reports info
-    const T rinv = precise_rcp(p);
-    const T rs = precise_rcp(sqrt(p));
-    if (tj == jb) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int R = 4 * ti + r;
-        Ls[R * LDP + j] = (R >= j) ? a[r][jr] * rs : T(0);
-      }
-    }
-    if (ti == jb) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        int Cc = 4 * tj + c;
-        Linvs[j * LDP + Cc] = (Cc <= j) ? g[jr][c] * rs : T(0);
-      }
-    }
-    if (active && (4 * ti + 3) > j) {
-      T cc[4], mm[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        cc[c] = cA[4 * tj + c];
-        mm[c] = rM[4 * tj + c];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int R = 4 * ti + r;
-        if (R > j) {
-          T f = cA[R] * rinv;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            int Cc = 4 * tj + c;
-            if (Cc > j) a[r][c] -= f * cc[c];
-            else g[r][c] -= f * mm[c];
-          }
-        }
-      }
-    }
   }
-  __syncthreads();
-}
-
-template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_potrf_panel(T* __restrict__ A, int64_t ld, int64_t k, T* __restrict__ X,
-                                                          int64_t ldx, int32_t* __restrict__ info, int64_t nvalid) {
-  __shared__ __attribute__((aligned(16))) T Ls[TILE * LDP];
-  __shared__ __attribute__((aligned(16))) T Linvs[TILE * LDP];
-  __shared__ T colA[2 * TILE];
-  __shared__ T rowM[2 * TILE];
-  const int tid = threadIdx.x;
-  const int ti = tid >> 4, tj = tid & 15;
-  const int64_t d0 = k * TILE;
-  T a[4][4];
+  T rsC[4], rsR[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    T pc = piv[tj + 16 * q], pr = piv[ti + 16 * q];
+    rsC[q] = T(1) / sqrt(pc > T(0) ? pc : T(1));
+    rsR[q] = T(1) / sqrt(pr > T(0) ? pr : T(1));
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      int R = 4 * ti + r, Cc = 4 * tj + c;
-      int lo = R >= Cc ? R : Cc, hi = R >= Cc ? Cc : R;  // read the lower triangle only
-      a[r][c] = A[(d0 + lo) * ld + d0 + hi];
+      int R = ti + 16 * r, Cc = tj + 16 * c;
+      bufA[R * LDP + Cc] = (R >= Cc) ? a[r][c] * rsC[c] : T(0);
+      bufB[R * LDP + Cc] = (R >= Cc) ? g[r][c] * rsR[r] : T(0);
     }
-  factor_diag_block<T>(a, colA, rowM, Ls, Linvs, info, d0, nvalid);
-  const int64_t b = blockIdx.x;
-  if (b == 0) {
-    for (int e = tid; e < TILE * TILE; e += NTHREADS) {
-      int R = e >> 6, Cc = e & 63;
-      A[(d0 + R) * ld + d0 + Cc] = Ls[R * LDP + Cc];
-      X[(d0 + R) * ldx + d0 + Cc] = Linvs[R * LDP + Cc];
+  __syncthreads();
+}
+
+// Extension rows ("augmented Cholesky"): ne extra 64-row blocks E (ld lde) are treated as block rows nt..nt+ne-1
+// BELOW A: they receive the panel solve and the trailing updates but never become diagonal blocks, so on exit
+// E = E_in * L^-T.  With E_in = [kappa ; eta1'] this yields W = kappa L_A^-T and v' = (L_A^-1 eta1)' -- all that
+// mean_f / var_f need (latentgp.jl:179,189) -- without forming L_A^-1 and without a separate B x m x m GEMM.
+// do_x == 0 drops the X (inverse) role.  Diagonal factors always go to Dg (A's diagonal tiles keep their input).
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_potrf_trtri_step(T* __restrict__ A, int64_t ld, T* __restrict__ X,
+                                                               int64_t ldx, T* __restrict__ Dg, T* __restrict__ E,
+                                                               int64_t lde, int64_t ne, int do_x, int64_t k,
+                                                               int64_t nt, int32_t* __restrict__ info,
+                                                               int64_t nvalid) {
+  // one LDS block: [bufA | bufB]; the GEMM staging (SMEM_ELEMS) aliases its start and is only live before bufA/bufB
+  __shared__ __attribute__((aligned(16))) T sm[2 * TILE * LDP];
+  __shared__ T piv[TILE];
+  static_assert(2 * TILE * LDP >= SMEM_ELEMS, "gemm staging must fit in bufA+bufB");
+  T* bufA = sm;
+  T* bufB = sm + TILE * LDP;
+  T* gsm = sm;
+  const int tid = threadIdx.x;
+  const int64_t nP = (k < nt) ? (nt - k + ne) : 0;
+  const int64_t nr = nt - k - 1;
+  const int64_t nU = (k >= 1 && k < nt && nr > 0) ? nr * (nr + 1) / 2 + ne * nr : 0;
+  int64_t bid = blockIdx.x;
+  if (bid < nP) {
+    // ---------------- P: panel of block column k ----------------
+    const int64_t b = bid, d0 = k * TILE, p0 = (k - 1) * TILE;
+    const bool ext = b >= (nt - k);
+    T* rowp = ext ? E + (b - (nt - k)) * TILE * lde : A + (k + b) * TILE * ld;  // first row of this block row
+    const int64_t ldr = ext ? lde : ld;
+    Acc<T> accD, accT;
+    accD.zero();
+    accT.zero();
+    if (k >= 1) {
+      gemm_tile<T, KC, KC>(A + d0 * ld + p0, ld, A + d0 * ld + p0, ld, 0, TILE, nullptr, accD, gsm);
+      if (b > 0) gemm_tile<T, KC, KC>(rowp + p0, ldr, A + d0 * ld + p0, ld, 0, TILE, nullptr, accT, gsm);
     }
+    acc_foreach<T>(accD, [&](int r, int c, T val) { bufA[r * LDP + c] = A[(d0 + r) * ld + d0 + c] - val; });
+    __syncthreads();
+    factor_diag_tile<T>(bufA, bufB, piv, info, d0, nvalid);
+    if (b == 0) {
+      for (int e = tid; e < TILE * TILE; e += NTHREADS) {
+        int R = e >> 6, Cc = e & 63;
+        Dg[k * TILE * TILE + e] = bufA[R * LDP + Cc];
+        if (do_x) X[(d0 + R) * ldx + d0 + Cc] = bufB[R * LDP + Cc];
+      }
+      return;
+    }
+    // L_ik = (A_ik - pending) * Linv^T
+    acc_foreach<T>(accT, [&](int r, int c, T val) { bufA[r * LDP + c] = rowp[r * ldr + d0 + c] - val; });
+    __syncthreads();
+    Acc<T> acc;
+    acc.zero();
+    mma_lds64<T>(bufA, bufB, acc);
+    acc_foreach<T>(acc, [&](int r, int c, T val) { rowp[r * ldr + d0 + c] = val; });
     return;
   }
-  // panel block i = k + b : L_ik = A_ik * Linv^T   (C[r][c] = sum_j A_ik[r][j] Linv[c][j])
-  const int64_t i0 = (k + b) * TILE;
-  for (int e = tid; e < TILE * TILE; e += NTHREADS) {
-    int R = e >> 6, Cc = e & 63;
-    Ls[R * LDP + Cc] = A[(i0 + R) * ld + d0 + Cc];
+  bid -= nP;
+  if (bid < nU) {
+    // ---------------- U: trailing update from column k-1, tiles (i, j) with j > k ----------------
+    const int64_t ntri = nr * (nr + 1) / 2, p0 = (k - 1) * TILE;
+    T* rowp;
+    int64_t ldr, j0;
+    if (bid < ntri) {
+      int64_t ii, jj;
+      tri_index(bid, ii, jj);
+      rowp = A + (k + 1 + ii) * TILE * ld;
+      ldr = ld;
+      j0 = (k + 1 + jj) * TILE;
+    } else {
+      const int64_t t = bid - ntri, e = t / nr, jj = t % nr;
+      rowp = E + e * TILE * lde;
+      ldr = lde;
+      j0 = (k + 1 + jj) * TILE;
+    }
+    Acc<T> acc;
+    acc.zero();
+    gemm_tile<T, KC, KC>(rowp + p0, ldr, A + j0 * ld + p0, ld, 0, TILE, nullptr, acc, gsm);
+    acc_foreach<T>(acc, [&](int r, int c, T val) { rowp[r * ldr + j0 + c] -= val; });
+    return;
   }
-  __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  Acc<T> acc;
-  acc.zero();
-#pragma unroll 4
-  for (int kk = 0; kk < TILE / 4; ++kk) {
-    T a0 = Ls[(wm * 32 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
-    T a1 = Ls[(wm * 32 + 16 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
-    T b0 = Linvs[(wn * 32 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
-    T b1 = Linvs[(wn * 32 + 16 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
-    acc.a[0][0] = Mfma<T>::mma(a0, b0, acc.a[0][0]);
-    acc.a[0][1] = Mfma<T>::mma(a0, b1, acc.a[0][1]);
-    acc.a[1][0] = Mfma<T>::mma(a1, b0, acc.a[1][0]);
-    acc.a[1][1] = Mfma<T>::mma(a1, b1, acc.a[1][1]);
+  bid -= nU;
+  if (do_x) {
+    // ---------------- X: row q = k-1 of L^-1, tile j = bid < q ----------------
+    const int64_t q = k - 1, j = bid, q0 = q * TILE, j0 = j * TILE;
+    if (j >= q) return;
+    Acc<T> acc;
+    acc.zero();
+    gemm_tile<T, KC, RC>(A + q0 * ld, ld, X + j0, ldx, j0, q0, nullptr, acc, gsm);
+    // stage S transposed (St[c][k]) and X_qq ([r][k]) for the 64-deep product
+    acc_foreach<T>(acc, [&](int r, int c, T val) { bufA[c * LDP + r] = val; });
+    for (int e = tid; e < TILE * TILE; e += NTHREADS) {
+      int R = e >> 6, Cc = e & 63;
+      bufB[R * LDP + Cc] = X[(q0 + R) * ldx + q0 + Cc];
+    }
+    __syncthreads();
+    Acc<T> out;
+    out.zero();
+    mma_lds64<T>(bufB, bufA, out);
+    acc_foreach<T>(out, [&](int r, int c, T val) { X[(q0 + r) * ldx + j0 + c] = -val; });
   }
-  acc_foreach<T>(acc, [&](int r, int c, T val) { A[(i0 + r) * ld + d0 + c] = val; });
 }
 
+// copy the diagonal factors from Dg into the diagonal tiles of an n x n matrix (state export / building blocks)
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_potrf_update(T* __restrict__ A, int64_t ld, int64_t k) {
-  __shared__ __attribute__((aligned(16))) T smem[SMEM_ELEMS];
-  int64_t ii, jj;
-  tri_index(blockIdx.x, ii, jj);
-  const int64_t i0 = (k + 1 + ii) * TILE, j0 = (k + 1 + jj) * TILE, k0 = k * TILE;
-  Acc<T> acc;
-  acc.zero();
-  gemm_tile<T, KC, KC>(A + i0 * ld + k0, ld, A + j0 * ld + k0, ld, 0, TILE, nullptr, acc, smem);
-  acc_foreach<T>(acc, [&](int r, int c, T val) { A[(i0 + r) * ld + j0 + c] -= val; });
+__global__ void k_publish_diag(T* __restrict__ A, int64_t ld, const T* __restrict__ Dg) {
+  const int64_t k = blockIdx.x;
+  for (int e = threadIdx.x; e < TILE * TILE; e += blockDim.x)
+    A[(k * TILE + (e >> 6)) * ld + k * TILE + (e & 63)] = Dg[k * TILE * TILE + e];
 }
 
-// zero the strict upper 64x64 tiles of an n x n matrix (n = nt*64) so factors read back clean
+// W row statistics: out0[i] = sum_j W[i][j]^2 ; out1[i] = sum_j W[i][j] v[j]   (one wave per row)
+template <typename T>
+__global__ void k_w_rowstats(const T* __restrict__ W, int64_t ld, int64_t rows, int64_t cols,
+                             const T* __restrict__ v, T* __restrict__ out0, T* __restrict__ out1) {
+  int64_t row = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  T s0 = T(0), s1 = T(0);
+  for (int64_t j = lane; j < cols; j += 64) {
+    T w = W[row * ld + j];
+    s0 += w * w;
+    s1 += w * v[j];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s0 += __shfl_down(s0, o);
+    s1 += __shfl_down(s1, o);
+  }
+  if (lane == 0) {
+    out0[row] = s0;
+    out1[row] = s1;
+  }
+}
+
+// micro-benchmark of the diagonal-tile factorisation alone (tools/bench_diag.py): `reps` factorizations per launch
+template <typename T, int VAR>
+__global__ __launch_bounds__(NTHREADS) void k_diag_bench(const T* __restrict__ A, T* __restrict__ out, int reps,
+                                                         int32_t* info) {
+  __shared__ __attribute__((aligned(16))) T sm[2 * TILE * LDP];
+  __shared__ T piv[TILE];
+  T* bufA = sm;
+  T* bufB = sm + TILE * LDP;
+  for (int it = 0; it < reps; ++it) {
+    for (int e = threadIdx.x; e < TILE * TILE; e += NTHREADS) bufA[(e >> 6) * LDP + (e & 63)] = A[e];
+    __syncthreads();
+    factor_diag_tile<T, VAR>(bufA, bufB, piv, info, 0, 64);
+  }
+  for (int e = threadIdx.x; e < TILE * TILE; e += NTHREADS) {
+    out[blockIdx.x * 2 * TILE * TILE + e] = bufA[(e >> 6) * LDP + (e & 63)];
+    out[blockIdx.x * 2 * TILE * TILE + TILE * TILE + e] = bufB[(e >> 6) * LDP + (e & 63)];
+  }
+}
+
+// strict-upper 64x64 tiles of an n x n matrix (n = nt*64) -> 0 (so factors read back clean)
 template <typename T>
 __global__ void k_zero_upper_tiles(T* __restrict__ A, int64_t ld, int64_t n) {
   int64_t i = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
   int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n && j < n && (j / TILE) > (i / TILE)) A[i * ld + j] = T(0);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Triangular inverse X = L^-1 by recursive doubling.  Diagonal 64-blocks of X were written by k_potrf_panel.
-// Level with half-size h pairs block p = (X11 at rows r0..r0+h, X22 at rows r1 = r0+h .. min(r1+h, n)):
-//   phase 0 : Tw[r1+i][r0+j] =  sum_k L[r1+i][r0+k] X[r0+k][r0+j]      (A = L21 KC ; B = X11 RC, lower: k >= j)
-//   phase 1 : X [r1+i][r0+j] = -sum_k X[r1+i][r1+k] Tw[r1+k][r0+j]     (A = X22 KC, lower: k <= i ; B = Tw RC)
-// grid = (h/64 column tiles, h/64 row tiles, pairs); tiles beyond n exit.
-// ---------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_trtri_step(const T* __restrict__ L, int64_t ldl, T* __restrict__ X,
-                                                         int64_t ldx, T* __restrict__ Tw, int64_t ldt, int64_t n,
-                                                         int64_t h, int phase) {
-  __shared__ __attribute__((aligned(16))) T smem[SMEM_ELEMS];
-  const int64_t p = blockIdx.z;
-  const int64_t r0 = 2 * p * h, r1 = r0 + h;
-  const int64_t ti = blockIdx.y, tj = blockIdx.x;
-  if (r1 + ti * TILE >= n) return;
-  Acc<T> acc;
-  acc.zero();
-  const int64_t i0 = r1 + ti * TILE, j0 = r0 + tj * TILE;
-  if (phase == 0) {
-    // k local in [tj*64, h)
-    gemm_tile<T, KC, RC>(L + i0 * ldl + r0, ldl, X + r0 * ldx + j0, ldx, tj * TILE, h, nullptr, acc, smem);
-    acc_foreach<T>(acc, [&](int r, int c, T val) { Tw[(i0 + r) * ldt + j0 + c] = val; });
-  } else {
-    // k local in [0, (ti+1)*64)
-    gemm_tile<T, KC, RC>(X + i0 * ldx + r1, ldx, Tw + r1 * ldt + j0, ldt, 0, (ti + 1) * TILE, nullptr, acc, smem);
-    acc_foreach<T>(acc, [&](int r, int c, T val) { X[(i0 + r) * ldx + j0 + c] = -val; });
-  }
 }
 
 // y[j] = sum_{k <= j} X[j][k] x[k]   (lower-triangular matvec, one wave per row)
@@ -378,10 +488,11 @@ __global__ void k_symv(const T* __restrict__ M, int64_t ld, int64_t n, const T* 
 
 // sum of log(diag) over the first nvalid entries (logdet from a Cholesky factor) -> out[0] (double)
 template <typename T>
-__global__ void k_logdiag_sum(const T* __restrict__ L, int64_t ld, int64_t nvalid, double* __restrict__ out) {
+__global__ void k_logdiag_sum(const T* __restrict__ Dg, int64_t nvalid, double* __restrict__ out) {
   __shared__ double red[16];
   double s = 0.0;
-  for (int64_t i = threadIdx.x; i < nvalid; i += blockDim.x) s += log((double)L[i * ld + i]);
+  for (int64_t i = threadIdx.x; i < nvalid; i += blockDim.x)
+    s += log((double)Dg[(i / TILE) * TILE * TILE + (i % TILE) * (TILE + 1)]);
   s = block_sum<double>(s, red);
   if (threadIdx.x == 0) out[0] = s;
 }

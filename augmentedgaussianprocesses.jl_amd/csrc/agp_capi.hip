@@ -1195,6 +1195,7 @@ agp_status agp_dev_diag_bench(agp_ctx* ctx, int32_t dtype, int32_t variant, int3
       case 1: return bb_diag_bench<double, 1>(ctx, blocks, reps, us);
       case 2: return bb_diag_bench<double, 2>(ctx, blocks, reps, us);
       case 3: return bb_diag_bench<double, 3>(ctx, blocks, reps, us);
+      case 4: return bb_diag_bench<double, 4>(ctx, blocks, reps, us);
     }
   } else {
     switch (variant) {
@@ -1202,6 +1203,7 @@ agp_status agp_dev_diag_bench(agp_ctx* ctx, int32_t dtype, int32_t variant, int3
       case 1: return bb_diag_bench<float, 1>(ctx, blocks, reps, us);
       case 2: return bb_diag_bench<float, 2>(ctx, blocks, reps, us);
       case 3: return bb_diag_bench<float, 3>(ctx, blocks, reps, us);
+      case 4: return bb_diag_bench<float, 4>(ctx, blocks, reps, us);
     }
   }
   return AGP_ERR_INVALID;

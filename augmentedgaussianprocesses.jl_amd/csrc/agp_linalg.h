@@ -236,8 +236,131 @@ __device__ __forceinline__ void eliminate_group(T (&a)[4][4], T (&g)[4][4], T* U
   }
 }
 
+// FOUR columns per LDS round trip.  The elimination chain is latency-bound (LDS write -> barrier -> read is ~180
+// cycles, every dependent f64 op ~25), so a 16-column group is processed as 4 rounds: owners publish the 4 raw panel
+// columns (rows below the dead zone) and the 4 M rows; EVERY thread redundantly factors the 4x4 pivot block
+// (LDL', 4 reciprocals), transforms the panel entries it needs (its rows, its columns, its M columns) and applies a
+// rank-4 update.  One barrier per 4 columns instead of one per column; reciprocal = v_rcp_f64 + 1 Newton step
+// (1.8e-15 measured).
+__device__ __forceinline__ double rcp1(double p) {
+  double r = __builtin_amdgcn_rcp(p);
+  return fma(r, fma(-p, r, 1.0), r);
+}
+__device__ __forceinline__ float rcp1(float p) {
+  float r = __builtin_amdgcn_rcpf(p);
+  return fmaf(r, fmaf(-p, r, 1.0f), r);
+}
+
+template <typename T, int J>
+__device__ __forceinline__ void eliminate_group4(T (&a)[4][4], T (&g)[4][4], T* PL, T* MW, T* piv, int ti, int tj) {
+#pragma unroll 1
+  for (int rr = 0; rr < 4; ++rr) {
+    const int jj0 = rr * 4, j0 = J * 16 + jj0;
+    T* P = PL + (rr & 1) * 4 * TILE;   // double-buffered: round r+1 may publish while stragglers read round r
+    T* Mw = MW + (rr & 1) * 4 * TILE;
+    const int qc = tj - jj0, qr = ti - jj0;
+    if (qc >= 0 && qc < 4) {
+#pragma unroll
+      for (int r = J; r < 4; ++r) {
+        T v = a[r][J];
+        if (r == J) v = (ti >= jj0) ? v : T(0);  // rows above the panel are dead
+        P[qc * TILE + ti + 16 * r] = v;
+      }
+    }
+    if (qr >= 0 && qr < 4) {
+#pragma unroll
+      for (int c = 0; c <= J; ++c) Mw[qr * TILE + tj + 16 * c] = g[J][c];
+    }
+    __syncthreads();
+    // ---- 4x4 pivot block, LDL' (every thread, redundantly) ----
+    const T d00 = P[0 * TILE + j0], d10 = P[0 * TILE + j0 + 1], d20 = P[0 * TILE + j0 + 2], d30 = P[0 * TILE + j0 + 3];
+    T d11 = P[1 * TILE + j0 + 1], d21 = P[1 * TILE + j0 + 2], d31 = P[1 * TILE + j0 + 3];
+    T d22 = P[2 * TILE + j0 + 2], d32 = P[2 * TILE + j0 + 3], d33 = P[3 * TILE + j0 + 3];
+    const T r0 = rcp1(d00);
+    const T l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
+    d11 = fma(-l10, d10, d11);
+    d21 = fma(-l20, d10, d21);
+    d31 = fma(-l30, d10, d31);
+    d22 = fma(-l20, d20, d22);
+    d32 = fma(-l30, d20, d32);
+    d33 = fma(-l30, d30, d33);
+    const T r1 = rcp1(d11);
+    const T l21 = d21 * r1, l31 = d31 * r1;
+    d22 = fma(-l21, d21, d22);
+    d32 = fma(-l31, d21, d32);
+    d33 = fma(-l31, d31, d33);
+    const T r2 = rcp1(d22);
+    const T l32 = d32 * r2;
+    d33 = fma(-l32, d32, d33);
+    const T r3 = rcp1(d33);
+    if (ti == 0 && tj == 0) {
+      piv[j0] = d00;
+      piv[j0 + 1] = d11;
+      piv[j0 + 2] = d22;
+      piv[j0 + 3] = d33;
+    }
+    // ---- panel transforms for my columns / my M columns, then row by row: multipliers + rank-4 update ----
+    T u[4][4], mw[4][4];  // [q][c]
+#pragma unroll
+    for (int c = J; c < 4; ++c) {
+      const int x = tj + 16 * c;
+      T y0 = P[x], y1 = P[TILE + x], y2 = P[2 * TILE + x], y3 = P[3 * TILE + x];
+      y1 = fma(-l10, y0, y1);
+      y2 = fma(-l21, y1, fma(-l20, y0, y2));
+      y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, y3)));
+      u[0][c] = y0;
+      u[1][c] = y1;
+      u[2][c] = y2;
+      u[3][c] = y3;
+      if (c == J) {  // columns on/left of pivot q are frozen
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u[q][c] = (tj > jj0 + q) ? u[q][c] : T(0);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c <= J; ++c) {
+      const int x = tj + 16 * c;
+      T y0 = Mw[x], y1 = Mw[TILE + x], y2 = Mw[2 * TILE + x], y3 = Mw[3 * TILE + x];
+      y1 = fma(-l10, y0, y1);
+      y2 = fma(-l21, y1, fma(-l20, y0, y2));
+      y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, y3)));
+      mw[0][c] = y0;
+      mw[1][c] = y1;
+      mw[2][c] = y2;
+      mw[3][c] = y3;
+    }
+#pragma unroll
+    for (int r = J; r < 4; ++r) {
+      const int x = ti + 16 * r;
+      T y0 = P[x], y1 = P[TILE + x], y2 = P[2 * TILE + x], y3 = P[3 * TILE + x];
+      y1 = fma(-l10, y0, y1);
+      y2 = fma(-l21, y1, fma(-l20, y0, y2));
+      y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, y3)));
+      T f[4] = {y0 * r0, y1 * r1, y2 * r2, y3 * r3};
+      if (r == J) {  // rows on/above pivot q take no part in its rank-1 update
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = (ti > jj0 + q) ? f[q] : T(0);
+      }
+#pragma unroll
+      for (int c = J; c <= r; ++c) {
+        T s0 = a[r][c];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s0 = fma(-f[q], u[q][c], s0);
+        a[r][c] = s0;
+      }
+#pragma unroll
+      for (int c = 0; c <= J; ++c) {
+        T s0 = g[r][c];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s0 = fma(-f[q], mw[q][c], s0);
+        g[r][c] = s0;
+      }
+    }
+  }
+}
+
 // In: bufA holds the SPD tile as [R*LDP + C] (lower triangle valid).  Out: bufA = L (upper zero), bufB = L^-1.
-template <typename T, int VAR = 0>
+template <typename T, int VAR = 4>
 __device__ __forceinline__ void factor_diag_tile(T* bufA, T* bufB, T* piv, int32_t* info, int64_t col0,
                                                  int64_t nvalid) {
   const int tid = threadIdx.x;
@@ -253,10 +376,17 @@ __device__ __forceinline__ void factor_diag_tile(T* bufA, T* bufB, T* piv, int32
       g[r][c] = (R == Cc) ? T(1) : T(0);
     }
   __syncthreads();  // bufA / bufB are reused as the u_j / M-row stores from here on
-  eliminate_group<T, 0, VAR>(a, g, bufA, bufB, piv, ti, tj);
-  eliminate_group<T, 1, VAR>(a, g, bufA, bufB, piv, ti, tj);
-  eliminate_group<T, 2, VAR>(a, g, bufA, bufB, piv, ti, tj);
-  eliminate_group<T, 3, VAR>(a, g, bufA, bufB, piv, ti, tj);
+  if (VAR == 4) {
+    eliminate_group4<T, 0>(a, g, bufA, bufB, piv, ti, tj);
+    eliminate_group4<T, 1>(a, g, bufA, bufB, piv, ti, tj);
+    eliminate_group4<T, 2>(a, g, bufA, bufB, piv, ti, tj);
+    eliminate_group4<T, 3>(a, g, bufA, bufB, piv, ti, tj);
+  } else {
+    eliminate_group<T, 0, VAR>(a, g, bufA, bufB, piv, ti, tj);
+    eliminate_group<T, 1, VAR>(a, g, bufA, bufB, piv, ti, tj);
+    eliminate_group<T, 2, VAR>(a, g, bufA, bufB, piv, ti, tj);
+    eliminate_group<T, 3, VAR>(a, g, bufA, bufB, piv, ti, tj);
+  }
   __syncthreads();  // all reads of U / MR done; piv complete
   if (tid < TILE) {
     const T p = piv[tid];
@@ -301,12 +431,13 @@ __global__ __launch_bounds__(NTHREADS) void k_potrf_trtri_step(T* __restrict__ A
                                                                int64_t lde, int64_t ne, int do_x, int64_t k,
                                                                int64_t nt, int32_t* __restrict__ info,
                                                                int64_t nvalid) {
-  // one LDS block: [bufA | bufB]; the GEMM staging (SMEM_ELEMS) aliases its start and is only live before bufA/bufB
-  __shared__ __attribute__((aligned(16))) T sm[2 * TILE * LDP];
+  // one LDS block: [bufA | bufB | bufC]; the GEMM staging (SMEM_ELEMS) aliases bufA+bufB and is only live before them
+  __shared__ __attribute__((aligned(16))) T sm[3 * TILE * LDP];
   __shared__ T piv[TILE];
   static_assert(2 * TILE * LDP >= SMEM_ELEMS, "gemm staging must fit in bufA+bufB");
   T* bufA = sm;
   T* bufB = sm + TILE * LDP;
+  T* bufC = sm + 2 * TILE * LDP;
   T* gsm = sm;
   const int tid = threadIdx.x;
   const int64_t nP = (k < nt) ? (nt - k + ne) : 0;
@@ -327,6 +458,8 @@ __global__ __launch_bounds__(NTHREADS) void k_potrf_trtri_step(T* __restrict__ A
       if (b > 0) gemm_tile<T, KC, KC>(rowp + p0, ldr, A + d0 * ld + p0, ld, 0, TILE, nullptr, accT, gsm);
     }
     acc_foreach<T>(accD, [&](int r, int c, T val) { bufA[r * LDP + c] = A[(d0 + r) * ld + d0 + c] - val; });
+    if (b > 0)  // own tile with the pending update applied: parked in LDS so no accumulator lives across the factorisation
+      acc_foreach<T>(accT, [&](int r, int c, T val) { bufC[r * LDP + c] = rowp[r * ldr + d0 + c] - val; });
     __syncthreads();
     factor_diag_tile<T>(bufA, bufB, piv, info, d0, nvalid);
     if (b == 0) {
@@ -338,11 +471,9 @@ __global__ __launch_bounds__(NTHREADS) void k_potrf_trtri_step(T* __restrict__ A
       return;
     }
     // L_ik = (A_ik - pending) * Linv^T
-    acc_foreach<T>(accT, [&](int r, int c, T val) { bufA[r * LDP + c] = rowp[r * ldr + d0 + c] - val; });
-    __syncthreads();
     Acc<T> acc;
     acc.zero();
-    mma_lds64<T>(bufA, bufB, acc);
+    mma_lds64<T>(bufC, bufB, acc);
     acc_foreach<T>(acc, [&](int r, int c, T val) { rowp[r * ldr + d0 + c] = val; });
     return;
   }

@@ -93,6 +93,8 @@ SYMBOLS = {
     "agp_svgp_step_stats": (_I32, [_VP]),
     "agp_svgp_stats_ptr": (_I32, [_VP, _PVP, _PI64]),
     "agp_svgp_step_global": (_I32, [_VP]),
+    "agp_svgp_timing_enable": (_I32, [_VP, _I32]),
+    "agp_svgp_timing_read": (_I32, [_VP, _PI64, _PDBL]),
     "agp_svgp_check_status": (_I32, [_VP]),
     "agp_svgp_elbo": (_I32, [_VP, _VP, _I64, _VP, _VP, _I64, _DBL, _I32, _PDBL]),
     "agp_svgp_get_state": (_I32, [_VP, _I32, _VP, _VP, _VP, _VP]),

@@ -88,7 +88,7 @@ template <typename T>
 static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* out, int64_t ldo) {
   const int64_t nt = n / TILE;
   hipLaunchKernelGGL((k_syrk_tn<T, SY_STORE>), dim3((unsigned)(nt * (nt + 1) / 2)), dim3(NTHREADS), 0, c->stream, X, ld,
-                     n, (const T*)nullptr, 1, out, ldo, (T*)nullptr, (const T*)nullptr, (int64_t)0, (const T*)nullptr);
+                     n, (const T*)nullptr, 1, out, ldo, (T*)nullptr, (const T*)nullptr, (int64_t)0, T(0));
   LAUNCHCHK(c);
   return AGP_OK;
 }
@@ -140,6 +140,44 @@ struct SvgpBase {
   virtual agp_status proba_y(const void* xt, int64_t ldx, int64_t nt, const double* nodes, const double* weights,
                              int nn, void* o0, void* o1) = 0;
   int64_t n_opt = 1;  // RobbinsMonro counter (optimisers.jl:12)
+  // HIP-event timing of the dominant kernel sequence (agp_svgp_timing_*)
+  bool timing = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<int64_t> ev_launches;
+  size_t ev_used = 0;
+  agp_status timing_begin() {
+    if (!timing) return AGP_OK;
+    if (ev_used + 2 > ev.size()) {
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t e;
+        HIPCHK(ctx, hipEventCreate(&e));
+        ev.push_back(e);
+      }
+    }
+    HIPCHK(ctx, hipEventRecord(ev[ev_used], ctx->stream));
+    return AGP_OK;
+  }
+  agp_status timing_end(int64_t launches) {
+    if (!timing) return AGP_OK;
+    HIPCHK(ctx, hipEventRecord(ev[ev_used + 1], ctx->stream));
+    ev_used += 2;
+    ev_launches.push_back(launches);
+    return AGP_OK;
+  }
+  agp_status timing_read(int64_t* n, double* ms) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *n = 0;
+    *ms = 0.0;
+    for (size_t i = 0; i + 1 < ev_used; i += 2) {
+      float t = 0;
+      HIPCHK(ctx, hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+      *ms += t;
+      *n += ev_launches[i / 2];
+    }
+    ev_used = 0;
+    ev_launches.clear();
+    return AGP_OK;
+  }
 };
 
 struct agp_svgp {
@@ -300,6 +338,7 @@ struct Svgp : SvgpBase {
   }
 
   ~Svgp() override {
+    for (auto e : ev) (void)hipEventDestroy(e);
     for (auto& g : lat) {
       T* ps[] = {g.scales, g.Z, g.L, g.Xk, g.Kinv, g.mu0, g.kinv_mu0, g.eta1, g.eta2, g.La, g.Xa, g.v,
                  g.Sigma, g.mu, g.Knm, g.kappa, g.Apred, g.apred, g.Wbuf, g.DgK, g.DgA};
@@ -464,12 +503,10 @@ struct Svgp : SvgpBase {
         HIPCHK(ctx, hipMemcpyAsync(g.Wbuf, g.kappa, sizeof(T) * Bq * mp, hipMemcpyDeviceToDevice, st()));
       }
       AGPCHK(aug_factor(g, Bq, 0));
-      hipLaunchKernelGGL((k_w_rowstats<T>), grid1(B * 64), dim3(256), 0, st(), (const T*)g.Wbuf, mp, B, mp,
-                         (const T*)(g.Wbuf + Bq * mp), pw0, pw1);
-      hipLaunchKernelGGL((k_local_update<T>), grid1(B), dim3(256), 0, st(), B, ns, 1, (const T*)pk, (const T*)pw0,
-                         (const T*)pw1, ldp, (T)g.k.variance, (T)jitter, (T)rho, lp, (const T*)y, idx, Kt + l * Bp,
-                         muf + l * Bp, varf + l * Bp, cbuf + l * Bp, theta + l * Bp, rbuf + l * Bp, wbuf + l * Bp,
-                         flags_dev, (int)keep);
+      hipLaunchKernelGGL((k_rowstats_local<T>), grid1(B * 64), dim3(256), 0, st(), B, ns, (const T*)pk, ldp,
+                         (const T*)g.Wbuf, mp, mp, (const T*)(g.Wbuf + Bq * mp), (T)g.k.variance, (T)jitter, (T)rho, lp,
+                         (const T*)y, idx, Kt + l * Bp, muf + l * Bp, varf + l * Bp, cbuf + l * Bp, theta + l * Bp,
+                         rbuf + l * Bp, wbuf + l * Bp, flags_dev, (int)keep);
       LAUNCHCHK(ctx);
     }
     x_last = x;
@@ -508,11 +545,8 @@ struct Svgp : SvgpBase {
     return AGP_OK;
   }
 
-  agp_status set_lr() {
-    double lr = desc.stochastic ? 1.0 / std::pow(desc.rm_tau + (double)n_opt, desc.rm_kappa) : 1.0;  // optimisers.jl:14-19
-    hipLaunchKernelGGL((k_set_scalar<T>), dim3(1), dim3(64), 0, st(), lr_dev, (T)lr);
-    LAUNCHCHK(ctx);
-    return AGP_OK;
+  double cur_lr() const {  // optimisers.jl:14-19 ; Descent(1.0) for AnalyticVI
+    return desc.stochastic ? 1.0 / std::pow(desc.rm_tau + (double)n_opt, desc.rm_kappa) : 1.0;
   }
 
   // batch statistics ; fused: eta1/eta2 are stepped directly, otherwise stats = [t | S] for an all-reduce
@@ -520,7 +554,7 @@ struct Svgp : SvgpBase {
     AGPCHK(lsm_finish());
     const int64_t Bq = rup64(B_last);
     const int64_t nt = mp / TILE;
-    if (fused) AGPCHK(set_lr());
+    const T lr = (T)cur_lr();
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
       dim3 gc((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
@@ -529,16 +563,16 @@ struct Svgp : SvgpBase {
       T* sl = stats + l * (mp + mp * mp);
       if (fused) {
         hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, (int)(Bq / TILE), (const T*)cpart, mp,
-                           (const T*)nullptr, (const T*)g.kinv_mu0, g.eta1, (const T*)lr_dev, (T*)nullptr);
+                           (const T*)nullptr, (const T*)g.kinv_mu0, g.eta1, lr, (T*)nullptr);
         hipLaunchKernelGGL((k_syrk_tn<T, SY_ETA2>), dim3((unsigned)(nt * (nt + 1) / 2)), dim3(NTHREADS), 0, st(),
                            (const T*)g.kappa, mp, Bq, (const T*)(wbuf + l * Bp), 0, g.La, mp, g.eta2, (const T*)g.Kinv,
-                           mp, (const T*)lr_dev);
+                           mp, lr);
       } else {
         hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, (int)(Bq / TILE), (const T*)cpart, mp,
-                           (const T*)nullptr, (const T*)nullptr, (T*)nullptr, (const T*)lr_dev, sl);
+                           (const T*)nullptr, (const T*)nullptr, (T*)nullptr, lr, sl);
         hipLaunchKernelGGL((k_syrk_tn<T, SY_STORE>), dim3((unsigned)(nt * (nt + 1) / 2)), dim3(NTHREADS), 0, st(),
                            (const T*)g.kappa, mp, Bq, (const T*)(wbuf + l * Bp), 0, sl + mp, mp, (T*)nullptr,
-                           (const T*)nullptr, (int64_t)0, (const T*)nullptr);
+                           (const T*)nullptr, (int64_t)0, T(0));
       }
       LAUNCHCHK(ctx);
     }
@@ -560,9 +594,10 @@ struct Svgp : SvgpBase {
       LAUNCHCHK(ctx);
     }
     T* ext = g.Wbuf + Bq * mp;
-    HIPCHK(ctx, hipMemsetAsync(ext, 0, sizeof(T) * TILE * mp, st()));
-    HIPCHK(ctx, hipMemcpyAsync(ext, g.eta1, sizeof(T) * mp, hipMemcpyDeviceToDevice, st()));
+    hipLaunchKernelGGL((k_set_ext_rows<T>), grid1(TILE * mp), dim3(256), 0, st(), ext, mp, mp, (const T*)g.eta1);
+    AGPCHK(timing_begin());
     AGPCHK(potrf_fused<T>(ctx, g.La, mp, mp, g.Xa, mp, g.DgA, g.Wbuf, mp, Bq / TILE + 1, with_x, info_dev, m));
+    AGPCHK(timing_end(mp / TILE + (with_x && mp / TILE >= 2 ? 1 : 0)));
     g.la_state = 1;
     g.xa_valid = with_x != 0;
     return AGP_OK;
@@ -579,15 +614,15 @@ struct Svgp : SvgpBase {
   }
 
   agp_status step_global(bool fused) override {
-    if (!fused) AGPCHK(set_lr());
+    const T lr = (T)cur_lr();
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
       if (!fused) {
         const T* sl = stats + l * (mp + mp * mp);
         hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, 0, (const T*)nullptr, (int64_t)0, sl,
-                           (const T*)g.kinv_mu0, g.eta1, (const T*)lr_dev, (T*)nullptr);
+                           (const T*)g.kinv_mu0, g.eta1, lr, (T*)nullptr);
         hipLaunchKernelGGL((k_eta2_from_stats<T>), grid1(mp * mp), dim3(256), 0, st(), sl + mp, mp, g.eta2,
-                           (const T*)g.Kinv, g.La, (const T*)lr_dev);
+                           (const T*)g.Kinv, g.La, lr);
         LAUNCHCHK(ctx);
       }
       g.la_state = 0;  // La now holds the new -2*eta2 (unfactored); it is factored inside the next local phase
@@ -1315,6 +1350,16 @@ agp_status agp_svgp_stats_ptr(agp_svgp* h, void** ptr, int64_t* count) {
 agp_status agp_svgp_step_global(agp_svgp* h) {
   HCHK(h);
   return h->impl->step_global(false);
+}
+agp_status agp_svgp_timing_enable(agp_svgp* h, int32_t on) {
+  HCHK(h);
+  h->impl->timing = on != 0;
+  return AGP_OK;
+}
+agp_status agp_svgp_timing_read(agp_svgp* h, int64_t* n_launches_host, double* total_ms_host) {
+  HCHK(h);
+  if (!n_launches_host || !total_ms_host) return AGP_ERR_INVALID;
+  return h->impl->timing_read(n_launches_host, total_ms_host);
 }
 agp_status agp_svgp_check_status(agp_svgp* h) {
   HCHK(h);

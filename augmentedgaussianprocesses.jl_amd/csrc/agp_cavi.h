@@ -170,21 +170,32 @@ struct LikParams {
   T p1;  // studentt sigma
 };
 
+// One wave per minibatch row i: row statistics of W (s0 = sum_j W_ij^2, s1 = sum_j W_ij v_j), the K~ slice sum, then
+// lane 0 finishes K~ / mean_f / var_f and runs the likelihood update -- rowstats and local update in ONE launch.
 template <typename T>
-__global__ void k_local_update(int64_t B, int nslices, int nslices_w, const T* __restrict__ pk, const T* __restrict__ pw0,
-                               const T* __restrict__ pw1, int64_t ldp, T kdiag, T jitter, T rho, LikParams<T> lp,
-                               const T* __restrict__ y, const int64_t* __restrict__ idx, T* __restrict__ Kt,
-                               T* __restrict__ muf, T* __restrict__ varf, T* __restrict__ c, T* __restrict__ theta,
-                               T* __restrict__ r, T* __restrict__ w, int* __restrict__ flags, int use_kt) {
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+__global__ void k_rowstats_local(int64_t B, int nslices, const T* __restrict__ pk, int64_t ldp,
+                                 const T* __restrict__ W, int64_t ldw, int64_t cols, const T* __restrict__ v,
+                                 T kdiag, T jitter, T rho, LikParams<T> lp, const T* __restrict__ y,
+                                 const int64_t* __restrict__ idx, T* __restrict__ Kt, T* __restrict__ muf,
+                                 T* __restrict__ varf, T* __restrict__ c, T* __restrict__ theta, T* __restrict__ r,
+                                 T* __restrict__ w, int* __restrict__ flags, int use_kt) {
+  const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (i >= B) return;
-  T sk = T(0), s0 = T(0), s1 = T(0);
-  if (!use_kt)
-    for (int s = 0; s < nslices; ++s) sk += pk[s * ldp + i];
-  for (int s = 0; s < nslices_w; ++s) {
-    s0 += pw0[s * ldp + i];
-    s1 += pw1[s * ldp + i];
+  T s0 = T(0), s1 = T(0), sk = T(0);
+  for (int64_t j = lane; j < cols; j += 64) {
+    T wv = W[i * ldw + j];
+    s0 += wv * wv;
+    s1 += wv * v[j];
   }
+  if (!use_kt)
+    for (int s = lane; s < nslices; s += 64) sk += pk[s * ldp + i];
+  for (int o = 32; o > 0; o >>= 1) {
+    s0 += __shfl_down(s0, o);
+    s1 += __shfl_down(s1, o);
+    sk += __shfl_down(sk, o);
+  }
+  if (lane != 0) return;
   // use_kt: kappa (hence K~) was kept from the previous full-batch step (training.jl:199-205)
   T kt = use_kt ? Kt[i] : kdiag + jitter - sk;
   if (!(kt > T(0))) atomicOr(flags, FLAG_NEG_KTILDE);
@@ -215,6 +226,15 @@ __global__ void k_local_update(int64_t B, int nslices, int nslices_w, const T* _
   theta[i] = th;
   r[i] = rho * g1;
   w[i] = rho * th / T(2);
+}
+
+// extension block of the augmented Cholesky: row 0 = eta1', rows 1..63 = 0
+template <typename T>
+__global__ void k_set_ext_rows(T* __restrict__ ext, int64_t ld, int64_t n, const T* __restrict__ eta1) {
+  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= 64 * n) return;
+  int64_t rr = e / n, cc2 = e % n;
+  ext[rr * ld + cc2] = (rr == 0) ? eta1[cc2] : T(0);
 }
 
 // LogisticSoftMax fixed point (logisticsoftmax.jl:65-72), arrays are [nl][ldb] per local latent:
@@ -289,8 +309,8 @@ __global__ __launch_bounds__(NTHREADS) void k_colsum_partial(const T* __restrict
 // t_in != nullptr: t already reduced (multi-GPU stats path) ; else sum nparts slices of part.
 template <typename T>
 __global__ void k_eta1_update(int64_t mp, int nparts, const T* __restrict__ part, int64_t ldp,
-                              const T* __restrict__ t_in, const T* __restrict__ kinv_mu0, T* __restrict__ eta1,
-                              const T* __restrict__ lr_dev, T* __restrict__ t_out) {
+                              const T* __restrict__ t_in, const T* __restrict__ kinv_mu0, T* __restrict__ eta1, T lr,
+                              T* __restrict__ t_out) {
   int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (a >= mp) return;
   T t = T(0);
@@ -303,7 +323,7 @@ __global__ void k_eta1_update(int64_t mp, int nparts, const T* __restrict__ part
   }
   T e = eta1[a];
   T g = t + (kinv_mu0 ? kinv_mu0[a] : T(0)) - e;
-  eta1[a] = e + (*lr_dev) * g;
+  eta1[a] = e + lr * g;
 }
 
 // mean_f / var_f only (ELBO with the updated posterior): mu = sum pw1 ; var = sum pw0 + K~

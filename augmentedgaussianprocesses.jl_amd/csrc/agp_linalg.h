@@ -77,7 +77,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_nt(const T* __restrict__ A, i
 //   SY_STORE : S -> out (both triangles)
 //   SY_ETA2  : fused natural-gradient step (analyticVI.jl:172-180, 229-246):
 //                g = -(S + Kinv/2) - eta2 ; eta2 += lr*g ; out(=Amat) = -2*eta2     (both triangles)
-//              lr is read from *lr_dev (RobbinsMonro step or 1 for AnalyticVI).
+//              lr = RobbinsMonro step (or 1 for AnalyticVI), passed by value.
 // ---------------------------------------------------------------------------------------------------
 enum { SY_STORE = 0, SY_ETA2 = 1 };
 
@@ -94,7 +94,7 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(NTHREADS) void k_syrk_tn(const T* __restrict__ A, int64_t lda, int64_t Kdim,
                                                       const T* __restrict__ w, int lower_a, T* __restrict__ out,
                                                       int64_t ldo, T* __restrict__ eta2, const T* __restrict__ Kinv,
-                                                      int64_t ldm, const T* __restrict__ lr_dev) {
+                                                      int64_t ldm, T lr) {
   __shared__ __attribute__((aligned(16))) T smem[SMEM_ELEMS];
   int64_t ta, tb;
   tri_index(blockIdx.x, ta, tb);
@@ -115,7 +115,6 @@ __global__ __launch_bounds__(NTHREADS) void k_syrk_tn(const T* __restrict__ A, i
       }
     });
   } else {
-    const T lr = *lr_dev;
     acc_foreach<T>(acc, [&](int r, int c, T val) {
       int64_t gr = a0 + r, gc = b0 + c;
       if (ta != tb || gc <= gr) {
@@ -134,10 +133,9 @@ __global__ __launch_bounds__(NTHREADS) void k_syrk_tn(const T* __restrict__ A, i
 // eta2 step from an already reduced statistic S (batch-parallel multi-GPU path: S was all-reduced)
 template <typename T>
 __global__ void k_eta2_from_stats(const T* __restrict__ S, int64_t n, T* __restrict__ eta2,
-                                  const T* __restrict__ Kinv, T* __restrict__ Amat, const T* __restrict__ lr_dev) {
+                                  const T* __restrict__ Kinv, T* __restrict__ Amat, T lr) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n * n) return;
-  const T lr = *lr_dev;
   T e2 = eta2[i];
   T g = -(S[i] + T(0.5) * Kinv[i]) - e2;
   e2 += lr * g;
@@ -177,6 +175,21 @@ __device__ __forceinline__ float fast_rcp(float p) {
   float r = __builtin_amdgcn_rcpf(p);
   float e = fmaf(-p, r, 1.0f);
   return fmaf(r, e, r);
+}
+
+// global 64x64 tile (row-major, leading dimension ld) -> LDS [r*LDP + c], 16-byte loads
+template <typename T>
+__device__ __forceinline__ void load_tile_lds(const T* __restrict__ G, int64_t ld, T* S) {
+  typedef typename Mfma<T>::vec_t vec_t;
+  constexpr int VEC = Mfma<T>::VEC, NV = TILE / VEC;
+#pragma unroll
+  for (int v = 0; v < TILE * NV / NTHREADS; ++v) {
+    int vi = threadIdx.x + v * NTHREADS;
+    int r = vi / NV, cv = vi % NV;
+    vec_t x = *reinterpret_cast<const vec_t*>(G + (int64_t)r * ld + cv * VEC);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) S[r * LDP + cv * VEC + e] = x[e];
+  }
 }
 
 // acc += As(64 x 64, [r][k] stride LDP) * Bs(64 x 64 given as [c][k] stride LDP)^T
@@ -453,9 +466,13 @@ __global__ __launch_bounds__(NTHREADS) void k_potrf_trtri_step(T* __restrict__ A
     Acc<T> accD, accT;
     accD.zero();
     accT.zero();
-    if (k >= 1) {
-      gemm_tile<T, KC, KC>(A + d0 * ld + p0, ld, A + d0 * ld + p0, ld, 0, TILE, nullptr, accD, gsm);
-      if (b > 0) gemm_tile<T, KC, KC>(rowp + p0, ldr, A + d0 * ld + p0, ld, 0, TILE, nullptr, accT, gsm);
+    if (k >= 1) {  // pending rank-64 update from column k-1: both 64-deep products straight from LDS, no k-loop
+      load_tile_lds<T>(A + d0 * ld + p0, ld, bufA);
+      if (b > 0) load_tile_lds<T>(rowp + p0, ldr, bufC);
+      __syncthreads();
+      mma_lds64<T>(bufA, bufA, accD);
+      if (b > 0) mma_lds64<T>(bufC, bufA, accT);
+      __syncthreads();
     }
     acc_foreach<T>(accD, [&](int r, int c, T val) { bufA[r * LDP + c] = A[(d0 + r) * ld + d0 + c] - val; });
     if (b > 0)  // own tile with the pending update applied: parked in LDS so no accumulator lives across the factorisation
@@ -497,7 +514,10 @@ __global__ __launch_bounds__(NTHREADS) void k_potrf_trtri_step(T* __restrict__ A
     }
     Acc<T> acc;
     acc.zero();
-    gemm_tile<T, KC, KC>(rowp + p0, ldr, A + j0 * ld + p0, ld, 0, TILE, nullptr, acc, gsm);
+    load_tile_lds<T>(rowp + p0, ldr, bufA);
+    load_tile_lds<T>(A + j0 * ld + p0, ld, bufB);
+    __syncthreads();
+    mma_lds64<T>(bufA, bufB, acc);
     acc_foreach<T>(acc, [&](int r, int c, T val) { rowp[r * ldr + j0 + c] -= val; });
     return;
   }

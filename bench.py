@@ -1,0 +1,301 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the SVGP / AnalyticSVI CAVI hot path on MI355X.
+
+Metric (BASELINE.json): CAVI iterations/sec (+ time-to-ELBO-tolerance) for SVGP m = 1024 inducing points on N = 1e6
+synthetic points.  Workload = BASELINE.json configs[1] ("C2"): SqExponential kernel + Logistic likelihood,
+AnalyticSVI(1024), m = 1024, N = 1e6, D = 32, fp64, hypers fixed (optimiser=false, as in every reference docs example).
+
+One "step" = one update_parameters!(model::SVGP, ...) (src/training/training.jl:140-144) on one minibatch: kernel
+matrix Knm, kappa = Knm K^-1, augmented Cholesky of -2*eta2 with [kappa; eta1'] (W = kappa L^-T), local updates,
+natural-gradient step on (eta1, eta2).  Inputs are resident in HBM before the timed region.
+
+N GPUs (launched by torch.distributed.run, one rank per GPU): latent-parallel weak scaling -- each rank owns one
+independent latent GP of an N-output model (the sharding north_star names) with its own Z,
+kernel and labels over the same X; no data-path collective (hypers fixed -> no Z hyper-gradient exchange).  `value`
+= latent-CAVI-iterations/s summed over ranks (at N = 1 this is plain iterations/s).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet FP64 matrix (dense); not in the local guide, see DESIGN.md
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=300)
+    p.add_argument("--warmup", type=int, default=30)
+    p.add_argument("--m", type=int, default=1024)
+    p.add_argument("--batch", type=int, default=1024)
+    p.add_argument("--N", type=int, default=1_000_000)
+    p.add_argument("--D", type=int, default=32)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-elbo-tol", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=15.0)
+    return p.parse_args()
+
+
+def make_data(N, D, seed, dev):
+    """X ~ U[0,1]^{N x D}; latent f = sum_j w_j cos(omega_j'x + b_j) sqrt(2/256), omega ~ N(0, l^-2 I),
+    l = sqrt(D)/4 (random-Fourier-feature GP draw); y = sign(f + logistic noise)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    X = torch.rand(N, D, dtype=torch.float64, device=dev, generator=g)
+    ell = math.sqrt(D) / 4.0
+    R = 256
+    om = torch.randn(D, R, dtype=torch.float64, device=dev, generator=g) / ell
+    b = torch.rand(R, dtype=torch.float64, device=dev, generator=g) * (2 * math.pi)
+    w = torch.randn(R, dtype=torch.float64, device=dev, generator=g)
+    f = torch.zeros(N, dtype=torch.float64, device=dev)
+    for s in range(0, N, 131072):
+        f[s:s + 131072] = torch.cos(X[s:s + 131072] @ om + b) @ w * math.sqrt(2.0 / R)
+    u = torch.rand(N, dtype=torch.float64, device=dev, generator=g).clamp_(1e-12, 1 - 1e-12)
+    noise = torch.log(u) - torch.log1p(-u)
+    y = torch.sign(f + noise)
+    y[y == 0] = 1.0
+    return X, y, ell
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+
+        dist = dist_
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as ge
+
+    if rank == 0:
+        ge.build()
+    if dist is not None:
+        dist.barrier()
+    import agp_amd as AGP
+    from agp_amd import capi
+
+    L = capi.lib()
+    N, D, m, B = a.N, a.D, a.m, a.batch
+    steps, warm = a.steps, a.warmup
+    # same X on every rank; per-rank latent (labels, Z) seeds
+    X, _, ell = make_data(N, D, 1234, dev)
+    _, y, _ = make_data(N, D, 1234 + 1000 * (rank + 1), dev) if world > 1 else make_data(N, D, 1234, dev)
+    rng = np.random.default_rng(4321 + rank)
+    Z = X[torch.as_tensor(rng.permutation(N)[:m], device=dev)].cpu().numpy()
+    total = steps + warm
+    idx_np = np.stack([rng.choice(N, B, replace=False) for _ in range(total)]).astype(np.int64)
+    idx_all = torch.as_tensor(idx_np, device=dev)
+    EVAL = 8192
+    eval_idx = torch.as_tensor(rng.choice(N, EVAL, replace=False).astype(np.int64), device=dev)
+
+    def new_model(max_batch):
+        k = AGP.with_lengthscale(AGP.SqExponentialKernel(), ell)
+        mdl = AGP.SVGP(k, AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z, optimiser=False, device=local_rank)
+        mdl.inference.rho = N / B
+        h = mdl._ensure_handle(max_batch)
+        mdl._chk(L.agp_svgp_refresh_K(h))
+        return mdl, h
+
+    model, h = new_model(B)
+    rho = N / B
+    xp, yp, ld = C.c_void_p(X.data_ptr()), C.c_void_p(y.data_ptr()), X.stride(0)
+
+    def step(i):
+        st = L.agp_svgp_cavi_step(h, xp, ld, yp, C.c_void_p(idx_all[i].data_ptr()), B, rho)
+        if st != 0:
+            capi.check(model._ctx, st)
+
+    for i in range(warm):
+        step(i)
+    model._chk(L.agp_svgp_check_status(h))
+    model._chk(L.agp_svgp_timing_enable(h, 1))
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warm, total):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t1 = time.perf_counter()
+    dt = t1 - t0
+    nl, kms = C.c_int64(), C.c_double()
+    model._chk(L.agp_svgp_timing_read(h, C.byref(nl), C.byref(kms)))
+    model._chk(L.agp_svgp_timing_enable(h, 0))
+    model._chk(L.agp_svgp_check_status(h))
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel (k_potrf_trtri_step: 16 launches per step at m = 1024) ----
+    mp = (m + 63) // 64 * 64
+    Bq = (B + 63) // 64 * 64
+    # algorithmic flops of one augmented factorisation: potrf m^3/3 + panel solves of the (B + 64) extension rows m^2 each
+    flops_seq = mp ** 3 / 3.0 + (Bq + 64) * mp ** 2
+    launches_per_step = nl.value / max(steps, 1)
+    avg_launch_s = (kms.value * 1e-3) / max(nl.value, 1)
+    achieved = (flops_seq / launches_per_step) / avg_launch_s / 1e12 if nl.value else 0.0
+    roofline = {
+        "kernel": "k_potrf_trtri_step<double>",
+        "bound": "mfma",
+        "achieved": round(achieved, 3),
+        "peak": FP64_MFMA_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+        "traffic": None,
+        "avg_launch_us": round(avg_launch_s * 1e6, 2),
+        "launches_per_step": round(launches_per_step, 2),
+        "algorithmic_flops_per_launch": flops_seq / launches_per_step,
+    }
+    # whole-iteration algorithmic rate (F_iter = 6 B m^2 + m^3 + B m (3D + 12))
+    f_iter = 6.0 * B * m * m + m ** 3 + B * m * (3 * D + 12)
+    out = {
+        "metric": "cavi_iters_per_sec",
+        "value": round(world * steps / dt, 2),
+        "unit": "latent-iter/s" if world > 1 else "iter/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warm,
+        "ms_per_step": round(dt / steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"C2: SVGP SqExponential+Logistic AnalyticSVI({B}) m={m} N={N} D={D} fp64, hypers fixed",
+            "parallelism": f"latent-parallel x{world} (one independent latent GP per GPU)" if world > 1 else "single GPU",
+            "global_batch": B * world,
+        },
+        "iter_algorithmic_tflops": round(f_iter * steps / dt / 1e12 * 1.0, 3),
+        "iter_frac_fp64_mfma_peak": round(f_iter * steps / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1:
+        # measured MFMA ceiling (issue-rate microbenchmark inside the library)
+        pk = C.c_double()
+        if L.agp_mfma_peak(model._ctx, capi.F64, C.byref(pk)) == 0:
+            out["roofline"]["measured_mfma_ceiling"] = round(pk.value, 1)
+
+    # ---- time to ELBO tolerance (build-defined rule) ----
+    if not a.no_elbo_tol and rank == 0:
+        del model
+        model2, h2 = new_model(EVAL)
+        rho_e = N / EVAL
+        e = C.c_double()
+        hist, it = [], 0
+        max_it = 3000
+        rng2 = np.random.default_rng(99)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        while it < max_it:
+            for _ in range(10):
+                ii = torch.as_tensor(rng2.choice(N, B, replace=False).astype(np.int64), device=dev)
+                st = L.agp_svgp_cavi_step(h2, xp, ld, yp, C.c_void_p(ii.data_ptr()), B, rho)
+                if st != 0:
+                    capi.check(model2._ctx, st)
+                it += 1
+            model2._chk(L.agp_svgp_elbo(h2, xp, ld, yp, C.c_void_p(eval_idx.data_ptr()), EVAL, rho_e, 1, C.byref(e)))
+            hist.append(e.value)
+            if len(hist) >= 20:
+                m1, m0 = sum(hist[-10:]) / 10.0, sum(hist[-20:-10]) / 10.0
+                if abs(m1 - m0) / abs(m1) < 1e-3:
+                    break
+        torch.cuda.synchronize()
+        out["time_to_elbo_tol_s"] = round(time.perf_counter() - ts, 4)
+        out["iters_to_elbo_tol"] = it
+        out["elbo_at_tol"] = hist[-1]
+        if os.environ.get("AGP_BENCH_TRACE"):
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "elbo_trace.json"), "w") as fh:
+                json.dump(hist, fh)
+        out["elbo_tol_rule"] = ("ELBO (corrected, fresh local vars) on a fixed 8192-point batch every 10 iters; stop when the "
+                                "mean of the last 10 checks moved < 1e-3 (relative) vs the 10 before (minibatch noise "
+                                "makes the raw 1e-4 rule of SURVEY 8d unreachable); wall-clock includes the ELBO evaluations")
+        del model2
+
+    # ---- CPU baseline: the oracle (numpy/scipy LAPACK) on the host cores, same workload, bounded sample ----
+    if not a.no_cpu_baseline and rank == 0 and world == 1:
+        from oracle import agp_ref as R
+
+        from threadpoolctl import threadpool_limits
+
+        avail = len(os.sched_getaffinity(0))
+        Xh = X.cpu().numpy()
+        yh = y.cpu().numpy()
+
+        def fresh_ref():
+            kern = R.Kernel("sqexponential", 1.0 / ell, 1.0)
+            kern.fast = True  # GEMM form of the distances: the favourable-to-CPU variant
+            r = R.SVGP(kern, R.LogisticLikelihood(), Z, stochastic=True, batchsize=B)
+            r.rho = N / B
+            return r
+
+        # pick the BLAS thread count that is fastest on this host for these 1024^3-sized LAPACK calls
+        best_thr, best_t = 1, float("inf")
+        for thr in sorted({t for t in (8, 16, 32, 64, avail) if t <= avail}):
+            with threadpool_limits(limits=thr):
+                r = fresh_ref()
+                r.update_parameters(Xh[idx_np[0]], yh[idx_np[0]])
+                tt = time.perf_counter()
+                for q in range(2):
+                    r.update_parameters(Xh[idx_np[1 + q]], yh[idx_np[1 + q]])
+                tq = (time.perf_counter() - tt) / 2
+            if tq < best_t:
+                best_thr, best_t = thr, tq
+        cores = best_thr
+        n_cpu, tcpu = 0, 0.0
+        with threadpool_limits(limits=best_thr):
+            ref = fresh_ref()
+            t_start = time.perf_counter()
+            while True:
+                ib = idx_np[n_cpu % total]
+                tt = time.perf_counter()
+                ref.update_parameters(Xh[ib], yh[ib])
+                tcpu += time.perf_counter() - tt
+                n_cpu += 1
+                if (time.perf_counter() - t_start) > a.cpu_seconds and n_cpu >= 3:
+                    break
+        out["cpu_baseline"] = {
+            "value": round(n_cpu / tcpu, 3),
+            "unit": "iter/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": f"{n_cpu} iterations of the same C2 workload with the NumPy/SciPy(OpenBLAS) oracle "
+                      f"(GEMM-form distances, best of {{8,16,32,64,all}} BLAS threads; host has {avail} cores), "
+                      f"{tcpu:.1f} s of CPU work",
+        }
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

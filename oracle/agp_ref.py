@@ -190,10 +190,15 @@ class Kernel:
             return np.exp(-d)
         raise ValueError(self.kind)
 
+    fast: bool = False  # CPU-baseline mode: GEMM form of the pairwise distances (what Distances.jl/BLAS does)
+
     def matrix(self, X, Y=None):
-        """kernelmatrix(k, X[, Y]) with direct pairwise squared distances (no GEMM trick)."""
+        """kernelmatrix(k, X[, Y]) with direct pairwise squared distances (no GEMM trick) unless self.fast."""
         Xs = self._scaled(X)
         Ys = Xs if Y is None else self._scaled(Y)
+        if self.fast:
+            d2 = (np.sum(Xs * Xs, axis=1)[:, None] + np.sum(Ys * Ys, axis=1)[None, :]) - 2.0 * (Xs @ Ys.T)
+            return self.sigma2 * self.base_from_d2(d2)
         d2 = np.zeros((Xs.shape[0], Ys.shape[0]))
         for d in range(Xs.shape[1]):
             diff = Xs[:, d][:, None] - Ys[:, d][None, :]

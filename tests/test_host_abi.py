@@ -1,0 +1,137 @@
+"""CPU tests of the host-side mirror and the C-ABI library surface (no compute calls, no GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "agp_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(agp_[A-Za-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    from agp_amd import capi
+
+    names = _header_functions()
+    assert len(names) >= 30
+    L = C.CDLL(capi.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), f"libagp_hip.so does not export {n} declared in include/agp_hip.h"
+    # and the Python binding table covers exactly the header
+    assert sorted(capi.SYMBOLS) == names
+    assert capi.lib().agp_version() >= 100
+
+
+def test_struct_layouts_match_header():
+    from agp_amd import capi
+
+    assert C.sizeof(capi.KernelDesc) == 32
+    assert C.sizeof(capi.LikDesc) == 24
+    assert C.sizeof(capi.SvgpDesc) == 4 * 4 + 3 * 8 + 24 + 3 * 8 + 8
+
+
+def test_missing_library_fails_loudly(monkeypatch, built):
+    from agp_amd import capi
+
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libagp_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        capi.lib()
+
+
+def test_no_product_import_of_oracle():
+    pkg = os.path.join(ROOT, "augmentedgaussianprocesses.jl_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.replace("oracle/", "").lower() or f == "__init__.py" and False, (
+                    f"{f} mentions the oracle: the product path must not use it")
+
+
+def test_kernel_objects():
+    import agp_amd as AGP
+
+    k = 2.0 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(10.0))
+    assert k.variance == 2.0 and np.allclose(k.scales(3), 10.0)
+    d, keep = k.desc(3)
+    assert (d.kind, d.ard, d.variance, d.scale) == (0, 0, 2.0, 10.0)
+    ka = AGP.Matern52Kernel() @ AGP.ARDTransform([1.0, 2.0])
+    d, keep = ka.desc(2)
+    assert d.kind == 1 and d.ard == 1 and [d.ard_scales_host[i] for i in range(2)] == [1.0, 2.0]
+    with pytest.raises(ValueError):
+        ka.desc(3)
+    kl = AGP.with_lengthscale(AGP.SqExponentialKernel(), 4.0)
+    assert np.allclose(kl.scales(2), 0.25)
+    assert "ScaleTransform" in repr(k)
+
+
+def test_likelihood_labels_mirror_reference_tests():
+    # test/likelihood/multiclass.jl:1-40 through the product-side host logic
+    import agp_amd as AGP
+    from agp_amd import likelihoods as LK
+
+    y = [1, 2, 3, 1, 1, 2, 3]
+    l = AGP.LogisticSoftMaxLikelihood(3)
+    LK.create_mapping(l, y)
+    assert sorted(l.class_mapping) == [1, 2, 3] and l.ind_mapping == {1: 1, 2: 2, 3: 3}
+    assert np.array_equal(LK.create_one_hot(l, y[:3]), np.eye(3, dtype=bool))
+    with pytest.raises(RuntimeError):
+        LK.create_mapping(AGP.LogisticSoftMaxLikelihood(2), y)
+    y = ["b", "a", "c", "a", "a"]
+    l = AGP.LogisticSoftMaxLikelihood(3)
+    Y = LK.treat_labels(y, l)
+    assert l.class_mapping == ["b", "a", "c"] and l.ind_mapping == {"b": 1, "a": 2, "c": 3}
+    assert np.array_equal(Y, np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [0, 1, 0], [0, 1, 0]], bool))
+    assert np.array_equal(LK.class_indices(Y), [0, 1, 2, 1, 1])
+    l = AGP.LogisticSoftMaxLikelihood(["a", "b", "c"])
+    assert l.ind_mapping == {"a": 1, "b": 2, "c": 3} and l.n_latent == 3
+    # Bernoulli labels (classification.jl:29-44)
+    assert np.array_equal(LK.treat_labels(np.array([0, 1, 1]), AGP.LogisticLikelihood()), [-1, 1, 1])
+    assert np.array_equal(LK.treat_labels(np.array([True, False]), AGP.LogisticLikelihood()), [1, -1])
+    with pytest.raises(ValueError):
+        LK.treat_labels(np.array([1, 2, 3]), AGP.LogisticLikelihood())
+    with pytest.raises(ValueError):
+        AGP.StudentTLikelihood(0.4)
+
+
+def test_constructor_checks_and_repr():
+    # SVGP.jl:45-49 ; test/inference/analyticVI.jl:1-20
+    import agp_amd as AGP
+
+    Z = np.random.default_rng(0).random((5, 2))
+    k = AGP.SqExponentialKernel()
+    with pytest.raises(TypeError):
+        AGP.SVGP(k, AGP.GaussianLikelihood(), "not an inference", Z)
+    with pytest.raises(RuntimeError):
+        AGP.SVGP(k, object(), AGP.AnalyticVI(), Z)
+    with pytest.raises(NotImplementedError):
+        AGP.SVGP(k, AGP.GaussianLikelihood(), AGP.AnalyticVI(), Z, optimiser=True)
+    m = AGP.SVGP(k, AGP.LogisticSoftMaxLikelihood(3), AGP.AnalyticSVI(10), Z)
+    assert m.n_latent == 3 and len(m.kernels) == 3 and m.kernels[0] is not m.kernels[1]
+    assert repr(AGP.AnalyticVI()) == "Analytic Variational Inference"
+    assert repr(AGP.AnalyticSVI(10)) == "Analytic Stochastic Variational Inference"
+    i = AGP.AnalyticSVI(10)
+    assert i.stoch and i.batchsize == 10 and i.rho == 1.0 and i.n_iter == 0
+    with pytest.raises(ValueError):
+        AGP.RobbinsMonro(0.4)
+    assert "Sparse Variational Gaussian Process" in repr(m)
+
+
+def test_no_gpu_no_cpu_fallback(built):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import agp_amd as AGP
+
+    Z = np.random.default_rng(0).random((5, 2))
+    m = AGP.SVGP(AGP.SqExponentialKernel(), AGP.GaussianLikelihood(), AGP.AnalyticVI(), Z)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        AGP.train_(m, np.zeros((10, 2)), np.zeros(10), 1)

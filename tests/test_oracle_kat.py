@@ -1,0 +1,225 @@
+"""CPU tests pinning the oracle (oracle/agp_ref.py): closed-form known answers, the reference's own unit-test
+identities (test/functions/utils.jl, test/likelihood/multiclass.jl), mpmath tables, behavioural thresholds of
+test/testingtools.jl, and the committed golden fixtures.  No GPU needed."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import agp_ref as R
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_jitter_constants():
+    # test/functions/utils.jl:2-5
+    assert R.jitt(np.float64) == pytest.approx(1e-4)
+    assert R.jitt(np.float32) == pytest.approx(1e-3)
+    assert R.jitt(np.float16) == pytest.approx(1e-2)
+
+
+def test_utils_identities():
+    # test/functions/utils.jl:7-30, 47-49
+    rng = np.random.default_rng(0)
+    A, B, x = rng.random((2, 2)), rng.random((2, 2)), rng.random(2)
+    assert R.delta(0, 1) == 0.0 and R.delta(1, 1) == 1.0
+    assert np.array_equal(R.hadamard(A, B), A * B)
+    assert np.allclose(R.add_transpose(A), A + A.T)
+    Dm = A @ A.T + np.eye(2)
+    Lc = np.linalg.cholesky(Dm)
+    assert R.invquad(Lc, x) == pytest.approx(x @ np.linalg.solve(Dm, x))
+    assert R.trace_ABt(A, B) == pytest.approx(np.trace(A @ B.T))
+    assert np.allclose(R.diag_ABt(A, B), np.diag(A @ B.T))
+    assert np.allclose(R.diagv_B(x, B), np.diag(x) @ B)
+    assert np.allclose(R.kappa_diag_theta_kappa(A, x), A.T @ np.diag(x) @ A)
+    assert np.allclose(R.rho_kappa_diag_theta_kappa(2.0, A, x), 2.0 * A.T @ np.diag(x) @ A)
+    assert np.allclose(R.opt_add_diag_mat(x, A), A + np.diag(x))
+    assert R.safe_expcosh(2.0, 1.0) == pytest.approx(np.exp(2.0) / np.cosh(1.0))
+    assert R.logcosh(2.0) == pytest.approx(np.log(np.cosh(2.0)))
+    # overflow fallback of safe_expcosh (utils.jl:84-86)
+    assert np.isfinite(R.safe_expcosh(800.0, 900.0))
+
+
+def test_multiclass_label_mapping():
+    # test/likelihood/multiclass.jl:1-40
+    y = [1, 2, 3, 1, 1, 2, 3]
+    l = R.LogisticSoftMaxLikelihood(3)
+    R.create_mapping(l, y)
+    assert sorted(l.class_mapping) == [1, 2, 3]
+    assert l.ind_mapping == {1: 1, 2: 2, 3: 3}
+    assert np.array_equal(R.create_one_hot(l, y[:3]), np.eye(3, dtype=bool))
+    with pytest.raises(RuntimeError):
+        R.create_mapping(R.LogisticSoftMaxLikelihood(2), y)
+    y = [1, 2, 1, 1]
+    l = R.LogisticSoftMaxLikelihood(3)
+    R.create_mapping(l, y)
+    assert l.class_mapping == [1, 2, 3]
+    assert np.array_equal(R.create_one_hot(l, y), np.array([[1, 0, 0], [0, 1, 0], [1, 0, 0], [1, 0, 0]], bool))
+    y = ["b", "a", "c", "a", "a"]
+    l = R.LogisticSoftMaxLikelihood(3)
+    R.create_mapping(l, y)
+    assert l.class_mapping == ["b", "a", "c"] and l.ind_mapping == {"b": 1, "a": 2, "c": 3}
+    assert np.array_equal(R.create_one_hot(l, y),
+                          np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [0, 1, 0], [0, 1, 0]], bool))
+    l = R.LogisticSoftMaxLikelihood(3)
+    l.class_mapping = ["a", "b", "c"]
+    assert np.array_equal(R.create_one_hot(l, y),
+                          np.array([[0, 1, 0], [1, 0, 0], [0, 0, 1], [1, 0, 0], [1, 0, 0]], bool))
+
+
+def test_binary_labels():
+    # classification.jl:29-44
+    l = R.LogisticLikelihood()
+    assert np.array_equal(R.treat_labels(np.array([0, 1, 1, 0]), l), [-1, 1, 1, -1])
+    assert np.array_equal(R.treat_labels(np.array([-1, 1]), l), [-1, 1])
+    with pytest.raises(ValueError):
+        R.treat_labels(np.array([0, 1, 2]), l)
+
+
+def test_special_functions_vs_mpmath():
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 50
+    for c in [1e-9, 1e-4, 0.3, 1.0, 7.5, 40.0]:
+        ref = mp.tanh(mp.mpf(c) / 2) / (2 * mp.mpf(c))
+        assert float(R.theta_pg(np.array([c]))[0]) == pytest.approx(float(ref), rel=1e-14)
+        assert float(R.logcosh(c)) == pytest.approx(float(mp.log(mp.cosh(c))), rel=1e-13, abs=5e-16)  # the reference formula cancels near 0 (utils.jl:89-91)
+    assert float(R.theta_pg(np.array([0.0]))[0]) == 0.25
+
+
+def _toy(seed=0, N=120, D=2, m=15):
+    rng = np.random.default_rng(seed)
+    X = rng.random((N, D))
+    f = np.sin(5 * X[:, 0]) * np.cos(3 * X[:, 1])
+    return rng, X, f, X[rng.permutation(N)[:m]].copy()
+
+
+def test_kat1_titsias_optimum():
+    """Gaussian likelihood, full batch, rho = 1, mu0 = 0: after ONE step eta1 = kappa'y/s2,
+    eta2 = -(kappa'kappa/s2 + Kinv)/2 (analyticVI.jl:168,179,241-242 + gaussian.jl:74-80); step two is a fixed point."""
+    rng, X, f, Z = _toy()
+    y = f + 0.1 * rng.standard_normal(len(f))
+    s2 = 0.01
+    kern = R.Kernel("sqexponential", 4.0, 1.0)
+    M = R.SVGP(kern, R.GaussianLikelihood(s2), Z)
+    M.train(X, y, 1)
+    g = M.latents[0]
+    K = kern.matrix(Z) + 1e-4 * np.eye(len(Z))
+    kappa = np.linalg.solve(K, kern.matrix(Z, X)).T
+    assert np.allclose(g.eta1, kappa.T @ y / s2, rtol=1e-10)
+    assert np.allclose(g.eta2, -0.5 * (kappa.T @ kappa / s2 + np.linalg.inv(K)), rtol=1e-9, atol=1e-9)
+    mu1, S1 = g.mu.copy(), g.Sigma.copy()
+    M.train(X, y, 1)
+    assert np.allclose(M.latents[0].mu, mu1, rtol=1e-9, atol=1e-12)
+    assert np.allclose(M.latents[0].Sigma, S1, rtol=1e-9, atol=1e-12)
+    # the optimum equals the Titsias posterior  Sigma = K (K + Kmn Knm / s2)^-1 K
+    Kmn = kern.matrix(Z, X)
+    S_t = K @ np.linalg.solve(K + Kmn @ Kmn.T / s2, K)
+    assert np.allclose(S1, S_t, rtol=1e-7, atol=1e-10)
+
+
+def test_kat2_exact_gp_limit():
+    """Z = X, m = N: predict_f equals exact GP regression up to the jitter terms."""
+    rng = np.random.default_rng(2)
+    N = 40
+    X = rng.random((N, 1))
+    y = np.sin(6 * X[:, 0]) + 0.05 * rng.standard_normal(N)
+    s2 = 0.05
+    kern = R.Kernel("sqexponential", 5.0, 1.0)
+    M = R.SVGP(kern, R.GaussianLikelihood(s2), X.copy())
+    M.train(X, y, 2)
+    Xt = rng.random((25, 1))
+    mu, var = M.predict_f(Xt, cov=True)
+    Kxx = kern.matrix(X) + 1e-4 * np.eye(N)
+    Ks = kern.matrix(Xt, X)
+    mu_exact = Ks @ np.linalg.solve(Kxx + s2 * np.eye(N), y)
+    var_exact = kern.diag(Xt) + 1e-4 - np.sum(Ks * np.linalg.solve(Kxx + s2 * np.eye(N), Ks.T).T, axis=1)
+    assert np.allclose(mu[0], mu_exact, atol=5e-3)
+    assert np.allclose(var[0], var_exact, atol=5e-3)
+
+
+@pytest.mark.parametrize("lik", ["gaussian", "logistic", "studentt", "logisticsoftmax"])
+def test_kat6_elbo_monotone_full_batch(lik):
+    rng, X, f, Z = _toy(3)
+    if lik == "gaussian":
+        L, y = R.GaussianLikelihood(0.05), f + 0.2 * rng.standard_normal(len(f))
+    elif lik == "logistic":
+        L, y = R.LogisticLikelihood(), (f > 0).astype(int)
+    elif lik == "studentt":
+        L, y = R.StudentTLikelihood(3.0), f + 0.2 * rng.standard_t(3, len(f))
+    else:
+        L, y = R.LogisticSoftMaxLikelihood(3), 1 + np.digitize(f, np.quantile(f, [0.33, 0.66]))
+    M = R.SVGP(R.Kernel("sqexponential", 4.0, 1.0), L, Z, elbo_mode="corrected")
+    es = []
+    M.train(X, y, 12, callback=lambda m, it, xb, yb: es.append(m.elbo(yb)))
+    d = np.diff(es)
+    assert np.all(d > -1e-7 * np.abs(es[1:])), es
+
+
+def test_reference_thresholds_on_reference_toy_setups():
+    """test/testingtools.jl:223-253 (testconv) and :14,17 (proba_y variance > 0) on the reference's own set-ups:
+    N = 20, d = 2, M = 10, SqExponentialKernel() ∘ ScaleTransform(10.0) (x2.0 for classification); 1 + 5 iterations."""
+    rng = np.random.default_rng(42)
+    N, d, Mi = 20, 2, 10
+    X = rng.random((N, d))
+    for lik, var in [(R.GaussianLikelihood(1e-3), 1.0), (R.StudentTLikelihood(3.0), 1.0), (R.LogisticLikelihood(), 2.0)]:
+        kern = R.Kernel("sqexponential", 10.0, var)
+        f = np.linalg.cholesky(kern.matrix(X) + 1e-5 * np.eye(N)) @ rng.standard_normal(N)
+        y = (f > 0) if lik.name == "logistic" else f + 0.1 * rng.standard_normal(N)
+        Z = X[rng.permutation(N)[:Mi]]
+        for stoch in (False, True):
+            M = R.SVGP(kern, lik, Z, stochastic=stoch, batchsize=10)
+            idx = [rng.choice(N, 10, replace=False) for _ in range(6)]
+            M.train(X, y, 1, idx_stream=idx)
+            M.train(X, y, 5, idx_stream=idx[1:])
+            yp = M.predict_y(X)
+            if lik.name == "logistic":
+                assert np.mean(yp != y) < 0.5
+            else:
+                assert np.mean(np.abs(yp - f)) < 15
+            assert np.all(M.proba_y(X)[1] > 0)
+    # multiclass: N = 100, d = 1, K = 3, error < 0.9
+    X = rng.random((100, 1))
+    y = 1 + np.digitize(X[:, 0], [0.33, 0.66])
+    M = R.SVGP(R.Kernel("sqexponential", 10.0, 1.0), R.LogisticSoftMaxLikelihood(3), X[rng.permutation(100)[:10]])
+    M.train(X, y, 6)
+    assert np.mean(M.predict_y(X) != y) < 0.9
+
+
+def test_robbins_monro_schedule():
+    # optimisers.jl:12-19 : state starts at 1, lr_t = (tau + n)^-kappa ; first step 2^-0.51
+    assert R.robbins_monro_lr(1) == pytest.approx(2.0 ** -0.51)
+    assert R.robbins_monro_lr(2) == pytest.approx(3.0 ** -0.51)
+
+
+def test_hyper_objective_matches_elbo_parts():
+    """the hyper-parameter objective (ELBO.jl:15-21) at the current hypers equals ELBO + rho*AugmentedKL."""
+    rng, X, f, Z = _toy(5)
+    y = (f > 0).astype(int)
+    M = R.SVGP(R.Kernel("sqexponential", 4.0, 1.3), R.LogisticLikelihood(), Z)
+    yt = R.treat_labels(y, M.likelihood)
+    M.train(X, yt, 3, labels_treated=True)
+    M.compute_kernel_matrices(X, update=True)
+    val = R.hyper_objective(M, X, yt, 0, 4.0, 1.3, Z, 1.0)
+    assert val == pytest.approx(M.elbo(yt) + R.augmented_kl(M.likelihood, M.local_vars, yt), rel=1e-10)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "*.npz"))))
+def test_oracle_reproduces_golden(path):
+    """The committed fixtures are regenerated bit-for-bit-ish by the oracle (guards against silent oracle edits)."""
+    g = np.load(path, allow_pickle=True)
+    name = os.path.basename(path)
+    lik = {"gaussian": lambda: R.GaussianLikelihood(0.05), "logistic": lambda: R.LogisticLikelihood(),
+           "studentt": lambda: R.StudentTLikelihood(3.0, 1.0),
+           "logisticsoftmax": lambda: R.LogisticSoftMaxLikelihood(3)}[name.split("_")[0]]()
+    M = R.SVGP(R.Kernel("sqexponential", float(g["scale"]), float(g["variance"])), lik, g["Z"],
+               stochastic=bool(g["stochastic"]), batchsize=int(g["B"]))
+    es = []
+    M.train(g["X"], g["y"], 10, idx_stream=g["idx"], callback=lambda m, it, xb, yb: es.append(m.elbo(yb)))
+    assert np.allclose(es, g["elbo"], rtol=1e-10)
+    for k, lat in enumerate(M.latents):
+        assert np.allclose(lat.eta2, g[f"eta2_it10_l{k}"], rtol=1e-10, atol=1e-12)
+        assert np.allclose(lat.mu, g[f"mu_it10_l{k}"], rtol=1e-9, atol=1e-12)
+    mu, var = M.predict_f(g["Xt"], cov=True)
+    assert np.allclose(np.stack(mu), g["pred_mu"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(np.stack(var), g["pred_var"], rtol=1e-8, atol=1e-12)

@@ -1,0 +1,181 @@
+"""Multi-GPU drivers: one process per GPU, torch.distributed (backend "nccl" == RCCL over xGMI; "gloo" in CPU tests).
+
+The path shards in two ways:
+
+* latent-parallel -- the latent GPs of a multi-class / multi-output model are independent between exchanges (each owns
+  kernel, Z, K, kappa, eta: deep copies in the reference, src/gpblocks/latentgp.jl:63-68).  Rank r holds the latent slice
+  `latent_slice(K, world, r)`; X, y and the minibatch index stream are replicated.  The only data-path collective is the
+  LogisticSoftMax fixed point: sum_k gamma_k over ALL latents, a length-B vector all-reduced twice per step
+  (src/likelihood/logisticsoftmax.jl:65-72).  Other likelihoods need no collective at all.
+* batch-parallel -- one latent, the minibatch split across ranks; every per-point quantity is row-independent and only the
+  batch statistics [kappa'(rho g1) | rho kappa' diag(g2) kappa] couple the shards: one all-reduce per step
+  (src/inference/analyticVI.jl:168,179), after which every rank applies the identical global step.
+
+The drivers below are backend-agnostic: they talk to an *engine* exposing the phase-split step of the C ABI
+(step_local / lsm_gamma / lsm_alpha / step_stats / step_global) and two tensors (`gsum`, `stats`) that live where the
+process group can reduce them.  `HipEngine` is the product engine (device buffers of libagp_hip.so, zero-copy).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import capi
+
+
+def latent_slice(n_latent: int, world: int, rank: int):
+    """Contiguous balanced slice [lo, hi) of the latents owned by `rank` (C4: 8 latents / 8 GPUs -> one each;
+    C5: 16 latents / 8 GPUs -> two each)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, rem = divmod(n_latent, world)
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def shard_batch(idx: np.ndarray, world: int, rank: int) -> np.ndarray:
+    """Rank r's contiguous share of a minibatch index vector (batch-parallel).  B must divide evenly so that every
+    rank carries the same weight rho = N / B_total."""
+    idx = np.asarray(idx)
+    if len(idx) % world != 0:
+        raise ValueError(f"batch size {len(idx)} is not divisible by the world size {world}")
+    per = len(idx) // world
+    return idx[rank * per:(rank + 1) * per]
+
+
+def _all_reduce(t, group=None):
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def latent_parallel_step(engine, idx, rho: float, group=None) -> None:
+    """One CAVI step with the latents sharded across ranks.  `idx` is the SAME minibatch on every rank."""
+    engine.step_local(idx, rho)
+    if engine.is_lsm:
+        for _ in range(2):  # the reference iterates the (gamma, alpha) fixed point twice
+            engine.lsm_gamma()
+            _all_reduce(engine.gsum, group)
+            engine.lsm_alpha()
+    engine.step_stats()
+    engine.step_global()
+
+
+def batch_parallel_step(engine, idx_local, rho: float, group=None) -> None:
+    """One CAVI step with the minibatch sharded across ranks (all latents replicated).  `idx_local` is this rank's
+    share; `rho` = N / B_total."""
+    engine.step_local(idx_local, rho)
+    if engine.is_lsm:
+        for _ in range(2):
+            engine.lsm_gamma()
+            engine.lsm_alpha()
+    engine.step_stats()
+    _all_reduce(engine.stats, group)
+    engine.step_global()
+
+
+class _DevBuf:
+    """Zero-copy view of a library-owned device buffer for torch (via __cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+class HipEngine:
+    """Phase-split engine over an `SVGP` model's device handle (data must already be resident: `bind_data`)."""
+
+    def __init__(self, model, max_batch: int):
+        self.model = model
+        self.L = capi.lib()
+        self.h = model._ensure_handle(max_batch)
+        model._chk(self.L.agp_svgp_refresh_K(self.h))
+        self.is_lsm = model.likelihood.kind == capi.LIK_LOGISTICSOFTMAX
+        self._X = self._y = None
+        self._stats = None
+        self._gsum = None
+        self._B = 0
+
+    def bind_data(self, X, y, obsdim: int = 1):
+        from .likelihoods import treat_labels
+
+        self._X = self.model._upload(X, obsdim)
+        self._y = self.model._upload_y(treat_labels(y, self.model.likelihood))
+        return self
+
+    def _view(self, ptr_fn):
+        import torch
+
+        p, n = C.c_void_p(), C.c_int64()
+        self.model._chk(ptr_fn(self.h, C.byref(p), C.byref(n)))
+        ts = "<f8" if self.model.T == np.dtype(np.float64) else "<f4"
+        return torch.as_tensor(_DevBuf(p.value, n.value, ts), device=self.model._dev())
+
+    def step_local(self, idx, rho: float):
+        import torch
+
+        idx_t = torch.as_tensor(np.asarray(idx, dtype=np.int64), device=self.model._dev())
+        self._keep = idx_t
+        self._B = idx_t.numel()
+        self.model._chk(self.L.agp_svgp_step_local(self.h, C.c_void_p(self._X.data_ptr()), self._X.stride(0),
+                                                   C.c_void_p(self._y.data_ptr()), C.c_void_p(idx_t.data_ptr()),
+                                                   self._B, float(rho)))
+        self._gsum = None
+
+    def lsm_gamma(self):
+        self.model._chk(self.L.agp_svgp_lsm_gamma(self.h))
+
+    def lsm_alpha(self):
+        self.model._chk(self.L.agp_svgp_lsm_alpha(self.h))
+
+    @property
+    def gsum(self):
+        if self._gsum is None:
+            self._gsum = self._view(self.L.agp_svgp_lsm_gsum_ptr)
+        return self._gsum
+
+    def step_stats(self):
+        self.model._chk(self.L.agp_svgp_step_stats(self.h))
+
+    @property
+    def stats(self):
+        if self._stats is None:
+            self._stats = self._view(self.L.agp_svgp_stats_ptr)
+        return self._stats
+
+    def step_global(self):
+        self.model._chk(self.L.agp_svgp_step_global(self.h))
+
+    def check(self):
+        self.model._chk(self.L.agp_svgp_check_status(self.h))
+
+
+def train_parallel(model, X, y, iterations: int, idx_stream: Sequence, *, mode: str = "latent", group=None,
+                   obsdim: int = 1) -> HipEngine:
+    """train! for a sharded model.  mode="latent": `model` was built with latent_slice=latent_slice(K, world, rank) and
+    every rank passes the same idx_stream.  mode="batch": every rank holds the full model and idx_stream entries are the
+    FULL minibatches (each rank takes its share)."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    N = np.asarray(X).shape[0] if obsdim == 1 else np.asarray(X).shape[1]
+    B_total = len(idx_stream[0])
+    B_local = B_total if mode == "latent" else B_total // world
+    eng = HipEngine(model, B_local).bind_data(X, y, obsdim)
+    model.inference.rho = N / B_total
+    model.inference.batchsize = B_local
+    for it in range(iterations):
+        idx = np.asarray(idx_stream[it])
+        if mode == "latent":
+            latent_parallel_step(eng, idx, N / B_total, group)
+        else:
+            batch_parallel_step(eng, shard_batch(idx, world, rank), N / B_total, group)
+        model.inference.n_iter += 1
+    eng.check()
+    model.trained = True
+    return eng

@@ -273,3 +273,28 @@ def test_large_m1024_step_matches_oracle(env):
     mu, Sig, e1, e2 = ma.get_state(0)
     g = mr.latents[0]
     assert _rel(e2, g.eta2) < 1e-9 and _rel(mu, g.mu) < 1e-8 and _rel(np.diag(Sig), np.diag(g.Sigma)) < 1e-8
+
+
+@pytest.mark.parametrize("likname", ["logistic", "logisticsoftmax"])
+def test_phase_split_engine_matches_oracle(env, likname):
+    """The multi-GPU phase-split ABI (step_local / lsm_* / step_stats / step_global, stats + gsum buffers exposed
+    zero-copy to torch) driven by parallel.latent_parallel_step / batch_parallel_step on one rank."""
+    AGP, R = env["AGP"], env["R"]
+    from agp_amd import parallel as P
+
+    rng = np.random.default_rng(21)
+    B, iters = 64, 4
+    X, y, ma, mr = _models(env, likname, rng, True, B)
+    idx = [rng.choice(len(X), B, replace=False) for _ in range(iters)]
+    eng = P.train_parallel(ma, X, y, iters, idx, mode="latent")
+    # the exposed buffers really alias device memory of the library
+    assert eng.stats.is_cuda and eng.stats.numel() == ma.n_latent * (64 + 64 * 64)
+    mr.train(X, y, iters, idx_stream=idx)
+    for k in range(ma.n_latent):
+        mu, Sig, e1, e2 = ma.get_state(k)
+        assert _rel(e2, mr.latents[k].eta2) < 1e-9 and _rel(mu, mr.latents[k].mu) < 1e-8
+    # batch mode on one rank == the same thing
+    X2, y2, mb, mr2 = _models(env, likname, np.random.default_rng(21), True, B)
+    P.train_parallel(mb, X2, y2, iters, idx, mode="batch")
+    for k in range(mb.n_latent):
+        assert _rel(mb.get_state(k)[3], mr.latents[k].eta2) < 1e-9

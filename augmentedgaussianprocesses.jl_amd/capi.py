@@ -87,6 +87,7 @@ SYMBOLS = {
     "agp_svgp_get_opt_state": (_I32, [_VP, _PI64]),
     "agp_svgp_cavi_step": (_I32, [_VP, _VP, _I64, _VP, _VP, _I64, _DBL]),
     "agp_svgp_step_local": (_I32, [_VP, _VP, _I64, _VP, _VP, _I64, _DBL]),
+    "agp_svgp_prefetch": (_I32, [_VP, _VP, _I64, _VP, _I64]),
     "agp_svgp_lsm_gamma": (_I32, [_VP]),
     "agp_svgp_lsm_alpha": (_I32, [_VP]),
     "agp_svgp_lsm_gsum_ptr": (_I32, [_VP, _PVP, _PI64]),

@@ -63,21 +63,20 @@ static agp_status dmalloc(agp_ctx* c, T** p, int64_t n) {
 }
 
 // ---- linear-algebra drivers on padded matrices ---------------------------------------------------------------
-// Cholesky (lower, in place; diagonal factors in Dg) of the n x n (n = nt*64) matrix A, optionally fused with
-// X = L^-1 (do_x) and with `ne` extension row blocks E <- E L^-T (augmented Cholesky).  nt (+1 if do_x) launches.
+// Cholesky (lower, in place; diagonal factors in Dg) of the n x n (n = nt*64) matrix A with `ne` extension row blocks
+// E <- E L^-T (augmented Cholesky): nt launches of k_chol_step; do_x adds X = L^-1 (one extra row launch per column).
 template <typename T>
 static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int64_t ldx, T* Dg, T* E, int64_t lde,
                               int64_t ne, int do_x, int32_t* info_dev, int64_t nvalid) {
   const int64_t nt = n / TILE;
-  for (int64_t k = 0; k <= nt; ++k) {
-    const int64_t nP = (k < nt) ? (nt - k + ne) : 0;
+  for (int64_t k = 0; k < nt; ++k) {
+    const int64_t nP = nt - k + ne;
     const int64_t nr = nt - k - 1;
-    const int64_t nU = (k >= 1 && k < nt && nr > 0) ? nr * (nr + 1) / 2 + ne * nr : 0;
-    const int64_t nX = (do_x && k >= 2) ? (k - 1) : 0;
-    const int64_t grid = nP + nU + nX;
-    if (grid == 0) continue;
-    hipLaunchKernelGGL((k_potrf_trtri_step<T>), dim3((unsigned)grid), dim3(NTHREADS), 0, c->stream, A, ld, X, ldx, Dg, E,
-                       lde, ne, do_x, k, nt, info_dev, nvalid);
+    const int64_t nU = (k >= 1 && nr > 0) ? nr * (nr + 1) / 2 + ne * nr : 0;
+    hipLaunchKernelGGL((k_chol_step<T>), dim3((unsigned)(nP + nU)), dim3(CHOL_THREADS), 0, c->stream, A, ld, X, ldx, Dg,
+                       E, lde, ne, do_x, k, nt, info_dev, nvalid);
+    if (do_x && k >= 1)
+      hipLaunchKernelGGL((k_trtri_row<T>), dim3((unsigned)k), dim3(NTHREADS), 0, c->stream, (const T*)A, ld, X, ldx, k);
   }
   LAUNCHCHK(c);
   return AGP_OK;
@@ -123,6 +122,7 @@ struct SvgpBase {
   virtual agp_status refresh_K() = 0;
   virtual agp_status step_local(const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B, double rho,
                                 bool fresh) = 0;
+  virtual agp_status prefetch(const void* x, int64_t ldx, const int64_t* idx, int64_t B) = 0;
   virtual agp_status lsm_gamma() = 0;
   virtual agp_status lsm_alpha() = 0;
   virtual agp_status lsm_gsum_ptr(void** p, int64_t* n) = 0;
@@ -205,6 +205,8 @@ struct Svgp : SvgpBase {
     T* Knm = nullptr;
     T* kappa = nullptr;
     T* Wbuf = nullptr;    // (Bp + 64) x mp : [kappa ; eta1'] -> [W ; v'] by the augmented Cholesky
+    T* pk = nullptr;      // K~ partial slices of this latent [2*mp/64][ldp]
+    T *Knm_alt = nullptr, *kappa_alt = nullptr, *Wbuf_alt = nullptr, *pk_alt = nullptr;  // prefetch targets
     T* DgK = nullptr;     // diagonal 64x64 factors of chol(K)      (mp x 64)
     T* DgA = nullptr;     // diagonal 64x64 factors of chol(-2 eta2)
     T* Apred = nullptr;   // K^-1 - K^-1 Sigma K^-1
@@ -221,7 +223,15 @@ struct Svgp : SvgpBase {
   double jitter = 1e-4;
   LikParams<T> lp{};
   // shared batch buffers
-  T *pk = nullptr, *pw0 = nullptr, *pw1 = nullptr;  // partial slices [2*mp/64][ldp]
+  T *pw0 = nullptr, *pw1 = nullptr;  // row-statistic scratch [ldp]
+  // prefetch of the next minibatch's Knm / kappa on a second stream (overlaps the latency-bound factorisation)
+  hipStream_t pf_stream = nullptr;
+  hipEvent_t pf_done = nullptr, step_done[2] = {nullptr, nullptr};
+  int step_parity = 0;
+  bool pf_valid = false;
+  const void* pf_x = nullptr;
+  const int64_t* pf_idx = nullptr;
+  int64_t pf_B = 0, pf_ldx = 0;
   int64_t ldp = 0;
   T *Kt = nullptr, *muf = nullptr, *varf = nullptr, *cbuf = nullptr, *theta = nullptr, *gamma = nullptr,
     *rbuf = nullptr, *wbuf = nullptr;              // [nl][Bp]
@@ -298,6 +308,7 @@ struct Svgp : SvgpBase {
       AGPCHK(dmalloc(ctx, &g.Knm, Bp * mp));
       AGPCHK(dmalloc(ctx, &g.kappa, Bp * mp));
       AGPCHK(dmalloc(ctx, &g.Wbuf, (Bp + TILE) * mp));
+      AGPCHK(dmalloc(ctx, &g.pk, (2 * mp / TILE) * Bp));
       AGPCHK(dmalloc(ctx, &g.DgK, mp * TILE));
       AGPCHK(dmalloc(ctx, &g.DgA, mp * TILE));
       AGPCHK(upload_scales(g));
@@ -305,9 +316,9 @@ struct Svgp : SvgpBase {
     }
     ldp = Bp;
     const int ns = (int)(2 * mp / TILE);
-    AGPCHK(dmalloc(ctx, &pk, ns * ldp));
-    AGPCHK(dmalloc(ctx, &pw0, ns * ldp));
-    AGPCHK(dmalloc(ctx, &pw1, ns * ldp));
+    (void)ns;
+    AGPCHK(dmalloc(ctx, &pw0, 2 * ldp > mp ? 2 * ldp : mp));
+    AGPCHK(dmalloc(ctx, &pw1, 2 * ldp > mp ? 2 * ldp : mp));
     T** bv[] = {&Kt, &muf, &varf, &cbuf, &theta, &gamma, &rbuf, &wbuf, &emuf, &evarf};
     for (auto p : bv) {
       AGPCHK(dmalloc(ctx, p, nl * Bp));
@@ -341,11 +352,15 @@ struct Svgp : SvgpBase {
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto& g : lat) {
       T* ps[] = {g.scales, g.Z, g.L, g.Xk, g.Kinv, g.mu0, g.kinv_mu0, g.eta1, g.eta2, g.La, g.Xa, g.v,
-                 g.Sigma, g.mu, g.Knm, g.kappa, g.Apred, g.apred, g.Wbuf, g.DgK, g.DgA};
+                 g.Sigma, g.mu, g.Knm, g.kappa, g.Apred, g.apred, g.Wbuf, g.DgK, g.DgA, g.pk, g.Knm_alt, g.kappa_alt, g.Wbuf_alt, g.pk_alt};
       for (T* p : ps)
         if (p) (void)hipFree(p);
     }
-    T* ps[] = {pk, pw0, pw1, Kt, muf, varf, cbuf, theta, gamma, rbuf, wbuf, alpha, beta, gsum, alpha_save, emuf,
+    if (pf_stream) (void)hipStreamDestroy(pf_stream);
+    if (pf_done) (void)hipEventDestroy(pf_done);
+    for (auto e : step_done)
+      if (e) (void)hipEventDestroy(e);
+    T* ps[] = {pw0, pw1, Kt, muf, varf, cbuf, theta, gamma, rbuf, wbuf, alpha, beta, gsum, alpha_save, emuf,
                evarf, cpart, stats, Tw, Tw2, tmpv, lr_dev, Kstar, ppm, ppv, pmu, pvar};
     for (T* p : ps)
       if (p) (void)hipFree(p);
@@ -387,6 +402,7 @@ struct Svgp : SvgpBase {
     for (int64_t d = 0; d < D; ++d) g.k.scales[d] = k->ard ? k->ard_scales_host[d] : k->scale;
     g.K_stale = true;
     g.kappa_valid = false;
+    pf_valid = false;
     g.pred_valid = g.predvar_valid = false;
     return upload_scales(g);
   }
@@ -398,6 +414,7 @@ struct Svgp : SvgpBase {
                                  st()));
     g.K_stale = true;
     g.kappa_valid = false;
+    pf_valid = false;
     g.pred_valid = g.predvar_valid = false;
     return AGP_OK;
   }
@@ -487,23 +504,36 @@ struct Svgp : SvgpBase {
     const int64_t Bq = rup64(B);
     const int ns = (int)(2 * mp / TILE);
     const bool reuse = !desc.stochastic && !fresh && x == x_last && idx == idx_last && B == B_last && ldx == ldx_last;
+    const bool prefetched = pf_valid && !fresh && x == pf_x && idx == pf_idx && B == pf_B && ldx == pf_ldx;
+    if (prefetched) {  // kappa of this minibatch was produced on the prefetch stream: adopt those buffers
+      HIPCHK(ctx, hipStreamWaitEvent(st(), pf_done, 0));
+      for (auto& g : lat) {
+        std::swap(g.Knm, g.Knm_alt);
+        std::swap(g.kappa, g.kappa_alt);
+        std::swap(g.Wbuf, g.Wbuf_alt);
+        std::swap(g.pk, g.pk_alt);
+      }
+      pf_valid = false;
+    }
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
       const bool keep = reuse && g.kappa_valid;
-      if (!keep) {
+      if (prefetched) {
+        // nothing to compute
+      } else if (!keep) {
         dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
         hipLaunchKernelGGL((k_kernelmatrix<T>), gk, dim3(NTHREADS), 0, st(), (const T*)x, ldx, idx, B, (const T*)g.Z,
                            D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Knm, mp, Bq, mp, 0, T(0),
                            (const T*)nullptr, (T*)nullptr, (int64_t)0);
         LAUNCHCHK(ctx);
-        AGPCHK((gemm_nt<T, EPI_KAPPA>(ctx, g.Knm, mp, g.Kinv, mp, Bq, mp, mp, 0, g.kappa, mp, g.Knm, mp, nullptr, pk,
+        AGPCHK((gemm_nt<T, EPI_KAPPA>(ctx, g.Knm, mp, g.Kinv, mp, Bq, mp, mp, 0, g.kappa, mp, g.Knm, mp, nullptr, g.pk,
                                       g.Wbuf, ldp)));
         g.kappa_valid = !desc.stochastic && !fresh;
       } else {
         HIPCHK(ctx, hipMemcpyAsync(g.Wbuf, g.kappa, sizeof(T) * Bq * mp, hipMemcpyDeviceToDevice, st()));
       }
       AGPCHK(aug_factor(g, Bq, 0));
-      hipLaunchKernelGGL((k_rowstats_local<T>), grid1(B * 64), dim3(256), 0, st(), B, ns, (const T*)pk, ldp,
+      hipLaunchKernelGGL((k_rowstats_local<T>), grid1(B * 64), dim3(256), 0, st(), B, ns, (const T*)g.pk, ldp,
                          (const T*)g.Wbuf, mp, mp, (const T*)(g.Wbuf + Bq * mp), (T)g.k.variance, (T)jitter, (T)rho, lp,
                          (const T*)y, idx, Kt + l * Bp, muf + l * Bp, varf + l * Bp, cbuf + l * Bp, theta + l * Bp,
                          rbuf + l * Bp, wbuf + l * Bp, flags_dev, (int)keep);
@@ -515,6 +545,52 @@ struct Svgp : SvgpBase {
     B_last = B;
     ldx_last = ldx;
     rho_last = rho;
+    return AGP_OK;
+  }
+
+  // Knm / kappa of the NEXT minibatch on a second stream.  The targets are the alternate buffers, last read by the
+  // step before the most recently enqueued one, so the prefetch only has to wait for that older step.
+  agp_status prefetch(const void* x, int64_t ldx, const int64_t* idx, int64_t B) override {
+    AGPCHK(check_batch(B));
+    if (!x || !idx || ldx < D) return AGP_ERR_INVALID;
+    for (auto& g : lat)
+      if (g.K_stale) return AGP_OK;  // nothing sensible to prefetch against
+    if (!pf_stream) {
+      HIPCHK(ctx, hipStreamCreateWithFlags(&pf_stream, hipStreamNonBlocking));
+      HIPCHK(ctx, hipEventCreateWithFlags(&pf_done, hipEventDisableTiming));
+      for (auto& e : step_done) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      HIPCHK(ctx, hipEventRecord(step_done[0], st()));
+      HIPCHK(ctx, hipEventRecord(step_done[1], st()));
+      for (auto& g : lat) {
+        AGPCHK(dmalloc(ctx, &g.Knm_alt, Bp * mp));
+        AGPCHK(dmalloc(ctx, &g.kappa_alt, Bp * mp));
+        AGPCHK(dmalloc(ctx, &g.Wbuf_alt, (Bp + TILE) * mp));
+        AGPCHK(dmalloc(ctx, &g.pk_alt, (2 * mp / TILE) * Bp));
+      }
+    }
+    // the alternate buffers were "current" in the step before the last enqueued one
+    HIPCHK(ctx, hipStreamWaitEvent(pf_stream, step_done[step_parity], 0));
+    const int64_t Bq = rup64(B);
+    hipStream_t keep_stream = ctx->stream;
+    ctx->stream = pf_stream;  // reuse the launch helpers on the prefetch stream
+    agp_status rc = AGP_OK;
+    for (auto& g : lat) {
+      dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
+      hipLaunchKernelGGL((k_kernelmatrix<T>), gk, dim3(NTHREADS), 0, pf_stream, (const T*)x, ldx, idx, B, (const T*)g.Z,
+                         D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Knm_alt, mp, Bq, mp, 0, T(0),
+                         (const T*)nullptr, (T*)nullptr, (int64_t)0);
+      rc = gemm_nt<T, EPI_KAPPA>(ctx, g.Knm_alt, mp, g.Kinv, mp, Bq, mp, mp, 0, g.kappa_alt, mp, g.Knm_alt, mp, nullptr,
+                                 g.pk_alt, g.Wbuf_alt, ldp);
+      if (rc != AGP_OK) break;
+    }
+    ctx->stream = keep_stream;
+    AGPCHK(rc);
+    HIPCHK(ctx, hipEventRecord(pf_done, pf_stream));
+    pf_valid = true;
+    pf_x = x;
+    pf_idx = idx;
+    pf_B = B;
+    pf_ldx = ldx;
     return AGP_OK;
   }
 
@@ -597,7 +673,7 @@ struct Svgp : SvgpBase {
     hipLaunchKernelGGL((k_set_ext_rows<T>), grid1(TILE * mp), dim3(256), 0, st(), ext, mp, mp, (const T*)g.eta1);
     AGPCHK(timing_begin());
     AGPCHK(potrf_fused<T>(ctx, g.La, mp, mp, g.Xa, mp, g.DgA, g.Wbuf, mp, Bq / TILE + 1, with_x, info_dev, m));
-    AGPCHK(timing_end(mp / TILE + (with_x && mp / TILE >= 2 ? 1 : 0)));
+    AGPCHK(timing_end(mp / TILE));
     g.la_state = 1;
     g.xa_valid = with_x != 0;
     return AGP_OK;
@@ -631,6 +707,10 @@ struct Svgp : SvgpBase {
       g.pred_valid = g.predvar_valid = false;
     }
     n_opt += 1;
+    if (pf_stream) {  // marks the last use of this step's kappa buffers (they become the next prefetch target)
+      step_parity ^= 1;
+      HIPCHK(ctx, hipEventRecord(step_done[step_parity ^ 1], st()));
+    }
     return AGP_OK;
   }
 
@@ -1149,7 +1229,7 @@ static agp_status bb_mfma_peak(agp_ctx* ctx, double* tflops) {
   return AGP_OK;
 }
 
-template <typename T, int VAR>
+template <typename T>
 static agp_status bb_diag_bench(agp_ctx* ctx, int blocks, int reps, double* us) {
   T *A = nullptr, *out = nullptr;
   int32_t* info = nullptr;
@@ -1164,10 +1244,10 @@ static agp_status bb_diag_bench(agp_ctx* ctx, int blocks, int reps, double* us) 
   hipEvent_t e0, e1;
   HIPCHK(ctx, hipEventCreate(&e0));
   HIPCHK(ctx, hipEventCreate(&e1));
-  hipLaunchKernelGGL((k_diag_bench<T, VAR>), dim3(blocks), dim3(NTHREADS), 0, ctx->stream, (const T*)A, out, 2, info);
+  hipLaunchKernelGGL((k_diag_bench<T>), dim3(blocks), dim3(CHOL_THREADS), 0, ctx->stream, (const T*)A, out, 2, info);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-  hipLaunchKernelGGL((k_diag_bench<T, VAR>), dim3(blocks), dim3(NTHREADS), 0, ctx->stream, (const T*)A, out, reps, info);
+  hipLaunchKernelGGL((k_diag_bench<T>), dim3(blocks), dim3(CHOL_THREADS), 0, ctx->stream, (const T*)A, out, reps, info);
   HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
   HIPCHK(ctx, hipEventSynchronize(e1));
   float ms = 0;
@@ -1224,24 +1304,9 @@ agp_status agp_mfma_peak(agp_ctx* ctx, int32_t dtype, double* tflops_host) {
 // development micro-benchmark (not part of include/agp_hip.h): microseconds per 64x64 diagonal-tile factorisation
 agp_status agp_dev_diag_bench(agp_ctx* ctx, int32_t dtype, int32_t variant, int32_t blocks, int32_t reps, double* us) {
   if (!ctx || !us) return AGP_ERR_INVALID;
-  if (dtype == AGP_F64) {
-    switch (variant) {
-      case 0: return bb_diag_bench<double, 0>(ctx, blocks, reps, us);
-      case 1: return bb_diag_bench<double, 1>(ctx, blocks, reps, us);
-      case 2: return bb_diag_bench<double, 2>(ctx, blocks, reps, us);
-      case 3: return bb_diag_bench<double, 3>(ctx, blocks, reps, us);
-      case 4: return bb_diag_bench<double, 4>(ctx, blocks, reps, us);
-    }
-  } else {
-    switch (variant) {
-      case 0: return bb_diag_bench<float, 0>(ctx, blocks, reps, us);
-      case 1: return bb_diag_bench<float, 1>(ctx, blocks, reps, us);
-      case 2: return bb_diag_bench<float, 2>(ctx, blocks, reps, us);
-      case 3: return bb_diag_bench<float, 3>(ctx, blocks, reps, us);
-      case 4: return bb_diag_bench<float, 4>(ctx, blocks, reps, us);
-    }
-  }
-  return AGP_ERR_INVALID;
+  (void)variant;
+  if (dtype == AGP_F64) return bb_diag_bench<double>(ctx, blocks, reps, us);
+  return bb_diag_bench<float>(ctx, blocks, reps, us);
 }
 
 agp_status agp_svgp_create(agp_ctx* ctx, const agp_svgp_desc* desc, agp_svgp** out) {
@@ -1326,6 +1391,10 @@ agp_status agp_svgp_step_local(agp_svgp* h, const void* x, int64_t ldx, const vo
                                double rho) {
   HCHK(h);
   return h->impl->step_local(x, ldx, y, idx, B, rho, false);
+}
+agp_status agp_svgp_prefetch(agp_svgp* h, const void* x, int64_t ldx, const int64_t* idx, int64_t B) {
+  HCHK(h);
+  return h->impl->prefetch(x, ldx, idx, B);
 }
 agp_status agp_svgp_lsm_gamma(agp_svgp* h) {
   HCHK(h);

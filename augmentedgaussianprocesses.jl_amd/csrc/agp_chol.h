@@ -1,0 +1,439 @@
+// agp_chol.h -- the augmented, fused blocked Cholesky of the CAVI step (gfx950, wave64, f64/f32 MFMA 16x16x4).
+//
+//   A = L L'  (n = nt*64, lower, in place; diagonal factors in the side buffer Dg)
+//   optional extension rows  E <- E L^-T   ("augmented Cholesky": E = [kappa ; eta1'] gives W = kappa L_A^-T and
+//                                           v' = (L_A^-1 eta1)', all that mean_f / var_f need, latentgp.jl:179,189)
+//   optional X = L^-1 (separate row kernel, only for Sigma / mu export, the ELBO's Gaussian KL and prediction)
+//
+// One launch of k_chol_step per block column k (nt launches), 512-thread workgroups (8 waves = 2 per SIMD):
+//   P workgroups (one per block row i >= k, then one per extension block): load L_{k,k-1}, L_{i,k-1}; the pending
+//       rank-64 update of the diagonal tile and of the own tile as two 64^3 MFMA products spread over the 8 waves;
+//       factor the 64x64 diagonal tile (redundantly in every P workgroup: it is the critical path and redundancy removes
+//       a launch); b == 0 stores L_kk (Dg) and L_kk^-1, b > 0 forms L_ik = T_ik L_kk^-T by a third MFMA product.
+//   U workgroups: trailing update from column k-1 of tiles (i, j), j > k (one 64^3 MFMA product each).
+//
+// Diagonal-tile factorisation = Gauss-Jordan on [A | I] without pivoting, which yields L and L^-1 together.  It is a
+// 64-long dependent chain, so everything is organised around latency (measured: LDS write->barrier->read 180 cycles,
+// dependent f64 op ~25 cycles, v_rcp_f64 + one Newton step 1.8e-15 accurate):
+//   * FOUR columns per round (16 rounds, one barrier each): owners publish the 4 raw panel columns and the 4 M rows;
+//   * every thread of waves 0-3 redundantly LDL'-factors the 4x4 pivot block, transforms the panel entries it needs and
+//     applies the rank-4 update to its cyclic 4x4 sub-blocks of A and of M; triangular skipping is compile-time per
+//     16-column group.
+#pragma once
+#include "agp_device.h"
+
+namespace agp {
+
+constexpr int LDP = TILE + 2;   // 66: [r][k] stride for 64-deep LDS tiles (conflict-free MFMA fragment reads)
+constexpr int CHOL_THREADS = 512;
+
+__device__ __forceinline__ double rcp1(double p) {
+  double r = __builtin_amdgcn_rcp(p);
+  return fma(r, fma(-p, r, 1.0), r);
+}
+__device__ __forceinline__ float rcp1(float p) {
+  float r = __builtin_amdgcn_rcpf(p);
+  return fmaf(r, fmaf(-p, r, 1.0f), r);
+}
+
+// global 64x64 tile (row-major, leading dimension ld) -> LDS [r*LDP + c], 16-byte loads, NT threads
+template <typename T, int NT>
+__device__ __forceinline__ void load_tile_lds(const T* __restrict__ G, int64_t ld, T* S) {
+  typedef typename Mfma<T>::vec_t vec_t;
+  constexpr int VEC = Mfma<T>::VEC, NV = TILE / VEC;
+#pragma unroll
+  for (int v = 0; v < TILE * NV / NT; ++v) {
+    int vi = threadIdx.x + v * NT;
+    int r = vi / NV, cv = vi % NV;
+    vec_t x = *reinterpret_cast<const vec_t*>(G + (int64_t)r * ld + cv * VEC);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) S[r * LDP + cv * VEC + e] = x[e];
+  }
+}
+
+// ---- 8-wave 64x64x64 product from LDS: wave w owns rows (w>>2)*32 + {0,16} + .., cols (w&3)*16 + .. ----
+template <typename T>
+struct Acc8 {
+  typename Mfma<T>::acc_t a[2];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[i][r] = T(0);
+  }
+};
+
+// acc += As(64 x 64, [r][k] stride LDP) * Bs(64 x 64 given as [c][k] stride LDP)^T
+template <typename T>
+__device__ __forceinline__ void mma8(const T* As, const T* Bs, Acc8<T>& acc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 2, wn = wave & 3;
+#pragma unroll 4
+  for (int kk = 0; kk < TILE / 4; ++kk) {
+    T a0 = As[(wm * 32 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    T a1 = As[(wm * 32 + 16 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    T b0 = Bs[(wn * 16 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    acc.a[0] = Mfma<T>::mma(a0, b0, acc.a[0]);
+    acc.a[1] = Mfma<T>::mma(a1, b0, acc.a[1]);
+  }
+}
+
+template <typename T, typename F>
+__device__ __forceinline__ void acc8_foreach(Acc8<T>& acc, F f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 2, wn = wave & 3;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) f(wm * 32 + mi * 16 + Mfma<T>::row(lane, r), wn * 16 + (lane & 15), acc.a[mi][r]);
+}
+
+// ---- 256-thread variant (the on-demand X row kernel keeps 4-wave workgroups because it uses gemm_tile) ----
+template <typename T>
+__device__ __forceinline__ void mma_lds64(const T* As, const T* Bs, Acc<T>& acc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+#pragma unroll 4
+  for (int kk = 0; kk < TILE / 4; ++kk) {
+    T a0 = As[(wm * 32 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    T a1 = As[(wm * 32 + 16 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    T b0 = Bs[(wn * 32 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    T b1 = Bs[(wn * 32 + 16 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    acc.a[0][0] = Mfma<T>::mma(a0, b0, acc.a[0][0]);
+    acc.a[0][1] = Mfma<T>::mma(a0, b1, acc.a[0][1]);
+    acc.a[1][0] = Mfma<T>::mma(a1, b0, acc.a[1][0]);
+    acc.a[1][1] = Mfma<T>::mma(a1, b1, acc.a[1][1]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Diagonal-tile factorisation.  Waves 0-3 (256 threads, cyclic 4x4 ownership: R = ti + 16 r, C = tj + 16 c) hold BOTH
+// the A sub-blocks and the sub-blocks of the running inverse M; waves 4-7 of the 512-thread workgroup only join the
+// barriers (they exist for the MFMA products around the factorisation).  Per round of 4 columns, with ONE barrier:
+//   owners publish the 4 raw panel columns + the 4 M rows; every active thread redundantly LDL'-factors the 4x4 pivot
+//   block, transforms the panel entries of its own rows / columns / M columns, and applies the rank-4 update.
+// (Measured alternatives, tools/bench_diag.py, f64 us per tile: one column per barrier 20-21; this scheme 14.5; pivot
+//  block + transforms done once by a dedicated wave and shared through a second barrier 16.7 -- the serial LDL' chain in
+//  a single wave costs more than the redundant work it saves.)
+// Scratch: PL[2][4][64] panel columns, MW[2][4][64] M rows (double-buffered: round r+1 publishes while stragglers of
+// round r may still be reading).
+// ---------------------------------------------------------------------------------------------------
+constexpr int SC_ELEMS = 2 * 2 * 4 * TILE;
+
+template <typename T, int J>
+__device__ __forceinline__ void chol_rounds(T (&a)[4][4], T (&g)[4][4], T* sc, T* piv, const bool act, const int ti,
+                                            const int tj) {
+#pragma unroll 1
+  for (int rr = 0; rr < 4; ++rr) {
+    const int jj0 = rr * 4, j0 = J * 16 + jj0;
+    T* P = sc + (rr & 1) * 4 * TILE;
+    T* Mw = sc + 2 * 4 * TILE + (rr & 1) * 4 * TILE;
+    if (act) {
+      const int qc = tj - jj0, qr = ti - jj0;
+      if (qc >= 0 && qc < 4) {
+#pragma unroll
+        for (int r = J; r < 4; ++r) {
+          T v = a[r][J];
+          if (r == J) v = (ti >= jj0) ? v : T(0);  // rows above the panel are dead
+          P[qc * TILE + ti + 16 * r] = v;
+        }
+      }
+      if (qr >= 0 && qr < 4) {
+#pragma unroll
+        for (int c = 0; c <= J; ++c) Mw[qr * TILE + tj + 16 * c] = g[J][c];
+      }
+    }
+    __syncthreads();
+    if (!act) continue;
+    // ---- 4x4 pivot block, LDL' (every active thread, redundantly) ----
+    const T d00 = P[j0], d10 = P[j0 + 1], d20 = P[j0 + 2], d30 = P[j0 + 3];
+    T d11 = P[TILE + j0 + 1], d21 = P[TILE + j0 + 2], d31 = P[TILE + j0 + 3];
+    T d22 = P[2 * TILE + j0 + 2], d32 = P[2 * TILE + j0 + 3], d33 = P[3 * TILE + j0 + 3];
+    const T r0 = rcp1(d00);
+    const T l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
+    d11 = fma(-l10, d10, d11);
+    d21 = fma(-l20, d10, d21);
+    d31 = fma(-l30, d10, d31);
+    d22 = fma(-l20, d20, d22);
+    d32 = fma(-l30, d20, d32);
+    d33 = fma(-l30, d30, d33);
+    const T r1 = rcp1(d11);
+    const T l21 = d21 * r1, l31 = d31 * r1;
+    d22 = fma(-l21, d21, d22);
+    d32 = fma(-l31, d21, d32);
+    d33 = fma(-l31, d31, d33);
+    const T r2 = rcp1(d22);
+    const T l32 = d32 * r2;
+    d33 = fma(-l32, d32, d33);
+    const T r3 = rcp1(d33);
+    if (ti == 0 && tj == 0) {
+      piv[j0] = d00;
+      piv[j0 + 1] = d11;
+      piv[j0 + 2] = d22;
+      piv[j0 + 3] = d33;
+    }
+    // ---- panel transforms for my columns / my M columns, then row by row: multipliers + rank-4 update ----
+    T u[4][4], mw[4][4];  // [q][c]
+#pragma unroll
+    for (int c = J; c < 4; ++c) {
+      const int x = tj + 16 * c;
+      T y0 = P[x], y1 = P[TILE + x], y2 = P[2 * TILE + x], y3 = P[3 * TILE + x];
+      y1 = fma(-l10, y0, y1);
+      y2 = fma(-l21, y1, fma(-l20, y0, y2));
+      y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, y3)));
+      u[0][c] = y0;
+      u[1][c] = y1;
+      u[2][c] = y2;
+      u[3][c] = y3;
+      if (c == J) {  // columns on/left of pivot q are frozen
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u[q][c] = (tj > jj0 + q) ? u[q][c] : T(0);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c <= J; ++c) {
+      const int x = tj + 16 * c;
+      T y0 = Mw[x], y1 = Mw[TILE + x], y2 = Mw[2 * TILE + x], y3 = Mw[3 * TILE + x];
+      y1 = fma(-l10, y0, y1);
+      y2 = fma(-l21, y1, fma(-l20, y0, y2));
+      y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, y3)));
+      mw[0][c] = y0;
+      mw[1][c] = y1;
+      mw[2][c] = y2;
+      mw[3][c] = y3;
+    }
+#pragma unroll
+    for (int r = J; r < 4; ++r) {
+      const int x = ti + 16 * r;
+      T y0 = P[x], y1 = P[TILE + x], y2 = P[2 * TILE + x], y3 = P[3 * TILE + x];
+      y1 = fma(-l10, y0, y1);
+      y2 = fma(-l21, y1, fma(-l20, y0, y2));
+      y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, y3)));
+      T f[4] = {y0 * r0, y1 * r1, y2 * r2, y3 * r3};
+      if (r == J) {  // rows on/above pivot q take no part in its rank-1 update
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = (ti > jj0 + q) ? f[q] : T(0);
+      }
+#pragma unroll
+      for (int c = J; c <= r; ++c) {
+        T s0 = a[r][c];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s0 = fma(-f[q], u[q][c], s0);
+        a[r][c] = s0;
+      }
+#pragma unroll
+      for (int c = 0; c <= J; ++c) {
+        T s0 = g[r][c];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s0 = fma(-f[q], mw[q][c], s0);
+        g[r][c] = s0;
+      }
+    }
+  }
+}
+
+// In: bufA = SPD tile [R*LDP + C] (lower triangle valid).  Out: bufA = L (strict upper zero), bufB = L^-1.
+// All threads of the (256- or 512-thread) workgroup must call.  info: first non-positive pivot (1-based global column).
+template <typename T>
+__device__ __forceinline__ void factor_diag_tile512(T* bufA, T* bufB, T* sc, T* piv, int32_t* info, int64_t col0,
+                                                    int64_t nvalid) {
+  const int tid = threadIdx.x;
+  const bool act = tid < 256;
+  const int ti = (tid & 255) >> 4, tj = tid & 15;
+  T a[4][4], g[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      int R = ti + 16 * r, Cc = tj + 16 * c;
+      int lo = R >= Cc ? R : Cc, hi = R >= Cc ? Cc : R;
+      a[r][c] = bufA[lo * LDP + hi];
+      g[r][c] = (R == Cc) ? T(1) : T(0);
+    }
+  __syncthreads();
+  chol_rounds<T, 0>(a, g, sc, piv, act, ti, tj);
+  chol_rounds<T, 1>(a, g, sc, piv, act, ti, tj);
+  chol_rounds<T, 2>(a, g, sc, piv, act, ti, tj);
+  chol_rounds<T, 3>(a, g, sc, piv, act, ti, tj);
+  __syncthreads();  // piv complete
+  if (tid < TILE) {
+    const T p = piv[tid];
+    const bool bad = !(p > T(0)) && (col0 + tid) < nvalid;
+    const unsigned long long mask = __ballot(bad);
+    if (mask != 0ull && tid == 0) {
+      int32_t want = (int32_t)(col0 + (__ffsll((long long)mask) - 1) + 1);
+      int32_t old = atomicCAS(info, 0, want);
+      while (old != 0 && old > want) {
+        int32_t prev = atomicCAS(info, old, want);
+        if (prev == old) break;
+        old = prev;
+      }
+    }
+  }
+  if (act) {
+    T rsC[4], rsR[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      T pc = piv[tj + 16 * q], pr = piv[ti + 16 * q];
+      rsC[q] = T(1) / sqrt(pc > T(0) ? pc : T(1));
+      rsR[q] = T(1) / sqrt(pr > T(0) ? pr : T(1));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        int R = ti + 16 * r, Cc = tj + 16 * c;
+        bufA[R * LDP + Cc] = (R >= Cc) ? a[r][c] * rsC[c] : T(0);
+        bufB[R * LDP + Cc] = (R >= Cc) ? g[r][c] * rsR[r] : T(0);
+      }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void tri_index(int64_t idx, int64_t& ti, int64_t& tj) {
+  // idx = ti*(ti+1)/2 + tj, tj <= ti
+  int64_t t = (int64_t)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+  while (t * (t + 1) / 2 > idx) --t;
+  while ((t + 1) * (t + 2) / 2 <= idx) ++t;
+  ti = t;
+  tj = idx - t * (t + 1) / 2;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launch S(k), k = 0..nt-1: grid = nP + nU, 512 threads
+//   nP = nt - k + ne  (block rows k..nt-1 of A, then the ne extension blocks)
+//   nU = k >= 1 ? T(nt-k-1) + ne*(nt-k-1) : 0
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(T* __restrict__ A, int64_t ld, T* __restrict__ X,
+                                                            int64_t ldx, T* __restrict__ Dg, T* __restrict__ E,
+                                                            int64_t lde, int64_t ne, int do_x, int64_t k, int64_t nt,
+                                                            int32_t* __restrict__ info, int64_t nvalid) {
+  __shared__ __attribute__((aligned(16))) T sm[3 * TILE * LDP];
+  __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
+  __shared__ T piv[TILE];
+  T* bufA = sm;
+  T* bufB = sm + TILE * LDP;
+  T* bufC = sm + 2 * TILE * LDP;
+  const int tid = threadIdx.x;
+  const int64_t nP = nt - k + ne;
+  const int64_t nr = nt - k - 1;
+  int64_t bid = blockIdx.x;
+  const int64_t d0 = k * TILE, p0 = (k - 1) * TILE;
+  if (bid < nP) {
+    // ---------------- P: panel of block column k ----------------
+    const int64_t b = bid;
+    const bool ext = b >= (nt - k);
+    T* rowp = ext ? E + (b - (nt - k)) * TILE * lde : A + (k + b) * TILE * ld;  // first row of this block row
+    const int64_t ldr = ext ? lde : ld;
+    Acc8<T> accD, accT;
+    accD.zero();
+    accT.zero();
+    if (k >= 1) {  // pending rank-64 update from column k-1
+      load_tile_lds<T, CHOL_THREADS>(A + d0 * ld + p0, ld, bufA);
+      if (b > 0) load_tile_lds<T, CHOL_THREADS>(rowp + p0, ldr, bufC);
+      __syncthreads();
+      mma8<T>(bufA, bufA, accD);
+      if (b > 0) mma8<T>(bufC, bufA, accT);
+      __syncthreads();
+    }
+    acc8_foreach<T>(accD, [&](int r, int c, T val) { bufA[r * LDP + c] = A[(d0 + r) * ld + d0 + c] - val; });
+    if (b > 0)  // own tile with the pending update applied, parked in LDS across the factorisation
+      acc8_foreach<T>(accT, [&](int r, int c, T val) { bufC[r * LDP + c] = rowp[r * ldr + d0 + c] - val; });
+    __syncthreads();
+    factor_diag_tile512<T>(bufA, bufB, sc, piv, info, d0, nvalid);
+    if (b == 0) {
+      for (int e = tid; e < TILE * TILE; e += CHOL_THREADS) {
+        int R = e >> 6, Cc = e & 63;
+        Dg[k * TILE * TILE + e] = bufA[R * LDP + Cc];
+        if (do_x) X[(d0 + R) * ldx + d0 + Cc] = bufB[R * LDP + Cc];
+      }
+      return;
+    }
+    Acc8<T> acc;  // L_ik = T_ik * Linv^T
+    acc.zero();
+    mma8<T>(bufC, bufB, acc);
+    acc8_foreach<T>(acc, [&](int r, int c, T val) { rowp[r * ldr + d0 + c] = val; });
+    return;
+  }
+  bid -= nP;
+  {
+    // ---------------- U: trailing update from column k-1, tiles (i, j) with j > k ----------------
+    const int64_t ntri = nr * (nr + 1) / 2;
+    T* rowp;
+    int64_t ldr, j0;
+    if (bid < ntri) {
+      int64_t ii, jj;
+      tri_index(bid, ii, jj);
+      rowp = A + (k + 1 + ii) * TILE * ld;
+      ldr = ld;
+      j0 = (k + 1 + jj) * TILE;
+    } else {
+      const int64_t t = bid - ntri, e = t / nr, jj = t % nr;
+      rowp = E + e * TILE * lde;
+      ldr = lde;
+      j0 = (k + 1 + jj) * TILE;
+    }
+    Acc8<T> acc;
+    acc.zero();
+    load_tile_lds<T, CHOL_THREADS>(rowp + p0, ldr, bufA);
+    load_tile_lds<T, CHOL_THREADS>(A + j0 * ld + p0, ld, bufB);
+    __syncthreads();
+    mma8<T>(bufA, bufB, acc);
+    acc8_foreach<T>(acc, [&](int r, int c, T val) { rowp[r * ldr + j0 + c] -= val; });
+  }
+}
+
+// Row q of X = L^-1 (on demand): X_qj = -X_qq sum_{i=j}^{q-1} L_qi X_ij, j < q.  grid = q, 256 threads.
+// Launched after S(q) (which stored X_qq); rows < q are complete by then.
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_trtri_row(const T* __restrict__ A, int64_t ld, T* __restrict__ X,
+                                                        int64_t ldx, int64_t q) {
+  __shared__ __attribute__((aligned(16))) T sm[2 * TILE * LDP];
+  static_assert(2 * TILE * LDP >= SMEM_ELEMS, "gemm staging must fit in bufA+bufB");
+  T* bufA = sm;
+  T* bufB = sm + TILE * LDP;
+  const int tid = threadIdx.x;
+  const int64_t j = blockIdx.x, q0 = q * TILE, j0 = j * TILE;
+  Acc<T> acc;
+  acc.zero();
+  gemm_tile<T, KC, RC>(A + q0 * ld, ld, X + j0, ldx, j0, q0, nullptr, acc, sm);
+  // stage S transposed (St[c][k]) and X_qq ([r][k]) for the 64-deep product
+  acc_foreach<T>(acc, [&](int r, int c, T val) { bufA[c * LDP + r] = val; });
+  for (int e = tid; e < TILE * TILE; e += NTHREADS) {
+    int R = e >> 6, Cc = e & 63;
+    bufB[R * LDP + Cc] = X[(q0 + R) * ldx + q0 + Cc];
+  }
+  __syncthreads();
+  Acc<T> out;
+  out.zero();
+  mma_lds64<T>(bufB, bufA, out);
+  acc_foreach<T>(out, [&](int r, int c, T val) { X[(q0 + r) * ldx + j0 + c] = -val; });
+}
+
+// copy the diagonal factors from Dg into the diagonal tiles of an n x n matrix (state export / building blocks)
+template <typename T>
+__global__ void k_publish_diag(T* __restrict__ A, int64_t ld, const T* __restrict__ Dg) {
+  const int64_t k = blockIdx.x;
+  for (int e = threadIdx.x; e < TILE * TILE; e += blockDim.x)
+    A[(k * TILE + (e >> 6)) * ld + k * TILE + (e & 63)] = Dg[k * TILE * TILE + e];
+}
+
+// micro-benchmark of the diagonal-tile factorisation alone (tools/bench_diag.py): `reps` factorizations per launch
+template <typename T>
+__global__ __launch_bounds__(CHOL_THREADS) void k_diag_bench(const T* __restrict__ A, T* __restrict__ out, int reps,
+                                                             int32_t* info) {
+  __shared__ __attribute__((aligned(16))) T sm[2 * TILE * LDP];
+  __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
+  __shared__ T piv[TILE];
+  T* bufA = sm;
+  T* bufB = sm + TILE * LDP;
+  for (int it = 0; it < reps; ++it) {
+    for (int e = threadIdx.x; e < TILE * TILE; e += CHOL_THREADS) bufA[(e >> 6) * LDP + (e & 63)] = A[e];
+    __syncthreads();
+    factor_diag_tile512<T>(bufA, bufB, sc, piv, info, 0, 64);
+  }
+  for (int e = threadIdx.x; e < TILE * TILE; e += CHOL_THREADS) {
+    out[blockIdx.x * 2 * TILE * TILE + e] = bufA[(e >> 6) * LDP + (e & 63)];
+    out[blockIdx.x * 2 * TILE * TILE + TILE * TILE + e] = bufB[(e >> 6) * LDP + (e & 63)];
+  }
+}
+
+}  // namespace agp

@@ -325,15 +325,20 @@ def train_(model: SVGP, X, y, iterations: int = 100, *, callback: Optional[Calla
         inf.HyperParametersUpdated = True
     model._chk(L.agp_svgp_refresh_K(h))
     local_iter = 1
+
+    def draw(it):  # StatsBase.sample(1:N, B; replace=false)  training.jl:51-53 (or the caller's stream)
+        if idx_stream is not None:
+            idx_np = np.asarray(idx_stream[it - 1], dtype=np.int64)
+            if idx_np.shape != (B,):
+                raise ValueError("idx_stream entries must have length batchsize")
+        else:
+            idx_np = model.rng.choice(N, B, replace=False).astype(np.int64)
+        return torch.as_tensor(idx_np, device=dev)
+
+    nxt = draw(1) if inf.stoch else None
     while True:
         if inf.stoch:
-            if idx_stream is not None:
-                idx_np = np.asarray(idx_stream[local_iter - 1], dtype=np.int64)
-                if idx_np.shape != (B,):
-                    raise ValueError("idx_stream entries must have length batchsize")
-            else:
-                idx_np = model.rng.choice(N, B, replace=False).astype(np.int64)
-            idx = torch.as_tensor(idx_np, device=dev)
+            idx = nxt
             idx_ptr = C.c_void_p(idx.data_ptr())
             model._keep = [idx]
         else:
@@ -342,6 +347,10 @@ def train_(model: SVGP, X, y, iterations: int = 100, *, callback: Optional[Calla
                                         idx_ptr, B, inf.rho))
         model.trained = True
         model._last_idx = idx_ptr
+        if inf.stoch and local_iter < iterations:  # look-ahead: next minibatch's kappa on the second stream
+            nxt = draw(local_iter + 1)
+            model._keep.append(nxt)
+            model._chk(L.agp_svgp_prefetch(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(nxt.data_ptr()), B))
         if callback is not None:
             callback(model, State(model), inf.n_iter)
         if model.verbose > 2 or (model.verbose > 1 and local_iter % 10 == 0):

@@ -125,6 +125,8 @@ def main():
         st = L.agp_svgp_cavi_step(h, xp, ld, yp, C.c_void_p(idx_all[i].data_ptr()), B, rho)
         if st != 0:
             capi.check(model._ctx, st)
+        if i + 1 < total:  # look-ahead: kappa of the next minibatch on the library's second stream
+            L.agp_svgp_prefetch(h, xp, ld, C.c_void_p(idx_all[i + 1].data_ptr()), B)
 
     for i in range(warm):
         step(i)

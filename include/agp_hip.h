@@ -166,6 +166,11 @@ agp_status agp_svgp_cavi_step(agp_svgp* h, const void* x, int64_t ldx, const voi
  *   step_global : natural-gradient step + (mu, Sigma) refresh      analyticVI.jl:229-246, inference.jl:25-28 */
 agp_status agp_svgp_step_local(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx,
                                int64_t B, double rho);
+/* Optional look-ahead: compute Knm / kappa of the NEXT minibatch (compute_kappa, latentgp.jl:209-215) on a second,
+ * library-owned stream so it overlaps the current step's latency-bound factorisation.  The next cavi_step /
+ * step_local called with the same (x, ldx, idx, B) adopts the result; any other call simply ignores it.  idx must stay
+ * valid until that step. */
+agp_status agp_svgp_prefetch(agp_svgp* h, const void* x, int64_t ldx, const int64_t* idx, int64_t B);
 agp_status agp_svgp_lsm_gamma(agp_svgp* h);
 agp_status agp_svgp_lsm_alpha(agp_svgp* h);
 agp_status agp_svgp_lsm_gsum_ptr(agp_svgp* h, void** ptr, int64_t* count);

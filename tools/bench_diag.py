@@ -10,10 +10,10 @@ f.restype = C.c_int32
 f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
 ctx = C.c_void_p()
 assert L.agp_ctx_create(0, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ctx)) == 0
-names = {0: "1col", 4: "4col-panel"}
+names = {0: "512thr"}
 for dt, dn in ((0, "f64"), (1, "f32")):
     for blocks in (1, 16):
-        for v in (0, 4):
+        for v in (0,):
             us = C.c_double()
             assert f(ctx, dt, v, blocks, 50, C.byref(us)) == 0
             print(f"{dn} blocks={blocks:3d} {names[v]:12s} {us.value:8.2f} us/tile  ({us.value*2.1e3/64:6.0f} cyc/col @2.1GHz)")

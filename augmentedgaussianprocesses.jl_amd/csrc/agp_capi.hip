@@ -92,13 +92,33 @@ static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* o
   return AGP_OK;
 }
 
+// S = A' diag(w) A (lower tiles mirrored), two k-groups per workgroup when the tile count underfills the chip
+template <typename T, int MODE>
+static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_t Kdim, const T* w, int lower_a, T* out,
+                          int64_t ldo, T* eta2, const T* Kinv, int64_t ldm, T lr) {
+  const int64_t nt = n / TILE, tiles = nt * (nt + 1) / 2;
+  if (tiles <= 320 && Kdim >= 4 * BK)
+    hipLaunchKernelGGL((k_syrk_tn<T, MODE, 2>), dim3((unsigned)tiles), dim3(2 * NTHREADS), 0, c->stream, A, lda, Kdim, w,
+                       lower_a, out, ldo, eta2, Kinv, ldm, lr);
+  else
+    hipLaunchKernelGGL((k_syrk_tn<T, MODE, 1>), dim3((unsigned)tiles), dim3(NTHREADS), 0, c->stream, A, lda, Kdim, w,
+                       lower_a, out, ldo, eta2, Kinv, ldm, lr);
+  LAUNCHCHK(c);
+  return AGP_OK;
+}
+
 template <typename T, int EPI>
 static agp_status gemm_nt(agp_ctx* c, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                           int tri_b, T* C, int64_t ldc, const T* E, int64_t lde, const T* v, T* p0, T* p1,
                           int64_t ldp) {
   dim3 g((unsigned)(N / TILE), (unsigned)(M / TILE));
-  hipLaunchKernelGGL((k_gemm_nt<T, EPI>), g, dim3(NTHREADS), 0, c->stream, A, lda, B, ldb, K, tri_b, C, ldc, E, lde, v,
-                     p0, p1, ldp);
+  // fewer tiles than ~1.25 waves of CUs: two k-groups per workgroup (2 waves per SIMD) instead of idle SIMD slots
+  if ((N / TILE) * (M / TILE) <= 320 && K >= 4 * BK)
+    hipLaunchKernelGGL((k_gemm_nt<T, EPI, 2>), g, dim3(2 * NTHREADS), 0, c->stream, A, lda, B, ldb, K, tri_b, C, ldc, E,
+                       lde, v, p0, p1, ldp);
+  else
+    hipLaunchKernelGGL((k_gemm_nt<T, EPI, 1>), g, dim3(NTHREADS), 0, c->stream, A, lda, B, ldb, K, tri_b, C, ldc, E, lde,
+                       v, p0, p1, ldp);
   LAUNCHCHK(c);
   return AGP_OK;
 }
@@ -640,15 +660,12 @@ struct Svgp : SvgpBase {
       if (fused) {
         hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, (int)(Bq / TILE), (const T*)cpart, mp,
                            (const T*)nullptr, (const T*)g.kinv_mu0, g.eta1, lr, (T*)nullptr);
-        hipLaunchKernelGGL((k_syrk_tn<T, SY_ETA2>), dim3((unsigned)(nt * (nt + 1) / 2)), dim3(NTHREADS), 0, st(),
-                           (const T*)g.kappa, mp, Bq, (const T*)(wbuf + l * Bp), 0, g.La, mp, g.eta2, (const T*)g.Kinv,
-                           mp, lr);
+        AGPCHK((syrk_tn<T, SY_ETA2>(ctx, g.kappa, mp, mp, Bq, wbuf + l * Bp, 0, g.La, mp, g.eta2, g.Kinv, mp, lr)));
       } else {
         hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, (int)(Bq / TILE), (const T*)cpart, mp,
                            (const T*)nullptr, (const T*)nullptr, (T*)nullptr, lr, sl);
-        hipLaunchKernelGGL((k_syrk_tn<T, SY_STORE>), dim3((unsigned)(nt * (nt + 1) / 2)), dim3(NTHREADS), 0, st(),
-                           (const T*)g.kappa, mp, Bq, (const T*)(wbuf + l * Bp), 0, sl + mp, mp, (T*)nullptr,
-                           (const T*)nullptr, (int64_t)0, T(0));
+        AGPCHK((syrk_tn<T, SY_STORE>(ctx, g.kappa, mp, mp, Bq, wbuf + l * Bp, 0, sl + mp, mp, (T*)nullptr,
+                                     (const T*)nullptr, (int64_t)0, T(0))));
       }
       LAUNCHCHK(ctx);
     }

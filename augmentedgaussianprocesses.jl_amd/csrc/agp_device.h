@@ -155,37 +155,72 @@ __device__ __forceinline__ void mma_slab(const T* As, const T* Bs, Acc<T>& acc, 
 
 // C_tile(64x64) += sum_{k in [kBegin,kEnd)} A(row,k) * B(col,k) ; kBegin/kEnd multiples of BK.
 // A, B already point at their 64-row origin (see TileIO::load).  wscaleA folds diag(w) into A (RC only).
-// smem: SMEM_ELEMS elements.  All 256 threads must call; ends with a barrier (smem reusable after return).
-template <typename T, typename LA, typename LB>
+// KG = 1: 256 threads.  KG = 2: 512 threads = two k-groups of 4 waves; group g takes slabs g, g+2, ... into its own
+// LDS staging area and group 1's accumulators are added to group 0's through LDS at the end (deterministic) -- used when
+// a problem has fewer 64x64 tiles than the chip has CUs, to put two waves on every SIMD.
+// smem: KG*SMEM_ELEMS elements.  All threads must call; on return only group 0 (threadIdx.x < 256) holds the result.
+template <typename T, typename LA, typename LB, int KG = 1>
 __device__ __forceinline__ void gemm_tile(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
                                           int64_t kBegin, int64_t kEnd, const T* __restrict__ wscaleA, Acc<T>& acc,
-                                          T* smem) {
-  const int tid = threadIdx.x;
+                                          T* smem_all) {
+  const int tid = threadIdx.x & (NTHREADS - 1);
+  const int grp = (KG > 1) ? (threadIdx.x >> 8) : 0;
   const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  T* smem = smem_all + grp * SMEM_ELEMS;
   typename TileIO<T, LA>::Regs ra;
   typename TileIO<T, LB>::Regs rb;
   if (kBegin >= kEnd) return;
-  TileIO<T, LA>::load(ra, A, lda, kBegin, tid);
-  TileIO<T, LB>::load(rb, B, ldb, kBegin, tid);
-  TileIO<T, LA>::store(ra, smem, tid, wscaleA, kBegin);
-  TileIO<T, LB>::store(rb, smem + OPER_ELEMS, tid, nullptr, kBegin);
+  const int64_t nslab = (kEnd - kBegin) / BK;
+  const int64_t niter = (nslab + KG - 1) / KG;
+  auto slab_k = [&](int64_t it) { return kBegin + (it * KG + grp) * BK; };
+  bool have = grp < nslab;
+  if (have) {
+    TileIO<T, LA>::load(ra, A, lda, slab_k(0), tid);
+    TileIO<T, LB>::load(rb, B, ldb, slab_k(0), tid);
+    TileIO<T, LA>::store(ra, smem, tid, wscaleA, slab_k(0));
+    TileIO<T, LB>::store(rb, smem + OPER_ELEMS, tid, nullptr, slab_k(0));
+  }
   __syncthreads();
   int cur = 0;
-  for (int64_t k0 = kBegin; k0 < kEnd; k0 += BK) {
-    const bool more = (k0 + BK) < kEnd;
+  for (int64_t it = 0; it < niter; ++it) {
+    const bool more = ((it + 1) * KG + grp) < nslab;
     if (more) {
-      TileIO<T, LA>::load(ra, A, lda, k0 + BK, tid);
-      TileIO<T, LB>::load(rb, B, ldb, k0 + BK, tid);
+      TileIO<T, LA>::load(ra, A, lda, slab_k(it + 1), tid);
+      TileIO<T, LB>::load(rb, B, ldb, slab_k(it + 1), tid);
     }
-    const T* As = smem + cur * 2 * OPER_ELEMS;
-    mma_slab<T, LA, LB>(As, As + OPER_ELEMS, acc, wm, wn, lane);
+    if (have) {
+      const T* As = smem + cur * 2 * OPER_ELEMS;
+      mma_slab<T, LA, LB>(As, As + OPER_ELEMS, acc, wm, wn, lane);
+    }
     if (more) {
       T* Ns = smem + (cur ^ 1) * 2 * OPER_ELEMS;
-      TileIO<T, LA>::store(ra, Ns, tid, wscaleA, k0 + BK);
-      TileIO<T, LB>::store(rb, Ns + OPER_ELEMS, tid, nullptr, k0 + BK);
+      TileIO<T, LA>::store(ra, Ns, tid, wscaleA, slab_k(it + 1));
+      TileIO<T, LB>::store(rb, Ns + OPER_ELEMS, tid, nullptr, slab_k(it + 1));
     }
+    have = more;
     __syncthreads();
     cur ^= 1;
+  }
+  if (KG > 1) {
+    // group 1 -> LDS -> group 0 (64x64 values fit in one staging area)
+    T* red = smem_all;
+    if (grp == 1) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[((mi * 2 + ni) * 4 + r) * NTHREADS + tid] = acc.a[mi][ni][r];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc.a[mi][ni][r] += red[((mi * 2 + ni) * 4 + r) * NTHREADS + tid];
+    }
   }
 }
 

@@ -25,19 +25,20 @@ namespace agp {
 // ---------------------------------------------------------------------------------------------------
 enum { EPI_STORE = 0, EPI_KAPPA = 1, EPI_W = 2, EPI_ROWDOT = 3, EPI_EMINUS = 4 };
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(NTHREADS) void k_gemm_nt(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+template <typename T, int EPI, int KG = 1>
+__global__ __launch_bounds__(NTHREADS * KG) void k_gemm_nt(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
                                                       int64_t ldb, int64_t K, int tri_b, T* __restrict__ C,
                                                       int64_t ldc, const T* __restrict__ E, int64_t lde,
                                                       const T* __restrict__ v, T* __restrict__ part0,
                                                       T* __restrict__ part1, int64_t ldp) {
-  __shared__ __attribute__((aligned(16))) T smem[SMEM_ELEMS];
+  __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
   const int64_t bn = blockIdx.x, bm = blockIdx.y;
   const int64_t r0 = bm * TILE, c0 = bn * TILE;
   Acc<T> acc;
   acc.zero();
   int64_t kEnd = tri_b ? ((c0 + TILE) < K ? (c0 + TILE) : K) : K;
-  gemm_tile<T, KC, KC>(A + r0 * lda, lda, B + c0 * ldb, ldb, 0, kEnd, nullptr, acc, smem);
+  gemm_tile<T, KC, KC, KG>(A + r0 * lda, lda, B + c0 * ldb, ldb, 0, kEnd, nullptr, acc, smem);
+  if (KG > 1 && threadIdx.x >= NTHREADS) return;  // the second k-group has handed its partial sums over
   if (EPI == EPI_STORE) {
     acc_foreach<T>(acc, [&](int r, int c, T val) { C[(r0 + r) * ldc + c0 + c] = val; });
   }
@@ -81,19 +82,20 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_nt(const T* __restrict__ A, i
 // ---------------------------------------------------------------------------------------------------
 enum { SY_STORE = 0, SY_ETA2 = 1 };
 
-template <typename T, int MODE>
-__global__ __launch_bounds__(NTHREADS) void k_syrk_tn(const T* __restrict__ A, int64_t lda, int64_t Kdim,
+template <typename T, int MODE, int KG = 1>
+__global__ __launch_bounds__(NTHREADS * KG) void k_syrk_tn(const T* __restrict__ A, int64_t lda, int64_t Kdim,
                                                       const T* __restrict__ w, int lower_a, T* __restrict__ out,
                                                       int64_t ldo, T* __restrict__ eta2, const T* __restrict__ Kinv,
                                                       int64_t ldm, T lr) {
-  __shared__ __attribute__((aligned(16))) T smem[SMEM_ELEMS];
+  __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
   int64_t ta, tb;
   tri_index(blockIdx.x, ta, tb);
   const int64_t a0 = ta * TILE, b0 = tb * TILE;
   Acc<T> acc;
   acc.zero();
   int64_t kBegin = lower_a ? a0 : 0;
-  gemm_tile<T, RC, RC>(A + a0, lda, A + b0, lda, kBegin, Kdim, w, acc, smem);
+  gemm_tile<T, RC, RC, KG>(A + a0, lda, A + b0, lda, kBegin, Kdim, w, acc, smem);
+  if (KG > 1 && threadIdx.x >= NTHREADS) return;
   if (MODE == SY_STORE) {
     acc_foreach<T>(acc, [&](int r, int c, T val) {
       int64_t gr = a0 + r, gc = b0 + c;

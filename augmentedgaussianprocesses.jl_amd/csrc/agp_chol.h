@@ -77,13 +77,33 @@ __device__ __forceinline__ void mma8(const T* As, const T* Bs, Acc8<T>& acc) {
   }
 }
 
+// acc -= As * Bs^T  (the subtraction rides on the negated A operand)
+template <typename T>
+__device__ __forceinline__ void mma8_sub(const T* As, const T* Bs, Acc8<T>& acc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 2, wn = wave & 3;
+#pragma unroll 4
+  for (int kk = 0; kk < TILE / 4; ++kk) {
+    T a0 = -As[(wm * 32 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    T a1 = -As[(wm * 32 + 16 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    T b0 = Bs[(wn * 16 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    acc.a[0] = Mfma<T>::mma(a0, b0, acc.a[0]);
+    acc.a[1] = Mfma<T>::mma(a1, b0, acc.a[1]);
+  }
+}
+
+// visit the accumulator elements of this thread: f(row_in_tile, col_in_tile, value&) ; ext-vector lanes cannot bind to
+// references, so each element goes through a scalar temporary
 template <typename T, typename F>
 __device__ __forceinline__ void acc8_foreach(Acc8<T>& acc, F f) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 2, wn = wave & 3;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) f(wm * 32 + mi * 16 + Mfma<T>::row(lane, r), wn * 16 + (lane & 15), acc.a[mi][r]);
+    for (int r = 0; r < 4; ++r) {
+      T t = acc.a[mi][r];
+      f(wm * 32 + mi * 16 + Mfma<T>::row(lane, r), wn * 16 + (lane & 15), t);
+      acc.a[mi][r] = t;
+    }
 }
 
 // ---- 256-thread variant (the on-demand X row kernel keeps 4-wave workgroups because it uses gemm_tile) ----
@@ -324,19 +344,21 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(T* __restrict__ A, i
     T* rowp = ext ? E + (b - (nt - k)) * TILE * lde : A + (k + b) * TILE * ld;  // first row of this block row
     const int64_t ldr = ext ? lde : ld;
     Acc8<T> accD, accT;
-    accD.zero();
-    accT.zero();
-    if (k >= 1) {  // pending rank-64 update from column k-1
+    // the tiles to be updated are fetched first (MFMA accumulator layout) so their HBM/L2 latency overlaps the loads
+    // and products of the pending update instead of following them
+    acc8_foreach<T>(accD, [&](int r, int c, T& val) { val = A[(d0 + r) * ld + d0 + c]; });
+    if (b > 0) acc8_foreach<T>(accT, [&](int r, int c, T& val) { val = rowp[r * ldr + d0 + c]; });
+    if (k >= 1) {  // pending rank-64 update from column k-1: acc = tile - L L'
       load_tile_lds<T, CHOL_THREADS>(A + d0 * ld + p0, ld, bufA);
       if (b > 0) load_tile_lds<T, CHOL_THREADS>(rowp + p0, ldr, bufC);
       __syncthreads();
-      mma8<T>(bufA, bufA, accD);
-      if (b > 0) mma8<T>(bufC, bufA, accT);
+      mma8_sub<T>(bufA, bufA, accD);
+      if (b > 0) mma8_sub<T>(bufC, bufA, accT);
       __syncthreads();
     }
-    acc8_foreach<T>(accD, [&](int r, int c, T val) { bufA[r * LDP + c] = A[(d0 + r) * ld + d0 + c] - val; });
+    acc8_foreach<T>(accD, [&](int r, int c, T& val) { bufA[r * LDP + c] = val; });
     if (b > 0)  // own tile with the pending update applied, parked in LDS across the factorisation
-      acc8_foreach<T>(accT, [&](int r, int c, T val) { bufC[r * LDP + c] = rowp[r * ldr + d0 + c] - val; });
+      acc8_foreach<T>(accT, [&](int r, int c, T& val) { bufC[r * LDP + c] = val; });
     __syncthreads();
     factor_diag_tile512<T>(bufA, bufB, sc, piv, info, d0, nvalid);
     if (b == 0) {
@@ -350,7 +372,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(T* __restrict__ A, i
     Acc8<T> acc;  // L_ik = T_ik * Linv^T
     acc.zero();
     mma8<T>(bufC, bufB, acc);
-    acc8_foreach<T>(acc, [&](int r, int c, T val) { rowp[r * ldr + d0 + c] = val; });
+    acc8_foreach<T>(acc, [&](int r, int c, T& val) { rowp[r * ldr + d0 + c] = val; });
     return;
   }
   bid -= nP;
@@ -372,12 +394,12 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(T* __restrict__ A, i
       j0 = (k + 1 + jj) * TILE;
     }
     Acc8<T> acc;
-    acc.zero();
+    acc8_foreach<T>(acc, [&](int r, int c, T& val) { val = rowp[r * ldr + j0 + c]; });
     load_tile_lds<T, CHOL_THREADS>(rowp + p0, ldr, bufA);
     load_tile_lds<T, CHOL_THREADS>(A + j0 * ld + p0, ld, bufB);
     __syncthreads();
-    mma8<T>(bufA, bufB, acc);
-    acc8_foreach<T>(acc, [&](int r, int c, T val) { rowp[r * ldr + j0 + c] -= val; });
+    mma8_sub<T>(bufA, bufB, acc);
+    acc8_foreach<T>(acc, [&](int r, int c, T& val) { rowp[r * ldr + j0 + c] = val; });
   }
 }
 

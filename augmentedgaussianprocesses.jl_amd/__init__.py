@@ -24,7 +24,9 @@ from .likelihoods import (  # noqa: F401
     StudentTLikelihood,
 )
 from .svgp import (  # noqa: F401
+    ADAM,
     ELBO,
+    MOSVGP,
     SVGP,
     AnalyticSVI,
     AnalyticVI,

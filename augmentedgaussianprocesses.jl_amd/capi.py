@@ -24,7 +24,7 @@ ERR_NAMES = {
 }
 F64, F32 = 0, 1
 K_SQEXP, K_MATERN52, K_MATERN32, K_EXPONENTIAL = 0, 1, 2, 3
-LIK_GAUSSIAN, LIK_LOGISTIC, LIK_STUDENTT, LIK_LOGISTICSOFTMAX = 0, 1, 2, 3
+LIK_GAUSSIAN, LIK_LOGISTIC, LIK_STUDENTT, LIK_LOGISTICSOFTMAX, LIK_MULTIOUTPUT = 0, 1, 2, 3, 4
 ELBO_CORRECTED, ELBO_REFERENCE = 0, 1
 MAT_L, MAT_KINV, MAT_KNM, MAT_KAPPA, VEC_KTILDE, VEC_MEAN_F, VEC_VAR_F, VEC_THETA, VEC_C, VEC_GAMMA, VEC_ALPHA = range(11)
 
@@ -87,6 +87,8 @@ SYMBOLS = {
     "agp_svgp_get_opt_state": (_I32, [_VP, _PI64]),
     "agp_svgp_cavi_step": (_I32, [_VP, _VP, _I64, _VP, _VP, _I64, _DBL]),
     "agp_svgp_step_local": (_I32, [_VP, _VP, _I64, _VP, _VP, _I64, _DBL]),
+    "agp_svgp_set_multioutput": (_I32, [_VP, _I32, C.POINTER(LikDesc), _PDBL, _DBL, _DBL, _DBL, _DBL]),
+    "agp_svgp_get_A": (_I32, [_VP, _PDBL]),
     "agp_svgp_prefetch": (_I32, [_VP, _VP, _I64, _VP, _I64]),
     "agp_svgp_lsm_gamma": (_I32, [_VP]),
     "agp_svgp_lsm_alpha": (_I32, [_VP]),

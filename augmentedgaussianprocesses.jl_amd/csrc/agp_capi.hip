@@ -143,6 +143,9 @@ struct SvgpBase {
   virtual agp_status step_local(const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B, double rho,
                                 bool fresh) = 0;
   virtual agp_status prefetch(const void* x, int64_t ldx, const int64_t* idx, int64_t B) = 0;
+  virtual agp_status set_multioutput(int n_task, const agp_lik_desc* liks, const double* A_host, double eta, double b1,
+                                     double b2, double eps) = 0;
+  virtual agp_status get_A(double* A_host) = 0;
   virtual agp_status lsm_gamma() = 0;
   virtual agp_status lsm_alpha() = 0;
   virtual agp_status lsm_gsum_ptr(void** p, int64_t* n) = 0;
@@ -244,6 +247,16 @@ struct Svgp : SvgpBase {
   LikParams<T> lp{};
   // shared batch buffers
   T *pw0 = nullptr, *pw1 = nullptr;  // row-statistic scratch [ldp]
+  // multi-output mode (MOSVGP): n_task likelihoods over A-mixed latents
+  bool mo = false;
+  MoCfg<T> mocfg{};
+  int nT = 0;
+  int64_t ystride = 0;
+  T* A_dev = nullptr;
+  double *gradA_dev = nullptr, *am_dev = nullptr, *av_dev = nullptr;
+  int a_step = 0;
+  double a_eta = 0, a_b1 = 0.9, a_b2 = 0.999, a_eps = 1e-8;
+  T *mo_mixm = nullptr, *mo_mixv = nullptr, *mo_th = nullptr, *mo_cc = nullptr, *mo_th_save = nullptr;
   // prefetch of the next minibatch's Knm / kappa on a second stream (overlaps the latency-bound factorisation)
   hipStream_t pf_stream = nullptr;
   hipEvent_t pf_done = nullptr, step_done[2] = {nullptr, nullptr};
@@ -295,7 +308,7 @@ struct Svgp : SvgpBase {
     lp.kind = desc.lik.kind;
     lp.p0 = (T)desc.lik.p0;
     lp.p1 = (T)desc.lik.p1;
-    if (lp.kind < 0 || lp.kind > AGP_LIK_LOGISTICSOFTMAX) {
+    if (lp.kind < 0 || lp.kind > AGP_LIK_MULTIOUTPUT) {
       ctx->err = "likelihood not implemented for AnalyticVI on this path";
       return AGP_ERR_UNSUPPORTED;
     }
@@ -304,7 +317,7 @@ struct Svgp : SvgpBase {
       ctx->err = "nu should be greater than 0.5";  // studentt.jl:28
       return AGP_ERR_INVALID;
     }
-    if (lp.kind != AGP_LIK_LOGISTICSOFTMAX && nl != 1) return AGP_ERR_INVALID;
+    if (lp.kind != AGP_LIK_LOGISTICSOFTMAX && lp.kind != AGP_LIK_MULTIOUTPUT && nl != 1) return AGP_ERR_INVALID;
     if (desc.stochastic && !(desc.rm_kappa > 0.5 && desc.rm_kappa <= 1.0 && desc.rm_tau > 0)) {
       ctx->err = "RobbinsMonro: kappa in (0.5,1], tau > 0";  // optimisers.jl:7-8
       return AGP_ERR_INVALID;
@@ -356,7 +369,7 @@ struct Svgp : SvgpBase {
     AGPCHK(dmalloc(ctx, &lr_dev, 1));
     AGPCHK(dmalloc(ctx, &info_dev, 1));
     AGPCHK(dmalloc(ctx, &flags_dev, 1));
-    AGPCHK(dmalloc(ctx, &scal_dev, 16));
+    AGPCHK(dmalloc(ctx, &scal_dev, 64));
     HIPCHK(ctx, hipMemsetAsync(info_dev, 0, sizeof(int32_t), st()));
     HIPCHK(ctx, hipMemsetAsync(flags_dev, 0, sizeof(int), st()));
     // LogisticSoftMax state: alpha = beta = K (total classes)  logisticsoftmax.jl:43-53
@@ -383,6 +396,12 @@ struct Svgp : SvgpBase {
     T* ps[] = {pw0, pw1, Kt, muf, varf, cbuf, theta, gamma, rbuf, wbuf, alpha, beta, gsum, alpha_save, emuf,
                evarf, cpart, stats, Tw, Tw2, tmpv, lr_dev, Kstar, ppm, ppv, pmu, pvar};
     for (T* p : ps)
+      if (p) (void)hipFree(p);
+    T* mops[] = {A_dev, mo_mixm, mo_mixv, mo_th, mo_cc, mo_th_save, mo_pmu, mo_pvar};
+    for (T* p : mops)
+      if (p) (void)hipFree(p);
+    double* dps[] = {gradA_dev, am_dev, av_dev};
+    for (double* p : dps)
       if (p) (void)hipFree(p);
     if (info_dev) (void)hipFree(info_dev);
     if (flags_dev) (void)hipFree(flags_dev);
@@ -565,6 +584,85 @@ struct Svgp : SvgpBase {
     B_last = B;
     ldx_last = ldx;
     rho_last = rho;
+    if (lp.kind == AGP_LIK_MULTIOUTPUT) {
+      if (!mo) {
+        ctx->err = "multi-output handle: call agp_svgp_set_multioutput first";
+        return AGP_ERR_INVALID;
+      }
+      AGPCHK(mo_local(y, idx, B, rho, !fresh));
+    }
+    return AGP_OK;
+  }
+
+  // MOSVGP(kernel, likelihoods, inference, Zs; Aoptimiser)  src/models/MOSVGP.jl:33-115 : install the task likelihoods,
+  // the mixing weights A (n_task x n_latent, rows normalised by the caller like MOSVGP.jl:101-104) and the A optimiser.
+  agp_status set_multioutput(int n_task, const agp_lik_desc* liks, const double* A_host, double eta, double b1,
+                             double b2, double eps) override {
+    if (lp.kind != AGP_LIK_MULTIOUTPUT || n_task <= 0 || n_task > MO_MAXT || !liks || !A_host) return AGP_ERR_INVALID;
+    for (int t = 0; t < n_task; ++t) {
+      if (liks[t].kind < AGP_LIK_GAUSSIAN || liks[t].kind > AGP_LIK_STUDENTT) {
+        ctx->err = "multi-output tasks support the Gaussian / Logistic / StudentT likelihoods on this path";
+        return AGP_ERR_UNSUPPORTED;
+      }
+      mocfg.kind[t] = liks[t].kind;
+      mocfg.p0[t] = (T)liks[t].p0;
+      mocfg.p1[t] = (T)liks[t].p1;
+    }
+    nT = n_task;
+    mocfg.nT = n_task;
+    ystride = n_task;  // targets are point-major: y[i * n_task + t]
+    a_eta = eta;
+    a_b1 = b1;
+    a_b2 = b2;
+    a_eps = eps;
+    a_step = 0;
+    if (!A_dev) {
+      AGPCHK(dmalloc(ctx, &A_dev, (int64_t)MO_MAXT * nl));
+      AGPCHK(dmalloc(ctx, &gradA_dev, (int64_t)MO_MAXT * nl));
+      AGPCHK(dmalloc(ctx, &am_dev, (int64_t)MO_MAXT * nl));
+      AGPCHK(dmalloc(ctx, &av_dev, (int64_t)MO_MAXT * nl));
+      T** bv[] = {&mo_mixm, &mo_mixv, &mo_th, &mo_cc, &mo_th_save};
+      for (auto p : bv) AGPCHK(dmalloc(ctx, p, (int64_t)MO_MAXT * Bp));
+    }
+    std::vector<T> ha((size_t)n_task * nl);
+    for (size_t i = 0; i < ha.size(); ++i) ha[i] = (T)A_host[i];
+    HIPCHK(ctx, hipMemcpyAsync(A_dev, ha.data(), sizeof(T) * ha.size(), hipMemcpyHostToDevice, st()));
+    HIPCHK(ctx, hipMemsetAsync(am_dev, 0, sizeof(double) * MO_MAXT * nl, st()));
+    HIPCHK(ctx, hipMemsetAsync(av_dev, 0, sizeof(double) * MO_MAXT * nl, st()));
+    HIPCHK(ctx, hipMemsetAsync(mo_cc, 0, sizeof(T) * MO_MAXT * Bp, st()));
+    // local variables before the first step (init_local_vars): theta = 1/sigma2 (Gaussian) or 0
+    for (int t = 0; t < n_task; ++t)
+      hipLaunchKernelGGL((k_fill<T>), grid1(Bp), dim3(256), 0, st(), mo_th + (int64_t)t * Bp, Bp,
+                         liks[t].kind == AGP_LIK_GAUSSIAN ? (T)(1.0 / liks[t].p0) : T(0));
+    LAUNCHCHK(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(st()));
+    mo = true;
+    return AGP_OK;
+  }
+
+  agp_status get_A(double* A_host) override {
+    if (!mo || !A_host) return AGP_ERR_INVALID;
+    std::vector<T> ha((size_t)nT * nl);
+    HIPCHK(ctx, hipMemcpyAsync(ha.data(), A_dev, sizeof(T) * ha.size(), hipMemcpyDeviceToHost, st()));
+    HIPCHK(ctx, hipStreamSynchronize(st()));
+    for (size_t i = 0; i < ha.size(); ++i) A_host[i] = (double)ha[i];
+    return AGP_OK;
+  }
+
+  // update_A! then the mixed local updates / gradients (update_parameters!(::MOSVGP), training.jl:153-158)
+  agp_status mo_local(const void* y, const int64_t* idx, int64_t B, double rho, bool update_A) {
+    if (update_A && a_eta > 0) {
+      a_step += 1;
+      hipLaunchKernelGGL((k_mo_gradA<T>), dim3((unsigned)nl, (unsigned)nT), dim3(256), 0, st(), B, nl, Bp, mocfg,
+                         (const T*)A_dev, (const T*)y, ystride, idx, (const T*)muf, (const T*)varf, (const T*)mo_th,
+                         gradA_dev);
+      hipLaunchKernelGGL((k_mo_applyA<T>), dim3(1), dim3(64), 0, st(), nT, nl, A_dev, (const double*)gradA_dev, am_dev,
+                         av_dev, a_step, a_eta, a_b1, a_b2, a_eps);
+    }
+    hipLaunchKernelGGL((k_mo_local<T>), grid1(B), dim3(256), 0, st(), B, nl, Bp, mocfg, (const T*)A_dev, (T)rho,
+                       (const T*)y, ystride, idx, (const T*)muf, (const T*)varf, mo_mixm, mo_mixv, mo_th, mo_cc, rbuf,
+                       wbuf, 1);
+    LAUNCHCHK(ctx);
     return AGP_OK;
   }
 
@@ -779,6 +877,7 @@ struct Svgp : SvgpBase {
         HIPCHK(ctx, hipMemcpyAsync(alpha_save, alpha, sizeof(T) * Bp, hipMemcpyDeviceToDevice, st()));
         hipLaunchKernelGGL((k_fill<T>), grid1(Bp), dim3(256), 0, st(), alpha, Bp, (T)desc.lik.n_class);
       }
+      if (mo) HIPCHK(ctx, hipMemcpyAsync(mo_th_save, mo_th, sizeof(T) * MO_MAXT * Bp, hipMemcpyDeviceToDevice, st()));
       AGPCHK(step_local(x, ldx, y, idx, B, rho, true));
       if (lsm) {
         for (int it = 0; it < 2; ++it) {
@@ -811,10 +910,35 @@ struct Svgp : SvgpBase {
       mf = emuf;
       vf = evarf;
     }
-    hipLaunchKernelGGL((k_elbo_terms<T>), dim3(1), dim3(1024), 0, st(), B, nl, Bp, lp, desc.elbo_mode, desc.latent_offset,
-                       (int)(desc.latent_offset == 0), (const T*)y, (const int32_t*)y, idx, mf, vf, (const T*)cbuf,
-                       (const T*)theta, (const T*)gamma, (const T*)alpha, (const T*)beta, scal_dev);
-    LAUNCHCHK(ctx);
+    if (mo) {
+      // multi-output ELBO (analyticVI.jl:277-297): per-task terms on the A-mixed mean_f / var_f
+      if (!fresh)
+        hipLaunchKernelGGL((k_mo_local<T>), grid1(B), dim3(256), 0, st(), B, nl, Bp, mocfg, (const T*)A_dev, (T)rho,
+                           (const T*)y, ystride, idx, mf, vf, mo_mixm, mo_mixv, mo_th, mo_cc, rbuf, wbuf, 0);
+      for (int t = 0; t < nT; ++t) {
+        LikParams<T> lt{mocfg.kind[t], mocfg.p0[t], mocfg.p1[t]};
+        hipLaunchKernelGGL((k_elbo_terms<T>), dim3(1), dim3(1024), 0, st(), B, 1, Bp, lt, desc.elbo_mode, 0, 0,
+                           (const T*)y + t, (const int32_t*)nullptr, idx,
+                           (const T*)(mo_mixm + (int64_t)t * Bp), (const T*)(mo_mixv + (int64_t)t * Bp),
+                           (const T*)(mo_cc + (int64_t)t * Bp), (const T*)(mo_th + (int64_t)t * Bp), (const T*)nullptr,
+                           (const T*)nullptr, (const T*)nullptr, scal_dev + 8 + 2 * t, (int64_t)nT);
+      }
+      LAUNCHCHK(ctx);
+      std::vector<double> ht(2 * nT);
+      HIPCHK(ctx, hipMemcpyAsync(ht.data(), scal_dev + 8, sizeof(double) * 2 * nT, hipMemcpyDeviceToHost, st()));
+      HIPCHK(ctx, hipStreamSynchronize(st()));
+      mo_e = mo_kl = 0.0;
+      for (int t = 0; t < nT; ++t) {
+        mo_e += ht[2 * t];
+        mo_kl += ht[2 * t + 1];
+      }
+      if (fresh) HIPCHK(ctx, hipMemcpyAsync(mo_th, mo_th_save, sizeof(T) * MO_MAXT * Bp, hipMemcpyDeviceToDevice, st()));
+    } else {
+      hipLaunchKernelGGL((k_elbo_terms<T>), dim3(1), dim3(1024), 0, st(), B, nl, Bp, lp, desc.elbo_mode,
+                         desc.latent_offset, (int)(desc.latent_offset == 0), (const T*)y, (const int32_t*)y, idx, mf, vf,
+                         (const T*)cbuf, (const T*)theta, (const T*)gamma, (const T*)alpha, (const T*)beta, scal_dev, (int64_t)1);
+      LAUNCHCHK(ctx);
+    }
     if (fresh && lsm)
       HIPCHK(ctx, hipMemcpyAsync(alpha, alpha_save, sizeof(T) * Bp, hipMemcpyDeviceToDevice, st()));
     // GaussianKL per latent (KLdivergences.jl:11-18)
@@ -835,8 +959,8 @@ struct Svgp : SvgpBase {
       HIPCHK(ctx, hipMemcpyAsync(h, scal_dev, sizeof(double) * 5, hipMemcpyDeviceToHost, st()));
       HIPCHK(ctx, hipStreamSynchronize(st()));
       if (l == 0) {
-        e_data = h[0];
-        kl_aug = h[1];
+        e_data = mo ? mo_e : h[0];
+        kl_aug = mo ? mo_kl : h[1];
       }
       const double logdetK = 2.0 * g.half_logdetK, logdetS = -2.0 * h[2];
       kl_gauss += 0.5 * (logdetK - logdetS + h[3] + h[4] - (double)m);
@@ -844,7 +968,7 @@ struct Svgp : SvgpBase {
     *out = rho * e_data - kl_gauss - rho * kl_aug;
     return AGP_OK;
   }
-  double e_data = 0, kl_aug = 0;
+  double e_data = 0, kl_aug = 0, mo_e = 0, mo_kl = 0;
 
   agp_status get_state(int l, void* mu, void* sigma, void* eta1, void* eta2) override {
     if (l < 0 || l >= nl) return AGP_ERR_INVALID;
@@ -969,7 +1093,30 @@ struct Svgp : SvgpBase {
     return AGP_OK;
   }
 
+  // multi-output: latent predictions mixed by A (predictions.jl:52-92) -> T[n_task][n_t]
   agp_status predict_f(const void* xt, int64_t ldx, int64_t nt, void* mu_out, void* var_out) override {
+    if (!mo) return predict_f_latent(xt, ldx, nt, mu_out, var_out);
+    AGPCHK(ensure_pred_ws(nt, var_out != nullptr));
+    if (nt > mo_pred_cap) {
+      if (mo_pmu) (void)hipFree(mo_pmu);
+      if (mo_pvar) (void)hipFree(mo_pvar);
+      AGPCHK(dmalloc(ctx, &mo_pmu, (int64_t)nl * nt));
+      AGPCHK(dmalloc(ctx, &mo_pvar, (int64_t)nl * nt));
+      mo_pred_cap = nt;
+    }
+    AGPCHK(predict_f_latent(xt, ldx, nt, mo_pmu, var_out ? mo_pvar : nullptr));
+    hipLaunchKernelGGL((k_mo_mix<T>), grid1(nt), dim3(256), 0, st(), nt, nl, nT, (const T*)A_dev, (const T*)mo_pmu, nt,
+                       (T*)mu_out, nt, 0);
+    if (var_out)
+      hipLaunchKernelGGL((k_mo_mix<T>), grid1(nt), dim3(256), 0, st(), nt, nl, nT, (const T*)A_dev, (const T*)mo_pvar, nt,
+                         (T*)var_out, nt, 1);
+    LAUNCHCHK(ctx);
+    return AGP_OK;
+  }
+  T *mo_pmu = nullptr, *mo_pvar = nullptr;
+  int64_t mo_pred_cap = 0;
+
+  agp_status predict_f_latent(const void* xt, int64_t ldx, int64_t nt, void* mu_out, void* var_out) {
     if (!xt || nt <= 0 || ldx < D || !mu_out) return AGP_ERR_INVALID;
     const bool need_var = var_out != nullptr;
     AGPCHK(ensure_pred_ws(0, need_var));
@@ -1000,6 +1147,14 @@ struct Svgp : SvgpBase {
 
   agp_status predict_y(const void* xt, int64_t ldx, int64_t nt, void* out) override {
     if (!out) return AGP_ERR_INVALID;
+    if (mo) {  // T[n_task][n_t]: regression tasks -> mean ; Bernoulli tasks -> 1.0 / 0.0 (mu_f > 0)
+      AGPCHK(predict_f(xt, ldx, nt, out, nullptr));
+      for (int t = 0; t < nT; ++t)
+        if (mocfg.kind[t] == AGP_LIK_LOGISTIC)
+          hipLaunchKernelGGL((k_step01<T>), grid1(nt), dim3(256), 0, st(), (T*)out + (int64_t)t * nt, nt);
+      LAUNCHCHK(ctx);
+      return AGP_OK;
+    }
     if (lp.kind == AGP_LIK_GAUSSIAN || lp.kind == AGP_LIK_STUDENTT) return predict_f(xt, ldx, nt, out, nullptr);
     AGPCHK(ensure_pred_ws(nt, false));
     AGPCHK(predict_f(xt, ldx, nt, pmu, nullptr));
@@ -1009,10 +1164,45 @@ struct Svgp : SvgpBase {
     return AGP_OK;
   }
 
+  agp_status upload_gh(const double* nodes, const double* weights, int nn) {
+    if (nn > gh_cap) {
+      if (gh_dev) (void)hipFree(gh_dev);
+      AGPCHK(dmalloc(ctx, &gh_dev, 2 * nn));
+      gh_cap = nn;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(gh_dev, nodes, sizeof(double) * nn, hipMemcpyHostToDevice, st()));
+    HIPCHK(ctx, hipMemcpyAsync(gh_dev + nn, weights, sizeof(double) * nn, hipMemcpyHostToDevice, st()));
+    HIPCHK(ctx, hipStreamSynchronize(st()));
+    return AGP_OK;
+  }
+
   agp_status proba_y(const void* xt, int64_t ldx, int64_t nt, const double* nodes, const double* weights, int nn,
                      void* o0, void* o1) override {
     if (!o0) return AGP_ERR_INVALID;
     AGPCHK(ensure_pred_ws(nt, true));
+    if (mo) {  // per task compute_proba on the mixed (mu_f, var_f): out0 / out1 are T[n_task][n_t]
+      if (!o1) return AGP_ERR_INVALID;
+      AGPCHK(predict_f(xt, ldx, nt, o0, o1));
+      for (int t = 0; t < nT; ++t) {
+        T* m0 = (T*)o0 + (int64_t)t * nt;
+        T* v0 = (T*)o1 + (int64_t)t * nt;
+        if (mocfg.kind[t] == AGP_LIK_GAUSSIAN) {
+          hipLaunchKernelGGL((k_proba_regression<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)m0, (const T*)v0,
+                             mocfg.p0[t], 0, m0, v0);
+        } else if (mocfg.kind[t] == AGP_LIK_STUDENTT) {
+          const double nu = (double)mocfg.p0[t], sg = (double)mocfg.p1[t];
+          hipLaunchKernelGGL((k_proba_regression<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)m0, (const T*)v0,
+                             (T)(nu * sg * sg / (2.0 * (nu / 2.0 - 1.0))), 1, m0, v0);
+        } else {
+          if (!nodes || !weights || nn <= 0) return AGP_ERR_INVALID;
+          AGPCHK(upload_gh(nodes, weights, nn));
+          hipLaunchKernelGGL((k_proba_logistic<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)m0, (const T*)v0, nn,
+                             (const double*)gh_dev, (const double*)(gh_dev + nn), m0, v0);
+        }
+      }
+      LAUNCHCHK(ctx);
+      return AGP_OK;
+    }
     AGPCHK(predict_f(xt, ldx, nt, pmu, pvar));
     if (lp.kind == AGP_LIK_GAUSSIAN) {
       if (!o1) return AGP_ERR_INVALID;
@@ -1025,14 +1215,7 @@ struct Svgp : SvgpBase {
                          (T)(nu * sg * sg / (2.0 * (nu / 2.0 - 1.0))), 1, (T*)o0, (T*)o1);
     } else if (lp.kind == AGP_LIK_LOGISTIC) {
       if (!o1 || !nodes || !weights || nn <= 0) return AGP_ERR_INVALID;
-      if (nn > gh_cap) {
-        if (gh_dev) (void)hipFree(gh_dev);
-        AGPCHK(dmalloc(ctx, &gh_dev, 2 * nn));
-        gh_cap = nn;
-      }
-      HIPCHK(ctx, hipMemcpyAsync(gh_dev, nodes, sizeof(double) * nn, hipMemcpyHostToDevice, st()));
-      HIPCHK(ctx, hipMemcpyAsync(gh_dev + nn, weights, sizeof(double) * nn, hipMemcpyHostToDevice, st()));
-      HIPCHK(ctx, hipStreamSynchronize(st()));
+      AGPCHK(upload_gh(nodes, weights, nn));
       hipLaunchKernelGGL((k_proba_logistic<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)pmu, (const T*)pvar, nn,
                          (const double*)gh_dev, (const double*)(gh_dev + nn), (T*)o0, (T*)o1);
     } else {
@@ -1412,6 +1595,15 @@ agp_status agp_svgp_step_local(agp_svgp* h, const void* x, int64_t ldx, const vo
 agp_status agp_svgp_prefetch(agp_svgp* h, const void* x, int64_t ldx, const int64_t* idx, int64_t B) {
   HCHK(h);
   return h->impl->prefetch(x, ldx, idx, B);
+}
+agp_status agp_svgp_set_multioutput(agp_svgp* h, int32_t n_task, const agp_lik_desc* liks_host, const double* A_host,
+                                    double adam_eta, double adam_b1, double adam_b2, double adam_eps) {
+  HCHK(h);
+  return h->impl->set_multioutput(n_task, liks_host, A_host, adam_eta, adam_b1, adam_b2, adam_eps);
+}
+agp_status agp_svgp_get_A(agp_svgp* h, double* A_host) {
+  HCHK(h);
+  return h->impl->get_A(A_host);
 }
 agp_status agp_svgp_lsm_gamma(agp_svgp* h) {
   HCHK(h);

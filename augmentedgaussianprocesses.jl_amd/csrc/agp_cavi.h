@@ -8,7 +8,7 @@
 namespace agp {
 
 enum { K_SQEXP = 0, K_MATERN52 = 1, K_MATERN32 = 2, K_EXPONENTIAL = 3 };
-enum { LIK_GAUSSIAN = 0, LIK_LOGISTIC = 1, LIK_STUDENTT = 2, LIK_LSM = 3 };
+enum { LIK_GAUSSIAN = 0, LIK_LOGISTIC = 1, LIK_STUDENTT = 2, LIK_LSM = 3, LIK_MO = 4 };
 enum { FLAG_NEG_KTILDE = 1 };
 
 template <typename T>
@@ -207,6 +207,7 @@ __global__ void k_rowstats_local(int64_t B, int nslices, const T* __restrict__ p
     c[i] = sqrt(mu * mu + var);  // logisticsoftmax.jl:62-64
     return;
   }
+  if (lp.kind == LIK_MO) return;  // multi-output: mixing + likelihoods follow in k_mo_local
   T yi = y[idx ? idx[i] : i];
   T th, cc = T(0), g1;
   if (lp.kind == LIK_GAUSSIAN) {  // gaussian.jl:70-80
@@ -279,6 +280,151 @@ __global__ void k_lsm_finish(int64_t B, int nl, int64_t ldb, int latent_offset, 
     theta[k * ldb + i] = th;
     r[k * ldb + i] = rho * (yk - g) / T(2);
     w[k * ldb + i] = rho * th / T(2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Multi-output mixing (src/models/single_and_multi_output_utils.jl:24-118, MOSVGP): task t sees f_t = sum_q A[t][q] f_q.
+// ---------------------------------------------------------------------------------------------------
+constexpr int MO_MAXT = 16;
+template <typename T>
+struct MoCfg {
+  int nT;
+  int kind[MO_MAXT];
+  T p0[MO_MAXT];
+  T p1[MO_MAXT];
+};
+
+template <typename T>
+__device__ __forceinline__ void lik_point(int kind, T p0, T p1, T m, T v, T yi, T& th, T& cc, T& g1) {
+  cc = T(0);
+  if (kind == LIK_GAUSSIAN) {
+    th = T(1) / p0;
+    g1 = yi / p0;
+  } else if (kind == LIK_LOGISTIC) {
+    cc = sqrt(m * m + v);
+    th = theta_pg<T>(cc);
+    g1 = yi / T(2);
+  } else {
+    T alpha = (p0 + T(1)) / T(2);
+    cc = ((m - yi) * (m - yi) + v + p1 * p1 * p0) / T(2);
+    th = alpha / cc;
+    g1 = th * yi;
+  }
+}
+
+// mixed mean_f / var_f (lines 24-45), per-task local updates, mixed gradients (lines 48-84):
+//   r_q = rho sum_t A_tq (g1_t - 2 g2_t (m_t - A_tq mu_q)) ; w_q = rho sum_t A_tq^2 g2_t
+template <typename T>
+__global__ void k_mo_local(int64_t B, int Q, int64_t ldb, MoCfg<T> cfg, const T* __restrict__ A, T rho,
+                           const T* __restrict__ y, int64_t ystride, const int64_t* __restrict__ idx,
+                           const T* __restrict__ muf, const T* __restrict__ varf, T* __restrict__ mixm,
+                           T* __restrict__ mixv, T* __restrict__ th, T* __restrict__ cc, T* __restrict__ r,
+                           T* __restrict__ w, int do_local) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  T gm[MO_MAXT], gs[MO_MAXT], mt[MO_MAXT];
+  const int64_t src = idx ? idx[i] : i;
+#pragma unroll
+  for (int t = 0; t < MO_MAXT; ++t) {
+    gm[t] = gs[t] = mt[t] = T(0);
+    if (t < cfg.nT) {
+      T m = T(0), v = T(0);
+      for (int q = 0; q < Q; ++q) {
+        T a = A[t * Q + q];
+        m += a * muf[q * ldb + i];
+        v += a * a * varf[q * ldb + i];
+      }
+      mixm[t * ldb + i] = m;
+      mixv[t * ldb + i] = v;
+      mt[t] = m;
+      if (do_local) {
+        T thv, cv, g1;
+        lik_point<T>(cfg.kind[t], cfg.p0[t], cfg.p1[t], m, v, y[src * ystride + t], thv, cv, g1);
+        th[t * ldb + i] = thv;
+        cc[t * ldb + i] = cv;
+        gm[t] = g1;
+        gs[t] = thv / T(2);
+      }
+    }
+  }
+  if (!do_local) return;
+  for (int q = 0; q < Q; ++q) {
+    T mq = muf[q * ldb + i], g1 = T(0), g2 = T(0);
+#pragma unroll
+    for (int t = 0; t < MO_MAXT; ++t) {
+      if (t < cfg.nT) {
+        T a = A[t * Q + q];
+        g1 += a * (gm[t] - T(2) * gs[t] * (mt[t] - a * mq));
+        g2 += a * a * gs[t];
+      }
+    }
+    r[q * ldb + i] = rho * g1;
+    w[q * ldb + i] = rho * g2;
+  }
+}
+
+// update_A! gradient (lines 87-109) with the local variables of the PREVIOUS step: grid (Q, nT), one workgroup each
+template <typename T>
+__global__ void k_mo_gradA(int64_t B, int Q, int64_t ldb, MoCfg<T> cfg, const T* __restrict__ A,
+                           const T* __restrict__ y, int64_t ystride, const int64_t* __restrict__ idx,
+                           const T* __restrict__ muf, const T* __restrict__ varf, const T* __restrict__ th,
+                           double* __restrict__ gradA) {
+  __shared__ double red[16];
+  const int q = blockIdx.x, t = blockIdx.y;
+  const T atq = A[t * Q + q];
+  double x1 = 0.0, x2 = 0.0;
+  for (int64_t i = threadIdx.x; i < B; i += blockDim.x) {
+    T thv = th[t * ldb + i];
+    T yi = y[(idx ? idx[i] : i) * ystride + t];
+    T g1 = cfg.kind[t] == LIK_GAUSSIAN ? yi / cfg.p0[t] : (cfg.kind[t] == LIK_LOGISTIC ? yi / T(2) : thv * yi);
+    T g2 = thv / T(2);
+    T m = T(0);
+    for (int qq = 0; qq < Q; ++qq) m += A[t * Q + qq] * muf[qq * ldb + i];
+    T mq = muf[q * ldb + i];
+    x1 += (double)(g1 * mq - T(2) * g2 * mq * (m - atq * mq));
+    x2 += (double)(g2 * (mq * mq + varf[q * ldb + i]));
+  }
+  x1 = block_sum<double>(x1, red);
+  x2 = block_sum<double>(x2, red);
+  if (threadIdx.x == 0) gradA[t * Q + q] = x1 - 2.0 * (double)atq * x2;
+}
+
+// ADAM ascent step on each row of A followed by the projection on the unit sphere (lines 110-112); one thread per task
+template <typename T>
+__global__ void k_mo_applyA(int nT, int Q, T* __restrict__ A, const double* __restrict__ gradA, double* __restrict__ am,
+                            double* __restrict__ av, int step, double eta, double b1, double b2, double eps) {
+  int t = threadIdx.x;
+  if (t >= nT) return;
+  const double c1 = 1.0 - pow(b1, (double)step), c2 = 1.0 - pow(b2, (double)step);
+  double nrm = 0.0;
+  for (int q = 0; q < Q; ++q) {
+    double g = gradA[t * Q + q];
+    double m = b1 * am[t * Q + q] + (1.0 - b1) * g;
+    double v = b2 * av[t * Q + q] + (1.0 - b2) * g * g;
+    am[t * Q + q] = m;
+    av[t * Q + q] = v;
+    double a = (double)A[t * Q + q] + eta * (m / c1) / (sqrt(v / c2) + eps);
+    A[t * Q + q] = (T)a;
+    nrm += a * a;
+  }
+  nrm = sqrt(nrm);
+  for (int q = 0; q < Q; ++q) A[t * Q + q] = (T)((double)A[t * Q + q] / nrm);
+}
+
+// out[t][i] = sum_q A[t][q]^p in[q][i]   (p = 1 means, p = 2 variances)   predictions.jl:60-64,75-79
+template <typename T>
+__global__ void k_mo_mix(int64_t n, int Q, int nT, const T* __restrict__ A, const T* __restrict__ in, int64_t ldi,
+                         T* __restrict__ out, int64_t ldo, int square) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int t = 0; t < nT; ++t) {
+    T s = T(0);
+    for (int q = 0; q < Q; ++q) {
+      T a = A[t * Q + q];
+      s += (square ? a * a : a) * in[q * ldi + i];
+    }
+    out[t * ldo + i] = s;
   }
 }
 
@@ -406,7 +552,8 @@ __global__ void k_elbo_terms(int64_t B, int nl, int64_t ldb, LikParams<T> lp, in
                              int add_global, const T* __restrict__ y, const int32_t* __restrict__ ycls,
                              const int64_t* __restrict__ idx, const T* __restrict__ muf, const T* __restrict__ varf,
                              const T* __restrict__ c, const T* __restrict__ theta, const T* __restrict__ gamma,
-                             const T* __restrict__ alpha, const T* __restrict__ beta, double* __restrict__ out) {
+                             const T* __restrict__ alpha, const T* __restrict__ beta, double* __restrict__ out,
+                             int64_t ystr) {
   __shared__ double red[16];
   double e = 0.0, kl = 0.0;
   const double LOG2 = 0.69314718055994530942, LOG2PI = 1.83787706640934548356;
@@ -426,7 +573,7 @@ __global__ void k_elbo_terms(int64_t B, int nl, int64_t ldb, LikParams<T> lp, in
       }
       if (add_global) kl += -a - lgamma(a) - (1.0 - a) * psi;               // GammaEntropy (sum parts)
     } else {
-      double yi = (double)y[idx ? idx[i] : i];
+      double yi = (double)y[(idx ? idx[i] : i) * ystr];
       double mu = (double)muf[i], s = (double)varf[i];
       if (lp.kind == LIK_GAUSSIAN) {
         double s2 = (double)lp.p0;
@@ -524,6 +671,13 @@ __global__ void k_predict_label(int64_t n, int nl, int64_t ldm, int latent_offse
     }
   }
   out[i] = best + latent_offset;
+}
+
+// x <- (x > 0) ? 1 : 0   (predict_y of a Bernoulli task inside a multi-output float buffer)
+template <typename T>
+__global__ void k_step01(T* __restrict__ x, int64_t n) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) x[i] = x[i] > T(0) ? T(1) : T(0);
 }
 
 // compute_proba for BernoulliLikelihood{LogisticLink} (classification.jl:14-26): Gauss-Hermite expectation of

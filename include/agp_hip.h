@@ -45,7 +45,13 @@ enum { AGP_F64 = 0, AGP_F32 = 1 };
 enum { AGP_K_SQEXP = 0, AGP_K_MATERN52 = 1, AGP_K_MATERN32 = 2, AGP_K_EXPONENTIAL = 3 };
 
 /* likelihoods with closed-form augmented updates on this path (src/likelihood/{gaussian,logistic,studentt,logisticsoftmax}.jl) */
-enum { AGP_LIK_GAUSSIAN = 0, AGP_LIK_LOGISTIC = 1, AGP_LIK_STUDENTT = 2, AGP_LIK_LOGISTICSOFTMAX = 3 };
+enum {
+  AGP_LIK_GAUSSIAN = 0,
+  AGP_LIK_LOGISTIC = 1,
+  AGP_LIK_STUDENTT = 2,
+  AGP_LIK_LOGISTICSOFTMAX = 3,
+  AGP_LIK_MULTIOUTPUT = 4 /* MOSVGP handle: task likelihoods are installed by agp_svgp_set_multioutput */
+};
 
 /* ELBO variants: Appendix-A Q2 of SURVEY.md (src/likelihood/logistic.jl:82 uses dot(theta, mu)) */
 enum { AGP_ELBO_CORRECTED = 0, AGP_ELBO_REFERENCE = 1 };
@@ -166,6 +172,17 @@ agp_status agp_svgp_cavi_step(agp_svgp* h, const void* x, int64_t ldx, const voi
  *   step_global : natural-gradient step + (mu, Sigma) refresh      analyticVI.jl:229-246, inference.jl:25-28 */
 agp_status agp_svgp_step_local(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx,
                                int64_t B, double rho);
+/* Multi-output model  MOSVGP(kernel, likelihoods, inference, Zs; Aoptimiser)  src/models/MOSVGP.jl:33-115 on a handle
+ * created with lik.kind = AGP_LIK_MULTIOUTPUT: the handle's n_latent latent GPs are mixed into n_task outputs
+ * f_t = sum_q A[t][q] f_q (mean_f / var_f / grad mixing: src/models/single_and_multi_output_utils.jl:24-84).
+ *   liks_host : n_task likelihoods (Gaussian / Logistic / StudentT: one latent function per task)
+ *   A_host    : n_task x n_latent row-major mixing weights (rows normalised, MOSVGP.jl:101-104)
+ *   y passed to the step / ELBO calls is then point-major T[N][n_task] (task t's target of point i at y[i*n_task + t])
+ *   adam_eta > 0 enables update_A! (ADAM ascent + projection on the unit sphere, lines 87-118); <= 0: Aoptimiser=false
+ * predict_f / predict_y / proba_y outputs become T[n_task][n_t] (Bernoulli tasks: predict_y -> 1.0 / 0.0). */
+agp_status agp_svgp_set_multioutput(agp_svgp* h, int32_t n_task, const agp_lik_desc* liks_host, const double* A_host,
+                                    double adam_eta, double adam_b1, double adam_b2, double adam_eps);
+agp_status agp_svgp_get_A(agp_svgp* h, double* A_host);
 /* Optional look-ahead: compute Knm / kappa of the NEXT minibatch (compute_kappa, latentgp.jl:209-215) on a second,
  * library-owned stream so it overlaps the current step's latency-bound factorisation.  The next cavi_step /
  * step_local called with the same (x, ldx, idx, B) adopts the result; any other call simply ignores it.  idx must stay

@@ -805,3 +805,178 @@ def hyper_objective(model: SVGP, X, y, latent_k, scale, sigma2, Z, rho):
         Lk = L if k == latent_k else g.L
         tot -= gaussian_kl(g.mu, g.mu0, g.Sigma, Lk)
     return float(tot)
+
+
+# --------------------------------------------------------------------------------------------
+# Multi-output sparse model (src/models/MOSVGP.jl, src/models/single_and_multi_output_utils.jl:24-118,
+# src/inference/analyticVI.jl:87-111,277-297, src/training/training.jl:153-158, predictions.jl:52-92).
+# Q latent GPs are mixed into n_task outputs f_t = sum_q A[t][q] f_q (nf_per_task = 1 for the likelihoods on this
+# path).  The reference confuses n_output (= Q) with the number of tasks (MOSVGP.jl:126, Appendix A Q7) and is only
+# self-consistent for Q == n_task; the loops below run over TASKS, the documented intent (docs/src/userguide.md:44).
+# --------------------------------------------------------------------------------------------
+@dataclass
+class Adam:
+    """Optimisers.jl ADAM(eta, (0.9, 0.999)) with bias correction, eps = 1e-8 [unvendored; stated, SURVEY 3.5]."""
+    eta: float = 0.01
+    b1: float = 0.9
+    b2: float = 0.999
+    eps: float = 1e-8
+
+    def init(self, x):
+        return {"m": np.zeros_like(x), "v": np.zeros_like(x), "t": 0}
+
+    def apply(self, st, g):
+        st["t"] += 1
+        st["m"] = self.b1 * st["m"] + (1 - self.b1) * g
+        st["v"] = self.b2 * st["v"] + (1 - self.b2) * g * g
+        mh = st["m"] / (1 - self.b1 ** st["t"])
+        vh = st["v"] / (1 - self.b2 ** st["t"])
+        return st, self.eta * mh / (np.sqrt(vh) + self.eps)
+
+
+def init_local_vars_single(lik, B):
+    """theta / c as the positional buffers of init_local_vars (classification.jl:10-12 etc.), with the `rand` entries that
+    are always overwritten before use set to zero."""
+    if lik.name == "gaussian":
+        return {"theta": np.full(B, 1.0 / lik.sigma2), "c": np.zeros(B)}
+    return {"theta": np.zeros(B), "c": np.zeros(B)}
+
+
+@dataclass
+class MOSVGP:
+    kernel: object
+    likelihoods: list
+    Zs: list                      # one (m, D) array per latent
+    A: np.ndarray                 # (n_task, Q) mixing weights (rows normalised, MOSVGP.jl:101-104)
+    stochastic: bool = False
+    batchsize: int = 0
+    A_opt: Optional[Adam] = None  # Aoptimiser (None == false)
+    kappa_rm: float = 0.51
+    tau_rm: float = 1.0
+    jitter: float = 1e-4
+    elbo_mode: str = "corrected"
+
+    def __post_init__(self):
+        import copy
+        kernels = self.kernel if isinstance(self.kernel, (list, tuple)) else [self.kernel]
+        self.latents = [Latent(copy.deepcopy(kernels[i % len(kernels)]), np.array(Z, dtype=np.float64))
+                        for i, Z in enumerate(self.Zs)]  # kernel[mod1(i, n_kernel)] MOSVGP.jl:96-98
+        self.A = np.array(self.A, dtype=np.float64)
+        self.n_task, self.Q = self.A.shape
+        assert len(self.likelihoods) == self.n_task and len(self.latents) == self.Q
+        for l in self.likelihoods:
+            assert l.name in ("gaussian", "logistic", "studentt")
+        self.local_vars = None
+        self.A_state = [self.A_opt.init(self.A[t]) for t in range(self.n_task)] if self.A_opt else None
+        self.rho = 1.0
+        self.hp_updated = True
+        self.n_iter = 0
+
+    compute_kernel_matrices = SVGP.compute_kernel_matrices
+
+    def lat_mean_var(self):
+        return ([mean_f(g.mu, g.kappa) for g in self.latents],
+                [var_f(g.Sigma, g.kappa, g.Kt) for g in self.latents])
+
+    def mixed(self):
+        mu_q, var_q = self.lat_mean_var()
+        mu_t = [sum(self.A[t, q] * mu_q[q] for q in range(self.Q)) for t in range(self.n_task)]
+        var_t = [sum(self.A[t, q] ** 2 * var_q[q] for q in range(self.Q)) for t in range(self.n_task)]
+        return mu_t, var_t
+
+    def update_A(self, ys):
+        """update_A! single_and_multi_output_utils.jl:87-118 (uses the local variables of the PREVIOUS step)."""
+        if self.A_opt is None:
+            return
+        mu_q, var_q = self.lat_mean_var()
+        for t, lik in enumerate(self.likelihoods):
+            gmu = grad_E_mu(lik, ys[t], self.local_vars[t])[0]
+            gS = grad_E_Sigma(lik, ys[t], self.local_vars[t])[0]
+            dA = np.zeros(self.Q)
+            for q in range(self.Q):
+                others = sum(self.A[t, qq] * mu_q[qq] for qq in range(self.Q) if qq != q)
+                x1 = np.dot(gmu, mu_q[q]) - 2.0 * np.dot(gS, mu_q[q] * others)
+                x2 = np.dot(gS, mu_q[q] ** 2 + var_q[q])
+                dA[q] = x1 - 2.0 * self.A[t, q] * x2
+            self.A_state[t], delta = self.A_opt.apply(self.A_state[t], dA)
+            self.A[t] = self.A[t] + delta
+            self.A[t] = self.A[t] / math.sqrt(np.sum(self.A[t] ** 2))
+
+    def variational_updates(self, ys):
+        """analyticVI.jl:87-111 with the mixed gradients of single_and_multi_output_utils.jl:48-84."""
+        mu_q, var_q = self.lat_mean_var()
+        mu_t, var_t = self.mixed()
+        for t, lik in enumerate(self.likelihoods):
+            self.local_vars[t] = local_updates(self.local_vars[t], lik, ys[t], (mu_t[t],), (var_t[t],))
+        gmu = [grad_E_mu(l, ys[t], self.local_vars[t])[0] for t, l in enumerate(self.likelihoods)]
+        gS = [grad_E_Sigma(l, ys[t], self.local_vars[t])[0] for t, l in enumerate(self.likelihoods)]
+        for q, gp in enumerate(self.latents):
+            g1 = sum(self.A[t, q] * (gmu[t] - 2.0 * gS[t] * (mu_t[t] - self.A[t, q] * mu_q[q]))
+                     for t in range(self.n_task))
+            g2 = sum(self.A[t, q] ** 2 * gS[t] for t in range(self.n_task))
+            d1 = grad_eta1(g1, self.rho, gp.kappa, gp.L, gp.mu0, gp.eta1)
+            d2 = grad_eta2(g2, self.rho, gp.kappa, gp.Kinv, gp.eta2)
+            lr = robbins_monro_lr(gp.n_eta1, self.kappa_rm, self.tau_rm) if self.stochastic else 1.0
+            gp.n_eta1 += 1
+            gp.n_eta2 += 1
+            gp.eta1 = gp.eta1 + lr * d1
+            gp.eta2 = gp.eta2 + lr * d2
+            gp.eta2 = (gp.eta2 + gp.eta2.T) / 2.0
+            gp.mu, gp.Sigma = natural_to_standard(gp.eta1, gp.eta2)
+
+    def train(self, X, ys, iterations, idx_stream=None, callback=None):
+        """train! + update_parameters!(::MOSVGP) training.jl:153-158.  ys: list of treated target vectors (one per task)."""
+        X = np.asarray(X, dtype=np.float64)
+        N = len(X)
+        if self.stochastic:
+            self.rho = N / self.batchsize
+        else:
+            self.batchsize = N
+            self.rho = 1.0
+        B = self.batchsize
+        if self.local_vars is None:
+            self.local_vars = [init_local_vars_single(l, B) for l in self.likelihoods]
+        for it in range(iterations):
+            idx = np.asarray(idx_stream[it]) if self.stochastic else np.arange(N)
+            xb, yb = X[idx], [y[idx] for y in ys]
+            self.compute_kernel_matrices(xb)
+            self.update_A(yb)
+            self.variational_updates(yb)
+            self.n_iter += 1
+            if callback is not None:
+                callback(self, it, xb, yb)
+        for gp in self.latents:
+            gp.K, gp.L = compute_K(gp.kernel, gp.Z, self.jitter)
+        return self
+
+    def elbo(self, ys, rho=None):
+        """analyticVI.jl:277-297."""
+        rho = self.rho if rho is None else rho
+        mu_t, var_t = self.mixed()
+        tot = rho * sum(expec_loglikelihood(l, ys[t], (mu_t[t],), (var_t[t],), self.local_vars[t], self.elbo_mode)
+                        for t, l in enumerate(self.likelihoods))
+        tot -= sum(gaussian_kl(gp.mu, gp.mu0, gp.Sigma, gp.L) for gp in self.latents)
+        tot -= rho * sum(augmented_kl(l, self.local_vars[t], ys[t]) for t, l in enumerate(self.likelihoods))
+        return float(tot)
+
+    def predict_f(self, Xt, cov=False):
+        """predictions.jl:52-92: latent predictions mixed by A (means by A, variances by A^2)."""
+        helper = SVGP.__new__(SVGP)
+        helper.latents, helper.jitter = self.latents, self.jitter
+        if cov:
+            mq, vq = SVGP.predict_f(helper, Xt, cov=True)
+        else:
+            mq, vq = SVGP.predict_f(helper, Xt, cov=False), None
+        mu_t = [sum(self.A[t, q] * mq[q] for q in range(self.Q)) for t in range(self.n_task)]
+        if not cov:
+            return tuple(mu_t)
+        var_t = [sum(self.A[t, q] ** 2 * vq[q] for q in range(self.Q)) for t in range(self.n_task)]
+        return tuple(mu_t), tuple(var_t)
+
+    def predict_y(self, Xt):
+        mu = self.predict_f(Xt)
+        return [m > 0 if l.name == "logistic" else m for m, l in zip(mu, self.likelihoods)]
+
+    def proba_y(self, Xt):
+        mu, var = self.predict_f(Xt, cov=True)
+        return [compute_proba(l, (mu[t],), (var[t],)) for t, l in enumerate(self.likelihoods)]

@@ -298,3 +298,51 @@ def test_phase_split_engine_matches_oracle(env, likname):
     P.train_parallel(mb, X2, y2, iters, idx, mode="batch")
     for k in range(mb.n_latent):
         assert _rel(mb.get_state(k)[3], mr.latents[k].eta2) < 1e-9
+
+
+@pytest.mark.parametrize("stochastic", [False, True])
+@pytest.mark.parametrize("aopt", [False, True])
+def test_multioutput_svgp_matches_oracle(env, stochastic, aopt):
+    """MOSVGP (src/models/MOSVGP.jl): Q = 3 latents mixed into 3 tasks (Gaussian, Logistic, StudentT) -- deliberately with
+    Q != n_task would break the reference (Appendix A Q7); also run 4 latents / 2 tasks below."""
+    AGP, R = env["AGP"], env["R"]
+    for Q, liks_a, liks_r in [
+        (3, [AGP.GaussianLikelihood(0.05), AGP.LogisticLikelihood(), AGP.StudentTLikelihood(3.0)],
+         [R.GaussianLikelihood(0.05), R.LogisticLikelihood(), R.StudentTLikelihood(3.0)]),
+        (4, [AGP.LogisticLikelihood(), AGP.GaussianLikelihood(0.1)], [R.LogisticLikelihood(), R.GaussianLikelihood(0.1)]),
+    ]:
+        rng = np.random.default_rng(31 + Q)
+        N, D, m, B, iters = 240, 2, 12, 60, 5
+        X = rng.random((N, D))
+        f = [np.sin(4 * X[:, 0]), X[:, 1] - 0.5, np.cos(3 * X[:, 0] * X[:, 1])]
+        ys_all = {"gaussian": f[0] + 0.1 * rng.standard_normal(N), "logistic": np.sign(f[1] + 0.1 * rng.standard_normal(N)),
+                  "studentt": f[2] + 0.1 * rng.standard_t(3, N)}
+        ys = [ys_all[l.name] for l in liks_r]
+        T = len(ys)
+        A = rng.standard_normal((T, Q))
+        A /= np.linalg.norm(A, axis=1, keepdims=True)
+        Zs = [X[rng.permutation(N)[:m]].copy() for _ in range(Q)]
+        idx = [rng.choice(N, B, replace=False) for _ in range(iters)]
+        inf = AGP.AnalyticSVI(B) if stochastic else AGP.AnalyticVI()
+        ma = AGP.MOSVGP(AGP.SqExponentialKernel() @ AGP.ScaleTransform(3.0), liks_a, inf, Zs, A=A.copy(),
+                        Aoptimiser=AGP.ADAM(0.01) if aopt else False)
+        mr = R.MOSVGP(R.Kernel("sqexponential", 3.0, 1.0), liks_r, Zs, A.copy(), stochastic=stochastic, batchsize=B,
+                      A_opt=R.Adam(0.01) if aopt else None)
+        ea, er = [], []
+        AGP.train_(ma, X, ys, iters, idx_stream=idx, callback=lambda mdl, s, i: ea.append(AGP.objective(mdl, s)))
+        mr.train(X, ys, iters, idx_stream=idx, callback=lambda M, it, xb, yb: er.append(M.elbo(yb)))
+        assert np.allclose(ea, er, rtol=1e-8, atol=1e-7), (ea, er)
+        assert _rel(ma.get_A(), mr.A) < 1e-9
+        for q in range(Q):
+            mu, Sig, e1, e2 = ma.get_state(q)
+            assert _rel(e2, mr.latents[q].eta2) < 1e-9 and _rel(mu, mr.latents[q].mu) < 1e-8
+        Xt = rng.random((50, D))
+        mf, vf = AGP.predict_f(ma, Xt, cov=True)
+        mfr, vfr = mr.predict_f(Xt, cov=True)
+        for t in range(T):
+            assert _rel(mf[t], mfr[t]) < 1e-8 and _rel(vf[t], vfr[t]) < 1e-7
+        pa, pr = AGP.proba_y(ma, Xt), mr.proba_y(Xt)
+        ya, yr = AGP.predict_y(ma, Xt), mr.predict_y(Xt)
+        for t in range(T):
+            assert _rel(pa[t][0], pr[t][0]) < 1e-8 and _rel(pa[t][1], pr[t][1]) < 1e-6
+            assert np.allclose(np.asarray(ya[t], float), np.asarray(yr[t], float), atol=1e-8)

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -11,6 +12,7 @@
 #include <vector>
 
 #include "agp_cavi.h"
+#include "agp_hyper.h"
 #include "agp_linalg.h"
 
 using namespace agp;
@@ -127,6 +129,7 @@ static agp_status gemm_nt(agp_ctx* c, const T* A, int64_t lda, const T* B, int64
 struct KernelHost {
   int kind = AGP_K_SQEXP;
   double variance = 1.0;
+  bool ard = false;
   std::vector<double> scales;  // length D
 };
 
@@ -146,6 +149,11 @@ struct SvgpBase {
   virtual agp_status set_multioutput(int n_task, const agp_lik_desc* liks, const double* A_host, double eta, double b1,
                                      double b2, double eps) = 0;
   virtual agp_status get_A(double* A_host) = 0;
+  virtual agp_status hyper_configure(int opt_k, double k_eta, int opt_z, double z_eta, double b1, double b2,
+                                     double eps) = 0;
+  virtual agp_status hypergrad(int l, double* dvar, double* dscale, void* dZ) = 0;
+  virtual agp_status hyper_step() = 0;
+  virtual agp_status get_kernel(int l, double* var, double* scales) = 0;
   virtual agp_status lsm_gamma() = 0;
   virtual agp_status lsm_alpha() = 0;
   virtual agp_status lsm_gsum_ptr(void** p, int64_t* n) = 0;
@@ -235,6 +243,10 @@ struct Svgp : SvgpBase {
     T* Apred = nullptr;   // K^-1 - K^-1 Sigma K^-1
     T* apred = nullptr;   // K^-1 mu
     bool K_stale = true, post_valid = false, pred_valid = false, predvar_valid = false, kappa_valid = false;
+    // hyper-parameter optimiser state (ADAM): kernel parameters on the host, Z on the device
+    std::vector<double> k_m, k_v;
+    int k_step = 0, z_step = 0;
+    double *z_am = nullptr, *z_av = nullptr;
     // La holds: 0 = -2*eta2 (unfactored), 1 = its Cholesky factor ; xa_valid: Xa = La^-1 is current
     int la_state = 0;
     bool xa_valid = false;
@@ -247,6 +259,12 @@ struct Svgp : SvgpBase {
   LikParams<T> lp{};
   // shared batch buffers
   T *pw0 = nullptr, *pw1 = nullptr;  // row-statistic scratch [ldp]
+  // hyper-parameter step (update_hyperparameters!, autotuning.jl:86-140)
+  bool hy_k = false, hy_z = false;
+  double hy_keta = 0.01, hy_zeta = 0.001, hy_b1 = 0.9, hy_b2 = 0.999, hy_eps = 1e-8;
+  T *hyH1 = nullptr, *hyH2 = nullptr, *hyH3 = nullptr, *hy_gmu = nullptr, *hy_gs = nullptr, *hy_muf = nullptr,
+    *hy_pZ = nullptr, *hy_dZ = nullptr;
+  double *hy_pvar = nullptr, *hy_pscale = nullptr, *hy_g = nullptr;
   // multi-output mode (MOSVGP): n_task likelihoods over A-mixed latents
   bool mo = false;
   MoCfg<T> mocfg{};
@@ -397,6 +415,16 @@ struct Svgp : SvgpBase {
                evarf, cpart, stats, Tw, Tw2, tmpv, lr_dev, Kstar, ppm, ppv, pmu, pvar};
     for (T* p : ps)
       if (p) (void)hipFree(p);
+    T* hps[] = {hyH1, hyH2, hyH3, hy_gmu, hy_gs, hy_muf, hy_pZ, hy_dZ};
+    for (T* p : hps)
+      if (p) (void)hipFree(p);
+    double* hds[] = {hy_pvar, hy_pscale, hy_g};
+    for (double* p : hds)
+      if (p) (void)hipFree(p);
+    for (auto& g : lat) {
+      if (g.z_am) (void)hipFree(g.z_am);
+      if (g.z_av) (void)hipFree(g.z_av);
+    }
     T* mops[] = {A_dev, mo_mixm, mo_mixv, mo_th, mo_cc, mo_th_save, mo_pmu, mo_pvar};
     for (T* p : mops)
       if (p) (void)hipFree(p);
@@ -438,6 +466,7 @@ struct Svgp : SvgpBase {
     Latent& g = lat[l];
     g.k.kind = k->kind;
     g.k.variance = k->variance;
+    g.k.ard = k->ard != 0;
     for (int64_t d = 0; d < D; ++d) g.k.scales[d] = k->ard ? k->ard_scales_host[d] : k->scale;
     g.K_stale = true;
     g.kappa_valid = false;
@@ -591,6 +620,205 @@ struct Svgp : SvgpBase {
       }
       AGPCHK(mo_local(y, idx, B, rho, !fresh));
     }
+    return AGP_OK;
+  }
+
+  // ---- hyper-parameter / inducing-point gradient (see agp_hyper.h) ------------------------------------------------
+  agp_status hyper_configure(int opt_k, double k_eta, int opt_z, double z_eta, double b1, double b2,
+                             double eps) override {
+    hy_k = opt_k != 0;
+    hy_z = opt_z != 0;
+    hy_keta = k_eta;
+    hy_zeta = z_eta;
+    hy_b1 = b1;
+    hy_b2 = b2;
+    hy_eps = eps;
+    return AGP_OK;
+  }
+
+  agp_status hyper_alloc() {
+    if (hyH1) return AGP_OK;
+    if (D > HB_MAXD) {
+      ctx->err = "hyper-gradient: input dimension above HB_MAXD";
+      return AGP_ERR_UNSUPPORTED;
+    }
+    const int64_t tiles = std::max((Bp / TILE) * (mp / TILE), (mp / TILE) * (mp / TILE));
+    const int64_t rowt = std::max(Bp / TILE, mp / TILE);
+    AGPCHK(dmalloc(ctx, &hyH1, Bp * mp));
+    AGPCHK(dmalloc(ctx, &hyH2, Bp * mp));
+    AGPCHK(dmalloc(ctx, &hyH3, Bp * mp));
+    AGPCHK(dmalloc(ctx, &hy_gmu, Bp));
+    AGPCHK(dmalloc(ctx, &hy_gs, Bp));
+    AGPCHK(dmalloc(ctx, &hy_muf, Bp));
+    AGPCHK(dmalloc(ctx, &hy_pZ, rowt * mp * D));
+    AGPCHK(dmalloc(ctx, &hy_dZ, m * D));
+    AGPCHK(dmalloc(ctx, &hy_pvar, tiles));
+    AGPCHK(dmalloc(ctx, &hy_pscale, tiles * D));
+    AGPCHK(dmalloc(ctx, &hy_g, 1 + D));
+    return AGP_OK;
+  }
+
+  // gradient of the hyper objective w.r.t. (variance, per-dimension scales, Z) of latent l, on the batch of the last step
+  agp_status hypergrad(int l, double* dvar, double* dscale, void* dZ_out) override {
+    if (l < 0 || l >= nl || !x_last || B_last <= 0) return AGP_ERR_INVALID;
+    if (mo) {
+      ctx->err = "hyper-gradient of the multi-output model is not wired yet";
+      return AGP_ERR_UNSUPPORTED;
+    }
+    Latent& g = lat[l];
+    if (g.k.kind == AGP_K_EXPONENTIAL) {
+      ctx->err = "hyper-gradient: ExponentialKernel is not differentiable at zero distance";
+      return AGP_ERR_UNSUPPORTED;
+    }
+    AGPCHK(hyper_alloc());
+    const int64_t B = B_last, Bq = rup64(B);
+    const T rho = (T)rho_last;
+    AGPCHK(ensure_pred(g, true));  // Sigma, mu, K^-1 mu, Apred = K^-1 - K^-1 Sigma K^-1
+    // mean_f with the current posterior, then g_mu / g_sigma from the step's local variables
+    hipLaunchKernelGGL((k_gemv_rows<T>), grid1(B * 64), dim3(256), 0, st(), (const T*)g.kappa, mp, B, mp, (const T*)g.mu,
+                       hy_muf);
+    hipLaunchKernelGGL((k_hyper_gvec<T>), grid1(B), dim3(256), 0, st(), B, rho,
+                       (int)(lp.kind == AGP_LIK_LOGISTIC && desc.elbo_mode == AGP_ELBO_REFERENCE),
+                       (const T*)(rbuf + l * Bp), (const T*)(theta + l * Bp), (const T*)hy_muf, hy_gmu, hy_gs);
+    LAUNCHCHK(ctx);
+    AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.kappa, mp, g.Sigma, mp, Bq, mp, mp, 0, hyH1, mp, nullptr, 0, nullptr, nullptr,
+                                  nullptr, 0)));
+    hipLaunchKernelGGL((k_hyper_gkappa<T>), grid2(Bq, mp), blk2, 0, st(), B, Bq, mp, mp, rho, (const T*)hy_gmu,
+                       (const T*)hy_gs, (const T*)g.mu, (const T*)g.Knm, hyH1);
+    LAUNCHCHK(ctx);
+    AGPCHK((gemm_nt<T, EPI_STORE>(ctx, hyH1, mp, g.Kinv, mp, Bq, mp, mp, 0, hyH2, mp, nullptr, 0, nullptr, nullptr,
+                                  nullptr, 0)));
+    hipLaunchKernelGGL((k_hyper_gknm<T>), grid2(Bq, mp), blk2, 0, st(), B, Bq, mp, mp, rho, (const T*)hy_gs,
+                       (const T*)hyH2, (const T*)g.kappa, hyH3);
+    {
+      dim3 gt((unsigned)(mp / TILE), (unsigned)(mp / TILE));
+      if ((mp / TILE) * (mp / TILE) <= 320)
+        hipLaunchKernelGGL((k_gemm_tn<T, 2>), gt, dim3(2 * NTHREADS), 0, st(), (const T*)g.kappa, mp, (const T*)hyH2, mp,
+                           Bq, Tw, mp);
+      else
+        hipLaunchKernelGGL((k_gemm_tn<T, 1>), gt, dim3(NTHREADS), 0, st(), (const T*)g.kappa, mp, (const T*)hyH2, mp, Bq,
+                           Tw, mp);
+    }
+    hipLaunchKernelGGL((k_axpby<T>), grid1(mp), dim3(256), 0, st(), mp, T(1), (const T*)g.apred, T(-1),
+                       (const T*)g.kinv_mu0, tmpv);
+    hipLaunchKernelGGL((k_hyper_gK<T>), grid2(mp, mp), blk2, 0, st(), m, mp, (const T*)Tw, (const T*)g.Apred,
+                       (const T*)tmpv, Tw2);
+    HIPCHK(ctx, hipMemsetAsync(hy_g, 0, sizeof(double) * (1 + D), st()));
+    // backward through kernelmatrix(k, x, Z)  (gradient w.r.t. the second argument)
+    {
+      dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
+      const int64_t tiles = (int64_t)gk.x * gk.y;
+      hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)x_last, ldx_last, idx_last, B,
+                         (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, (const T*)hyH3, mp,
+                         hy_pvar, hy_pscale, hy_pZ, mp);
+      hipLaunchKernelGGL((k_hyper_reduce_scalar<T>), dim3(1), dim3(128), 0, st(), tiles, D, (const double*)hy_pvar,
+                         (const double*)hy_pscale, hy_g, 1.0);
+      hipLaunchKernelGGL((k_hyper_reduce_Z<T>), grid1(m * D), dim3(256), 0, st(), (int64_t)gk.y, m, mp, D,
+                         (const T*)hy_pZ, hy_dZ, T(1), 0);
+    }
+    // backward through kernelmatrix(k, Z) : both arguments are Z and G_K is symmetric -> twice the second-argument part
+    {
+      dim3 gk((unsigned)(mp / TILE), (unsigned)(mp / TILE));
+      const int64_t tiles = (int64_t)gk.x * gk.y;
+      hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)g.Z, D, (const int64_t*)nullptr,
+                         m, (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, (const T*)Tw2, mp,
+                         hy_pvar, hy_pscale, hy_pZ, mp);
+      hipLaunchKernelGGL((k_hyper_reduce_scalar<T>), dim3(1), dim3(128), 0, st(), tiles, D, (const double*)hy_pvar,
+                         (const double*)hy_pscale, hy_g, 1.0);
+      hipLaunchKernelGGL((k_hyper_reduce_Z<T>), grid1(m * D), dim3(256), 0, st(), (int64_t)gk.y, m, mp, D,
+                         (const T*)hy_pZ, hy_dZ, T(2), 1);
+    }
+    hipLaunchKernelGGL((k_hyper_sum<T>), dim3(1), dim3(1024), 0, st(), B, (const T*)hy_gs, (double)rho, hy_g);
+    LAUNCHCHK(ctx);
+    std::vector<double> hg(1 + D);
+    HIPCHK(ctx, hipMemcpyAsync(hg.data(), hy_g, sizeof(double) * (1 + D), hipMemcpyDeviceToHost, st()));
+    if (dZ_out) HIPCHK(ctx, hipMemcpyAsync(dZ_out, hy_dZ, sizeof(T) * m * D, hipMemcpyDeviceToDevice, st()));
+    HIPCHK(ctx, hipStreamSynchronize(st()));
+    if (dvar) *dvar = hg[0];
+    if (dscale)
+      for (int64_t d = 0; d < D; ++d) dscale[d] = hg[1 + d];
+    hy_last = hg;
+    return AGP_OK;
+  }
+  std::vector<double> hy_last;
+
+  static void adam_host(std::vector<double>& am, std::vector<double>& av, int step, const std::vector<double>& g, double eta,
+                        double b1, double b2, double eps, std::vector<double>& delta) {
+    delta.resize(g.size());
+    for (size_t i = 0; i < g.size(); ++i) {
+      am[i] = b1 * am[i] + (1 - b1) * g[i];
+      av[i] = b2 * av[i] + (1 - b2) * g[i] * g[i];
+      double mh = am[i] / (1 - std::pow(b1, step)), vh = av[i] / (1 - std::pow(b2, step));
+      delta[i] = eta * mh / (std::sqrt(vh) + eps);
+    }
+  }
+
+  // update_hyperparameters!(m, state, x, y): ADAM ASCENT; positive kernel parameters are stepped in log space
+  // (update_kernel!, autotuning_utils.jl:63-67), Z directly (update_Z!, :70-76).  K is refreshed before the next step.
+  agp_status hyper_step() override {
+    if (!hy_k && !hy_z) return AGP_OK;
+    for (int l = 0; l < nl; ++l) {
+      Latent& g = lat[l];
+      AGPCHK(hypergrad(l, nullptr, nullptr, nullptr));
+      const std::vector<double>& hg = hy_last;
+      if (hy_k) {
+        const size_t np = 1 + (g.k.ard ? (size_t)D : 1);
+        if (g.k_m.size() != np) {
+          g.k_m.assign(np, 0.0);
+          g.k_v.assign(np, 0.0);
+          g.k_step = 0;
+        }
+        std::vector<double> p(np), gl(np), delta;
+        p[0] = g.k.variance;
+        gl[0] = p[0] * hg[0];
+        if (g.k.ard) {
+          for (int64_t d = 0; d < D; ++d) {
+            p[1 + d] = g.k.scales[d];
+            gl[1 + d] = p[1 + d] * hg[1 + d];
+          }
+        } else {
+          double s = 0;
+          for (int64_t d = 0; d < D; ++d) s += hg[1 + d];
+          p[1] = g.k.scales[0];
+          gl[1] = p[1] * s;
+        }
+        g.k_step += 1;
+        // variance and scale(s) are separate parameter arrays in the reference: separate ADAM states, same step count
+        adam_host(g.k_m, g.k_v, g.k_step, gl, hy_keta, hy_b1, hy_b2, hy_eps, delta);
+        g.k.variance = std::exp(std::log(p[0]) + delta[0]);
+        for (int64_t d = 0; d < D; ++d) {
+          const size_t j = g.k.ard ? 1 + (size_t)d : 1;
+          g.k.scales[d] = std::exp(std::log(p[j]) + delta[j]);
+        }
+      }
+      if (hy_z) {
+        if (!g.z_am) {
+          AGPCHK(dmalloc(ctx, &g.z_am, m * D));
+          AGPCHK(dmalloc(ctx, &g.z_av, m * D));
+          HIPCHK(ctx, hipMemsetAsync(g.z_am, 0, sizeof(double) * m * D, st()));
+          HIPCHK(ctx, hipMemsetAsync(g.z_av, 0, sizeof(double) * m * D, st()));
+        }
+        g.z_step += 1;
+        hipLaunchKernelGGL((k_adam_ascent<T>), grid1(m * D), dim3(256), 0, st(), m * D, g.Z, (const T*)hy_dZ, g.z_am,
+                           g.z_av, g.z_step, hy_zeta, hy_b1, hy_b2, hy_eps);
+        LAUNCHCHK(ctx);
+      }
+    }
+    for (auto& g : lat) {
+      if (hy_k) AGPCHK(upload_scales(g));
+      g.K_stale = true;
+      g.kappa_valid = false;
+      g.pred_valid = g.predvar_valid = false;
+    }
+    pf_valid = false;
+    return AGP_OK;
+  }
+
+  agp_status get_kernel(int l, double* var, double* scales) override {
+    if (l < 0 || l >= nl) return AGP_ERR_INVALID;
+    if (var) *var = lat[l].k.variance;
+    if (scales)
+      for (int64_t d = 0; d < D; ++d) scales[d] = lat[l].k.scales[d];
     return AGP_OK;
   }
 
@@ -1604,6 +1832,23 @@ agp_status agp_svgp_set_multioutput(agp_svgp* h, int32_t n_task, const agp_lik_d
 agp_status agp_svgp_get_A(agp_svgp* h, double* A_host) {
   HCHK(h);
   return h->impl->get_A(A_host);
+}
+agp_status agp_svgp_hyper_configure(agp_svgp* h, int32_t opt_kernel, double kernel_eta, int32_t opt_Z, double z_eta,
+                                    double adam_b1, double adam_b2, double adam_eps) {
+  HCHK(h);
+  return h->impl->hyper_configure(opt_kernel, kernel_eta, opt_Z, z_eta, adam_b1, adam_b2, adam_eps);
+}
+agp_status agp_svgp_hypergrad(agp_svgp* h, int32_t latent, double* dvariance_host, double* dscale_host, void* dZ) {
+  HCHK(h);
+  return h->impl->hypergrad(latent, dvariance_host, dscale_host, dZ);
+}
+agp_status agp_svgp_hyper_step(agp_svgp* h) {
+  HCHK(h);
+  return h->impl->hyper_step();
+}
+agp_status agp_svgp_get_kernel(agp_svgp* h, int32_t latent, double* variance_host, double* scales_host) {
+  HCHK(h);
+  return h->impl->get_kernel(latent, variance_host, scales_host);
 }
 agp_status agp_svgp_lsm_gamma(agp_svgp* h) {
   HCHK(h);

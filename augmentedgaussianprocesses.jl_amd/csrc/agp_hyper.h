@@ -1,0 +1,274 @@
+// agp_hyper.h -- hand-derived reverse mode of the hyper-parameter objective for gfx950.
+//
+// The reference differentiates ELBO(model, x, y, mu0, kernels, Zs, state) (src/functions/ELBO.jl:15-21) with Zygote
+// (src/hyperparameter/autotuning.jl:86-140; custom rule for A / ::Cholesky in zygote_rules.jl:1-8) holding (mu, Sigma,
+// local variables) fixed and ignoring AugmentedKL (analyticVI.jl:269-271).  With g_mu = dE/dmu_f, g_s = dE/dsigma2_f:
+//   G_kappa = rho [ g_mu mu' + 2 diag(g_s) kappa Sigma - diag(g_s) Knm ]
+//   H       = G_kappa K^-1 ;  G_Knm = H - rho diag(g_s) kappa ;  G_kdiag = rho g_s
+//   G_K     = -sym(kappa' H) - 1/2 [ K^-1 - K^-1 Sigma K^-1 ] + 1/2 a a' ,  a = K^-1 (mu - mu0)
+// followed by the chain rule through k(x, z) = s2 * phi(|| s .* (x - z) ||^2)  (k_kernel_backward).
+// The dense contractions reuse the MFMA GEMM kernels; this file holds the element-wise glue and the kernel backward.
+#pragma once
+#include "agp_cavi.h"
+
+namespace agp {
+
+// g_mu = r/rho - theta mu_f (reference-bug logistic mode: r/rho - theta/2) ; g_s = -theta/2
+template <typename T>
+__global__ void k_hyper_gvec(int64_t B, T rho, int ref_logistic, const T* __restrict__ r, const T* __restrict__ theta,
+                             const T* __restrict__ muf, T* __restrict__ gmu, T* __restrict__ gs) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  T th = theta[i];
+  gmu[i] = r[i] / rho - (ref_logistic ? th / T(2) : th * muf[i]);
+  gs[i] = -th / T(2);
+}
+
+// in place on T1 = kappa*Sigma :  Gk = rho ( g_mu mu' + 2 g_s T1 - g_s Knm ) ; rows >= B are zero
+template <typename T>
+__global__ void k_hyper_gkappa(int64_t B, int64_t rows, int64_t cols, int64_t ld, T rho, const T* __restrict__ gmu,
+                               const T* __restrict__ gs, const T* __restrict__ mu, const T* __restrict__ Knm,
+                               T* __restrict__ T1) {
+  int64_t i = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
+  int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= rows || j >= cols) return;
+  T v = T(0);
+  if (i < B) v = rho * (gmu[i] * mu[j] + T(2) * gs[i] * T1[i * ld + j] - gs[i] * Knm[i * ld + j]);
+  T1[i * ld + j] = v;
+}
+
+// G_Knm = H - rho g_s kappa   (rows >= B zero)
+template <typename T>
+__global__ void k_hyper_gknm(int64_t B, int64_t rows, int64_t cols, int64_t ld, T rho, const T* __restrict__ gs,
+                             const T* __restrict__ H, const T* __restrict__ kappa, T* __restrict__ out) {
+  int64_t i = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
+  int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= rows || j >= cols) return;
+  out[i * ld + j] = (i < B) ? H[i * ld + j] - rho * gs[i] * kappa[i * ld + j] : T(0);
+}
+
+// G_K = -1/2 (M1 + M1') - 1/2 Apred + 1/2 a a'   on the valid m x m block, zero in the padding
+template <typename T>
+__global__ void k_hyper_gK(int64_t m, int64_t mp, const T* __restrict__ M1, const T* __restrict__ Apred,
+                           const T* __restrict__ a, T* __restrict__ out) {
+  int64_t i = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
+  int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= mp || j >= mp) return;
+  T v = T(0);
+  if (i < m && j < m)
+    v = T(-0.5) * (M1[i * mp + j] + M1[j * mp + i]) - T(0.5) * Apred[i * mp + j] + T(0.5) * a[i] * a[j];
+  out[i * mp + j] = v;
+}
+
+template <typename T>
+__device__ __forceinline__ T kernel_dbase(int kind, T d2) {
+  d2 = d2 > T(0) ? d2 : T(0);
+  if (kind == K_SQEXP) return T(-0.5) * exp(T(-0.5) * d2);
+  T r = sqrt(d2);
+  if (kind == K_MATERN52) {
+    const T s5 = T(2.23606797749978969641);
+    return -(T(5) / T(6)) * (T(1) + s5 * r) * exp(-s5 * r);
+  }
+  const T s3 = T(1.73205080756887729353);  // Matern32
+  return T(-1.5) * exp(-s3 * r);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward of k_kernelmatrix for one 64x64 tile: given G = dL/dk(x_i, z_j),
+//   dvar   += sum_ij G_ij phi_ij
+//   dscale_d += (2/s_d) sum_ij c_ij t_ijd^2         c = G * variance * phi'(d2) ,  t = s_d (x_d - z_d)
+//   dZ[j][d] += -2 s_d sum_i c_ij t_ijd               (gradient w.r.t. the SECOND argument z_j)
+// Partials (deterministic two-stage reduction):  pvar[tile], pscale[tile][D], pZ[tile row][p][D].
+// grid = (ceil(p/64), ceil(n/64)).  D <= HB_MAXD.
+// ---------------------------------------------------------------------------------------------------
+constexpr int HB_MAXD = 64;
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restrict__ X, int64_t ldx,
+                                                              const int64_t* __restrict__ idx, int64_t n,
+                                                              const T* __restrict__ Y, int64_t ldy, int64_t p, int64_t D,
+                                                              const T* __restrict__ scales, int kind, T variance,
+                                                              const T* __restrict__ G, int64_t ldg,
+                                                              double* __restrict__ pvar, double* __restrict__ pscale,
+                                                              T* __restrict__ pZ, int64_t p_pad) {
+  __shared__ T xs[TILE][KM_DC + 1];
+  __shared__ T ys[TILE][KM_DC + 1];
+  __shared__ T zred[4][TILE][KM_DC];  // per wave: column sums for the chunk
+  __shared__ double sred[4][KM_DC];
+  __shared__ double red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ty = tid >> 4, tx = tid & 15;
+  const int64_t i0 = blockIdx.y * (int64_t)TILE, j0 = blockIdx.x * (int64_t)TILE;
+  const int64_t tile = blockIdx.y * (int64_t)gridDim.x + blockIdx.x;
+  T acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = T(0);
+  auto stage = [&](int64_t d0) {
+    for (int e = tid; e < TILE * KM_DC; e += NTHREADS) {
+      int r = e / KM_DC, d = e % KM_DC;
+      int64_t gd = d0 + d;
+      T sc = (scales && gd < D) ? scales[gd] : T(1);
+      int64_t gi = i0 + r, gj = j0 + r;
+      T xv = T(0), yv = T(0);
+      if (gd < D) {
+        if (gi < n) xv = X[(idx ? idx[gi] : gi) * ldx + gd] * sc;
+        if (gj < p) yv = Y[gj * ldy + gd] * sc;
+      }
+      xs[r][d] = xv;
+      ys[r][d] = yv;
+    }
+  };
+  // pass 1: squared distances
+  for (int64_t d0 = 0; d0 < D; d0 += KM_DC) {
+    stage(d0);
+    __syncthreads();
+#pragma unroll 8
+    for (int d = 0; d < KM_DC; ++d) {
+      T xv[4], yv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) xv[a] = xs[ty + 16 * a][d];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) yv[b] = ys[tx + 16 * b][d];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          T df = xv[a] - yv[b];
+          acc[a][b] += df * df;
+        }
+    }
+    __syncthreads();
+  }
+  // c_ij = G_ij * variance * phi'(d2) ; dvar partial
+  double dv = 0.0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      int64_t gi = i0 + ty + 16 * a, gj = j0 + tx + 16 * b;
+      T g = (gi < n && gj < p) ? G[gi * ldg + gj] : T(0);
+      dv += (double)(g * kernel_base<T>(kind, acc[a][b]));
+      acc[a][b] = g * variance * kernel_dbase<T>(kind, acc[a][b]);
+    }
+  dv = block_sum<double>(dv, red);
+  if (tid == 0) pvar[tile] = dv;
+  // pass 2: per-dimension reductions
+  for (int64_t d0 = 0; d0 < D; d0 += KM_DC) {
+    __syncthreads();
+    stage(d0);
+    __syncthreads();
+    for (int d = 0; d < KM_DC; ++d) {
+      T xv[4], yv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) xv[a] = xs[ty + 16 * a][d];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) yv[b] = ys[tx + 16 * b][d];
+      T ssum = T(0), zc[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        zc[b] = T(0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          T t = xv[a] - yv[b];
+          T ct = acc[a][b] * t;
+          zc[b] += ct;
+          ssum += ct * t;
+        }
+      }
+      // column sums over the 4 ty of this wave (lanes tx, tx+16, tx+32, tx+48), then all 64 lanes for the scale sum
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        zc[b] += __shfl_xor(zc[b], 16);
+        zc[b] += __shfl_xor(zc[b], 32);
+      }
+      for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o);
+      if (lane < 16) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) zred[wave][tx + 16 * b][d] = zc[b];
+      }
+      if (lane == 0) sred[wave][d] = (double)ssum;
+    }
+    __syncthreads();
+    for (int e = tid; e < TILE * KM_DC; e += NTHREADS) {
+      int c = e / KM_DC, d = e % KM_DC;
+      int64_t gd = d0 + d, gj = j0 + c;
+      if (gd < D && gj < p_pad) {
+        T sc = scales ? scales[gd] : T(1);
+        T z = zred[0][c][d] + zred[1][c][d] + zred[2][c][d] + zred[3][c][d];
+        pZ[(blockIdx.y * p_pad + gj) * D + gd] = T(-2) * sc * z;
+      }
+    }
+    if (tid < KM_DC && d0 + tid < D) {
+      T sc = scales ? scales[d0 + tid] : T(1);
+      pscale[tile * D + d0 + tid] = 2.0 / (double)sc * (sred[0][tid] + sred[1][tid] + sred[2][tid] + sred[3][tid]);
+    }
+  }
+}
+
+// out[0] = sum pvar ; out[1 + d] = sum_tiles pscale[tile][d]   (one workgroup, deterministic order)
+template <typename T>
+__global__ void k_hyper_reduce_scalar(int64_t ntiles, int64_t D, const double* __restrict__ pvar,
+                                      const double* __restrict__ pscale, double* __restrict__ out, double wgt) {
+  int d = threadIdx.x;  // thread 0: variance, threads 1..D: scales
+  if (d > D) return;
+  double s = 0.0;
+  if (d == 0)
+    for (int64_t t = 0; t < ntiles; ++t) s += pvar[t];
+  else
+    for (int64_t t = 0; t < ntiles; ++t) s += pscale[t * D + d - 1];
+  out[d] += wgt * s;
+}
+
+// dZ[j][d] (+)= wgt * sum_by pZ[by][j][d]
+template <typename T>
+__global__ void k_hyper_reduce_Z(int64_t nrowtiles, int64_t p, int64_t p_pad, int64_t D, const T* __restrict__ pZ,
+                                 T* __restrict__ dZ, T wgt, int accumulate) {
+  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= p * D) return;
+  int64_t j = e / D, d = e % D;
+  T s = T(0);
+  for (int64_t b = 0; b < nrowtiles; ++b) s += pZ[(b * p_pad + j) * D + d];
+  dZ[e] = (accumulate ? dZ[e] : T(0)) + wgt * s;
+}
+
+// sum over the first B entries of x -> out[0] += wgt * sum   (G_kdiag term of the variance gradient)
+template <typename T>
+__global__ void k_hyper_sum(int64_t B, const T* __restrict__ x, double wgt, double* __restrict__ out) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < B; i += blockDim.x) s += (double)x[i];
+  s = block_sum<double>(s, red);
+  if (threadIdx.x == 0) out[0] += wgt * s;
+}
+
+// ADAM ascent on Z (update_Z!, autotuning_utils.jl:70-76): z += eta * mhat / (sqrt(vhat) + eps)
+template <typename T>
+__global__ void k_adam_ascent(int64_t n, T* __restrict__ z, const T* __restrict__ g, double* __restrict__ am,
+                              double* __restrict__ av, int step, double eta, double b1, double b2, double eps) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double gi = (double)g[i];
+  double m = b1 * am[i] + (1.0 - b1) * gi, v = b2 * av[i] + (1.0 - b2) * gi * gi;
+  am[i] = m;
+  av[i] = v;
+  double mh = m / (1.0 - pow(b1, (double)step)), vh = v / (1.0 - pow(b2, (double)step));
+  z[i] = (T)((double)z[i] + eta * mh / (sqrt(vh) + eps));
+}
+
+// C(M x N) = A(K x M)^T B(K x N)  (both operands row-contiguous; general, non-symmetric).  grid = (N/64, M/64)
+template <typename T, int KG>
+__global__ __launch_bounds__(NTHREADS * KG) void k_gemm_tn(const T* __restrict__ A, int64_t lda,
+                                                           const T* __restrict__ B, int64_t ldb, int64_t K,
+                                                           T* __restrict__ C, int64_t ldc) {
+  __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
+  const int64_t r0 = blockIdx.y * (int64_t)TILE, c0 = blockIdx.x * (int64_t)TILE;
+  Acc<T> acc;
+  acc.zero();
+  gemm_tile<T, RC, RC, KG>(A + r0, lda, B + c0, ldb, 0, K, nullptr, acc, smem);
+  if (KG > 1 && threadIdx.x >= NTHREADS) return;
+  acc_foreach<T>(acc, [&](int r, int c, T val) { C[(r0 + r) * ldc + c0 + c] = val; });
+}
+
+}  // namespace agp

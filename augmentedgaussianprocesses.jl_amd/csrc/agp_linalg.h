@@ -191,6 +191,19 @@ __global__ void k_trmv_lower_t(const T* __restrict__ X, int64_t ld, int64_t n, c
   y[j] = s;
 }
 
+// y[i] = sum_j M[i][j] x[j], i < rows (one wave per row)
+template <typename T>
+__global__ void k_gemv_rows(const T* __restrict__ M, int64_t ld, int64_t rows, int64_t cols, const T* __restrict__ x,
+                            T* __restrict__ y) {
+  int64_t row = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  T s = T(0);
+  for (int64_t k = lane; k < cols; k += 64) s += M[row * ld + k] * x[k];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if (lane == 0) y[row] = s;
+}
+
 // y = M x for symmetric dense M (n x n): one wave per row
 template <typename T>
 __global__ void k_symv(const T* __restrict__ M, int64_t ld, int64_t n, const T* __restrict__ x, T* __restrict__ y) {

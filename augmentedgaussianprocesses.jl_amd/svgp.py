@@ -110,11 +110,12 @@ class State:
 class SVGP:
     """Sparse Variational GP (src/models/SVGP.jl:22-80).  Z: (m, D) array of inducing points (rows = points).
 
-    Keyword arguments follow the reference; hyper-parameter optimisation (`optimiser`, `Zoptimiser`) is the
-    next-tier row of SURVEY.md §8f and is not wired yet: pass optimiser=False (as every docs example does).
+    Keyword arguments follow the reference (SVGP.jl:33-44): `optimiser` (kernel parameters; default ADAM(0.01), Bool ->
+    ADAM(0.001) / off), `Zoptimiser` (inducing points; default off, True -> ADAM(0.001)), `atfrequency`.  The hyper step is
+    the hand-derived gradient of libagp_hip (agp_svgp_hyper_step), ADAM ascent with positive parameters in log space.
     """
 
-    def __init__(self, kernel, likelihood, inference, Z, *, verbose: int = 0, optimiser=False, atfrequency: int = 1,
+    def __init__(self, kernel, likelihood, inference, Z, *, verbose: int = 0, optimiser=None, atfrequency: int = 1,
                  mean=None, Zoptimiser=False, T=np.float64, device: Optional[int] = None, seed: Optional[int] = None,
                  elbo_mode: str = "corrected", latent_slice: Optional[tuple] = None):
         if not isinstance(inference, AnalyticVI):
@@ -123,9 +124,19 @@ class SVGP:
         if not isinstance(likelihood, (GaussianLikelihood, LogisticLikelihood, StudentTLikelihood,
                                        LogisticSoftMaxLikelihood, _MultiOutputLikelihood)):
             raise RuntimeError(f"The {likelihood} is not compatible or implemented with the {inference}")  # :48-49
-        if optimiser or Zoptimiser:
-            raise NotImplementedError("hyper-parameter / inducing-point optimisation is the next-tier row "
-                                      "(SURVEY.md §8f-1); pass optimiser=False, Zoptimiser=False")
+        if optimiser is None:
+            optimiser = ADAM(0.01)                       # SVGP.jl:39
+        if isinstance(optimiser, bool):
+            optimiser = ADAM(0.001) if optimiser else None  # SVGP.jl:51-53
+        if isinstance(Zoptimiser, bool):
+            Zoptimiser = ADAM(0.001) if Zoptimiser else None  # SVGP.jl:61-65
+        for o in (optimiser, Zoptimiser):
+            if o is not None and not isinstance(o, ADAM):
+                raise NotImplementedError("only ADAM is wired as hyper-parameter optimiser")
+        if isinstance(likelihood, _MultiOutputLikelihood) and (optimiser or Zoptimiser):
+            raise NotImplementedError("hyper-parameter steps of the multi-output model are not wired yet: pass "
+                                      "optimiser=False, Zoptimiser=False")
+        self.k_opt, self.z_opt = optimiser, Zoptimiser
         if mean is not None and not (np.isscalar(mean) or isinstance(mean, (list, np.ndarray))):
             raise TypeError("mean must be None (ZeroMean), a Real (ConstantMean) or a vector (EmpiricalMean)")
         self.likelihood = likelihood
@@ -247,10 +258,46 @@ class SVGP:
         return h
 
     def _post_create(self, h):
-        pass
+        o = self.k_opt or self.z_opt
+        if o is not None:
+            self._chk(capi.lib().agp_svgp_hyper_configure(
+                h, 1 if self.k_opt else 0, self.k_opt.eta if self.k_opt else 0.0, 1 if self.z_opt else 0,
+                self.z_opt.eta if self.z_opt else 0.0, o.beta[0], o.beta[1], o.eps))
 
     def _pre_destroy(self):
-        pass
+        self._pull_hypers()
+
+    def _pull_hypers(self):
+        """copy the (possibly optimised) kernel parameters and inducing points back into the Python objects"""
+        if self._h is None or not (self.k_opt or self.z_opt):
+            return
+        from .kernels import ARDTransform, ScaleTransform
+
+        torch = _torch()
+        L = capi.lib()
+        for i in range(self.n_latent):
+            var = C.c_double()
+            sc = (C.c_double * self.D)()
+            self._chk(L.agp_svgp_get_kernel(self._h, i, C.byref(var), sc))
+            k = self.kernels[i]
+            k.variance = var.value
+            if isinstance(k.transform, ARDTransform):
+                k.transform = ARDTransform(list(sc))
+            else:
+                k.transform = ScaleTransform(sc[0])
+            z = torch.empty(self.m, self.D, dtype=self.tdtype, device=self._dev())
+            self._chk(L.agp_svgp_get_Z(self._h, i, C.c_void_p(z.data_ptr()), self.D))
+            self._chk(L.agp_ctx_sync(self._ctx))
+            self.Zs[i] = z.cpu().numpy().astype(np.float64)
+
+    def hypergrad(self, latent: int = 0):
+        """(d variance, d scales[D], dZ[m, D]) of the hyper objective on the last minibatch (autotuning.jl:96-98)."""
+        torch = _torch()
+        dv = C.c_double()
+        ds = (C.c_double * self.D)()
+        dz = torch.empty(self.m, self.D, dtype=self.tdtype, device=self._dev())
+        self._chk(capi.lib().agp_svgp_hypergrad(self._h, latent, C.byref(dv), ds, C.c_void_p(dz.data_ptr())))
+        return dv.value, np.array(list(ds)), dz.cpu().numpy()
 
     @property
     def n_out(self):
@@ -462,12 +509,18 @@ def train_(model: SVGP, X, y, iterations: int = 100, *, callback: Optional[Calla
                                         idx_ptr, B, inf.rho))
         model.trained = True
         model._last_idx = idx_ptr
-        if inf.stoch and local_iter < iterations:  # look-ahead: next minibatch's kappa on the second stream
+        hyper_on = model.k_opt is not None or model.z_opt is not None
+        if inf.stoch and local_iter < iterations:
             nxt = draw(local_iter + 1)
             model._keep.append(nxt)
-            model._chk(L.agp_svgp_prefetch(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(nxt.data_ptr()), B))
+            if not hyper_on:  # look-ahead: next minibatch's kappa on the second stream (pointless if K is about to change)
+                model._chk(L.agp_svgp_prefetch(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0),
+                                               C.c_void_p(nxt.data_ptr()), B))
         if callback is not None:
             callback(model, State(model), inf.n_iter)
+        # training.jl:65-69 (n_iter is the counter before this iteration's increment)
+        if hyper_on and inf.n_iter % model.atfrequency == 0 and inf.n_iter >= 3 and local_iter != iterations:
+            model._chk(L.agp_svgp_hyper_step(h))
         if model.verbose > 2 or (model.verbose > 1 and local_iter % 10 == 0):
             print(f"iter {local_iter}  ELBO {objective(model, State(model), None):.6f}")
         local_iter += 1
@@ -475,6 +528,7 @@ def train_(model: SVGP, X, y, iterations: int = 100, *, callback: Optional[Calla
         if local_iter > iterations:
             break
     model._chk(L.agp_svgp_check_status(h))
+    model._pull_hypers()
     return model, State(model)
 
 

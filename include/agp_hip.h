@@ -172,6 +172,21 @@ agp_status agp_svgp_cavi_step(agp_svgp* h, const void* x, int64_t ldx, const voi
  *   step_global : natural-gradient step + (mu, Sigma) refresh      analyticVI.jl:229-246, inference.jl:25-28 */
 agp_status agp_svgp_step_local(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx,
                                int64_t B, double rho);
+/* Hyper-parameter / inducing-point step: update_hyperparameters!(m, state, x, y)  src/hyperparameter/autotuning.jl:86-140
+ * = reverse mode of ELBO(model, x, y, mu0, kernels, Zs, state) (src/functions/ELBO.jl:15-21; (mu, Sigma, local variables)
+ * fixed, AugmentedKL ignored) w.r.t. the kernel parameters (variance, ScaleTransform / ARDTransform scales) and Z,
+ * hand-derived instead of Zygote, on the minibatch of the LAST cavi_step; then ADAM ascent with the positive kernel
+ * parameters stepped in log space (update_kernel!, autotuning_utils.jl:63-67) and Z directly (update_Z!, :70-76).
+ * K is marked stale and refreshed by the next step (the reference leaves it stale inside train!).
+ *   hyper_configure : optimiser=ADAM(kernel_eta) / Zoptimiser=ADAM(z_eta) of SVGP(...)  (SVGP.jl:39-42); 0 disables
+ *   hypergrad       : the gradient only (parity): dscale_host[D] per input dimension (a ScaleTransform's single
+ *                     parameter receives their sum), dZ device T[m][D] (nullable)
+ *   get_kernel      : current variance and per-dimension scales */
+agp_status agp_svgp_hyper_configure(agp_svgp* h, int32_t opt_kernel, double kernel_eta, int32_t opt_Z, double z_eta,
+                                    double adam_b1, double adam_b2, double adam_eps);
+agp_status agp_svgp_hypergrad(agp_svgp* h, int32_t latent, double* dvariance_host, double* dscale_host, void* dZ);
+agp_status agp_svgp_hyper_step(agp_svgp* h);
+agp_status agp_svgp_get_kernel(agp_svgp* h, int32_t latent, double* variance_host, double* scales_host);
 /* Multi-output model  MOSVGP(kernel, likelihoods, inference, Zs; Aoptimiser)  src/models/MOSVGP.jl:33-115 on a handle
  * created with lik.kind = AGP_LIK_MULTIOUTPUT: the handle's n_latent latent GPs are mixed into n_task outputs
  * f_t = sum_q A[t][q] f_q (mean_f / var_f / grad mixing: src/models/single_and_multi_output_utils.jl:24-84).

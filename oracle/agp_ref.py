@@ -599,6 +599,12 @@ class SVGP:
     rho: float = 1.0
     n_iter: int = 0
     hp_updated: bool = True
+    # hyper-parameter optimisation (SVGP(...; optimiser, Zoptimiser, atfrequency) SVGP.jl:39-42): Adam objects or None
+    k_opt: object = None
+    z_opt: object = None
+    ard: bool = False          # True: the scale is an ARDTransform vector (one parameter per dim), else ScaleTransform
+    atfrequency: int = 1
+    hyper_state: list = None
 
     def __post_init__(self):
         import copy
@@ -675,13 +681,48 @@ class SVGP:
             else:
                 xb, yb = X, y
             self.update_parameters(xb, yb)
-            self.n_iter += 1
             if callback is not None:
                 callback(self, it, xb, yb)
+            # training.jl:65-69 : n_iter is the counter BEFORE this iteration's increment
+            if (self.k_opt or self.z_opt) and self.n_iter % self.atfrequency == 0 and self.n_iter >= 3 \
+                    and (it + 1) != iterations:
+                self.update_hyperparameters(xb, yb)
+            self.n_iter += 1
         # compute_Ks training.jl:107,210-215
         for gp in self.latents:
             gp.K, gp.L = compute_K(gp.kernel, gp.Z, self.jitter)
         return self
+
+    # -- autotuning.jl:86-140 + autotuning_utils.jl:47-82 (ADAM ascent; positive parameters stepped in log space) ----
+    def update_hyperparameters(self, xb, yb):
+        if self.hyper_state is None:
+            self.hyper_state = [None] * len(self.latents)
+        for k, gp in enumerate(self.latents):
+            g = hyper_gradient(self, xb, yb, k, self.rho)
+            D = gp.Z.shape[1]
+            sc = np.broadcast_to(np.asarray(gp.kernel.scale, dtype=np.float64), (D,)).copy()
+            if self.hyper_state[k] is None:
+                self.hyper_state[k] = {
+                    "var": self.k_opt.init(np.zeros(1)) if self.k_opt else None,
+                    "scale": self.k_opt.init(np.zeros(D if self.ard else 1)) if self.k_opt else None,
+                    "Z": self.z_opt.init(np.zeros_like(gp.Z)) if self.z_opt else None,
+                }
+            st = self.hyper_state[k]
+            if self.k_opt:
+                v = np.array([gp.kernel.sigma2])
+                st["var"], dv = self.k_opt.apply(st["var"], v * np.array([g["dvariance"]]))
+                gp.kernel.sigma2 = float(np.exp(np.log(v) + dv)[0])
+                if self.ard:
+                    st["scale"], ds = self.k_opt.apply(st["scale"], sc * g["dscale"])
+                    gp.kernel.scale = np.exp(np.log(sc) + ds)
+                else:
+                    s0 = np.array([sc[0]])
+                    st["scale"], ds = self.k_opt.apply(st["scale"], s0 * np.array([np.sum(g["dscale"])]))
+                    gp.kernel.scale = float(np.exp(np.log(s0) + ds)[0])
+            if self.z_opt:
+                st["Z"], dz = self.z_opt.apply(st["Z"], g["dZ"])
+                gp.Z = gp.Z + dz
+        self.hp_updated = True  # refresh K next step (the reference leaves it stale, Appendix A Q1: corrected here)
 
     # -- analyticVI.jl:255-274 ----------------------------------------------------------
     def elbo(self, y, rho=None):
@@ -980,3 +1021,70 @@ class MOSVGP:
     def proba_y(self, Xt):
         mu, var = self.predict_f(Xt, cov=True)
         return [compute_proba(l, (mu[t],), (var[t],)) for t, l in enumerate(self.likelihoods)]
+
+
+# --------------------------------------------------------------------------------------------
+# Analytic hyper-gradient of the objective the reference differentiates with Zygote
+# (src/hyperparameter/autotuning.jl:86-140 over src/functions/ELBO.jl:15-21): ELBO as a function of the kernel parameters
+# and Z of ONE latent with (mu, Sigma, local variables) fixed and AugmentedKL ignored.  Formula sheet: SURVEY.md 8(a15),
+# re-derived here; pinned against central finite differences of hyper_objective in tests/test_oracle_kat.py.
+# --------------------------------------------------------------------------------------------
+def dphi_dd2(kind, d2):
+    """d base(d2) / d d2 for the stationary base kernels (finite at d2 = 0 for SE / Matern)."""
+    d2 = np.maximum(d2, 0.0)
+    if kind == "sqexponential":
+        return -0.5 * np.exp(-0.5 * d2)
+    r = np.sqrt(d2)
+    if kind == "matern52":
+        s5 = math.sqrt(5.0)
+        return -(5.0 / 6.0) * (1.0 + s5 * r) * np.exp(-s5 * r)
+    if kind == "matern32":
+        s3 = math.sqrt(3.0)
+        return -1.5 * np.exp(-s3 * r)
+    raise ValueError("hyper-gradients are defined for SqExponential / Matern32 / Matern52 here")
+
+
+def expec_grads(lik, y, mu_f, lv, latent_k=0, elbo_mode="corrected"):
+    """(dE/dmu_f, dE/dsigma2_f) of expec_loglikelihood for one latent: g_mu = grad_E_mu - theta*mu_f, g_sigma = -theta/2
+    (all four augmented likelihoods; the reference-bug logistic variant has g_mu = y/2 - theta/2)."""
+    g1 = grad_E_mu(lik, y, lv)[latent_k]
+    th = lv["theta"][latent_k] if lik.name == "logisticsoftmax" else lv["theta"]
+    if lik.name == "logistic" and elbo_mode == "reference":
+        return g1 - th / 2.0, -th / 2.0
+    return g1 - th * mu_f, -th / 2.0
+
+
+def hyper_gradient(model, X, y, latent_k, rho):
+    """Returns dict(dvariance, dscale (array, one per dim: sum it for a ScaleTransform), dZ) at the current state."""
+    gp = model.latents[latent_k]
+    ker, Z = gp.kernel, gp.Z
+    m = len(Z)
+    K, L = compute_K(ker, Z, model.jitter)
+    Kinv = sla.cho_solve((L, True), np.eye(m))
+    Knm, kappa, Kt = compute_kappa(ker, X, Z, L, model.jitter)
+    mu_f = mean_f(gp.mu, kappa)
+    gmu, gsig = expec_grads(model.likelihood, y, mu_f, model.local_vars, latent_k, model.elbo_mode)
+    G_kappa = rho * (np.outer(gmu, gp.mu) + 2.0 * gsig[:, None] * (kappa @ gp.Sigma) - gsig[:, None] * Knm)
+    H = G_kappa @ Kinv
+    G_Knm = H - rho * gsig[:, None] * kappa
+    G_kdiag = rho * gsig
+    d = gp.mu - gp.mu0
+    a = Kinv @ d
+    M1 = kappa.T @ H
+    G_K = -0.5 * (M1 + M1.T) - 0.5 * (Kinv - Kinv @ gp.Sigma @ Kinv) + 0.5 * np.outer(a, a)
+    s = np.broadcast_to(np.asarray(ker.scale, dtype=np.float64), (X.shape[1],)).copy()
+
+    def back(Gm, Xa, Zb):
+        Xs, Zs_ = Xa * s, Zb * s
+        diff = Xs[:, None, :] - Zs_[None, :, :]          # s_d (x_d - z_d)
+        d2 = np.sum(diff * diff, axis=2)
+        phi = ker.base_from_d2(d2)
+        GK = Gm * ker.sigma2 * dphi_dd2(ker.kind, d2)     # dL/dd2
+        dvar = np.sum(Gm * phi)
+        dscale = 2.0 * np.einsum("ij,ijd->d", GK, diff * (Xa[:, None, :] - Zb[None, :, :]))
+        dZcol = -2.0 * np.einsum("ij,ijd->jd", GK, diff) * s[None, :]
+        return dvar, dscale, dZcol
+
+    v1, s1, z1 = back(G_Knm, X, Z)
+    v2, s2, z2 = back(G_K, Z, Z)
+    return {"dvariance": v1 + v2 + np.sum(G_kdiag), "dscale": s1 + s2, "dZ": z1 + 2.0 * z2}

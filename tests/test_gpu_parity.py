@@ -346,3 +346,76 @@ def test_multioutput_svgp_matches_oracle(env, stochastic, aopt):
         for t in range(T):
             assert _rel(pa[t][0], pr[t][0]) < 1e-8 and _rel(pa[t][1], pr[t][1]) < 1e-6
             assert np.allclose(np.asarray(ya[t], float), np.asarray(yr[t], float), atol=1e-8)
+
+
+@pytest.mark.parametrize("likname,kname,ard", [("logistic", "sq", False), ("studentt", "m52", True),
+                                               ("gaussian", "m32", False), ("logisticsoftmax", "sq", True)])
+def test_hypergrad_matches_oracle(env, likname, kname, ard):
+    """Hand-derived reverse mode (agp_hyper.h) vs the oracle's analytic gradient (itself pinned by finite differences in
+    tests/test_oracle_kat.py) of the objective the reference hands to Zygote (autotuning.jl:96-98)."""
+    AGP, R = env["AGP"], env["R"]
+    rng = np.random.default_rng(41)
+    N, D, m, B, iters = 200, 3, 14, 70, 3
+    X = rng.random((N, D))
+    f = np.sin(4 * X[:, 0]) + X[:, 1] * X[:, 2]
+    la, lr, y = {
+        "gaussian": (AGP.GaussianLikelihood(0.05), R.GaussianLikelihood(0.05), f + 0.1 * rng.standard_normal(N)),
+        "logistic": (AGP.LogisticLikelihood(), R.LogisticLikelihood(), (f > f.mean()).astype(int)),
+        "studentt": (AGP.StudentTLikelihood(3.0), R.StudentTLikelihood(3.0), f + 0.1 * rng.standard_t(3, N)),
+        "logisticsoftmax": (AGP.LogisticSoftMaxLikelihood(3), R.LogisticSoftMaxLikelihood(3),
+                            1 + np.digitize(f, np.quantile(f, [0.33, 0.66]))),
+    }[likname]
+    kcls, kn = {"sq": (AGP.SqExponentialKernel, "sqexponential"), "m52": (AGP.Matern52Kernel, "matern52"),
+                "m32": (AGP.Matern32Kernel, "matern32")}[kname]
+    sc = np.array([2.0, 3.0, 1.5]) if ard else 2.5
+    ka = 1.3 * (kcls() @ (AGP.ARDTransform(sc) if ard else AGP.ScaleTransform(sc)))
+    Z = X[rng.permutation(N)[:m]].copy()
+    idx = [rng.choice(N, B, replace=False) for _ in range(iters)]
+    ma = AGP.SVGP(ka, la, AGP.AnalyticSVI(B), Z, optimiser=False)
+    AGP.train_(ma, X, y, iters, idx_stream=idx)
+    mr = R.SVGP(R.Kernel(kn, sc, 1.3), lr, Z, stochastic=True, batchsize=B)
+    yt = R.treat_labels(y, lr)
+    mr.train(X, yt, iters, idx_stream=idx, labels_treated=True)
+    xb, yb = X[idx[-1]], yt[idx[-1]]
+    mr.hp_updated = True
+    mr.compute_kernel_matrices(xb)
+    for k in range(ma.n_latent):
+        g = R.hyper_gradient(mr, xb, yb, k, N / B)
+        dv, ds, dz = ma.hypergrad(k)
+        assert abs(dv - g["dvariance"]) < 1e-8 * max(1.0, abs(g["dvariance"]))
+        assert _rel(ds, g["dscale"]) < 1e-8
+        assert _rel(dz, g["dZ"]) < 1e-8
+
+
+@pytest.mark.parametrize("likname,ard,zopt", [("logistic", False, True), ("gaussian", True, False),
+                                              ("logisticsoftmax", False, True)])
+def test_training_with_hyper_steps_matches_oracle(env, likname, ard, zopt):
+    """train! with optimiser / Zoptimiser (update_hyperparameters!, training.jl:65-69) against the oracle's training loop."""
+    AGP, R = env["AGP"], env["R"]
+    rng = np.random.default_rng(43)
+    N, D, m, B, iters = 180, 2, 10, 60, 9
+    X = rng.random((N, D))
+    f = np.sin(5 * X[:, 0]) - X[:, 1]
+    la, lr, y = {
+        "gaussian": (AGP.GaussianLikelihood(0.05), R.GaussianLikelihood(0.05), f + 0.1 * rng.standard_normal(N)),
+        "logistic": (AGP.LogisticLikelihood(), R.LogisticLikelihood(), (f > f.mean()).astype(int)),
+        "logisticsoftmax": (AGP.LogisticSoftMaxLikelihood(3), R.LogisticSoftMaxLikelihood(3),
+                            1 + np.digitize(f, np.quantile(f, [0.33, 0.66]))),
+    }[likname]
+    sc = np.array([3.0, 2.0]) if ard else 3.0
+    ka = 1.2 * (AGP.SqExponentialKernel() @ (AGP.ARDTransform(sc) if ard else AGP.ScaleTransform(sc)))
+    Z = X[rng.permutation(N)[:m]].copy()
+    idx = [rng.choice(N, B, replace=False) for _ in range(iters)]
+    ma = AGP.SVGP(ka, la, AGP.AnalyticSVI(B), Z, optimiser=AGP.ADAM(0.05), Zoptimiser=AGP.ADAM(0.01) if zopt else False)
+    AGP.train_(ma, X, y, iters, idx_stream=idx)
+    mr = R.SVGP(R.Kernel("sqexponential", sc, 1.2), lr, Z, stochastic=True, batchsize=B, k_opt=R.Adam(0.05),
+                z_opt=R.Adam(0.01) if zopt else None, ard=ard)
+    mr.train(X, y, iters, idx_stream=idx)
+    for k in range(ma.n_latent):
+        kr = mr.latents[k].kernel
+        assert ma.kernels[k].variance == pytest.approx(kr.sigma2, rel=1e-8)
+        assert _rel(ma.kernels[k].scales(D), np.broadcast_to(kr.scale, (D,))) < 1e-8
+        assert _rel(ma.Zs[k], mr.latents[k].Z) < 1e-8
+        assert abs(ma.kernels[k].variance - 1.2) > 1e-3  # the hypers really moved
+        mu, Sig, e1, e2 = ma.get_state(k)
+        assert _rel(e2, mr.latents[k].eta2) < 1e-7 and _rel(mu, mr.latents[k].mu) < 1e-7

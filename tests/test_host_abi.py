@@ -111,8 +111,13 @@ def test_constructor_checks_and_repr():
         AGP.SVGP(k, AGP.GaussianLikelihood(), "not an inference", Z)
     with pytest.raises(RuntimeError):
         AGP.SVGP(k, object(), AGP.AnalyticVI(), Z)
-    with pytest.raises(NotImplementedError):
-        AGP.SVGP(k, AGP.GaussianLikelihood(), AGP.AnalyticVI(), Z, optimiser=True)
+    # SVGP.jl:39-42,51-65: optimiser defaults to ADAM(0.01), Bool -> ADAM(0.001) / nothing ; Zoptimiser defaults to nothing
+    d = AGP.SVGP(k, AGP.GaussianLikelihood(), AGP.AnalyticVI(), Z)
+    assert d.k_opt.eta == 0.01 and d.z_opt is None
+    t = AGP.SVGP(k, AGP.GaussianLikelihood(), AGP.AnalyticVI(), Z, optimiser=True, Zoptimiser=True)
+    assert t.k_opt.eta == 0.001 and t.z_opt.eta == 0.001
+    f = AGP.SVGP(k, AGP.GaussianLikelihood(), AGP.AnalyticVI(), Z, optimiser=False)
+    assert f.k_opt is None
     m = AGP.SVGP(k, AGP.LogisticSoftMaxLikelihood(3), AGP.AnalyticSVI(10), Z)
     assert m.n_latent == 3 and len(m.kernels) == 3 and m.kernels[0] is not m.kernels[1]
     assert repr(AGP.AnalyticVI()) == "Analytic Variational Inference"

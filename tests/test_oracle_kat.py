@@ -223,3 +223,43 @@ def test_oracle_reproduces_golden(path):
     mu, var = M.predict_f(g["Xt"], cov=True)
     assert np.allclose(np.stack(mu), g["pred_mu"], rtol=1e-9, atol=1e-12)
     assert np.allclose(np.stack(var), g["pred_var"], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("likname,kind", [("logistic", "sqexponential"), ("studentt", "matern52"),
+                                          ("gaussian", "matern32"), ("logisticsoftmax", "sqexponential")])
+def test_kat7_hyper_gradient_vs_finite_differences(likname, kind):
+    """analytic hyper-gradient (formula sheet) == central finite differences of the objective the reference
+    hands to Zygote (autotuning.jl:96-98)."""
+    rng, X, f, Z = _toy(7, N=40, D=2, m=6)
+    if likname == "gaussian":
+        L, y = R.GaussianLikelihood(0.1), f + 0.1 * rng.standard_normal(len(f))
+    elif likname == "logistic":
+        L, y = R.LogisticLikelihood(), (f > 0).astype(int)
+    elif likname == "studentt":
+        L, y = R.StudentTLikelihood(3.0), f + 0.1 * rng.standard_t(3, len(f))
+    else:
+        L, y = R.LogisticSoftMaxLikelihood(3), 1 + np.digitize(f, np.quantile(f, [0.33, 0.66]))
+    M = R.SVGP(R.Kernel(kind, np.array([2.0, 3.0]), 1.4), L, Z)
+    yt = R.treat_labels(y, L)
+    M.train(X, yt, 2, labels_treated=True)
+    M.compute_kernel_matrices(X, update=True)
+    lat = M.n_latent - 1 if hasattr(M, "n_latent") else 0
+    lat = len(M.latents) - 1
+    g = R.hyper_gradient(M, X, yt, lat, 1.7)
+    gp = M.latents[lat]
+    sc0, v0, Z0 = np.array(gp.kernel.scale, float), gp.kernel.sigma2, gp.Z.copy()
+    obj = lambda sc, v, Zz: R.hyper_objective(M, X, yt, lat, sc, v, Zz, 1.7)
+    h = 1e-6
+    fd_v = (obj(sc0, v0 + h, Z0) - obj(sc0, v0 - h, Z0)) / (2 * h)
+    assert g["dvariance"] == pytest.approx(fd_v, rel=2e-6, abs=1e-7)
+    for d in range(2):
+        e = np.zeros(2)
+        e[d] = h
+        fd = (obj(sc0 + e, v0, Z0) - obj(sc0 - e, v0, Z0)) / (2 * h)
+        assert g["dscale"][d] == pytest.approx(fd, rel=2e-6, abs=1e-7)
+    for (a, d) in [(0, 0), (3, 1), (5, 0)]:
+        Zp, Zm = Z0.copy(), Z0.copy()
+        Zp[a, d] += h
+        Zm[a, d] -= h
+        fd = (obj(sc0, v0, Zp) - obj(sc0, v0, Zm)) / (2 * h)
+        assert g["dZ"][a, d] == pytest.approx(fd, rel=5e-6, abs=1e-6)

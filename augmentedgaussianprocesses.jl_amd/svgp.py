@@ -412,7 +412,7 @@ class MOSVGP(SVGP):
         if A is None:
             A = self.rng.standard_normal((self.n_task, Q))
             A = A / np.linalg.norm(A, axis=1, keepdims=True)
-        self.A = np.ascontiguousarray(A, dtype=np.float64)
+        self.A = np.array(A, dtype=np.float64, order="C", copy=True)
         if self.A.shape != (self.n_task, Q):
             raise ValueError("A must be (n_task, n_latent)")
 

@@ -1,0 +1,145 @@
+"""GPU: BASELINE.json configs at FULL size, checked through size-independent properties (the oracle cannot run these in
+seconds): inverse round trips (K^-1 K = I, Sigma (-2 eta2) = I), symmetry, 0 < K~ <= variance, chunk-independence of the
+streaming predictor, finiteness / improvement of the ELBO, probabilities in [0, 1]."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(torch, N, D, dtype, seed=0):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    X = torch.rand(N, D, dtype=dtype, device="cuda", generator=g)
+    w = torch.randn(D, dtype=dtype, device="cuda", generator=g)
+    f = torch.sin(X @ w)
+    return X, f, g
+
+
+def _check_latent(AGP, capi, model, l, variance, tol):
+    import torch
+
+    mu, Sig, e1, e2 = model.get_state(l)
+    m = model.m
+    assert np.all(np.isfinite(Sig)) and np.all(np.isfinite(mu))
+    assert np.max(np.abs(Sig - Sig.T)) <= 1e-12 * np.max(np.abs(Sig)) + 1e-300
+    R = torch.as_tensor(Sig, device="cuda") @ torch.as_tensor(-2.0 * e2, device="cuda")
+    assert float((R - torch.eye(m, device="cuda", dtype=R.dtype)).abs().max()) < tol  # Sigma = (-2 eta2)^-1
+    Kinv = torch.as_tensor(model.get_matrix(capi.MAT_KINV, l), device="cuda")
+    Lk = torch.as_tensor(model.get_matrix(capi.MAT_L, l), device="cuda")
+    R2 = Kinv @ (Lk @ Lk.T)
+    assert float((R2 - torch.eye(m, device="cuda", dtype=R2.dtype)).abs().max()) < tol  # K^-1 (L L') = I
+    kt = model.get_matrix(capi.VEC_KTILDE, l, model.inference.batchsize)
+    assert np.all(kt > 0) and np.all(kt <= variance + 2e-3)
+
+
+def test_c2_full_size(built):
+    """C2: SE + Logistic, AnalyticSVI(1024), m = 1024, N = 1e6, D = 32, fp64."""
+    import torch
+    import agp_amd as AGP
+    from agp_amd import capi
+
+    N, D, m, B = 1_000_000, 32, 1024, 1024
+    X, f, g = _data(torch, N, D, torch.float64)
+    y = torch.sign(f + 0.3 * torch.randn(N, dtype=torch.float64, device="cuda", generator=g))
+    rng = np.random.default_rng(0)
+    Z = X[torch.as_tensor(rng.permutation(N)[:m], device="cuda")].cpu().numpy()
+    model = AGP.SVGP(AGP.with_lengthscale(AGP.SqExponentialKernel(), np.sqrt(D) / 4), AGP.LogisticLikelihood(),
+                     AGP.AnalyticSVI(B), Z, optimiser=False, seed=1)
+    e0 = None
+    elbos = []
+    ev = rng.choice(N, 4096, replace=False)
+    Xe, ye = X[torch.as_tensor(ev, device="cuda")], y[torch.as_tensor(ev, device="cuda")].cpu().numpy()
+    for _ in range(4):
+        AGP.train_(model, X, y.cpu().numpy() if e0 is None else yh, 10, state=True if e0 is not None else None)
+        if e0 is None:
+            yh = y.cpu().numpy()
+            e0 = True
+        elbos.append(AGP.ELBO(model, Xe, ye, rho=N / 4096))
+    assert np.all(np.isfinite(elbos)) and elbos[-1] > elbos[0]
+    _check_latent(AGP, capi, model, 0, 1.0, 1e-7)
+    # streaming predictor over all N points: chunk independence + probabilities
+    p_all, v_all = AGP.proba_y(model, X)
+    assert p_all.shape == (N,) and np.all((p_all >= 0) & (p_all <= 1)) and np.all(v_all >= 0)
+    lo = 123_457
+    p_part, _ = AGP.proba_y(model, X[lo:lo + 5000])
+    # (not bit-identical: chunks with few tiles use the two-k-group GEMM, which sums in a different order)
+    assert np.allclose(p_part, p_all[lo:lo + 5000], rtol=1e-11, atol=1e-13)
+    yhat = AGP.predict_y(model, X)
+    assert np.mean(yhat == (y.cpu().numpy() > 0)) > 0.6
+
+
+def test_c3_full_size_fp32(built):
+    """C3: Matern52 + StudentT, AnalyticSVI(2048), m = 2048, N = 1e6, D = 64, fp32."""
+    import torch
+    import agp_amd as AGP
+    from agp_amd import capi
+
+    N, D, m, B = 1_000_000, 64, 2048, 2048
+    X, f, g = _data(torch, N, D, torch.float32)
+    y = (f + 0.1 * torch.randn(N, dtype=torch.float32, device="cuda", generator=g)).cpu().numpy()
+    rng = np.random.default_rng(1)
+    Z = X[torch.as_tensor(rng.permutation(N)[:m], device="cuda")].cpu().numpy()
+    model = AGP.SVGP(AGP.with_lengthscale(AGP.Matern52Kernel(), np.sqrt(D) / 4), AGP.StudentTLikelihood(3.0),
+                     AGP.AnalyticSVI(B), Z, optimiser=False, T=np.float32, seed=2)
+    AGP.train_(model, X, y, 20)
+    _check_latent(AGP, capi, model, 0, 1.0, 5e-2)
+    mu, var = AGP.predict_f(model, X[:200_000], cov=True)
+    assert np.all(np.isfinite(mu)) and np.all(var > -1e-3)
+    assert np.mean(np.abs(mu - f[:200_000].cpu().numpy())) < 15  # the reference's regression threshold, testingtools.jl:237
+
+
+def test_c4_full_size_logisticsoftmax(built):
+    """C4: LogisticSoftMax, 8 classes = 8 latent GPs, m = 1024, N = 1e6, D = 32 (all latents on one GPU here; the
+    latent-parallel split is covered by tests/test_parallel_gloo.py and test_phase_split_engine)."""
+    import torch
+    import agp_amd as AGP
+    from agp_amd import capi
+
+    N, D, m, B, K = 1_000_000, 32, 1024, 1024, 8
+    X, f, g = _data(torch, N, D, torch.float64, seed=3)
+    y = (1 + torch.bucketize(f, torch.quantile(f[:100000], torch.linspace(0, 1, K + 1, device="cuda", dtype=f.dtype)[1:-1])
+                             )).cpu().numpy()
+    rng = np.random.default_rng(2)
+    Z = X[torch.as_tensor(rng.permutation(N)[:m], device="cuda")].cpu().numpy()
+    model = AGP.SVGP(AGP.with_lengthscale(AGP.SqExponentialKernel(), np.sqrt(D) / 4), AGP.LogisticSoftMaxLikelihood(K),
+                     AGP.AnalyticSVI(B), Z, optimiser=False, seed=3)
+    AGP.train_(model, X, y, 15)
+    for l in (0, 7):
+        _check_latent(AGP, capi, model, l, 1.0, 1e-7)
+    pr = AGP.proba_y(model, X[:50_000])
+    tot = sum(pr[c] for c in range(1, K + 1))
+    assert np.allclose(tot, 1.0, atol=1e-12)
+    alpha = model.get_matrix(capi.VEC_ALPHA, 0, B)
+    assert np.all(alpha > 1.0)
+
+
+def test_c5_shape_multioutput(built):
+    """C5: multi-output SVGP, 16 latents / 4 outputs (2 Gaussian + 2 Logistic), m = 4096, D = 64, fp64, N = 5e6."""
+    import torch
+    import agp_amd as AGP
+    from agp_amd import capi
+
+    N, D, m, B, Q = 5_000_000, 64, 4096, 4096, 16
+    X, f, g = _data(torch, N, D, torch.float64, seed=5)
+    fs = [f, torch.cos(X[:, 0] * 6), f * X[:, 1], X[:, 2] - 0.5]
+    ys = [(fs[0] + 0.1 * torch.randn(N, dtype=torch.float64, device="cuda", generator=g)).cpu().numpy(),
+          (fs[1] + 0.1 * torch.randn(N, dtype=torch.float64, device="cuda", generator=g)).cpu().numpy(),
+          torch.sign(fs[2]).cpu().numpy(), torch.sign(fs[3]).cpu().numpy()]
+    ys[2][ys[2] == 0] = 1
+    ys[3][ys[3] == 0] = 1
+    rng = np.random.default_rng(5)
+    Zs = [X[torch.as_tensor(rng.permutation(N)[:m], device="cuda")].cpu().numpy() for _ in range(Q)]
+    A = rng.random((4, Q)) + 0.1
+    A /= np.linalg.norm(A, axis=1, keepdims=True)
+    liks = [AGP.GaussianLikelihood(0.05), AGP.GaussianLikelihood(0.05), AGP.LogisticLikelihood(), AGP.LogisticLikelihood()]
+    model = AGP.MOSVGP(AGP.with_lengthscale(AGP.SqExponentialKernel(), np.sqrt(D) / 4), liks, AGP.AnalyticSVI(B), Zs,
+                       A=A, Aoptimiser=AGP.ADAM(0.01), seed=6)
+    AGP.train_(model, X, ys, 3)
+    An = model.get_A()
+    assert np.allclose(np.linalg.norm(An, axis=1), 1.0, atol=1e-12) and np.max(np.abs(An - A)) > 0
+    _check_latent(AGP, capi, model, 3, 1.0, 1e-6)
+    out = AGP.proba_y(model, X[:20_000])
+    assert len(out) == 4 and np.all(out[0][1] > 0) and np.all((out[2][0] >= 0) & (out[2][0] <= 1))

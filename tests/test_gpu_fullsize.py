@@ -142,4 +142,7 @@ def test_c5_shape_multioutput(built):
     assert np.allclose(np.linalg.norm(An, axis=1), 1.0, atol=1e-12) and np.max(np.abs(An - A)) > 0
     _check_latent(AGP, capi, model, 3, 1.0, 1e-6)
     out = AGP.proba_y(model, X[:20_000])
-    assert len(out) == 4 and np.all(out[0][1] > 0) and np.all((out[2][0] >= 0) & (out[2][0] <= 1))
+    # (3 noisy SVI steps of the Jacobi-style 16-latent update overshoot -- means are O(100) -- so only structure is checked;
+    #  a saturated Gauss-Hermite sum may exceed 1 by an ulp, as in the reference's dot(pred_weights, ...))
+    assert len(out) == 4 and np.all(out[0][1] > 0)
+    assert np.all(np.isfinite(out[2][0])) and np.all((out[2][0] >= 0) & (out[2][0] <= 1 + 1e-12))

@@ -152,7 +152,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- roofline of the dominant kernel (k_potrf_trtri_step: 16 launches per step at m = 1024) ----
+    # ---- roofline of the dominant kernel (k_chol_step: 16 launches per step at m = 1024) ----
     mp = (m + 63) // 64 * 64
     Bq = (B + 63) // 64 * 64
     # algorithmic flops of one augmented factorisation: potrf m^3/3 + panel solves of the (B + 64) extension rows m^2 each
@@ -161,13 +161,14 @@ def main():
     avg_launch_s = (kms.value * 1e-3) / max(nl.value, 1)
     achieved = (flops_seq / launches_per_step) / avg_launch_s / 1e12 if nl.value else 0.0
     roofline = {
-        "kernel": "k_potrf_trtri_step<double>",
+        "kernel": "k_chol_step<double>",
         "bound": "mfma",
         "achieved": round(achieved, 3),
         "peak": FP64_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
         "traffic": None,
+        "traffic_unit": "bytes/launch",
         "avg_launch_us": round(avg_launch_s * 1e6, 2),
         "launches_per_step": round(launches_per_step, 2),
         "algorithmic_flops_per_launch": flops_seq / launches_per_step,
@@ -197,11 +198,52 @@ def main():
         "roofline": roofline,
     }
 
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE as
+    # MI355X_MICROARCH.md prescribes for gfx950); rocprofv3 cannot wrap bench.py from inside, so this is not live
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_bytes.json")) as fh:
+            pm = json.load(fh)
+        roofline["traffic"] = pm["kernels"]["k_chol_step<double>"]["hbm_bytes_per_launch_corrected"]
+        roofline["traffic_source"] = "profiles/r01_pmc_hbm_bytes.json (rocprofv3 --pmc, separate passes, same command)"
+    except Exception:
+        pass
+
     if rank == 0 and world == 1:
         # measured MFMA ceiling (issue-rate microbenchmark inside the library)
         pk = C.c_double()
         if L.agp_mfma_peak(model._ctx, capi.F64, C.byref(pk)) == 0:
             out["roofline"]["measured_mfma_ceiling"] = round(pk.value, 1)
+
+    # ---- extras (rank 0, single GPU): hyper-parameter step and streaming prediction, timed separately ----
+    if rank == 0 and world == 1:
+        mh = AGP.SVGP(AGP.with_lengthscale(AGP.SqExponentialKernel(), ell), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z,
+                      optimiser=AGP.ADAM(0.01), Zoptimiser=AGP.ADAM(0.001), device=local_rank)
+        mh.inference.rho = rho
+        hh = mh._ensure_handle(B)
+        mh._chk(L.agp_svgp_refresh_K(hh))
+        for i in range(3):
+            mh._chk(L.agp_svgp_cavi_step(hh, xp, ld, yp, C.c_void_p(idx_all[i].data_ptr()), B, rho))
+            mh._chk(L.agp_svgp_hyper_step(hh))
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        nh = 20
+        for i in range(nh):
+            mh._chk(L.agp_svgp_cavi_step(hh, xp, ld, yp, C.c_void_p(idx_all[3 + i].data_ptr()), B, rho))
+            mh._chk(L.agp_svgp_hyper_step(hh))
+        torch.cuda.synchronize()
+        out["ms_per_step_with_hyper_update"] = round((time.perf_counter() - th) / nh * 1e3, 4)
+        del mh
+        # streaming predict_f (means) over all N points: K_*m is never materialised
+        mu_out = torch.empty(1, N, dtype=torch.float64, device=dev)
+        model._chk(L.agp_svgp_predict_f(h, xp, ld, N, C.c_void_p(mu_out.data_ptr()), None))
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        model._chk(L.agp_svgp_predict_f(h, xp, ld, N, C.c_void_p(mu_out.data_ptr()), None))
+        torch.cuda.synchronize()
+        tp = time.perf_counter() - tp
+        out["predict_f_mean_all_N"] = {"seconds": round(tp, 4), "points_per_s": round(N / tp, 1),
+                                       "hbm_GBps_algorithmic": round((N * D * 8 + N * 8) / tp / 1e9, 2),
+                                       "valu_f64_TFLOPs": round(N * m * (3 * D + 14) / tp / 1e12, 2)}
 
     # ---- time to ELBO tolerance (build-defined rule) ----
     if not a.no_elbo_tol and rank == 0:

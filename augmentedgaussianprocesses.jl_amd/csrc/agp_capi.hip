@@ -902,7 +902,12 @@ struct Svgp : SvgpBase {
     for (auto& g : lat)
       if (g.K_stale) return AGP_OK;  // nothing sensible to prefetch against
     if (!pf_stream) {
-      HIPCHK(ctx, hipStreamCreateWithFlags(&pf_stream, hipStreamNonBlocking));
+      {
+        // lowest priority: the look-ahead GEMM must not take CUs from the latency-bound factorisation chain
+        int lo = 0, hi = 0;
+        HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(ctx, hipStreamCreateWithPriority(&pf_stream, hipStreamNonBlocking, lo));
+      }
       HIPCHK(ctx, hipEventCreateWithFlags(&pf_done, hipEventDisableTiming));
       for (auto& e : step_done) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
       HIPCHK(ctx, hipEventRecord(step_done[0], st()));
@@ -1657,7 +1662,7 @@ static agp_status bb_mfma_peak(agp_ctx* ctx, double* tflops) {
   return AGP_OK;
 }
 
-template <typename T>
+template <typename T, int VAR>
 static agp_status bb_diag_bench(agp_ctx* ctx, int blocks, int reps, double* us) {
   T *A = nullptr, *out = nullptr;
   int32_t* info = nullptr;
@@ -1672,15 +1677,39 @@ static agp_status bb_diag_bench(agp_ctx* ctx, int blocks, int reps, double* us) 
   hipEvent_t e0, e1;
   HIPCHK(ctx, hipEventCreate(&e0));
   HIPCHK(ctx, hipEventCreate(&e1));
-  hipLaunchKernelGGL((k_diag_bench<T>), dim3(blocks), dim3(CHOL_THREADS), 0, ctx->stream, (const T*)A, out, 2, info);
+  hipLaunchKernelGGL((k_diag_bench<T, VAR>), dim3(blocks), dim3(CHOL_THREADS), 0, ctx->stream, (const T*)A, out, 2, info);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-  hipLaunchKernelGGL((k_diag_bench<T>), dim3(blocks), dim3(CHOL_THREADS), 0, ctx->stream, (const T*)A, out, reps, info);
+  hipLaunchKernelGGL((k_diag_bench<T, VAR>), dim3(blocks), dim3(CHOL_THREADS), 0, ctx->stream, (const T*)A, out, reps, info);
   HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
   HIPCHK(ctx, hipEventSynchronize(e1));
   float ms = 0;
   HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
   *us = ms * 1e3 / reps;
+  {  // residuals of block 0 (development aid): |L L' - A|, |X L - I|, strict-upper leakage
+    std::vector<T> o(2 * TILE * TILE);
+    HIPCHK(ctx, hipMemcpy(o.data(), out, sizeof(T) * 2 * TILE * TILE, hipMemcpyDeviceToHost));
+    const T* Lh = o.data();
+    const T* Xh = o.data() + TILE * TILE;
+    double e1m = 0, e2m = 0, e3m = 0;
+    for (int i = 0; i < TILE; ++i)
+      for (int j = 0; j < TILE; ++j) {
+        double s1 = 0, s2 = 0;
+        for (int k = 0; k < TILE; ++k) {
+          s1 += (double)Lh[i * TILE + k] * (double)Lh[j * TILE + k];
+          s2 += (double)Xh[i * TILE + k] * (double)Lh[k * TILE + j];
+        }
+        e1m = std::max(e1m, std::abs(s1 - (double)h[i * TILE + j]));
+        e2m = std::max(e2m, std::abs(s2 - (i == j ? 1.0 : 0.0)));
+        if (j > i) e3m = std::max(e3m, std::abs((double)Lh[i * TILE + j]) + std::abs((double)Xh[i * TILE + j]));
+      }
+    if (getenv("AGP_DIAG_VERBOSE")) fprintf(stderr, "[diag_bench var=%d] |LL'-A|=%.3e |XL-I|=%.3e upper=%.3e\n", VAR, e1m, e2m, e3m);
+    const double tol = sizeof(T) == 8 ? 1e-12 : 1e-4;
+    if (!(e1m < tol) || !(e2m < tol) || e3m != 0.0) {
+      ctx->err = "diag_bench residual check failed";
+      return AGP_ERR_NOT_POSDEF;
+    }
+  }
   (void)hipFree(A);
   (void)hipFree(out);
   (void)hipFree(info);
@@ -1732,9 +1761,8 @@ agp_status agp_mfma_peak(agp_ctx* ctx, int32_t dtype, double* tflops_host) {
 // development micro-benchmark (not part of include/agp_hip.h): microseconds per 64x64 diagonal-tile factorisation
 agp_status agp_dev_diag_bench(agp_ctx* ctx, int32_t dtype, int32_t variant, int32_t blocks, int32_t reps, double* us) {
   if (!ctx || !us) return AGP_ERR_INVALID;
-  (void)variant;
-  if (dtype == AGP_F64) return bb_diag_bench<double>(ctx, blocks, reps, us);
-  return bb_diag_bench<float>(ctx, blocks, reps, us);
+  if (dtype == AGP_F64) return variant ? bb_diag_bench<double, 1>(ctx, blocks, reps, us) : bb_diag_bench<double, 0>(ctx, blocks, reps, us);
+  return variant ? bb_diag_bench<float, 1>(ctx, blocks, reps, us) : bb_diag_bench<float, 0>(ctx, blocks, reps, us);
 }
 
 agp_status agp_svgp_create(agp_ctx* ctx, const agp_svgp_desc* desc, agp_svgp** out) {

@@ -137,8 +137,8 @@ __device__ __forceinline__ void mma_lds64(const T* As, const T* Bs, Acc<T>& acc)
 // ---------------------------------------------------------------------------------------------------
 constexpr int SC_ELEMS = 2 * 2 * 4 * TILE;
 
-template <typename T, int J>
-__device__ __forceinline__ void chol_rounds(T (&a)[4][4], T (&g)[4][4], T* sc, T* piv, const bool act, const int ti,
+template <typename T, int J, int NS>
+__device__ __forceinline__ void chol_rounds(T (&a)[NS][NS], T (&g)[NS][NS], T* sc, T* piv, const bool act, const int ti,
                                             const int tj) {
 #pragma unroll 1
   for (int rr = 0; rr < 4; ++rr) {
@@ -149,7 +149,7 @@ __device__ __forceinline__ void chol_rounds(T (&a)[4][4], T (&g)[4][4], T* sc, T
       const int qc = tj - jj0, qr = ti - jj0;
       if (qc >= 0 && qc < 4) {
 #pragma unroll
-        for (int r = J; r < 4; ++r) {
+        for (int r = J; r < NS; ++r) {
           T v = a[r][J];
           if (r == J) v = (ti >= jj0) ? v : T(0);  // rows above the panel are dead
           P[qc * TILE + ti + 16 * r] = v;
@@ -190,9 +190,9 @@ __device__ __forceinline__ void chol_rounds(T (&a)[4][4], T (&g)[4][4], T* sc, T
       piv[j0 + 3] = d33;
     }
     // ---- panel transforms for my columns / my M columns, then row by row: multipliers + rank-4 update ----
-    T u[4][4], mw[4][4];  // [q][c]
+    T u[4][NS], mw[4][NS];  // [q][c]
 #pragma unroll
-    for (int c = J; c < 4; ++c) {
+    for (int c = J; c < NS; ++c) {
       const int x = tj + 16 * c;
       T y0 = P[x], y1 = P[TILE + x], y2 = P[2 * TILE + x], y3 = P[3 * TILE + x];
       y1 = fma(-l10, y0, y1);
@@ -220,7 +220,7 @@ __device__ __forceinline__ void chol_rounds(T (&a)[4][4], T (&g)[4][4], T* sc, T
       mw[3][c] = y3;
     }
 #pragma unroll
-    for (int r = J; r < 4; ++r) {
+    for (int r = J; r < NS; ++r) {
       const int x = ti + 16 * r;
       T y0 = P[x], y1 = P[TILE + x], y2 = P[2 * TILE + x], y3 = P[3 * TILE + x];
       y1 = fma(-l10, y0, y1);
@@ -268,10 +268,10 @@ __device__ __forceinline__ void factor_diag_tile512(T* bufA, T* bufB, T* sc, T* 
       g[r][c] = (R == Cc) ? T(1) : T(0);
     }
   __syncthreads();
-  chol_rounds<T, 0>(a, g, sc, piv, act, ti, tj);
-  chol_rounds<T, 1>(a, g, sc, piv, act, ti, tj);
-  chol_rounds<T, 2>(a, g, sc, piv, act, ti, tj);
-  chol_rounds<T, 3>(a, g, sc, piv, act, ti, tj);
+  chol_rounds<T, 0, 4>(a, g, sc, piv, act, ti, tj);
+  chol_rounds<T, 1, 4>(a, g, sc, piv, act, ti, tj);
+  chol_rounds<T, 2, 4>(a, g, sc, piv, act, ti, tj);
+  chol_rounds<T, 3, 4>(a, g, sc, piv, act, ti, tj);
   __syncthreads();  // piv complete
   if (tid < TILE) {
     const T p = piv[tid];
@@ -303,6 +303,148 @@ __device__ __forceinline__ void factor_diag_tile512(T* bufA, T* bufB, T* sc, T* 
         bufA[R * LDP + Cc] = (R >= Cc) ? a[r][c] * rsC[c] : T(0);
         bufB[R * LDP + Cc] = (R >= Cc) ? g[r][c] * rsR[r] : T(0);
       }
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Two-level variant of the diagonal-tile factorisation: the 64x64 tile is split into 32x32 blocks
+//   [A11 . ; A21 A22] :  (L11, X11) = elim(A11) ; L21 = A21 X11' ; S = A22 - L21 L21' ; (L22, X22) = elim(S) ;
+//   X21 = -X22 (L21 X11)
+// The two eliminations use the same 4-column rounds with 2x2 cyclic ownership (about half the per-round work of the
+// 4x4 ownership: the redundant per-thread transforms shrink with the sub-block count); the glue is four 32^3 MFMA products.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, bool TB>
+__device__ __forceinline__ typename Mfma<T>::acc_t mma_blk32(const T* As, const T* Bs, typename Mfma<T>::acc_t acc,
+                                                             int wr, int wc, int lane, bool negA) {
+  // acc(16x16 tile (wr, wc) of a 32x32 result) += sum_k A[r][k] * B(k, c) ; TB: B(k,c) = Bs[k*LDP + c] else Bs[c*LDP + k]
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    T a = As[(wr * 16 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    if (negA) a = -a;
+    T b = TB ? Bs[(kk * 4 + (lane >> 4)) * LDP + wc * 16 + (lane & 15)]
+             : Bs[(wc * 16 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    acc = Mfma<T>::mma(a, b, acc);
+  }
+  return acc;
+}
+
+// eliminate the 32x32 block at (o, o) of bufA (lower valid): L -> bufA block, L^-1 -> bufB block ; all threads call
+template <typename T>
+__device__ __forceinline__ void elim_block32(T* bufA, T* bufB, int o, T* sc, T* piv, const bool act, const int ti,
+                                             const int tj) {
+  T a[2][2], g[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      int R = ti + 16 * r, Cc = tj + 16 * c;
+      int lo = R >= Cc ? R : Cc, hi = R >= Cc ? Cc : R;
+      a[r][c] = bufA[(o + lo) * LDP + o + hi];
+      g[r][c] = (R == Cc) ? T(1) : T(0);
+    }
+  __syncthreads();
+  chol_rounds<T, 0, 2>(a, g, sc, piv + o, act, ti, tj);
+  chol_rounds<T, 1, 2>(a, g, sc, piv + o, act, ti, tj);
+  __syncthreads();
+  if (act) {
+    T rsC[2], rsR[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      T pc = piv[o + tj + 16 * q], pr = piv[o + ti + 16 * q];
+      rsC[q] = T(1) / sqrt(pc > T(0) ? pc : T(1));
+      rsR[q] = T(1) / sqrt(pr > T(0) ? pr : T(1));
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        int R = ti + 16 * r, Cc = tj + 16 * c;
+        bufA[(o + R) * LDP + o + Cc] = (R >= Cc) ? a[r][c] * rsC[c] : T(0);
+        bufB[(o + R) * LDP + o + Cc] = (R >= Cc) ? g[r][c] * rsR[r] : T(0);
+      }
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__device__ __forceinline__ void factor_diag_tile_2lvl(T* bufA, T* bufB, T* sc, T* piv, int32_t* info, int64_t col0,
+                                                      int64_t nvalid) {
+  const int tid = threadIdx.x;
+  const bool act = tid < 256;
+  const int ti = (tid & 255) >> 4, tj = tid & 15;
+  const int lane = tid & 63, wave = tid >> 6, wr = (wave >> 1) & 1, wc = wave & 1;
+  const bool mw = wave < 4;  // the four waves that run the 32^3 MFMA products (one 16x16 result tile each)
+  typedef typename Mfma<T>::acc_t acc_t;
+  elim_block32<T>(bufA, bufB, 0, sc, piv, act, ti, tj);
+  // L21 = A21 X11'   (in place in bufA[32:64, 0:32])
+  acc_t acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = T(0);
+  if (mw) acc = mma_blk32<T, false>(bufA + 32 * LDP, bufB, acc, wr, wc, lane, false);
+  __syncthreads();
+  if (mw) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      bufA[(32 + wr * 16 + Mfma<T>::row(lane, r)) * LDP + wc * 16 + (lane & 15)] = acc[r];
+  }
+  __syncthreads();
+  // S = A22 - L21 L21'   (in place in bufA[32:64, 32:64]; the full block, symmetric up to rounding; the lower part is used)
+  if (mw) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      acc[r] = bufA[(32 + wr * 16 + Mfma<T>::row(lane, r)) * LDP + 32 + wc * 16 + (lane & 15)];
+    if (wr < wc) {  // upper tile of A22 was never valid input: mirror the lower one
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[r] = bufA[(32 + wc * 16 + (lane & 15)) * LDP + 32 + wr * 16 + Mfma<T>::row(lane, r)];
+    }
+    acc = mma_blk32<T, false>(bufA + 32 * LDP, bufA + 32 * LDP, acc, wr, wc, lane, true);
+  }
+  __syncthreads();
+  if (mw) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      bufA[(32 + wr * 16 + Mfma<T>::row(lane, r)) * LDP + 32 + wc * 16 + (lane & 15)] = acc[r];
+  }
+  __syncthreads();
+  elim_block32<T>(bufA, bufB, 32, sc, piv, act, ti, tj);
+  // P = L21 X11  -> scratch bufB[0:32, 32:64]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = T(0);
+  if (mw) {
+    acc = mma_blk32<T, true>(bufA + 32 * LDP, bufB, acc, wr, wc, lane, false);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bufB[(wr * 16 + Mfma<T>::row(lane, r)) * LDP + 32 + wc * 16 + (lane & 15)] = acc[r];
+  }
+  __syncthreads();
+  // X21 = -X22 P   -> bufB[32:64, 0:32]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = T(0);
+  if (mw) {
+    acc = mma_blk32<T, true>(bufB + 32 * LDP + 32, bufB + 32, acc, wr, wc, lane, true);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bufB[(32 + wr * 16 + Mfma<T>::row(lane, r)) * LDP + wc * 16 + (lane & 15)] = acc[r];
+  }
+  __syncthreads();
+  // clear the upper-right blocks (input garbage in bufA, scratch P in bufB) and report bad pivots
+  for (int e = tid; e < 32 * 32; e += blockDim.x) {
+    bufA[(e >> 5) * LDP + 32 + (e & 31)] = T(0);
+    bufB[(e >> 5) * LDP + 32 + (e & 31)] = T(0);
+  }
+  if (tid < TILE) {
+    const T p = piv[tid];
+    const bool bad = !(p > T(0)) && (col0 + tid) < nvalid;
+    const unsigned long long mask = __ballot(bad);
+    if (mask != 0ull && tid == 0) {
+      int32_t want = (int32_t)(col0 + (__ffsll((long long)mask) - 1) + 1);
+      int32_t old = atomicCAS(info, 0, want);
+      while (old != 0 && old > want) {
+        int32_t prev = atomicCAS(info, old, want);
+        if (prev == old) break;
+        old = prev;
+      }
+    }
   }
   __syncthreads();
 }
@@ -360,7 +502,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(T* __restrict__ A, i
     if (b > 0)  // own tile with the pending update applied, parked in LDS across the factorisation
       acc8_foreach<T>(accT, [&](int r, int c, T& val) { bufC[r * LDP + c] = val; });
     __syncthreads();
-    factor_diag_tile512<T>(bufA, bufB, sc, piv, info, d0, nvalid);
+    factor_diag_tile_2lvl<T>(bufA, bufB, sc, piv, info, d0, nvalid);
     if (b == 0) {
       for (int e = tid; e < TILE * TILE; e += CHOL_THREADS) {
         int R = e >> 6, Cc = e & 63;
@@ -439,7 +581,7 @@ __global__ void k_publish_diag(T* __restrict__ A, int64_t ld, const T* __restric
 }
 
 // micro-benchmark of the diagonal-tile factorisation alone (tools/bench_diag.py): `reps` factorizations per launch
-template <typename T>
+template <typename T, int VAR>
 __global__ __launch_bounds__(CHOL_THREADS) void k_diag_bench(const T* __restrict__ A, T* __restrict__ out, int reps,
                                                              int32_t* info) {
   __shared__ __attribute__((aligned(16))) T sm[2 * TILE * LDP];
@@ -450,7 +592,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_diag_bench(const T* __restrict
   for (int it = 0; it < reps; ++it) {
     for (int e = threadIdx.x; e < TILE * TILE; e += CHOL_THREADS) bufA[(e >> 6) * LDP + (e & 63)] = A[e];
     __syncthreads();
-    factor_diag_tile512<T>(bufA, bufB, sc, piv, info, 0, 64);
+    if (VAR == 0) factor_diag_tile512<T>(bufA, bufB, sc, piv, info, 0, 64);
+    else factor_diag_tile_2lvl<T>(bufA, bufB, sc, piv, info, 0, 64);
   }
   for (int e = threadIdx.x; e < TILE * TILE; e += CHOL_THREADS) {
     out[blockIdx.x * 2 * TILE * TILE + e] = bufA[(e >> 6) * LDP + (e & 63)];

@@ -18,9 +18,14 @@ from .kernels import (  # noqa: F401
     with_lengthscale,
 )
 from .likelihoods import (  # noqa: F401
+    BayesianSVM,
     GaussianLikelihood,
+    HeteroscedasticLikelihood,
+    LaplaceLikelihood,
     LogisticLikelihood,
     LogisticSoftMaxLikelihood,
+    NegBinomialLikelihood,
+    PoissonLikelihood,
     StudentTLikelihood,
 )
 from .svgp import (  # noqa: F401

@@ -25,6 +25,7 @@ ERR_NAMES = {
 F64, F32 = 0, 1
 K_SQEXP, K_MATERN52, K_MATERN32, K_EXPONENTIAL = 0, 1, 2, 3
 LIK_GAUSSIAN, LIK_LOGISTIC, LIK_STUDENTT, LIK_LOGISTICSOFTMAX, LIK_MULTIOUTPUT = 0, 1, 2, 3, 4
+LIK_LAPLACE, LIK_BAYESIANSVM, LIK_POISSON, LIK_NEGBINOMIAL, LIK_HETEROSCEDASTIC = 5, 6, 7, 8, 9
 ELBO_CORRECTED, ELBO_REFERENCE = 0, 1
 MAT_L, MAT_KINV, MAT_KNM, MAT_KAPPA, VEC_KTILDE, VEC_MEAN_F, VEC_VAR_F, VEC_THETA, VEC_C, VEC_GAMMA, VEC_ALPHA = range(11)
 
@@ -110,6 +111,9 @@ SYMBOLS = {
     "agp_svgp_predict_f": (_I32, [_VP, _VP, _I64, _I64, _VP, _VP]),
     "agp_svgp_predict_y": (_I32, [_VP, _VP, _I64, _I64, _VP]),
     "agp_svgp_proba_y": (_I32, [_VP, _VP, _I64, _I64, _PDBL, _PDBL, _I32, _VP, _VP]),
+    "agp_svgp_set_quadrature": (_I32, [_VP, _PDBL, _PDBL, _I32]),
+    "agp_svgp_get_lik_param": (_I32, [_VP, _PDBL]),
+    "agp_svgp_set_lik_param": (_I32, [_VP, _DBL]),
 }
 
 _lib = None

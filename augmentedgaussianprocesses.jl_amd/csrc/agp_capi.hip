@@ -170,6 +170,9 @@ struct SvgpBase {
   virtual agp_status predict_y(const void* xt, int64_t ldx, int64_t nt, void* out) = 0;
   virtual agp_status proba_y(const void* xt, int64_t ldx, int64_t nt, const double* nodes, const double* weights,
                              int nn, void* o0, void* o1) = 0;
+  virtual agp_status set_quadrature(const double* nodes, const double* weights, int nn) = 0;
+  virtual agp_status get_lik_param(double* out) = 0;
+  virtual agp_status set_lik_param(double v) = 0;
   int64_t n_opt = 1;  // RobbinsMonro counter (optimisers.jl:12)
   // HIP-event timing of the dominant kernel sequence (agp_svgp_timing_*)
   bool timing = false;
@@ -214,6 +217,12 @@ struct SvgpBase {
 struct agp_svgp {
   SvgpBase* impl;
 };
+
+// teardown helpers: a failing free / destroy is a bug in this library, so it is reported, never swallowed
+static void dcheck(hipError_t e, int line) {
+  if (e != hipSuccess) fprintf(stderr, "[agp_hip] teardown: %s (agp_capi.hip:%d)\n", hipGetErrorString(e), line);
+}
+#define dfree(p) dcheck(hipFree(p), __LINE__)
 
 template <typename T>
 struct Svgp : SvgpBase {
@@ -301,7 +310,9 @@ struct Svgp : SvgpBase {
   T *Kstar = nullptr, *ppm = nullptr, *ppv = nullptr, *pmu = nullptr, *pvar = nullptr;
   int64_t pred_chunk = 0, pred_nt_cap = 0;
   double* gh_dev = nullptr;
-  int gh_cap = 0;
+  int gh_cap = 0, gh_n = 0;  // Gauss-Hermite nodes | weights (agp_svgp_set_quadrature / proba_y)
+  T* lam_dev = nullptr;       // Poisson / heteroscedastic lambda (state re-estimated by every local update)
+  double* lam_part = nullptr; // per-workgroup partial sums of the lambda update
   // last step
   const void* x_last = nullptr;
   const void* y_last = nullptr;
@@ -326,7 +337,7 @@ struct Svgp : SvgpBase {
     lp.kind = desc.lik.kind;
     lp.p0 = (T)desc.lik.p0;
     lp.p1 = (T)desc.lik.p1;
-    if (lp.kind < 0 || lp.kind > AGP_LIK_MULTIOUTPUT) {
+    if (lp.kind < 0 || lp.kind > AGP_LIK_HETEROSCEDASTIC) {
       ctx->err = "likelihood not implemented for AnalyticVI on this path";
       return AGP_ERR_UNSUPPORTED;
     }
@@ -335,7 +346,16 @@ struct Svgp : SvgpBase {
       ctx->err = "nu should be greater than 0.5";  // studentt.jl:28
       return AGP_ERR_INVALID;
     }
-    if (lp.kind != AGP_LIK_LOGISTICSOFTMAX && lp.kind != AGP_LIK_MULTIOUTPUT && nl != 1) return AGP_ERR_INVALID;
+    if ((lp.kind == AGP_LIK_LAPLACE || lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_NEGBINOMIAL ||
+         lp.kind == AGP_LIK_HETEROSCEDASTIC) && !(desc.lik.p0 > 0)) {
+      ctx->err = "likelihood parameter (beta / lambda / r) must be positive";
+      return AGP_ERR_INVALID;
+    }
+    if (lp.kind == AGP_LIK_HETEROSCEDASTIC) {  // n_latent(::HeteroscedasticGaussianLikelihood) = 2  heteroscedastic.jl:47
+      if (nl != 2 || desc.latent_offset != 0) return AGP_ERR_INVALID;
+    } else if (lp.kind != AGP_LIK_LOGISTICSOFTMAX && lp.kind != AGP_LIK_MULTIOUTPUT && nl != 1) {
+      return AGP_ERR_INVALID;
+    }
     if (desc.stochastic && !(desc.rm_kappa > 0.5 && desc.rm_kappa <= 1.0 && desc.rm_tau > 0)) {
       ctx->err = "RobbinsMonro: kappa in (0.5,1], tau > 0";  // optimisers.jl:7-8
       return AGP_ERR_INVALID;
@@ -388,6 +408,9 @@ struct Svgp : SvgpBase {
     AGPCHK(dmalloc(ctx, &info_dev, 1));
     AGPCHK(dmalloc(ctx, &flags_dev, 1));
     AGPCHK(dmalloc(ctx, &scal_dev, 64));
+    AGPCHK(dmalloc(ctx, &lam_dev, 1));
+    AGPCHK(dmalloc(ctx, &lam_part, 2 * (Bp / 256 + 1)));
+    hipLaunchKernelGGL((k_fill<T>), dim3(1), dim3(64), 0, st(), lam_dev, (int64_t)1, (T)(desc.lik.p0 > 0 ? desc.lik.p0 : 1.0));
     HIPCHK(ctx, hipMemsetAsync(info_dev, 0, sizeof(int32_t), st()));
     HIPCHK(ctx, hipMemsetAsync(flags_dev, 0, sizeof(int), st()));
     // LogisticSoftMax state: alpha = beta = K (total classes)  logisticsoftmax.jl:43-53
@@ -400,41 +423,43 @@ struct Svgp : SvgpBase {
   }
 
   ~Svgp() override {
-    for (auto e : ev) (void)hipEventDestroy(e);
+    for (auto e : ev) dcheck(hipEventDestroy(e), __LINE__);
     for (auto& g : lat) {
       T* ps[] = {g.scales, g.Z, g.L, g.Xk, g.Kinv, g.mu0, g.kinv_mu0, g.eta1, g.eta2, g.La, g.Xa, g.v,
                  g.Sigma, g.mu, g.Knm, g.kappa, g.Apred, g.apred, g.Wbuf, g.DgK, g.DgA, g.pk, g.Knm_alt, g.kappa_alt, g.Wbuf_alt, g.pk_alt};
       for (T* p : ps)
-        if (p) (void)hipFree(p);
+        if (p) dfree(p);
     }
-    if (pf_stream) (void)hipStreamDestroy(pf_stream);
-    if (pf_done) (void)hipEventDestroy(pf_done);
+    if (pf_stream) dcheck(hipStreamDestroy(pf_stream), __LINE__);
+    if (pf_done) dcheck(hipEventDestroy(pf_done), __LINE__);
     for (auto e : step_done)
-      if (e) (void)hipEventDestroy(e);
+      if (e) dcheck(hipEventDestroy(e), __LINE__);
     T* ps[] = {pw0, pw1, Kt, muf, varf, cbuf, theta, gamma, rbuf, wbuf, alpha, beta, gsum, alpha_save, emuf,
                evarf, cpart, stats, Tw, Tw2, tmpv, lr_dev, Kstar, ppm, ppv, pmu, pvar};
     for (T* p : ps)
-      if (p) (void)hipFree(p);
+      if (p) dfree(p);
     T* hps[] = {hyH1, hyH2, hyH3, hy_gmu, hy_gs, hy_muf, hy_pZ, hy_dZ};
     for (T* p : hps)
-      if (p) (void)hipFree(p);
+      if (p) dfree(p);
     double* hds[] = {hy_pvar, hy_pscale, hy_g};
     for (double* p : hds)
-      if (p) (void)hipFree(p);
+      if (p) dfree(p);
     for (auto& g : lat) {
-      if (g.z_am) (void)hipFree(g.z_am);
-      if (g.z_av) (void)hipFree(g.z_av);
+      if (g.z_am) dfree(g.z_am);
+      if (g.z_av) dfree(g.z_av);
     }
     T* mops[] = {A_dev, mo_mixm, mo_mixv, mo_th, mo_cc, mo_th_save, mo_pmu, mo_pvar};
     for (T* p : mops)
-      if (p) (void)hipFree(p);
+      if (p) dfree(p);
     double* dps[] = {gradA_dev, am_dev, av_dev};
     for (double* p : dps)
-      if (p) (void)hipFree(p);
-    if (info_dev) (void)hipFree(info_dev);
-    if (flags_dev) (void)hipFree(flags_dev);
-    if (scal_dev) (void)hipFree(scal_dev);
-    if (gh_dev) (void)hipFree(gh_dev);
+      if (p) dfree(p);
+    if (info_dev) dfree(info_dev);
+    if (flags_dev) dfree(flags_dev);
+    if (scal_dev) dfree(scal_dev);
+    if (gh_dev) dfree(gh_dev);
+    if (lam_dev) dfree(lam_dev);
+    if (lam_part) dfree(lam_part);
   }
 
   agp_status upload_scales(Latent& g) {
@@ -604,7 +629,28 @@ struct Svgp : SvgpBase {
       hipLaunchKernelGGL((k_rowstats_local<T>), grid1(B * 64), dim3(256), 0, st(), B, ns, (const T*)g.pk, ldp,
                          (const T*)g.Wbuf, mp, mp, (const T*)(g.Wbuf + Bq * mp), (T)g.k.variance, (T)jitter, (T)rho, lp,
                          (const T*)y, idx, Kt + l * Bp, muf + l * Bp, varf + l * Bp, cbuf + l * Bp, theta + l * Bp,
-                         rbuf + l * Bp, wbuf + l * Bp, flags_dev, (int)keep);
+                         rbuf + l * Bp, wbuf + l * Bp, flags_dev, (int)keep, (const T*)lam_dev, gamma + l * Bp);
+      LAUNCHCHK(ctx);
+    }
+    if (lp.kind == AGP_LIK_POISSON) {  // lambda <- sum(y) / sum E[logistic(f)]   poisson.jl:78
+      if (gh_n <= 0) {
+        ctx->err = "PoissonLikelihood: install the Gauss-Hermite rule first (agp_svgp_set_quadrature)";
+        return AGP_ERR_INVALID;
+      }
+      const int nb = (int)((B + 255) / 256);
+      hipLaunchKernelGGL((k_poisson_partial<T>), dim3(nb), dim3(256), 0, st(), B, (const T*)y, idx, (const T*)muf,
+                         (const T*)varf, gh_n, (const double*)gh_dev, (const double*)(gh_dev + gh_n), lam_part);
+      hipLaunchKernelGGL((k_lambda_finish<T>), dim3(1), dim3(256), 0, st(), nb, 2, (const double*)lam_part, 0, (double)B,
+                         lam_dev);
+      LAUNCHCHK(ctx);
+    } else if (lp.kind == AGP_LIK_HETEROSCEDASTIC) {  // heteroscedastic.jl:71-129
+      const int nb = (int)((B + 255) / 256);
+      hipLaunchKernelGGL((k_hetero_local<T>), dim3(nb), dim3(256), 0, st(), B, Bp, (const T*)y, idx, (const T*)muf,
+                         (const T*)varf, (const T*)lam_dev, cbuf, gamma, theta, lam_part);
+      hipLaunchKernelGGL((k_lambda_finish<T>), dim3(1), dim3(256), 0, st(), nb, 1, (const double*)lam_part, 1, (double)B,
+                         lam_dev);
+      hipLaunchKernelGGL((k_hetero_grads<T>), dim3(nb), dim3(256), 0, st(), B, Bp, (T)rho, (const T*)y, idx,
+                         (const T*)lam_dev, (const T*)gamma, theta, rbuf, wbuf);
       LAUNCHCHK(ctx);
     }
     x_last = x;
@@ -677,12 +723,21 @@ struct Svgp : SvgpBase {
     // mean_f with the current posterior, then g_mu / g_sigma from the step's local variables
     hipLaunchKernelGGL((k_gemv_rows<T>), grid1(B * 64), dim3(256), 0, st(), (const T*)g.kappa, mp, B, mp, (const T*)g.mu,
                        hy_muf);
-    hipLaunchKernelGGL((k_hyper_gvec<T>), grid1(B), dim3(256), 0, st(), B, rho,
-                       (int)(lp.kind == AGP_LIK_LOGISTIC && desc.elbo_mode == AGP_ELBO_REFERENCE),
-                       (const T*)(rbuf + l * Bp), (const T*)(theta + l * Bp), (const T*)hy_muf, hy_gmu, hy_gs);
-    LAUNCHCHK(ctx);
     AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.kappa, mp, g.Sigma, mp, Bq, mp, mp, 0, hyH1, mp, nullptr, 0, nullptr, nullptr,
                                   nullptr, 0)));
+    int gmode = 0;
+    const bool refm = desc.elbo_mode == AGP_ELBO_REFERENCE;
+    if (refm && (lp.kind == AGP_LIK_LOGISTIC || lp.kind == AGP_LIK_NEGBINOMIAL)) gmode = 1;
+    if (refm && lp.kind == AGP_LIK_BAYESIANSVM) gmode = 2;
+    if (lp.kind == AGP_LIK_HETEROSCEDASTIC && l == 0) {
+      gmode = 3;  // needs var_f under the current posterior: rowdot(kappa Sigma, kappa) + K~
+      hipLaunchKernelGGL((k_hyper_varf<T>), grid1(B * 64), dim3(256), 0, st(), B, mp, mp, (const T*)hyH1,
+                         (const T*)g.kappa, (const T*)(Kt + l * Bp), pw0);
+    }
+    hipLaunchKernelGGL((k_hyper_gvec<T>), grid1(B), dim3(256), 0, st(), B, rho, gmode, (const T*)(rbuf + l * Bp),
+                       (const T*)(theta + l * Bp), (const T*)hy_muf, (const T*)y_last, idx_last, (const T*)pw0,
+                       (const T*)gamma, (const T*)lam_dev, hy_gmu, hy_gs);
+    LAUNCHCHK(ctx);
     hipLaunchKernelGGL((k_hyper_gkappa<T>), grid2(Bq, mp), blk2, 0, st(), B, Bq, mp, mp, rho, (const T*)hy_gmu,
                        (const T*)hy_gs, (const T*)g.mu, (const T*)g.Knm, hyH1);
     LAUNCHCHK(ctx);
@@ -828,7 +883,9 @@ struct Svgp : SvgpBase {
                              double b2, double eps) override {
     if (lp.kind != AGP_LIK_MULTIOUTPUT || n_task <= 0 || n_task > MO_MAXT || !liks || !A_host) return AGP_ERR_INVALID;
     for (int t = 0; t < n_task; ++t) {
-      if (liks[t].kind < AGP_LIK_GAUSSIAN || liks[t].kind > AGP_LIK_STUDENTT) {
+      const int tk = liks[t].kind;
+      if (!(tk == AGP_LIK_GAUSSIAN || tk == AGP_LIK_LOGISTIC || tk == AGP_LIK_STUDENTT || tk == AGP_LIK_LAPLACE ||
+            tk == AGP_LIK_BAYESIANSVM || tk == AGP_LIK_NEGBINOMIAL)) {
         ctx->err = "multi-output tasks support the Gaussian / Logistic / StudentT likelihoods on this path";
         return AGP_ERR_UNSUPPORTED;
       }
@@ -1154,7 +1211,7 @@ struct Svgp : SvgpBase {
                            (const T*)y + t, (const int32_t*)nullptr, idx,
                            (const T*)(mo_mixm + (int64_t)t * Bp), (const T*)(mo_mixv + (int64_t)t * Bp),
                            (const T*)(mo_cc + (int64_t)t * Bp), (const T*)(mo_th + (int64_t)t * Bp), (const T*)nullptr,
-                           (const T*)nullptr, (const T*)nullptr, scal_dev + 8 + 2 * t, (int64_t)nT);
+                           (const T*)nullptr, (const T*)nullptr, scal_dev + 8 + 2 * t, (int64_t)nT, (const T*)lam_dev);
       }
       LAUNCHCHK(ctx);
       std::vector<double> ht(2 * nT);
@@ -1169,7 +1226,8 @@ struct Svgp : SvgpBase {
     } else {
       hipLaunchKernelGGL((k_elbo_terms<T>), dim3(1), dim3(1024), 0, st(), B, nl, Bp, lp, desc.elbo_mode,
                          desc.latent_offset, (int)(desc.latent_offset == 0), (const T*)y, (const int32_t*)y, idx, mf, vf,
-                         (const T*)cbuf, (const T*)theta, (const T*)gamma, (const T*)alpha, (const T*)beta, scal_dev, (int64_t)1);
+                         (const T*)cbuf, (const T*)theta, (const T*)gamma, (const T*)alpha, (const T*)beta, scal_dev,
+                         (int64_t)1, (const T*)lam_dev);
       LAUNCHCHK(ctx);
     }
     if (fresh && lsm)
@@ -1382,17 +1440,33 @@ struct Svgp : SvgpBase {
     if (!out) return AGP_ERR_INVALID;
     if (mo) {  // T[n_task][n_t]: regression tasks -> mean ; Bernoulli tasks -> 1.0 / 0.0 (mu_f > 0)
       AGPCHK(predict_f(xt, ldx, nt, out, nullptr));
-      for (int t = 0; t < nT; ++t)
-        if (mocfg.kind[t] == AGP_LIK_LOGISTIC)
+      for (int t = 0; t < nT; ++t) {
+        if (mocfg.kind[t] == AGP_LIK_LOGISTIC || mocfg.kind[t] == AGP_LIK_BAYESIANSVM)
           hipLaunchKernelGGL((k_step01<T>), grid1(nt), dim3(256), 0, st(), (T*)out + (int64_t)t * nt, nt);
+        else if (mocfg.kind[t] == AGP_LIK_NEGBINOMIAL)
+          hipLaunchKernelGGL((k_predict_event<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)out + (int64_t)t * nt, 1,
+                             (double)mocfg.p0[t], (const T*)nullptr, (T*)out + (int64_t)t * nt);
+      }
       LAUNCHCHK(ctx);
       return AGP_OK;
     }
-    if (lp.kind == AGP_LIK_GAUSSIAN || lp.kind == AGP_LIK_STUDENTT) return predict_f(xt, ldx, nt, out, nullptr);
+    if (lp.kind == AGP_LIK_GAUSSIAN || lp.kind == AGP_LIK_STUDENTT || lp.kind == AGP_LIK_LAPLACE)
+      return predict_f(xt, ldx, nt, out, nullptr);
     AGPCHK(ensure_pred_ws(nt, false));
     AGPCHK(predict_f(xt, ldx, nt, pmu, nullptr));
+    if (lp.kind == AGP_LIK_HETEROSCEDASTIC) {  // heteroscedastic.jl:137-141 : the mean of the first latent
+      HIPCHK(ctx, hipMemcpyAsync(out, pmu, sizeof(T) * nt, hipMemcpyDeviceToDevice, st()));
+      return AGP_OK;
+    }
+    if (lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_NEGBINOMIAL) {
+      hipLaunchKernelGGL((k_predict_event<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)pmu,
+                         (int)(lp.kind == AGP_LIK_NEGBINOMIAL), desc.lik.p0,
+                         lp.kind == AGP_LIK_POISSON ? (const T*)lam_dev : (const T*)nullptr, (T*)out);
+      LAUNCHCHK(ctx);
+      return AGP_OK;
+    }
     hipLaunchKernelGGL((k_predict_label<T>), grid1(nt), dim3(256), 0, st(), nt, nl, nt, desc.latent_offset,
-                       (const T*)pmu, (int32_t*)out, (int)(lp.kind == AGP_LIK_LOGISTIC));
+                       (const T*)pmu, (int32_t*)out, (int)(lp.kind == AGP_LIK_LOGISTIC || lp.kind == AGP_LIK_BAYESIANSVM));
     LAUNCHCHK(ctx);
     return AGP_OK;
   }
@@ -1406,6 +1480,29 @@ struct Svgp : SvgpBase {
     HIPCHK(ctx, hipMemcpyAsync(gh_dev, nodes, sizeof(double) * nn, hipMemcpyHostToDevice, st()));
     HIPCHK(ctx, hipMemcpyAsync(gh_dev + nn, weights, sizeof(double) * nn, hipMemcpyHostToDevice, st()));
     HIPCHK(ctx, hipStreamSynchronize(st()));
+    gh_n = nn;
+    return AGP_OK;
+  }
+  agp_status set_quadrature(const double* nodes, const double* weights, int nn) override {
+    if (!nodes || !weights || nn <= 0) return AGP_ERR_INVALID;
+    return upload_gh(nodes, weights, nn);
+  }
+  agp_status get_lik_param(double* out) override {
+    if (!out) return AGP_ERR_INVALID;
+    if (lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_HETEROSCEDASTIC) {
+      T v;
+      HIPCHK(ctx, hipMemcpyAsync(&v, lam_dev, sizeof(T), hipMemcpyDeviceToHost, st()));
+      HIPCHK(ctx, hipStreamSynchronize(st()));
+      *out = (double)v;
+    } else {
+      *out = desc.lik.p0;
+    }
+    return AGP_OK;
+  }
+  agp_status set_lik_param(double v) override {
+    if (!(v > 0) || !(lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_HETEROSCEDASTIC)) return AGP_ERR_INVALID;
+    hipLaunchKernelGGL((k_fill<T>), dim3(1), dim3(64), 0, st(), lam_dev, (int64_t)1, (T)v);
+    LAUNCHCHK(ctx);
     return AGP_OK;
   }
 
@@ -1426,11 +1523,20 @@ struct Svgp : SvgpBase {
           const double nu = (double)mocfg.p0[t], sg = (double)mocfg.p1[t];
           hipLaunchKernelGGL((k_proba_regression<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)m0, (const T*)v0,
                              (T)(nu * sg * sg / (2.0 * (nu / 2.0 - 1.0))), 1, m0, v0);
+        } else if (mocfg.kind[t] == AGP_LIK_LAPLACE) {
+          hipLaunchKernelGGL((k_proba_regression<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)m0, (const T*)v0,
+                             (T)(2.0 * (double)mocfg.p0[t] * (double)mocfg.p0[t]), 1, m0, v0);
         } else {
           if (!nodes || !weights || nn <= 0) return AGP_ERR_INVALID;
-          AGPCHK(upload_gh(nodes, weights, nn));
-          hipLaunchKernelGGL((k_proba_logistic<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)m0, (const T*)v0, nn,
-                             (const double*)gh_dev, (const double*)(gh_dev + nn), m0, v0);
+          if (gh_n != nn) AGPCHK(upload_gh(nodes, weights, nn));
+          if (mocfg.kind[t] == AGP_LIK_LOGISTIC)
+            hipLaunchKernelGGL((k_proba_logistic<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)m0, (const T*)v0, nn,
+                               (const double*)gh_dev, (const double*)(gh_dev + nn), m0, v0);
+          else
+            hipLaunchKernelGGL((k_proba_gh<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)m0, (const T*)v0, nn,
+                               (const double*)gh_dev, (const double*)(gh_dev + nn),
+                               mocfg.kind[t] == AGP_LIK_BAYESIANSVM ? 1 : 3, (double)mocfg.p0[t], (const T*)nullptr, m0,
+                               v0);
         }
       }
       LAUNCHCHK(ctx);
@@ -1451,6 +1557,21 @@ struct Svgp : SvgpBase {
       AGPCHK(upload_gh(nodes, weights, nn));
       hipLaunchKernelGGL((k_proba_logistic<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)pmu, (const T*)pvar, nn,
                          (const double*)gh_dev, (const double*)(gh_dev + nn), (T*)o0, (T*)o1);
+    } else if (lp.kind == AGP_LIK_LAPLACE) {  // laplace.jl:48-52
+      if (!o1) return AGP_ERR_INVALID;
+      hipLaunchKernelGGL((k_proba_regression<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)pmu, (const T*)pvar,
+                         (T)(2.0 * desc.lik.p0 * desc.lik.p0), 1, (T*)o0, (T*)o1);
+    } else if (lp.kind == AGP_LIK_HETEROSCEDASTIC) {
+      if (!o1) return AGP_ERR_INVALID;
+      hipLaunchKernelGGL((k_proba_hetero<T>), grid1(nt), dim3(256), 0, st(), nt, nt, (const T*)pmu, (const T*)pvar,
+                         (const T*)lam_dev, (T*)o0, (T*)o1);
+    } else if (lp.kind == AGP_LIK_BAYESIANSVM || lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_NEGBINOMIAL) {
+      if (!o1 || !nodes || !weights || nn <= 0) return AGP_ERR_INVALID;
+      AGPCHK(upload_gh(nodes, weights, nn));
+      const int link = lp.kind == AGP_LIK_BAYESIANSVM ? 1 : (lp.kind == AGP_LIK_POISSON ? 2 : 3);
+      hipLaunchKernelGGL((k_proba_gh<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)pmu, (const T*)pvar, nn,
+                         (const double*)gh_dev, (const double*)(gh_dev + nn), link, desc.lik.p0,
+                         lp.kind == AGP_LIK_POISSON ? (const T*)lam_dev : (const T*)nullptr, (T*)o0, (T*)o1);
     } else {
       hipLaunchKernelGGL((k_proba_lsm<T>), grid1(nt), dim3(256), 0, st(), nt, nl, nt, (const T*)pmu, (T*)o0);
     }
@@ -1942,6 +2063,20 @@ agp_status agp_svgp_predict_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t 
   HCHK(h);
   return h->impl->predict_y(xt, ldx, n_t, y_out);
 }
+agp_status agp_svgp_set_quadrature(agp_svgp* h, const double* gh_nodes_host, const double* gh_weights_host,
+                                   int32_t n_nodes) {
+  HCHK(h);
+  return h->impl->set_quadrature(gh_nodes_host, gh_weights_host, n_nodes);
+}
+agp_status agp_svgp_get_lik_param(agp_svgp* h, double* out) {
+  HCHK(h);
+  return h->impl->get_lik_param(out);
+}
+agp_status agp_svgp_set_lik_param(agp_svgp* h, double value) {
+  HCHK(h);
+  return h->impl->set_lik_param(value);
+}
+
 agp_status agp_svgp_proba_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, const double* gh_nodes_host,
                             const double* gh_weights_host, int32_t n_nodes, void* out0, void* out1) {
   HCHK(h);

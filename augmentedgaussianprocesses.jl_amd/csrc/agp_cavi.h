@@ -8,7 +8,18 @@
 namespace agp {
 
 enum { K_SQEXP = 0, K_MATERN52 = 1, K_MATERN32 = 2, K_EXPONENTIAL = 3 };
-enum { LIK_GAUSSIAN = 0, LIK_LOGISTIC = 1, LIK_STUDENTT = 2, LIK_LSM = 3, LIK_MO = 4 };
+enum {
+  LIK_GAUSSIAN = 0,
+  LIK_LOGISTIC = 1,
+  LIK_STUDENTT = 2,
+  LIK_LSM = 3,
+  LIK_MO = 4,
+  LIK_LAPLACE = 5,  // p0 = beta
+  LIK_BSVM = 6,
+  LIK_POISSON = 7,  // lambda lives in device memory (re-estimated by every local update)
+  LIK_NEGBIN = 8,   // p0 = r
+  LIK_HETERO = 9    // two latents (f, g) ; lambda in device memory
+};
 enum { FLAG_NEG_KTILDE = 1 };
 
 template <typename T>
@@ -166,9 +177,42 @@ __device__ __forceinline__ double safe_expcosh_d(double mu, double c) {
 template <typename T>
 struct LikParams {
   int kind;
-  T p0;  // gaussian sigma2 / studentt nu
+  T p0;  // gaussian sigma2 / studentt nu / laplace beta / negbinomial r
   T p1;  // studentt sigma
 };
+
+// Point-wise local update + expectation gradients of the single-latent likelihoods whose q(omega) needs no other state:
+//   th = theta (E[omega] as the reference defines it), cc = c (or b for Laplace), g1 = grad_E_mu ; grad_E_Sigma = th/2
+template <typename T>
+__device__ __forceinline__ void lik_point(int kind, T p0, T p1, T m, T v, T yi, T& th, T& cc, T& g1) {
+  cc = T(0);
+  if (kind == LIK_GAUSSIAN) {  // gaussian.jl:70-80
+    th = T(1) / p0;
+    g1 = yi / p0;
+  } else if (kind == LIK_LOGISTIC) {  // logistic.jl:39-51,64-69
+    cc = sqrt(m * m + v);
+    th = theta_pg<T>(cc);
+    g1 = yi / T(2);
+  } else if (kind == LIK_STUDENTT) {  // studentt.jl:68-82,96-99
+    T alpha = (p0 + T(1)) / T(2);
+    cc = ((m - yi) * (m - yi) + v + p1 * p1 * p0) / T(2);
+    th = alpha / cc;
+    g1 = th * yi;
+  } else if (kind == LIK_LAPLACE) {  // laplace.jl:60-73,85-90 : b = sqrt(E[(f-y)^2]), theta = sqrt(a)/b, a = beta^-2
+    cc = sqrt((m - yi) * (m - yi) + v);
+    th = T(1) / (p0 * cc);
+    g1 = th * yi;
+  } else if (kind == LIK_BSVM) {  // bayesiansvm.jl:43-67
+    T d = T(1) - yi * m;
+    cc = d * d + v;
+    th = T(1) / sqrt(cc);
+    g1 = yi * (th + T(1));
+  } else {  // LIK_NEGBIN negativebinomial.jl:69-99 : theta = (r + y) tanh(c/2)/c (no 1/2, as the reference writes it)
+    cc = sqrt(m * m + v);
+    th = (p0 + yi) * T(2) * theta_pg<T>(cc);
+    g1 = (yi - p0) / T(2);
+  }
+}
 
 // One wave per minibatch row i: row statistics of W (s0 = sum_j W_ij^2, s1 = sum_j W_ij v_j), the K~ slice sum, then
 // lane 0 finishes K~ / mean_f / var_f and runs the likelihood update -- rowstats and local update in ONE launch.
@@ -178,7 +222,8 @@ __global__ void k_rowstats_local(int64_t B, int nslices, const T* __restrict__ p
                                  T kdiag, T jitter, T rho, LikParams<T> lp, const T* __restrict__ y,
                                  const int64_t* __restrict__ idx, T* __restrict__ Kt, T* __restrict__ muf,
                                  T* __restrict__ varf, T* __restrict__ c, T* __restrict__ theta, T* __restrict__ r,
-                                 T* __restrict__ w, int* __restrict__ flags, int use_kt) {
+                                 T* __restrict__ w, int* __restrict__ flags, int use_kt, const T* __restrict__ lam,
+                                 T* __restrict__ gamma) {
   const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= B) return;
@@ -207,26 +252,116 @@ __global__ void k_rowstats_local(int64_t B, int nslices, const T* __restrict__ p
     c[i] = sqrt(mu * mu + var);  // logisticsoftmax.jl:62-64
     return;
   }
-  if (lp.kind == LIK_MO) return;  // multi-output: mixing + likelihoods follow in k_mo_local
+  if (lp.kind == LIK_MO || lp.kind == LIK_HETERO) return;  // mixing / two-latent coupling follow in k_mo_local, k_hetero_*
   T yi = y[idx ? idx[i] : i];
-  T th, cc = T(0), g1;
-  if (lp.kind == LIK_GAUSSIAN) {  // gaussian.jl:70-80
-    th = T(1) / lp.p0;
-    g1 = yi / lp.p0;
-  } else if (lp.kind == LIK_LOGISTIC) {  // logistic.jl:39-51,64-69
+  T th, cc, g1;
+  if (lp.kind == LIK_POISSON) {  // poisson.jl:64-80,94-103 (lambda itself is re-estimated afterwards by k_poisson_*)
     cc = sqrt(mu * mu + var);
-    th = theta_pg<T>(cc);
-    g1 = yi / T(2);
-  } else {  // studentt.jl:68-82,96-99
-    T alpha = (lp.p0 + T(1)) / T(2);
-    cc = ((mu - yi) * (mu - yi) + var + lp.p1 * lp.p1 * lp.p0) / T(2);
-    th = alpha / cc;
-    g1 = th * yi;
+    T gam = (T)((double)lam[0] * safe_expcosh_d(-0.5 * (double)mu, 0.5 * (double)cc) / 2.0);
+    th = (yi + gam) * T(2) * theta_pg<T>(cc);
+    g1 = (yi - gam) / T(2);
+    gamma[i] = gam;
+  } else {
+    lik_point<T>(lp.kind, lp.p0, lp.p1, mu, var, yi, th, cc, g1);
   }
   c[i] = cc;
   theta[i] = th;
   r[i] = rho * g1;
   w[i] = rho * th / T(2);
+}
+
+// Poisson: lambda <- sum(y) / sum_i E_{N(mu_i, var_i)}[logistic]  (poisson.jl:78 ; expectation = Gauss-Hermite, utils.jl:16-19)
+// stage 1: per-block partial sums part[2*b] = sum y, part[2*b+1] = sum E[sigma(f)]
+template <typename T>
+__global__ void k_poisson_partial(int64_t B, const T* __restrict__ y, const int64_t* __restrict__ idx,
+                                  const T* __restrict__ muf, const T* __restrict__ varf, int nn,
+                                  const double* __restrict__ nodes, const double* __restrict__ weights,
+                                  double* __restrict__ part) {
+  __shared__ double red[16];
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  double sy = 0.0, se = 0.0;
+  if (i < B) {
+    sy = (double)y[idx ? idx[i] : i];
+    double m = (double)muf[i], sd = sqrt(fmax((double)varf[i], 0.0));
+    for (int q = 0; q < nn; ++q) {
+      double x = nodes[q] * sd + m;
+      se += weights[q] * (x >= 0.0 ? 1.0 / (1.0 + exp(-x)) : exp(x) / (1.0 + exp(x)));
+    }
+  }
+  sy = block_sum<double>(sy, red);
+  se = block_sum<double>(se, red);
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = sy;
+    part[2 * blockIdx.x + 1] = se;
+  }
+}
+
+// stage 2 (one workgroup): mode 0 Poisson  lam = S0/S1 ; mode 1 heteroscedastic lam = max(B / (2 S0), lam)
+template <typename T>
+__global__ void k_lambda_finish(int nparts, int stride, const double* __restrict__ part, int mode, double Bn,
+                                T* __restrict__ lam) {
+  __shared__ double red[16];
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = threadIdx.x; b < nparts; b += blockDim.x) {
+    s0 += part[stride * b];
+    if (stride > 1) s1 += part[stride * b + 1];
+  }
+  s0 = block_sum<double>(s0, red);
+  s1 = block_sum<double>(s1, red);
+  if (threadIdx.x == 0) {
+    if (mode == 0) {
+      lam[0] = (T)(s0 / s1);
+    } else {
+      double cand = Bn / (2.0 * s0), cur = (double)lam[0];
+      lam[0] = (T)(cand > cur ? cand : cur);
+    }
+  }
+}
+
+// Heteroscedastic Gaussian (heteroscedastic.jl:71-97): latent 0 = f, latent 1 = g ; arrays are [2][ldb]:
+//   c[0] = phi = E[(f-y)^2]/2 ; c[1] = c = sqrt(E[g^2]) ; gamma[1] = sigg ~ E[sigma(-g)] ; gamma[0] = gamma = lam phi sigg ;
+//   theta[1] = (1/2 + gamma) tanh(c/2)/(2c) ; part[b] = sum_block phi (1 - sigg)
+template <typename T>
+__global__ void k_hetero_local(int64_t B, int64_t ldb, const T* __restrict__ y, const int64_t* __restrict__ idx,
+                               const T* __restrict__ muf, const T* __restrict__ varf, const T* __restrict__ lam,
+                               T* __restrict__ c, T* __restrict__ gamma, T* __restrict__ theta,
+                               double* __restrict__ part) {
+  __shared__ double red[16];
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  double contrib = 0.0;
+  if (i < B) {
+    T yi = y[idx ? idx[i] : i];
+    T m0 = muf[i], v0 = varf[i], m1 = muf[ldb + i], v1 = varf[ldb + i];
+    T phi = ((m0 - yi) * (m0 - yi) + v0) / T(2);
+    T cc = sqrt(m1 * m1 + v1);
+    T sg = (T)(safe_expcosh_d(-0.5 * (double)m1, 0.5 * (double)cc) / 2.0);
+    T gam = lam[0] * phi * sg;
+    c[i] = phi;
+    c[ldb + i] = cc;
+    gamma[ldb + i] = sg;
+    gamma[i] = gam;
+    theta[ldb + i] = (T(0.5) + gam) * theta_pg<T>(cc);
+    contrib = (double)phi * (1.0 - (double)sg);
+  }
+  contrib = block_sum<double>(contrib, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = contrib;
+}
+
+// grad_E_mu / grad_E_Sigma with the UPDATED lambda (heteroscedastic.jl:113-129): theta[0] keeps lam*sigg so that
+// grad_E_Sigma = theta/2 holds for both latents
+template <typename T>
+__global__ void k_hetero_grads(int64_t B, int64_t ldb, T rho, const T* __restrict__ y, const int64_t* __restrict__ idx,
+                               const T* __restrict__ lam, const T* __restrict__ gamma, T* __restrict__ theta,
+                               T* __restrict__ r, T* __restrict__ w) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  T yi = y[idx ? idx[i] : i];
+  T ls = lam[0] * gamma[ldb + i];
+  theta[i] = ls;
+  r[i] = rho * yi * ls / T(2);
+  w[i] = rho * ls / T(2);
+  r[ldb + i] = rho * (T(0.5) - gamma[i]) / T(2);
+  w[ldb + i] = rho * theta[ldb + i] / T(2);
 }
 
 // extension block of the augmented Cholesky: row 0 = eta1', rows 1..63 = 0
@@ -295,22 +430,14 @@ struct MoCfg {
   T p1[MO_MAXT];
 };
 
+// grad_E_mu from the stored theta (the local variables of a previous step)
 template <typename T>
-__device__ __forceinline__ void lik_point(int kind, T p0, T p1, T m, T v, T yi, T& th, T& cc, T& g1) {
-  cc = T(0);
-  if (kind == LIK_GAUSSIAN) {
-    th = T(1) / p0;
-    g1 = yi / p0;
-  } else if (kind == LIK_LOGISTIC) {
-    cc = sqrt(m * m + v);
-    th = theta_pg<T>(cc);
-    g1 = yi / T(2);
-  } else {
-    T alpha = (p0 + T(1)) / T(2);
-    cc = ((m - yi) * (m - yi) + v + p1 * p1 * p0) / T(2);
-    th = alpha / cc;
-    g1 = th * yi;
-  }
+__device__ __forceinline__ T lik_g1(int kind, T p0, T yi, T thv) {
+  if (kind == LIK_GAUSSIAN) return yi / p0;
+  if (kind == LIK_LOGISTIC) return yi / T(2);
+  if (kind == LIK_BSVM) return yi * (thv + T(1));
+  if (kind == LIK_NEGBIN) return (yi - p0) / T(2);
+  return thv * yi;  // StudentT, Laplace
 }
 
 // mixed mean_f / var_f (lines 24-45), per-task local updates, mixed gradients (lines 48-84):
@@ -377,7 +504,7 @@ __global__ void k_mo_gradA(int64_t B, int Q, int64_t ldb, MoCfg<T> cfg, const T*
   for (int64_t i = threadIdx.x; i < B; i += blockDim.x) {
     T thv = th[t * ldb + i];
     T yi = y[(idx ? idx[i] : i) * ystride + t];
-    T g1 = cfg.kind[t] == LIK_GAUSSIAN ? yi / cfg.p0[t] : (cfg.kind[t] == LIK_LOGISTIC ? yi / T(2) : thv * yi);
+    T g1 = lik_g1<T>(cfg.kind[t], cfg.p0[t], yi, thv);
     T g2 = thv / T(2);
     T m = T(0);
     for (int qq = 0; qq < Q; ++qq) m += A[t * Q + qq] * muf[qq * ldb + i];
@@ -553,10 +680,11 @@ __global__ void k_elbo_terms(int64_t B, int nl, int64_t ldb, LikParams<T> lp, in
                              const int64_t* __restrict__ idx, const T* __restrict__ muf, const T* __restrict__ varf,
                              const T* __restrict__ c, const T* __restrict__ theta, const T* __restrict__ gamma,
                              const T* __restrict__ alpha, const T* __restrict__ beta, double* __restrict__ out,
-                             int64_t ystr) {
+                             int64_t ystr, const T* __restrict__ lam) {
   __shared__ double red[16];
   double e = 0.0, kl = 0.0;
-  const double LOG2 = 0.69314718055994530942, LOG2PI = 1.83787706640934548356;
+  const double LOG2 = 0.69314718055994530942, LOG2PI = 1.83787706640934548356, LOGPI = 1.14472988584940017414;
+  const double lamv = (lp.kind == LIK_POISSON || lp.kind == LIK_HETERO) ? (double)lam[0] : 1.0;
   for (int64_t i = threadIdx.x; i < B; i += blockDim.x) {
     if (lp.kind == LIK_LSM) {
       int cls = ycls[idx ? idx[i] : i];
@@ -572,6 +700,15 @@ __global__ void k_elbo_terms(int64_t B, int nl, int64_t ldb, LikParams<T> lp, in
         kl += lam0 - g + (g > 0.0 ? g * log(g) : 0.0) - g * psil;           // PoissonKL
       }
       if (add_global) kl += -a - lgamma(a) - (1.0 - a) * psi;               // GammaEntropy (sum parts)
+    } else if (lp.kind == LIK_HETERO) {  // heteroscedastic.jl:142-179 ; layout as in k_hetero_local
+      double yi = (double)y[(idx ? idx[i] : i) * ystr];
+      double m0 = (double)muf[i], s0 = (double)varf[i], m1 = (double)muf[ldb + i], s1 = (double)varf[ldb + i];
+      double g = (double)gamma[i], th = (double)theta[ldb + i], cc = (double)c[ldb + i];
+      double lam0 = lamv * ((yi - m0) * (yi - m0) + s0) / 2.0;
+      e += 0.5 * log(lamv) - log(2.0 * sqrt(2.0 * 3.14159265358979323846));
+      e += 0.5 * (m1 * (0.5 - g) - m1 * m1 * th - s1 * th);
+      e -= lam0 - g + (g > 0.0 ? g * log(g) : 0.0) - g * log(lam0);  // PoissonKL(gamma, lam0, log lam0)
+      kl += (0.5 + g) * logcosh_d(0.5 * cc) - 0.5 * cc * cc * th;
     } else {
       double yi = (double)y[(idx ? idx[i] : i) * ystr];
       double mu = (double)muf[i], s = (double)varf[i];
@@ -583,6 +720,33 @@ __global__ void k_elbo_terms(int64_t B, int nl, int64_t ldb, LikParams<T> lp, in
         double quad = elbo_ref ? th * mu : th * mu * mu;
         e += -0.5 * LOG2 + 0.5 * (mu * yi - th * s - quad);
         kl += logcosh_d(0.5 * cc) - 0.5 * cc * cc * th;
+      } else if (lp.kind == LIK_LAPLACE) {
+        // laplace.jl:93-123 ; GIGEntropy (KLdivergences.jl:105-113) at p = 1/2 in closed form:
+        //   log(2 K_1/2(s)) = log2 + (log(pi/2) - log s)/2 - s ;  s (K_3/2 + K_-1/2) / (2 K_1/2) = s + 1/2
+        // elbo_ref keeps the reference's scalar-iteration quirks: log(a) counted once, log(2 K_p) of the first point only
+        double be = (double)lp.p0, a = 1.0 / (be * be);
+        double th = (double)theta[i], b = (double)c[i], sab = sqrt(a) * b;
+        e += -0.5 * LOG2PI + 0.5 * log(th) - 0.5 * th * (s + mu * mu - 2.0 * mu * yi + yi * yi);
+        double l2k = LOG2 + 0.5 * (LOGPI - LOG2 - log(sab)) - sab;
+        double ent = -0.5 * log(b * b) + sab + 0.5;
+        if (elbo_ref) ent += (i == 0) ? 0.5 * log(a) + l2k : 0.0;
+        else ent += 0.5 * log(a) + l2k;
+        double expo = -log(2.0 * be * be) - 0.5 * (a * b + b * b * sqrt(a)) / (a * b * b * be * be);
+        kl += ent - expo;
+      } else if (lp.kind == LIK_BSVM) {  // bayesiansvm.jl:71-92 ; elbo_ref: + theta (1 - y mu)^2 as written in line 81
+        double th = (double)theta[i], cc = (double)c[i], d = 1.0 - yi * mu, sc = sqrt(cc);
+        e += -0.5 * LOG2 + mu * yi - 0.5 * th * s + (elbo_ref ? th * d * d : -0.5 * th * d * d);
+        kl += 0.5 * log(cc) + (LOG2 + 0.5 * (LOGPI - LOG2 - log(sc)) - sc) - 0.5 * sc;
+      } else if (lp.kind == LIK_POISSON) {  // poisson.jl:106-132
+        double th = (double)theta[i], cc = (double)c[i], g = (double)gamma[i];
+        e += 0.5 * (mu * (yi - g) - th * mu * mu - th * s) + yi * log(lamv) - lgamma(yi + 1.0) - LOG2 * (yi + g);
+        kl += lamv - (1.0 + log(lamv)) * g + (g > 0.0 ? g * log(g) : 0.0);      // PoissonKL(gamma, lambda)
+        kl += (yi + g) * logcosh_d(0.5 * cc) - 0.5 * cc * cc * th;              // PolyaGammaKL(y + gamma, c, theta)
+      } else if (lp.kind == LIK_NEGBIN) {  // negativebinomial.jl:103-131 ; elbo_ref: dot(theta, mu) as written in line 125
+        double th = (double)theta[i], cc = (double)c[i], rr = (double)lp.p0;
+        e += lgamma(yi + rr) - lgamma(yi + 1.0) - lgamma(rr) - LOG2 * (yi + rr);
+        e += 0.5 * mu * (yi - rr) - 0.5 * (elbo_ref ? th * mu : th * mu * mu) - 0.5 * th * s;
+        kl += (yi + rr) * logcosh_d(0.5 * cc) - 0.5 * cc * cc * th;
       } else {
         double nu = (double)lp.p0, sig = (double)lp.p1;
         double al = 0.5 * (nu + 1.0), alp = 0.5 * nu, bp = alp * sig * sig;
@@ -698,6 +862,62 @@ __global__ void k_proba_logistic(int64_t n, const T* __restrict__ mu, const T* _
   }
   p[i] = (T)s1;
   pv[i] = (T)fmax(s2 - s1 * s1, 0.0);
+}
+
+// compute_proba by Gauss-Hermite for the other links: link 1 = SVMLink (bayesiansvm.jl:27-40, variance clamped at 0 as in
+// classification.jl:23), 2 = lambda*logistic (poisson.jl:46-57), 3 = NegBinomial mean p r/(1-p) (negativebinomial.jl:46-62)
+template <typename T>
+__global__ void k_proba_gh(int64_t n, const T* __restrict__ mu, const T* __restrict__ var, int nn,
+                           const double* __restrict__ nodes, const double* __restrict__ weights, int link, double par,
+                           const T* __restrict__ lam, T* __restrict__ p, T* __restrict__ pv) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (link == 2 && lam) par = (double)lam[0];
+  double m = (double)mu[i], sd = sqrt(fmax((double)var[i], 0.0));
+  double s1 = 0.0, s2 = 0.0;
+  for (int q = 0; q < nn; ++q) {
+    double x = nodes[q] * sd + m, v;
+    if (link == 1) {
+      double pos = exp(-2.0 * fmax(1.0 - x, 0.0)), neg = exp(-2.0 * fmax(1.0 + x, 0.0));
+      v = pos / (pos + neg);
+    } else {
+      double sg = x >= 0.0 ? 1.0 / (1.0 + exp(-x)) : exp(x) / (1.0 + exp(x));
+      v = link == 2 ? par * sg : sg * par / (1.0 - sg);
+    }
+    s1 += weights[q] * v;
+    s2 += weights[q] * v * v;
+  }
+  p[i] = (T)s1;
+  double vv = s2 - s1 * s1;
+  pv[i] = (T)(link == 1 ? fmax(vv, 0.0) : vv);
+}
+
+// predict_y of the event likelihoods (predictions.jl:211): Poisson lambda*logistic(mu) ; NegBinomial r (1-p)/p, p = logistic(-mu)
+template <typename T>
+__global__ void k_predict_event(int64_t n, const T* __restrict__ mu, int negbin, double par, const T* __restrict__ lam,
+                                T* __restrict__ out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double x = (double)mu[i];
+  if (!negbin) {
+    if (lam) par = (double)lam[0];
+    out[i] = (T)(par * (x >= 0.0 ? 1.0 / (1.0 + exp(-x)) : exp(x) / (1.0 + exp(x))));
+  } else {
+    double pn = -x >= 0.0 ? 1.0 / (1.0 + exp(x)) : exp(-x) / (1.0 + exp(-x));
+    out[i] = (T)(par * (1.0 - pn) / pn);
+  }
+}
+
+// heteroscedastic compute_proba (heteroscedastic.jl:63-69): (mu_f, var_f + 1/(lambda logistic(mu_g))) ; mu/var are [2][ld]
+template <typename T>
+__global__ void k_proba_hetero(int64_t n, int64_t ld, const T* __restrict__ mu, const T* __restrict__ var,
+                               const T* __restrict__ lam, T* __restrict__ o0, T* __restrict__ o1) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double x = (double)mu[ld + i];
+  double sg = x >= 0.0 ? 1.0 / (1.0 + exp(-x)) : exp(x) / (1.0 + exp(x));
+  o0[i] = mu[i];
+  o1[i] = (T)((double)var[i] + 1.0 / ((double)lam[0] * sg));
 }
 
 // (mu, var + add) for Gaussian (gaussian.jl:41-45) ; (mu, max(var,0) + add) for StudentT (studentt.jl:57-61)

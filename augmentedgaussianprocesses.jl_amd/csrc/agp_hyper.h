@@ -13,15 +13,47 @@
 
 namespace agp {
 
-// g_mu = r/rho - theta mu_f (reference-bug logistic mode: r/rho - theta/2) ; g_s = -theta/2
+// g_mu = r/rho - theta mu_f , g_s = -theta/2   (every augmented likelihood's expec_loglikelihood is quadratic in f)
+// mode 1: the reference's dot(theta, mu) variant (logistic.jl:82, negativebinomial.jl:125): g_mu = r/rho - theta/2
+// mode 2: the reference's BayesianSVM expression (bayesiansvm.jl:81): g_mu = y - 2 theta (1 - y mu) y
+// mode 3: heteroscedastic latent f: the data term is -PoissonKL(gamma, lam0, log lam0), lam0 = lam ((y-mu)^2 + var)/2 at
+//         the CURRENT (mu, var) => t = lam - 2 gamma / ((y-mu)^2 + var), g_mu = -t (mu - y), g_s = -t/2
 template <typename T>
-__global__ void k_hyper_gvec(int64_t B, T rho, int ref_logistic, const T* __restrict__ r, const T* __restrict__ theta,
-                             const T* __restrict__ muf, T* __restrict__ gmu, T* __restrict__ gs) {
+__global__ void k_hyper_gvec(int64_t B, T rho, int mode, const T* __restrict__ r, const T* __restrict__ theta,
+                             const T* __restrict__ muf, const T* __restrict__ y, const int64_t* __restrict__ idx,
+                             const T* __restrict__ varf, const T* __restrict__ gam, const T* __restrict__ lam,
+                             T* __restrict__ gmu, T* __restrict__ gs) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= B) return;
   T th = theta[i];
-  gmu[i] = r[i] / rho - (ref_logistic ? th / T(2) : th * muf[i]);
+  if (mode == 3) {
+    T yi = y[idx ? idx[i] : i];
+    T dm = muf[i] - yi;
+    T t = lam[0] - T(2) * gam[i] / (dm * dm + varf[i]);
+    gmu[i] = -t * (muf[i] - yi);
+    gs[i] = -t / T(2);
+    return;
+  }
+  if (mode == 2) {
+    T yi = y[idx ? idx[i] : i];
+    gmu[i] = yi - T(2) * th * (T(1) - yi * muf[i]) * yi;
+  } else {
+    gmu[i] = r[i] / rho - (mode == 1 ? th / T(2) : th * muf[i]);
+  }
   gs[i] = -th / T(2);
+}
+
+// var_f = rowdot(T1, kappa) + K~ with T1 = kappa*Sigma (latentgp.jl:189) ; one wave per row
+template <typename T>
+__global__ void k_hyper_varf(int64_t B, int64_t cols, int64_t ld, const T* __restrict__ T1, const T* __restrict__ kappa,
+                             const T* __restrict__ Kt, T* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= B) return;
+  T s = T(0);
+  for (int64_t j = lane; j < cols; j += 64) s += T1[i * ld + j] * kappa[i * ld + j];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if (lane == 0) out[i] = s + Kt[i];
 }
 
 // in place on T1 = kappa*Sigma :  Gk = rho ( g_mu mu' + 2 g_s T1 - g_s Knm ) ; rows >= B are zero

@@ -1,6 +1,7 @@
 """Likelihood descriptors + label handling (host logic, no numerics).
 
-Mirrors src/likelihood/{gaussian,logistic,classification,studentt,regression,logisticsoftmax,multiclass}.jl:
+Mirrors src/likelihood/{gaussian,logistic,classification,studentt,regression,logisticsoftmax,multiclass,laplace,
+bayesiansvm,poisson,negativebinomial,event,heteroscedastic}.jl:
 constructors, `implemented`, `n_latent`, `treat_labels!`, class mapping / one-hot.  The local updates, gradients,
 ELBO terms and compute_proba run on the GPU (csrc/agp_cavi.h).
 """
@@ -98,6 +99,93 @@ class LogisticSoftMaxLikelihood(AbstractLikelihood):
         return f"Multiclass Likelihood ({self.n_class} classes, Logistic-SoftMax Link )"
 
 
+class LaplaceLikelihood(AbstractLikelihood):
+    """LaplaceLikelihood(β=1.0)  src/likelihood/laplace.jl:17-30 (q(ω) = GIG(a = β⁻², b, p = 1/2))."""
+
+    kind = capi.LIK_LAPLACE
+
+    def __init__(self, beta: float = 1.0):
+        if not beta > 0:
+            raise ValueError("β must be positive")
+        self.beta = float(beta)
+        self.a = self.beta ** -2
+        self.p = 0.5
+
+    def lik_desc(self):
+        return capi.LikDesc(self.kind, 1, self.beta, 0.0)
+
+    def __repr__(self):
+        return f"Laplace likelihood (β={self.beta})"
+
+
+class BayesianSVM(AbstractLikelihood):
+    """BayesianSVM() -> BernoulliLikelihood(SVMLink())  src/likelihood/bayesiansvm.jl:19-23."""
+
+    kind = capi.LIK_BAYESIANSVM
+
+    def lik_desc(self):
+        return capi.LikDesc(self.kind, 1, 0.0, 0.0)
+
+    def __repr__(self):
+        return "Bernoulli Likelihood with SVM Link"
+
+
+class PoissonLikelihood(AbstractLikelihood):
+    """PoissonLikelihood(λ) -> PoissonLikelihood(ScaledLogistic([λ]))  src/likelihood/poisson.jl:16-24.
+
+    λ is state: every local update re-estimates it (poisson.jl:78).  `lam` is the constructor value until a model has
+    trained with this likelihood, then the value read back from the device."""
+
+    kind = capi.LIK_POISSON
+
+    def __init__(self, lam: float):
+        if not lam > 0:
+            raise ValueError("λ must be positive")
+        self.lam = float(lam)
+
+    def lik_desc(self):
+        return capi.LikDesc(self.kind, 1, self.lam, 0.0)
+
+    def __repr__(self):
+        return f"Poisson Likelihood (λ = {self.lam})"
+
+
+class NegBinomialLikelihood(AbstractLikelihood):
+    """NegBinomialLikelihood(r)  src/likelihood/negativebinomial.jl:22-27 (LogisticLink)."""
+
+    kind = capi.LIK_NEGBINOMIAL
+
+    def __init__(self, r):
+        if not r > 0:
+            raise ValueError("r must be positive")
+        self.r = float(r)
+
+    def lik_desc(self):
+        return capi.LikDesc(self.kind, 1, self.r, 0.0)
+
+    def __repr__(self):
+        return f"Negative Binomial Likelihood (r = {self.r:g})"
+
+
+class HeteroscedasticLikelihood(AbstractLikelihood):
+    """HeteroscedasticLikelihood(λ) -> HeteroscedasticGaussianLikelihood(InvScaledLogistic([λ]))
+    src/likelihood/heteroscedastic.jl:17-47 ; two latents (f, g) ; λ is state (heteroscedastic.jl:95)."""
+
+    kind = capi.LIK_HETEROSCEDASTIC
+    n_latent = 2
+
+    def __init__(self, lam: float = 1.0):
+        if not lam > 0:
+            raise ValueError("λ must be positive")
+        self.lam = float(lam)
+
+    def lik_desc(self):
+        return capi.LikDesc(self.kind, 1, self.lam, 0.0)
+
+    def __repr__(self):
+        return "Gaussian likelihood with heteroscedastic noise"
+
+
 def _unique_in_order(y):
     seen = []
     for v in y:
@@ -142,16 +230,21 @@ def _as_list(y):
 
 
 def treat_labels(y, l: AbstractLikelihood):
-    """treat_labels!  regression.jl:10-15, classification.jl:29-44, multiclass.jl:40-44.
+    """treat_labels!  regression.jl:10-15, classification.jl:29-44, multiclass.jl:40-44, event.jl:7-13.
 
     Returns what view_y hands to the inference: real vector (regression), ±1 vector (Bernoulli), one-hot bool
     matrix (multiclass)."""
-    if isinstance(l, (GaussianLikelihood, StudentTLikelihood)):
+    if isinstance(l, (GaussianLikelihood, StudentTLikelihood, LaplaceLikelihood, HeteroscedasticLikelihood)):
         arr = np.asarray(y)
         if not (np.issubdtype(arr.dtype, np.floating) or np.issubdtype(arr.dtype, np.integer)):
             raise ValueError("For regression target(s) should be real valued")
         return arr.astype(np.float64)
-    if isinstance(l, LogisticLikelihood):
+    if isinstance(l, (PoissonLikelihood, NegBinomialLikelihood)):  # event.jl:7-13
+        arr = np.asarray(y)
+        if not np.issubdtype(arr.dtype, np.integer):
+            raise TypeError("For event count target(s) should be integers")
+        return arr.astype(np.float64)
+    if isinstance(l, (LogisticLikelihood, BayesianSVM)):
         arr = np.asarray(y)
         if not (np.issubdtype(arr.dtype, np.floating) or np.issubdtype(arr.dtype, np.integer)
                 or arr.dtype == bool):

@@ -163,6 +163,10 @@ def train_parallel(model, X, y, iterations: int, idx_stream: Sequence, *, mode: 
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world > 1 and type(model.likelihood).__name__ in ("PoissonLikelihood", "HeteroscedasticLikelihood"):
+        # their lambda update (poisson.jl:78, heteroscedastic.jl:95) is a reduction over the whole minibatch that the sharded
+        # drivers do not exchange; the two heteroscedastic latents are coupled point-wise and stay on one handle
+        raise NotImplementedError(f"{model.likelihood} is not wired for multi-GPU sharding")
     N = np.asarray(X).shape[0] if obsdim == 1 else np.asarray(X).shape[1]
     B_total = len(idx_stream[0])
     B_local = B_total if mode == "latent" else B_total // world

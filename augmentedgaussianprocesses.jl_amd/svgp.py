@@ -21,6 +21,11 @@ import numpy as np
 from . import capi
 from .kernels import Kernel
 from .likelihoods import (
+    BayesianSVM,
+    HeteroscedasticLikelihood,
+    LaplaceLikelihood,
+    NegBinomialLikelihood,
+    PoissonLikelihood,
     AbstractLikelihood,
     GaussianLikelihood,
     LogisticLikelihood,
@@ -63,7 +68,8 @@ class _MultiOutputLikelihood(AbstractLikelihood):
 
     def __init__(self, likelihoods, n_latent):
         for l in likelihoods:
-            if not isinstance(l, (GaussianLikelihood, LogisticLikelihood, StudentTLikelihood)):
+            if not isinstance(l, (GaussianLikelihood, LogisticLikelihood, StudentTLikelihood, LaplaceLikelihood,
+                                  BayesianSVM, NegBinomialLikelihood)):
                 raise RuntimeError(f"One (or more) of the likelihoods {likelihoods} are not compatible or implemented "
                                    "with the multi-output analytic path")  # MOSVGP.jl:56-58
         self.likelihoods = list(likelihoods)
@@ -122,7 +128,9 @@ class SVGP:
             raise TypeError("The inference object should be of type `VariationalInference` : either `AnalyticVI` or "
                             "`NumericalVI`")  # SVGP.jl:45-47 (only AnalyticVI exists on this path)
         if not isinstance(likelihood, (GaussianLikelihood, LogisticLikelihood, StudentTLikelihood,
-                                       LogisticSoftMaxLikelihood, _MultiOutputLikelihood)):
+                                       LogisticSoftMaxLikelihood, _MultiOutputLikelihood, LaplaceLikelihood,
+                                       BayesianSVM, PoissonLikelihood, NegBinomialLikelihood,
+                                       HeteroscedasticLikelihood)):
             raise RuntimeError(f"The {likelihood} is not compatible or implemented with the {inference}")  # :48-49
         if optimiser is None:
             optimiser = ADAM(0.01)                       # SVGP.jl:39
@@ -258,6 +266,10 @@ class SVGP:
         return h
 
     def _post_create(self, h):
+        if isinstance(self.likelihood, PoissonLikelihood):  # the lambda update integrates logistic by Gauss-Hermite
+            nodes, weights = _gauss_hermite()
+            self._chk(capi.lib().agp_svgp_set_quadrature(h, nodes.ctypes.data_as(C.POINTER(C.c_double)),
+                                                         weights.ctypes.data_as(C.POINTER(C.c_double)), len(nodes)))
         o = self.k_opt or self.z_opt
         if o is not None:
             self._chk(capi.lib().agp_svgp_hyper_configure(
@@ -266,6 +278,14 @@ class SVGP:
 
     def _pre_destroy(self):
         self._pull_hypers()
+        self._pull_lik_state()
+
+    def _pull_lik_state(self):
+        """λ of PoissonLikelihood / HeteroscedasticLikelihood lives on the device while training; mirror it back"""
+        if self._h is not None and isinstance(self.likelihood, (PoissonLikelihood, HeteroscedasticLikelihood)):
+            v = C.c_double()
+            self._chk(capi.lib().agp_svgp_get_lik_param(self._h, C.byref(v)))
+            self.likelihood.lam = v.value
 
     def _pull_hypers(self):
         """copy the (possibly optimised) kernel parameters and inducing points back into the Python objects"""
@@ -529,6 +549,7 @@ def train_(model: SVGP, X, y, iterations: int = 100, *, callback: Optional[Calla
             break
     model._chk(L.agp_svgp_check_status(h))
     model._pull_hypers()
+    model._pull_lik_state()
     return model, State(model)
 
 
@@ -606,7 +627,8 @@ def predict_y(model: SVGP, X_test, state: Optional[State] = None, *, obsdim: int
     lik = model.likelihood
     if isinstance(model, MOSVGP):
         out = torch.empty(model.n_task, nt, dtype=model.tdtype, device=dev)
-    elif isinstance(lik, (GaussianLikelihood, StudentTLikelihood)):
+    elif isinstance(lik, (GaussianLikelihood, StudentTLikelihood, LaplaceLikelihood, HeteroscedasticLikelihood,
+                          PoissonLikelihood, NegBinomialLikelihood)):
         out = torch.empty(nt, dtype=model.tdtype, device=dev)
     else:
         out = torch.empty(nt, dtype=torch.int32, device=dev)
@@ -614,8 +636,9 @@ def predict_y(model: SVGP, X_test, state: Optional[State] = None, *, obsdim: int
     model._chk(L.agp_ctx_sync(model._ctx))
     o = out.cpu().numpy()
     if isinstance(model, MOSVGP):
-        return [o[t] > 0.5 if isinstance(l, LogisticLikelihood) else o[t] for t, l in enumerate(lik.likelihoods)]
-    if isinstance(lik, LogisticLikelihood):
+        return [o[t] > 0.5 if isinstance(l, (LogisticLikelihood, BayesianSVM)) else o[t]
+                for t, l in enumerate(lik.likelihoods)]
+    if isinstance(lik, (LogisticLikelihood, BayesianSVM)):
         return o.astype(bool)
     if isinstance(lik, LogisticSoftMaxLikelihood):
         cm = lik.class_mapping or list(range(1, lik.n_class + 1))

@@ -44,13 +44,20 @@ enum { AGP_F64 = 0, AGP_F32 = 1 };
 /* KernelFunctions.jl kernels (call sites src/gpblocks/latentgp.jl:202-212): sigma2 * base(||s .* (x-y)||) */
 enum { AGP_K_SQEXP = 0, AGP_K_MATERN52 = 1, AGP_K_MATERN32 = 2, AGP_K_EXPONENTIAL = 3 };
 
-/* likelihoods with closed-form augmented updates on this path (src/likelihood/{gaussian,logistic,studentt,logisticsoftmax}.jl) */
+/* likelihoods with closed-form augmented updates (implemented(l, ::AnalyticVI) == true):
+ * src/likelihood/{gaussian,logistic,studentt,logisticsoftmax,laplace,bayesiansvm,poisson,negativebinomial,heteroscedastic}.jl */
 enum {
   AGP_LIK_GAUSSIAN = 0,
   AGP_LIK_LOGISTIC = 1,
   AGP_LIK_STUDENTT = 2,
   AGP_LIK_LOGISTICSOFTMAX = 3,
-  AGP_LIK_MULTIOUTPUT = 4 /* MOSVGP handle: task likelihoods are installed by agp_svgp_set_multioutput */
+  AGP_LIK_MULTIOUTPUT = 4, /* MOSVGP handle: task likelihoods are installed by agp_svgp_set_multioutput */
+  AGP_LIK_LAPLACE = 5,         /* LaplaceLikelihood(beta)            laplace.jl:17-25          p0 = beta */
+  AGP_LIK_BAYESIANSVM = 6,     /* BayesianSVM()                      bayesiansvm.jl:19-23 */
+  AGP_LIK_POISSON = 7,         /* PoissonLikelihood(lambda)          poisson.jl:16-24          p0 = initial lambda (state) */
+  AGP_LIK_NEGBINOMIAL = 8,     /* NegBinomialLikelihood(r)           negativebinomial.jl:22-27 p0 = r */
+  AGP_LIK_HETEROSCEDASTIC = 9  /* HeteroscedasticLikelihood(lambda)  heteroscedastic.jl:17-47  p0 = initial lambda (state);
+                                  n_latent must be 2 (latent 0 = f, latent 1 = g) */
 };
 
 /* ELBO variants: Appendix-A Q2 of SURVEY.md (src/likelihood/logistic.jl:82 uses dot(theta, mu)) */
@@ -66,8 +73,8 @@ enum {
   AGP_VEC_MEAN_F = 5, /* B   kappa*mu   (value used by the last local update)     (latentgp.jl:179) */
   AGP_VEC_VAR_F = 6,  /* B                                                        (latentgp.jl:189) */
   AGP_VEC_THETA = 7,  /* B   local variable theta                                 (likelihood local_updates!) */
-  AGP_VEC_C = 8,      /* B   local variable c */
-  AGP_VEC_GAMMA = 9,  /* B   LogisticSoftMax gamma_k */
+  AGP_VEC_C = 8,      /* B   local variable c (Laplace: b).  Heteroscedastic: latent 0 -> phi, latent 1 -> c */
+  AGP_VEC_GAMMA = 9,  /* B   LogisticSoftMax gamma_k ; Poisson gamma ; Heteroscedastic: latent 0 -> gamma, latent 1 -> sigg */
   AGP_VEC_ALPHA = 10  /* B   LogisticSoftMax alpha (shared by all latents) */
 };
 
@@ -85,7 +92,7 @@ typedef struct {
 typedef struct {
   int32_t kind;    /* AGP_LIK_* */
   int32_t n_class; /* LogisticSoftMax: K (= number of latent GPs); else 1 */
-  double p0;       /* Gaussian: sigma2 ; StudentT: nu */
+  double p0;       /* Gaussian: sigma2 ; StudentT: nu ; Laplace: beta ; NegBinomial: r ; Poisson / Heteroscedastic: lambda_0 */
   double p1;       /* StudentT: sigma */
 } agp_lik_desc;
 
@@ -234,10 +241,21 @@ agp_status agp_svgp_get_matrix(agp_svgp* h, int32_t latent, int32_t which, void*
 /* _predict_f (sparse)  src/training/predictions.jl:25-50 : streams over n_t test points without materialising
  * K_*m.  mu_out / var_out : T[n_latent][n_t] (var_out NULL -> cov=false). */
 agp_status agp_svgp_predict_f(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* mu_out, void* var_out);
-/* predict_y  predictions.jl:178-198 : regression -> T[n_t] mean ; logistic -> int32[n_t] (mu_f > 0) ;
+/* predict_y  predictions.jl:178-198 : regression (Gaussian, StudentT, Laplace, Heteroscedastic) -> T[n_t] mean ;
+ * logistic / BayesianSVM -> int32[n_t] (mu_f > 0) ; Poisson / NegBinomial -> T[n_t] expected count (predictions.jl:211) ;
  * LogisticSoftMax -> int32[n_t] argmax_k mu_f,k (0-based LOCAL latent index + latent_offset) */
 agp_status agp_svgp_predict_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* y_out);
-/* proba_y  predictions.jl:225-247 + compute_proba : Gaussian / StudentT -> (mean, var) ; logistic -> (p, var) by
+/* Gauss-Hermite rule used INSIDE training by PoissonLikelihood's lambda update (expectation(logistic, mu, sigma2),
+ * src/functions/utils.jl:16-19 ; same nodes as predictions.jl:4: x*sqrt2, w/sqrt(pi)).  Must be called before the first
+ * step of a Poisson handle; other likelihoods ignore it. */
+agp_status agp_svgp_set_quadrature(agp_svgp* h, const double* gh_nodes_host, const double* gh_weights_host,
+                                   int32_t n_nodes);
+/* likelihood state: the lambda of Poisson (poisson.jl:78) / Heteroscedastic (heteroscedastic.jl:95), which every local
+ * update re-estimates; other likelihoods: get returns p0, set is AGP_ERR_INVALID.  get synchronises. */
+agp_status agp_svgp_get_lik_param(agp_svgp* h, double* value_host);
+agp_status agp_svgp_set_lik_param(agp_svgp* h, double value);
+/* proba_y  predictions.jl:225-247 + compute_proba : Gaussian / StudentT / Laplace / Heteroscedastic -> (mean, var) ;
+ * BayesianSVM / Poisson / NegBinomial -> (E[link(f)], Var) by Gauss-Hermite like logistic ; logistic -> (p, var) by
  * Gauss-Hermite with the caller's nodes/weights (predictions.jl:4 : x*sqrt2, w/sqrt(pi), 100 nodes) ;
  * LogisticSoftMax -> out0 = T[n_t][K] normalised logistic(mu_f) (multiclass.jl:96-117), out1 unused. */
 agp_status agp_svgp_proba_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, const double* gh_nodes_host,

@@ -88,6 +88,21 @@ lik_desc(l::GaussianLikelihood) = LikDesc(0, 1, AGP.noise(l), 0.0)
 lik_desc(::AGP.BernoulliLikelihood{<:AGP.LogisticLink}) = LikDesc(1, 1, 0.0, 0.0)
 lik_desc(l::StudentTLikelihood) = LikDesc(2, 1, l.ν, l.σ)
 lik_desc(l::AGP.MultiClassLikelihood{<:AGP.LogisticSoftMaxLink}) = LikDesc(3, AGP.n_class(l), 0.0, 0.0)
+lik_desc(l::LaplaceLikelihood) = LikDesc(5, 1, l.β, 0.0)
+lik_desc(::AGP.BernoulliLikelihood{<:AGP.SVMLink}) = LikDesc(6, 1, 0.0, 0.0)
+lik_desc(l::AGP.PoissonLikelihood{<:AGP.ScaledLogistic}) = LikDesc(7, 1, only(l.invlink.λ), 0.0)   # λ is state: see pull_lik_state!
+lik_desc(l::NegBinomialLikelihood) = LikDesc(8, 1, Float64(l.r), 0.0)
+lik_desc(l::AGP.HeteroscedasticGaussianLikelihood{<:AGP.InvScaledLogistic}) = LikDesc(9, 1, only(l.invlink.λ), 0.0)
+
+# λ of Poisson / Heteroscedastic is re-estimated on the device by every local update (poisson.jl:78, heteroscedastic.jl:95);
+# copy it back into the reference object after training / before predicting with reference-side code.
+function pull_lik_state!(s, l::Union{AGP.PoissonLikelihood,AGP.HeteroscedasticGaussianLikelihood})
+    v = Ref{Float64}()
+    check(s.ctx, ccall((:agp_svgp_get_lik_param, libagp), Int32, (Ptr{Cvoid}, Ref{Float64}), s.h, v))
+    l.invlink.λ .= v[]
+    return l
+end
+pull_lik_state!(s, l) = l
 
 # ---- device handle living next to the reference model -----------------------------------------------------------------
 mutable struct HipState{T}
@@ -118,6 +133,10 @@ function make_handle(model::SVGP{T}, X::AbstractMatrix, y, maxbatch::Int; obsdim
         GC.@preserve keep check(ctx[], ccall((:agp_svgp_set_kernel, libagp), Int32, (Ptr{Cvoid}, Int32, Ref{KernelDesc}), h[], i - 1, kd))
         Zd = ROCArray{T}(reduce(hcat, AGP.Zview(gp)))       # D x m, point-major
         check(ctx[], ccall((:agp_svgp_set_Z, libagp), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64), h[], i - 1, pointer(Zd), D))
+    end
+    if AGP.likelihood(model) isa AGP.PoissonLikelihood       # the λ update integrates logistic by Gauss-Hermite (utils.jl:16-19)
+        check(ctx[], ccall((:agp_svgp_set_quadrature, libagp), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int32),
+                           h[], AGP.pred_nodes, AGP.pred_weights, length(AGP.pred_nodes)))
     end
     yd = AGP.likelihood(model) isa AGP.MultiClassLikelihood ? ROCArray(Int32.(map(r -> findfirst(r) - 1, eachrow(y)))) : ROCArray{T}(y)
     return HipState{T}(ctx[], h[], Xd, yd, maxbatch)

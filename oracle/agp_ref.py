@@ -257,11 +257,66 @@ class LogisticSoftMaxLikelihood:
         return self.n_class
 
 
+@dataclass
+class LaplaceLikelihood:
+    """src/likelihood/laplace.jl:17-25 ; a = beta^-2, p = 1/2 (GIG parameters of q(omega))."""
+
+    beta: float = 1.0
+    n_latent: int = 1
+    name: str = "laplace"
+
+    @property
+    def a(self):
+        return self.beta ** -2
+
+
+@dataclass
+class BayesianSVM:
+    """src/likelihood/bayesiansvm.jl:19-23 : BernoulliLikelihood(SVMLink())."""
+
+    n_latent: int = 1
+    name: str = "bayesiansvm"
+
+
+@dataclass
+class PoissonLikelihood:
+    """src/likelihood/poisson.jl:16-24 : PoissonLikelihood(ScaledLogistic([lambda])); lambda is STATE: it is re-estimated
+    at the end of every local update (poisson.jl:78)."""
+
+    lam: float = 1.0
+    n_latent: int = 1
+    name: str = "poisson"
+
+
+@dataclass
+class NegBinomialLikelihood:
+    """src/likelihood/negativebinomial.jl:22-27 (LogisticLink, r failures)."""
+
+    r: float = 10.0
+    n_latent: int = 1
+    name: str = "negbinomial"
+
+
+@dataclass
+class HeteroscedasticLikelihood:
+    """src/likelihood/heteroscedastic.jl:17-27 : HeteroscedasticGaussianLikelihood(InvScaledLogistic([lambda])),
+    two latents (f, g) ; lambda is STATE (heteroscedastic.jl:95)."""
+
+    lam: float = 1.0
+    n_latent: int = 2
+    name: str = "heteroscedastic"
+
+
 def treat_labels(y, lik):
-    """treat_labels! : classification.jl:29-44, regression.jl:10-15, multiclass.jl:40-94."""
-    if lik.name in ("gaussian", "studentt"):
+    """treat_labels! : classification.jl:29-44, regression.jl:10-15, multiclass.jl:40-94, event.jl:7-13."""
+    if lik.name in ("gaussian", "studentt", "laplace", "heteroscedastic"):
         return np.asarray(y, dtype=np.float64)
-    if lik.name == "logistic":
+    if lik.name in ("poisson", "negbinomial"):
+        ya = np.asarray(y)
+        if not np.issubdtype(ya.dtype, np.integer):
+            raise ValueError("For event count target(s) should be integers")
+        return ya.astype(np.float64)
+    if lik.name in ("logistic", "bayesiansvm"):
         y = np.asarray(y)
         labels = sorted(int(v) for v in np.unique(y))
         if labels == [0, 1]:
@@ -316,8 +371,14 @@ def init_local_vars(lik, B, rng=None):
     rng = rng or np.random.default_rng(0)
     if lik.name == "gaussian":
         return {"theta": np.full(B, 1.0 / lik.sigma2)}
-    if lik.name in ("logistic", "studentt"):
+    if lik.name in ("logistic", "studentt", "bayesiansvm", "negbinomial"):
         return {"c": rng.random(B), "theta": np.zeros(B)}
+    if lik.name == "laplace":  # laplace.jl:56-58
+        return {"b": rng.random(B), "theta": np.zeros(B)}
+    if lik.name == "poisson":  # poisson.jl:60-62
+        return {"c": rng.random(B), "theta": np.zeros(B), "gamma": rng.random(B)}
+    if lik.name == "heteroscedastic":  # heteroscedastic.jl:49-61
+        return {k: np.ones(B) for k in ("c", "phi", "gamma", "theta", "sigg")}
     if lik.name == "logisticsoftmax":
         K = lik.n_class
         return {
@@ -346,6 +407,38 @@ def local_updates(lv, lik, y, mu_f, var_f):
         lv["c"] = c
         lv["theta"] = lik.alpha / c
         return lv
+    if lik.name == "laplace":  # laplace.jl:60-73
+        b = sqrt_expec_square(mu_f[0], var_f[0], y)
+        lv["b"] = b
+        lv["theta"] = math.sqrt(lik.a) / b
+        return lv
+    if lik.name == "bayesiansvm":  # bayesiansvm.jl:43-55
+        c = np.abs(1.0 - y * mu_f[0]) ** 2 + var_f[0]
+        lv["c"] = c
+        lv["theta"] = 1.0 / np.sqrt(c)
+        return lv
+    if lik.name == "poisson":  # poisson.jl:64-80 (theta has no 1/2: mirrored as written)
+        lam = lik.lam
+        c = sqrt_expec_square(mu_f[0], var_f[0])
+        lv["c"] = c
+        lv["gamma"] = lam * safe_expcosh(-mu_f[0] / 2.0, c / 2.0) / 2.0
+        lv["theta"] = (y + lv["gamma"]) / c * np.tanh(c / 2.0)
+        lik.lam = float(np.sum(y) / np.sum(expectation_logistic(mu_f[0], var_f[0])))
+        return lv
+    if lik.name == "negbinomial":  # negativebinomial.jl:69-81
+        c = sqrt_expec_square(mu_f[0], var_f[0])
+        lv["c"] = c
+        lv["theta"] = (lik.r + y) * np.tanh(c / 2.0) / c
+        return lv
+    if lik.name == "heteroscedastic":  # heteroscedastic.jl:71-97 ; latent 0 is f, latent 1 is g
+        lam = lik.lam
+        lv["phi"] = (np.abs(mu_f[0] - y) ** 2 + var_f[0]) / 2.0
+        lv["c"] = sqrt_expec_square(mu_f[1], var_f[1])
+        lv["sigg"] = safe_expcosh(-mu_f[1] / 2.0, lv["c"] / 2.0) / 2.0
+        lv["gamma"] = lam * lv["phi"] * lv["sigg"]
+        lv["theta"] = (0.5 + lv["gamma"]) * np.tanh(lv["c"] / 2.0) / (2.0 * lv["c"])
+        lik.lam = float(max(len(y) / (2.0 * np.dot(lv["phi"], 1.0 - lv["sigg"])), lam))
+        return lv
     if lik.name == "logisticsoftmax":
         K = lik.n_class
         lv["c"] = [sqrt_expec_square(mu_f[k], var_f[k]) for k in range(K)]
@@ -373,6 +466,16 @@ def grad_E_mu(lik, y, lv):
         return (lv["theta"] * y,)
     if lik.name == "logisticsoftmax":
         return tuple((y[:, k].astype(np.float64) - lv["gamma"][k]) / 2.0 for k in range(lik.n_class))
+    if lik.name == "laplace":  # laplace.jl:85-87
+        return (lv["theta"] * y,)
+    if lik.name == "bayesiansvm":  # bayesiansvm.jl:57-61
+        return (y * (lv["theta"] + 1.0),)
+    if lik.name == "poisson":  # poisson.jl:94-98
+        return ((y - lv["gamma"]) / 2.0,)
+    if lik.name == "negbinomial":  # negativebinomial.jl:94-96
+        return ((y - lik.r) / 2.0,)
+    if lik.name == "heteroscedastic":  # heteroscedastic.jl:113-120 (lambda already updated by local_updates!)
+        return (y * lik.lam * lv["sigg"] / 2.0, (0.5 - lv["gamma"]) / 2.0)
     raise ValueError(lik.name)
 
 
@@ -381,7 +484,9 @@ def grad_E_Sigma(lik, y, lv):
     studentt.jl:97-99, logisticsoftmax.jl:101-103."""
     if lik.name == "logisticsoftmax":
         return tuple(lv["theta"][k] / 2.0 for k in range(lik.n_class))
-    return (lv["theta"] / 2.0,)
+    if lik.name == "heteroscedastic":  # heteroscedastic.jl:122-129
+        return (lik.lam * lv["sigg"] / 2.0, lv["theta"] / 2.0)
+    return (lv["theta"] / 2.0,)  # also laplace.jl:88-90, bayesiansvm.jl:63-67, poisson.jl:99-103, negativebinomial.jl:97-99
 
 
 def expec_loglikelihood(lik, y, mu_f, var_f, lv, elbo_mode="corrected"):
@@ -419,7 +524,53 @@ def expec_loglikelihood(lik, y, mu_f, var_f, lv, elbo_mode="corrected"):
                   - np.dot(lv["theta"][k], var_f[k]))
         tot += s / 2.0
         return tot
+    if lik.name == "laplace":  # laplace.jl:93-110
+        th, mu = lv["theta"], mu_f[0]
+        tot = -len(y) * LOG2PI / 2.0 + np.sum(np.log(th)) / 2.0
+        tot += -(np.dot(th, var_f[0]) + np.dot(th, mu * mu) - 2.0 * np.dot(th, mu * y) + np.dot(th, y * y)) / 2.0
+        return tot
+    if lik.name == "bayesiansvm":
+        # bayesiansvm.jl:71-83 ; "reference": + dot(theta, (1 - y mu)^2) exactly as written (line 81);
+        # "corrected": -1/2 dot(theta, (1 - y mu)^2), the expectation of -(1 + w - y f)^2 / (2 w) (docstring :14-16)
+        th, mu = lv["theta"], mu_f[0]
+        q = np.dot(th, (1.0 - y * mu) ** 2)
+        tot = -len(y) * LOG2 / 2.0 + np.dot(mu, y) - np.dot(th, var_f[0]) / 2.0
+        tot += q if elbo_mode == "reference" else -q / 2.0
+        return tot
+    if lik.name == "poisson":  # poisson.jl:106-120 (lambda = the value left by the last local update)
+        th, mu, g = lv["theta"], mu_f[0], lv["gamma"]
+        tot = (np.dot(mu, y - g) - np.dot(th, mu * mu) - np.dot(th, var_f[0])) / 2.0
+        tot += np.sum(y * math.log(lik.lam)) - np.sum(gammaln(y + 1.0)) - LOG2 * np.sum(y + g)
+        return tot
+    if lik.name == "negbinomial":
+        # negativebinomial.jl:116-127 ; "reference": dot(theta, mu)/2 as written (line 125); "corrected": dot(theta, mu^2)/2
+        th, mu = lv["theta"], mu_f[0]
+        logconst = gammaln(y + lik.r) - gammaln(y + 1.0) - gammaln(lik.r)  # negbin_logconst :105-113
+        tot = np.sum(logconst) - LOG2 * np.sum(y + lik.r)
+        quad = np.dot(th, mu) if elbo_mode == "reference" else np.dot(th, mu * mu)
+        tot += np.dot(mu, y - lik.r) / 2.0 - quad / 2.0 - np.dot(th, var_f[0]) / 2.0
+        return tot
+    if lik.name == "heteroscedastic":  # heteroscedastic.jl:142-158 + PoissonKL :166-175
+        lam = lik.lam
+        tot = len(y) * (math.log(lam) / 2.0 - math.log(2.0 * math.sqrt(2.0 * math.pi)))
+        tot += (np.dot(mu_f[1], 0.5 - lv["gamma"]) - np.dot(mu_f[1] ** 2, lv["theta"])
+                - np.dot(var_f[1], lv["theta"])) / 2.0
+        lam0 = lam * ((y - mu_f[0]) ** 2 + var_f[0]) / 2.0
+        tot -= poisson_kl(lv["gamma"], lam0, np.log(lam0))
+        return tot
     raise ValueError(lik.name)
+
+
+def expectation_logistic(mu, s2):
+    """expectation(logistic, mu, sigma2) : src/functions/utils.jl:16-19 (Gauss-Hermite 100, predictions.jl:4)."""
+    nodes, weights = gauss_hermite_100()
+    x = nodes[None, :] * np.sqrt(np.maximum(s2, 0.0))[:, None] + np.asarray(mu)[:, None]
+    return logistic(x) @ weights
+
+
+def log2besselk_half(s):
+    """log(2 K_{1/2}(s)) with K_{1/2}(s) = sqrt(pi / (2 s)) exp(-s) (closed form of besselk(0.5, s))."""
+    return LOG2 + 0.5 * (np.log(np.pi) - LOG2 - np.log(s)) - s
 
 
 # src/functions/KLdivergences.jl ------------------------------------------------------------
@@ -454,7 +605,7 @@ def poisson_kl(lam, lam0, psi):
     return float(np.sum(lam0) - np.sum(lam) + np.sum(xlogx(lam)) - np.dot(lam, psi))
 
 
-def augmented_kl(lik, lv, y):
+def augmented_kl(lik, lv, y, mode="corrected"):
     """AugmentedKL : gaussian.jl:95 (0), logistic.jl:86-92, studentt.jl:121-127,
     logisticsoftmax.jl:117-140."""
     if lik.name == "gaussian":
@@ -477,6 +628,31 @@ def augmented_kl(lik, lv, y):
         # GammaEntropy logisticsoftmax.jl:136-140 : sum(log, first(beta)) == log(beta[1]) (Q16)
         ge = (-np.sum(a) + math.log(lv["beta"][0]) - np.sum(gammaln(a)) - np.dot(1.0 - a, digamma(a)))
         return float(pg + po + ge)
+    if lik.name == "laplace":
+        # laplace.jl:112-123 + GIGEntropy KLdivergences.jl:105-113 with (a, b, p) = (beta^-2, b.^2, 1/2).  For p = 1/2:
+        # K_{3/2}(s) = K_{1/2}(s)(1 + 1/s), K_{-1/2} = K_{1/2}  =>  s/K_p (K_{p+1} + K_{p-1}) / 2 = s + 1/2.
+        # "reference" keeps two Julia iteration quirks of GIGEntropy with a scalar a and p: sum(log, a) = log(a) ONCE and
+        # mapreduce(f, +, p, sqrt_ab) zips the scalar p with the vector => only the FIRST point's log(2 K_p) enters.
+        a, b = lik.a, lv["b"]
+        sab = np.sqrt(a * b * b)
+        n = len(b)
+        if mode == "reference":
+            ent = (math.log(a) - np.sum(np.log(b * b))) / 2.0 + float(log2besselk_half(sab[:1])[0]) + np.sum(sab + 0.5)
+        else:
+            ent = (n * math.log(a) - np.sum(np.log(b * b))) / 2.0 + np.sum(log2besselk_half(sab)) + np.sum(sab + 0.5)
+        expo = np.sum(-math.log(2.0 * lik.beta ** 2) - (a * b + b * b * math.sqrt(a)) / (a * b * b * lik.beta ** 2) / 2.0)
+        return float(ent - expo)
+    if lik.name == "bayesiansvm":  # bayesiansvm.jl:85-92
+        c = lv["c"]
+        return float(np.sum(np.log(c)) / 2.0 + np.sum(log2besselk_half(np.sqrt(c))) - np.sum(np.sqrt(c)) / 2.0)
+    if lik.name == "poisson":  # poisson.jl:122-132 ; PoissonKL(lambda vec, lambda0 scalar) KLdivergences.jl:74-76
+        g, lam0 = lv["gamma"], lik.lam
+        pk = lam0 * len(g) - (1.0 + math.log(lam0)) * np.sum(g) + np.sum(xlogx(g))
+        return float(pk + polya_gamma_kl(y + g, lv["c"], lv["theta"]))
+    if lik.name == "negbinomial":  # negativebinomial.jl:103,129-131
+        return polya_gamma_kl(y + lik.r, lv["c"], lv["theta"])
+    if lik.name == "heteroscedastic":  # heteroscedastic.jl:160-164,177-179
+        return polya_gamma_kl(0.5 + lv["gamma"], lv["c"], lv["theta"])
     raise ValueError(lik.name)
 
 
@@ -731,7 +907,7 @@ class SVGP:
         tot = rho * expec_loglikelihood(self.likelihood, y, self.mean_f(), self.var_f(),
                                         self.local_vars, self.elbo_mode)
         tot -= sum(gaussian_kl(gp.mu, gp.mu0, gp.Sigma, gp.L) for gp in self.latents)
-        tot -= rho * augmented_kl(self.likelihood, self.local_vars, y)
+        tot -= rho * augmented_kl(self.likelihood, self.local_vars, y, self.elbo_mode)
         return float(tot)
 
     def elbo_fresh(self, X, y, rho):
@@ -770,10 +946,15 @@ class SVGP:
         """predictions.jl:178-198 + regression.jl:17-18, classification.jl:47-48."""
         mu = self.predict_f(Xt, cov=False)
         lik = self.likelihood
-        if lik.name in ("gaussian", "studentt"):
-            return mu[0]
-        if lik.name == "logistic":
+        if lik.name in ("gaussian", "studentt", "laplace", "heteroscedastic"):
+            return mu[0]  # regression.jl:17-18 ; heteroscedastic.jl:137-141 (first latent)
+        if lik.name in ("logistic", "bayesiansvm"):
             return mu[0] > 0
+        if lik.name == "poisson":  # predictions.jl:211 : mean(Poisson(lambda logistic(mu)))
+            return lik.lam * logistic(mu[0])
+        if lik.name == "negbinomial":  # mean(NegativeBinomial(r, logistic(-mu))) = r (1 - p)/p = r exp(mu)
+            p = logistic(-mu[0])
+            return lik.r * (1.0 - p) / p
         if lik.name == "logisticsoftmax":
             am = np.argmax(np.stack(mu, axis=1), axis=1)
             cm = lik.class_mapping or list(range(1, lik.n_class + 1))
@@ -815,6 +996,26 @@ def compute_proba(lik, mu, var):
     if lik.name == "logisticsoftmax":
         s = logistic(np.stack(mu, axis=1))
         return s / np.sum(np.abs(s), axis=1, keepdims=True)
+    if lik.name == "laplace":  # laplace.jl:48-52
+        return mu[0], np.maximum(var[0], 0.0) + 2.0 * lik.beta ** 2
+    if lik.name == "heteroscedastic":  # heteroscedastic.jl:63-69
+        return mu[0], var[0] + 1.0 / (lik.lam * logistic(mu[1]))
+    if lik.name in ("bayesiansvm", "poisson", "negbinomial"):
+        nodes, weights = gauss_hermite_100()
+        x = nodes[None, :] * np.sqrt(np.maximum(var[0], 0.0))[:, None] + mu[0][:, None]
+        if lik.name == "bayesiansvm":  # classification.jl:14-26 with SVMLink (bayesiansvm.jl:27-40)
+            pos = np.exp(-2.0 * np.maximum(1.0 - x, 0.0))
+            neg = np.exp(-2.0 * np.maximum(1.0 + x, 0.0))
+            s = pos / (pos + neg)
+            pred = s @ weights
+            return pred, np.maximum((s * s) @ weights - pred ** 2, 0.0)
+        if lik.name == "poisson":  # poisson.jl:46-57
+            s = lik.lam * logistic(x)
+        else:  # negativebinomial.jl:46-62
+            p = logistic(x)
+            s = p * lik.r / (1.0 - p)
+        pred = s @ weights
+        return pred, (s * s) @ weights - pred ** 2
     raise ValueError(lik.name)
 
 
@@ -906,7 +1107,7 @@ class MOSVGP:
         self.n_task, self.Q = self.A.shape
         assert len(self.likelihoods) == self.n_task and len(self.latents) == self.Q
         for l in self.likelihoods:
-            assert l.name in ("gaussian", "logistic", "studentt")
+            assert l.name in ("gaussian", "logistic", "studentt", "laplace", "bayesiansvm", "negbinomial")
         self.local_vars = None
         self.A_state = [self.A_opt.init(self.A[t]) for t in range(self.n_task)] if self.A_opt else None
         self.rho = 1.0
@@ -997,7 +1198,8 @@ class MOSVGP:
         tot = rho * sum(expec_loglikelihood(l, ys[t], (mu_t[t],), (var_t[t],), self.local_vars[t], self.elbo_mode)
                         for t, l in enumerate(self.likelihoods))
         tot -= sum(gaussian_kl(gp.mu, gp.mu0, gp.Sigma, gp.L) for gp in self.latents)
-        tot -= rho * sum(augmented_kl(l, self.local_vars[t], ys[t]) for t, l in enumerate(self.likelihoods))
+        tot -= rho * sum(augmented_kl(l, self.local_vars[t], ys[t], self.elbo_mode)
+                         for t, l in enumerate(self.likelihoods))
         return float(tot)
 
     def predict_f(self, Xt, cov=False):
@@ -1016,7 +1218,16 @@ class MOSVGP:
 
     def predict_y(self, Xt):
         mu = self.predict_f(Xt)
-        return [m > 0 if l.name == "logistic" else m for m, l in zip(mu, self.likelihoods)]
+        out = []
+        for m, l in zip(mu, self.likelihoods):  # predict_y.(likelihood(model), ...) predictions.jl:196
+            if l.name in ("logistic", "bayesiansvm"):
+                out.append(m > 0)
+            elif l.name == "negbinomial":
+                p = logistic(-m)
+                out.append(l.r * (1.0 - p) / p)
+            else:
+                out.append(m)
+        return out
 
     def proba_y(self, Xt):
         mu, var = self.predict_f(Xt, cov=True)
@@ -1044,13 +1255,20 @@ def dphi_dd2(kind, d2):
     raise ValueError("hyper-gradients are defined for SqExponential / Matern32 / Matern52 here")
 
 
-def expec_grads(lik, y, mu_f, lv, latent_k=0, elbo_mode="corrected"):
+def expec_grads(lik, y, mu_f, lv, latent_k=0, elbo_mode="corrected", var_f=None):
     """(dE/dmu_f, dE/dsigma2_f) of expec_loglikelihood for one latent: g_mu = grad_E_mu - theta*mu_f, g_sigma = -theta/2
     (all four augmented likelihoods; the reference-bug logistic variant has g_mu = y/2 - theta/2)."""
+    if lik.name == "heteroscedastic" and latent_k == 0:
+        # d/d(mu_1, sigma2_1) of -PoissonKL(gamma, lambda0, log lambda0), lambda0 = lam ((y-mu_1)^2 + sigma2_1)/2 evaluated
+        # at the CURRENT (mu_1, sigma2_1) with gamma fixed: t = lam - gamma / phi_now ; (-t (mu_1 - y), -t/2)
+        t1 = lik.lam - lv["gamma"] / (((mu_f - y) ** 2 + var_f) / 2.0)
+        return -t1 * (mu_f - y), -t1 / 2.0
     g1 = grad_E_mu(lik, y, lv)[latent_k]
     th = lv["theta"][latent_k] if lik.name == "logisticsoftmax" else lv["theta"]
-    if lik.name == "logistic" and elbo_mode == "reference":
+    if lik.name in ("logistic", "negbinomial") and elbo_mode == "reference":
         return g1 - th / 2.0, -th / 2.0
+    if lik.name == "bayesiansvm" and elbo_mode == "reference":
+        return y - 2.0 * th * (1.0 - y * mu_f) * y, -th / 2.0
     return g1 - th * mu_f, -th / 2.0
 
 
@@ -1063,7 +1281,8 @@ def hyper_gradient(model, X, y, latent_k, rho):
     Kinv = sla.cho_solve((L, True), np.eye(m))
     Knm, kappa, Kt = compute_kappa(ker, X, Z, L, model.jitter)
     mu_f = mean_f(gp.mu, kappa)
-    gmu, gsig = expec_grads(model.likelihood, y, mu_f, model.local_vars, latent_k, model.elbo_mode)
+    gmu, gsig = expec_grads(model.likelihood, y, mu_f, model.local_vars, latent_k, model.elbo_mode,
+                            var_f(gp.Sigma, kappa, Kt))
     G_kappa = rho * (np.outer(gmu, gp.mu) + 2.0 * gsig[:, None] * (kappa @ gp.Sigma) - gsig[:, None] * Knm)
     H = G_kappa @ Kinv
     G_Knm = H - rho * gsig[:, None] * kappa

@@ -21,22 +21,27 @@ def test_hip_matches_golden(built, path):
 
     g = np.load(path, allow_pickle=True)
     name = os.path.basename(path).split("_")[0]
-    lik = {"gaussian": lambda: AGP.GaussianLikelihood(0.05), "logistic": AGP.LogisticLikelihood,
-           "studentt": lambda: AGP.StudentTLikelihood(3.0, 1.0),
-           "logisticsoftmax": lambda: AGP.LogisticSoftMaxLikelihood(3)}[name]()
+    from _liks import agp_lik
+
+    lik = agp_lik(AGP, name)
     B = int(g["B"])
     inf = AGP.AnalyticSVI(B) if int(g["stochastic"]) else AGP.AnalyticVI()
     k = float(g["variance"]) * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(float(g["scale"])))
     m = AGP.SVGP(k, lik, inf, g["Z"], optimiser=False)
-    elbos, snaps = [], {}
+    elbos, snaps, lams = [], {}, []
 
     def cb(model, state, it):
         elbos.append(AGP.objective(model, state))
+        if hasattr(lik, "lam"):
+            model._pull_lik_state()
+            lams.append(lik.lam)
         if len(elbos) in (1, 2, 10):
             snaps[len(elbos)] = [model.get_state(l) for l in range(model.n_latent)]
 
     AGP.train_(m, g["X"], g["y"], 10, idx_stream=g["idx"], callback=cb)
     assert np.allclose(elbos, g["elbo"], rtol=1e-8, atol=1e-7)
+    if lams:  # lambda of Poisson / Heteroscedastic after every iteration
+        assert np.allclose(lams, g["lam"], rtol=1e-10)
     for it in (1, 2, 10):
         for l, (mu, Sig, e1, e2) in enumerate(snaps[it]):
             assert _rel(e1, g[f"eta1_it{it}_l{l}"]) < 1e-9
@@ -48,6 +53,10 @@ def test_hip_matches_golden(built, path):
         assert _rel(m.get_matrix(capi.MAT_KAPPA, l, nb), g[f"kappa_l{l}"]) < 1e-9
         assert _rel(m.get_matrix(capi.VEC_KTILDE, l, nb), g[f"Ktilde_l{l}"]) < 1e-8
         assert _rel(m.get_matrix(capi.VEC_THETA, l, nb), g[f"theta_l{l}"]) < 1e-8
+        if f"gamma_l{l}" in g.files and name != "logisticsoftmax":
+            assert _rel(m.get_matrix(capi.VEC_GAMMA, l, nb), g[f"gamma_l{l}"]) < 1e-8
+        if f"c_l{l}" in g.files:
+            assert _rel(m.get_matrix(capi.VEC_C, l, nb), g[f"c_l{l}"]) < 1e-9
     if name == "logisticsoftmax":
         assert _rel(m.get_matrix(capi.VEC_ALPHA, 0, nb), g["alpha"]) < 1e-9
     mu, var = AGP.predict_f(m, g["Xt"], cov=True)
@@ -58,4 +67,10 @@ def test_hip_matches_golden(built, path):
         assert _rel(np.stack([pr[c] for c in (1, 2, 3)], axis=1), g["proba"]) < 1e-8
     else:
         assert _rel(pr[0], g["proba"][0]) < 1e-8 and _rel(pr[1], g["proba"][1]) < 1e-6
+    if "pred_y" in g.files:
+        py = np.asarray(AGP.predict_y(m, g["Xt"]), dtype=np.float64)
+        assert _rel(py, g["pred_y"]) < 1e-8
     assert AGP.ELBO(m, g["X"], g["y"], rho=1.0) == pytest.approx(float(g["elbo_fresh_rho1"]), rel=1e-8)
+    if hasattr(lik, "lam"):  # the external ELBO runs a local update, which re-estimates lambda (reference side effect)
+        m._pull_lik_state()
+        assert lik.lam == pytest.approx(float(g["lam_final"]), rel=1e-10)

@@ -141,9 +141,14 @@ def _models(env, likname, rng, stochastic, B=64, T=np.float64, m=20, N=300):
     elif likname == "studentt":
         y = f + 0.1 * rng.standard_t(3, len(f))
         la, lr = AGP.StudentTLikelihood(3.0), R.StudentTLikelihood(3.0)
-    else:
+    elif likname == "logisticsoftmax":
         y = 1 + np.digitize(f, np.quantile(f, [0.33, 0.66]))
         la, lr = AGP.LogisticSoftMaxLikelihood(3), R.LogisticSoftMaxLikelihood(3)
+    else:
+        from _liks import agp_lik, labels, oracle_lik
+
+        y = labels(likname, f, X, rng)
+        la, lr = agp_lik(AGP, likname), oracle_lik(R, likname)
     ka = 1.5 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0))
     kr = R.Kernel("sqexponential", 2.0, 1.5)
     inf = AGP.AnalyticSVI(B) if stochastic else AGP.AnalyticVI()
@@ -152,7 +157,10 @@ def _models(env, likname, rng, stochastic, B=64, T=np.float64, m=20, N=300):
     return X, y, ma, mr
 
 
-@pytest.mark.parametrize("likname", ["gaussian", "logistic", "studentt", "logisticsoftmax"])
+NEW_LIKS = ["laplace", "bayesiansvm", "poisson", "negbinomial", "heteroscedastic"]
+
+
+@pytest.mark.parametrize("likname", ["gaussian", "logistic", "studentt", "logisticsoftmax"] + NEW_LIKS)
 @pytest.mark.parametrize("stochastic", [False, True])
 def test_cavi_trajectory_fp64(env, likname, stochastic):
     AGP, R, capi = env["AGP"], env["R"], env["capi"]
@@ -179,15 +187,27 @@ def test_cavi_trajectory_fp64(env, likname, stochastic):
     assert _rel(ma.get_matrix(capi.VEC_KTILDE, 0, nb), g.Kt) < 1e-8
     # predictions
     Xt = rng.random((131, X.shape[1]))
-    if ma.n_latent == 1:
+    if hasattr(mr.likelihood, "lam"):
+        assert ma.likelihood.lam == pytest.approx(mr.likelihood.lam, rel=1e-10)
+    if likname == "heteroscedastic":
+        mf, vf = AGP.predict_f(ma, Xt, cov=True)
+        mfr, vfr = mr.predict_f(Xt, cov=True)
+        for k in range(2):
+            assert _rel(mf[k], mfr[k]) < 1e-8 and _rel(vf[k], vfr[k]) < 1e-7
+        pa, pr = AGP.proba_y(ma, Xt), mr.proba_y(Xt)
+        assert _rel(pa[0], pr[0]) < 1e-8 and _rel(pa[1], pr[1]) < 1e-7
+        assert _rel(AGP.predict_y(ma, Xt), mr.predict_y(Xt)) < 1e-8
+    elif ma.n_latent == 1:
         mf, vf = AGP.predict_f(ma, Xt, cov=True)
         mfr, vfr = mr.predict_f(Xt, cov=True)
         assert _rel(mf, mfr[0]) < 1e-8 and _rel(vf, vfr[0]) < 1e-7
         pa = AGP.proba_y(ma, Xt)
         pr = mr.proba_y(Xt)
         assert _rel(pa[0], pr[0]) < 1e-8 and _rel(pa[1], pr[1]) < 1e-6
-        assert np.array_equal(np.asarray(AGP.predict_y(ma, Xt)), np.asarray(mr.predict_y(Xt))) or likname in (
-            "gaussian", "studentt")
+        if likname in ("gaussian", "studentt", "laplace", "poisson", "negbinomial"):
+            assert _rel(AGP.predict_y(ma, Xt), mr.predict_y(Xt)) < 1e-8
+        else:
+            assert np.array_equal(np.asarray(AGP.predict_y(ma, Xt)), np.asarray(mr.predict_y(Xt)))
     else:
         mf = AGP.predict_f(ma, Xt)
         mfr = mr.predict_f(Xt)
@@ -310,13 +330,17 @@ def test_multioutput_svgp_matches_oracle(env, stochastic, aopt):
         (3, [AGP.GaussianLikelihood(0.05), AGP.LogisticLikelihood(), AGP.StudentTLikelihood(3.0)],
          [R.GaussianLikelihood(0.05), R.LogisticLikelihood(), R.StudentTLikelihood(3.0)]),
         (4, [AGP.LogisticLikelihood(), AGP.GaussianLikelihood(0.1)], [R.LogisticLikelihood(), R.GaussianLikelihood(0.1)]),
+        (2, [AGP.LaplaceLikelihood(0.3), AGP.BayesianSVM(), AGP.NegBinomialLikelihood(5.0)],
+         [R.LaplaceLikelihood(0.3), R.BayesianSVM(), R.NegBinomialLikelihood(5.0)]),
     ]:
         rng = np.random.default_rng(31 + Q)
         N, D, m, B, iters = 240, 2, 12, 60, 5
         X = rng.random((N, D))
         f = [np.sin(4 * X[:, 0]), X[:, 1] - 0.5, np.cos(3 * X[:, 0] * X[:, 1])]
         ys_all = {"gaussian": f[0] + 0.1 * rng.standard_normal(N), "logistic": np.sign(f[1] + 0.1 * rng.standard_normal(N)),
-                  "studentt": f[2] + 0.1 * rng.standard_t(3, N)}
+                  "studentt": f[2] + 0.1 * rng.standard_t(3, N), "laplace": f[0] + rng.laplace(0, 0.3, N),
+                  "bayesiansvm": np.sign(f[1] + 0.1 * rng.standard_normal(N)),
+                  "negbinomial": rng.negative_binomial(5, 1.0 / (1.0 + np.exp(f[2]))).astype(np.int64)}
         ys = [ys_all[l.name] for l in liks_r]
         T = len(ys)
         A = rng.standard_normal((T, Q))
@@ -349,7 +373,10 @@ def test_multioutput_svgp_matches_oracle(env, stochastic, aopt):
 
 
 @pytest.mark.parametrize("likname,kname,ard", [("logistic", "sq", False), ("studentt", "m52", True),
-                                               ("gaussian", "m32", False), ("logisticsoftmax", "sq", True)])
+                                               ("gaussian", "m32", False), ("logisticsoftmax", "sq", True),
+                                               ("laplace", "sq", True), ("bayesiansvm", "m52", False),
+                                               ("poisson", "sq", False), ("negbinomial", "m32", True),
+                                               ("heteroscedastic", "sq", False)])
 def test_hypergrad_matches_oracle(env, likname, kname, ard):
     """Hand-derived reverse mode (agp_hyper.h) vs the oracle's analytic gradient (itself pinned by finite differences in
     tests/test_oracle_kat.py) of the objective the reference hands to Zygote (autotuning.jl:96-98)."""
@@ -358,13 +385,18 @@ def test_hypergrad_matches_oracle(env, likname, kname, ard):
     N, D, m, B, iters = 200, 3, 14, 70, 3
     X = rng.random((N, D))
     f = np.sin(4 * X[:, 0]) + X[:, 1] * X[:, 2]
-    la, lr, y = {
-        "gaussian": (AGP.GaussianLikelihood(0.05), R.GaussianLikelihood(0.05), f + 0.1 * rng.standard_normal(N)),
-        "logistic": (AGP.LogisticLikelihood(), R.LogisticLikelihood(), (f > f.mean()).astype(int)),
-        "studentt": (AGP.StudentTLikelihood(3.0), R.StudentTLikelihood(3.0), f + 0.1 * rng.standard_t(3, N)),
-        "logisticsoftmax": (AGP.LogisticSoftMaxLikelihood(3), R.LogisticSoftMaxLikelihood(3),
-                            1 + np.digitize(f, np.quantile(f, [0.33, 0.66]))),
-    }[likname]
+    if likname in NEW_LIKS:
+        from _liks import agp_lik, labels, oracle_lik
+
+        la, lr, y = agp_lik(AGP, likname), oracle_lik(R, likname), labels(likname, f, X, rng)
+    else:
+        la, lr, y = {
+            "gaussian": (AGP.GaussianLikelihood(0.05), R.GaussianLikelihood(0.05), f + 0.1 * rng.standard_normal(N)),
+            "logistic": (AGP.LogisticLikelihood(), R.LogisticLikelihood(), (f > f.mean()).astype(int)),
+            "studentt": (AGP.StudentTLikelihood(3.0), R.StudentTLikelihood(3.0), f + 0.1 * rng.standard_t(3, N)),
+            "logisticsoftmax": (AGP.LogisticSoftMaxLikelihood(3), R.LogisticSoftMaxLikelihood(3),
+                                1 + np.digitize(f, np.quantile(f, [0.33, 0.66]))),
+        }[likname]
     kcls, kn = {"sq": (AGP.SqExponentialKernel, "sqexponential"), "m52": (AGP.Matern52Kernel, "matern52"),
                 "m32": (AGP.Matern32Kernel, "matern32")}[kname]
     sc = np.array([2.0, 3.0, 1.5]) if ard else 2.5

@@ -140,3 +140,30 @@ def test_no_gpu_no_cpu_fallback(built):
     m = AGP.SVGP(AGP.SqExponentialKernel(), AGP.GaussianLikelihood(), AGP.AnalyticVI(), Z)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         AGP.train_(m, np.zeros((10, 2)), np.zeros(10), 1)
+
+
+def test_event_regression_svm_likelihood_mirrors():
+    """constructors / labels of the remaining augmented likelihoods (laplace.jl:17-30, bayesiansvm.jl:19-23, poisson.jl:16-24,
+    negativebinomial.jl:22-27, heteroscedastic.jl:17-47, event.jl:7-13)."""
+    import numpy as np
+
+    import agp_amd as AGP
+    from agp_amd import capi
+    from agp_amd.likelihoods import treat_labels
+
+    lap = AGP.LaplaceLikelihood(3.0)
+    assert lap.a == pytest.approx(1 / 9) and lap.p == 0.5 and lap.lik_desc().kind == capi.LIK_LAPLACE
+    assert repr(lap) == "Laplace likelihood (β=3.0)"
+    assert AGP.HeteroscedasticLikelihood(2.0).n_latent == 2
+    assert repr(AGP.PoissonLikelihood(5.0)) == "Poisson Likelihood (λ = 5.0)"
+    assert repr(AGP.NegBinomialLikelihood(10)) == "Negative Binomial Likelihood (r = 10)"
+    assert np.array_equal(treat_labels(np.array([0, 1, 1]), AGP.BayesianSVM()), [-1.0, 1.0, 1.0])
+    with pytest.raises(ValueError):
+        treat_labels(np.array([0, 2]), AGP.BayesianSVM())
+    with pytest.raises(TypeError):  # "For event count target(s) should be integers"
+        treat_labels(np.array([1.0, 2.0]), AGP.PoissonLikelihood(2.0))
+    assert treat_labels(np.array([3, 0, 2]), AGP.NegBinomialLikelihood(4)).dtype == np.float64
+    for bad in (lambda: AGP.LaplaceLikelihood(0.0), lambda: AGP.PoissonLikelihood(-1.0),
+                lambda: AGP.NegBinomialLikelihood(0), lambda: AGP.HeteroscedasticLikelihood(0.0)):
+        with pytest.raises(ValueError):
+            bad()

@@ -2,6 +2,7 @@
 identities (test/functions/utils.jl, test/likelihood/multiclass.jl), mpmath tables, behavioural thresholds of
 test/testingtools.jl, and the committed golden fixtures.  No GPU needed."""
 import glob
+import math
 import os
 
 import numpy as np
@@ -209,9 +210,9 @@ def test_oracle_reproduces_golden(path):
     """The committed fixtures are regenerated bit-for-bit-ish by the oracle (guards against silent oracle edits)."""
     g = np.load(path, allow_pickle=True)
     name = os.path.basename(path)
-    lik = {"gaussian": lambda: R.GaussianLikelihood(0.05), "logistic": lambda: R.LogisticLikelihood(),
-           "studentt": lambda: R.StudentTLikelihood(3.0, 1.0),
-           "logisticsoftmax": lambda: R.LogisticSoftMaxLikelihood(3)}[name.split("_")[0]]()
+    from _liks import oracle_lik
+
+    lik = oracle_lik(R, name.split("_")[0])
     M = R.SVGP(R.Kernel("sqexponential", float(g["scale"]), float(g["variance"])), lik, g["Z"],
                stochastic=bool(g["stochastic"]), batchsize=int(g["B"]))
     es = []
@@ -223,6 +224,172 @@ def test_oracle_reproduces_golden(path):
     mu, var = M.predict_f(g["Xt"], cov=True)
     assert np.allclose(np.stack(mu), g["pred_mu"], rtol=1e-9, atol=1e-12)
     assert np.allclose(np.stack(var), g["pred_var"], rtol=1e-8, atol=1e-12)
+    if "lam" in g.files and hasattr(lik, "lam"):
+        assert lik.lam == pytest.approx(float(g["lam"][-1]), rel=1e-12)
+
+
+def test_half_order_bessel_closed_forms():
+    """The GIG terms of the Laplace / BayesianSVM ELBO (KLdivergences.jl:105-113, bayesiansvm.jl:89-92) call besselk at
+    orders 1/2, 3/2, -1/2 only; the closed forms the oracle and the HIP kernel use agree with scipy's besselk."""
+    from scipy.special import kv
+
+    s = np.array([1e-3, 0.05, 0.7, 3.0, 25.0, 300.0])
+    assert np.allclose(R.log2besselk_half(s[:5]), np.log(2.0 * kv(0.5, s[:5])), rtol=1e-13, atol=1e-13)
+    ratio = s[:5] / kv(0.5, s[:5]) * (kv(1.5, s[:5]) + kv(-0.5, s[:5])) / 2.0
+    assert np.allclose(ratio, s[:5] + 0.5, rtol=1e-12)
+
+
+def test_gauss_hermite_expectation_of_logistic():
+    """expectation(logistic, mu, s2) (utils.jl:16-19) against adaptive quadrature."""
+    from scipy.integrate import quad
+
+    for mu, s2 in [(0.3, 0.5), (-2.0, 4.0), (1.5, 1e-3)]:
+        ref = quad(lambda t: R.logistic(mu + math.sqrt(s2) * t) * math.exp(-t * t / 2) / math.sqrt(2 * math.pi), -12, 12,
+                   epsabs=1e-13, epsrel=1e-13)[0]
+        assert R.expectation_logistic(np.array([mu]), np.array([s2]))[0] == pytest.approx(ref, rel=1e-10)
+
+
+def _new_lik_case(name, seed=3, N=150, m=12):
+    from _liks import labels, oracle_lik
+
+    rng, X, f, Z = _toy(seed, N=N, D=2, m=m)
+    lik = oracle_lik(R, name)
+    y = labels(name, f, X, rng)
+    return rng, X, f, Z, lik, y
+
+
+@pytest.mark.parametrize("name", ["laplace", "bayesiansvm", "poisson", "negbinomial", "heteroscedastic"])
+def test_new_likelihood_local_updates_follow_the_reference_formulas(name):
+    """One local update evaluated by hand from the reference source lines."""
+    rng = np.random.default_rng(5)
+    B = 9
+    mu, s2 = rng.standard_normal(B), rng.random(B) + 0.1
+    lik = __import__("_liks").oracle_lik(R, name)
+    lv = R.init_local_vars(lik, B)
+    if name == "laplace":
+        y = rng.standard_normal(B)
+        lv = R.local_updates(lv, lik, y, (mu,), (s2,))
+        b = np.sqrt((mu - y) ** 2 + s2)                                            # laplace.jl:67
+        assert np.allclose(lv["theta"], (1 / 0.4) / b)                             # sqrt(a)/b, a = beta^-2  :68-70
+        assert np.allclose(R.grad_E_mu(lik, y, lv)[0], lv["theta"] * y)            # :85-87
+    elif name == "bayesiansvm":
+        y = np.sign(rng.standard_normal(B))
+        lv = R.local_updates(lv, lik, y, (mu,), (s2,))
+        assert np.allclose(lv["c"], (1 - y * mu) ** 2 + s2)                        # bayesiansvm.jl:50-52
+        assert np.allclose(lv["theta"], lv["c"] ** -0.5)                           # :53
+        assert np.allclose(R.grad_E_mu(lik, y, lv)[0], y * (lv["theta"] + 1))      # :57-61
+    elif name == "poisson":
+        y = rng.poisson(2.0, B).astype(float)
+        lam0 = lik.lam
+        lv = R.local_updates(lv, lik, y, (mu,), (s2,))
+        c = np.sqrt(mu ** 2 + s2)
+        g = lam0 * np.exp(-mu / 2) / np.cosh(c / 2) / 2                            # poisson.jl:72-74
+        assert np.allclose(lv["gamma"], g)
+        assert np.allclose(lv["theta"], (y + g) / c * np.tanh(c / 2))              # :75-77
+        assert lik.lam == pytest.approx(y.sum() / R.expectation_logistic(mu, s2).sum())  # :78
+        assert np.allclose(R.grad_E_mu(lik, y, lv)[0], (y - g) / 2)                # :94-98
+    elif name == "negbinomial":
+        y = rng.poisson(3.0, B).astype(float)
+        lv = R.local_updates(lv, lik, y, (mu,), (s2,))
+        c = np.sqrt(mu ** 2 + s2)
+        assert np.allclose(lv["theta"], (6.0 + y) * np.tanh(c / 2) / c)            # negativebinomial.jl:77-79
+        assert np.allclose(R.grad_E_mu(lik, y, lv)[0], (y - 6.0) / 2)              # :94-96
+    else:
+        y = rng.standard_normal(B)
+        mu2, s22 = rng.standard_normal(B), rng.random(B) + 0.1
+        lam0 = lik.lam
+        lv = R.local_updates(lv, lik, y, (mu, mu2), (s2, s22))
+        phi = ((mu - y) ** 2 + s2) / 2                                             # heteroscedastic.jl:80-82
+        c = np.sqrt(mu2 ** 2 + s22)                                                # :83
+        sg = np.exp(-mu2 / 2) / np.cosh(c / 2) / 2                                 # :84-86
+        gam = lam0 * phi * sg                                                      # :87-89
+        assert np.allclose(lv["gamma"], gam)
+        assert np.allclose(lv["theta"], (0.5 + gam) * np.tanh(c / 2) / (2 * c))    # :90-92
+        assert lik.lam == pytest.approx(max(B / (2 * np.dot(phi, 1 - sg)), lam0))  # :95
+        g1 = R.grad_E_mu(lik, y, lv)
+        assert np.allclose(g1[0], y * lik.lam * sg / 2) and np.allclose(g1[1], (0.5 - gam) / 2)  # :113-120
+        g2 = R.grad_E_Sigma(lik, y, lv)
+        assert np.allclose(g2[0], lik.lam * sg / 2) and np.allclose(g2[1], lv["theta"] / 2)      # :122-129
+
+
+def test_laplace_cavi_increases_the_collapsed_bound():
+    """With q(omega) at its optimum the augmented bound collapses to sum_i [-log(2 beta) - sqrt(E(y_i - f_i)^2)/beta] - KL(q(u)||p(u));
+    full-batch CAVI with the reference's updates (laplace.jl:60-90) must never decrease it."""
+    rng, X, f, Z, lik, y = _new_lik_case("laplace")
+    M = R.SVGP(R.Kernel("sqexponential", 3.0, 1.0), lik, Z)
+    vals = []
+
+    def cb(m, it, xb, yb):
+        b = np.sqrt((m.mean_f()[0] - yb) ** 2 + m.var_f()[0])
+        vals.append(np.sum(-math.log(2 * lik.beta) - b / lik.beta)
+                    - R.gaussian_kl(m.latents[0].mu, m.latents[0].mu0, m.latents[0].Sigma, m.latents[0].L))
+
+    M.train(X, y, 12, callback=cb)
+    assert np.all(np.diff(vals) > -1e-9), vals
+
+
+def test_heteroscedastic_elbo_monotone_full_batch():
+    rng, X, f, Z, lik, y = _new_lik_case("heteroscedastic")
+    M = R.SVGP(R.Kernel("sqexponential", 3.0, 1.0), lik, Z)
+    es = []
+    M.train(X, y, 12, callback=lambda m, it, xb, yb: es.append(m.elbo(yb)))
+    assert np.all(np.diff(es) > -1e-8), es
+
+
+@pytest.mark.parametrize("name,tol", [("laplace", 0.4), ("bayesiansvm", 0.3), ("poisson", 2.0), ("negbinomial", 8.0),
+                                      ("heteroscedastic", 0.6)])
+def test_new_likelihoods_reference_style_thresholds(name, tol):
+    """Same spirit as test/testingtools.jl:223-253: a few iterations must give a usable predictor and positive proba_y
+    variances (test/testingtools.jl:14,17)."""
+    rng, X, f, Z, lik, y = _new_lik_case(name, N=200, m=20)
+    M = R.SVGP(R.Kernel("sqexponential", 3.0, 1.0), lik, Z)
+    M.train(X, y, 8)
+    py = np.asarray(M.predict_y(X), dtype=float)
+    yt = R.treat_labels(y, lik)
+    if name == "bayesiansvm":
+        assert np.mean(py != (yt > 0)) < tol
+    elif name in ("laplace", "heteroscedastic"):
+        assert np.mean(np.abs(py - f)) < tol
+    else:
+        assert np.mean(np.abs(py - yt)) < tol
+    pr = M.proba_y(X)
+    assert np.all(pr[1] > 0)
+
+
+def test_event_labels_must_be_integers():
+    with pytest.raises(ValueError):
+        R.treat_labels(np.array([1.0, 2.0]), R.PoissonLikelihood(2.0))  # event.jl:11-13
+
+
+@pytest.mark.parametrize("likname,kind", [("laplace", "sqexponential"), ("bayesiansvm", "matern32"),
+                                          ("poisson", "sqexponential"), ("negbinomial", "matern52"),
+                                          ("heteroscedastic", "sqexponential")])
+@pytest.mark.parametrize("mode", ["corrected", "reference"])
+def test_kat7_new_likelihoods_hyper_gradient_vs_finite_differences(likname, kind, mode):
+    rng, X, f, Z, L, y = _new_lik_case(likname, seed=7, N=40, m=6)
+    M = R.SVGP(R.Kernel(kind, np.array([2.0, 3.0]), 1.4), L, Z, elbo_mode=mode)
+    yt = R.treat_labels(y, L)
+    M.train(X, yt, 2, labels_treated=True)
+    M.compute_kernel_matrices(X, update=True)
+    h = 1e-6
+    for lat in range(len(M.latents)):
+        g = R.hyper_gradient(M, X, yt, lat, 1.7)
+        gp = M.latents[lat]
+        sc0, v0, Z0 = np.array(gp.kernel.scale, float), gp.kernel.sigma2, gp.Z.copy()
+        obj = lambda sc, v, Zz: R.hyper_objective(M, X, yt, lat, sc, v, Zz, 1.7)
+        fd_v = (obj(sc0, v0 + h, Z0) - obj(sc0, v0 - h, Z0)) / (2 * h)
+        assert g["dvariance"] == pytest.approx(fd_v, rel=5e-6, abs=1e-6)
+        for d in range(2):
+            e = np.zeros(2)
+            e[d] = h
+            fd = (obj(sc0 + e, v0, Z0) - obj(sc0 - e, v0, Z0)) / (2 * h)
+            assert g["dscale"][d] == pytest.approx(fd, rel=5e-6, abs=1e-6)
+        for (a, d) in [(0, 0), (3, 1)]:
+            Zp, Zm = Z0.copy(), Z0.copy()
+            Zp[a, d] += h
+            Zm[a, d] -= h
+            fd = (obj(sc0, v0, Zp) - obj(sc0, v0, Zm)) / (2 * h)
+            assert g["dZ"][a, d] == pytest.approx(fd, rel=1e-5, abs=2e-6)
 
 
 @pytest.mark.parametrize("likname,kind", [("logistic", "sqexponential"), ("studentt", "matern52"),

@@ -1,0 +1,73 @@
+"""HBM traffic per kernel launch from rocprofv3 PMC passes (run on the GPU box).
+
+  python tools/pmc_traffic.py collect   # two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over a short bench.py run
+  python tools/pmc_traffic.py parse     # -> gpurun_out/pmc/r01_pmc_hbm_bytes.json  (copy it to profiles/)
+
+Units / corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): the counters are in KB and
+FETCH_SIZE reports half of the bytes actually fetched on gfx950, so bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  The
+calibration block re-checks both facts on this machine with a torch fill (pure write) and a rocBLAS gemv (pure read) of
+a 256 MB array.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out", "pmc")
+CMD = ["python", os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-elbo-tol", "--steps", "40", "--warmup", "10"]
+CAL = ["python", "-c", "import torch; x=torch.empty(1000000,32,dtype=torch.float64,device='cuda'); x.fill_(1.0); "
+       "v=torch.ones(32,dtype=torch.float64,device='cuda'); y=x@v; torch.cuda.synchronize()"]
+
+
+def collect():
+    env = dict(os.environ, TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        for tag, cmd in (("bench", CMD), ("cal", CAL)):
+            d = os.path.join(OUT, f"{tag}_{ctr}")
+            os.makedirs(d, exist_ok=True)
+            subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"]
+                           + cmd, check=True, env=env, cwd="/tmp", stdout=subprocess.DEVNULL)
+
+
+def _read(tag, ctr):
+    acc = {}  # name -> [launches, sum, max]
+    for f in glob.glob(os.path.join(OUT, f"{tag}_{ctr}", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != ctr:
+                continue
+            name = re.sub(r"^void agp::", "", r["Kernel_Name"])
+            name = re.sub(r"\(.*$", "", name)
+            a = acc.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+            a[2] = max(a[2], float(r["Counter_Value"]))
+    return acc
+
+
+def parse():
+    res = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- " + " ".join(CMD[:1] + ["bench.py"] + CMD[2:]),
+           "units": "counter values are KB; corrected bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024", "kernels": {}}
+    f, w = _read("bench", "FETCH_SIZE"), _read("bench", "WRITE_SIZE")
+    for k in f:
+        if k not in w or not k.startswith("k_"):
+            continue
+        fa, wa = f[k][1] / f[k][0], w[k][1] / w[k][0]
+        res["kernels"][k] = {"FETCH_SIZE": {"launches": f[k][0], "avg_counter_KB": round(fa, 1)},
+                             "WRITE_SIZE": {"launches": w[k][0], "avg_counter_KB": round(wa, 1)},
+                             "hbm_bytes_per_launch_corrected": int((2 * fa + wa) * 1024)}
+    cf, cw = _read("cal", "FETCH_SIZE"), _read("cal", "WRITE_SIZE")
+    res["calibration"] = {"note": "fill of 1e6x32 f64 (256.0 MB written) and gemv over it (256.0 MB read)",
+                          "WRITE_SIZE_KB_largest_launch": {k: round(v[2], 1) for k, v in cw.items() if v[2] > 1e5},
+                          "FETCH_SIZE_KB_largest_launch": {k: round(v[2], 1) for k, v in cf.items() if v[2] > 5e4}}
+    with open(os.path.join(OUT, "r01_pmc_hbm_bytes.json"), "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps({k: v["hbm_bytes_per_launch_corrected"] for k, v in res["kernels"].items()}, indent=1))
+    print(json.dumps(res["calibration"], indent=1))
+
+
+if __name__ == "__main__":
+    {"collect": collect, "parse": parse}[sys.argv[1]]()

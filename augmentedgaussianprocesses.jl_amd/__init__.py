@@ -43,3 +43,4 @@ from .svgp import (  # noqa: F401
     train_,
 )
 from .capi import AGPError  # noqa: F401
+from .inducingpoints import KmeansAlg, RandomSubset, inducingpoints  # noqa: F401

@@ -13,6 +13,7 @@
 
 #include "agp_cavi.h"
 #include "agp_hyper.h"
+#include "agp_kmeans.h"
 #include "agp_linalg.h"
 
 using namespace agp;
@@ -1837,6 +1838,105 @@ static agp_status bb_diag_bench(agp_ctx* ctx, int blocks, int reps, double* us) 
   return AGP_OK;
 }
 
+
+// ---- inducing-point selection: nearest-centre assignment and Lloyd iterations (agp_kmeans.h) --------------------------
+template <typename T>
+static agp_status km_assign(agp_ctx* ctx, const T* x, int64_t n, int64_t ldx, int64_t D, const T* c, int64_t ldc, int64_t m,
+                            T* cn, int32_t* labels, T* mind) {
+  const int64_t mp = rup64(m);
+  const int Dp = (int)((D + 15) / 16 * 16);
+  hipLaunchKernelGGL((k_km_cnorm<T>), grid1(mp), dim3(256), 0, ctx->stream, c, ldc, m, mp, D, cn);
+  const size_t sh = sizeof(T) * (2 * TILE * (Dp + 2) + 4 * TILE) + sizeof(int) * 2 * TILE;
+  if (sh > 64 * 1024)  // gfx950 has 160 KB of LDS per workgroup; more than 64 KB of dynamic LDS has to be requested
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_km_assign<T>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+  hipLaunchKernelGGL((k_km_assign<T>), dim3((unsigned)((n + TILE - 1) / TILE)), dim3(NTHREADS), sh, ctx->stream, x, ldx, n, D,
+                     Dp, c, ldc, m, mp, (const T*)cn, labels, mind);
+  LAUNCHCHK(ctx);
+  return AGP_OK;
+}
+
+template <typename T>
+static agp_status km_objective(agp_ctx* ctx, const T* mind, int64_t n, double* part, double* host) {
+  const int nb = 256;
+  hipLaunchKernelGGL((k_km_sum_partial<T>), dim3(nb), dim3(256), 0, ctx->stream, mind, n, part);
+  hipLaunchKernelGGL(k_km_sum_final, dim3(1), dim3(256), 0, ctx->stream, (const double*)part, nb, part + nb);
+  LAUNCHCHK(ctx);
+  HIPCHK(ctx, hipMemcpyAsync(host, part + nb, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return AGP_OK;
+}
+
+template <typename T>
+static agp_status bb_nearest(agp_ctx* ctx, const void* x, int64_t n, int64_t ldx, int64_t D, const void* c, int64_t ldc,
+                             int64_t m, int32_t* labels, void* mind) {
+  if (!x || !c || n <= 0 || m <= 0 || D <= 0 || D > KM_MAXD || ldx < D || ldc < D || (!labels && !mind)) return AGP_ERR_INVALID;
+  T* cn = nullptr;
+  int32_t* lab = labels;
+  T* md = (T*)mind;
+  AGPCHK(dmalloc(ctx, &cn, rup64(m)));
+  if (!lab) AGPCHK(dmalloc(ctx, &lab, n));
+  if (!md) AGPCHK(dmalloc(ctx, &md, n));
+  agp_status st = km_assign<T>(ctx, (const T*)x, n, ldx, D, (const T*)c, ldc, m, cn, lab, md);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(cn);
+  if (!labels) (void)hipFree(lab);
+  if (!mind) (void)hipFree(md);
+  return st;
+}
+
+template <typename T>
+static agp_status bb_kmeans(agp_ctx* ctx, const void* xv, int64_t n, int64_t ldx, int64_t D, void* cv, int64_t ldc,
+                            int64_t m, int max_iter, double tol, int32_t* labels_out, int32_t* counts_out, int32_t* iters,
+                            double* objective, int32_t* converged) {
+  if (!xv || !cv || n <= 0 || m <= 0 || m > n || D <= 0 || D > KM_MAXD || ldx < D || ldc < D || max_iter < 0)
+    return AGP_ERR_INVALID;
+  const T* x = (const T*)xv;
+  T* c = (T*)cv;
+  const int64_t mp = rup64(m);
+  const int Dp = (int)((D + 15) / 16 * 16);
+  const int nchunks = (int)((n + KM_CHUNK - 1) / KM_CHUNK);
+  T *cn = nullptr, *mind = nullptr, *part = nullptr;
+  double* red = nullptr;
+  int32_t* lab = labels_out;
+  AGPCHK(dmalloc(ctx, &cn, mp));
+  AGPCHK(dmalloc(ctx, &mind, n));
+  AGPCHK(dmalloc(ctx, &part, (int64_t)nchunks * mp * (Dp + 16)));
+  AGPCHK(dmalloc(ctx, &red, 512));
+  if (!lab) AGPCHK(dmalloc(ctx, &lab, n));
+  agp_status st = AGP_OK;
+  double obj = 0.0, prev = 0.0;
+  int it = 0, conv = 0;
+  // Clustering.kmeans!: assignments for the seeds, then { centres <- cluster means ; assignments ; |change of cost| < tol }
+  st = km_assign<T>(ctx, x, n, ldx, D, c, ldc, m, cn, lab, mind);
+  if (st == AGP_OK) st = km_objective<T>(ctx, mind, n, red, &obj);
+  while (st == AGP_OK && it < max_iter && !conv) {
+    ++it;
+    hipLaunchKernelGGL((k_km_sums<T>), dim3((unsigned)(mp / TILE), (unsigned)nchunks), dim3(NTHREADS), 0, ctx->stream, x, ldx, n,
+                       D, Dp, (const int32_t*)lab, mp, part);
+    hipLaunchKernelGGL((k_km_finish<T>), grid1(m * D), dim3(256), 0, ctx->stream, (const T*)part, nchunks, mp, Dp, m, D, c, ldc,
+                       counts_out);
+    if (hipGetLastError() != hipSuccess) {
+      st = AGP_ERR_HIP;
+      break;
+    }
+    st = km_assign<T>(ctx, x, n, ldx, D, c, ldc, m, cn, lab, mind);
+    prev = obj;
+    if (st == AGP_OK) st = km_objective<T>(ctx, mind, n, red, &obj);
+    if (m == 1 || std::abs(obj - prev) < tol) conv = 1;
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(cn);
+  (void)hipFree(mind);
+  (void)hipFree(part);
+  (void)hipFree(red);
+  if (!labels_out) (void)hipFree(lab);
+  if (iters) *iters = it;
+  if (objective) *objective = obj;
+  if (converged) *converged = conv;
+  return st;
+}
+
 #define DISPATCH(dtype, call_f64, call_f32)        \
   do {                                             \
     if ((dtype) == AGP_F64) return call_f64;       \
@@ -1880,6 +1980,24 @@ agp_status agp_mfma_peak(agp_ctx* ctx, int32_t dtype, double* tflops_host) {
 }
 
 // development micro-benchmark (not part of include/agp_hip.h): microseconds per 64x64 diagonal-tile factorisation
+agp_status agp_nearest_center(agp_ctx* ctx, int32_t dtype, const void* x, int64_t n, int64_t ldx, int64_t D,
+                              const void* centers, int64_t ldc, int64_t m, int32_t* labels_out, void* mind_out) {
+  if (!ctx) return AGP_ERR_INVALID;
+  DISPATCH(dtype, bb_nearest<double>(ctx, x, n, ldx, D, centers, ldc, m, labels_out, mind_out),
+           bb_nearest<float>(ctx, x, n, ldx, D, centers, ldc, m, labels_out, mind_out));
+}
+
+agp_status agp_kmeans(agp_ctx* ctx, int32_t dtype, const void* x, int64_t n, int64_t ldx, int64_t D, void* centers,
+                      int64_t ldc, int64_t m, int32_t max_iter, double tol, int32_t* labels_out, int32_t* counts_out,
+                      int32_t* iters_host, double* objective_host, int32_t* converged_host) {
+  if (!ctx) return AGP_ERR_INVALID;
+  DISPATCH(dtype,
+           bb_kmeans<double>(ctx, x, n, ldx, D, centers, ldc, m, max_iter, tol, labels_out, counts_out, iters_host,
+                             objective_host, converged_host),
+           bb_kmeans<float>(ctx, x, n, ldx, D, centers, ldc, m, max_iter, tol, labels_out, counts_out, iters_host,
+                            objective_host, converged_host));
+}
+
 agp_status agp_dev_diag_bench(agp_ctx* ctx, int32_t dtype, int32_t variant, int32_t blocks, int32_t reps, double* us) {
   if (!ctx || !us) return AGP_ERR_INVALID;
   if (dtype == AGP_F64) return variant ? bb_diag_bench<double, 1>(ctx, blocks, reps, us) : bb_diag_bench<double, 0>(ctx, blocks, reps, us);

@@ -137,6 +137,22 @@ agp_status agp_spd_inverse(agp_ctx* ctx, int32_t dtype, const void* a, int64_t l
 /* X = B / cholesky(A)  (Knm / K, two triangular solves in the reference, latentgp.jl:211); b is r x n */
 agp_status agp_solve_right_spd(agp_ctx* ctx, int32_t dtype, const void* a, int64_t lda, int64_t n, const void* b,
                                int64_t ldb, int64_t r, void* x, int64_t ldx, int32_t* info_host);
+/* ---- inducing-point selection (the step before the path) ----------------------------------------------------------------
+ * `inducingpoints(KmeansAlg(m), X)` is how every reference example / test picks Z (test/testingtools.jl:66,
+ * docs/examples/gpclassification.jl:47, docs/src/userguide.md:140-143).  The algorithm is third party and unvendored
+ * (InducingPoints.jl kmeans_ip = AFK-MC2 seeding + Clustering.kmeans!(X, C; tol)); the deterministic part -- Lloyd
+ * iterations from given seeds -- runs here, the random seeding stays with the caller (it needs the caller's RNG).
+ *
+ * agp_nearest_center: labels_out[i] = argmin_j ||x_i - c_j||^2 (ties -> smaller j), mind_out[i] = that squared distance
+ *   (either output may be NULL); device pointers, row-major, x is n x D (ldx), centers m x D (ldc); D <= 128.
+ * agp_kmeans: centers (in: seeds, out: result) ; Clustering.kmeans! control flow: assign, then repeat { centres <- cluster
+ *   means (an emptied cluster keeps its centre) ; assign ; stop when |cost change| < tol } at most max_iter times.
+ *   labels_out / counts_out: nullable device int32[n] / int32[m] of the final assignment.  Synchronises. */
+agp_status agp_nearest_center(agp_ctx* ctx, int32_t dtype, const void* x, int64_t n, int64_t ldx, int64_t D,
+                              const void* centers, int64_t ldc, int64_t m, int32_t* labels_out, void* mind_out);
+agp_status agp_kmeans(agp_ctx* ctx, int32_t dtype, const void* x, int64_t n, int64_t ldx, int64_t D, void* centers,
+                      int64_t ldc, int64_t m, int32_t max_iter, double tol, int32_t* labels_out, int32_t* counts_out,
+                      int32_t* iters_host, double* objective_host, int32_t* converged_host);
 /* MFMA microbenchmark: TFLOP/s of back-to-back v_mfma_{f64,f32}_16x16x4 (roofline ceiling measurement) */
 agp_status agp_mfma_peak(agp_ctx* ctx, int32_t dtype, double* tflops_host);
 

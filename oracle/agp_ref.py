@@ -1307,3 +1307,78 @@ def hyper_gradient(model, X, y, latent_k, rho):
     v1, s1, z1 = back(G_Knm, X, Z)
     v2, s2, z2 = back(G_K, Z, Z)
     return {"dvariance": v1 + v2 + np.sum(G_kdiag), "dscale": s1 + s2, "dZ": z1 + 2.0 * z2}
+
+
+# --------------------------------------------------------------------------------------------
+# Inducing-point selection: inducingpoints(KmeansAlg(m), X)  (call sites test/testingtools.jl:66,
+# test/models/MOSVGP.jl:14, docs/examples/gpclassification.jl:47, docs/src/userguide.md:140-143).
+# The algorithm is THIRD PARTY and unvendored: InducingPoints.jl (re-exported, src/AugmentedGaussianProcesses.jl:33; no
+# pinned version) `kmeans_ip` = `kmeans_seeding` (the AFK-MC2 seeding of Bachem et al., "Fast and Provably Good Seedings for
+# k-Means", NeurIPS 2016, with chain length nMarkov = 10) followed by Clustering.jl `kmeans!(X, C; tol = 1e-3)` (Lloyd).
+# Restated from the published algorithms; parity unpinned (no reference test pins centres: they are random).
+# --------------------------------------------------------------------------------------------
+def nearest_center(X, C):
+    """argmin_j ||x_i - c_j||^2 (ties -> smaller j) and the squared distance, in the GEMM form the device uses."""
+    X, C = np.asarray(X, dtype=np.float64), np.asarray(C, dtype=np.float64)
+    d = np.sum(C * C, axis=1)[None, :] - 2.0 * (X @ C.T)
+    lab = np.argmin(d, axis=1)
+    mind = np.maximum(np.sum(X * X, axis=1) + d[np.arange(len(X)), lab], 0.0)
+    return lab.astype(np.int32), mind
+
+
+def kmeans_seeding(X, nC, n_markov, rng):
+    """AFK-MC2 seeding as InducingPoints.jl's kmeans_seeding runs it: proposal q(x) = d(x, c1)^2 / (2 sum d^2) + 1/(2N);
+    every further centre is the end of a length-n_markov Metropolis chain that accepts y over x when
+    d(y, C)^2 / d(x, C)^2 > u.  Draw order (shared with the host mirror so that both see the same randomness):
+    first index, then all proposal indices, then all uniforms."""
+    X = np.asarray(X, dtype=np.float64)
+    N = len(X)
+    first = int(rng.integers(N))
+    q = np.sum((X - X[first]) ** 2, axis=1)
+    q = q / np.sum(q) / 2.0 + 1.0 / (2.0 * N)
+    q = q / np.sum(q)
+    prop = rng.choice(N, size=(max(nC - 1, 0), n_markov), p=q)
+    u = rng.random((max(nC - 1, 0), max(n_markov - 1, 0)))
+    return seeding_chains(X[first], X[prop.ravel()].reshape(prop.shape + (X.shape[1],)), u)
+
+
+def seeding_chains(x_first, cand, u):
+    """the sequential part of kmeans_seeding on pre-drawn candidates cand[i, j] (point j of chain i) and uniforms u[i, j-1]"""
+    C = [np.asarray(x_first, dtype=np.float64)]
+    for i in range(cand.shape[0]):
+        Cm = np.stack(C)
+        x = cand[i, 0]
+        mind = np.min(np.sum((Cm - x) ** 2, axis=1))
+        for j in range(1, cand.shape[1]):
+            y = cand[i, j]
+            dist = np.min(np.sum((Cm - y) ** 2, axis=1))
+            if dist > u[i, j - 1] * mind:  # dist / mindist > rand(), written without the division (mindist may be 0)
+                x, mind = y, dist
+        C.append(np.asarray(x, dtype=np.float64))
+    return np.stack(C)
+
+
+def kmeans_lloyd(X, C0, tol=1e-3, maxiter=100):
+    """Clustering.kmeans! control flow: assign ; repeat { centres <- cluster means ; assign ; stop when the cost changed by
+    less than tol (absolute) }.  A cluster that lost all its points keeps its centre (Clustering.jl re-seeds it at random;
+    not reproduced).  Returns (centres, labels, iterations, cost, converged)."""
+    X = np.asarray(X, dtype=np.float64)
+    C = np.array(C0, dtype=np.float64)
+    lab, mind = nearest_center(X, C)
+    obj = float(np.sum(mind))
+    it, conv = 0, False
+    while it < maxiter and not conv:
+        it += 1
+        for j in range(len(C)):
+            msk = lab == j
+            if np.any(msk):
+                C[j] = X[msk].mean(axis=0)
+        lab, mind = nearest_center(X, C)
+        prev, obj = obj, float(np.sum(mind))
+        conv = len(C) == 1 or abs(obj - prev) < tol
+    return C, lab, it, obj, conv
+
+
+def kmeans_inducingpoints(X, m, rng, n_markov=10, tol=1e-3):
+    """inducingpoints(KmeansAlg(m; nMarkov = 10, tol = 1e-3), X)"""
+    return kmeans_lloyd(X, kmeans_seeding(X, m, n_markov, rng), tol)[0]

@@ -430,3 +430,32 @@ def test_kat7_hyper_gradient_vs_finite_differences(likname, kind):
         Zm[a, d] -= h
         fd = (obj(sc0, v0, Zp) - obj(sc0, v0, Zm)) / (2 * h)
         assert g["dZ"][a, d] == pytest.approx(fd, rel=5e-6, abs=1e-6)
+
+
+def test_kmeans_restatement_properties():
+    """inducingpoints(KmeansAlg(m), X) restated (InducingPoints.jl / Clustering.jl are unvendored): GEMM-form nearest centre
+    == brute force, Lloyd cost never increases, the result is a fixed point (centres = cluster means), separated blobs are
+    recovered, the seeding returns data points and is reproducible."""
+    rng = np.random.default_rng(11)
+    X = rng.random((500, 3))
+    Cc = rng.random((17, 3))
+    lab, mind = R.nearest_center(X, Cc)
+    d = ((X[:, None, :] - Cc[None, :, :]) ** 2).sum(-1)
+    assert np.array_equal(lab, d.argmin(1)) and np.allclose(mind, d.min(1), rtol=1e-12, atol=1e-14)
+    means = np.array([[0.0, 0.0], [5.0, 5.0], [0.0, 6.0], [7.0, -1.0]])
+    Xb = np.concatenate([mu + 0.2 * rng.standard_normal((80, 2)) for mu in means])
+    seeds = R.kmeans_seeding(Xb, 4, 10, np.random.default_rng(3))
+    assert all(any(np.array_equal(s, x) for x in Xb) for s in seeds)
+    assert np.array_equal(seeds, R.kmeans_seeding(Xb, 4, 10, np.random.default_rng(3)))
+    costs = []
+    Cc = seeds.copy()
+    for _ in range(6):
+        lab, mind = R.nearest_center(Xb, Cc)
+        costs.append(mind.sum())
+        Cc = np.stack([Xb[lab == j].mean(0) if np.any(lab == j) else Cc[j] for j in range(4)])
+    assert np.all(np.diff(costs) <= 1e-12)
+    Cf, labf, it, obj, conv = R.kmeans_lloyd(Xb, seeds, tol=1e-3)
+    assert conv and it <= 20
+    for j in range(4):
+        assert np.allclose(Cf[j], Xb[labf == j].mean(0), atol=1e-12)
+    assert max(np.min(np.linalg.norm(Cf - mu, axis=1)) for mu in means) < 0.1

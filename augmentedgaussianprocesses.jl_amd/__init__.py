@@ -44,3 +44,12 @@ from .svgp import (  # noqa: F401
 )
 from .capi import AGPError  # noqa: F401
 from .inducingpoints import KmeansAlg, RandomSubset, inducingpoints  # noqa: F401
+from .online import (  # noqa: F401
+    OIPS,
+    OnlineSVGP,
+    online_objective,
+    online_predict_f,
+    online_predict_y,
+    online_proba_y,
+    train_online,
+)

@@ -113,6 +113,10 @@ SYMBOLS = {
     "agp_svgp_proba_y": (_I32, [_VP, _VP, _I64, _I64, _PDBL, _PDBL, _I32, _VP, _VP]),
     "agp_nearest_center": (_I32, [_VP, _I32, _VP, _I64, _I64, _I64, _VP, _I64, _I64, _VP, _VP]),
     "agp_kmeans": (_I32, [_VP, _I32, _VP, _I64, _I64, _I64, _VP, _I64, _I64, _I32, _DBL, _VP, _VP, _PI32, _PDBL, _PI32]),
+    "agp_svgp_online_snapshot": (_I32, [_VP, _I32, _VP, _I64, _VP, _PDBL]),
+    "agp_svgp_set_online_prior": (_I32, [_VP, _I32, _VP, _I64, _I64, _VP, _I64, _VP, _DBL]),
+    "agp_svgp_adopt_local": (_I32, [_VP, _VP]),
+    "agp_svgp_online_first_step": (_I32, [_VP, _VP, _VP, _I64, _VP, _I64]),
     "agp_svgp_set_quadrature": (_I32, [_VP, _PDBL, _PDBL, _I32]),
     "agp_svgp_get_lik_param": (_I32, [_VP, _PDBL]),
     "agp_svgp_set_lik_param": (_I32, [_VP, _DBL]),

@@ -172,6 +172,10 @@ struct SvgpBase {
   virtual agp_status proba_y(const void* xt, int64_t ldx, int64_t nt, const double* nodes, const double* weights,
                              int nn, void* o0, void* o1) = 0;
   virtual agp_status set_quadrature(const double* nodes, const double* weights, int nn) = 0;
+  virtual agp_status set_online_prior(int l, const void* za, int64_t ldza, int64_t ma, const void* invDa, int64_t ldi,
+                                      const void* peta1, double prevLa) = 0;
+  virtual agp_status online_snapshot(int l, void* invDa_out, int64_t ldi, void* eta1_out, double* prevLa_host) = 0;
+  virtual agp_status adopt_local(SvgpBase* src) = 0;
   virtual agp_status get_lik_param(double* out) = 0;
   virtual agp_status set_lik_param(double v) = 0;
   int64_t n_opt = 1;  // RobbinsMonro counter (optimisers.jl:12)
@@ -261,6 +265,13 @@ struct Svgp : SvgpBase {
     int la_state = 0;
     bool xa_valid = false;
     double half_logdetK = 0.0;
+    // OnlineSVGP streaming prior (onlinetraining.jl:170-180, latentgp.jl:217-237): the previous posterior enters through
+    // Z_a, invD_a = Sigma_a^-1 - K_a^-1, eta1_a ; kappa_a = K_ab K^-1, K~_a = K_a - kappa_a K_ab'
+    bool on = false, on_dirty = false, on_first = false;
+    int64_t ma = 0, map = 0;
+    T *Za = nullptr, *invDa = nullptr, *peta1 = nullptr, *kappa_a = nullptr, *Kab = nullptr, *Kta = nullptr, *onT = nullptr,
+      *onQ = nullptr, *kinv_mu0_on = nullptr, *Kinv_on = nullptr, *ov0 = nullptr, *ov1 = nullptr;
+    double prevLa = 0.0;
   };
   std::vector<Latent> lat;
   int64_t m = 0, mp = 0, D = 0, Bmax = 0, Bp = 0;  // Bp = padded max batch
@@ -446,6 +457,7 @@ struct Svgp : SvgpBase {
     for (double* p : hds)
       if (p) dfree(p);
     for (auto& g : lat) {
+      free_online(g);
       if (g.z_am) dfree(g.z_am);
       if (g.z_av) dfree(g.z_av);
     }
@@ -578,6 +590,169 @@ struct Svgp : SvgpBase {
         return AGP_ERR_NOT_POSDEF;
       }
     }
+    for (auto& g : lat)
+      if (g.on && (g.on_dirty || any)) AGPCHK(online_refresh(g));
+    return AGP_OK;
+  }
+
+  // ---- OnlineSVGP streaming prior ------------------------------------------------------------------------------------
+  void free_online(Latent& g) {
+    T* ps[] = {g.Za, g.invDa, g.peta1, g.kappa_a, g.Kab, g.Kta, g.onT, g.onQ, g.kinv_mu0_on, g.Kinv_on, g.ov0, g.ov1};
+    for (T* p : ps)
+      if (p) dfree(p);
+    g.Za = g.invDa = g.peta1 = g.kappa_a = g.Kab = g.Kta = g.onT = g.onQ = g.kinv_mu0_on = g.Kinv_on = g.ov0 = g.ov1 = nullptr;
+    g.on = false;
+  }
+
+  agp_status set_online_prior(int l, const void* za, int64_t ldza, int64_t ma, const void* invDa, int64_t ldi,
+                              const void* peta1, double prevLa) override {
+    if (l < 0 || l >= nl || ma <= 0 || !invDa || !peta1 || ldi < ma || (za && ldza < D)) return AGP_ERR_INVALID;
+    if (desc.stochastic) {  // set_rho!(model, ...) in the stochastic branch of onlinetraining.jl:52 references an undefined name
+      ctx->err = "OnlineSVGP runs with AnalyticVI() (full batches); the reference's stochastic branch is broken";
+      return AGP_ERR_UNSUPPORTED;
+    }
+    if (!za && ma != m) return AGP_ERR_INVALID;  // first batch: kappa_a = I needs the sizes to agree
+    Latent& g = lat[l];
+    free_online(g);
+    g.ma = ma;
+    g.map = rup64(ma);
+    const int64_t map = g.map;
+    AGPCHK(dmalloc(ctx, &g.invDa, map * map));
+    AGPCHK(dmalloc(ctx, &g.peta1, map));
+    AGPCHK(dmalloc(ctx, &g.kappa_a, map * mp));
+    AGPCHK(dmalloc(ctx, &g.Kab, map * mp));
+    AGPCHK(dmalloc(ctx, &g.Kta, map * map));
+    AGPCHK(dmalloc(ctx, &g.onT, map * mp));
+    AGPCHK(dmalloc(ctx, &g.onQ, std::max(map * map, mp * mp)));
+    AGPCHK(dmalloc(ctx, &g.kinv_mu0_on, mp));
+    AGPCHK(dmalloc(ctx, &g.Kinv_on, mp * mp));
+    AGPCHK(dmalloc(ctx, &g.ov0, map));
+    AGPCHK(dmalloc(ctx, &g.ov1, map));
+    hipLaunchKernelGGL((k_copy2d_zero<T>), grid2(map, map), blk2, 0, st(), (const T*)invDa, ldi, ma, ma, g.invDa, map, map, map);
+    HIPCHK(ctx, hipMemsetAsync(g.peta1, 0, sizeof(T) * map, st()));
+    HIPCHK(ctx, hipMemcpyAsync(g.peta1, peta1, sizeof(T) * ma, hipMemcpyDeviceToDevice, st()));
+    if (za) {
+      AGPCHK(dmalloc(ctx, &g.Za, ma * D));
+      HIPCHK(ctx, hipMemcpy2DAsync(g.Za, sizeof(T) * D, za, sizeof(T) * ldza, sizeof(T) * D, ma, hipMemcpyDeviceToDevice, st()));
+    }
+    LAUNCHCHK(ctx);
+    g.on_first = za == nullptr;
+    g.prevLa = prevLa;
+    g.on = true;
+    g.on_dirty = true;
+    return AGP_OK;
+  }
+
+  agp_status online_refresh(Latent& g) {
+    const int64_t map = g.map, ma = g.ma;
+    if (g.on_first) {  // compute_kappa with empty Z_a (latentgp.jl:220-223): K_ab = 0, kappa_a = I, K~_a = 0
+      HIPCHK(ctx, hipMemsetAsync(g.Kab, 0, sizeof(T) * map * mp, st()));
+      HIPCHK(ctx, hipMemsetAsync(g.kappa_a, 0, sizeof(T) * map * mp, st()));
+      HIPCHK(ctx, hipMemsetAsync(g.Kta, 0, sizeof(T) * map * map, st()));
+      hipLaunchKernelGGL((k_add_diag<T>), grid1(ma), dim3(256), 0, st(), g.kappa_a, mp, ma, T(1));
+    } else {
+      dim3 gk((unsigned)(mp / TILE), (unsigned)(map / TILE));
+      hipLaunchKernelGGL((k_kernelmatrix<T>), gk, dim3(NTHREADS), 0, st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
+                         (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Kab, mp, map, mp, 0, T(0),
+                         (const T*)nullptr, (T*)nullptr, (int64_t)0);
+      LAUNCHCHK(ctx);
+      AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.Kab, mp, g.Kinv, mp, map, mp, mp, 0, g.kappa_a, mp, nullptr, 0, nullptr, nullptr,
+                                    nullptr, 0)));
+      dim3 ga((unsigned)(map / TILE), (unsigned)(map / TILE));
+      hipLaunchKernelGGL((k_kernelmatrix<T>), ga, dim3(NTHREADS), 0, st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
+                         (const T*)g.Za, D, ma, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Kta, map, map, map, 0,
+                         T(0), (const T*)nullptr, (T*)nullptr, (int64_t)0);
+      hipLaunchKernelGGL((k_add_diag<T>), grid1(ma), dim3(256), 0, st(), g.Kta, map, ma, (T)jitter);
+      LAUNCHCHK(ctx);
+      AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.kappa_a, mp, g.Kab, mp, map, map, mp, 0, g.onQ, map, nullptr, 0, nullptr, nullptr,
+                                    nullptr, 0)));
+      hipLaunchKernelGGL((k_sub2d<T>), grid2(ma, ma), blk2, 0, st(), g.Kta, (const T*)g.onQ, map, ma);
+    }
+    LAUNCHCHK(ctx);
+    // eta1 target gains kappa_a' eta1_a ; -eta2 target gains kappa_a' invD_a kappa_a / 2  (analyticVI.jl:197-201): folded into
+    // the K^-1 mu0 and K^-1 operands of the step kernels
+    hipLaunchKernelGGL((k_gemv_cols<T>), grid1(mp), dim3(256), 0, st(), (const T*)g.kappa_a, mp, ma, mp, (const T*)g.peta1,
+                       g.kinv_mu0_on);
+    hipLaunchKernelGGL((k_axpby<T>), grid1(mp), dim3(256), 0, st(), mp, T(1), (const T*)g.kinv_mu0_on, T(1),
+                       (const T*)g.kinv_mu0, g.kinv_mu0_on);
+    {
+      dim3 g1((unsigned)(mp / TILE), (unsigned)(map / TILE));  // T = invD_a kappa_a  (invD_a symmetric)
+      hipLaunchKernelGGL((k_gemm_tn<T, 1>), g1, dim3(NTHREADS), 0, st(), (const T*)g.invDa, map, (const T*)g.kappa_a, mp, map,
+                         g.onT, mp);
+      dim3 g2((unsigned)(mp / TILE), (unsigned)(mp / TILE));   // kappa_a' T
+      hipLaunchKernelGGL((k_gemm_tn<T, 1>), g2, dim3(NTHREADS), 0, st(), (const T*)g.kappa_a, mp, (const T*)g.onT, mp, map,
+                         g.onQ, mp);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(g.Kinv_on, g.Kinv, sizeof(T) * mp * mp, hipMemcpyDeviceToDevice, st()));
+    hipLaunchKernelGGL((k_add_sym<T>), grid2(m, m), blk2, 0, st(), (const T*)g.Kinv, (const T*)g.onQ, mp, m, g.Kinv_on);
+    LAUNCHCHK(ctx);
+    g.on_dirty = false;
+    return AGP_OK;
+  }
+
+  // (invD_a, eta1_a, L_a) of save_old_gp! (onlinetraining.jl:170-180) from the current posterior
+  agp_status online_snapshot(int l, void* invDa_out, int64_t ldi, void* eta1_out, double* prevLa_host) override {
+    if (l < 0 || l >= nl || !invDa_out || !eta1_out || !prevLa_host || ldi < m) return AGP_ERR_INVALID;
+    Latent& g = lat[l];
+    AGPCHK(refresh_K());
+    AGPCHK(materialize(g));
+    hipLaunchKernelGGL((k_axpby<T>), grid1(mp * mp), dim3(256), 0, st(), mp * mp, T(-2), (const T*)g.eta2, T(-1),
+                       (const T*)g.Kinv, Tw);
+    LAUNCHCHK(ctx);
+    HIPCHK(ctx, hipMemcpy2DAsync(invDa_out, sizeof(T) * ldi, Tw, sizeof(T) * mp, sizeof(T) * m, m, hipMemcpyDeviceToDevice,
+                                 st()));
+    HIPCHK(ctx, hipMemcpyAsync(eta1_out, g.eta1, sizeof(T) * m, hipMemcpyDeviceToDevice, st()));
+    hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.DgA, m, scal_dev + 2);
+    hipLaunchKernelGGL((k_dot<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.mu, (const T*)g.eta1, m, scal_dev + 3);
+    LAUNCHCHK(ctx);
+    double h[2];
+    HIPCHK(ctx, hipMemcpyAsync(h, scal_dev + 2, sizeof(double) * 2, hipMemcpyDeviceToHost, st()));
+    HIPCHK(ctx, hipStreamSynchronize(st()));
+    // (-logdet Sigma + logdet K - mu'eta1)/2 with logdet Sigma = -2 sum log diag chol(-2 eta2)
+    *prevLa_host = 0.5 * (2.0 * h[0] + 2.0 * g.half_logdetK - h[1]);
+    return AGP_OK;
+  }
+
+  // local variables and expectation gradients of `src` (same likelihood, same batch capacity) become this handle's:
+  // first iteration of a new streaming batch (onlinetraining.jl:78-104: local update under the OLD inducing points)
+  agp_status adopt_local(SvgpBase* srcb) override {
+    Svgp<T>* src = dynamic_cast<Svgp<T>*>(srcb);
+    if (!src || src == this || src->nl != nl || src->Bp != Bp || src->lp.kind != lp.kind ||
+        src->ctx->device != ctx->device || src->ctx->stream != ctx->stream)
+      return AGP_ERR_INVALID;  // both handles must enqueue on the same stream: the copies are ordered by it
+    AGPCHK(src->lsm_finish());
+    const size_t nb = sizeof(T) * nl * Bp;
+    T* d[] = {cbuf, theta, gamma, rbuf, wbuf};
+    T* s0[] = {src->cbuf, src->theta, src->gamma, src->rbuf, src->wbuf};
+    for (int i = 0; i < 5; ++i) HIPCHK(ctx, hipMemcpyAsync(d[i], s0[i], nb, hipMemcpyDeviceToDevice, st()));
+    HIPCHK(ctx, hipMemcpyAsync(alpha, src->alpha, sizeof(T) * Bp, hipMemcpyDeviceToDevice, st()));
+    HIPCHK(ctx, hipMemcpyAsync(lam_dev, src->lam_dev, sizeof(T), hipMemcpyDeviceToDevice, st()));
+    return AGP_OK;
+  }
+
+  // extraKL (KLdivergences.jl:30-54)
+  agp_status extra_kl(Latent& g, double* out) {
+    const int64_t map = g.map, ma = g.ma;
+    AGPCHK(materialize(g));
+    hipLaunchKernelGGL((k_gemv_rows<T>), grid1(ma * 64), dim3(256), 0, st(), (const T*)g.kappa_a, mp, ma, mp, (const T*)g.mu,
+                       g.ov0);                                                     // kappa_a mu
+    hipLaunchKernelGGL((k_frob_dot<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.invDa, (const T*)g.Kta, map, ma,
+                       scal_dev + 48);                                           // tr(invD_a K~_a)
+    LAUNCHCHK(ctx);
+    AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.kappa_a, mp, g.Sigma, mp, map, mp, mp, 0, g.onT, mp, nullptr, 0, nullptr, nullptr,
+                                  nullptr, 0)));                                 // kappa_a Sigma
+    AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.onT, mp, g.kappa_a, mp, map, map, mp, 0, g.onQ, map, nullptr, 0, nullptr, nullptr,
+                                  nullptr, 0)));                                 // (kappa_a Sigma) kappa_a'
+    hipLaunchKernelGGL((k_frob_dot<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.invDa, (const T*)g.onQ, map, ma,
+                       scal_dev + 49);
+    hipLaunchKernelGGL((k_dot<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.peta1, (const T*)g.ov0, ma, scal_dev + 50);
+    hipLaunchKernelGGL((k_symv<T>), grid1(ma * 64), dim3(256), 0, st(), (const T*)g.invDa, map, ma, (const T*)g.ov0, g.ov1);
+    hipLaunchKernelGGL((k_dot<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.ov0, (const T*)g.ov1, ma, scal_dev + 51);
+    LAUNCHCHK(ctx);
+    double h[4];
+    HIPCHK(ctx, hipMemcpyAsync(h, scal_dev + 48, sizeof(double) * 4, hipMemcpyDeviceToHost, st()));
+    HIPCHK(ctx, hipStreamSynchronize(st()));
+    *out = g.prevLa - 0.5 * (h[0] + h[1]) + h[2] - 0.5 * h[3];
     return AGP_OK;
   }
 
@@ -1048,8 +1223,9 @@ struct Svgp : SvgpBase {
       T* sl = stats + l * (mp + mp * mp);
       if (fused) {
         hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, (int)(Bq / TILE), (const T*)cpart, mp,
-                           (const T*)nullptr, (const T*)g.kinv_mu0, g.eta1, lr, (T*)nullptr);
-        AGPCHK((syrk_tn<T, SY_ETA2>(ctx, g.kappa, mp, mp, Bq, wbuf + l * Bp, 0, g.La, mp, g.eta2, g.Kinv, mp, lr)));
+                           (const T*)nullptr, (const T*)(g.on ? g.kinv_mu0_on : g.kinv_mu0), g.eta1, lr, (T*)nullptr);
+        AGPCHK((syrk_tn<T, SY_ETA2>(ctx, g.kappa, mp, mp, Bq, wbuf + l * Bp, 0, g.La, mp, g.eta2,
+                                    g.on ? g.Kinv_on : g.Kinv, mp, lr)));
       } else {
         hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, (int)(Bq / TILE), (const T*)cpart, mp,
                            (const T*)nullptr, (const T*)nullptr, (T*)nullptr, lr, sl);
@@ -1102,9 +1278,9 @@ struct Svgp : SvgpBase {
       if (!fused) {
         const T* sl = stats + l * (mp + mp * mp);
         hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, 0, (const T*)nullptr, (int64_t)0, sl,
-                           (const T*)g.kinv_mu0, g.eta1, lr, (T*)nullptr);
+                           (const T*)(g.on ? g.kinv_mu0_on : g.kinv_mu0), g.eta1, lr, (T*)nullptr);
         hipLaunchKernelGGL((k_eta2_from_stats<T>), grid1(mp * mp), dim3(256), 0, st(), sl + mp, mp, g.eta2,
-                           (const T*)g.Kinv, g.La, lr);
+                           (const T*)(g.on ? g.Kinv_on : g.Kinv), g.La, lr);
         LAUNCHCHK(ctx);
       }
       g.la_state = 0;  // La now holds the new -2*eta2 (unfactored); it is factored inside the next local phase
@@ -1256,6 +1432,11 @@ struct Svgp : SvgpBase {
       }
       const double logdetK = 2.0 * g.half_logdetK, logdetS = -2.0 * h[2];
       kl_gauss += 0.5 * (logdetK - logdetS + h[3] + h[4] - (double)m);
+      if (g.on) {
+        double ek = 0.0;
+        AGPCHK(extra_kl(g, &ek));
+        kl_gauss += ek;
+      }
     }
     *out = rho * e_data - kl_gauss - rho * kl_aug;
     return AGP_OK;
@@ -2181,6 +2362,41 @@ agp_status agp_svgp_predict_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t 
   HCHK(h);
   return h->impl->predict_y(xt, ldx, n_t, y_out);
 }
+agp_status agp_svgp_set_online_prior(agp_svgp* h, int32_t latent, const void* za, int64_t ldza, int64_t ma, const void* invDa,
+                                     int64_t ldi, const void* prev_eta1, double prevLa) {
+  HCHK(h);
+  return h->impl->set_online_prior(latent, za, ldza, ma, invDa, ldi, prev_eta1, prevLa);
+}
+agp_status agp_svgp_online_snapshot(agp_svgp* h, int32_t latent, void* invDa_out, int64_t ldi, void* eta1_out,
+                                    double* prevLa_host) {
+  HCHK(h);
+  return h->impl->online_snapshot(latent, invDa_out, ldi, eta1_out, prevLa_host);
+}
+agp_status agp_svgp_adopt_local(agp_svgp* dst, agp_svgp* src) {
+  HCHK(dst);
+  HCHK(src);
+  return dst->impl->adopt_local(src->impl);
+}
+agp_status agp_svgp_online_first_step(agp_svgp* h_new, agp_svgp* h_old, const void* x, int64_t ldx, const void* y,
+                                      int64_t B) {
+  HCHK(h_new);
+  HCHK(h_old);
+  SvgpBase *n = h_new->impl, *o = h_old->impl;
+  // local update of the new batch under the OLD inducing points and posterior (compute_old_matrices, onlinetraining.jl:80-89)
+  AGPCHK(o->step_local(x, ldx, y, nullptr, B, 1.0, true));
+  if (o->desc.lik.kind == AGP_LIK_LOGISTICSOFTMAX) {
+    for (int it = 0; it < 2; ++it) {
+      AGPCHK(o->lsm_gamma());
+      AGPCHK(o->lsm_alpha());
+    }
+  }
+  // kernel matrices of the new inducing points, then the online natural gradient with those expectation gradients (:93-104)
+  AGPCHK(n->step_local(x, ldx, y, nullptr, B, 1.0, true));
+  AGPCHK(n->adopt_local(o));
+  AGPCHK(n->step_stats(true));
+  return n->step_global(true);
+}
+
 agp_status agp_svgp_set_quadrature(agp_svgp* h, const double* gh_nodes_host, const double* gh_weights_host,
                                    int32_t n_nodes) {
   HCHK(h);

@@ -637,6 +637,44 @@ __global__ void k_copy2d_zero(const T* __restrict__ src, int64_t lds, int64_t rs
   dst[r * ldd + c] = (r < rs && c < cs) ? src[r * lds + c] : T(0);
 }
 
+// y[j] = sum_{i < rows} M[i][j] x[i]   (M' x ; one thread per column, fixed summation order)
+template <typename T>
+__global__ void k_gemv_cols(const T* __restrict__ M, int64_t ld, int64_t rows, int64_t cols, const T* __restrict__ x,
+                            T* __restrict__ y) {
+  int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  T s = T(0);
+  for (int64_t i = 0; i < rows; ++i) s += M[i * ld + j] * x[i];
+  y[j] = s;
+}
+
+// out = A + (B + B')/2 on the n x n block (ld shared)  -- Kinv + sym(kappa_a' invD_a kappa_a) of the online natural gradient
+template <typename T>
+__global__ void k_add_sym(const T* __restrict__ A, const T* __restrict__ Bm, int64_t ld, int64_t n, T* __restrict__ out) {
+  int64_t r = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= n || c >= n) return;
+  out[r * ld + c] = A[r * ld + c] + T(0.5) * (Bm[r * ld + c] + Bm[c * ld + r]);
+}
+
+// A -= B on an n x n block
+template <typename T>
+__global__ void k_sub2d(T* __restrict__ A, const T* __restrict__ Bm, int64_t ld, int64_t n) {
+  int64_t r = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r < n && c < n) A[r * ld + c] -= Bm[r * ld + c];
+}
+
+// out[0] = sum_{i<n} x[i] y[i]
+template <typename T>
+__global__ void k_dot(const T* __restrict__ x, const T* __restrict__ y, int64_t n, double* __restrict__ out) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += (double)x[i] * (double)y[i];
+  s = block_sum<double>(s, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
 template <typename T>
 __global__ void k_set_scalar(T* p, T v) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *p = v;

@@ -261,6 +261,32 @@ agp_status agp_svgp_predict_f(agp_svgp* h, const void* xt, int64_t ldx, int64_t 
  * logistic / BayesianSVM -> int32[n_t] (mu_f > 0) ; Poisson / NegBinomial -> T[n_t] expected count (predictions.jl:211) ;
  * LogisticSoftMax -> int32[n_t] argmax_k mu_f,k (0-based LOCAL latent index + latent_offset) */
 agp_status agp_svgp_predict_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* y_out);
+/* ---- OnlineSVGP (src/models/OnlineSVGP.jl, src/training/onlinetraining.jl) ------------------------------------------------
+ * A streaming model is a sequence of handles: when a batch arrives the caller snapshots the current posterior, picks the
+ * new inducing points (InducingPoints.OIPS on its side, with agp_kernelmatrix for the kernel values), creates a handle
+ * for the new Z and installs the previous posterior as its prior.  Only AnalyticVI() (stochastic = 0) is accepted: the
+ * reference's stochastic branch is dead code (onlinetraining.jl:52 uses an undefined name).
+ *
+ * agp_svgp_online_snapshot: save_old_gp! (onlinetraining.jl:170-180): invDa_out (m x m, ld ldi) = -2 eta2 - inv(K),
+ *   eta1_out (m) = eta1, *prevLa_host = (-logdet Sigma + logdet K - mu'eta1)/2.  Device outputs; synchronises.
+ * agp_svgp_set_online_prior: previous_gp of the opt state + Z_a of the latent.  za = NULL: first batch (Z_a empty:
+ *   kappa_a = I, K_ab = 0, K~_a = 0; pass invDa = I, prev_eta1 = 0, prevLa = 0 as init_opt_state does, states.jl:85-97;
+ *   ma must equal m).  From then on every step uses the online natural gradient (analyticVI.jl:183-203)
+ *     eta1 = K\mu0 + kappa' grad_E_mu + kappa_a' eta1_a ;  eta2 = -(kappa' diag(grad_E_Sigma) kappa + kappa_a' invD_a kappa_a/2 + inv(K)/2)
+ *   and agp_svgp_elbo subtracts extraKL (KLdivergences.jl:30-54).
+ * agp_svgp_adopt_local: dst takes src's local variables and expectation gradients (same likelihood / max_batch / ctx):
+ *   the first iteration on a new batch updates the local variables under the OLD inducing points (compute_old_matrices,
+ *   onlinetraining.jl:78-104): run agp_svgp_step_local on the old handle, then on the new one
+ *   agp_svgp_step_local + agp_svgp_adopt_local(new, old) + agp_svgp_step_stats(fused) + agp_svgp_step_global. */
+agp_status agp_svgp_online_snapshot(agp_svgp* h, int32_t latent, void* invDa_out, int64_t ldi, void* eta1_out,
+                                    double* prevLa_host);
+agp_status agp_svgp_set_online_prior(agp_svgp* h, int32_t latent, const void* za, int64_t ldza, int64_t ma, const void* invDa,
+                                     int64_t ldi, const void* prev_eta1, double prevLa);
+agp_status agp_svgp_adopt_local(agp_svgp* dst, agp_svgp* src);
+/* the whole first iteration on a new batch (onlinetraining.jl:78-104) in one call: h_old.step_local(x, y) [+ the
+ * LogisticSoftMax fixed point] ; h_new.step_local ; adopt_local(h_new, h_old) ; h_new natural gradient + global update */
+agp_status agp_svgp_online_first_step(agp_svgp* h_new, agp_svgp* h_old, const void* x, int64_t ldx, const void* y,
+                                      int64_t B);
 /* Gauss-Hermite rule used INSIDE training by PoissonLikelihood's lambda update (expectation(logistic, mu, sigma2),
  * src/functions/utils.jl:16-19 ; same nodes as predictions.jl:4: x*sqrt2, w/sqrt(pi)).  Must be called before the first
  * step of a Poisson handle; other likelihoods ignore it. */

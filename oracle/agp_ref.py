@@ -1382,3 +1382,198 @@ def kmeans_lloyd(X, C0, tol=1e-3, maxiter=100):
 def kmeans_inducingpoints(X, m, rng, n_markov=10, tol=1e-3):
     """inducingpoints(KmeansAlg(m; nMarkov = 10, tol = 1e-3), X)"""
     return kmeans_lloyd(X, kmeans_seeding(X, m, n_markov, rng), tol)[0]
+
+
+# --------------------------------------------------------------------------------------------
+# OnlineSVGP (src/models/OnlineSVGP.jl, src/training/onlinetraining.jl, latentgp.jl:90-131,217-237,
+# analyticVI.jl:183-203, KLdivergences.jl:30-54, states.jl:85-97, posterior.jl:39-55): streaming sparse GP of
+# Bui et al. 2017 with closed-form augmented updates.  Inducing points come from the third-party, unvendored
+# InducingPoints.jl OIPS (Galy-Fajou & Opper 2021): restated below from the published algorithm (parity unpinned).
+# --------------------------------------------------------------------------------------------
+@dataclass
+class OIPS:
+    """Online Inducing Point Selection: a point joins Z when its largest kernel value with the current Z is below
+    rho_accept; optional pruning (`remove_point`) drops one of the points whose kernel value with another inducing point
+    exceeds rho_remove, drawn with weights = number of such neighbours (needs the caller's RNG; rho_remove >= 1 disables it)."""
+
+    rho_accept: float = 0.8
+    rho_remove: float = 1.0
+    kmin: int = 10
+
+    def init(self, X, kernel):
+        """inducingpoints(alg, X; kernel): start from the first point, then add_point over the rest."""
+        return self.update(np.asarray(X[:1], dtype=np.float64).copy(), X[1:], kernel)
+
+    def update(self, Z, X, kernel):
+        """updateZ(Z, alg, X; kernel): sequential scan, every accepted point is visible to the later ones."""
+        Z = [z for z in np.asarray(Z, dtype=np.float64)]
+        for x in np.asarray(X, dtype=np.float64):
+            kx = kernel.matrix(x[None, :], np.stack(Z))[0]
+            if np.max(kx) < self.rho_accept:
+                Z.append(x.copy())
+        return np.stack(Z)
+
+    def remove_point(self, rng, Z, Kmat):
+        if self.rho_remove >= 1.0:
+            return Z
+        overlap = np.sum(Kmat > self.rho_remove, axis=1) - 1
+        removable = np.flatnonzero(overlap > 0)
+        if len(removable) > 1 and len(Z) > self.kmin:
+            w = overlap[removable].astype(np.float64)
+            gone = removable[rng.choice(len(removable), p=w / w.sum())]
+            return np.delete(Z, gone, axis=0)
+        return Z
+
+
+class OnlineSVGP:
+    """OnlineSVGP(kernel, likelihood, AnalyticVI(), Zalg; optimiser=false): one `train` call per arriving batch."""
+
+    def __init__(self, kernel, likelihood, Zalg=None, jitter=1e-4, elbo_mode="corrected", rng=None):
+        self.kernel, self.likelihood, self.Zalg = kernel, likelihood, Zalg or OIPS(0.9)
+        self.jitter, self.elbo_mode = jitter, elbo_mode
+        self.rng = rng or np.random.default_rng(0)
+        self.latents = None  # list of dicts, one per latent
+        self.local_vars = None
+        self.n_iter = 0
+        self.rho = 1.0
+
+    # -- init_online_gp! onlinetraining.jl:188-197 + OnlineVarPosterior posterior.jl:47-55 + init_opt_state states.jl:85-97
+    def _init(self, X):
+        import copy
+        self.latents = []
+        for _ in range(self.likelihood.n_latent):
+            ker = copy.deepcopy(self.kernel)
+            Z = self.Zalg.init(X, ker)
+            k = len(Z)
+            self.latents.append(dict(kernel=ker, Z=Z, Za=None, mu=np.zeros(k), Sigma=np.eye(k), eta1=np.zeros(k),
+                                     eta2=-0.5 * np.eye(k), mu0=np.zeros(k), prevLa=0.0, invDa=np.eye(k), prev_eta1=np.zeros(k)))
+
+    # -- save_old_gp! onlinetraining.jl:170-180 and updateZs! :153-160
+    def _roll(self, X):
+        for g in self.latents:
+            g["Za"] = g["Z"].copy()
+            g["Z"] = self.Zalg.remove_point(self.rng, g["Z"], g["K"])
+            g["invDa"] = -2.0 * g["eta2"] - g["Kinv"]
+            g["invDa"] = (g["invDa"] + g["invDa"].T) / 2.0
+            g["prev_eta1"] = g["eta1"].copy()
+            g["prevLa"] = float((-np.linalg.slogdet(g["Sigma"])[1] + 2.0 * np.sum(np.log(np.diag(g["L"])))
+                                 - np.dot(g["mu"], g["eta1"])) / 2.0)
+            g["Z"] = self.Zalg.update(g["Z"], X, g["kernel"])
+            g["mu0"] = np.zeros(len(g["Z"]))
+
+    # -- compute_old_matrices onlinetraining.jl:210-217 : matrices of the new batch w.r.t. the OLD inducing points
+    def _old_matrices(self, X):
+        out = []
+        for g in self.latents:
+            K, L = compute_K(g["kernel"], g["Za"], self.jitter)
+            out.append(compute_kappa(g["kernel"], X, g["Za"], L, self.jitter))
+        return out
+
+    # -- compute_K + compute_kappa(::OnlineVarLatent) latentgp.jl:217-237
+    def _matrices(self, X):
+        for g in self.latents:
+            ker, Z = g["kernel"], g["Z"]
+            g["K"], g["L"] = compute_K(ker, Z, self.jitter)
+            g["Kinv"] = sla.cho_solve((g["L"], True), np.eye(len(Z)))
+            g["Kinv"] = (g["Kinv"] + g["Kinv"].T) / 2.0
+            k = len(Z)
+            if g["Za"] is None:
+                g["Kab"], g["kappa_a"], g["Kt_a"] = np.zeros((k, k)), np.eye(k), np.zeros((k, k))
+            else:
+                g["Kab"] = ker.matrix(g["Za"], Z)
+                g["kappa_a"] = sla.cho_solve((g["L"], True), g["Kab"].T).T
+                Ka = ker.matrix(g["Za"]) + self.jitter * np.eye(len(g["Za"]))
+                g["Kt_a"] = Ka - g["kappa_a"] @ g["Kab"].T
+            g["Knm"], g["kappa"], g["Kt"] = compute_kappa(ker, X, Z, g["L"], self.jitter)
+
+    # -- natural_gradient!(::OnlineVarLatent) analyticVI.jl:183-203 + global_update! :221-224
+    def _natural(self, g1, g2):
+        for k, g in enumerate(self.latents):
+            ka = g["kappa_a"]
+            g["eta1"] = sla.cho_solve((g["L"], True), g["mu0"]) + g["kappa"].T @ g1[k] + ka.T @ g["prev_eta1"]
+            e2 = -(rho_kappa_diag_theta_kappa(1.0, g["kappa"], g2[k]) + ka.T @ g["invDa"] @ ka / 2.0 + g["Kinv"] / 2.0)
+            g["eta2"] = (e2 + e2.T) / 2.0
+            g["mu"], g["Sigma"] = natural_to_standard(g["eta1"], g["eta2"])
+
+    def mean_var(self):
+        return (tuple(mean_f(g["mu"], g["kappa"]) for g in self.latents),
+                tuple(var_f(g["Sigma"], g["kappa"], g["Kt"]) for g in self.latents))
+
+    # -- train!(::OnlineSVGP, X, y, state; iterations) onlinetraining.jl:36-135
+    def train(self, X, y, iterations=5, callback=None):
+        X = np.asarray(X, dtype=np.float64)
+        lik = self.likelihood
+        y = treat_labels(y, lik)
+        B = len(X)
+        first = self.n_iter == 0
+        if first:
+            self._init(X)
+        else:
+            self._roll(X)
+        if self.local_vars is None or len(np.atleast_1d(_first_array(self.local_vars))) != B:
+            self.local_vars = init_local_vars(lik, B)
+        for it in range(iterations):
+            if it == 0:
+                if first:
+                    self._matrices(X)
+                    mf, vf = self.mean_var()
+                else:
+                    old = self._old_matrices(X)
+                    mf = tuple(mean_f(g["mu"], o[1]) for g, o in zip(self.latents, old))
+                    vf = tuple(var_f(g["Sigma"], o[1], o[2]) for g, o in zip(self.latents, old))
+                self.local_vars = local_updates(self.local_vars, lik, y, mf, vf)
+                g1, g2 = grad_E_mu(lik, y, self.local_vars), grad_E_Sigma(lik, y, self.local_vars)
+                self._matrices(X)
+            else:
+                mf, vf = self.mean_var()
+                self.local_vars = local_updates(self.local_vars, lik, y, mf, vf)
+                g1, g2 = grad_E_mu(lik, y, self.local_vars), grad_E_Sigma(lik, y, self.local_vars)
+            self._natural(g1, g2)
+            self.n_iter += 1
+            if callback is not None:
+                callback(self, it, X, y)
+        return self
+
+    # -- ELBO analyticVI.jl:255-274 with extraKL KLdivergences.jl:30-54
+    def extra_kl(self):
+        tot = 0.0
+        for g in self.latents:
+            ka, iD = g["kappa_a"], g["invDa"]
+            kam = ka @ g["mu"]
+            kl = g["prevLa"]
+            kl += -(trace_ABt(iD, g["Kt_a"]) + trace_ABt(iD, ka @ g["Sigma"] @ ka.T)) / 2.0
+            kl += np.dot(g["prev_eta1"], kam) - np.dot(kam, iD @ kam) / 2.0
+            tot += kl
+        return float(tot)
+
+    def elbo(self, y):
+        mf, vf = self.mean_var()
+        tot = self.rho * expec_loglikelihood(self.likelihood, y, mf, vf, self.local_vars, self.elbo_mode)
+        tot -= sum(gaussian_kl(g["mu"], g["mu0"], g["Sigma"], g["L"]) for g in self.latents)
+        tot -= self.rho * augmented_kl(self.likelihood, self.local_vars, y, self.elbo_mode)
+        tot -= self.extra_kl()
+        return float(tot)
+
+    def _as_svgp(self):
+        helper = SVGP.__new__(SVGP)
+        helper.likelihood, helper.jitter = self.likelihood, self.jitter
+        helper.latents = []
+        for g in self.latents:
+            lt = Latent(g["kernel"], g["Z"])
+            lt.mu, lt.Sigma, lt.K, lt.L = g["mu"], g["Sigma"], g["K"], g["L"]
+            helper.latents.append(lt)
+        return helper
+
+    def predict_f(self, Xt, cov=False):
+        return self._as_svgp().predict_f(Xt, cov)
+
+    def predict_y(self, Xt):
+        return self._as_svgp().predict_y(Xt)
+
+    def proba_y(self, Xt):
+        return self._as_svgp().proba_y(Xt)
+
+
+def _first_array(lv):
+    v = next(iter(lv.values()))
+    return v[0] if isinstance(v, list) else v

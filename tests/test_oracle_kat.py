@@ -459,3 +459,35 @@ def test_kmeans_restatement_properties():
     for j in range(4):
         assert np.allclose(Cf[j], Xb[labf == j].mean(0), atol=1e-12)
     assert max(np.min(np.linalg.norm(Cf - mu, axis=1)) for mu in means) < 0.1
+
+
+def test_oips_and_online_svgp_restatement_properties():
+    """OIPS keeps every pair of inducing points below rho_accept and covers the data (every point has a neighbour in Z at
+    or above rho_accept); OnlineSVGP (onlinetraining.jl) improves as batches stream in, its first batch reproduces the
+    closed form eta2 = -(kappa' diag(theta) kappa + I/2 + K^-1/2) of the init_opt_state prior (states.jl:85-97), and
+    extraKL of the first batch is -(tr Sigma + mu'mu)/2 (KLdivergences.jl:30-54 with kappa_a = I, K~_a = 0)."""
+    rng = np.random.default_rng(4)
+    N = 300
+    X = rng.random((N, 1)) * 6
+    f = np.sin(2 * X[:, 0])
+    y = f + 0.1 * rng.standard_normal(N)
+    ker = R.Kernel("sqexponential", 2.0, 1.0)
+    alg = R.OIPS(0.8)
+    Z = alg.init(X, ker)
+    Kz = ker.matrix(Z)
+    assert np.max(Kz - np.eye(len(Z))) < 0.8
+    assert np.all(ker.matrix(X, Z).max(axis=1) >= 0.8 - 1e-12)
+    M = R.OnlineSVGP(ker, R.GaussianLikelihood(0.01), R.OIPS(0.8))
+    M.train(X[:60], y[:60], 1)
+    g = M.latents[0]
+    k = len(g["Z"])
+    want = -(g["kappa"].T @ (g["kappa"] / 0.01) / 2.0 + np.eye(k) / 2.0 + g["Kinv"] / 2.0)
+    assert np.allclose(g["eta2"], want, rtol=1e-12, atol=1e-12)
+    assert M.extra_kl() == pytest.approx(-(np.trace(g["Sigma"]) + g["mu"] @ g["mu"]) / 2.0, rel=1e-12)
+    errs = [np.mean(np.abs(M.predict_y(X) - f))]
+    for b in range(60, N, 60):
+        M.train(X[b:b + 60], y[b:b + 60], 3)
+        errs.append(np.mean(np.abs(M.predict_y(X) - f)))
+        assert np.isfinite(M.elbo(y[b:b + 60]))
+    assert errs[-1] < 0.05 and errs[-1] < errs[0]
+    assert len(M.latents[0]["Z"]) >= k

@@ -883,10 +883,6 @@ struct Svgp : SvgpBase {
   // gradient of the hyper objective w.r.t. (variance, per-dimension scales, Z) of latent l, on the batch of the last step
   agp_status hypergrad(int l, double* dvar, double* dscale, void* dZ_out) override {
     if (l < 0 || l >= nl || !x_last || B_last <= 0) return AGP_ERR_INVALID;
-    if (mo) {
-      ctx->err = "hyper-gradient of the multi-output model is not wired yet";
-      return AGP_ERR_UNSUPPORTED;
-    }
     Latent& g = lat[l];
     if (g.k.kind == AGP_K_EXPONENTIAL) {
       ctx->err = "hyper-gradient: ExponentialKernel is not differentiable at zero distance";
@@ -901,19 +897,32 @@ struct Svgp : SvgpBase {
                        hy_muf);
     AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.kappa, mp, g.Sigma, mp, Bq, mp, mp, 0, hyH1, mp, nullptr, 0, nullptr, nullptr,
                                   nullptr, 0)));
-    int gmode = 0;
-    const bool refm = desc.elbo_mode == AGP_ELBO_REFERENCE;
-    if (refm && (lp.kind == AGP_LIK_LOGISTIC || lp.kind == AGP_LIK_NEGBINOMIAL)) gmode = 1;
-    if (refm && lp.kind == AGP_LIK_BAYESIANSVM) gmode = 2;
-    if (lp.kind == AGP_LIK_HETEROSCEDASTIC && l == 0) {
-      gmode = 3;  // needs var_f under the current posterior: rowdot(kappa Sigma, kappa) + K~
-      hipLaunchKernelGGL((k_hyper_varf<T>), grid1(B * 64), dim3(256), 0, st(), B, mp, mp, (const T*)hyH1,
-                         (const T*)g.kappa, (const T*)(Kt + l * Bp), pw0);
+    if (mo) {
+      // mixed means under the current posterior need every latent's mean_f on this batch
+      for (int q = 0; q < nl; ++q) {
+        AGPCHK(materialize(lat[q]));
+        hipLaunchKernelGGL((k_gemv_rows<T>), grid1(B * 64), dim3(256), 0, st(), (const T*)lat[q].kappa, mp, B, mp,
+                           (const T*)lat[q].mu, emuf + q * Bp);
+      }
+      hipLaunchKernelGGL((k_mo_hyper_gvec<T>), grid1(B), dim3(256), 0, st(), B, nl, Bp, mocfg, (const T*)A_dev,
+                         (const T*)y_last, ystride, idx_last, (const T*)emuf, (const T*)mo_th, l,
+                         (int)(desc.elbo_mode == AGP_ELBO_REFERENCE), hy_gmu, hy_gs);
+      LAUNCHCHK(ctx);
+    } else {
+      int gmode = 0;
+      const bool refm = desc.elbo_mode == AGP_ELBO_REFERENCE;
+      if (refm && (lp.kind == AGP_LIK_LOGISTIC || lp.kind == AGP_LIK_NEGBINOMIAL)) gmode = 1;
+      if (refm && lp.kind == AGP_LIK_BAYESIANSVM) gmode = 2;
+      if (lp.kind == AGP_LIK_HETEROSCEDASTIC && l == 0) {
+        gmode = 3;  // needs var_f under the current posterior: rowdot(kappa Sigma, kappa) + K~
+        hipLaunchKernelGGL((k_hyper_varf<T>), grid1(B * 64), dim3(256), 0, st(), B, mp, mp, (const T*)hyH1,
+                           (const T*)g.kappa, (const T*)(Kt + l * Bp), pw0);
+      }
+      hipLaunchKernelGGL((k_hyper_gvec<T>), grid1(B), dim3(256), 0, st(), B, rho, gmode, (const T*)(rbuf + l * Bp),
+                         (const T*)(theta + l * Bp), (const T*)hy_muf, (const T*)y_last, idx_last, (const T*)pw0,
+                         (const T*)gamma, (const T*)lam_dev, hy_gmu, hy_gs);
+      LAUNCHCHK(ctx);
     }
-    hipLaunchKernelGGL((k_hyper_gvec<T>), grid1(B), dim3(256), 0, st(), B, rho, gmode, (const T*)(rbuf + l * Bp),
-                       (const T*)(theta + l * Bp), (const T*)hy_muf, (const T*)y_last, idx_last, (const T*)pw0,
-                       (const T*)gamma, (const T*)lam_dev, hy_gmu, hy_gs);
-    LAUNCHCHK(ctx);
     hipLaunchKernelGGL((k_hyper_gkappa<T>), grid2(Bq, mp), blk2, 0, st(), B, Bq, mp, mp, rho, (const T*)hy_gmu,
                        (const T*)hy_gs, (const T*)g.mu, (const T*)g.Knm, hyH1);
     LAUNCHCHK(ctx);

@@ -491,6 +491,35 @@ __global__ void k_mo_local(int64_t B, int Q, int64_t ldb, MoCfg<T> cfg, const T*
   }
 }
 
+// hyper-gradient inputs of latent l in the multi-output model: the data term sees f_l only through the mixed f_t, so
+//   dE/dmu_l = sum_t A_tl (g1_t - theta_t m_t) ,  dE/dsigma2_l = -sum_t A_tl^2 theta_t / 2
+// (m_t = mixed mean under the CURRENT posterior; theta_t, g1_t from the step's local variables; elbo_ref keeps the
+// reference's dot(theta, mu) / BayesianSVM expressions per task like k_hyper_gvec)
+template <typename T>
+__global__ void k_mo_hyper_gvec(int64_t B, int Q, int64_t ldb, MoCfg<T> cfg, const T* __restrict__ A,
+                                const T* __restrict__ y, int64_t ystride, const int64_t* __restrict__ idx,
+                                const T* __restrict__ muf, const T* __restrict__ th, int l, int elbo_ref,
+                                T* __restrict__ gmu, T* __restrict__ gs) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const int64_t src = idx ? idx[i] : i;
+  T a1 = T(0), a2 = T(0);
+  for (int t = 0; t < cfg.nT; ++t) {
+    T m = T(0);
+    for (int q = 0; q < Q; ++q) m += A[t * Q + q] * muf[q * ldb + i];
+    const T thv = th[t * ldb + i], yi = y[src * ystride + t], atl = A[t * Q + l];
+    const int kind = cfg.kind[t];
+    T g;
+    if (elbo_ref && (kind == LIK_LOGISTIC || kind == LIK_NEGBIN)) g = lik_g1<T>(kind, cfg.p0[t], yi, thv) - thv / T(2);
+    else if (elbo_ref && kind == LIK_BSVM) g = yi - T(2) * thv * (T(1) - yi * m) * yi;
+    else g = lik_g1<T>(kind, cfg.p0[t], yi, thv) - thv * m;
+    a1 += atl * g;
+    a2 += atl * atl * thv;
+  }
+  gmu[i] = a1;
+  gs[i] = -a2 / T(2);
+}
+
 // update_A! gradient (lines 87-109) with the local variables of the PREVIOUS step: grid (Q, nT), one workgroup each
 template <typename T>
 __global__ void k_mo_gradA(int64_t B, int Q, int64_t ldb, MoCfg<T> cfg, const T* __restrict__ A,

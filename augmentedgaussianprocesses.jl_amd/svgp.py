@@ -141,9 +141,6 @@ class SVGP:
         for o in (optimiser, Zoptimiser):
             if o is not None and not isinstance(o, ADAM):
                 raise NotImplementedError("only ADAM is wired as hyper-parameter optimiser")
-        if isinstance(likelihood, _MultiOutputLikelihood) and (optimiser or Zoptimiser):
-            raise NotImplementedError("hyper-parameter steps of the multi-output model are not wired yet: pass "
-                                      "optimiser=False, Zoptimiser=False")
         self.k_opt, self.z_opt = optimiser, Zoptimiser
         if mean is not None and not (np.isscalar(mean) or isinstance(mean, (list, np.ndarray))):
             raise TypeError("mean must be None (ZeroMean), a Real (ConstantMean) or a vector (EmpiricalMean)")
@@ -452,6 +449,7 @@ class MOSVGP(SVGP):
         return torch.as_tensor(np.ascontiguousarray(y_treated.T), dtype=self.tdtype, device=self._dev())
 
     def _post_create(self, h):
+        super()._post_create(h)  # hyper-parameter optimiser configuration
         liks = (capi.LikDesc * self.n_task)(*[l.lik_desc() for l in self.likelihood.likelihoods])
         o = self.A_opt
         self._chk(capi.lib().agp_svgp_set_multioutput(
@@ -459,6 +457,7 @@ class MOSVGP(SVGP):
             o.beta[0] if o else 0.9, o.beta[1] if o else 0.999, o.eps if o else 1e-8))
 
     def _pre_destroy(self):
+        super()._pre_destroy()
         self.get_A()  # carry the mixing weights into the re-created handle (the ADAM moments restart)
 
     def get_A(self):

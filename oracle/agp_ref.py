@@ -1097,6 +1097,10 @@ class MOSVGP:
     tau_rm: float = 1.0
     jitter: float = 1e-4
     elbo_mode: str = "corrected"
+    k_opt: object = None          # optimiser / Zoptimiser of MOSVGP(...) (MOSVGP.jl:39-42): Adam objects or None
+    z_opt: object = None
+    ard: bool = False
+    atfrequency: int = 1
 
     def __post_init__(self):
         import copy
@@ -1184,12 +1188,81 @@ class MOSVGP:
             self.compute_kernel_matrices(xb)
             self.update_A(yb)
             self.variational_updates(yb)
-            self.n_iter += 1
             if callback is not None:
                 callback(self, it, xb, yb)
+            if (self.k_opt or self.z_opt) and self.n_iter % self.atfrequency == 0 and self.n_iter >= 3 \
+                    and (it + 1) != iterations:  # training.jl:65-69
+                self.update_hyperparameters(xb, yb)
+            self.n_iter += 1
         for gp in self.latents:
             gp.K, gp.L = compute_K(gp.kernel, gp.Z, self.jitter)
         return self
+
+    # -- update_hyperparameters! (sparse, autotuning.jl:86-140) for the multi-output model: the data term sees latent q through
+    #    the mixed means / variances, so dE/dmu_q = sum_t A_tq dE_t/dmu_t and dE/dsigma2_q = sum_t A_tq^2 dE_t/dsigma2_t
+    def hyper_gradient(self, xb, ys, q):
+        self.hp_updated = True
+        self.compute_kernel_matrices(xb)
+        mu_t, _ = self.mixed()
+        gmu, gsig = np.zeros(len(xb)), np.zeros(len(xb))
+        for t, lik in enumerate(self.likelihoods):
+            gm, gs = expec_grads(lik, ys[t], mu_t[t], self.local_vars[t], 0, self.elbo_mode)
+            gmu += self.A[t, q] * gm
+            gsig += self.A[t, q] ** 2 * gs
+        return hyper_gradient_core(self.latents[q], xb, gmu, gsig, self.rho, self.jitter)
+
+    def hyper_objective(self, xb, ys, q, scale, sigma2, Z):
+        """ELBO.jl:15-21 as a function of latent q's kernel parameters and inducing points ((mu, Sigma, local variables, A)
+        fixed, AugmentedKL ignored): what autotuning.jl:96-98 hands to Zygote; finite differences of it pin hyper_gradient."""
+        import copy
+        mus, vs = [], []
+        kl = 0.0
+        for k, g in enumerate(self.latents):
+            ker, Zk = g.kernel, g.Z
+            if k == q:
+                ker = copy.deepcopy(ker)
+                ker.scale, ker.sigma2 = scale, sigma2
+                Zk = Z
+            K, L = compute_K(ker, Zk, self.jitter)
+            Knm, kappa, Kt = compute_kappa(ker, xb, Zk, L, self.jitter)
+            mus.append(mean_f(g.mu, kappa))
+            vs.append(var_f(g.Sigma, kappa, Kt))
+            kl += gaussian_kl(g.mu, g.mu0, g.Sigma, L)
+        tot = 0.0
+        for t, lik in enumerate(self.likelihoods):
+            mt = sum(self.A[t, k] * mus[k] for k in range(self.Q))
+            vt = sum(self.A[t, k] ** 2 * vs[k] for k in range(self.Q))
+            tot += expec_loglikelihood(lik, ys[t], (mt,), (vt,), self.local_vars[t], self.elbo_mode)
+        return float(self.rho * tot - kl)
+
+    def update_hyperparameters(self, xb, ys):
+        if getattr(self, "hyper_state", None) is None:
+            self.hyper_state = [None] * self.Q
+        grads = [self.hyper_gradient(xb, ys, q) for q in range(self.Q)]  # all gradients at the same state
+        for q, gp in enumerate(self.latents):
+            g = grads[q]
+            D = gp.Z.shape[1]
+            sc = np.broadcast_to(np.asarray(gp.kernel.scale, dtype=np.float64), (D,)).copy()
+            if self.hyper_state[q] is None:
+                self.hyper_state[q] = {"var": self.k_opt.init(np.zeros(1)) if self.k_opt else None,
+                                       "scale": self.k_opt.init(np.zeros(D if self.ard else 1)) if self.k_opt else None,
+                                       "Z": self.z_opt.init(np.zeros_like(gp.Z)) if self.z_opt else None}
+            st = self.hyper_state[q]
+            if self.k_opt:
+                v = np.array([gp.kernel.sigma2])
+                st["var"], dv = self.k_opt.apply(st["var"], v * np.array([g["dvariance"]]))
+                gp.kernel.sigma2 = float(np.exp(np.log(v) + dv)[0])
+                if self.ard:
+                    st["scale"], ds = self.k_opt.apply(st["scale"], sc * g["dscale"])
+                    gp.kernel.scale = np.exp(np.log(sc) + ds)
+                else:
+                    s0 = np.array([sc[0]])
+                    st["scale"], ds = self.k_opt.apply(st["scale"], s0 * np.array([np.sum(g["dscale"])]))
+                    gp.kernel.scale = float(np.exp(np.log(s0) + ds)[0])
+            if self.z_opt:
+                st["Z"], dz = self.z_opt.apply(st["Z"], g["dZ"])
+                gp.Z = gp.Z + dz
+        self.hp_updated = True
 
     def elbo(self, ys, rho=None):
         """analyticVI.jl:277-297."""
@@ -1276,13 +1349,21 @@ def hyper_gradient(model, X, y, latent_k, rho):
     """Returns dict(dvariance, dscale (array, one per dim: sum it for a ScaleTransform), dZ) at the current state."""
     gp = model.latents[latent_k]
     ker, Z = gp.kernel, gp.Z
-    m = len(Z)
     K, L = compute_K(ker, Z, model.jitter)
-    Kinv = sla.cho_solve((L, True), np.eye(m))
     Knm, kappa, Kt = compute_kappa(ker, X, Z, L, model.jitter)
     mu_f = mean_f(gp.mu, kappa)
     gmu, gsig = expec_grads(model.likelihood, y, mu_f, model.local_vars, latent_k, model.elbo_mode,
                             var_f(gp.Sigma, kappa, Kt))
+    return hyper_gradient_core(gp, X, gmu, gsig, rho, model.jitter)
+
+
+def hyper_gradient_core(gp, X, gmu, gsig, rho, jitter):
+    """the backward pass given (dE/dmu_f, dE/dsigma2_f) of the data term for this latent"""
+    ker, Z = gp.kernel, gp.Z
+    m = len(Z)
+    K, L = compute_K(ker, Z, jitter)
+    Kinv = sla.cho_solve((L, True), np.eye(m))
+    Knm, kappa, Kt = compute_kappa(ker, X, Z, L, jitter)
     G_kappa = rho * (np.outer(gmu, gp.mu) + 2.0 * gsig[:, None] * (kappa @ gp.Sigma) - gsig[:, None] * Knm)
     H = G_kappa @ Kinv
     G_Knm = H - rho * gsig[:, None] * kappa

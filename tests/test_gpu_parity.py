@@ -451,3 +451,35 @@ def test_training_with_hyper_steps_matches_oracle(env, likname, ard, zopt):
         assert abs(ma.kernels[k].variance - 1.2) > 1e-3  # the hypers really moved
         mu, Sig, e1, e2 = ma.get_state(k)
         assert _rel(e2, mr.latents[k].eta2) < 1e-7 and _rel(mu, mr.latents[k].mu) < 1e-7
+
+
+@pytest.mark.parametrize("ard,zopt", [(False, True), (True, False)])
+def test_multioutput_hyper_steps_match_oracle(env, ard, zopt):
+    """MOSVGP(...; optimiser=ADAM, Zoptimiser=ADAM): gradient of every latent through the A-mixed data term, then the ADAM
+    trajectory (kernel parameters in log space, Z directly) against the oracle (FD-pinned in tests/test_oracle_kat.py)."""
+    AGP, R = env["AGP"], env["R"]
+    rng = np.random.default_rng(77)
+    N, D, m, B, Q, iters = 240, 2, 10, 60, 3, 7
+    X = rng.random((N, D))
+    f = [np.sin(4 * X[:, 0]), X[:, 1] - 0.5]
+    ys = [f[0] + 0.1 * rng.standard_normal(N), np.sign(f[1] + 0.1 * rng.standard_normal(N))]
+    A = rng.standard_normal((2, Q))
+    A /= np.linalg.norm(A, axis=1, keepdims=True)
+    Zs = [X[rng.permutation(N)[:m]].copy() for _ in range(Q)]
+    idx = [rng.choice(N, B, replace=False) for _ in range(iters)]
+    sc = np.array([2.0, 3.0]) if ard else 2.5
+    ka = 1.3 * (AGP.SqExponentialKernel() @ (AGP.ARDTransform(sc) if ard else AGP.ScaleTransform(sc)))
+    ma = AGP.MOSVGP(ka, [AGP.GaussianLikelihood(0.05), AGP.LogisticLikelihood()], AGP.AnalyticSVI(B), Zs, A=A.copy(),
+                    Aoptimiser=False, optimiser=AGP.ADAM(0.01), Zoptimiser=AGP.ADAM(0.001) if zopt else False)
+    mr = R.MOSVGP(R.Kernel("sqexponential", sc, 1.3), [R.GaussianLikelihood(0.05), R.LogisticLikelihood()], Zs, A.copy(),
+                  stochastic=True, batchsize=B, k_opt=R.Adam(0.01), z_opt=R.Adam(0.001) if zopt else None, ard=ard)
+    AGP.train_(ma, X, ys, iters, idx_stream=idx)
+    mr.train(X, ys, iters, idx_stream=idx)
+    for q in range(Q):
+        kq = ma.kernels[q]
+        assert kq.variance == pytest.approx(mr.latents[q].kernel.sigma2, rel=1e-8)
+        got = np.asarray(kq.transform.s if hasattr(kq.transform, "s") else kq.transform.v, dtype=float)
+        assert _rel(got, np.asarray(mr.latents[q].kernel.scale, dtype=float)) < 1e-8
+        assert _rel(ma.Zs[q], mr.latents[q].Z) < 1e-8
+        mu, Sig, e1, e2 = ma.get_state(q)
+        assert _rel(e2, mr.latents[q].eta2) < 1e-7 and _rel(mu, mr.latents[q].mu) < 1e-7

@@ -491,3 +491,28 @@ def test_oips_and_online_svgp_restatement_properties():
         assert np.isfinite(M.elbo(y[b:b + 60]))
     assert errs[-1] < 0.05 and errs[-1] < errs[0]
     assert len(M.latents[0]["Z"]) >= k
+
+
+def test_kat7_multioutput_hyper_gradient_vs_finite_differences():
+    rng = np.random.default_rng(0)
+    N, D, m, Q = 60, 2, 6, 3
+    X = rng.random((N, D))
+    ys = [np.sin(4 * X[:, 0]) + 0.1 * rng.standard_normal(N), np.sign(X[:, 1] - 0.5 + 0.1 * rng.standard_normal(N))]
+    A = rng.standard_normal((2, Q))
+    A /= np.linalg.norm(A, axis=1, keepdims=True)
+    Zs = [X[rng.permutation(N)[:m]].copy() for _ in range(Q)]
+    M = R.MOSVGP(R.Kernel("matern52", np.array([2.0, 3.0]), 1.3), [R.GaussianLikelihood(0.05), R.LogisticLikelihood()], Zs, A)
+    M.train(X, ys, 2)
+    h = 1e-6
+    for q in range(Q):
+        g = M.hyper_gradient(X, ys, q)
+        gp = M.latents[q]
+        sc0, v0, Z0 = np.array(gp.kernel.scale, float), gp.kernel.sigma2, gp.Z.copy()
+        obj = lambda sc, v, Z: M.hyper_objective(X, ys, q, sc, v, Z)
+        assert g["dvariance"] == pytest.approx((obj(sc0, v0 + h, Z0) - obj(sc0, v0 - h, Z0)) / (2 * h), rel=5e-6, abs=1e-6)
+        e = np.array([0.0, h])
+        assert g["dscale"][1] == pytest.approx((obj(sc0 + e, v0, Z0) - obj(sc0 - e, v0, Z0)) / (2 * h), rel=5e-6, abs=1e-6)
+        Zp, Zm = Z0.copy(), Z0.copy()
+        Zp[2, 1] += h
+        Zm[2, 1] -= h
+        assert g["dZ"][2, 1] == pytest.approx((obj(sc0, v0, Zp) - obj(sc0, v0, Zm)) / (2 * h), rel=1e-5, abs=2e-6)

@@ -46,6 +46,34 @@ def shard_batch(idx: np.ndarray, world: int, rank: int) -> np.ndarray:
     return idx[rank * per:(rank + 1) * per]
 
 
+def row_slice(n: int, world: int, rank: int):
+    """Contiguous balanced slice [lo, hi) of n test points for `rank` (data-parallel prediction: independent units,
+    no collective -- SURVEY.md section 8e, third row)."""
+    return latent_slice(n, world, rank)
+
+
+def predict_sharded(predict_fn, X_test, group=None, gather: bool = True):
+    """Data-parallel predict_f / proba_y over the rows of X_test: every rank runs `predict_fn` (e.g.
+    `lambda X: agp_amd.predict_f(model, X, cov=True)`) on its row slice.  gather=True all-gathers the (numpy) results so
+    every rank returns the full arrays; gather=False returns (lo, hi, local result)."""
+    import torch.distributed as dist
+
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    n = len(X_test)
+    lo, hi = row_slice(n, world, rank)
+    local = predict_fn(X_test[lo:hi])
+    if not gather or world == 1:
+        return local if world == 1 else (lo, hi, local)
+    parts = [None] * world
+    dist.all_gather_object(parts, local, group=group)
+    if isinstance(local, tuple):
+        return tuple(np.concatenate([p[i] for p in parts], axis=-1 if np.ndim(parts[0][i]) > 1 else 0)
+                     for i in range(len(local)))
+    return np.concatenate(parts, axis=-1 if np.ndim(local) > 1 else 0)
+
+
 def _all_reduce(t, group=None):
     import torch.distributed as dist
 

@@ -170,6 +170,44 @@ def test_two_rank_drivers_match_single_process(likname, mode):
             assert np.allclose(e2, g.eta2, rtol=1e-9, atol=1e-11)
 
 
+def _pred_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    import agp_amd  # noqa: F401
+    from agp_amd import parallel as P
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    Xt = np.arange(37 * 3, dtype=np.float64).reshape(37, 3)
+    fn = lambda X: (X.sum(axis=1), (X ** 2).sum(axis=1))  # stands in for predict_f(model, X, cov=True)
+    mu, var = P.predict_sharded(fn, Xt)
+    lo, hi, loc = P.predict_sharded(fn, Xt, gather=False)
+    q.put((rank, mu, var, lo, hi, len(loc[0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_prediction_two_ranks():
+    """data-parallel predict over test rows: independent units, all-gather only to hand every rank the full result"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pred_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    Xt = np.arange(37 * 3, dtype=np.float64).reshape(37, 3)
+    spans = []
+    for rank, mu, var, lo, hi, nloc in res:
+        assert np.array_equal(mu, Xt.sum(axis=1)) and np.array_equal(var, (Xt ** 2).sum(axis=1))
+        assert nloc == hi - lo
+        spans.append((lo, hi))
+    assert sorted(spans) == [(0, 19), (19, 37)]
+
+
 def test_sharding_helpers():
     import agp_amd  # noqa: F401
     from agp_amd import parallel as P

@@ -117,14 +117,35 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     LAUNCHCHK(c);
     return AGP_OK;
   }
+  CholBatch<T> bt{};
+  bt.A[0] = A;
+  bt.X[0] = X;
+  bt.Dg[0] = Dg;
+  bt.E[0] = E;
   for (int64_t k = 0; k < nt; ++k) {
     const int64_t nP = nt - k + ne;
     const int64_t nr = nt - k - 1;
     const int64_t nU = (k >= 1 && nr > 0) ? nr * (nr + 1) / 2 + ne * nr : 0;
-    hipLaunchKernelGGL((k_chol_step<T>), dim3((unsigned)(nP + nU)), dim3(CHOL_THREADS), 0, c->stream, A, ld, X, ldx, Dg,
-                       E, lde, ne, do_x, k, nt, info_dev, nvalid);
+    hipLaunchKernelGGL((k_chol_step<T>), dim3((unsigned)(nP + nU)), dim3(CHOL_THREADS), 0, c->stream, bt, ld, ldx, lde, ne,
+                       do_x, k, nt, info_dev, nvalid);
     if (do_x && k >= 1)
       hipLaunchKernelGGL((k_trtri_row<T>), dim3((unsigned)k), dim3(NTHREADS), 0, c->stream, (const T*)A, ld, X, ldx, k);
+  }
+  LAUNCHCHK(c);
+  return AGP_OK;
+}
+
+// the same factorisation for nb <= CHOL_MAXB independent problems of identical shape in shared launches (no X = L^-1)
+template <typename T>
+static agp_status potrf_fused_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, int64_t ld, int64_t n, int64_t ldx,
+                                    int64_t lde, int64_t ne, int32_t* info_dev, int64_t nvalid) {
+  const int64_t nt = n / TILE;
+  for (int64_t k = 0; k < nt; ++k) {
+    const int64_t nP = nt - k + ne;
+    const int64_t nr = nt - k - 1;
+    const int64_t nU = (k >= 1 && nr > 0) ? nr * (nr + 1) / 2 + ne * nr : 0;
+    hipLaunchKernelGGL((k_chol_step<T>), dim3((unsigned)(nP + nU), (unsigned)nb), dim3(CHOL_THREADS), 0, c->stream, bt, ld,
+                       ldx, lde, ne, 0, k, nt, info_dev, nvalid);
   }
   LAUNCHCHK(c);
   return AGP_OK;
@@ -302,6 +323,7 @@ struct Svgp : SvgpBase {
     T* Apred = nullptr;   // K^-1 - K^-1 Sigma K^-1
     T* apred = nullptr;   // K^-1 mu
     bool K_stale = true, post_valid = false, pred_valid = false, predvar_valid = false, kappa_valid = false;
+    bool keep_last = false;  // this step reuses kappa / K~ of the previous full-batch step
     // hyper-parameter optimiser state (ADAM): kernel parameters on the host, Z on the device
     std::vector<double> k_m, k_v;
     int k_step = 0, z_step = 0;
@@ -832,6 +854,7 @@ struct Svgp : SvgpBase {
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
       const bool keep = reuse && g.kappa_valid;
+      g.keep_last = keep;
       if (prefetched) {
         // nothing to compute
       } else if (!keep) {
@@ -846,7 +869,35 @@ struct Svgp : SvgpBase {
       } else {
         HIPCHK(ctx, hipMemcpyAsync(g.Wbuf, g.kappa, sizeof(T) * Bq * mp, hipMemcpyDeviceToDevice, st()));
       }
-      AGPCHK(aug_factor(g, Bq, 0));
+      // pre-factorisation part of aug_factor: -2*eta2 back into La if it holds a factor, extension rows [eta1' ; 0]
+      if (g.la_state != 0) {
+        hipLaunchKernelGGL((k_copy2d<T>), grid2(mp, mp), blk2, 0, st(), (const T*)g.eta2, mp, mp, mp, g.La, mp, mp, mp,
+                           T(1), T(-2));
+      }
+      hipLaunchKernelGGL((k_set_ext_rows<T>), grid1(TILE * mp), dim3(256), 0, st(), g.Wbuf + Bq * mp, mp, mp,
+                         (const T*)g.eta1);
+      LAUNCHCHK(ctx);
+    }
+    // the augmented Cholesky factorisations of all latents share their launches (independent chains overlap)
+    AGPCHK(timing_begin());
+    for (int l0 = 0; l0 < nl; l0 += CHOL_MAXB) {
+      const int nb = std::min(CHOL_MAXB, nl - l0);
+      CholBatch<T> bt{};
+      for (int q = 0; q < nb; ++q) {
+        Latent& g = lat[l0 + q];
+        bt.A[q] = g.La;
+        bt.X[q] = g.Xa;
+        bt.Dg[q] = g.DgA;
+        bt.E[q] = g.Wbuf;
+        g.la_state = 1;
+        g.xa_valid = false;
+      }
+      AGPCHK(potrf_fused_batch<T>(ctx, bt, nb, mp, mp, mp, mp, Bq / TILE + 1, info_dev, m));
+    }
+    AGPCHK(timing_end(mp / TILE));
+    for (int l = 0; l < nl; ++l) {
+      Latent& g = lat[l];
+      const bool keep = g.keep_last;
       hipLaunchKernelGGL((k_rowstats_local<T>), grid1(B * 64), dim3(256), 0, st(), B, ns, (const T*)g.pk, ldp,
                          (const T*)g.Wbuf, mp, mp, (const T*)(g.Wbuf + Bq * mp), (T)g.k.variance, (T)jitter, (T)rho, lp,
                          (const T*)y, idx, Kt + l * Bp, muf + l * Bp, varf + l * Bp, cbuf + l * Bp, theta + l * Bp,

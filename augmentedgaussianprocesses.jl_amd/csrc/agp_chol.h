@@ -483,16 +483,30 @@ __device__ __forceinline__ void tri_index(int64_t idx, int64_t& ti, int64_t& tj)
   tj = idx - t * (t + 1) / 2;
 }
 
+// Independent factorisations of equal shape (the latent GPs of a multi-class / multi-output / heteroscedastic model) share
+// the launches: blockIdx.y selects the problem, so their latency-bound chains overlap instead of queueing.
+constexpr int CHOL_MAXB = 16;
+template <typename T>
+struct CholBatch {
+  T* A[CHOL_MAXB];
+  T* X[CHOL_MAXB];
+  T* Dg[CHOL_MAXB];
+  T* E[CHOL_MAXB];
+};
+
 // ---------------------------------------------------------------------------------------------------
-// launch S(k), k = 0..nt-1: grid = nP + nU, 512 threads
+// launch S(k), k = 0..nt-1: grid = (nP + nU, n_problems), 512 threads
 //   nP = nt - k + ne  (block rows k..nt-1 of A, then the ne extension blocks)
 //   nU = k >= 1 ? T(nt-k-1) + ne*(nt-k-1) : 0
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(T* __restrict__ A, int64_t ld, T* __restrict__ X,
-                                                            int64_t ldx, T* __restrict__ Dg, T* __restrict__ E,
-                                                            int64_t lde, int64_t ne, int do_x, int64_t k, int64_t nt,
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(CholBatch<T> bt, int64_t ld, int64_t ldx, int64_t lde,
+                                                            int64_t ne, int do_x, int64_t k, int64_t nt,
                                                             int32_t* __restrict__ info, int64_t nvalid) {
+  T* __restrict__ A = bt.A[blockIdx.y];
+  T* __restrict__ X = bt.X[blockIdx.y];
+  T* __restrict__ Dg = bt.Dg[blockIdx.y];
+  T* __restrict__ E = bt.E[blockIdx.y];
   __shared__ __attribute__((aligned(16))) T sm[3 * TILE * LDP];
   __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
   __shared__ T piv[TILE];

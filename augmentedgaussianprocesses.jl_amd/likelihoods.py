@@ -187,6 +187,11 @@ class HeteroscedasticLikelihood(AbstractLikelihood):
 
 
 def _unique_in_order(y):
+    """unique(y) in first-occurrence order (Julia's `unique`); vectorised for numeric / string arrays"""
+    arr = np.asarray(y)
+    if arr.dtype != object and arr.ndim == 1 and len(arr) > 0:
+        _, first = np.unique(arr, return_index=True)
+        return [v.item() if hasattr(v, "item") else v for v in arr[np.sort(first)]]
     seen = []
     for v in y:
         if v not in seen:
@@ -212,11 +217,25 @@ def create_mapping(l: LogisticSoftMaxLikelihood, y):
 
 
 def create_one_hot(l: LogisticSoftMaxLikelihood, y):
-    """create_one_hot  src/likelihood/multiclass.jl:81-94 (bool matrix N x K)."""
+    """create_one_hot  src/likelihood/multiclass.jl:81-94 (bool matrix N x K); O(N log N) instead of the reference's loops."""
+    arr = np.asarray(y)
+    Y = np.zeros((len(arr), l.n_class), dtype=bool)
+    if arr.dtype != object and arr.ndim == 1 and len(arr) > 0:
+        uniq, inv = np.unique(arr, return_inverse=True)
+        col = np.full(len(uniq), -1, dtype=np.int64)
+        for u, v in enumerate(uniq):
+            key = v.item() if hasattr(v, "item") else v
+            for j, c in enumerate(l.class_mapping):
+                if key == c:
+                    col[u] = j
+                    break
+        if np.any(col < 0):
+            raise RuntimeError("Some labels of y are not part of the expect labels")
+        Y[np.arange(len(arr)), col[inv]] = True
+        return Y
     for v in _unique_in_order(y):
         if v not in l.class_mapping:
             raise RuntimeError("Some labels of y are not part of the expect labels")
-    Y = np.zeros((len(y), l.n_class), dtype=bool)
     for i, v in enumerate(y):
         for j in range(l.n_class):
             if v == l.class_mapping[j]:

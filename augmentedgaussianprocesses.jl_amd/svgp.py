@@ -507,14 +507,28 @@ def train_(model: SVGP, X, y, iterations: int = 100, *, callback: Optional[Calla
     model._chk(L.agp_svgp_refresh_K(h))
     local_iter = 1
 
+    CH = 64  # minibatch indices are drawn on the host like the reference does, but uploaded 64 iterations at a time: one
+    #          blocking host->device copy per iteration would stall the launch queue for longer than the step itself
+    chunk = {"base": -1, "dev": None}
+
     def draw(it):  # StatsBase.sample(1:N, B; replace=false)  training.jl:51-53 (or the caller's stream)
-        if idx_stream is not None:
-            idx_np = np.asarray(idx_stream[it - 1], dtype=np.int64)
-            if idx_np.shape != (B,):
-                raise ValueError("idx_stream entries must have length batchsize")
-        else:
-            idx_np = model.rng.choice(N, B, replace=False).astype(np.int64)
-        return torch.as_tensor(idx_np, device=dev)
+        c0 = (it - 1) // CH * CH
+        if chunk["base"] != c0:
+            n_here = min(CH, iterations - c0)
+            rows = []
+            for q in range(c0, c0 + n_here):
+                if idx_stream is not None:
+                    idx_np = np.asarray(idx_stream[q], dtype=np.int64)
+                    if idx_np.shape != (B,):
+                        raise ValueError("idx_stream entries must have length batchsize")
+                else:
+                    idx_np = model.rng.choice(N, B, replace=False).astype(np.int64)
+                rows.append(idx_np)
+            prev = chunk["dev"]
+            chunk["dev"] = torch.as_tensor(np.stack(rows), device=dev)
+            chunk["base"] = c0
+            model._keep_chunks = [prev, chunk["dev"]]  # the previous chunk may still be referenced by a queued prefetch
+        return chunk["dev"][it - 1 - c0]
 
     nxt = draw(1) if inf.stoch else None
     while True:

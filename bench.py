@@ -77,6 +77,11 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # test hook: AGP_BENCH_SHARE_GPU=1 maps every rank to GPU 0 and uses gloo, so the N > 1 code path can be exercised on a
+    # single-GPU box (never set by the driver; numbers from such a run are meaningless)
+    share = os.environ.get("AGP_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -84,7 +89,10 @@ def main():
         import torch.distributed as dist_
 
         dist = dist_
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import __graft_entry__ as ge
 
@@ -148,7 +156,7 @@ def main():
     model._chk(L.agp_svgp_timing_enable(h, 0))
     model._chk(L.agp_svgp_check_status(h))
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -178,7 +186,7 @@ def main():
     out = {
         "metric": "cavi_iters_per_sec",
         "value": round(world * steps / dt, 2),
-        "unit": "latent-iter/s" if world > 1 else "iter/s",
+        "unit": "iter/s",  # N > 1: every GPU steps its own latent GP, value = latent-iterations/s summed over the GPUs
         "n_gpus": world,
         "steps": steps,
         "warmup": warm,

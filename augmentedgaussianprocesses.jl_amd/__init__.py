@@ -43,6 +43,7 @@ from .svgp import (  # noqa: F401
     train_,
 )
 from .capi import AGPError  # noqa: F401
+from .persistence import load_trained_model, save_trained_model  # noqa: F401
 from .inducingpoints import KmeansAlg, RandomSubset, inducingpoints  # noqa: F401
 from .online import (  # noqa: F401
     OIPS,

@@ -119,6 +119,7 @@ SYMBOLS = {
     "agp_svgp_online_first_step": (_I32, [_VP, _VP, _VP, _I64, _VP, _I64]),
     "agp_svgp_set_quadrature": (_I32, [_VP, _PDBL, _PDBL, _I32]),
     "agp_svgp_get_lik_param": (_I32, [_VP, _PDBL]),
+    "agp_svgp_set_lsm_alpha": (_I32, [_VP, _VP, _I64]),
     "agp_svgp_set_lik_param": (_I32, [_VP, _DBL]),
 }
 

@@ -238,6 +238,7 @@ struct SvgpBase {
   virtual agp_status proba_y(const void* xt, int64_t ldx, int64_t nt, const double* nodes, const double* weights,
                              int nn, void* o0, void* o1) = 0;
   virtual agp_status set_quadrature(const double* nodes, const double* weights, int nn) = 0;
+  virtual agp_status set_lsm_alpha(const void* a, int64_t n) = 0;
   virtual agp_status set_online_prior(int l, const void* za, int64_t ldza, int64_t ma, const void* invDa, int64_t ldi,
                                       const void* peta1, double prevLa) = 0;
   virtual agp_status online_snapshot(int l, void* invDa_out, int64_t ldi, void* eta1_out, double* prevLa_host) = 0;
@@ -1774,6 +1775,11 @@ struct Svgp : SvgpBase {
     if (!nodes || !weights || nn <= 0) return AGP_ERR_INVALID;
     return upload_gh(nodes, weights, nn);
   }
+  agp_status set_lsm_alpha(const void* a, int64_t n) override {
+    if (lp.kind != AGP_LIK_LOGISTICSOFTMAX || !a || n <= 0 || n > Bp) return AGP_ERR_INVALID;
+    HIPCHK(ctx, hipMemcpyAsync(alpha, a, sizeof(T) * n, hipMemcpyDeviceToDevice, st()));
+    return AGP_OK;
+  }
   agp_status get_lik_param(double* out) override {
     if (!out) return AGP_ERR_INVALID;
     if (lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_HETEROSCEDASTIC) {
@@ -2510,6 +2516,10 @@ agp_status agp_svgp_set_quadrature(agp_svgp* h, const double* gh_nodes_host, con
                                    int32_t n_nodes) {
   HCHK(h);
   return h->impl->set_quadrature(gh_nodes_host, gh_weights_host, n_nodes);
+}
+agp_status agp_svgp_set_lsm_alpha(agp_svgp* h, const void* alpha, int64_t n) {
+  HCHK(h);
+  return h->impl->set_lsm_alpha(alpha, n);
 }
 agp_status agp_svgp_get_lik_param(agp_svgp* h, double* out) {
   HCHK(h);

@@ -1,0 +1,140 @@
+"""save_trained_model(filename, model) / load_trained_model(filename)  -- documented by the reference as "in construction"
+(docs/src/userguide.md:207-215) and absent from its src; here they are the host half of the checkpoint / resume story
+(SURVEY.md section 5): everything a handle needs is exported through the C ABI (agp_svgp_get_state / get_kernel / get_Z /
+get_opt_state / get_lik_param / get_A) into one .npz and pushed back into a fresh handle on load.  Unlike the reference's
+note, a reloaded model CAN be trained further (the Robbins-Monro counter travels with it; ADAM moments restart).
+"""
+from __future__ import annotations
+
+import json
+
+import numpy as np
+
+from . import kernels as K
+from . import likelihoods as LK
+from .svgp import ADAM, MOSVGP, SVGP, AnalyticSVI, AnalyticVI, RobbinsMonro
+
+_KERNELS = {"SqExponentialKernel": K.SqExponentialKernel, "Matern52Kernel": K.Matern52Kernel,
+            "Matern32Kernel": K.Matern32Kernel, "ExponentialKernel": K.ExponentialKernel}
+
+
+def _kernel_spec(k):
+    tr = k.transform
+    if type(k).__name__ not in _KERNELS:
+        raise TypeError(f"cannot serialise kernel {type(k).__name__}")
+    ard = isinstance(tr, K.ARDTransform)
+    scale = tr.v.tolist() if ard else (float(tr.s) if tr is not None else 1.0)
+    return {"base": type(k).__name__, "variance": float(k.variance), "ard": ard, "scale": scale}
+
+
+def _kernel_from(spec):
+    k = _KERNELS[spec["base"]]()
+    k = k @ (K.ARDTransform(np.asarray(spec["scale"])) if spec["ard"] else K.ScaleTransform(spec["scale"]))
+    return spec["variance"] * k
+
+
+def _lik_spec(l):
+    d = {"type": type(l).__name__}
+    for a in ("sigma2", "nu", "sigma", "beta", "lam", "r", "n_class", "class_mapping"):
+        if hasattr(l, a):
+            v = getattr(l, a)
+            d[a] = v if not isinstance(v, np.generic) else v.item()
+    return d
+
+
+def _lik_from(d):
+    t = d["type"]
+    if t == "GaussianLikelihood":
+        return LK.GaussianLikelihood(d["sigma2"])
+    if t == "LogisticLikelihood":
+        return LK.LogisticLikelihood()
+    if t == "StudentTLikelihood":
+        return LK.StudentTLikelihood(d["nu"], d["sigma"])
+    if t == "LogisticSoftMaxLikelihood":
+        return LK.LogisticSoftMaxLikelihood(d["class_mapping"] if d.get("class_mapping") else d["n_class"])
+    if t == "LaplaceLikelihood":
+        return LK.LaplaceLikelihood(d["beta"])
+    if t == "BayesianSVM":
+        return LK.BayesianSVM()
+    if t == "PoissonLikelihood":
+        return LK.PoissonLikelihood(d["lam"])
+    if t == "NegBinomialLikelihood":
+        return LK.NegBinomialLikelihood(d["r"])
+    if t == "HeteroscedasticLikelihood":
+        return LK.HeteroscedasticLikelihood(d["lam"])
+    raise ValueError(f"unknown likelihood {t}")
+
+
+def save_trained_model(filename: str, model: SVGP) -> None:
+    """save_trained_model(filename, model): kernels, inducing points, natural parameters, likelihood state, mixing weights."""
+    if model._h is None:
+        raise RuntimeError("the model has no device state yet: train it first")
+    model._pull_hypers()
+    model._pull_lik_state()
+    mo = isinstance(model, MOSVGP)
+    inf = model.inference
+    opt = inf.optimiser or RobbinsMonro()
+    meta = {
+        "class": "MOSVGP" if mo else "SVGP",
+        "kernels": [_kernel_spec(k) for k in model.kernels],
+        "likelihood": [_lik_spec(l) for l in model.likelihood.likelihoods] if mo else _lik_spec(model.likelihood),
+        "stochastic": bool(inf.stoch), "batchsize": int(inf.batchsize), "n_iter": int(inf.n_iter),
+        "rm": [opt.kappa, opt.tau], "T": str(model.T), "elbo_mode": model.elbo_mode,
+        "k_opt": model.k_opt.eta if model.k_opt else None, "z_opt": model.z_opt.eta if model.z_opt else None,
+        "atfrequency": model.atfrequency, "mean": model.mean if np.isscalar(model.mean) or model.mean is None else None,
+    }
+    import ctypes as C
+
+    from . import capi
+
+    n_opt = C.c_int64()
+    model._chk(capi.lib().agp_svgp_get_opt_state(model._h, C.byref(n_opt)))
+    arrays = {"meta": np.array(json.dumps(meta)), "n_opt": np.array(n_opt.value)}
+    for l in range(model.n_latent):
+        mu, Sig, e1, e2 = model.get_state(l)
+        arrays[f"eta1_{l}"], arrays[f"eta2_{l}"], arrays[f"Z_{l}"] = e1, e2, model.Zs[l]
+    if mo:
+        arrays["A"] = model.get_A()
+    if isinstance(model.likelihood, LK.LogisticSoftMaxLikelihood) and inf.batchsize > 0:
+        arrays["lsm_alpha"] = model.get_matrix(capi.VEC_ALPHA, 0, int(inf.batchsize))  # carried between minibatches
+    if isinstance(model.mean, (list, np.ndarray)):
+        arrays["mean_vec"] = np.asarray(model.mean, dtype=np.float64)
+    np.savez_compressed(filename, **arrays)
+
+
+def load_trained_model(filename: str, *, device=None):
+    """load_trained_model(filename) -> the model with its posterior restored on the device (ready to predict or train on)."""
+    import ctypes as C
+
+    from . import capi
+
+    g = np.load(filename if str(filename).endswith(".npz") else str(filename) + ".npz", allow_pickle=False)
+    meta = json.loads(str(g["meta"]))
+    kernels = [_kernel_from(s) for s in meta["kernels"]]
+    nl = len(kernels)
+    Zs = [g[f"Z_{l}"] for l in range(nl)]
+    inf = AnalyticSVI(meta["batchsize"], optimiser=RobbinsMonro(*meta["rm"])) if meta["stochastic"] else AnalyticVI()
+    T = np.float64 if "64" in meta["T"] else np.float32
+    mean = g["mean_vec"] if "mean_vec" in g.files else meta.get("mean")
+    kw = dict(optimiser=ADAM(meta["k_opt"]) if meta["k_opt"] else False, Zoptimiser=ADAM(meta["z_opt"]) if meta["z_opt"] else False,
+              atfrequency=meta["atfrequency"], mean=mean, T=T, device=device, elbo_mode=meta["elbo_mode"])
+    if meta["class"] == "MOSVGP":
+        model = MOSVGP(kernels, [_lik_from(d) for d in meta["likelihood"]], inf, Zs, A=g["A"], Aoptimiser=False, **kw)
+    else:
+        model = SVGP(kernels, _lik_from(meta["likelihood"]), inf, Zs, **kw)
+    inf.n_iter = meta["n_iter"]
+    h = model._ensure_handle(max(meta["batchsize"], 1))
+    for l in range(nl):
+        model.set_state(l, g[f"eta1_{l}"], g[f"eta2_{l}"])
+    model._chk(capi.lib().agp_svgp_set_opt_state(h, int(g["n_opt"])))
+    lik = model.likelihood
+    if hasattr(lik, "lam") and not isinstance(lik, list):
+        model._chk(capi.lib().agp_svgp_set_lik_param(h, float(lik.lam)))
+    if "lsm_alpha" in g.files:
+        import torch
+
+        a = torch.as_tensor(g["lsm_alpha"], dtype=model.tdtype, device=model._dev()).contiguous()
+        model._chk(capi.lib().agp_svgp_set_lsm_alpha(h, C.c_void_p(a.data_ptr()), a.numel()))
+        model._chk(capi.lib().agp_ctx_sync(model._ctx))
+    model.trained = True
+    return model

@@ -295,6 +295,10 @@ agp_status agp_svgp_set_quadrature(agp_svgp* h, const double* gh_nodes_host, con
 /* likelihood state: the lambda of Poisson (poisson.jl:78) / Heteroscedastic (heteroscedastic.jl:95), which every local
  * update re-estimates; other likelihoods: get returns p0, set is AGP_ERR_INVALID.  get synchronises. */
 agp_status agp_svgp_get_lik_param(agp_svgp* h, double* value_host);
+/* LogisticSoftMax: the Gamma shape alpha of the local variables is the one piece of local state the reference carries from
+ * one minibatch to the next (logisticsoftmax.jl:65-72 starts its fixed point from the previous alpha); read it with
+ * agp_svgp_get_matrix(AGP_VEC_ALPHA), restore it here (device pointer, n <= max_batch) when resuming a saved model. */
+agp_status agp_svgp_set_lsm_alpha(agp_svgp* h, const void* alpha, int64_t n);
 agp_status agp_svgp_set_lik_param(agp_svgp* h, double value);
 /* proba_y  predictions.jl:225-247 + compute_proba : Gaussian / StudentT / Laplace / Heteroscedastic -> (mean, var) ;
  * BayesianSVM / Poisson / NegBinomial -> (E[link(f)], Var) by Gauss-Hermite like logistic ; logistic -> (p, var) by

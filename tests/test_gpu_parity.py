@@ -483,3 +483,31 @@ def test_multioutput_hyper_steps_match_oracle(env, ard, zopt):
         assert _rel(ma.Zs[q], mr.latents[q].Z) < 1e-8
         mu, Sig, e1, e2 = ma.get_state(q)
         assert _rel(e2, mr.latents[q].eta2) < 1e-7 and _rel(mu, mr.latents[q].mu) < 1e-7
+
+
+@pytest.mark.parametrize("likname", ["logistic", "poisson", "logisticsoftmax"])
+def test_save_and_load_trained_model_round_trip(env, likname, tmp_path):
+    """save_trained_model / load_trained_model (docs/src/userguide.md:207-215; checkpoint / resume of SURVEY section 5):
+    the reloaded model predicts identically AND continues training on the same trajectory as the uninterrupted one."""
+    AGP = env["AGP"]
+    rng = np.random.default_rng(12)
+    B = 64
+    X, y, ma, _ = _models(env, likname, rng, True, B)
+    _, _, mb, _ = _models(env, likname, np.random.default_rng(12), True, B)
+    idx = [rng.choice(len(X), B, replace=False) for _ in range(8)]
+    AGP.train_(ma, X, y, 8, idx_stream=idx)              # uninterrupted
+    AGP.train_(mb, X, y, 4, idx_stream=idx[:4])          # interrupted after 4 ...
+    path = str(tmp_path / "model.npz")
+    AGP.save_trained_model(path, mb)
+    mc = AGP.load_trained_model(path)
+    Xt = rng.random((40, X.shape[1]))
+    pb, pc = AGP.predict_f(mb, Xt, cov=True), AGP.predict_f(mc, Xt, cov=True)
+    for a, b in zip(np.atleast_2d(pb[0]), np.atleast_2d(pc[0])):
+        assert _rel(b, a) < 1e-10
+    AGP.train_(mc, X, y, 4, idx_stream=idx[4:], state=True)  # ... resumed from the file
+    for l in range(ma.n_latent):
+        mu_a, Sig_a, e1a, e2a = ma.get_state(l)
+        mu_c, Sig_c, e1c, e2c = mc.get_state(l)
+        assert _rel(e2c, e2a) < 1e-8 and _rel(mu_c, mu_a) < 1e-7
+    if hasattr(ma.likelihood, "lam"):
+        assert mc.likelihood.lam == pytest.approx(ma.likelihood.lam, rel=1e-8)

@@ -24,6 +24,8 @@ struct agp_ctx {
   std::string err;
   int32_t* flow_flags = nullptr;  // dependency flags of the dataflow factorisation (k_chol_flow)
   int64_t flow_cap = 0;
+  void* tri_scratch = nullptr;    // n x n scratch of the recursive-doubling triangular inverse
+  size_t tri_bytes = 0;
 };
 
 #define HIPCHK(ctx, expr)                                                                       \
@@ -70,6 +72,33 @@ static agp_status dmalloc(agp_ctx* c, T** p, int64_t n) {
 // ---- linear-algebra drivers on padded matrices ---------------------------------------------------------------
 // Cholesky (lower, in place; diagonal factors in Dg) of the n x n (n = nt*64) matrix A with `ne` extension row blocks
 // E <- E L^-T (augmented Cholesky): nt launches of k_chol_step; do_x adds X = L^-1 (one extra row launch per column).
+// X = L^-1 (all off-diagonal tiles) from L and the diagonal inverses already in X: recursive doubling, 2 launches per level
+template <typename T>
+static agp_status trtri_levels(agp_ctx* c, const T* A, int64_t ld, T* X, int64_t ldx, int64_t nt) {
+  if (nt <= 1) return AGP_OK;
+  const int64_t n = nt * TILE;
+  const size_t need = sizeof(T) * (size_t)n * (size_t)n;
+  if (c->tri_bytes < need) {
+    if (c->tri_scratch) {
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipFree(c->tri_scratch);
+    }
+    c->tri_scratch = nullptr;
+    c->tri_bytes = 0;
+    if (hipMalloc(&c->tri_scratch, need) != hipSuccess) return AGP_ERR_NOMEM;
+    c->tri_bytes = need;
+  }
+  T* S = (T*)c->tri_scratch;
+  for (int64_t bs = 1; bs < nt; bs *= 2) {
+    const int64_t pairs = (nt + 2 * bs - 1) / (2 * bs);
+    dim3 g((unsigned)bs, (unsigned)bs, (unsigned)pairs);
+    hipLaunchKernelGGL((k_trtri_level<T>), g, dim3(NTHREADS), 0, c->stream, A, ld, X, ldx, S, n, nt, bs, 0);
+    hipLaunchKernelGGL((k_trtri_level<T>), g, dim3(NTHREADS), 0, c->stream, A, ld, X, ldx, S, n, nt, bs, 1);
+  }
+  LAUNCHCHK(c);
+  return AGP_OK;
+}
+
 template <typename T>
 static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int64_t ldx, T* Dg, T* E, int64_t lde,
                               int64_t ne, int do_x, int32_t* info_dev, int64_t nvalid) {
@@ -128,10 +157,9 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     const int64_t nU = (k >= 1 && nr > 0) ? nr * (nr + 1) / 2 + ne * nr : 0;
     hipLaunchKernelGGL((k_chol_step<T>), dim3((unsigned)(nP + nU)), dim3(CHOL_THREADS), 0, c->stream, bt, ld, ldx, lde, ne,
                        do_x, k, nt, info_dev, nvalid);
-    if (do_x && k >= 1)
-      hipLaunchKernelGGL((k_trtri_row<T>), dim3((unsigned)k), dim3(NTHREADS), 0, c->stream, (const T*)A, ld, X, ldx, k);
   }
   LAUNCHCHK(c);
+  if (do_x) AGPCHK(trtri_levels<T>(c, (const T*)A, ld, X, ldx, nt));
   return AGP_OK;
 }
 
@@ -1048,7 +1076,7 @@ struct Svgp : SvgpBase {
       hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)x_last, ldx_last, idx_last, B,
                          (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, (const T*)hyH3, mp,
                          hy_pvar, hy_pscale, hy_pZ, mp);
-      hipLaunchKernelGGL((k_hyper_reduce_scalar<T>), dim3(1), dim3(128), 0, st(), tiles, D, (const double*)hy_pvar,
+      hipLaunchKernelGGL((k_hyper_reduce_scalar<T>), dim3((unsigned)(D + 1)), dim3(256), 0, st(), tiles, D, (const double*)hy_pvar,
                          (const double*)hy_pscale, hy_g, 1.0);
       hipLaunchKernelGGL((k_hyper_reduce_Z<T>), grid1(m * D), dim3(256), 0, st(), (int64_t)gk.y, m, mp, D,
                          (const T*)hy_pZ, hy_dZ, T(1), 0);
@@ -1060,7 +1088,7 @@ struct Svgp : SvgpBase {
       hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)g.Z, D, (const int64_t*)nullptr,
                          m, (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, (const T*)Tw2, mp,
                          hy_pvar, hy_pscale, hy_pZ, mp);
-      hipLaunchKernelGGL((k_hyper_reduce_scalar<T>), dim3(1), dim3(128), 0, st(), tiles, D, (const double*)hy_pvar,
+      hipLaunchKernelGGL((k_hyper_reduce_scalar<T>), dim3((unsigned)(D + 1)), dim3(256), 0, st(), tiles, D, (const double*)hy_pvar,
                          (const double*)hy_pscale, hy_g, 1.0);
       hipLaunchKernelGGL((k_hyper_reduce_Z<T>), grid1(m * D), dim3(256), 0, st(), (int64_t)gk.y, m, mp, D,
                          (const T*)hy_pZ, hy_dZ, T(2), 1);
@@ -1431,7 +1459,7 @@ struct Svgp : SvgpBase {
       HIPCHK(ctx, hipMemcpyAsync(g.v, g.Wbuf, sizeof(T) * mp, hipMemcpyDeviceToDevice, st()));
     }
     AGPCHK(xtx_padded<T>(ctx, g.Xa, mp, mp, g.Sigma, mp));
-    hipLaunchKernelGGL((k_trmv_lower_t<T>), grid1(mp), dim3(256), 0, st(), (const T*)g.Xa, mp, mp, (const T*)g.v, g.mu);
+    hipLaunchKernelGGL((k_trmv_lower_t<T>), dim3((unsigned)(mp / 64)), dim3(1024), 0, st(), (const T*)g.Xa, mp, mp, (const T*)g.v, g.mu);
     LAUNCHCHK(ctx);
     g.post_valid = true;
     return AGP_OK;
@@ -1894,9 +1922,10 @@ agp_status agp_ctx_create(int32_t device, void* hip_stream, agp_ctx** out) {
 }
 
 agp_status agp_ctx_destroy(agp_ctx* ctx) {
-  if (ctx && ctx->flow_flags) {
+  if (ctx && (ctx->flow_flags || ctx->tri_scratch)) {
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(ctx->flow_flags);
+    if (ctx->flow_flags) (void)hipFree(ctx->flow_flags);
+    if (ctx->tri_scratch) (void)hipFree(ctx->tri_scratch);
   }
   delete ctx;
   return AGP_OK;

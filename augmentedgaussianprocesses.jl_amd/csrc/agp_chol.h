@@ -763,6 +763,38 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_flow(T* A, int64_t ld, T*
 #undef FLOW_TR
 }
 
+// ---------------------------------------------------------------------------------------------------
+// X = L^-1 from the diagonal inverses by recursive doubling (replaces the chain of nt-1 dependent row launches):
+//   level with block size bs tiles: for every pair (left block [b, b+bs), right block [b+bs, b+bs+nr)), nr <= bs:
+//       T   = L21 X11        (phase 0, into scratch at the coordinates of X21)
+//       X21 = -X22 T         (phase 1)
+// grid (bs, bs, pairs) of 64x64 tiles, 256 threads; log2(nt) levels x 2 launches, each a batch of independent tile GEMMs.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_trtri_level(const T* __restrict__ A, int64_t ld, T* __restrict__ X, int64_t ldx,
+                                                          T* __restrict__ S, int64_t lds, int64_t nt, int64_t bs,
+                                                          int phase) {
+  __shared__ __attribute__((aligned(16))) T smem[SMEM_ELEMS];
+  const int64_t base = (int64_t)blockIdx.z * 2 * bs, r0 = base + bs, c0 = base;
+  if (r0 >= nt) return;
+  const int64_t nr = (nt - r0) < bs ? (nt - r0) : bs;
+  const int64_t bx = blockIdx.x, by = blockIdx.y;
+  if (by >= nr) return;
+  Acc<T> acc;
+  acc.zero();
+  if (phase == 0) {
+    // T(by, bx) = sum_k L[r0+by][c0+k] X[c0+k][c0+bx] ; X11 is lower triangular: k >= bx
+    gemm_tile<T, KC, RC>(A + (r0 + by) * TILE * ld + c0 * TILE, ld, X + c0 * TILE * ldx + (c0 + bx) * TILE, ldx, bx * TILE,
+                         bs * TILE, nullptr, acc, smem);
+    acc_foreach<T>(acc, [&](int r, int c, T val) { S[((r0 + by) * TILE + r) * lds + (c0 + bx) * TILE + c] = val; });
+  } else {
+    // X21(by, bx) = -sum_k X[r0+by][r0+k] T[r0+k][c0+bx] ; X22 is lower triangular: k <= by
+    gemm_tile<T, KC, RC>(X + (r0 + by) * TILE * ldx + r0 * TILE, ldx, S + r0 * TILE * lds + (c0 + bx) * TILE, lds, 0,
+                         (by + 1) * TILE, nullptr, acc, smem);
+    acc_foreach<T>(acc, [&](int r, int c, T val) { X[((r0 + by) * TILE + r) * ldx + (c0 + bx) * TILE + c] = -val; });
+  }
+}
+
 // copy the diagonal factors from Dg into the diagonal tiles of an n x n matrix (state export / building blocks)
 template <typename T>
 __global__ void k_publish_diag(T* __restrict__ A, int64_t ld, const T* __restrict__ Dg) {

@@ -239,18 +239,16 @@ __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restric
   }
 }
 
-// out[0] = sum pvar ; out[1 + d] = sum_tiles pscale[tile][d]   (one workgroup, deterministic order)
+// out[0] += wgt * sum pvar ; out[1 + d] += wgt * sum_tiles pscale[tile][d] : one workgroup per output, fixed-order tree
 template <typename T>
 __global__ void k_hyper_reduce_scalar(int64_t ntiles, int64_t D, const double* __restrict__ pvar,
                                       const double* __restrict__ pscale, double* __restrict__ out, double wgt) {
-  int d = threadIdx.x;  // thread 0: variance, threads 1..D: scales
-  if (d > D) return;
+  __shared__ double red[16];
+  const int d = blockIdx.x;  // 0: variance, 1..D: scales
   double s = 0.0;
-  if (d == 0)
-    for (int64_t t = 0; t < ntiles; ++t) s += pvar[t];
-  else
-    for (int64_t t = 0; t < ntiles; ++t) s += pscale[t * D + d - 1];
-  out[d] += wgt * s;
+  for (int64_t t = threadIdx.x; t < ntiles; t += blockDim.x) s += (d == 0) ? pvar[t] : pscale[t * D + d - 1];
+  s = block_sum<double>(s, red);
+  if (threadIdx.x == 0) out[d] += wgt * s;
 }
 
 // dZ[j][d] (+)= wgt * sum_by pZ[by][j][d]

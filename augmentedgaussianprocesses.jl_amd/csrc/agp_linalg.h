@@ -180,15 +180,26 @@ __global__ void k_trmv_lower(const T* __restrict__ X, int64_t ld, int64_t n, con
   if (lane == 0) y[row] = s;
 }
 
-// y[j] = sum_{k >= j} X[k][j] x[k]   (transpose of the above: mu = X' v) ; one thread per column, coalesced
+// y[j] = sum_{k >= j} X[k][j] x[k]   (transpose of the above: mu = X' v).  One workgroup per 64 columns, 16 row groups of
+// 64 lanes (coalesced 512-byte rows); the 16 partial sums are combined in a fixed order through LDS.  blockDim = 1024.
 template <typename T>
-__global__ void k_trmv_lower_t(const T* __restrict__ X, int64_t ld, int64_t n, const T* __restrict__ x,
-                               T* __restrict__ y) {
-  int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (j >= n) return;
+__global__ __launch_bounds__(1024) void k_trmv_lower_t(const T* __restrict__ X, int64_t ld, int64_t n,
+                                                        const T* __restrict__ x, T* __restrict__ y) {
+  __shared__ T part[16][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t j = blockIdx.x * 64 + col;
   T s = T(0);
-  for (int64_t k = j; k < n; ++k) s += X[k * ld + j] * x[k];
-  y[j] = s;
+  if (j < n)
+    for (int64_t k = blockIdx.x * 64 + grp; k < n; k += 16)
+      if (k >= j) s += X[k * ld + j] * x[k];
+  part[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && j < n) {
+    T t = T(0);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += part[g][col];
+    y[j] = t;
+  }
 }
 
 // y[i] = sum_j M[i][j] x[j], i < rows (one wave per row)

@@ -353,6 +353,7 @@ struct Svgp : SvgpBase {
     T* apred = nullptr;   // K^-1 mu
     bool K_stale = true, post_valid = false, pred_valid = false, predvar_valid = false, kappa_valid = false;
     bool keep_last = false;  // this step reuses kappa / K~ of the previous full-batch step
+    bool via_inverse = false;  // this step gets W, v from the available inverse factor instead of a new factorisation
     // hyper-parameter optimiser state (ADAM): kernel parameters on the host, Z on the device
     std::vector<double> k_m, k_v;
     int k_step = 0, z_step = 0;
@@ -898,6 +899,18 @@ struct Svgp : SvgpBase {
       } else {
         HIPCHK(ctx, hipMemcpyAsync(g.Wbuf, g.kappa, sizeof(T) * Bq * mp, hipMemcpyDeviceToDevice, st()));
       }
+      // When the factor of the CURRENT -2*eta2 and its inverse X_a are still around (a materialize() since the last
+      // global update: ELBO callback, hyper-parameter step, prediction), W = kappa X_a' and v = X_a eta1 are one GEMM and
+      // one triangular mat-vec -- no second 16-launch factorisation chain of the same matrix.
+      g.via_inverse = g.la_state == 1 && g.xa_valid;
+      if (g.via_inverse) {
+        AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.kappa, mp, g.Xa, mp, Bq, mp, mp, 1, g.Wbuf, mp, nullptr, 0, nullptr, nullptr,
+                                      nullptr, 0)));
+        hipLaunchKernelGGL((k_trmv_lower<T>), grid1(mp * 64), dim3(256), 0, st(), (const T*)g.Xa, mp, mp, (const T*)g.eta1,
+                           g.Wbuf + Bq * mp);
+        LAUNCHCHK(ctx);
+        continue;
+      }
       // pre-factorisation part of aug_factor: -2*eta2 back into La if it holds a factor, extension rows [eta1' ; 0]
       if (g.la_state != 0) {
         hipLaunchKernelGGL((k_copy2d<T>), grid2(mp, mp), blk2, 0, st(), (const T*)g.eta2, mp, mp, mp, g.La, mp, mp, mp,
@@ -907,23 +920,28 @@ struct Svgp : SvgpBase {
                          (const T*)g.eta1);
       LAUNCHCHK(ctx);
     }
-    // the augmented Cholesky factorisations of all latents share their launches (independent chains overlap)
-    AGPCHK(timing_begin());
-    for (int l0 = 0; l0 < nl; l0 += CHOL_MAXB) {
-      const int nb = std::min(CHOL_MAXB, nl - l0);
-      CholBatch<T> bt{};
-      for (int q = 0; q < nb; ++q) {
-        Latent& g = lat[l0 + q];
-        bt.A[q] = g.La;
-        bt.X[q] = g.Xa;
-        bt.Dg[q] = g.DgA;
-        bt.E[q] = g.Wbuf;
-        g.la_state = 1;
-        g.xa_valid = false;
+    // the augmented Cholesky factorisations of the remaining latents share their launches (independent chains overlap)
+    {
+      std::vector<int> todo;
+      for (int l = 0; l < nl; ++l)
+        if (!lat[l].via_inverse) todo.push_back(l);
+      if (!todo.empty()) AGPCHK(timing_begin());
+      for (size_t l0 = 0; l0 < todo.size(); l0 += CHOL_MAXB) {
+        const int nb = (int)std::min<size_t>(CHOL_MAXB, todo.size() - l0);
+        CholBatch<T> bt{};
+        for (int q = 0; q < nb; ++q) {
+          Latent& g = lat[todo[l0 + q]];
+          bt.A[q] = g.La;
+          bt.X[q] = g.Xa;
+          bt.Dg[q] = g.DgA;
+          bt.E[q] = g.Wbuf;
+          g.la_state = 1;
+          g.xa_valid = false;
+        }
+        AGPCHK(potrf_fused_batch<T>(ctx, bt, nb, mp, mp, mp, mp, Bq / TILE + 1, info_dev, m));
       }
-      AGPCHK(potrf_fused_batch<T>(ctx, bt, nb, mp, mp, mp, mp, Bq / TILE + 1, info_dev, m));
+      if (!todo.empty()) AGPCHK(timing_end(mp / TILE));
     }
-    AGPCHK(timing_end(mp / TILE));
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
       const bool keep = g.keep_last;

@@ -1497,6 +1497,9 @@ struct Svgp : SvgpBase {
         hipLaunchKernelGGL((k_fill<T>), grid1(Bp), dim3(256), 0, st(), alpha, Bp, (T)desc.lik.n_class);
       }
       if (mo) HIPCHK(ctx, hipMemcpyAsync(mo_th_save, mo_th, sizeof(T) * MO_MAXT * Bp, hipMemcpyDeviceToDevice, st()));
+      // the Gaussian KL below needs Sigma, mu anyway: factor -2*eta2 WITH its inverse first, so that the local step on the
+      // evaluation batch (and the next training step) take W, v from the inverse instead of two more factorisation chains
+      for (auto& g : lat) AGPCHK(materialize(g));
       AGPCHK(step_local(x, ldx, y, idx, B, rho, true));
       if (lsm) {
         for (int it = 0; it < 2; ++it) {

@@ -266,6 +266,7 @@ struct SvgpBase {
   virtual agp_status proba_y(const void* xt, int64_t ldx, int64_t nt, const double* nodes, const double* weights,
                              int nn, void* o0, void* o1) = 0;
   virtual agp_status set_quadrature(const double* nodes, const double* weights, int nn) = 0;
+  virtual agp_status hyper_state(int l, int set, double* k_m, double* k_v, int32_t* k_step) = 0;
   virtual agp_status set_lsm_alpha(const void* a, int64_t n) = 0;
   virtual agp_status set_online_prior(int l, const void* za, int64_t ldza, int64_t ma, const void* invDa, int64_t ldi,
                                       const void* peta1, double prevLa) = 0;
@@ -367,7 +368,8 @@ struct Svgp : SvgpBase {
     bool on = false, on_dirty = false, on_first = false;
     int64_t ma = 0, map = 0;
     T *Za = nullptr, *invDa = nullptr, *peta1 = nullptr, *kappa_a = nullptr, *Kab = nullptr, *Kta = nullptr, *onT = nullptr,
-      *onQ = nullptr, *kinv_mu0_on = nullptr, *Kinv_on = nullptr, *ov0 = nullptr, *ov1 = nullptr;
+      *onQ = nullptr, *kinv_mu0_on = nullptr, *Kinv_on = nullptr, *ov0 = nullptr, *ov1 = nullptr, *oh1 = nullptr,
+      *oh2 = nullptr, *oh3 = nullptr;
     double prevLa = 0.0;
   };
   std::vector<Latent> lat;
@@ -694,10 +696,12 @@ struct Svgp : SvgpBase {
 
   // ---- OnlineSVGP streaming prior ------------------------------------------------------------------------------------
   void free_online(Latent& g) {
-    T* ps[] = {g.Za, g.invDa, g.peta1, g.kappa_a, g.Kab, g.Kta, g.onT, g.onQ, g.kinv_mu0_on, g.Kinv_on, g.ov0, g.ov1};
+    T* ps[] = {g.Za, g.invDa, g.peta1, g.kappa_a, g.Kab, g.Kta, g.onT, g.onQ, g.kinv_mu0_on, g.Kinv_on, g.ov0, g.ov1,
+               g.oh1, g.oh2, g.oh3};
     for (T* p : ps)
       if (p) dfree(p);
     g.Za = g.invDa = g.peta1 = g.kappa_a = g.Kab = g.Kta = g.onT = g.onQ = g.kinv_mu0_on = g.Kinv_on = g.ov0 = g.ov1 = nullptr;
+    g.oh1 = g.oh2 = g.oh3 = nullptr;
     g.on = false;
   }
 
@@ -725,6 +729,9 @@ struct Svgp : SvgpBase {
     AGPCHK(dmalloc(ctx, &g.Kinv_on, mp * mp));
     AGPCHK(dmalloc(ctx, &g.ov0, map));
     AGPCHK(dmalloc(ctx, &g.ov1, map));
+    AGPCHK(dmalloc(ctx, &g.oh1, map * mp));
+    AGPCHK(dmalloc(ctx, &g.oh2, map * mp));
+    AGPCHK(dmalloc(ctx, &g.oh3, map * mp));
     hipLaunchKernelGGL((k_copy2d_zero<T>), grid2(map, map), blk2, 0, st(), (const T*)invDa, ldi, ma, ma, g.invDa, map, map, map);
     HIPCHK(ctx, hipMemsetAsync(g.peta1, 0, sizeof(T) * map, st()));
     HIPCHK(ctx, hipMemcpyAsync(g.peta1, peta1, sizeof(T) * ma, hipMemcpyDeviceToDevice, st()));
@@ -1099,6 +1106,41 @@ struct Svgp : SvgpBase {
       hipLaunchKernelGGL((k_hyper_reduce_Z<T>), grid1(m * D), dim3(256), 0, st(), (int64_t)gk.y, m, mp, D,
                          (const T*)hy_pZ, hy_dZ, T(1), 0);
     }
+    const bool online_x = g.on && !g.on_first;
+    if (online_x) {
+      // -extraKL (KLdivergences.jl:30-54) is part of the differentiated ELBO; its kernel matrices K_ab, kappa_a, K~_a are
+      // recomputed with the candidate kernel / Z by compute_kappa(::OnlineVarLatent):
+      //   G_kappa_a = D kappa_a (Sigma + mu mu') - eta_a mu' - D K_ab/2 ; G_Kab = G_kappa_a K^-1 - D kappa_a/2 ;
+      //   G_K -= sym(kappa_a' G_kappa_a K^-1) ; G_Ka = D/2
+      const int64_t map = g.map, ma = g.ma;
+      if (map / TILE > std::max(Bp / TILE, mp / TILE)) {
+        ctx->err = "online hyper-gradient: more old inducing points than the scratch was sized for";
+        return AGP_ERR_UNSUPPORTED;
+      }
+      dim3 gam((unsigned)(mp / TILE), (unsigned)(map / TILE));
+      hipLaunchKernelGGL((k_add_outer<T>), grid2(mp, mp), blk2, 0, st(), (const T*)g.Sigma, (const T*)g.mu, mp, m, Tw);
+      AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.kappa_a, mp, Tw, mp, map, mp, mp, 0, g.oh1, mp, nullptr, 0, nullptr, nullptr, nullptr,
+                                    0)));                                                       // kappa_a (Sigma + mu mu')
+      hipLaunchKernelGGL((k_gemm_tn<T, 1>), gam, dim3(NTHREADS), 0, st(), (const T*)g.invDa, map, (const T*)g.oh1, mp, map,
+                         g.oh2, mp);                                                              // D (.)
+      hipLaunchKernelGGL((k_gemm_tn<T, 1>), gam, dim3(NTHREADS), 0, st(), (const T*)g.invDa, map, (const T*)g.Kab, mp, map,
+                         g.oh3, mp);                                                              // D K_ab
+      hipLaunchKernelGGL((k_online_gkappa<T>), grid2(map, mp), blk2, 0, st(), ma, m, map, mp, mp, (const T*)g.peta1,
+                         (const T*)g.mu, (const T*)g.oh3, g.oh2);                                 // G_kappa_a
+      LAUNCHCHK(ctx);
+      AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.oh2, mp, g.Kinv, mp, map, mp, mp, 0, g.oh1, mp, nullptr, 0, nullptr, nullptr,
+                                    nullptr, 0)));                                              // G_kappa_a K^-1
+      {
+        dim3 gmm((unsigned)(mp / TILE), (unsigned)(mp / TILE));
+        hipLaunchKernelGGL((k_gemm_tn<T, 1>), gmm, dim3(NTHREADS), 0, st(), (const T*)g.kappa_a, mp, (const T*)g.oh1, mp, map,
+                           Tw, mp);                                                               // kappa_a' (G_kappa_a K^-1)
+      }
+      hipLaunchKernelGGL((k_sub_sym<T>), grid2(m, m), blk2, 0, st(), Tw2, (const T*)Tw, mp, m);
+      hipLaunchKernelGGL((k_gemm_tn<T, 1>), gam, dim3(NTHREADS), 0, st(), (const T*)g.invDa, map, (const T*)g.kappa_a, mp, map,
+                         g.oh3, mp);                                                              // D kappa_a
+      hipLaunchKernelGGL((k_axpy2d<T>), grid2(map, mp), blk2, 0, st(), map, mp, mp, T(-0.5), (const T*)g.oh3, g.oh1);  // G_Kab
+      LAUNCHCHK(ctx);
+    }
     // backward through kernelmatrix(k, Z) : both arguments are Z and G_K is symmetric -> twice the second-argument part
     {
       dim3 gk((unsigned)(mp / TILE), (unsigned)(mp / TILE));
@@ -1110,6 +1152,25 @@ struct Svgp : SvgpBase {
                          (const double*)hy_pscale, hy_g, 1.0);
       hipLaunchKernelGGL((k_hyper_reduce_Z<T>), grid1(m * D), dim3(256), 0, st(), (int64_t)gk.y, m, mp, D,
                          (const T*)hy_pZ, hy_dZ, T(2), 1);
+    }
+    if (online_x) {
+      // K_ab = k(Z_a, Z): gradient w.r.t. the kernel parameters and the second argument ; K_a = k(Z_a, Z_a): parameters only
+      const int64_t map = g.map, ma = g.ma;
+      dim3 gk((unsigned)(mp / TILE), (unsigned)(map / TILE));
+      hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
+                         (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, (const T*)g.oh1, mp, hy_pvar,
+                         hy_pscale, hy_pZ, mp);
+      hipLaunchKernelGGL((k_hyper_reduce_scalar<T>), dim3((unsigned)(D + 1)), dim3(256), 0, st(), (int64_t)gk.x * gk.y, D,
+                         (const double*)hy_pvar, (const double*)hy_pscale, hy_g, 1.0);
+      hipLaunchKernelGGL((k_hyper_reduce_Z<T>), grid1(m * D), dim3(256), 0, st(), (int64_t)gk.y, m, mp, D, (const T*)hy_pZ,
+                         hy_dZ, T(1), 1);
+      dim3 ga((unsigned)(map / TILE), (unsigned)(map / TILE));
+      hipLaunchKernelGGL((k_kernel_backward<T>), ga, dim3(NTHREADS), 0, st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
+                         (const T*)g.Za, D, ma, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, (const T*)g.invDa, map,
+                         hy_pvar, hy_pscale, hy_pZ, map);
+      hipLaunchKernelGGL((k_hyper_reduce_scalar<T>), dim3((unsigned)(D + 1)), dim3(256), 0, st(), (int64_t)ga.x * ga.y, D,
+                         (const double*)hy_pvar, (const double*)hy_pscale, hy_g, 0.5);
+      LAUNCHCHK(ctx);
     }
     hipLaunchKernelGGL((k_hyper_sum<T>), dim3(1), dim3(1024), 0, st(), B, (const T*)hy_gs, (double)rho, hy_g);
     LAUNCHCHK(ctx);
@@ -1138,6 +1199,25 @@ struct Svgp : SvgpBase {
 
   // update_hyperparameters!(m, state, x, y): ADAM ASCENT; positive kernel parameters are stepped in log space
   // (update_kernel!, autotuning_utils.jl:63-67), Z directly (update_Z!, :70-76).  K is refreshed before the next step.
+  // ADAM moments of the kernel-parameter optimiser (1 + D entries: variance, scales; a ScaleTransform uses entry 1 only)
+  agp_status hyper_state(int l, int set, double* k_m, double* k_v, int32_t* k_step) override {
+    if (l < 0 || l >= nl || !k_m || !k_v || !k_step) return AGP_ERR_INVALID;
+    Latent& g = lat[l];
+    const size_t np = 1 + (g.k.ard ? (size_t)D : 1);
+    if (set) {
+      g.k_m.assign(k_m, k_m + np);
+      g.k_v.assign(k_v, k_v + np);
+      g.k_step = *k_step;
+    } else {
+      for (size_t i = 0; i < np; ++i) {
+        k_m[i] = i < g.k_m.size() ? g.k_m[i] : 0.0;
+        k_v[i] = i < g.k_v.size() ? g.k_v[i] : 0.0;
+      }
+      *k_step = g.k_m.size() == np ? g.k_step : 0;
+    }
+    return AGP_OK;
+  }
+
   agp_status hyper_step() override {
     if (!hy_k && !hy_z) return AGP_OK;
     for (int l = 0; l < nl; ++l) {
@@ -2562,6 +2642,11 @@ agp_status agp_svgp_online_first_step(agp_svgp* h_new, agp_svgp* h_old, const vo
   return n->step_global(true);
 }
 
+agp_status agp_svgp_hyper_opt_state(agp_svgp* h, int32_t latent, int32_t set, double* k_m_host, double* k_v_host,
+                                    int32_t* k_step_host) {
+  HCHK(h);
+  return h->impl->hyper_state(latent, set, k_m_host, k_v_host, k_step_host);
+}
 agp_status agp_svgp_set_quadrature(agp_svgp* h, const double* gh_nodes_host, const double* gh_weights_host,
                                    int32_t n_nodes) {
   HCHK(h);

@@ -694,6 +694,41 @@ __global__ void k_sub2d(T* __restrict__ A, const T* __restrict__ Bm, int64_t ld,
   if (r < n && c < n) A[r * ld + c] -= Bm[r * ld + c];
 }
 
+// out = A + x x' on the n x n block (Sigma + mu mu')
+template <typename T>
+__global__ void k_add_outer(const T* __restrict__ A, const T* __restrict__ x, int64_t ld, int64_t n, T* __restrict__ out) {
+  int64_t r = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= ld || c >= ld) return;
+  out[r * ld + c] = (r < n && c < n) ? A[r * ld + c] + x[r] * x[c] : T(0);
+}
+
+// G_kappa_a = H2 - eta_a mu' - H3/2   (rows < ma, cols < m ; zero elsewhere)  -- online hyper-gradient
+template <typename T>
+__global__ void k_online_gkappa(int64_t ma, int64_t m, int64_t rows, int64_t cols, int64_t ld, const T* __restrict__ ea,
+                                const T* __restrict__ mu, const T* __restrict__ H3, T* __restrict__ H2) {
+  int64_t r = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= rows || c >= cols) return;
+  H2[r * ld + c] = (r < ma && c < m) ? H2[r * ld + c] - ea[r] * mu[c] - T(0.5) * H3[r * ld + c] : T(0);
+}
+
+// A += alpha * Bm (rows x cols, shared ld)
+template <typename T>
+__global__ void k_axpy2d(int64_t rows, int64_t cols, int64_t ld, T alpha, const T* __restrict__ Bm, T* __restrict__ A) {
+  int64_t r = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r < rows && c < cols) A[r * ld + c] += alpha * Bm[r * ld + c];
+}
+
+// A -= (M + M')/2 on the n x n block
+template <typename T>
+__global__ void k_sub_sym(T* __restrict__ A, const T* __restrict__ M, int64_t ld, int64_t n) {
+  int64_t r = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r < n && c < n) A[r * ld + c] -= T(0.5) * (M[r * ld + c] + M[c * ld + r]);
+}
+
 // out[0] = sum_{i<n} x[i] y[i]
 template <typename T>
 __global__ void k_dot(const T* __restrict__ x, const T* __restrict__ y, int64_t n, double* __restrict__ out) {

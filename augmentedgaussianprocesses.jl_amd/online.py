@@ -90,8 +90,15 @@ class OnlineSVGP:
         if inference.stoch:
             raise NotImplementedError("OnlineSVGP streams full batches; the reference's stochastic branch "
                                       "(onlinetraining.jl:48-53) references an undefined variable")
-        if optimiser or Zoptimiser:
-            raise NotImplementedError("hyper-parameter steps of the online model are not wired: pass optimiser=False")
+        from .svgp import ADAM
+
+        if optimiser is None:
+            optimiser = ADAM(0.01)                             # OnlineSVGP.jl:38
+        if isinstance(optimiser, bool):
+            optimiser = ADAM(0.01) if optimiser else None      # OnlineSVGP.jl:49-51
+        if isinstance(Zoptimiser, bool):
+            Zoptimiser = ADAM(0.001) if Zoptimiser else None
+        self.k_opt, self.z_opt = optimiser, Zoptimiser
         if mean is not None:
             raise NotImplementedError("only ZeroMean is wired for the online model")
         self.kernel, self.likelihood, self.inference = kernel, likelihood, inference
@@ -118,7 +125,8 @@ class OnlineSVGP:
 
     def _new_svgp(self, Zs, max_batch):
         m = SVGP(self.kernel if self._cur is None else self._cur.kernels, self.likelihood, AnalyticVI(), list(Zs),
-                 optimiser=False, T=self.T, device=self.device, elbo_mode=self.elbo_mode)
+                 optimiser=self.k_opt if self.k_opt else False, Zoptimiser=self.z_opt if self.z_opt else False, T=self.T,
+                 device=self.device, elbo_mode=self.elbo_mode)
         m._ensure_handle(max_batch)
         return m
 
@@ -159,6 +167,7 @@ def train_online(model: OnlineSVGP, X, y, state=None, *, iterations: int = 20, c
         start = 0
     else:
         old = model._cur
+        old._pull_hypers()  # kernels / inducing points as the hyper steps of the previous batch left them
         if mb > old._max_batch:
             old._ensure_handle(mb)
         dev = old._dev()
@@ -186,6 +195,12 @@ def train_online(model: OnlineSVGP, X, y, state=None, *, iterations: int = 20, c
             za = torch.as_tensor(old.Zs[l], dtype=new.tdtype, device=dev).contiguous()
             new._chk(L.agp_svgp_set_online_prior(new._h, l, C.c_void_p(za.data_ptr()), za.stride(0), za.shape[0],
                                                  C.c_void_p(iD.data_ptr()), old.m, C.c_void_p(e1.data_ptr()), pl))
+        if model.k_opt:  # the kernel-parameter ADAM state lives on (hyperopt_state of the reference's `state`)
+            nk = 1 + new.D
+            for l in range(new.n_latent):
+                km, kv, ks = (C.c_double * nk)(), (C.c_double * nk)(), C.c_int32()
+                old._chk(L.agp_svgp_hyper_opt_state(old._h, l, 0, km, kv, C.byref(ks)))
+                new._chk(L.agp_svgp_hyper_opt_state(new._h, l, 1, km, kv, C.byref(ks)))
         new._chk(L.agp_ctx_sync(new._ctx))
         # first iteration: local update under the old inducing points, natural gradient under the new ones
         new._chk(L.agp_svgp_online_first_step(new._h, old._h, C.c_void_p(Xd.data_ptr()), Xd.stride(0),
@@ -202,8 +217,12 @@ def train_online(model: OnlineSVGP, X, y, state=None, *, iterations: int = 20, c
                                           B, 1.0))
         if callback is not None:
             callback(model, new, model.inference.n_iter)
+        # onlinetraining.jl:112-114 (n_iter is the counter before this iteration's increment)
+        if (model.k_opt or model.z_opt) and model.inference.n_iter % model.atfrequency == 0 and model.inference.n_iter >= 3:
+            new._chk(L.agp_svgp_hyper_step(new._h))
         model.inference.n_iter += 1
     new._chk(L.agp_svgp_check_status(new._h))
+    new._pull_hypers()
     new._pull_lik_state()
     new.trained = True
     return model, new

@@ -210,6 +210,11 @@ agp_status agp_svgp_hyper_configure(agp_svgp* h, int32_t opt_kernel, double kern
 agp_status agp_svgp_hypergrad(agp_svgp* h, int32_t latent, double* dvariance_host, double* dscale_host, void* dZ);
 agp_status agp_svgp_hyper_step(agp_svgp* h);
 agp_status agp_svgp_get_kernel(agp_svgp* h, int32_t latent, double* variance_host, double* scales_host);
+/* ADAM moments of a latent's kernel-parameter optimiser (hyperopt_state.state_k of the reference's state): host arrays of
+ * 1 + D doubles (entry 0 variance, then scales; a ScaleTransform uses entry 1), set = 0 reads, set = 1 writes.  Lets a
+ * streaming model (OnlineSVGP: a new handle per batch) and a resumed run continue the optimiser instead of restarting it. */
+agp_status agp_svgp_hyper_opt_state(agp_svgp* h, int32_t latent, int32_t set, double* k_m_host, double* k_v_host,
+                                    int32_t* k_step_host);
 /* Multi-output model  MOSVGP(kernel, likelihoods, inference, Zs; Aoptimiser)  src/models/MOSVGP.jl:33-115 on a handle
  * created with lik.kind = AGP_LIK_MULTIOUTPUT: the handle's n_latent latent GPs are mixed into n_task outputs
  * f_t = sum_q A[t][q] f_q (mean_f / var_f / grad mixing: src/models/single_and_multi_output_utils.jl:24-84).

@@ -1357,8 +1357,13 @@ def hyper_gradient(model, X, y, latent_k, rho):
     return hyper_gradient_core(gp, X, gmu, gsig, rho, model.jitter)
 
 
-def hyper_gradient_core(gp, X, gmu, gsig, rho, jitter):
-    """the backward pass given (dE/dmu_f, dE/dsigma2_f) of the data term for this latent"""
+def hyper_gradient_core(gp, X, gmu, gsig, rho, jitter, online=None):
+    """the backward pass given (dE/dmu_f, dE/dsigma2_f) of the data term for this latent.
+    online = dict(Za, invDa, prev_eta1): adds the gradient of -extraKL (KLdivergences.jl:30-54), which the reference's
+    ELBO closure recomputes with the candidate kernel / Z through compute_kappa(::OnlineVarLatent) (latentgp.jl:217-237):
+      E_x = 1/2 tr(D K~_a) + 1/2 tr(D kappa_a Sigma kappa_a') - eta_a' kappa_a mu + 1/2 mu' kappa_a' D kappa_a mu
+      G_kappa_a = D kappa_a (Sigma + mu mu') - eta_a mu' - D K_ab / 2 ;  G_Kab = G_kappa_a K^-1 - D kappa_a / 2 ;
+      G_K += -sym(kappa_a' G_kappa_a K^-1) ;  G_Ka = D / 2"""
     ker, Z = gp.kernel, gp.Z
     m = len(Z)
     K, L = compute_K(ker, Z, jitter)
@@ -1385,9 +1390,22 @@ def hyper_gradient_core(gp, X, gmu, gsig, rho, jitter):
         dZcol = -2.0 * np.einsum("ij,ijd->jd", GK, diff) * s[None, :]
         return dvar, dscale, dZcol
 
+    extra_v, extra_s, extra_z = 0.0, 0.0, 0.0
+    if online is not None and online.get("Za") is not None:
+        Za, Dm, ea = online["Za"], online["invDa"], online["prev_eta1"]
+        Kab = ker.matrix(Za, Z)
+        ka = Kab @ Kinv
+        G_ka = Dm @ ka @ (gp.Sigma + np.outer(gp.mu, gp.mu)) - np.outer(ea, gp.mu) - 0.5 * Dm @ Kab
+        HK = G_ka @ Kinv
+        G_Kab = HK - 0.5 * Dm @ ka
+        M2 = ka.T @ HK
+        G_K = G_K - 0.5 * (M2 + M2.T)
+        va, sa, za = back(G_Kab, Za, Z)
+        vb, sb, _ = back(0.5 * Dm, Za, Za)
+        extra_v, extra_s, extra_z = va + vb, sa + sb, za
     v1, s1, z1 = back(G_Knm, X, Z)
     v2, s2, z2 = back(G_K, Z, Z)
-    return {"dvariance": v1 + v2 + np.sum(G_kdiag), "dscale": s1 + s2, "dZ": z1 + 2.0 * z2}
+    return {"dvariance": v1 + v2 + np.sum(G_kdiag) + extra_v, "dscale": s1 + s2 + extra_s, "dZ": z1 + 2.0 * z2 + extra_z}
 
 
 # --------------------------------------------------------------------------------------------
@@ -1509,7 +1527,10 @@ class OIPS:
 class OnlineSVGP:
     """OnlineSVGP(kernel, likelihood, AnalyticVI(), Zalg; optimiser=false): one `train` call per arriving batch."""
 
-    def __init__(self, kernel, likelihood, Zalg=None, jitter=1e-4, elbo_mode="corrected", rng=None):
+    def __init__(self, kernel, likelihood, Zalg=None, jitter=1e-4, elbo_mode="corrected", rng=None, k_opt=None, z_opt=None,
+                 atfrequency=1):
+        self.k_opt, self.z_opt, self.atfrequency = k_opt, z_opt, atfrequency
+        self._hp_dirty = False
         self.kernel, self.likelihood, self.Zalg = kernel, likelihood, Zalg or OIPS(0.9)
         self.jitter, self.elbo_mode = jitter, elbo_mode
         self.rng = rng or np.random.default_rng(0)
@@ -1541,6 +1562,9 @@ class OnlineSVGP:
                                  - np.dot(g["mu"], g["eta1"])) / 2.0)
             g["Z"] = self.Zalg.update(g["Z"], X, g["kernel"])
             g["mu0"] = np.zeros(len(g["Z"]))
+        for st in (getattr(self, "hyper_state", None) or []):
+            if st is not None:
+                st["Zshape"] = None  # the Z optimiser restarts with every arriving batch (its parameter array is a new one)
 
     # -- compute_old_matrices onlinetraining.jl:210-217 : matrices of the new batch w.r.t. the OLD inducing points
     def _old_matrices(self, X):
@@ -1606,14 +1630,86 @@ class OnlineSVGP:
                 g1, g2 = grad_E_mu(lik, y, self.local_vars), grad_E_Sigma(lik, y, self.local_vars)
                 self._matrices(X)
             else:
+                if self._hp_dirty:  # update_parameters! -> compute_kernel_matrices recomputes after a hyper step
+                    self._matrices(X)
+                    self._hp_dirty = False
                 mf, vf = self.mean_var()
                 self.local_vars = local_updates(self.local_vars, lik, y, mf, vf)
                 g1, g2 = grad_E_mu(lik, y, self.local_vars), grad_E_Sigma(lik, y, self.local_vars)
             self._natural(g1, g2)
-            self.n_iter += 1
             if callback is not None:
                 callback(self, it, X, y)
+            # onlinetraining.jl:112-114 (n_iter is the counter before this iteration's increment)
+            if (self.k_opt or self.z_opt) and self.n_iter % self.atfrequency == 0 and self.n_iter >= 3:
+                self.update_hyperparameters(X, y)
+            self.n_iter += 1
+        if self._hp_dirty:  # final compute_kernel_matrices(m, state, X, true) onlinetraining.jl:133
+            self._matrices(X)
+            self._hp_dirty = False
         return self
+
+    # -- update_hyperparameters! (sparse, autotuning.jl:86-140) on the online model: the differentiated ELBO includes extraKL
+    def _latent_view(self, g):
+        lt = Latent(g["kernel"], g["Z"])
+        lt.mu, lt.Sigma, lt.mu0 = g["mu"], g["Sigma"], g["mu0"]
+        return lt
+
+    def hyper_gradient(self, X, y, l):
+        g = self.latents[l]
+        K, L = compute_K(g["kernel"], g["Z"], self.jitter)
+        Knm, kappa, Kt = compute_kappa(g["kernel"], X, g["Z"], L, self.jitter)
+        gmu, gsig = expec_grads(self.likelihood, y, mean_f(g["mu"], kappa), self.local_vars, l, self.elbo_mode,
+                                var_f(g["Sigma"], kappa, Kt))
+        return hyper_gradient_core(self._latent_view(g), X, gmu, gsig, 1.0, self.jitter,
+                                   online=dict(Za=g["Za"], invDa=g["invDa"], prev_eta1=g["prev_eta1"]))
+
+    def hyper_objective(self, X, y, l, scale, sigma2, Z):
+        """ELBO.jl:15-21 for the online model as a function of latent l's kernel parameters and inducing points"""
+        import copy
+        keep = {k: self.latents[l][k] for k in ("kernel", "Z", "K", "L", "Kinv", "Kab", "kappa_a", "Kt_a", "Knm", "kappa", "Kt")}
+        ker = copy.deepcopy(self.latents[l]["kernel"])
+        ker.scale, ker.sigma2 = scale, sigma2
+        self.latents[l]["kernel"], self.latents[l]["Z"] = ker, Z
+        self._matrices(X)
+        mf, vf = self.mean_var()
+        val = expec_loglikelihood(self.likelihood, y, mf, vf, self.local_vars, self.elbo_mode)
+        val -= sum(gaussian_kl(g["mu"], g["mu0"], g["Sigma"], g["L"]) for g in self.latents)
+        val -= self.extra_kl()
+        self.latents[l].update(keep)
+        return float(val)
+
+    def update_hyperparameters(self, X, y):
+        grads = [self.hyper_gradient(X, y, l) for l in range(len(self.latents))]
+        if getattr(self, "hyper_state", None) is None:
+            self.hyper_state = [None] * len(self.latents)
+        for l, g in enumerate(self.latents):
+            gr = grads[l]
+            D = g["Z"].shape[1]
+            ker = g["kernel"]
+            sc = np.broadcast_to(np.asarray(ker.scale, dtype=np.float64), (D,)).copy()
+            ard = np.ndim(ker.scale) > 0
+            st = self.hyper_state[l]
+            if st is None or (self.z_opt and st["Z"] is not None and st["Zshape"] != g["Z"].shape):
+                old = st
+                st = {"var": old["var"] if old else (self.k_opt.init(np.zeros(1)) if self.k_opt else None),
+                      "scale": old["scale"] if old else (self.k_opt.init(np.zeros(D if ard else 1)) if self.k_opt else None),
+                      "Z": self.z_opt.init(np.zeros_like(g["Z"])) if self.z_opt else None, "Zshape": g["Z"].shape}
+                self.hyper_state[l] = st
+            if self.k_opt:
+                v = np.array([ker.sigma2])
+                st["var"], dv = self.k_opt.apply(st["var"], v * np.array([gr["dvariance"]]))
+                ker.sigma2 = float(np.exp(np.log(v) + dv)[0])
+                if ard:
+                    st["scale"], ds = self.k_opt.apply(st["scale"], sc * gr["dscale"])
+                    ker.scale = np.exp(np.log(sc) + ds)
+                else:
+                    s0 = np.array([sc[0]])
+                    st["scale"], ds = self.k_opt.apply(st["scale"], s0 * np.array([np.sum(gr["dscale"])]))
+                    ker.scale = float(np.exp(np.log(s0) + ds)[0])
+            if self.z_opt:
+                st["Z"], dz = self.z_opt.apply(st["Z"], gr["dZ"])
+                g["Z"] = g["Z"] + dz
+        self._hp_dirty = True
 
     # -- ELBO analyticVI.jl:255-274 with extraKL KLdivergences.jl:30-54
     def extra_kl(self):

@@ -92,5 +92,32 @@ def test_online_learns_and_rejects_unsupported(env):
     assert np.all(v > 0)
     with pytest.raises(NotImplementedError):
         AGP.OnlineSVGP(AGP.SqExponentialKernel(), AGP.GaussianLikelihood(0.01), AGP.AnalyticSVI(10))
-    with pytest.raises(NotImplementedError):
-        AGP.OnlineSVGP(AGP.SqExponentialKernel(), AGP.GaussianLikelihood(0.01), AGP.AnalyticVI(), optimiser=True)
+
+
+@pytest.mark.parametrize("likname,ard,zopt", [("gaussian", False, True), ("logistic", True, False)])
+def test_online_hyper_steps_match_oracle(env, likname, ard, zopt):
+    """OnlineSVGP with its default-on hyper-parameter optimisation: the differentiated ELBO includes extraKL, whose kernel
+    matrices (K_ab, kappa_a, K~_a) move with the kernel and with Z (oracle gradient FD-pinned in tests/test_oracle_kat.py)."""
+    from _liks import agp_lik, labels, oracle_lik
+
+    AGP, R = env["AGP"], env["R"]
+    rng = np.random.default_rng(23)
+    X, f = _stream(rng, N=300)
+    y = labels(likname, f, X, rng)
+    sc = np.array([1.5, 1.0]) if ard else 1.5
+    ka = 1.2 * (AGP.SqExponentialKernel() @ (AGP.ARDTransform(sc) if ard else AGP.ScaleTransform(sc)))
+    ma = AGP.OnlineSVGP(ka, agp_lik(AGP, likname), AGP.AnalyticVI(), AGP.OIPS(0.7), optimiser=AGP.ADAM(0.01),
+                        Zoptimiser=AGP.ADAM(0.001) if zopt else False)
+    mr = R.OnlineSVGP(R.Kernel("sqexponential", sc, 1.2), oracle_lik(R, likname), R.OIPS(0.7), k_opt=R.Adam(0.01),
+                      z_opt=R.Adam(0.001) if zopt else None)
+    for b in range(0, len(X), 60):
+        AGP.train_online(ma, X[b:b + 60], y[b:b + 60], iterations=4)
+        mr.train(X[b:b + 60], y[b:b + 60], 4)
+        g = mr.latents[0]
+        k = ma._cur.kernels[0]
+        assert k.variance == pytest.approx(g["kernel"].sigma2, rel=1e-7), b
+        got = np.asarray(k.transform.v if ard else k.transform.s, dtype=float)
+        assert _rel(got, np.asarray(g["kernel"].scale, dtype=float)) < 1e-7
+        assert len(ma.Zs[0]) == len(g["Z"]) and _rel(ma.Zs[0], g["Z"]) < 1e-7
+        mu, Sig, e1, e2 = ma.get_state(0)
+        assert _rel(e2, g["eta2"]) < 1e-6 and _rel(mu, g["mu"]) < 1e-6

@@ -516,3 +516,29 @@ def test_kat7_multioutput_hyper_gradient_vs_finite_differences():
         Zp[2, 1] += h
         Zm[2, 1] -= h
         assert g["dZ"][2, 1] == pytest.approx((obj(sc0, v0, Zp) - obj(sc0, v0, Zm)) / (2 * h), rel=1e-5, abs=2e-6)
+
+
+def test_kat7_online_hyper_gradient_with_extra_kl_vs_finite_differences():
+    rng = np.random.default_rng(1)
+    N = 160
+    X = rng.random((N, 2)) * np.array([4.0, 2.0])
+    f = np.sin(2 * X[:, 0]) + 0.5 * np.cos(3 * X[:, 1])
+    y = (f + 0.2 * rng.standard_normal(N) > 0).astype(int)
+    M = R.OnlineSVGP(R.Kernel("sqexponential", np.array([1.5, 1.0]), 1.2), R.LogisticLikelihood(), R.OIPS(0.7))
+    M.train(X[:80], y[:80], 3)
+    M.train(X[80:], y[80:], 2)
+    yt, Xb = R.treat_labels(y[80:], M.likelihood), X[80:]
+    g, gp = M.hyper_gradient(Xb, yt, 0), M.latents[0]
+    assert gp["Za"] is not None
+    sc0, v0, Z0, h = np.array(gp["kernel"].scale, float), gp["kernel"].sigma2, gp["Z"].copy(), 1e-6
+    obj = lambda sc, v, Z: M.hyper_objective(Xb, yt, 0, sc, v, Z)
+    assert g["dvariance"] == pytest.approx((obj(sc0, v0 + h, Z0) - obj(sc0, v0 - h, Z0)) / (2 * h), rel=1e-5, abs=1e-6)
+    for d in range(2):
+        e = np.zeros(2)
+        e[d] = h
+        assert g["dscale"][d] == pytest.approx((obj(sc0 + e, v0, Z0) - obj(sc0 - e, v0, Z0)) / (2 * h), rel=1e-5, abs=1e-6)
+    for a, d in [(0, 0), (3, 1), (len(Z0) - 1, 0)]:
+        Zp, Zm = Z0.copy(), Z0.copy()
+        Zp[a, d] += h
+        Zm[a, d] -= h
+        assert g["dZ"][a, d] == pytest.approx((obj(sc0, v0, Zp) - obj(sc0, v0, Zm)) / (2 * h), rel=1e-5, abs=2e-6)

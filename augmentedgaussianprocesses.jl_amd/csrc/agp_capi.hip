@@ -2324,11 +2324,17 @@ static agp_status bb_kmeans(agp_ctx* ctx, const void* xv, int64_t n, int64_t ldx
   const int nchunks = (int)((n + KM_CHUNK - 1) / KM_CHUNK);
   T *cn = nullptr, *mind = nullptr, *part = nullptr;
   double* red = nullptr;
-  int32_t* lab = labels_out;
+  int32_t *lab = labels_out, *blist = nullptr, *boff = nullptr;
+  if (mp / TILE > KM_MAXTILES) {
+    ctx->err = "agp_kmeans: more than 16384 centres";
+    return AGP_ERR_UNSUPPORTED;
+  }
   AGPCHK(dmalloc(ctx, &cn, mp));
   AGPCHK(dmalloc(ctx, &mind, n));
   AGPCHK(dmalloc(ctx, &part, (int64_t)nchunks * mp * (Dp + 16)));
   AGPCHK(dmalloc(ctx, &red, 512));
+  AGPCHK(dmalloc(ctx, &blist, (int64_t)nchunks * KM_CHUNK));
+  AGPCHK(dmalloc(ctx, &boff, (int64_t)nchunks * (KM_MAXTILES + 1)));
   if (!lab) AGPCHK(dmalloc(ctx, &lab, n));
   agp_status st = AGP_OK;
   double obj = 0.0, prev = 0.0;
@@ -2338,8 +2344,10 @@ static agp_status bb_kmeans(agp_ctx* ctx, const void* xv, int64_t n, int64_t ldx
   if (st == AGP_OK) st = km_objective<T>(ctx, mind, n, red, &obj);
   while (st == AGP_OK && it < max_iter && !conv) {
     ++it;
+    hipLaunchKernelGGL(k_km_bucket, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream, (const int32_t*)lab, n,
+                       (int)(mp / TILE), blist, boff);
     hipLaunchKernelGGL((k_km_sums<T>), dim3((unsigned)(mp / TILE), (unsigned)nchunks), dim3(NTHREADS), 0, ctx->stream, x, ldx, n,
-                       D, Dp, (const int32_t*)lab, mp, part);
+                       D, Dp, (const int32_t*)lab, mp, (const int32_t*)blist, (const int32_t*)boff, part);
     hipLaunchKernelGGL((k_km_finish<T>), grid1(m * D), dim3(256), 0, ctx->stream, (const T*)part, nchunks, mp, Dp, m, D, c, ldc,
                        counts_out);
     if (hipGetLastError() != hipSuccess) {
@@ -2356,6 +2364,8 @@ static agp_status bb_kmeans(agp_ctx* ctx, const void* xv, int64_t n, int64_t ldx
   (void)hipFree(mind);
   (void)hipFree(part);
   (void)hipFree(red);
+  (void)hipFree(blist);
+  (void)hipFree(boff);
   if (!labels_out) (void)hipFree(lab);
   if (iters) *iters = it;
   if (objective) *objective = obj;

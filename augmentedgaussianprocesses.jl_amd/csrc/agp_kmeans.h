@@ -6,9 +6,10 @@
 //                 centre tiles stream through; distances in GEMM form  ||c||^2 - 2 x.c  (+ ||x||^2 at the end) on
 //                 v_mfma 16x16x4, running (min, argmin) in registers, ties to the smaller index.  The N x m distance
 //                 matrix never exists.
+//   k_km_bucket : stable bucketing of every 8192-point chunk by centre tile (index order kept inside a bucket)
 //   k_km_sums   : centre sums as H' X (H = one-hot assignment) on MFMA with the one-hot operand generated from the labels
-//                 on the fly, split over point chunks; k_km_finish reduces the chunk partials in chunk order, so the
-//                 new centres are bit-reproducible (no floating-point atomics anywhere).
+//                 on the fly, over the bucket of its centre tile only; k_km_finish reduces the chunk partials in chunk
+//                 order, so the new centres are bit-reproducible (no floating-point atomics anywhere).
 #pragma once
 #include "agp_device.h"
 
@@ -147,25 +148,75 @@ __global__ __launch_bounds__(NTHREADS) void k_km_assign(const T* __restrict__ X,
   }
 }
 
-// partial centre sums of one point chunk: part[chunk][mp][Dp + 16] ; column Dp holds the member count
+// Stable bucketing of one point chunk by centre tile (64 centres): list[chunk][.] holds the chunk's point indices grouped by
+// tile, in index order inside every group (so the sums below add in a fixed order), off[chunk][t] the group starts.
+// One workgroup (256 threads) per chunk; ntile = mp/64 <= KM_MAXTILES.
+constexpr int KM_MAXTILES = 256;
+
+__global__ __launch_bounds__(256) void k_km_bucket(const int32_t* __restrict__ labels, int64_t N, int ntile,
+                                                   int32_t* __restrict__ list, int32_t* __restrict__ off) {
+  __shared__ int cnt[KM_MAXTILES], base[KM_MAXTILES + 1], sub[KM_MAXTILES];
+  __shared__ int tl[256];
+  const int tid = threadIdx.x;
+  const int64_t pbeg = (int64_t)blockIdx.x * KM_CHUNK;
+  const int64_t pend = pbeg + KM_CHUNK < N ? pbeg + KM_CHUNK : N;
+  for (int t = tid; t < ntile; t += 256) cnt[t] = 0;
+  __syncthreads();
+  for (int64_t p = pbeg + tid; p < pend; p += 256) atomicAdd(&cnt[labels[p] >> 6], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int a = 0;
+    for (int t = 0; t < ntile; ++t) {
+      base[t] = a;
+      a += cnt[t];
+    }
+    base[ntile] = a;
+  }
+  __syncthreads();
+  for (int t = tid; t <= ntile; t += 256) off[(int64_t)blockIdx.x * (KM_MAXTILES + 1) + t] = base[t];
+  // placement, 256 points at a time in index order; rank among the same-tile points of the sub-block = stable
+  for (int64_t p0 = pbeg; p0 < pend; p0 += 256) {
+    const int64_t p = p0 + tid;
+    const int t = p < pend ? (labels[p] >> 6) : -1;
+    for (int q = tid; q < ntile; q += 256) sub[q] = 0;
+    tl[tid] = t;
+    __syncthreads();
+    if (t >= 0) {
+      int rank = 0;
+      for (int q = 0; q < tid; ++q) rank += (tl[q] == t);
+      list[(int64_t)blockIdx.x * KM_CHUNK + base[t] + rank] = (int32_t)(p - pbeg);
+      atomicAdd(&sub[t], 1);
+    }
+    __syncthreads();
+    for (int q = tid; q < ntile; q += 256) base[q] += sub[q];
+    __syncthreads();
+  }
+}
+
+// partial centre sums of one point chunk: part[chunk][mp][Dp + 16] ; column Dp holds the member count.
+// H' X on MFMA with the one-hot operand generated from the labels on the fly, but only over the chunk's points that belong
+// to this centre tile (the bucket list above) -- a point contributes to exactly one centre.
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void k_km_sums(const T* __restrict__ X, int64_t ldx, int64_t N, int64_t D, int Dp,
                                                       const int32_t* __restrict__ labels, int64_t mp,
+                                                      const int32_t* __restrict__ list, const int32_t* __restrict__ off,
                                                       T* __restrict__ part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const int c0 = blockIdx.x * TILE + wave * 16;  // this wave's 16 centres
   const int64_t pbeg = (int64_t)blockIdx.y * KM_CHUNK;
-  const int64_t pend = pbeg + KM_CHUNK < N ? pbeg + KM_CHUNK : N;
+  const int32_t* lst = list + (int64_t)blockIdx.y * KM_CHUNK;
+  const int qbeg = off[(int64_t)blockIdx.y * (KM_MAXTILES + 1) + blockIdx.x];
+  const int qend = off[(int64_t)blockIdx.y * (KM_MAXTILES + 1) + blockIdx.x + 1];
   const int NT = Dp / 16;
   typename Mfma<T>::acc_t acc[KM_MAXD / 16 + 1];
 #pragma unroll
   for (int t = 0; t <= KM_MAXD / 16; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[t][r] = T(0);
-  for (int64_t p = pbeg; p < pend; p += 4) {
-    const int64_t pk = p + lk;
-    const bool ok = pk < pend;
+  for (int q = qbeg; q < qend; q += 4) {
+    const bool ok = q + lk < qend;
+    const int64_t pk = ok ? pbeg + lst[q + lk] : 0;
     const int lab = ok ? labels[pk] : -1;
     const T a = (lab == c0 + lr) ? T(1) : T(0);
 #pragma unroll

@@ -242,17 +242,24 @@ def test_titsias_optimum_gaussian(env):
     assert _rel(mu2, mu1) < 1e-9 and _rel(S2, S1) < 1e-9
 
 
-def test_fp32_mode(env):
+@pytest.mark.parametrize("likname", ["studentt", "logistic", "laplace", "negbinomial", "poisson", "heteroscedastic"])
+def test_fp32_mode(env, likname):
+    """T = Float32 (SVGP.jl:43): same trajectory in fp32 arithmetic (jitter 1e-3), predictive mean within 2e-3 of the fp64 oracle"""
     AGP, R = env["AGP"], env["R"]
     rng = np.random.default_rng(11)
     B, iters = 64, 5
-    X, y, ma, mr = _models(env, "studentt", rng, True, B, T=np.float32)
+    X, y, ma, mr = _models(env, likname, rng, True, B, T=np.float32)
     idx = [rng.choice(len(X), B, replace=False) for _ in range(iters)]
     AGP.train_(ma, X, y, iters, idx_stream=idx)
     mr.train(X, y, iters, idx_stream=idx)
     Xt = rng.random((50, X.shape[1]))
     mf = AGP.predict_f(ma, Xt)
-    assert _rel(mf, mr.predict_f(Xt)[0]) < 2e-3
+    mfr = mr.predict_f(Xt)
+    if ma.n_latent == 1:
+        assert _rel(mf, mfr[0]) < 2e-3
+    else:
+        for k in range(ma.n_latent):
+            assert _rel(mf[k], mfr[k]) < 5e-3
 
 
 def test_error_mapping(env):

@@ -117,6 +117,7 @@ SYMBOLS = {
     "agp_svgp_set_online_prior": (_I32, [_VP, _I32, _VP, _I64, _I64, _VP, _I64, _VP, _DBL]),
     "agp_svgp_adopt_local": (_I32, [_VP, _VP]),
     "agp_svgp_online_first_step": (_I32, [_VP, _VP, _VP, _I64, _VP, _I64]),
+    "agp_svgp_hyper_apply": (_I32, [_VP, _I32, _PDBL, _PDBL, _VP]),
     "agp_svgp_hyper_opt_state": (_I32, [_VP, _I32, _I32, _PDBL, _PDBL, _PI32]),
     "agp_svgp_set_quadrature": (_I32, [_VP, _PDBL, _PDBL, _I32]),
     "agp_svgp_get_lik_param": (_I32, [_VP, _PDBL]),

@@ -267,6 +267,7 @@ struct SvgpBase {
                              int nn, void* o0, void* o1) = 0;
   virtual agp_status set_quadrature(const double* nodes, const double* weights, int nn) = 0;
   virtual agp_status hyper_state(int l, int set, double* k_m, double* k_v, int32_t* k_step) = 0;
+  virtual agp_status hyper_apply(int l, const double* dvar, const double* dscale, const void* dZ) = 0;
   virtual agp_status set_lsm_alpha(const void* a, int64_t n) = 0;
   virtual agp_status set_online_prior(int l, const void* za, int64_t ldza, int64_t ma, const void* invDa, int64_t ldi,
                                       const void* peta1, double prevLa) = 0;
@@ -1218,55 +1219,56 @@ struct Svgp : SvgpBase {
     return AGP_OK;
   }
 
-  agp_status hyper_step() override {
-    if (!hy_k && !hy_z) return AGP_OK;
-    for (int l = 0; l < nl; ++l) {
-      Latent& g = lat[l];
-      AGPCHK(hypergrad(l, nullptr, nullptr, nullptr));
-      const std::vector<double>& hg = hy_last;
-      if (hy_k) {
-        const size_t np = 1 + (g.k.ard ? (size_t)D : 1);
-        if (g.k_m.size() != np) {
-          g.k_m.assign(np, 0.0);
-          g.k_v.assign(np, 0.0);
-          g.k_step = 0;
-        }
-        std::vector<double> p(np), gl(np), delta;
-        p[0] = g.k.variance;
-        gl[0] = p[0] * hg[0];
-        if (g.k.ard) {
-          for (int64_t d = 0; d < D; ++d) {
-            p[1 + d] = g.k.scales[d];
-            gl[1 + d] = p[1 + d] * hg[1 + d];
-          }
-        } else {
-          double s = 0;
-          for (int64_t d = 0; d < D; ++d) s += hg[1 + d];
-          p[1] = g.k.scales[0];
-          gl[1] = p[1] * s;
-        }
-        g.k_step += 1;
-        // variance and scale(s) are separate parameter arrays in the reference: separate ADAM states, same step count
-        adam_host(g.k_m, g.k_v, g.k_step, gl, hy_keta, hy_b1, hy_b2, hy_eps, delta);
-        g.k.variance = std::exp(std::log(p[0]) + delta[0]);
-        for (int64_t d = 0; d < D; ++d) {
-          const size_t j = g.k.ard ? 1 + (size_t)d : 1;
-          g.k.scales[d] = std::exp(std::log(p[j]) + delta[j]);
-        }
+  // ADAM ascent on latent l with the gradient hg = [dvariance, dscale_0..D-1] (w.r.t. the parameters themselves; positive
+  // parameters are stepped in log space, update_kernel! autotuning_utils.jl:63-67) and dZ (device, m x D; update_Z! :70-76)
+  agp_status hyper_apply_one(int l, const std::vector<double>& hg, const T* dZ_dev) {
+    Latent& g = lat[l];
+    if (hy_k) {
+      const size_t np = 1 + (g.k.ard ? (size_t)D : 1);
+      if (g.k_m.size() != np) {
+        g.k_m.assign(np, 0.0);
+        g.k_v.assign(np, 0.0);
+        g.k_step = 0;
       }
-      if (hy_z) {
-        if (!g.z_am) {
-          AGPCHK(dmalloc(ctx, &g.z_am, m * D));
-          AGPCHK(dmalloc(ctx, &g.z_av, m * D));
-          HIPCHK(ctx, hipMemsetAsync(g.z_am, 0, sizeof(double) * m * D, st()));
-          HIPCHK(ctx, hipMemsetAsync(g.z_av, 0, sizeof(double) * m * D, st()));
+      std::vector<double> p(np), gl(np), delta;
+      p[0] = g.k.variance;
+      gl[0] = p[0] * hg[0];
+      if (g.k.ard) {
+        for (int64_t d = 0; d < D; ++d) {
+          p[1 + d] = g.k.scales[d];
+          gl[1 + d] = p[1 + d] * hg[1 + d];
         }
-        g.z_step += 1;
-        hipLaunchKernelGGL((k_adam_ascent<T>), grid1(m * D), dim3(256), 0, st(), m * D, g.Z, (const T*)hy_dZ, g.z_am,
-                           g.z_av, g.z_step, hy_zeta, hy_b1, hy_b2, hy_eps);
-        LAUNCHCHK(ctx);
+      } else {
+        double s = 0;
+        for (int64_t d = 0; d < D; ++d) s += hg[1 + d];
+        p[1] = g.k.scales[0];
+        gl[1] = p[1] * s;
+      }
+      g.k_step += 1;
+      // variance and scale(s) are separate parameter arrays in the reference: separate ADAM states, same step count
+      adam_host(g.k_m, g.k_v, g.k_step, gl, hy_keta, hy_b1, hy_b2, hy_eps, delta);
+      g.k.variance = std::exp(std::log(p[0]) + delta[0]);
+      for (int64_t d = 0; d < D; ++d) {
+        const size_t j = g.k.ard ? 1 + (size_t)d : 1;
+        g.k.scales[d] = std::exp(std::log(p[j]) + delta[j]);
       }
     }
+    if (hy_z && dZ_dev) {
+      if (!g.z_am) {
+        AGPCHK(dmalloc(ctx, &g.z_am, m * D));
+        AGPCHK(dmalloc(ctx, &g.z_av, m * D));
+        HIPCHK(ctx, hipMemsetAsync(g.z_am, 0, sizeof(double) * m * D, st()));
+        HIPCHK(ctx, hipMemsetAsync(g.z_av, 0, sizeof(double) * m * D, st()));
+      }
+      g.z_step += 1;
+      hipLaunchKernelGGL((k_adam_ascent<T>), grid1(m * D), dim3(256), 0, st(), m * D, g.Z, dZ_dev, g.z_am, g.z_av, g.z_step,
+                         hy_zeta, hy_b1, hy_b2, hy_eps);
+      LAUNCHCHK(ctx);
+    }
+    return AGP_OK;
+  }
+
+  agp_status hyper_finish() {
     for (auto& g : lat) {
       if (hy_k) AGPCHK(upload_scales(g));
       g.K_stale = true;
@@ -1275,6 +1277,28 @@ struct Svgp : SvgpBase {
     }
     pf_valid = false;
     return AGP_OK;
+  }
+
+  // update_hyperparameters!(m, state, x, y): ADAM ASCENT; positive kernel parameters are stepped in log space
+  // (update_kernel!, autotuning_utils.jl:63-67), Z directly (update_Z!, :70-76).  K is refreshed before the next step.
+  agp_status hyper_step() override {
+    if (!hy_k && !hy_z) return AGP_OK;
+    for (int l = 0; l < nl; ++l) {
+      AGPCHK(hypergrad(l, nullptr, nullptr, nullptr));
+      AGPCHK(hyper_apply_one(l, hy_last, (const T*)hy_dZ));
+    }
+    return hyper_finish();
+  }
+
+  // the optimiser step with a caller-supplied gradient (e.g. summed over latents / all-reduced over ranks: tied-Z mode)
+  agp_status hyper_apply(int l, const double* dvar, const double* dscale, const void* dZ) override {
+    if (l < 0 || l >= nl || !dvar || !dscale) return AGP_ERR_INVALID;
+    if (!hy_k && !hy_z) return AGP_OK;
+    std::vector<double> hg(1 + D);
+    hg[0] = *dvar;
+    for (int64_t d = 0; d < D; ++d) hg[1 + d] = dscale[d];
+    AGPCHK(hyper_apply_one(l, hg, (const T*)dZ));
+    return hyper_finish();
   }
 
   agp_status get_kernel(int l, double* var, double* scales) override {
@@ -2652,6 +2676,11 @@ agp_status agp_svgp_online_first_step(agp_svgp* h_new, agp_svgp* h_old, const vo
   return n->step_global(true);
 }
 
+agp_status agp_svgp_hyper_apply(agp_svgp* h, int32_t latent, const double* dvariance_host, const double* dscale_host,
+                                const void* dZ) {
+  HCHK(h);
+  return h->impl->hyper_apply(latent, dvariance_host, dscale_host, dZ);
+}
 agp_status agp_svgp_hyper_opt_state(agp_svgp* h, int32_t latent, int32_t set, double* k_m_host, double* k_v_host,
                                     int32_t* k_step_host) {
   HCHK(h);

@@ -107,6 +107,17 @@ def batch_parallel_step(engine, idx_local, rho: float, group=None) -> None:
     engine.step_global()
 
 
+def tied_hyper_step(engine, group=None) -> None:
+    """Hyper-parameter / inducing-point step of a model whose latents share ONE kernel and ONE set of inducing points
+    ("tied Z": an opt-in extension -- the reference gives every latent its own deep copy, latentgp.jl:63-68).  The gradient of
+    the shared parameters is the sum over all latents, so every rank sums the gradients of its latent slice, the sums are
+    all-reduced (m x D + 1 + D numbers: BASELINE.json config 4's "all-reduce on the Z hyper-grad"), and every latent on every
+    rank applies the same ADAM step -- kernels and Z stay identical everywhere without ever being broadcast."""
+    g = engine.hyper_gradients()   # flat tensor [dvariance | dscale(D) | dZ(m*D)] summed over the local latents
+    _all_reduce(g, group)
+    engine.hyper_apply(g)
+
+
 class _DevBuf:
     """Zero-copy view of a library-owned device buffer for torch (via __cuda_array_interface__)."""
 
@@ -177,6 +188,32 @@ class HipEngine:
 
     def step_global(self):
         self.model._chk(self.L.agp_svgp_step_global(self.h))
+
+    def hyper_gradients(self):
+        """sum over this rank's latents of (dvariance, dscale[D], dZ[m, D]) as one flat device tensor"""
+        import torch
+
+        mdl = self.model
+        D, m = mdl.D, mdl.m
+        tot = torch.zeros(1 + D + m * D, dtype=torch.float64, device=mdl._dev())
+        dz = torch.empty(m, D, dtype=mdl.tdtype, device=mdl._dev())
+        for l in range(mdl.n_latent):
+            dv, ds = C.c_double(), (C.c_double * D)()
+            mdl._chk(self.L.agp_svgp_hypergrad(self.h, l, C.byref(dv), ds, C.c_void_p(dz.data_ptr())))
+            tot[0] += dv.value
+            tot[1:1 + D] += torch.tensor(list(ds), dtype=torch.float64, device=tot.device)
+            tot[1 + D:] += dz.reshape(-1).to(torch.float64)
+        return tot
+
+    def hyper_apply(self, g):
+        mdl = self.model
+        D, m = mdl.D, mdl.m
+        host = g[:1 + D].cpu().numpy()
+        dz = g[1 + D:].reshape(m, D).to(mdl.tdtype).contiguous()
+        ds = (C.c_double * D)(*host[1:])
+        for l in range(mdl.n_latent):
+            dv = C.c_double(float(host[0]))
+            mdl._chk(self.L.agp_svgp_hyper_apply(self.h, l, C.byref(dv), ds, C.c_void_p(dz.data_ptr())))
 
     def check(self):
         self.model._chk(self.L.agp_svgp_check_status(self.h))

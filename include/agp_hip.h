@@ -209,6 +209,11 @@ agp_status agp_svgp_hyper_configure(agp_svgp* h, int32_t opt_kernel, double kern
                                     double adam_b1, double adam_b2, double adam_eps);
 agp_status agp_svgp_hypergrad(agp_svgp* h, int32_t latent, double* dvariance_host, double* dscale_host, void* dZ);
 agp_status agp_svgp_hyper_step(agp_svgp* h);
+/* the optimiser half of hyper_step with a caller-supplied gradient in the layout of agp_svgp_hypergrad (dZ: device m x D,
+ * nullable).  hypergrad + hyper_apply == hyper_step; in between a multi-GPU driver can sum the gradient over latents and
+ * all-reduce it over ranks (tied-Z mode: one kernel and one Z shared by all latents, BASELINE.json config 4). */
+agp_status agp_svgp_hyper_apply(agp_svgp* h, int32_t latent, const double* dvariance_host, const double* dscale_host,
+                                const void* dZ);
 agp_status agp_svgp_get_kernel(agp_svgp* h, int32_t latent, double* variance_host, double* scales_host);
 /* ADAM moments of a latent's kernel-parameter optimiser (hyperopt_state.state_k of the reference's state): host arrays of
  * 1 + D doubles (entry 0 variance, then scales; a ScaleTransform uses entry 1), set = 0 reads, set = 1 writes.  Lets a

@@ -327,6 +327,38 @@ def test_phase_split_engine_matches_oracle(env, likname):
         assert _rel(mb.get_state(k)[3], mr.latents[k].eta2) < 1e-9
 
 
+def test_tied_z_hyper_step_engine_matches_oracle(env):
+    """tied-Z mode (parallel.tied_hyper_step): 4-class LogisticSoftMax, the hyper-gradient summed over the latents and the
+    same ADAM step applied to each -- HipEngine against the oracle engine of the gloo test, one rank."""
+    AGP, R = env["AGP"], env["R"]
+    import ctypes as C
+
+    from agp_amd import parallel as P
+    from test_parallel_gloo import TiedOracleEngine, _data
+
+    X, y, lik, Z, idx, N, B, iters = _data("logisticsoftmax")
+    ma = AGP.SVGP(1.0 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(3.0)), AGP.LogisticSoftMaxLikelihood(4),
+                  AGP.AnalyticSVI(B), Z, optimiser=False)
+    eng = P.HipEngine(ma, B).bind_data(X, y)
+    ma._chk(eng.L.agp_svgp_hyper_configure(eng.h, 1, 0.01, 1, 0.001, 0.9, 0.999, 1e-8))
+    ref = TiedOracleEngine(R.Kernel("sqexponential", 3.0, 1.0), lik, Z, X, R.treat_labels(y, lik), 0, 4, batchsize=B)
+    for it in range(iters):
+        P.latent_parallel_step(eng, idx[it], N / B)
+        P.tied_hyper_step(eng)
+        P.latent_parallel_step(ref, idx[it], N / B)
+        P.tied_hyper_step(ref)
+    eng.check()
+    ma.k_opt = ma.z_opt = AGP.ADAM()
+    ma._pull_hypers()
+    for k in range(4):
+        g = ref.M.latents[k]
+        assert _rel(ma.Zs[k], g.Z) < 1e-9 and np.array_equal(ma.Zs[k], ma.Zs[0])
+        assert ma.kernels[k].variance == pytest.approx(g.kernel.sigma2, rel=1e-9)
+        assert ma.kernels[k].transform.s == pytest.approx(g.kernel.scale, rel=1e-9)
+        assert _rel(ma.get_state(k)[2], g.eta1) < 1e-7
+    assert _rel(ma.Zs[0], Z) > 1e-5
+
+
 @pytest.mark.parametrize("stochastic", [False, True])
 @pytest.mark.parametrize("aopt", [False, True])
 def test_multioutput_svgp_matches_oracle(env, stochastic, aopt):
@@ -518,3 +550,32 @@ def test_save_and_load_trained_model_round_trip(env, likname, tmp_path):
         assert _rel(e2c, e2a) < 1e-8 and _rel(mu_c, mu_a) < 1e-7
     if hasattr(ma.likelihood, "lam"):
         assert mc.likelihood.lam == pytest.approx(ma.likelihood.lam, rel=1e-8)
+
+
+def test_hypergrad_plus_apply_equals_hyper_step(env):
+    """agp_svgp_hypergrad + agp_svgp_hyper_apply (the split a tied-Z multi-GPU driver all-reduces in between) takes exactly
+    the step agp_svgp_hyper_step takes."""
+    import ctypes as C
+
+    AGP, capi = env["AGP"], env["capi"]
+    torch = env["torch"]
+    L = capi.lib()
+    B = 64
+    out = []
+    for split in (False, True):
+        X, y, m, _ = _models(env, "logistic", np.random.default_rng(5), True, B)
+        idx = [np.random.default_rng(9).choice(len(X), B, replace=False) for _ in range(3)]
+        AGP.train_(m, X, y, 1, idx_stream=idx[:1])
+        m.k_opt, m.z_opt = AGP.ADAM(0.01), AGP.ADAM(0.001)  # after the step: only this test's explicit hyper step runs
+        h = m._h
+        m._chk(L.agp_svgp_hyper_configure(h, 1, 0.01, 1, 0.001, 0.9, 0.999, 1e-8))
+        if split:
+            dz = torch.empty(m.m, m.D, dtype=m.tdtype, device="cuda")
+            dv, ds = C.c_double(), (C.c_double * m.D)()
+            m._chk(L.agp_svgp_hypergrad(h, 0, C.byref(dv), ds, C.c_void_p(dz.data_ptr())))
+            m._chk(L.agp_svgp_hyper_apply(h, 0, C.byref(dv), ds, C.c_void_p(dz.data_ptr())))
+        else:
+            m._chk(L.agp_svgp_hyper_step(h))
+        m._pull_hypers()
+        out.append((m.kernels[0].variance, m.kernels[0].transform.s, m.Zs[0].copy()))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2])

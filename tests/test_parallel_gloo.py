@@ -95,6 +95,97 @@ class OracleEngine:
         self.n += 1
 
 
+class TiedOracleEngine(OracleEngine):
+    """OracleEngine + the tied-Z hyper step (gradients through the oracle's hand backward, ADAM like agp_svgp_hyper_apply)."""
+
+    def step_stats(self):
+        super().step_stats()
+        nl = len(self.M.latents)
+        Y = self.yb[:, self.lo:self.hi].astype(np.float64)
+        self._theta = [(Y[:, k] + self.gamma[k]) * R.theta_pg(self.c[k]) for k in range(nl)]
+        self._g1 = [(Y[:, k] - self.gamma[k]) / 2 for k in range(nl)]
+
+    def hyper_gradients(self):
+        xb = self.X[self.idx]
+        tot = None
+        for k, g in enumerate(self.M.latents):
+            muf = R.mean_f(g.mu, g.kappa)
+            gr = R.hyper_gradient_core(g, xb, self._g1[k] - self._theta[k] * muf, -self._theta[k] / 2.0, self.rho, self.M.jitter)
+            v = np.concatenate([[gr["dvariance"]], gr["dscale"], gr["dZ"].ravel()])
+            tot = v if tot is None else tot + v
+        return torch.from_numpy(tot)
+
+    def hyper_apply(self, gt):
+        g = gt.numpy()
+        D = self.X.shape[1]
+        for lat in self.M.latents:
+            if not hasattr(lat, "_adam"):
+                lat._adam = [R.Adam(0.01).init(np.zeros(1)), R.Adam(0.01).init(np.zeros(1)), R.Adam(0.001).init(np.zeros_like(lat.Z))]
+            ak, az = R.Adam(0.01), R.Adam(0.001)
+            v = np.array([lat.kernel.sigma2])
+            lat._adam[0], dv = ak.apply(lat._adam[0], v * g[:1])
+            lat.kernel.sigma2 = float(np.exp(np.log(v) + dv)[0])
+            s0 = np.array([float(lat.kernel.scale)])
+            lat._adam[1], ds = ak.apply(lat._adam[1], s0 * np.array([np.sum(g[1:1 + D])]))
+            lat.kernel.scale = float(np.exp(np.log(s0) + ds)[0])
+            lat._adam[2], dz = az.apply(lat._adam[2], g[1 + D:].reshape(lat.Z.shape))
+            lat.Z = lat.Z + dz
+        self.M.hp_updated = True
+
+
+def _tied_worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import agp_amd  # noqa: F401
+    from agp_amd import parallel as P
+
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    X, y, lik, Z, idx, N, B, iters = _data("logisticsoftmax")
+    yt = R.treat_labels(y, lik)
+    lo, hi = P.latent_slice(lik.n_latent, world, rank)
+    eng = TiedOracleEngine(R.Kernel("sqexponential", 3.0, 1.0), lik, Z, X, yt, lo, hi, batchsize=B)
+    for it in range(iters):
+        P.latent_parallel_step(eng, idx[it], N / B)
+        P.tied_hyper_step(eng)
+    q.put((rank, lo, hi, [g.Z for g in eng.M.latents], [g.kernel.sigma2 for g in eng.M.latents],
+           [g.kernel.scale for g in eng.M.latents], [g.eta1 for g in eng.M.latents]))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_tied_z_hyper_step_all_reduce_two_ranks():
+    """tied-Z mode: the Z / kernel hyper-gradient summed over latents and all-reduced over ranks keeps one shared kernel and
+    one shared Z on every latent of every rank; the 2-rank run equals the single-process run of the same driver."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tied_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    q1 = ctx.Queue()
+    p1 = ctx.Process(target=_tied_worker, args=(0, 1, port, q1))
+    p1.start()
+    ref = q1.get(timeout=180)
+    p1.join(timeout=60)
+    _, _, _, Zr, vr, sr, e1r = ref
+    for rank, lo, hi, Zs, vs, ss, e1s in res:
+        for k in range(hi - lo):
+            assert np.allclose(Zs[k], Zr[lo + k], rtol=1e-9, atol=1e-12)
+            assert vs[k] == pytest.approx(vr[lo + k], rel=1e-9) and ss[k] == pytest.approx(sr[lo + k], rel=1e-9)
+            assert np.allclose(e1s[k], e1r[lo + k], rtol=1e-8, atol=1e-10)
+            assert np.allclose(Zs[k], Zs[0]) and np.allclose(Zs[0], res[0][3][0])  # one Z everywhere
+    assert not np.allclose(Zr[0], _data("logisticsoftmax")[3])  # and it moved
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -94,6 +94,12 @@ SYMBOLS = {
     "agp_svgp_get_kernel": (_I32, [_VP, _I32, _PDBL, _PDBL]),
     "agp_svgp_set_multioutput": (_I32, [_VP, _I32, C.POINTER(LikDesc), _PDBL, _DBL, _DBL, _DBL, _DBL]),
     "agp_svgp_get_A": (_I32, [_VP, _PDBL]),
+    "agp_svgp_elbo_terms": (_I32, [_VP, _PDBL]),
+    "agp_svgp_mo_shard": (_I32, [_VP, _I32]),
+    "agp_svgp_mo_fbuf_ptr": (_I32, [_VP, _PVP, _PI64]),
+    "agp_svgp_mo_mix": (_I32, [_VP]),
+    "agp_svgp_mo_refresh_f": (_I32, [_VP]),
+    "agp_svgp_mo_predict_from_f": (_I32, [_VP, _I64, _I32, _VP, _VP, _PDBL, _PDBL, _I32]),
     "agp_svgp_prefetch": (_I32, [_VP, _VP, _I64, _VP, _I64]),
     "agp_svgp_lsm_gamma": (_I32, [_VP]),
     "agp_svgp_lsm_alpha": (_I32, [_VP]),

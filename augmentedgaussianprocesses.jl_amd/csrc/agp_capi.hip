@@ -244,6 +244,12 @@ struct SvgpBase {
   virtual agp_status set_multioutput(int n_task, const agp_lik_desc* liks, const double* A_host, double eta, double b1,
                                      double b2, double eps) = 0;
   virtual agp_status get_A(double* A_host) = 0;
+  virtual agp_status mo_shard(int q_total) = 0;
+  virtual agp_status mo_fbuf_ptr(void** p, int64_t* n) = 0;
+  virtual agp_status mo_mix() = 0;
+  virtual agp_status mo_refresh_f() = 0;
+  virtual agp_status mo_predict_from_f(int64_t nt, int mode, void* o0, void* o1, const double* nodes,
+                                       const double* weights, int nn) = 0;
   virtual agp_status hyper_configure(int opt_k, double k_eta, int opt_z, double z_eta, double b1, double b2,
                                      double eps) = 0;
   virtual agp_status hypergrad(int l, double* dvar, double* dscale, void* dZ) = 0;
@@ -258,6 +264,7 @@ struct SvgpBase {
   virtual agp_status check_status() = 0;
   virtual agp_status elbo(const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B, double rho,
                           int fresh, double* out) = 0;
+  virtual agp_status elbo_terms(double* out3) = 0;
   virtual agp_status get_state(int l, void* mu, void* sigma, void* eta1, void* eta2) = 0;
   virtual agp_status set_state(int l, const void* eta1, const void* eta2) = 0;
   virtual agp_status get_matrix(int l, int which, void* out, int64_t ldo) = 0;
@@ -396,6 +403,14 @@ struct Svgp : SvgpBase {
   int a_step = 0;
   double a_eta = 0, a_b1 = 0.9, a_b2 = 0.999, a_eps = 1e-8;
   T *mo_mixm = nullptr, *mo_mixv = nullptr, *mo_th = nullptr, *mo_cc = nullptr, *mo_th_save = nullptr;
+  // latent-sharded multi-output model (one handle per GPU holds the latents [qlo, qlo + nl) of qtot): the mixing needs every
+  // latent's (mean_f, var_f) on the batch, exchanged through `fall` = T[2][qtot][Bp] (own rows filled, the rest zero, so the
+  // sum over ranks is the all-gather of SURVEY.md section 8e).  fall_state: 0 empty, 1 = pre-update values published by
+  // step_local (-> mo_mix), 2 = current-posterior values published by mo_refresh_f (-> elbo / hypergrad), 3 = consumed.
+  bool mo_sharded = false;
+  int qtot = 0, qlo = 0, fall_state = 0;
+  T* fall = nullptr;
+  int Qa() const { return mo_sharded ? qtot : nl; }
   // prefetch of the next minibatch's Knm / kappa on a second stream (overlaps the latency-bound factorisation)
   hipStream_t pf_stream = nullptr;
   hipEvent_t pf_done = nullptr, step_done[2] = {nullptr, nullptr};
@@ -561,7 +576,7 @@ struct Svgp : SvgpBase {
       if (g.z_am) dfree(g.z_am);
       if (g.z_av) dfree(g.z_av);
     }
-    T* mops[] = {A_dev, mo_mixm, mo_mixv, mo_th, mo_cc, mo_th_save, mo_pmu, mo_pvar};
+    T* mops[] = {A_dev, mo_mixm, mo_mixv, mo_th, mo_cc, mo_th_save, mo_pmu, mo_pvar, fall};
     for (T* p : mops)
       if (p) dfree(p);
     double* dps[] = {gradA_dev, am_dev, av_dev};
@@ -991,7 +1006,8 @@ struct Svgp : SvgpBase {
         ctx->err = "multi-output handle: call agp_svgp_set_multioutput first";
         return AGP_ERR_INVALID;
       }
-      AGPCHK(mo_local(y, idx, B, rho, !fresh));
+      if (mo_sharded) return publish_f(muf, varf, 1);  // the driver all-reduces `fall`, then agp_svgp_mo_mix
+      AGPCHK(mo_local(y, idx, B, rho, !fresh, muf, varf));
     }
     return AGP_OK;
   }
@@ -1050,13 +1066,19 @@ struct Svgp : SvgpBase {
                                   nullptr, 0)));
     if (mo) {
       // mixed means under the current posterior need every latent's mean_f on this batch
-      for (int q = 0; q < nl; ++q) {
+      if (mo_sharded && fall_state != 2) {
+        ctx->err = "latent-sharded multi-output hyper-gradient: call agp_svgp_mo_refresh_f and all-reduce the exchange "
+                   "buffer first";
+        return AGP_ERR_INVALID;
+      }
+      for (int q = 0; q < nl && !mo_sharded; ++q) {
         AGPCHK(materialize(lat[q]));
         hipLaunchKernelGGL((k_gemv_rows<T>), grid1(B * 64), dim3(256), 0, st(), (const T*)lat[q].kappa, mp, B, mp,
                            (const T*)lat[q].mu, emuf + q * Bp);
       }
-      hipLaunchKernelGGL((k_mo_hyper_gvec<T>), grid1(B), dim3(256), 0, st(), B, nl, Bp, mocfg, (const T*)A_dev,
-                         (const T*)y_last, ystride, idx_last, (const T*)emuf, (const T*)mo_th, l,
+      hipLaunchKernelGGL((k_mo_hyper_gvec<T>), grid1(B), dim3(256), 0, st(), B, Qa(), Bp, mocfg, (const T*)A_dev,
+                         (const T*)y_last, ystride, idx_last, mo_sharded ? (const T*)fall : (const T*)emuf,
+                         (const T*)mo_th, l + qlo,
                          (int)(desc.elbo_mode == AGP_ELBO_REFERENCE), hy_gmu, hy_gs);
       LAUNCHCHK(ctx);
     } else {
@@ -1334,18 +1356,19 @@ struct Svgp : SvgpBase {
     a_eps = eps;
     a_step = 0;
     if (!A_dev) {
-      AGPCHK(dmalloc(ctx, &A_dev, (int64_t)MO_MAXT * nl));
-      AGPCHK(dmalloc(ctx, &gradA_dev, (int64_t)MO_MAXT * nl));
-      AGPCHK(dmalloc(ctx, &am_dev, (int64_t)MO_MAXT * nl));
-      AGPCHK(dmalloc(ctx, &av_dev, (int64_t)MO_MAXT * nl));
+      AGPCHK(dmalloc(ctx, &A_dev, (int64_t)MO_MAXT * Qa()));
+      AGPCHK(dmalloc(ctx, &gradA_dev, (int64_t)MO_MAXT * Qa()));
+      AGPCHK(dmalloc(ctx, &am_dev, (int64_t)MO_MAXT * Qa()));
+      AGPCHK(dmalloc(ctx, &av_dev, (int64_t)MO_MAXT * Qa()));
+      if (mo_sharded) AGPCHK(dmalloc(ctx, &fall, (int64_t)2 * qtot * Bp));
       T** bv[] = {&mo_mixm, &mo_mixv, &mo_th, &mo_cc, &mo_th_save};
       for (auto p : bv) AGPCHK(dmalloc(ctx, p, (int64_t)MO_MAXT * Bp));
     }
-    std::vector<T> ha((size_t)n_task * nl);
+    std::vector<T> ha((size_t)n_task * Qa());
     for (size_t i = 0; i < ha.size(); ++i) ha[i] = (T)A_host[i];
     HIPCHK(ctx, hipMemcpyAsync(A_dev, ha.data(), sizeof(T) * ha.size(), hipMemcpyHostToDevice, st()));
-    HIPCHK(ctx, hipMemsetAsync(am_dev, 0, sizeof(double) * MO_MAXT * nl, st()));
-    HIPCHK(ctx, hipMemsetAsync(av_dev, 0, sizeof(double) * MO_MAXT * nl, st()));
+    HIPCHK(ctx, hipMemsetAsync(am_dev, 0, sizeof(double) * MO_MAXT * Qa(), st()));
+    HIPCHK(ctx, hipMemsetAsync(av_dev, 0, sizeof(double) * MO_MAXT * Qa(), st()));
     HIPCHK(ctx, hipMemsetAsync(mo_cc, 0, sizeof(T) * MO_MAXT * Bp, st()));
     // local variables before the first step (init_local_vars): theta = 1/sigma2 (Gaussian) or 0
     for (int t = 0; t < n_task; ++t)
@@ -1359,7 +1382,7 @@ struct Svgp : SvgpBase {
 
   agp_status get_A(double* A_host) override {
     if (!mo || !A_host) return AGP_ERR_INVALID;
-    std::vector<T> ha((size_t)nT * nl);
+    std::vector<T> ha((size_t)nT * Qa());
     HIPCHK(ctx, hipMemcpyAsync(ha.data(), A_dev, sizeof(T) * ha.size(), hipMemcpyDeviceToHost, st()));
     HIPCHK(ctx, hipStreamSynchronize(st()));
     for (size_t i = 0; i < ha.size(); ++i) A_host[i] = (double)ha[i];
@@ -1367,19 +1390,75 @@ struct Svgp : SvgpBase {
   }
 
   // update_A! then the mixed local updates / gradients (update_parameters!(::MOSVGP), training.jl:153-158)
-  agp_status mo_local(const void* y, const int64_t* idx, int64_t B, double rho, bool update_A) {
+  // fm / fv: T[Qa][Bp] mean_f / var_f of ALL latents (the handle's own muf / varf, or the exchanged `fall` when sharded:
+  // update_A! is then replicated on every rank, the gradients r / w are written for the owned latents only)
+  agp_status mo_local(const void* y, const int64_t* idx, int64_t B, double rho, bool update_A, const T* fm,
+                      const T* fv) {
+    const int Q = Qa();
     if (update_A && a_eta > 0) {
       a_step += 1;
-      hipLaunchKernelGGL((k_mo_gradA<T>), dim3((unsigned)nl, (unsigned)nT), dim3(256), 0, st(), B, nl, Bp, mocfg,
-                         (const T*)A_dev, (const T*)y, ystride, idx, (const T*)muf, (const T*)varf, (const T*)mo_th,
-                         gradA_dev);
-      hipLaunchKernelGGL((k_mo_applyA<T>), dim3(1), dim3(64), 0, st(), nT, nl, A_dev, (const double*)gradA_dev, am_dev,
+      hipLaunchKernelGGL((k_mo_gradA<T>), dim3((unsigned)Q, (unsigned)nT), dim3(256), 0, st(), B, Q, Bp, mocfg,
+                         (const T*)A_dev, (const T*)y, ystride, idx, fm, fv, (const T*)mo_th, gradA_dev);
+      hipLaunchKernelGGL((k_mo_applyA<T>), dim3(1), dim3(64), 0, st(), nT, Q, A_dev, (const double*)gradA_dev, am_dev,
                          av_dev, a_step, a_eta, a_b1, a_b2, a_eps);
     }
-    hipLaunchKernelGGL((k_mo_local<T>), grid1(B), dim3(256), 0, st(), B, nl, Bp, mocfg, (const T*)A_dev, (T)rho,
-                       (const T*)y, ystride, idx, (const T*)muf, (const T*)varf, mo_mixm, mo_mixv, mo_th, mo_cc, rbuf,
-                       wbuf, 1);
+    hipLaunchKernelGGL((k_mo_local<T>), grid1(B), dim3(256), 0, st(), B, Q, Bp, mocfg, (const T*)A_dev, (T)rho,
+                       (const T*)y, ystride, idx, fm, fv, mo_mixm, mo_mixv, mo_th, mo_cc, rbuf, wbuf, 1, qlo, nl);
     LAUNCHCHK(ctx);
+    return AGP_OK;
+  }
+
+  agp_status mo_shard(int q_total) override {
+    if (lp.kind != AGP_LIK_MULTIOUTPUT || mo || q_total < desc.latent_offset + nl || desc.latent_offset < 0) {
+      ctx->err = "agp_svgp_mo_shard: call before agp_svgp_set_multioutput with q_total >= latent_offset + n_latent";
+      return AGP_ERR_INVALID;
+    }
+    mo_sharded = true;
+    qtot = q_total;
+    qlo = desc.latent_offset;
+    return AGP_OK;
+  }
+  // own rows of (mean_f, var_f) into the exchange buffer, zeros elsewhere
+  agp_status publish_f(const T* fm, const T* fv, int state) {
+    HIPCHK(ctx, hipMemsetAsync(fall, 0, sizeof(T) * 2 * qtot * Bp, st()));
+    HIPCHK(ctx, hipMemcpyAsync(fall + (int64_t)qlo * Bp, fm, sizeof(T) * nl * Bp, hipMemcpyDeviceToDevice, st()));
+    HIPCHK(ctx, hipMemcpyAsync(fall + (int64_t)(qtot + qlo) * Bp, fv, sizeof(T) * nl * Bp, hipMemcpyDeviceToDevice, st()));
+    fall_state = state;
+    return AGP_OK;
+  }
+  agp_status mo_fbuf_ptr(void** p, int64_t* n) override {
+    if (!mo_sharded || !fall || !p || !n) return AGP_ERR_INVALID;
+    *p = fall;
+    *n = (int64_t)2 * qtot * Bp;
+    return AGP_OK;
+  }
+  agp_status mo_mix() override {
+    if (!mo_sharded || !mo || fall_state != 1) {
+      ctx->err = "agp_svgp_mo_mix: needs a latent-sharded multi-output handle right after agp_svgp_step_local";
+      return AGP_ERR_INVALID;
+    }
+    fall_state = 3;
+    return mo_local(y_last, idx_last, B_last, rho_last, true, fall, fall + (int64_t)qtot * Bp);
+  }
+  agp_status mo_refresh_f() override {
+    if (!mo_sharded || !mo || B_last <= 0) return AGP_ERR_INVALID;
+    AGPCHK(posterior_f(B_last));
+    return publish_f(emuf, evarf, 2);
+  }
+  // mean_f / var_f of the owned latents on the last batch with the CURRENT posterior -> emuf / evarf (analyticVI.jl:260-266)
+  agp_status posterior_f(int64_t B) {
+    const int64_t Bq = rup64(B);
+    for (int l = 0; l < nl; ++l) {
+      Latent& g = lat[l];
+      HIPCHK(ctx, hipMemcpyAsync(g.Wbuf, g.kappa, sizeof(T) * Bq * mp, hipMemcpyDeviceToDevice, st()));
+      AGPCHK(aug_factor(g, Bq, 1));
+      HIPCHK(ctx, hipMemcpyAsync(g.v, g.Wbuf + Bq * mp, sizeof(T) * mp, hipMemcpyDeviceToDevice, st()));
+      hipLaunchKernelGGL((k_w_rowstats<T>), grid1(B * 64), dim3(256), 0, st(), (const T*)g.Wbuf, mp, B, mp,
+                         (const T*)g.v, pw0, pw1);
+      hipLaunchKernelGGL((k_meanvar_finish<T>), grid1(B), dim3(256), 0, st(), B, 1, (const T*)pw0, (const T*)pw1, ldp,
+                         (const T*)(Kt + l * Bp), emuf + l * Bp, evarf + l * Bp);
+      LAUNCHCHK(ctx);
+    }
     return AGP_OK;
   }
 
@@ -1594,7 +1673,16 @@ struct Svgp : SvgpBase {
     const bool lsm = lp.kind == AGP_LIK_LOGISTICSOFTMAX;
     const T* mf;
     const T* vf;
-    if (fresh) {
+    if (mo_sharded) {
+      if (fresh || fall_state != 2) {
+        ctx->err = "latent-sharded multi-output ELBO: fresh_local = 0 only, after agp_svgp_mo_refresh_f + the all-reduce "
+                   "of the exchange buffer";
+        return fresh ? AGP_ERR_UNSUPPORTED : AGP_ERR_INVALID;
+      }
+      if (B != B_last) return AGP_ERR_INVALID;
+      mf = fall;
+      vf = fall + (int64_t)qtot * Bp;
+    } else if (fresh) {
       // ELBO.jl:32-47 : recompute kernel matrices on (x, y), fresh local variables, one local update
       if (lsm) {
         HIPCHK(ctx, hipMemcpyAsync(alpha_save, alpha, sizeof(T) * Bp, hipMemcpyDeviceToDevice, st()));
@@ -1621,26 +1709,15 @@ struct Svgp : SvgpBase {
         return AGP_ERR_INVALID;
       }
       // mean_f / var_f with the UPDATED posterior, local variables from the step (analyticVI.jl:260-266)
-      const int64_t Bq = rup64(B);
-      for (int l = 0; l < nl; ++l) {
-        Latent& g = lat[l];
-        HIPCHK(ctx, hipMemcpyAsync(g.Wbuf, g.kappa, sizeof(T) * Bq * mp, hipMemcpyDeviceToDevice, st()));
-        AGPCHK(aug_factor(g, Bq, 1));
-        HIPCHK(ctx, hipMemcpyAsync(g.v, g.Wbuf + Bq * mp, sizeof(T) * mp, hipMemcpyDeviceToDevice, st()));
-        hipLaunchKernelGGL((k_w_rowstats<T>), grid1(B * 64), dim3(256), 0, st(), (const T*)g.Wbuf, mp, B, mp,
-                           (const T*)g.v, pw0, pw1);
-        hipLaunchKernelGGL((k_meanvar_finish<T>), grid1(B), dim3(256), 0, st(), B, 1, (const T*)pw0, (const T*)pw1, ldp,
-                           (const T*)(Kt + l * Bp), emuf + l * Bp, evarf + l * Bp);
-        LAUNCHCHK(ctx);
-      }
+      AGPCHK(posterior_f(B));
       mf = emuf;
       vf = evarf;
     }
     if (mo) {
       // multi-output ELBO (analyticVI.jl:277-297): per-task terms on the A-mixed mean_f / var_f
       if (!fresh)
-        hipLaunchKernelGGL((k_mo_local<T>), grid1(B), dim3(256), 0, st(), B, nl, Bp, mocfg, (const T*)A_dev, (T)rho,
-                           (const T*)y, ystride, idx, mf, vf, mo_mixm, mo_mixv, mo_th, mo_cc, rbuf, wbuf, 0);
+        hipLaunchKernelGGL((k_mo_local<T>), grid1(B), dim3(256), 0, st(), B, Qa(), Bp, mocfg, (const T*)A_dev, (T)rho,
+                           (const T*)y, ystride, idx, mf, vf, mo_mixm, mo_mixv, mo_th, mo_cc, rbuf, wbuf, 0, qlo, nl);
       for (int t = 0; t < nT; ++t) {
         LikParams<T> lt{mocfg.kind[t], mocfg.p0[t], mocfg.p1[t]};
         hipLaunchKernelGGL((k_elbo_terms<T>), dim3(1), dim3(1024), 0, st(), B, 1, Bp, lt, desc.elbo_mode, 0, 0,
@@ -1697,10 +1774,21 @@ struct Svgp : SvgpBase {
         kl_gauss += ek;
       }
     }
+    // sharded multi-output: the (replicated) data terms are counted by the rank that owns latent 0, the Gaussian KLs by their
+    // owners; the driver sums the scalars over ranks
+    if (mo_sharded && qlo != 0) e_data = kl_aug = 0.0;
+    kl_gauss_last = kl_gauss;
     *out = rho * e_data - kl_gauss - rho * kl_aug;
     return AGP_OK;
   }
-  double e_data = 0, kl_aug = 0, mo_e = 0, mo_kl = 0;
+  double e_data = 0, kl_aug = 0, mo_e = 0, mo_kl = 0, kl_gauss_last = 0;
+  agp_status elbo_terms(double* out3) override {
+    if (!out3) return AGP_ERR_INVALID;
+    out3[0] = e_data;
+    out3[1] = kl_gauss_last;
+    out3[2] = kl_aug;
+    return AGP_OK;
+  }
 
   agp_status get_state(int l, void* mu, void* sigma, void* eta1, void* eta2) override {
     if (l < 0 || l >= nl) return AGP_ERR_INVALID;
@@ -1837,11 +1925,12 @@ struct Svgp : SvgpBase {
       mo_pred_cap = nt;
     }
     AGPCHK(predict_f_latent(xt, ldx, nt, mo_pmu, var_out ? mo_pvar : nullptr));
-    hipLaunchKernelGGL((k_mo_mix<T>), grid1(nt), dim3(256), 0, st(), nt, nl, nT, (const T*)A_dev, (const T*)mo_pmu, nt,
-                       (T*)mu_out, nt, 0);
+    // a latent-sharded handle returns its PARTIAL mix (own columns of A): summed over ranks it is the full one
+    hipLaunchKernelGGL((k_mo_mix<T>), grid1(nt), dim3(256), 0, st(), nt, nl, nT, (const T*)(A_dev + qlo), Qa(),
+                       (const T*)mo_pmu, nt, (T*)mu_out, nt, 0);
     if (var_out)
-      hipLaunchKernelGGL((k_mo_mix<T>), grid1(nt), dim3(256), 0, st(), nt, nl, nT, (const T*)A_dev, (const T*)mo_pvar, nt,
-                         (T*)var_out, nt, 1);
+      hipLaunchKernelGGL((k_mo_mix<T>), grid1(nt), dim3(256), 0, st(), nt, nl, nT, (const T*)(A_dev + qlo), Qa(),
+                         (const T*)mo_pvar, nt, (T*)var_out, nt, 1);
     LAUNCHCHK(ctx);
     return AGP_OK;
   }
@@ -1880,16 +1969,9 @@ struct Svgp : SvgpBase {
   agp_status predict_y(const void* xt, int64_t ldx, int64_t nt, void* out) override {
     if (!out) return AGP_ERR_INVALID;
     if (mo) {  // T[n_task][n_t]: regression tasks -> mean ; Bernoulli tasks -> 1.0 / 0.0 (mu_f > 0)
+      if (mo_sharded) return sharded_predict_error();
       AGPCHK(predict_f(xt, ldx, nt, out, nullptr));
-      for (int t = 0; t < nT; ++t) {
-        if (mocfg.kind[t] == AGP_LIK_LOGISTIC || mocfg.kind[t] == AGP_LIK_BAYESIANSVM)
-          hipLaunchKernelGGL((k_step01<T>), grid1(nt), dim3(256), 0, st(), (T*)out + (int64_t)t * nt, nt);
-        else if (mocfg.kind[t] == AGP_LIK_NEGBINOMIAL)
-          hipLaunchKernelGGL((k_predict_event<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)out + (int64_t)t * nt, 1,
-                             (double)mocfg.p0[t], (const T*)nullptr, (T*)out + (int64_t)t * nt);
-      }
-      LAUNCHCHK(ctx);
-      return AGP_OK;
+      return mo_predict_from_f(nt, 0, out, nullptr, nullptr, nullptr, 0);
     }
     if (lp.kind == AGP_LIK_GAUSSIAN || lp.kind == AGP_LIK_STUDENTT || lp.kind == AGP_LIK_LAPLACE)
       return predict_f(xt, ldx, nt, out, nullptr);
@@ -1958,7 +2040,35 @@ struct Svgp : SvgpBase {
     AGPCHK(ensure_pred_ws(nt, true));
     if (mo) {  // per task compute_proba on the mixed (mu_f, var_f): out0 / out1 are T[n_task][n_t]
       if (!o1) return AGP_ERR_INVALID;
+      if (mo_sharded) return sharded_predict_error();
       AGPCHK(predict_f(xt, ldx, nt, o0, o1));
+      return mo_predict_from_f(nt, 1, o0, o1, nodes, weights, nn);
+    }
+    return proba_y_single(xt, ldx, nt, nodes, weights, nn, o0, o1);
+  }
+
+  agp_status sharded_predict_error() {
+    ctx->err = "latent-sharded multi-output model: predict_f returns the partial mix; all-reduce it and finish with "
+               "agp_svgp_mo_predict_from_f";
+    return AGP_ERR_UNSUPPORTED;
+  }
+  // the likelihood half of predict_y (mode 0: o0 = mixed mean_f, in place) / proba_y (mode 1: o0, o1 = mixed mean_f, var_f, in
+  // place) of a multi-output model: what follows the mixing in predictions.jl:178-247
+  agp_status mo_predict_from_f(int64_t nt, int mode, void* o0, void* o1, const double* nodes, const double* weights,
+                               int nn) override {
+    if (!mo || !o0 || nt <= 0 || (mode == 1 && !o1)) return AGP_ERR_INVALID;
+    if (mode == 0) {
+      for (int t = 0; t < nT; ++t) {
+        if (mocfg.kind[t] == AGP_LIK_LOGISTIC || mocfg.kind[t] == AGP_LIK_BAYESIANSVM)
+          hipLaunchKernelGGL((k_step01<T>), grid1(nt), dim3(256), 0, st(), (T*)o0 + (int64_t)t * nt, nt);
+        else if (mocfg.kind[t] == AGP_LIK_NEGBINOMIAL)
+          hipLaunchKernelGGL((k_predict_event<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)o0 + (int64_t)t * nt, 1,
+                             (double)mocfg.p0[t], (const T*)nullptr, (T*)o0 + (int64_t)t * nt);
+      }
+      LAUNCHCHK(ctx);
+      return AGP_OK;
+    }
+    {
       for (int t = 0; t < nT; ++t) {
         T* m0 = (T*)o0 + (int64_t)t * nt;
         T* v0 = (T*)o1 + (int64_t)t * nt;
@@ -1988,6 +2098,10 @@ struct Svgp : SvgpBase {
       LAUNCHCHK(ctx);
       return AGP_OK;
     }
+  }
+
+  agp_status proba_y_single(const void* xt, int64_t ldx, int64_t nt, const double* nodes, const double* weights, int nn,
+                            void* o0, void* o1) {
     AGPCHK(predict_f(xt, ldx, nt, pmu, pvar));
     if (lp.kind == AGP_LIK_GAUSSIAN) {
       if (!o1) return AGP_ERR_INVALID;
@@ -2559,6 +2673,31 @@ agp_status agp_svgp_set_multioutput(agp_svgp* h, int32_t n_task, const agp_lik_d
 agp_status agp_svgp_get_A(agp_svgp* h, double* A_host) {
   HCHK(h);
   return h->impl->get_A(A_host);
+}
+agp_status agp_svgp_elbo_terms(agp_svgp* h, double* terms_host) {
+  HCHK(h);
+  return h->impl->elbo_terms(terms_host);
+}
+agp_status agp_svgp_mo_shard(agp_svgp* h, int32_t q_total) {
+  HCHK(h);
+  return h->impl->mo_shard(q_total);
+}
+agp_status agp_svgp_mo_fbuf_ptr(agp_svgp* h, void** ptr, int64_t* count) {
+  HCHK(h);
+  return h->impl->mo_fbuf_ptr(ptr, count);
+}
+agp_status agp_svgp_mo_mix(agp_svgp* h) {
+  HCHK(h);
+  return h->impl->mo_mix();
+}
+agp_status agp_svgp_mo_refresh_f(agp_svgp* h) {
+  HCHK(h);
+  return h->impl->mo_refresh_f();
+}
+agp_status agp_svgp_mo_predict_from_f(agp_svgp* h, int64_t n_t, int32_t mode, void* out0, void* out1,
+                                      const double* gh_nodes_host, const double* gh_weights_host, int32_t n_nodes) {
+  HCHK(h);
+  return h->impl->mo_predict_from_f(n_t, mode, out0, out1, gh_nodes_host, gh_weights_host, n_nodes);
 }
 agp_status agp_svgp_hyper_configure(agp_svgp* h, int32_t opt_kernel, double kernel_eta, int32_t opt_Z, double z_eta,
                                     double adam_b1, double adam_b2, double adam_eps) {

@@ -447,7 +447,7 @@ __global__ void k_mo_local(int64_t B, int Q, int64_t ldb, MoCfg<T> cfg, const T*
                            const T* __restrict__ y, int64_t ystride, const int64_t* __restrict__ idx,
                            const T* __restrict__ muf, const T* __restrict__ varf, T* __restrict__ mixm,
                            T* __restrict__ mixv, T* __restrict__ th, T* __restrict__ cc, T* __restrict__ r,
-                           T* __restrict__ w, int do_local) {
+                           T* __restrict__ w, int do_local, int q_lo, int q_n) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= B) return;
   T gm[MO_MAXT], gs[MO_MAXT], mt[MO_MAXT];
@@ -476,7 +476,9 @@ __global__ void k_mo_local(int64_t B, int Q, int64_t ldb, MoCfg<T> cfg, const T*
     }
   }
   if (!do_local) return;
-  for (int q = 0; q < Q; ++q) {
+  // gradients of the latents this handle owns (all of them, or the slice [q_lo, q_lo + q_n) of a latent-sharded model)
+  for (int ql = 0; ql < q_n; ++ql) {
+    const int q = q_lo + ql;
     T mq = muf[q * ldb + i], g1 = T(0), g2 = T(0);
 #pragma unroll
     for (int t = 0; t < MO_MAXT; ++t) {
@@ -486,8 +488,8 @@ __global__ void k_mo_local(int64_t B, int Q, int64_t ldb, MoCfg<T> cfg, const T*
         g2 += a * a * gs[t];
       }
     }
-    r[q * ldb + i] = rho * g1;
-    w[q * ldb + i] = rho * g2;
+    r[ql * ldb + i] = rho * g1;
+    w[ql * ldb + i] = rho * g2;
   }
 }
 
@@ -570,14 +572,14 @@ __global__ void k_mo_applyA(int nT, int Q, T* __restrict__ A, const double* __re
 
 // out[t][i] = sum_q A[t][q]^p in[q][i]   (p = 1 means, p = 2 variances)   predictions.jl:60-64,75-79
 template <typename T>
-__global__ void k_mo_mix(int64_t n, int Q, int nT, const T* __restrict__ A, const T* __restrict__ in, int64_t ldi,
-                         T* __restrict__ out, int64_t ldo, int square) {
+__global__ void k_mo_mix(int64_t n, int Q, int nT, const T* __restrict__ A, int lda, const T* __restrict__ in,
+                         int64_t ldi, T* __restrict__ out, int64_t ldo, int square) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   for (int t = 0; t < nT; ++t) {
     T s = T(0);
     for (int q = 0; q < Q; ++q) {
-      T a = A[t * Q + q];
+      T a = A[t * lda + q];
       s += (square ? a * a : a) * in[q * ldi + i];
     }
     out[t * ldo + i] = s;

@@ -7,6 +7,10 @@ The path shards in two ways:
   `latent_slice(K, world, r)`; X, y and the minibatch index stream are replicated.  The only data-path collective is the
   LogisticSoftMax fixed point: sum_k gamma_k over ALL latents, a length-B vector all-reduced twice per step
   (src/likelihood/logisticsoftmax.jl:65-72).  Other likelihoods need no collective at all.
+  A latent-sharded multi-output model (MOSVGP(..., latent_slice=...)) mixes ALL latents into every task
+  (src/models/single_and_multi_output_utils.jl:24-84): the (mean_f, var_f) of the owned latents are exchanged once per step
+  (2 Q B numbers, the all-gather of section 8e written as an all-reduce over a zero-padded buffer), after which the task-side
+  work and update_A! run redundantly on every rank.
 * batch-parallel -- one latent, the minibatch split across ranks; every per-point quantity is row-independent and only the
   batch statistics [kappa'(rho g1) | rho kappa' diag(g2) kappa] couple the shards: one all-reduce per step
   (src/inference/analyticVI.jl:168,179), after which every rank applies the identical global step.
@@ -77,6 +81,10 @@ def predict_sharded(predict_fn, X_test, group=None, gather: bool = True):
 def _all_reduce(t, group=None):
     import torch.distributed as dist
 
+    if group is not None and hasattr(group, "all_reduce_sum"):
+        group.all_reduce_sum(t)  # in-process group (tests: several ranks as threads sharing one GPU)
+        return t
+
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
@@ -90,8 +98,50 @@ def latent_parallel_step(engine, idx, rho: float, group=None) -> None:
             engine.lsm_gamma()
             _all_reduce(engine.gsum, group)
             engine.lsm_alpha()
+    if getattr(engine, "is_mo_sharded", False):
+        _all_reduce(engine.fbuf, group)  # every latent's (mean_f, var_f) on the minibatch
+        engine.mo_mix()                  # update_A! + mixed local updates + the owned latents' gradients
     engine.step_stats()
     engine.step_global()
+
+
+def elbo_parallel(engine, mode: str = "latent", group=None) -> float:
+    """ELBO(model, state, y) on the last minibatch of a sharded run (analyticVI.jl:255-297), identical on every rank.
+    latent mode: every rank evaluates its latents' share (shared terms are counted by the owner of latent 0), one scalar
+    all-reduce; a latent-sharded multi-output model first re-exchanges (mean_f, var_f) under the updated posterior.
+    batch mode: the data / augmented-KL sums are per-shard, the Gaussian KL is replicated and counted once."""
+    import torch
+
+    if getattr(engine, "is_mo_sharded", False):
+        engine.mo_refresh_f()
+        _all_reduce(engine.fbuf, group)
+    total, (e_data, kl_gauss, kl_aug) = engine.elbo_local()
+    if mode == "latent":
+        t = torch.tensor([total], dtype=torch.float64, device=engine.reduce_device)
+        return float(_all_reduce(t, group)[0])
+    t = torch.tensor([e_data, kl_aug], dtype=torch.float64, device=engine.reduce_device)
+    _all_reduce(t, group)
+    return float(engine.rho * t[0] - kl_gauss - engine.rho * t[1])
+
+
+def hyper_step_parallel(engine, group=None) -> None:
+    """update_hyperparameters! (autotuning.jl:86-140) of a latent-sharded model: every latent optimises its own kernel and Z
+    (the reference's deep copies), so the step itself needs no collective; only a sharded multi-output model first
+    re-exchanges the latents' mean_f under the updated posterior, which the mixed data term of the gradient reads."""
+    if getattr(engine, "is_mo_sharded", False):
+        engine.mo_refresh_f()
+        _all_reduce(engine.fbuf, group)
+    engine.hyper_step()
+
+
+def predict_mo_sharded(engine, X_test, what: str = "f", group=None):
+    """predict_f / predict_y / proba_y of a latent-sharded multi-output model: the partial mixes sum_{q owned} A[t][q]^p f_q
+    are all-reduced (n_task x n_t numbers each), the task likelihoods then finish in place on every rank."""
+    mu, var = engine.predict_f_partial(X_test, need_var=(what != "y"))
+    _all_reduce(mu, group)
+    if var is not None:
+        _all_reduce(var, group)
+    return engine.finish_predict(mu, var, what)
 
 
 def batch_parallel_step(engine, idx_local, rho: float, group=None) -> None:
@@ -134,16 +184,21 @@ class HipEngine:
         self.h = model._ensure_handle(max_batch)
         model._chk(self.L.agp_svgp_refresh_K(self.h))
         self.is_lsm = model.likelihood.kind == capi.LIK_LOGISTICSOFTMAX
+        self.is_mo_sharded = bool(getattr(model, "sharded", False))
         self._X = self._y = None
         self._stats = None
         self._gsum = None
+        self._fbuf = None
         self._B = 0
+        self.rho = 1.0
+
+    @property
+    def reduce_device(self):
+        return self.model._dev()
 
     def bind_data(self, X, y, obsdim: int = 1):
-        from .likelihoods import treat_labels
-
         self._X = self.model._upload(X, obsdim)
-        self._y = self.model._upload_y(treat_labels(y, self.model.likelihood))
+        self._y = self.model._upload_y(self.model._treat(y))
         return self
 
     def _view(self, ptr_fn):
@@ -160,6 +215,7 @@ class HipEngine:
         idx_t = torch.as_tensor(np.asarray(idx, dtype=np.int64), device=self.model._dev())
         self._keep = idx_t
         self._B = idx_t.numel()
+        self.rho = float(rho)
         self.model._chk(self.L.agp_svgp_step_local(self.h, C.c_void_p(self._X.data_ptr()), self._X.stride(0),
                                                    C.c_void_p(self._y.data_ptr()), C.c_void_p(idx_t.data_ptr()),
                                                    self._B, float(rho)))
@@ -177,6 +233,58 @@ class HipEngine:
             self._gsum = self._view(self.L.agp_svgp_lsm_gsum_ptr)
         return self._gsum
 
+    @property
+    def fbuf(self):
+        """exchange buffer T[2][Q][Bp] of a latent-sharded multi-output handle (own rows filled, zeros elsewhere)"""
+        if self._fbuf is None:
+            self._fbuf = self._view(self.L.agp_svgp_mo_fbuf_ptr)
+        return self._fbuf
+
+    def mo_mix(self):
+        self.model._chk(self.L.agp_svgp_mo_mix(self.h))
+
+    def mo_refresh_f(self):
+        self.model._chk(self.L.agp_svgp_mo_refresh_f(self.h))
+
+    def elbo_local(self):
+        """(this rank's ELBO share, (data term, Gaussian KL, augmented KL)) on the last minibatch"""
+        out = C.c_double()
+        parts = (C.c_double * 3)()
+        self.model._chk(self.L.agp_svgp_elbo(self.h, C.c_void_p(self._X.data_ptr()), self._X.stride(0),
+                                             C.c_void_p(self._y.data_ptr()), C.c_void_p(self._keep.data_ptr()), self._B,
+                                             self.rho, 0, C.byref(out)))
+        self.model._chk(self.L.agp_svgp_elbo_terms(self.h, parts))
+        return out.value, tuple(parts)
+
+    def predict_f_partial(self, X_test, need_var=True):
+        import torch
+
+        mdl = self.model
+        Xt = mdl._upload(X_test, 1)
+        nt = Xt.shape[0]
+        mu = torch.empty(mdl.n_task, nt, dtype=mdl.tdtype, device=mdl._dev())
+        var = torch.empty_like(mu) if need_var else None
+        mdl._chk(self.L.agp_svgp_predict_f(self.h, C.c_void_p(Xt.data_ptr()), Xt.stride(0), nt,
+                                           C.c_void_p(mu.data_ptr()), C.c_void_p(var.data_ptr()) if need_var else None))
+        return mu, var
+
+    def finish_predict(self, mu, var, what):
+        from .svgp import _gauss_hermite as _gh
+
+        mdl = self.model
+        nt = mu.shape[1]
+        if what == "y":
+            mdl._chk(self.L.agp_svgp_mo_predict_from_f(self.h, nt, 0, C.c_void_p(mu.data_ptr()), None, None, None, 0))
+        elif what == "proba":
+            nodes, weights = _gh()
+            mdl._chk(self.L.agp_svgp_mo_predict_from_f(
+                self.h, nt, 1, C.c_void_p(mu.data_ptr()), C.c_void_p(var.data_ptr()),
+                nodes.ctypes.data_as(C.POINTER(C.c_double)), weights.ctypes.data_as(C.POINTER(C.c_double)), len(nodes)))
+        mdl._chk(self.L.agp_ctx_sync(mdl._ctx))
+        if what == "y":
+            return mu.cpu().numpy()
+        return mu.cpu().numpy(), var.cpu().numpy()
+
     def step_stats(self):
         self.model._chk(self.L.agp_svgp_step_stats(self.h))
 
@@ -188,6 +296,9 @@ class HipEngine:
 
     def step_global(self):
         self.model._chk(self.L.agp_svgp_step_global(self.h))
+
+    def hyper_step(self):
+        self.model._chk(self.L.agp_svgp_hyper_step(self.h))
 
     def hyper_gradients(self):
         """sum over this rank's latents of (dvariance, dscale[D], dZ[m, D]) as one flat device tensor"""

@@ -411,7 +411,8 @@ class MOSVGP(SVGP):
 
     def __init__(self, kernel, likelihoods, inference, Zs, *, Aoptimiser=None, A=None, verbose: int = 0,
                  optimiser=False, atfrequency: int = 1, mean=None, Zoptimiser=False, T=np.float64,
-                 device: Optional[int] = None, seed: Optional[int] = None, elbo_mode: str = "corrected"):
+                 device: Optional[int] = None, seed: Optional[int] = None, elbo_mode: str = "corrected",
+                 latent_slice: Optional[tuple] = None):
         if not isinstance(inference, AnalyticVI):
             raise TypeError("The inference object should be of type `AnalyticVI`")  # MOSVGP.jl:55
         Zs = [np.asarray(z, dtype=np.float64) for z in Zs]
@@ -421,7 +422,10 @@ class MOSVGP(SVGP):
         kernels = [kernels[i % len(kernels)] for i in range(Q)]  # kernel[mod1(i, n_kernel)]  MOSVGP.jl:96-98
         super().__init__(kernels, _MultiOutputLikelihood(liks, Q), inference, Zs, verbose=verbose, optimiser=optimiser,
                          atfrequency=atfrequency, mean=mean, Zoptimiser=Zoptimiser, T=T, device=device, seed=seed,
-                         elbo_mode=elbo_mode)
+                         elbo_mode=elbo_mode, latent_slice=latent_slice)
+        # latent_slice=(lo, hi): this rank owns latents [lo, hi) of the Q (parallel.latent_parallel_step exchanges their
+        # mean_f / var_f); A stays (n_task, Q) and replicated -- pass the same A (or the same seed) on every rank
+        self.sharded = latent_slice is not None
         self.n_task = len(liks)
         if Aoptimiser is None:
             Aoptimiser = ADAM(0.01)  # MOSVGP.jl:42
@@ -452,6 +456,8 @@ class MOSVGP(SVGP):
         super()._post_create(h)  # hyper-parameter optimiser configuration
         liks = (capi.LikDesc * self.n_task)(*[l.lik_desc() for l in self.likelihood.likelihoods])
         o = self.A_opt
+        if self.sharded:
+            self._chk(capi.lib().agp_svgp_mo_shard(h, self.n_latent_total))
         self._chk(capi.lib().agp_svgp_set_multioutput(
             h, self.n_task, liks, self.A.ctypes.data_as(C.POINTER(C.c_double)), o.eta if o else 0.0,
             o.beta[0] if o else 0.9, o.beta[1] if o else 0.999, o.eps if o else 1e-8))

@@ -231,6 +231,24 @@ agp_status agp_svgp_hyper_opt_state(agp_svgp* h, int32_t latent, int32_t set, do
 agp_status agp_svgp_set_multioutput(agp_svgp* h, int32_t n_task, const agp_lik_desc* liks_host, const double* A_host,
                                     double adam_eta, double adam_b1, double adam_b2, double adam_eps);
 agp_status agp_svgp_get_A(agp_svgp* h, double* A_host);
+/* Latent-sharded multi-output model (C5 = 16 latents over 8 GPUs): every rank's handle owns the latents
+ * [desc.latent_offset, desc.latent_offset + desc.n_latent) of q_total.  Call agp_svgp_mo_shard BEFORE set_multioutput; A_host /
+ * get_A are then n_task x q_total (replicated on every rank, update_A! runs redundantly and stays bit-identical).  The mixing
+ * (single_and_multi_output_utils.jl:24-84) needs every latent's (mean_f, var_f) on the minibatch; they travel through one
+ * exchange buffer T[2][q_total][Bp] (mo_fbuf_ptr; own rows filled, the others zero, so an all-reduce(sum) over the ranks is
+ * the all-gather).  One training step:
+ *     step_local -> all-reduce(fbuf) -> mo_mix -> step_stats -> step_global
+ * ELBO (fresh_local = 0) and hypergrad / hyper_step need the mixed means under the UPDATED posterior:
+ *     mo_refresh_f -> all-reduce(fbuf) -> elbo / hypergrad     (elbo returns this rank's share: sum the scalars over ranks)
+ * predict_f returns this rank's PARTIAL mix sum_{q owned} A[t][q]^p f_q: all-reduce it; predict_y / proba_y are then
+ * finished in place by mo_predict_from_f (mode 0: out0 = mixed mean_f -> predict_y ; mode 1: out0, out1 = mixed mean_f,
+ * var_f -> proba_y's two outputs; the Gauss-Hermite rule is only read for Bernoulli / NegBinomial tasks in mode 1). */
+agp_status agp_svgp_mo_shard(agp_svgp* h, int32_t q_total);
+agp_status agp_svgp_mo_fbuf_ptr(agp_svgp* h, void** ptr, int64_t* count);
+agp_status agp_svgp_mo_mix(agp_svgp* h);
+agp_status agp_svgp_mo_refresh_f(agp_svgp* h);
+agp_status agp_svgp_mo_predict_from_f(agp_svgp* h, int64_t n_t, int32_t mode, void* out0, void* out1,
+                                      const double* gh_nodes_host, const double* gh_weights_host, int32_t n_nodes);
 /* Optional look-ahead: compute Knm / kappa of the NEXT minibatch (compute_kappa, latentgp.jl:209-215) on a second,
  * library-owned stream so it overlaps the current step's latency-bound factorisation.  The next cavi_step /
  * step_local called with the same (x, ldx, idx, B) adopts the result; any other call simply ignores it.  idx must stay
@@ -257,6 +275,10 @@ agp_status agp_svgp_check_status(agp_svgp* h);
  *                     batch, re-initialise local variables, one local update, then the ELBO; rho explicit. */
 agp_status agp_svgp_elbo(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B,
                          double rho, int32_t fresh_local, double* elbo_host);
+/* the three terms of the last agp_svgp_elbo call, ELBO = rho * terms[0] - terms[1] - rho * terms[2]: unscaled data term
+ * (expec_loglikelihood), Gaussian KL (+ extraKL), unscaled augmented KL.  A batch-parallel driver sums terms 0 and 2 over the
+ * minibatch shards and counts the (replicated) Gaussian KL once. */
+agp_status agp_svgp_elbo_terms(agp_svgp* h, double* terms_host);
 
 /* state export / import : VarPosterior(mu, Sigma, eta1, eta2)  src/gpblocks/posterior.jl:21-27 ; any pointer
  * may be NULL.  set_state installs (eta1, eta2) and re-derives (mu, Sigma) (inference.jl:25-28). */

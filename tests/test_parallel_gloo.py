@@ -186,6 +186,164 @@ def test_tied_z_hyper_step_all_reduce_two_ranks():
     assert not np.allclose(Zr[0], _data("logisticsoftmax")[3])  # and it moved
 
 
+class MOOracleEngine:
+    """Latent-sharded multi-output model restated with the oracle: this rank owns latents [lo, hi) of Q; everything on the
+    task side (mixing, local variables, update_A!) is replicated and only sees the exchanged buffer."""
+
+    is_lsm = False
+    is_mo_sharded = True
+    reduce_device = "cpu"
+
+    def __init__(self, kern, liks, Zs, A, X, ys, lo, hi, batchsize, a_opt):
+        self.M = R.MOSVGP(kern, liks, Zs, A.copy(), stochastic=True, batchsize=batchsize, A_opt=a_opt)
+        self.lo, self.hi = lo, hi
+        self.own = self.M.latents[lo:hi]
+        for q, g in enumerate(self.M.latents):  # poison what this rank does not own: it must never be read
+            if not (lo <= q < hi):
+                g.mu = np.full_like(g.mu, np.nan)
+        self.X, self.ys = X, ys
+        self.M.local_vars = [R.init_local_vars_single(l, batchsize) for l in liks]
+        self.fbuf = None
+
+    def _publish(self):
+        Q, B = self.M.Q, len(self.idx)
+        f = np.zeros((2, Q, B))
+        for q in range(self.lo, self.hi):
+            g = self.M.latents[q]
+            f[0, q], f[1, q] = R.mean_f(g.mu, g.kappa), R.var_f(g.Sigma, g.kappa, g.Kt)
+        self.fbuf = torch.from_numpy(f)
+
+    def step_local(self, idx, rho):
+        self.rho = self.M.rho = rho
+        self.idx = np.asarray(idx)
+        self.yb = [y[self.idx] for y in self.ys]
+        helper = R.SVGP.__new__(R.SVGP)
+        helper.latents, helper.jitter, helper.hp_updated, helper.stochastic = self.own, self.M.jitter, self.M.hp_updated, True
+        R.SVGP.compute_kernel_matrices(helper, self.X[self.idx])
+        self.M.hp_updated = False
+        self._publish()
+
+    def _mixed(self):
+        f, A = self.fbuf.numpy(), self.M.A
+        return ([A[t] @ f[0] for t in range(self.M.n_task)], [(A[t] ** 2) @ f[1] for t in range(self.M.n_task)])
+
+    def mo_mix(self):
+        M, f = self.M, self.fbuf.numpy()
+        if M.A_opt is not None:  # update_A! on the exchanged values (replicated)
+            for t, lik in enumerate(M.likelihoods):
+                gmu = R.grad_E_mu(lik, self.yb[t], M.local_vars[t])[0]
+                gS = R.grad_E_Sigma(lik, self.yb[t], M.local_vars[t])[0]
+                mt = M.A[t] @ f[0]
+                dA = np.zeros(M.Q)
+                for q in range(M.Q):
+                    others = mt - M.A[t, q] * f[0, q]
+                    x1 = np.dot(gmu, f[0, q]) - 2.0 * np.dot(gS, f[0, q] * others)
+                    x2 = np.dot(gS, f[0, q] ** 2 + f[1, q])
+                    dA[q] = x1 - 2.0 * M.A[t, q] * x2
+                M.A_state[t], delta = M.A_opt.apply(M.A_state[t], dA)
+                M.A[t] = M.A[t] + delta
+                M.A[t] = M.A[t] / np.sqrt(np.sum(M.A[t] ** 2))
+        mu_t, var_t = self._mixed()
+        for t, lik in enumerate(M.likelihoods):
+            M.local_vars[t] = R.local_updates(M.local_vars[t], lik, self.yb[t], (mu_t[t],), (var_t[t],))
+        gmu = [R.grad_E_mu(l, self.yb[t], M.local_vars[t])[0] for t, l in enumerate(M.likelihoods)]
+        gS = [R.grad_E_Sigma(l, self.yb[t], M.local_vars[t])[0] for t, l in enumerate(M.likelihoods)]
+        self.g1 = {q: sum(M.A[t, q] * (gmu[t] - 2.0 * gS[t] * (mu_t[t] - M.A[t, q] * f[0, q])) for t in range(M.n_task))
+                   for q in range(self.lo, self.hi)}
+        self.g2 = {q: sum(M.A[t, q] ** 2 * gS[t] for t in range(M.n_task)) for q in range(self.lo, self.hi)}
+
+    def step_stats(self):
+        pass
+
+    def step_global(self):
+        M = self.M
+        for q in range(self.lo, self.hi):
+            gp = M.latents[q]
+            d1 = R.grad_eta1(self.g1[q], self.rho, gp.kappa, gp.L, gp.mu0, gp.eta1)
+            d2 = R.grad_eta2(self.g2[q], self.rho, gp.kappa, gp.Kinv, gp.eta2)
+            lr = R.robbins_monro_lr(gp.n_eta1, M.kappa_rm, M.tau_rm)
+            gp.n_eta1 += 1
+            gp.eta1 = gp.eta1 + lr * d1
+            gp.eta2 = gp.eta2 + lr * d2
+            gp.eta2 = (gp.eta2 + gp.eta2.T) / 2.0
+            gp.mu, gp.Sigma = R.natural_to_standard(gp.eta1, gp.eta2)
+
+    def mo_refresh_f(self):
+        self._publish()
+
+    def elbo_local(self):
+        M = self.M
+        mu_t, var_t = self._mixed()
+        e = sum(R.expec_loglikelihood(l, self.yb[t], (mu_t[t],), (var_t[t],), M.local_vars[t], M.elbo_mode)
+                for t, l in enumerate(M.likelihoods))
+        ka = sum(R.augmented_kl(l, M.local_vars[t], self.yb[t], M.elbo_mode) for t, l in enumerate(M.likelihoods))
+        if self.lo != 0:
+            e = ka = 0.0
+        kg = sum(R.gaussian_kl(g.mu, g.mu0, g.Sigma, g.L) for g in self.own)
+        return self.rho * e - kg - self.rho * ka, (e, kg, ka)
+
+
+def _mo_data():
+    rng = np.random.default_rng(23)
+    N, D, m, B, iters, Q = 150, 2, 10, 50, 5, 4
+    X = rng.random((N, D))
+    f = np.sin(4 * X[:, 0]) + X[:, 1]
+    liks = [R.GaussianLikelihood(0.05), R.LogisticLikelihood(), R.StudentTLikelihood(3.0)]
+    ys = [f + 0.1 * rng.standard_normal(N), np.where(f > f.mean(), 1.0, -1.0), f ** 2 + 0.1 * rng.standard_normal(N)]
+    Zs = [X[rng.permutation(N)[:m]].copy() for _ in range(Q)]
+    A = rng.standard_normal((3, Q))
+    A /= np.linalg.norm(A, axis=1, keepdims=True)
+    idx = [rng.choice(N, B, replace=False) for _ in range(iters)]
+    return X, ys, liks, Zs, A, idx, N, B, iters, Q
+
+
+def _mo_worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import agp_amd  # noqa: F401
+    from agp_amd import parallel as P
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    X, ys, liks, Zs, A, idx, N, B, iters, Q = _mo_data()
+    lo, hi = P.latent_slice(Q, world, rank)
+    eng = MOOracleEngine(R.Kernel("sqexponential", 3.0, 1.0), liks, Zs, A, X, ys, lo, hi, B, R.Adam(0.01))
+    elbos = []
+    for it in range(iters):
+        P.latent_parallel_step(eng, idx[it], N / B)
+        elbos.append(P.elbo_parallel(eng, "latent"))
+    q.put((rank, lo, hi, [(g.eta1, g.eta2) for g in eng.own], eng.M.A.copy(), elbos))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_multioutput_latent_sharded_two_ranks():
+    """MOSVGP with its 4 latents over 2 ranks: one exchange of (mean_f, var_f) per step (+ one per ELBO), update_A! replicated.
+    Equals the single-process oracle model (training.jl:153-158) step for step."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    X, ys, liks, Zs, A, idx, N, B, iters, Q = _mo_data()
+    ref = R.MOSVGP(R.Kernel("sqexponential", 3.0, 1.0), liks, Zs, A.copy(), stochastic=True, batchsize=B, A_opt=R.Adam(0.01))
+    elbos = []
+    ref.train(X, ys, iters, idx_stream=idx, callback=lambda M, it, xb, yb: elbos.append(M.elbo(yb)))
+    for rank, lo, hi, st, A2, el in res:
+        for k in range(hi - lo):
+            assert np.allclose(st[k][0], ref.latents[lo + k].eta1, rtol=1e-9, atol=1e-11)
+            assert np.allclose(st[k][1], ref.latents[lo + k].eta2, rtol=1e-9, atol=1e-11)
+        assert np.allclose(A2, ref.A, rtol=1e-10, atol=1e-12)
+        assert np.allclose(el, elbos, rtol=1e-9)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

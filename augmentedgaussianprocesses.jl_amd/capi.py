@@ -95,6 +95,7 @@ SYMBOLS = {
     "agp_svgp_set_multioutput": (_I32, [_VP, _I32, C.POINTER(LikDesc), _PDBL, _DBL, _DBL, _DBL, _DBL]),
     "agp_svgp_get_A": (_I32, [_VP, _PDBL]),
     "agp_svgp_elbo_terms": (_I32, [_VP, _PDBL]),
+    "agp_svgp_set_batch_shard": (_I32, [_VP, _I32, _I32]),
     "agp_svgp_mo_shard": (_I32, [_VP, _I32]),
     "agp_svgp_mo_fbuf_ptr": (_I32, [_VP, _PVP, _PI64]),
     "agp_svgp_mo_mix": (_I32, [_VP]),

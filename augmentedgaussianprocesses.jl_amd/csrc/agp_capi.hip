@@ -265,6 +265,7 @@ struct SvgpBase {
   virtual agp_status elbo(const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B, double rho,
                           int fresh, double* out) = 0;
   virtual agp_status elbo_terms(double* out3) = 0;
+  virtual agp_status set_batch_shard(int rank, int world) = 0;
   virtual agp_status get_state(int l, void* mu, void* sigma, void* eta1, void* eta2) = 0;
   virtual agp_status set_state(int l, const void* eta1, const void* eta2) = 0;
   virtual agp_status get_matrix(int l, int which, void* out, int64_t ldo) = 0;
@@ -1724,7 +1725,8 @@ struct Svgp : SvgpBase {
                            (const T*)y + t, (const int32_t*)nullptr, idx,
                            (const T*)(mo_mixm + (int64_t)t * Bp), (const T*)(mo_mixv + (int64_t)t * Bp),
                            (const T*)(mo_cc + (int64_t)t * Bp), (const T*)(mo_th + (int64_t)t * Bp), (const T*)nullptr,
-                           (const T*)nullptr, (const T*)nullptr, scal_dev + 8 + 2 * t, (int64_t)nT, (const T*)lam_dev);
+                           (const T*)nullptr, (const T*)nullptr, scal_dev + 8 + 2 * t, (int64_t)nT, (const T*)lam_dev,
+                           (int)shard_once);
       }
       LAUNCHCHK(ctx);
       std::vector<double> ht(2 * nT);
@@ -1740,7 +1742,7 @@ struct Svgp : SvgpBase {
       hipLaunchKernelGGL((k_elbo_terms<T>), dim3(1), dim3(1024), 0, st(), B, nl, Bp, lp, desc.elbo_mode,
                          desc.latent_offset, (int)(desc.latent_offset == 0), (const T*)y, (const int32_t*)y, idx, mf, vf,
                          (const T*)cbuf, (const T*)theta, (const T*)gamma, (const T*)alpha, (const T*)beta, scal_dev,
-                         (int64_t)1, (const T*)lam_dev);
+                         (int64_t)1, (const T*)lam_dev, (int)shard_once);
       LAUNCHCHK(ctx);
     }
     if (fresh && lsm)
@@ -1782,6 +1784,12 @@ struct Svgp : SvgpBase {
     return AGP_OK;
   }
   double e_data = 0, kl_aug = 0, mo_e = 0, mo_kl = 0, kl_gauss_last = 0;
+  bool shard_once = true;
+  agp_status set_batch_shard(int rank, int world) override {
+    if (world < 1 || rank < 0 || rank >= world) return AGP_ERR_INVALID;
+    shard_once = rank == 0;
+    return AGP_OK;
+  }
   agp_status elbo_terms(double* out3) override {
     if (!out3) return AGP_ERR_INVALID;
     out3[0] = e_data;
@@ -2677,6 +2685,10 @@ agp_status agp_svgp_get_A(agp_svgp* h, double* A_host) {
 agp_status agp_svgp_elbo_terms(agp_svgp* h, double* terms_host) {
   HCHK(h);
   return h->impl->elbo_terms(terms_host);
+}
+agp_status agp_svgp_set_batch_shard(agp_svgp* h, int32_t rank, int32_t world) {
+  HCHK(h);
+  return h->impl->set_batch_shard(rank, world);
 }
 agp_status agp_svgp_mo_shard(agp_svgp* h, int32_t q_total) {
   HCHK(h);

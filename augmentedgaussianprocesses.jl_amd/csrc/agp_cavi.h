@@ -784,7 +784,9 @@ __global__ void k_elbo_terms(int64_t B, int nl, int64_t ldb, LikParams<T> lp, in
                              const int64_t* __restrict__ idx, const T* __restrict__ muf, const T* __restrict__ varf,
                              const T* __restrict__ c, const T* __restrict__ theta, const T* __restrict__ gamma,
                              const T* __restrict__ alpha, const T* __restrict__ beta, double* __restrict__ out,
-                             int64_t ystr, const T* __restrict__ lam) {
+                             int64_t ystr, const T* __restrict__ lam, int once) {
+  // once = 0 on the minibatch shards of a batch-parallel run other than the first: the reference's once-per-evaluation terms
+  // (not sums over points) must enter the all-reduced ELBO a single time
   __shared__ double red[16];
   double e = 0.0, kl = 0.0;
   const double LOG2 = 0.69314718055994530942, LOG2PI = 1.83787706640934548356, LOGPI = 1.14472988584940017414;
@@ -833,7 +835,7 @@ __global__ void k_elbo_terms(int64_t B, int nl, int64_t ldb, LikParams<T> lp, in
         e += -0.5 * LOG2PI + 0.5 * log(th) - 0.5 * th * (s + mu * mu - 2.0 * mu * yi + yi * yi);
         double l2k = LOG2 + 0.5 * (LOGPI - LOG2 - log(sab)) - sab;
         double ent = -0.5 * log(b * b) + sab + 0.5;
-        if (elbo_ref) ent += (i == 0) ? 0.5 * log(a) + l2k : 0.0;
+        if (elbo_ref) ent += (i == 0 && once) ? 0.5 * log(a) + l2k : 0.0;
         else ent += 0.5 * log(a) + l2k;
         double expo = -log(2.0 * be * be) - 0.5 * (a * b + b * b * sqrt(a)) / (a * b * b * be * be);
         kl += ent - expo;
@@ -864,7 +866,7 @@ __global__ void k_elbo_terms(int64_t B, int nl, int64_t ldb, LikParams<T> lp, in
   e = block_sum<double>(e, red);
   kl = block_sum<double>(kl, red);
   if (threadIdx.x == 0) {
-    if (lp.kind == LIK_LSM && add_global) kl += log((double)beta[0]);  // sum(log, first(beta)) (Q16)
+    if (lp.kind == LIK_LSM && add_global && once) kl += log((double)beta[0]);  // sum(log, first(beta)) (Q16)
     out[0] = e;
     out[1] = kl;
   }

@@ -196,6 +196,12 @@ class HipEngine:
     def reduce_device(self):
         return self.model._dev()
 
+    def set_batch_shard(self, rank: int, world: int):
+        """this engine sees shard `rank` of `world` of every minibatch (batch-parallel): once-per-evaluation ELBO terms are
+        then counted by rank 0 only"""
+        self.model._chk(self.L.agp_svgp_set_batch_shard(self.h, rank, world))
+        return self
+
     def bind_data(self, X, y, obsdim: int = 1):
         self._X = self.model._upload(X, obsdim)
         self._y = self.model._upload_y(self.model._treat(y))
@@ -347,6 +353,8 @@ def train_parallel(model, X, y, iterations: int, idx_stream: Sequence, *, mode: 
     B_total = len(idx_stream[0])
     B_local = B_total if mode == "latent" else B_total // world
     eng = HipEngine(model, B_local).bind_data(X, y, obsdim)
+    if mode == "batch":
+        eng.set_batch_shard(rank, world)
     model.inference.rho = N / B_total
     model.inference.batchsize = B_local
     for it in range(iterations):

@@ -279,6 +279,10 @@ agp_status agp_svgp_elbo(agp_svgp* h, const void* x, int64_t ldx, const void* y,
  * (expec_loglikelihood), Gaussian KL (+ extraKL), unscaled augmented KL.  A batch-parallel driver sums terms 0 and 2 over the
  * minibatch shards and counts the (replicated) Gaussian KL once. */
 agp_status agp_svgp_elbo_terms(agp_svgp* h, double* terms_host);
+/* batch-parallel run: this handle sees shard `rank` of `world` of every minibatch.  Only changes the ELBO: the reference's
+ * once-per-evaluation terms (LogisticSoftMax `sum(log, first(beta))` logisticsoftmax.jl:138, the scalar-iteration terms of
+ * the Laplace GIGEntropy in AGP_ELBO_REFERENCE mode) are then counted by rank 0 only. */
+agp_status agp_svgp_set_batch_shard(agp_svgp* h, int32_t rank, int32_t world);
 
 /* state export / import : VarPosterior(mu, Sigma, eta1, eta2)  src/gpblocks/posterior.jl:21-27 ; any pointer
  * may be NULL.  set_state installs (eta1, eta2) and re-derives (mu, Sigma) (inference.jl:25-28). */

@@ -144,3 +144,70 @@ def test_sharded_multioutput_misuse_fails_loudly():
         eng.elbo_local()  # exchange buffer holds pre-update values
     with pytest.raises(Exception, match="partial mix"):
         AGP.predict_y(m, X[:5])
+
+
+def _toy(likname):
+    from test_parallel_gloo import _data
+
+    return _data(likname)
+
+
+def _run_generic(P, group, rank, eng, idx, N, B, iters, mode, world, out):
+    try:
+        group.tl.rank = rank
+        elbos = []
+        for it in range(iters):
+            if mode == "latent":
+                P.latent_parallel_step(eng, idx[it], N / B, group)
+            else:
+                P.batch_parallel_step(eng, P.shard_batch(idx[it], world, rank), N / B, group)
+            elbos.append(P.elbo_parallel(eng, mode, group))
+        eng.check()
+        out[rank] = elbos
+    except BaseException as e:
+        out[rank] = e
+        group.bar.abort()
+
+
+@pytest.mark.parametrize("mode,likname", [("latent", "logisticsoftmax"), ("batch", "logistic"), ("batch", "logisticsoftmax")])
+def test_two_rank_drivers_on_device_match_single_handle(mode, likname):
+    """C4's plan (LogisticSoftMax latents over ranks, the sum_k gamma_k all-reduce) and the batch-parallel plan (minibatch over
+    ranks, the statistics all-reduce), each with two handles driven by two threads, against one handle; ELBO included."""
+    import agp_amd as AGP
+    from agp_amd import parallel as P
+
+    X, y, lik, Z, idx, N, B, iters = _toy(likname)
+    K = 4
+    mk = lambda sl=None: AGP.SVGP(1.0 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(3.0)),  # noqa: E731
+                                  AGP.LogisticSoftMaxLikelihood(K) if likname == "logisticsoftmax" else AGP.LogisticLikelihood(),
+                                  AGP.AnalyticSVI(B), Z, optimiser=False, latent_slice=sl)
+    m1 = mk()
+    e1 = P.HipEngine(m1, B).bind_data(X, y)
+    el1 = []
+    for it in range(iters):
+        P.latent_parallel_step(e1, idx[it], N / B)
+        el1.append(P.elbo_parallel(e1, "latent"))
+    e1.check()
+    group = ThreadGroup(2)
+    if mode == "latent":
+        models = [mk(P.latent_slice(K, 2, r)) for r in range(2)]
+        engs = [P.HipEngine(models[r], B).bind_data(X, y) for r in range(2)]
+    else:
+        models = [mk() for r in range(2)]
+        engs = [P.HipEngine(models[r], B // 2).bind_data(X, y).set_batch_shard(r, 2) for r in range(2)]
+    out = [None, None]
+    th = [threading.Thread(target=_run_generic, args=(P, group, r, engs[r], idx, N, B, iters, mode, 2, out)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    for o in out:
+        if isinstance(o, BaseException):
+            raise o
+        assert o is not None
+    for r in range(2):
+        lo, hi = P.latent_slice(K, 2, r) if mode == "latent" else (0, m1.n_latent)
+        for k in range(hi - lo):
+            a, b = models[r].get_state(k), m1.get_state(lo + k)
+            assert _rel(a[2], b[2]) < 1e-9 and _rel(a[3], b[3]) < 1e-9
+        assert np.allclose(out[r], el1, rtol=1e-9), (out[r], el1)

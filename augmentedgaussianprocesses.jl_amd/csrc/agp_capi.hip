@@ -24,6 +24,9 @@ struct agp_ctx {
   std::string err;
   int32_t* flow_flags = nullptr;  // dependency flags of the dataflow factorisation (k_chol_flow)
   int64_t flow_cap = 0;
+  int32_t* dag_flags = nullptr;   // tile / x-ready / abort flags of the task-graph factorisation (k_chol_dag), epoch-stamped
+  int64_t dag_cap = 0;
+  int32_t dag_epoch = 0;
   void* tri_scratch = nullptr;    // n x n scratch of the recursive-doubling triangular inverse
   size_t tri_bytes = 0;
 };
@@ -99,6 +102,14 @@ static agp_status trtri_levels(agp_ctx* c, const T* A, int64_t ld, T* X, int64_t
   return AGP_OK;
 }
 
+static bool chol_use_dag() {
+  static const bool v = []() {
+    const char* e = getenv("AGP_CHOL_DAG");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+
 template <typename T>
 static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int64_t ldx, T* Dg, T* E, int64_t lde,
                               int64_t ne, int do_x, int32_t* info_dev, int64_t nvalid) {
@@ -144,6 +155,54 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       for (int64_t k = 1; k < nt; ++k)
         hipLaunchKernelGGL((k_trtri_row<T>), dim3((unsigned)k), dim3(NTHREADS), 0, c->stream, (const T*)A, ld, X, ldx, k);
     LAUNCHCHK(c);
+    return AGP_OK;
+  }
+  // default: the whole factorisation as ONE launch of the tile task graph (k_chol_dag); AGP_CHOL_DAG=0 falls back to one
+  // launch per block column (k_chol_step), which is also what several problems sharing their launches use
+  const bool use_dag = chol_use_dag();
+  if (use_dag && X) {
+    const int64_t nf = ((nt + ne) * nt + 3 * nt + 1) * DAG_FS;
+    if (c->dag_cap < nf) {
+      if (c->dag_flags) (void)hipFree(c->dag_flags);
+      c->dag_flags = nullptr;
+      c->dag_cap = 0;
+      if (hipMalloc((void**)&c->dag_flags, sizeof(int32_t) * (size_t)(nf + 1024)) != hipSuccess) return AGP_ERR_NOMEM;
+      c->dag_cap = nf + 1024;
+      HIPCHK(c, hipMemsetAsync(c->dag_flags, 0, sizeof(int32_t) * (size_t)c->dag_cap, c->stream));
+      c->dag_epoch = 0;
+    }
+    c->dag_epoch += 1;
+    const int64_t ntiles = nt * (nt + 1) / 2 + ne * nt;
+    unsigned long long* trace = nullptr;
+    static const char* trace_path = getenv("AGP_DAG_TRACE");  // development aid: per-tile timestamps of one launch
+    if (trace_path && ne > 0) {
+      if (hipMalloc((void**)&trace, (size_t)ntiles * 8 * 8) != hipSuccess) trace = nullptr;
+      if (trace) (void)hipMemsetAsync(trace, 0, (size_t)ntiles * 8 * 8, c->stream);
+    }
+    static const bool fused = []() {
+      const char* e = getenv("AGP_CHOL_DAG_FUSED");
+      return !(e && e[0] == '0');
+    }();
+    if (fused)
+      hipLaunchKernelGGL((k_chol_dag<T, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, A, ld, X, ldx, Dg, E,
+                         lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace);
+    else
+      hipLaunchKernelGGL((k_chol_dag<T, false>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, A, ld, X, ldx, Dg, E,
+                         lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace);
+    LAUNCHCHK(c);
+    if (trace) {
+      std::vector<unsigned long long> h((size_t)ntiles * 8);
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipMemcpy(h.data(), trace, h.size() * 8, hipMemcpyDeviceToHost);
+      (void)hipFree(trace);
+      FILE* f = fopen(trace_path, "w");
+      if (f) {
+        fprintf(f, "%lld %lld\n", (long long)nt, (long long)ne);
+        for (size_t i = 0; i < h.size(); ++i) fprintf(f, "%llu\n", h[i]);
+        fclose(f);
+      }
+    }
+    if (do_x) AGPCHK(trtri_levels<T>(c, (const T*)A, ld, X, ldx, nt));
     return AGP_OK;
   }
   CholBatch<T> bt{};
@@ -962,9 +1021,12 @@ struct Svgp : SvgpBase {
           g.la_state = 1;
           g.xa_valid = false;
         }
-        AGPCHK(potrf_fused_batch<T>(ctx, bt, nb, mp, mp, mp, mp, Bq / TILE + 1, info_dev, m));
+        if (nb == 1)  // a single problem may take the one-launch task-graph path
+          AGPCHK(potrf_fused<T>(ctx, bt.A[0], mp, mp, bt.X[0], mp, bt.Dg[0], bt.E[0], mp, Bq / TILE + 1, 0, info_dev, m));
+        else
+          AGPCHK(potrf_fused_batch<T>(ctx, bt, nb, mp, mp, mp, mp, Bq / TILE + 1, info_dev, m));
       }
-      if (!todo.empty()) AGPCHK(timing_end(mp / TILE));
+      if (!todo.empty()) AGPCHK(timing_end(todo.size() == 1 && chol_use_dag() ? 1 : mp / TILE));
     }
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
@@ -1591,7 +1653,7 @@ struct Svgp : SvgpBase {
     hipLaunchKernelGGL((k_set_ext_rows<T>), grid1(TILE * mp), dim3(256), 0, st(), ext, mp, mp, (const T*)g.eta1);
     AGPCHK(timing_begin());
     AGPCHK(potrf_fused<T>(ctx, g.La, mp, mp, g.Xa, mp, g.DgA, g.Wbuf, mp, Bq / TILE + 1, with_x, info_dev, m));
-    AGPCHK(timing_end(mp / TILE));
+    AGPCHK(timing_end(chol_use_dag() ? 1 : mp / TILE));
     g.la_state = 1;
     g.xa_valid = with_x != 0;
     return AGP_OK;
@@ -1645,6 +1707,10 @@ struct Svgp : SvgpBase {
     if (flags & FLAG_NEG_KTILDE) {
       ctx->err = "K~ has negative values";  // latentgp.jl:213
       return AGP_ERR_NEG_KTILDE;
+    }
+    if (info < 0) {
+      ctx->err = "task-graph factorisation aborted: a tile dependency never arrived (spin limit)";
+      return AGP_ERR_HIP;
     }
     if (info != 0) {
       ctx->err = "PosDefException: -2*eta2 is not positive definite; leading minor " + std::to_string(info);
@@ -2169,9 +2235,10 @@ agp_status agp_ctx_create(int32_t device, void* hip_stream, agp_ctx** out) {
 }
 
 agp_status agp_ctx_destroy(agp_ctx* ctx) {
-  if (ctx && (ctx->flow_flags || ctx->tri_scratch)) {
+  if (ctx && (ctx->flow_flags || ctx->tri_scratch || ctx->dag_flags)) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->flow_flags) (void)hipFree(ctx->flow_flags);
+    if (ctx->dag_flags) (void)hipFree(ctx->dag_flags);
     if (ctx->tri_scratch) (void)hipFree(ctx->tri_scratch);
   }
   delete ctx;

@@ -162,9 +162,15 @@ __device__ __forceinline__ void mma_lds64(const T* As, const T* Bs, Acc<T>& acc)
 // ---------------------------------------------------------------------------------------------------
 constexpr int SC_ELEMS = 2 * 2 * 4 * TILE;
 
-template <typename T, int J, int NS>
+// hook: called once per round by every thread right after the round's barrier (the idle waves 4-7 of a 512-thread workgroup
+// can step a side job there -- the chain workgroup of k_chol_dag prefetches its next two tiles this way)
+struct NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+template <typename T, int J, int NS, typename H>
 __device__ __forceinline__ void chol_rounds(T (&a)[NS][NS], T (&g)[NS][NS], T* sc, T* piv, const bool act, const int ti,
-                                            const int tj) {
+                                            const int tj, H& hook, const int hbase) {
 #pragma unroll 1
   for (int rr = 0; rr < 4; ++rr) {
     const int jj0 = rr * 4, j0 = J * 16 + jj0;
@@ -186,6 +192,7 @@ __device__ __forceinline__ void chol_rounds(T (&a)[NS][NS], T (&g)[NS][NS], T* s
       }
     }
     __syncthreads();
+    hook(hbase + rr);
     if (!act) continue;
     // ---- 4x4 pivot block, LDL' (every active thread, redundantly) ----
     const T d00 = P[j0], d10 = P[j0 + 1], d20 = P[j0 + 2], d30 = P[j0 + 3];
@@ -282,6 +289,7 @@ __device__ __forceinline__ void factor_diag_tile512(T* bufA, T* bufB, T* sc, T* 
   const int tid = threadIdx.x;
   const bool act = tid < 256;
   const int ti = (tid & 255) >> 4, tj = tid & 15;
+  NoHook nohook;
   T a[4][4], g[4][4];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
@@ -293,10 +301,10 @@ __device__ __forceinline__ void factor_diag_tile512(T* bufA, T* bufB, T* sc, T* 
       g[r][c] = (R == Cc) ? T(1) : T(0);
     }
   __syncthreads();
-  chol_rounds<T, 0, 4>(a, g, sc, piv, act, ti, tj);
-  chol_rounds<T, 1, 4>(a, g, sc, piv, act, ti, tj);
-  chol_rounds<T, 2, 4>(a, g, sc, piv, act, ti, tj);
-  chol_rounds<T, 3, 4>(a, g, sc, piv, act, ti, tj);
+  chol_rounds<T, 0, 4, NoHook>(a, g, sc, piv, act, ti, tj, nohook, 0);
+  chol_rounds<T, 1, 4, NoHook>(a, g, sc, piv, act, ti, tj, nohook, 0);
+  chol_rounds<T, 2, 4, NoHook>(a, g, sc, piv, act, ti, tj, nohook, 0);
+  chol_rounds<T, 3, 4, NoHook>(a, g, sc, piv, act, ti, tj, nohook, 0);
   __syncthreads();  // piv complete
   if (tid < TILE) {
     const T p = piv[tid];
@@ -355,9 +363,9 @@ __device__ __forceinline__ typename Mfma<T>::acc_t mma_blk32(const T* As, const 
 }
 
 // eliminate the 32x32 block at (o, o) of bufA (lower valid): L -> bufA block, L^-1 -> bufB block ; all threads call
-template <typename T>
+template <typename T, typename H>
 __device__ __forceinline__ void elim_block32(T* bufA, T* bufB, int o, T* sc, T* piv, const bool act, const int ti,
-                                             const int tj) {
+                                             const int tj, H& hook) {
   T a[2][2], g[2][2];
 #pragma unroll
   for (int r = 0; r < 2; ++r)
@@ -369,8 +377,8 @@ __device__ __forceinline__ void elim_block32(T* bufA, T* bufB, int o, T* sc, T* 
       g[r][c] = (R == Cc) ? T(1) : T(0);
     }
   __syncthreads();
-  chol_rounds<T, 0, 2>(a, g, sc, piv + o, act, ti, tj);
-  chol_rounds<T, 1, 2>(a, g, sc, piv + o, act, ti, tj);
+  chol_rounds<T, 0, 2, H>(a, g, sc, piv + o, act, ti, tj, hook, 0);
+  chol_rounds<T, 1, 2, H>(a, g, sc, piv + o, act, ti, tj, hook, 4);
   __syncthreads();
   if (act) {
     T rsC[2], rsR[2];
@@ -392,16 +400,17 @@ __device__ __forceinline__ void elim_block32(T* bufA, T* bufB, int o, T* sc, T* 
   __syncthreads();
 }
 
-template <typename T>
+template <typename T, typename H>
 __device__ __forceinline__ void factor_diag_tile_2lvl(T* bufA, T* bufB, T* sc, T* piv, int32_t* info, int64_t col0,
-                                                      int64_t nvalid) {
+                                                      int64_t nvalid, H& hook) {
   const int tid = threadIdx.x;
   const bool act = tid < 256;
   const int ti = (tid & 255) >> 4, tj = tid & 15;
   const int lane = tid & 63, wave = tid >> 6, wr = (wave >> 1) & 1, wc = wave & 1;
   const bool mw = wave < 4;  // the four waves that run the 32^3 MFMA products (one 16x16 result tile each)
   typedef typename Mfma<T>::acc_t acc_t;
-  elim_block32<T>(bufA, bufB, 0, sc, piv, act, ti, tj);
+  NoHook nohook;
+  elim_block32<T, NoHook>(bufA, bufB, 0, sc, piv, act, ti, tj, nohook);
   // L21 = A21 X11'   (in place in bufA[32:64, 0:32])
   acc_t acc;
 #pragma unroll
@@ -433,7 +442,7 @@ __device__ __forceinline__ void factor_diag_tile_2lvl(T* bufA, T* bufB, T* sc, T
       bufA[(32 + wr * 16 + Mfma<T>::row(lane, r)) * LDP + 32 + wc * 16 + (lane & 15)] = acc[r];
   }
   __syncthreads();
-  elim_block32<T>(bufA, bufB, 32, sc, piv, act, ti, tj);
+  elim_block32<T, H>(bufA, bufB, 32, sc, piv, act, ti, tj, hook);  // hook rounds 0..7 of the second half
   // P = L21 X11  -> scratch bufB[0:32, 32:64]
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = T(0);
@@ -472,6 +481,13 @@ __device__ __forceinline__ void factor_diag_tile_2lvl(T* bufA, T* bufB, T* sc, T
     }
   }
   __syncthreads();
+}
+
+template <typename T>
+__device__ __forceinline__ void factor_diag_tile_2lvl(T* bufA, T* bufB, T* sc, T* piv, int32_t* info, int64_t col0,
+                                                      int64_t nvalid) {
+  NoHook nohook;
+  factor_diag_tile_2lvl<T, NoHook>(bufA, bufB, sc, piv, info, col0, nvalid, nohook);
 }
 
 __device__ __forceinline__ void tri_index(int64_t idx, int64_t& ti, int64_t& tj) {
@@ -761,6 +777,291 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_flow(T* A, int64_t ld, T*
   flow_signal(xready + bid);
   FLOW_TR(nt, 2);
 #undef FLOW_TR
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_chol_dag: the augmented factorisation as ONE launch of a tile task graph -- one 512-thread workgroup per 64x64 tile
+// (r, c), c <= r (matrix rows, then the extension row blocks), numbered column-major so that every dependency points to a
+// lower workgroup index (in-order dispatch => no deadlock even when the grid is not fully resident).  The tile lives in the
+// MFMA accumulators for its whole life -- no read-modify-write of the trailing matrix in global memory:
+//     for j < c :  wait L(r,j), L(c,j)          acc -= L(r,j) L(c,j)'
+//     r == c    :  factor the tile -> L_cc (Dg), X_c = L_cc^-1 (X) ; publish X_c
+//     r >  c    :  wait X_c ; L(r,c) = acc X_c' ; publish L(r,c)
+// Hand-over between workgroups WITHOUT cache-wide fences: the producer writes the tile with agent-scope relaxed atomic
+// stores (sc1: write-through to the memory side), waits for their acknowledgement (s_waitcnt), barrier, then stores the flag;
+// consumers poll the flag with agent-scope loads and read the tile with agent-scope (sc1) loads.  Measured
+// (tools/ubench/hop.hip): 1.6 us per hop (0.4 publish + 0.4 flag + 0.8 fetch of 32 KB), independent of how much dirty data
+// the other workgroups keep in the L2s; the release / acquire fences of k_chol_flow cost 3.8 - 10 us for the same hop.
+// Flags hold the launch's epoch (never reset); a bounded spin turns a lost dependency into info = -1 instead of a hang.
+// flags: int32 [(nt + ne) * nt] tile-ready | [nt] x-ready | [1] abort, each on its own 256-byte line (stride DAG_FS)
+// ---------------------------------------------------------------------------------------------------
+constexpr long DAG_SPIN_LIMIT = 1L << 24;  // ~10 s of polling
+__device__ __forceinline__ int64_t chain_slot(int64_t col, int64_t nt, int64_t ne) {  // workgroup index of diagonal tile `col`
+  return col * (nt + ne) - col * (col - 1) / 2;
+}
+constexpr int DAG_FS = 64;  // flag stride in int32: one 256-byte line per flag, so the pollers spread over the memory channels
+
+template <typename T>
+__device__ __forceinline__ void load_tile_lds_coh(const T* G, int64_t ld, T* S) {
+  // all loads are issued before the first LDS write: the compiler keeps an atomic load ordered against a following store, so
+  // the interleaved form ran the eight loads back to back (2.5 us per tile instead of 0.8 us)
+  constexpr int Q = TILE * TILE / CHOL_THREADS;
+  T v[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int e = threadIdx.x + q * CHOL_THREADS;
+    v[q] = __hip_atomic_load(G + (int64_t)(e >> 6) * ld + (e & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int e = threadIdx.x + q * CHOL_THREADS;
+    S[(e >> 6) * LDP + (e & 63)] = v[q];
+  }
+}
+
+// two tiles at once (both operands of a pending update): 16 loads in flight per thread
+template <typename T>
+__device__ __forceinline__ void load_tiles_lds_coh2(const T* G0, int64_t ld0, T* S0, const T* G1, int64_t ld1, T* S1) {
+  constexpr int Q = TILE * TILE / CHOL_THREADS;
+  T v[2 * Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int e = threadIdx.x + q * CHOL_THREADS;
+    v[q] = __hip_atomic_load(G0 + (int64_t)(e >> 6) * ld0 + (e & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v[Q + q] = __hip_atomic_load(G1 + (int64_t)(e >> 6) * ld1 + (e & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int e = threadIdx.x + q * CHOL_THREADS;
+    S0[(e >> 6) * LDP + (e & 63)] = v[q];
+    S1[(e >> 6) * LDP + (e & 63)] = v[Q + q];
+  }
+}
+
+// one thread polls up to two flags for `epoch`; returns false (workgroup-uniform) when the run was aborted
+__device__ __forceinline__ bool dag_wait(const int32_t* f0, const int32_t* f1, int32_t epoch, int32_t* abort_flag,
+                                         int32_t* info, int* lds_ok) {
+  if (threadIdx.x == 0) {
+    long spins = 0;
+    int ok = 1;
+    for (int w = 0; w < 2 && ok; ++w) {
+      const int32_t* f = w == 0 ? f0 : f1;
+      if (!f) continue;
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > DAG_SPIN_LIMIT ||
+            ((spins & 63) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)) {
+          __hip_atomic_store(abort_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicExch(info, -1);
+          ok = 0;
+          break;
+        }
+      }
+    }
+    *lds_ok = ok;
+  }
+  __syncthreads();
+  return *lds_ok != 0;
+}
+
+// every thread's coherent stores acknowledged -> barrier -> flag
+__device__ __forceinline__ void dag_signal(int32_t* flag, int32_t epoch) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt vmcnt(0): no L2 write-back
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// side job of the chain workgroup, stepped by the idle waves 4-7 during the second half of a tile factorisation: look once
+// whether the two feeder tiles of the next column are parked, then move them into LDS one tile per round
+template <typename T>
+struct ChainPrefetch {
+  const T* src;  // tile (k+1, k) in A ; the diagonal tile (k+1, k+1) follows TILE columns to the right
+  int64_t ld;
+  T *dT, *dD;    // LDS destinations
+  const int32_t *f1, *f2;
+  int32_t epoch;
+  int* ok;       // LDS
+  T v[TILE * TILE / 256];
+  __device__ __forceinline__ void operator()(int round) {
+    const int t = (int)threadIdx.x - 256;
+    if (t < 0 || !src) return;
+    if (round == 3) {
+      if (t == 0)
+        *ok = (__hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) &&
+              (__hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch);
+      return;
+    }
+    if (round < 4 || round > 6 || !*ok) return;
+    if (round >= 5) {
+      T* d = round == 5 ? dT : dD;
+#pragma unroll
+      for (int q = 0; q < TILE * TILE / 256; ++q) {
+        const int e = t + q * 256;
+        d[(e >> 6) * LDP + (e & 63)] = v[q];
+      }
+    }
+    if (round <= 5) {
+      const T* g = round == 4 ? src : src + TILE;
+#pragma unroll
+      for (int q = 0; q < TILE * TILE / 256; ++q) {
+        const int e = t + q * 256;
+        v[q] = __hip_atomic_load(g + (int64_t)(e >> 6) * ld + (e & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+};
+
+template <typename T, bool FUSED>
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* X, int64_t ldx, T* __restrict__ Dg, T* E,
+                                                           int64_t lde, int64_t ne, int64_t nt,
+                                                           int32_t* __restrict__ info, int64_t nvalid, int32_t* flags,
+                                                           int32_t epoch, unsigned long long* trace) {
+  __shared__ __attribute__((aligned(16))) T sm[(FUSED ? 4 : 2) * TILE * LDP];
+  __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
+  __shared__ T piv[TILE];
+  __shared__ int wait_ok, pf_ok;
+  T* bufA = sm;
+  T* bufB = sm + TILE * LDP;
+  const int tid = threadIdx.x;
+  // column-major tile numbering: column c holds its diagonal tile, rows c+1..nt-1, then the ne extension blocks
+  int64_t b = blockIdx.x, c = 0;
+  while (b >= nt - c + ne) {
+    b -= nt - c + ne;
+    ++c;
+  }
+  const bool diag = b == 0, ext = b >= nt - c;
+  const int64_t R = ext ? nt + (b - (nt - c)) : c + b;  // block-row index in [0, nt + ne)
+  T* rowp = ext ? E + (R - nt) * TILE * lde : A + R * TILE * ld;
+  const int64_t ldr = ext ? lde : ld, c0 = c * TILE;
+  int32_t* ready = flags;
+  int32_t* xready = flags + (nt + ne) * nt * DAG_FS;
+  int32_t* pre1 = xready + nt * DAG_FS;  // FUSED: tile (c, c-1) with all its pending updates is parked in place for the chain
+  int32_t* pre2 = pre1 + nt * DAG_FS;    // FUSED: diagonal tile (c, c) with the updates of columns < c-1 parked in place
+  int32_t* abortf = pre2 + nt * DAG_FS;
+#define DAG_TR(slot) \
+  if (trace && tid == 0) trace[blockIdx.x * 8 + (slot)] = wall_clock64()
+#define DAG_TRC(col, slot) \
+  if (trace && tid == 0) trace[chain_slot(col, nt, ne) * 8 + (slot)] = wall_clock64()
+  DAG_TR(0);
+  Acc8<T> acc;
+  acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = rowp[r * ldr + c0 + cc]; });
+  if (FUSED && blockIdx.x == 0) {
+    // ---- the chain: ONE workgroup carries the critical path through all columns, so that per column only the tile
+    // factorisation and two 64^3 products are serial:  factor(c) -> L(c+1,c) = T X_c' -> S = D - L L' -> factor(c+1).
+    // T = tile (c+1, c) and D = tile (c+1, c+1) arrive with all their other updates already applied by feeder workgroups.
+    acc8_foreach<T>(acc, [&](int r, int cc, T& val) { bufA[r * LDP + cc] = val; });
+    __syncthreads();
+    T* bufC = sm + (FUSED ? 2 : 0) * TILE * LDP;
+    T* bufD = sm + (FUSED ? 3 : 0) * TILE * LDP;
+    for (int64_t k = 0; k < nt; ++k) {
+      const int64_t k0 = k * TILE;
+      T* trow = A + (k + 1) * TILE * ld;  // block row k+1 (only touched while k + 1 < nt)
+      ChainPrefetch<T> pf;
+      pf.src = k + 1 < nt ? trow + k0 : nullptr;
+      pf.ld = ld;
+      pf.dT = bufC;
+      pf.dD = bufD;
+      pf.f1 = pre1 + (k + 1) * DAG_FS;
+      pf.f2 = pre2 + (k + 1) * DAG_FS;
+      pf.epoch = epoch;
+      pf.ok = &pf_ok;
+      if (tid == 0) pf_ok = 0;
+      factor_diag_tile_2lvl<T, ChainPrefetch<T>>(bufA, bufB, sc, piv, info, k0, nvalid, pf);
+      DAG_TRC(k, 2);
+      for (int e = tid; e < TILE * TILE; e += CHOL_THREADS) {
+        const int r = e >> 6, cc = e & 63;
+        __hip_atomic_store(X + (k0 + r) * ldx + k0 + cc, bufB[r * LDP + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Dg[k * TILE * TILE + e] = bufA[r * LDP + cc];
+      }
+      if (k + 1 == nt) {
+        dag_signal(xready + k * DAG_FS, epoch);
+        DAG_TRC(k, 3);
+        return;
+      }
+      if (!pf_ok) {  // the feeders were not done when the side job looked: fetch now
+        if (!dag_wait(pf.f1, pf.f2, epoch, abortf, info, &wait_ok)) return;
+        load_tiles_lds_coh2<T>(trow + k0, ld, bufC, trow + k0 + TILE, ld, bufD);
+        __syncthreads();
+      }
+      if (trace && tid == 0) trace[chain_slot(k + 1, nt, ne) * 8 + 7] = (unsigned long long)pf_ok;
+      Acc8<T> accD;
+      acc8_foreach<T>(accD, [&](int r, int cc, T& val) { val = bufD[r * LDP + cc]; });
+      DAG_TRC(k + 1, 4);
+      Acc8<T> out;
+      out.zero();
+      mma8<T>(bufC, bufB, out);
+      // X_k went out before the product: its stores are acknowledged by now, so publishing it here costs the chain one
+      // barrier instead of a store round trip (the column's other tiles see X_k ~2 us later; they have ~10 us of slack)
+      dag_signal(xready + k * DAG_FS, epoch);
+      DAG_TRC(k, 3);
+      acc8_foreach<T>(out, [&](int r, int cc, T& val) {
+        bufA[r * LDP + cc] = val;  // the factor L_kk that lived here has been stored (Dg) above
+        __hip_atomic_store(trow + r * ld + k0 + cc, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      });
+      __syncthreads();
+      DAG_TRC(k + 1, 5);
+      mma8_sub<T>(bufA, bufA, accD);
+      dag_signal(ready + ((k + 1) * nt + k) * DAG_FS, epoch);
+      acc8_foreach<T>(accD, [&](int r, int cc, T& val) { bufA[r * LDP + cc] = val; });
+      __syncthreads();
+      DAG_TRC(k + 1, 1);
+    }
+    return;
+  }
+  const bool f1 = FUSED && b == 1 && !ext;  // tile (c+1, c): feeds the chain instead of waiting for X_c itself
+  const bool f2 = FUSED && diag;            // diagonal tile (c, c), c >= 1: the chain applies the last update itself
+  const int64_t jend = f2 ? c - 1 : c;
+  for (int64_t j = 0; j < jend; ++j) {
+    if (!dag_wait(ready + (R * nt + j) * DAG_FS, diag ? nullptr : ready + (c * nt + j) * DAG_FS, epoch, abortf, info, &wait_ok))
+      return;
+    if (j == c - 1) DAG_TR(4);
+    if (diag) load_tile_lds_coh<T>(rowp + j * TILE, ldr, bufA);
+    else load_tiles_lds_coh2<T>(rowp + j * TILE, ldr, bufA, A + c0 * ld + j * TILE, ld, bufB);
+    __syncthreads();
+    if (j == c - 1) DAG_TR(5);
+    mma8_sub<T>(bufA, diag ? bufA : bufB, acc);
+    __syncthreads();
+  }
+  if (!f2) DAG_TR(1);
+  if (f1 || f2) {
+    acc8_foreach<T>(acc, [&](int r, int cc, T& val) {
+      __hip_atomic_store(rowp + r * ldr + c0 + cc, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    });
+    dag_signal((f1 ? pre1 + (c + 1) * DAG_FS : pre2 + c * DAG_FS), epoch);
+    if (f2) DAG_TR(6);
+    else DAG_TR(3);
+    return;
+  }
+  acc8_foreach<T>(acc, [&](int r, int cc, T& val) { bufA[r * LDP + cc] = val; });
+  if (diag) {
+    __syncthreads();
+    factor_diag_tile_2lvl<T>(bufA, bufB, sc, piv, info, c0, nvalid);
+    DAG_TR(2);
+    for (int e = tid; e < TILE * TILE; e += CHOL_THREADS) {
+      const int r = e >> 6, cc = e & 63;
+      __hip_atomic_store(X + (c0 + r) * ldx + c0 + cc, bufB[r * LDP + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    dag_signal(xready + c * DAG_FS, epoch);
+    for (int e = tid; e < TILE * TILE; e += CHOL_THREADS) Dg[c * TILE * TILE + e] = bufA[(e >> 6) * LDP + (e & 63)];
+    DAG_TR(3);
+    return;
+  }
+  if (!dag_wait(xready + c * DAG_FS, nullptr, epoch, abortf, info, &wait_ok)) return;
+  DAG_TR(2);
+  load_tile_lds_coh<T>(X + c0 * ldx + c0, ldx, bufB);
+  __syncthreads();
+  DAG_TR(6);
+  Acc8<T> out;
+  out.zero();
+  mma8<T>(bufA, bufB, out);
+  acc8_foreach<T>(out, [&](int r, int cc, T& val) {
+    __hip_atomic_store(rowp + r * ldr + c0 + cc, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  });
+  DAG_TR(7);
+  dag_signal(ready + (R * nt + c) * DAG_FS, epoch);
+  DAG_TR(3);
+#undef DAG_TR
+#undef DAG_TRC
 }
 
 // ---------------------------------------------------------------------------------------------------

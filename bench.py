@@ -160,7 +160,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- roofline of the dominant kernel (k_chol_step: 16 launches per step at m = 1024) ----
+    # ---- roofline of the dominant kernel: the augmented Cholesky factorisation, ONE launch of the tile task graph k_chol_dag per
+    # step (AGP_CHOL_DAG=0: 16 launches of k_chol_step at m = 1024) ----
     mp = (m + 63) // 64 * 64
     Bq = (B + 63) // 64 * 64
     # algorithmic flops of one augmented factorisation: potrf m^3/3 + panel solves of the (B + 64) extension rows m^2 each
@@ -169,7 +170,7 @@ def main():
     avg_launch_s = (kms.value * 1e-3) / max(nl.value, 1)
     achieved = (flops_seq / launches_per_step) / avg_launch_s / 1e12 if nl.value else 0.0
     roofline = {
-        "kernel": "k_chol_step<double>",
+        "kernel": "k_chol_dag<double, true>" if launches_per_step < 1.5 else "k_chol_step<double>",
         "bound": "mfma",
         "achieved": round(achieved, 3),
         "peak": FP64_MFMA_PEAK_TFLOPS,
@@ -211,7 +212,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_bytes.json")) as fh:
             pm = json.load(fh)
-        roofline["traffic"] = pm["kernels"]["k_chol_step<double>"]["hbm_bytes_per_launch_corrected"]
+        roofline["traffic"] = pm["kernels"][roofline["kernel"]]["hbm_bytes_per_launch_corrected"]
         roofline["traffic_source"] = "profiles/r01_pmc_hbm_bytes.json (rocprofv3 --pmc, separate passes, same command)"
     except Exception:
         pass

@@ -871,6 +871,32 @@ __device__ __forceinline__ void dag_signal(int32_t* flag, int32_t epoch) {
   if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// one 16x16 result tile over k in [0, kend), kend a multiple of 8: acc += (neg ? -1 : 1) * Ar(16 rows, [r][k]) * Bc(16
+// columns given as [c][k])' ; two partial accumulators keep dependent MFMAs apart
+template <typename T>
+__device__ __forceinline__ typename Mfma<T>::acc_t mma_tile16(const T* Ar, const T* Bc, int kend,
+                                                              typename Mfma<T>::acc_t acc, bool neg, int lane) {
+  const T* pa = Ar + (lane & 15) * LDP + (lane >> 4);
+  const T* pb = Bc + (lane & 15) * LDP + (lane >> 4);
+  typename Mfma<T>::acc_t p1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) p1[r] = T(0);
+#pragma unroll 2
+  for (int kk = 0; kk < kend / 4; kk += 2) {
+    T a0 = pa[kk * 4], a1 = pa[kk * 4 + 4];
+    const T b0 = pb[kk * 4], b1 = pb[kk * 4 + 4];
+    if (neg) {
+      a0 = -a0;
+      a1 = -a1;
+    }
+    acc = Mfma<T>::mma(a0, b0, acc);
+    p1 = Mfma<T>::mma(a1, b1, p1);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] += p1[r];
+  return acc;
+}
+
 // side job of the chain workgroup, stepped by the idle waves 4-7 during the second half of a tile factorisation: look once
 // whether the two feeder tiles of the next column are parked, then move them into LDS one tile per round
 template <typename T>
@@ -984,26 +1010,65 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* 
         __syncthreads();
       }
       if (trace && tid == 0) trace[chain_slot(k + 1, nt, ne) * 8 + 7] = (unsigned long long)pf_ok;
-      Acc8<T> accD;
-      acc8_foreach<T>(accD, [&](int r, int cc, T& val) { val = bufD[r * LDP + cc]; });
       DAG_TRC(k + 1, 4);
-      Acc8<T> out;
-      out.zero();
-      mma8<T>(bufC, bufB, out);
-      // X_k went out before the product: its stores are acknowledged by now, so publishing it here costs the chain one
-      // barrier instead of a store round trip (the column's other tiles see X_k ~2 us later; they have ~10 us of slack)
-      dag_signal(xready + k * DAG_FS, epoch);
-      DAG_TRC(k, 3);
-      acc8_foreach<T>(out, [&](int r, int cc, T& val) {
-        bufA[r * LDP + cc] = val;  // the factor L_kk that lived here has been stored (Dg) above
-        __hip_atomic_store(trow + r * ld + k0 + cc, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      });
+      // both products skip what the structure makes zero or redundant (a 64^3 f64 product is MFMA-throughput bound on one CU:
+      // 2.2 us; these take 40/64 and 48/64 of it):
+      //   L = T X_k'  with X_k lower triangular: column tile j only needs k < 16 (j + 1); wave -> row tile w >> 1 and the column
+      //   tile pair {3, 0} or {2, 1} (20 MFMAs each way)
+      typedef typename Mfma<T>::acc_t acc_t;
+      const int lane = tid & 63, wave = tid >> 6;
+      {
+        const int ri = wave >> 1, cA = (wave & 1) ? 2 : 3, cB = 3 - cA;
+        acc_t oa, ob;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oa[r] = ob[r] = T(0);
+        oa = mma_tile16<T>(bufC + 16 * ri * LDP, bufB + 16 * cA * LDP, 16 * (cA + 1), oa, false, lane);
+        ob = mma_tile16<T>(bufC + 16 * ri * LDP, bufB + 16 * cB * LDP, 16 * (cB + 1), ob, false, lane);
+        // X_k went out before the product: its stores are acknowledged by now, so publishing it here costs the chain one
+        // barrier instead of a store round trip (the column's other tiles see X_k ~2 us later; they have ~10 us of slack)
+        dag_signal(xready + k * DAG_FS, epoch);
+        DAG_TRC(k, 3);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * ri + Mfma<T>::row(lane, r);
+          bufA[row * LDP + 16 * cA + (lane & 15)] = oa[r];  // the factor L_kk that lived here has been stored (Dg) above
+          bufA[row * LDP + 16 * cB + (lane & 15)] = ob[r];
+          __hip_atomic_store(trow + row * ld + k0 + 16 * cA + (lane & 15), oa[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(trow + row * ld + k0 + 16 * cB + (lane & 15), ob[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
       __syncthreads();
       DAG_TRC(k + 1, 5);
-      mma8_sub<T>(bufA, bufA, accD);
+      //   S = D - L L': only the ten 16x16 tiles on and below the diagonal (the factorisation never reads above it); every
+      //   wave takes one, waves 0 and 1 a second (SIMDs 0, 1: three tiles, SIMDs 2, 3: two).  In place in bufD.
+      {
+        // tiles in row-major lower order: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) (3,0) (3,1) (3,2) (3,3)
+        const int ti_[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3}, tj_[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+          const int tl = rep == 0 ? 2 + wave : wave;  // second pass: tiles 0, 1 on waves 0, 1
+          if (rep == 1 && wave >= 2) break;
+          int i2 = 0, j2 = 0;
+#pragma unroll
+          for (int q = 0; q < 10; ++q)
+            if (q == tl) {
+              i2 = ti_[q];
+              j2 = tj_[q];
+            }
+          acc_t a;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r] = bufD[(16 * i2 + Mfma<T>::row(lane, r)) * LDP + 16 * j2 + (lane & 15)];
+          a = mma_tile16<T>(bufA + 16 * i2 * LDP, bufA + 16 * j2 * LDP, TILE, a, true, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bufD[(16 * i2 + Mfma<T>::row(lane, r)) * LDP + 16 * j2 + (lane & 15)] = a[r];
+        }
+      }
       dag_signal(ready + ((k + 1) * nt + k) * DAG_FS, epoch);
-      acc8_foreach<T>(accD, [&](int r, int cc, T& val) { bufA[r * LDP + cc] = val; });
-      __syncthreads();
+      {  // the tile to factor next: bufD -> bufA (lower tiles are what the factorisation reads; copy everything)
+        T* t0 = bufA;
+        bufA = bufD;
+        bufD = t0;
+      }
       DAG_TRC(k + 1, 1);
     }
     return;

@@ -907,10 +907,23 @@ struct ChainPrefetch {
   const int32_t *f1, *f2;
   int32_t epoch;
   int* ok;       // LDS
+  const T* dgsrc;  // LDS: factor of the previous column, still to be stored to Dg (nullptr: none)
+  T* gDg;
   T v[TILE * TILE / 256];
   __device__ __forceinline__ void operator()(int round) {
     const int t = (int)threadIdx.x - 256;
-    if (t < 0 || !src) return;
+    if (t < 0) return;
+    if (round < 2) {  // L_{k-1,k-1} -> Dg, off the critical path (plain stores, read by later kernels only)
+      if (dgsrc) {
+#pragma unroll
+        for (int q = 0; q < TILE * TILE / 512; ++q) {
+          const int e = t + (2 * q + round) * 256;
+          gDg[e] = dgsrc[(e >> 6) * LDP + (e & 63)];
+        }
+      }
+      return;
+    }
+    if (!src) return;
     if (round == 3) {
       if (t == 0)
         *ok = (__hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) &&
@@ -991,13 +1004,15 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* 
       pf.f2 = pre2 + (k + 1) * DAG_FS;
       pf.epoch = epoch;
       pf.ok = &pf_ok;
+      pf.dgsrc = k >= 1 ? bufD : nullptr;  // after the swap below bufD is where L_{k-1,k-1} still sits
+      pf.gDg = Dg + (k - 1) * TILE * TILE;
       if (tid == 0) pf_ok = 0;
       factor_diag_tile_2lvl<T, ChainPrefetch<T>>(bufA, bufB, sc, piv, info, k0, nvalid, pf);
       DAG_TRC(k, 2);
       for (int e = tid; e < TILE * TILE; e += CHOL_THREADS) {
         const int r = e >> 6, cc = e & 63;
         __hip_atomic_store(X + (k0 + r) * ldx + k0 + cc, bufB[r * LDP + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        Dg[k * TILE * TILE + e] = bufA[r * LDP + cc];
+        if (k + 1 == nt) Dg[k * TILE * TILE + e] = bufA[r * LDP + cc];  // otherwise during the next factorisation
       }
       if (k + 1 == nt) {
         dag_signal(xready + k * DAG_FS, epoch);
@@ -1031,8 +1046,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * ri + Mfma<T>::row(lane, r);
-          bufA[row * LDP + 16 * cA + (lane & 15)] = oa[r];  // the factor L_kk that lived here has been stored (Dg) above
-          bufA[row * LDP + 16 * cB + (lane & 15)] = ob[r];
+          bufC[row * LDP + 16 * cA + (lane & 15)] = oa[r];  // in place of T (every wave is past the barrier above)
+          bufC[row * LDP + 16 * cB + (lane & 15)] = ob[r];
           __hip_atomic_store(trow + row * ld + k0 + 16 * cA + (lane & 15), oa[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(trow + row * ld + k0 + 16 * cB + (lane & 15), ob[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1058,13 +1073,13 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* 
           acc_t a;
 #pragma unroll
           for (int r = 0; r < 4; ++r) a[r] = bufD[(16 * i2 + Mfma<T>::row(lane, r)) * LDP + 16 * j2 + (lane & 15)];
-          a = mma_tile16<T>(bufA + 16 * i2 * LDP, bufA + 16 * j2 * LDP, TILE, a, true, lane);
+          a = mma_tile16<T>(bufC + 16 * i2 * LDP, bufC + 16 * j2 * LDP, TILE, a, true, lane);
 #pragma unroll
           for (int r = 0; r < 4; ++r) bufD[(16 * i2 + Mfma<T>::row(lane, r)) * LDP + 16 * j2 + (lane & 15)] = a[r];
         }
       }
       dag_signal(ready + ((k + 1) * nt + k) * DAG_FS, epoch);
-      {  // the tile to factor next: bufD -> bufA (lower tiles are what the factorisation reads; copy everything)
+      {  // the tile to factor next is in bufD; L_kk stays where it is (now called bufD) until the side job has stored it
         T* t0 = bufA;
         bufA = bufD;
         bufD = t0;

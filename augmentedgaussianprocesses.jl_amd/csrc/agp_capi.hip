@@ -102,12 +102,17 @@ static agp_status trtri_levels(agp_ctx* c, const T* A, int64_t ld, T* X, int64_t
   return AGP_OK;
 }
 
-static bool chol_use_dag() {
-  static const bool v = []() {
+// One-launch task graph (k_chol_dag) or one launch per block column (k_chol_step)?  Measured on MI355X, whole CAVI step:
+// m = 1024 f64 0.39 vs 0.52 ms, m = 2048 f32 0.80 vs 1.05 ms, m = 4096 f64 11.6 vs 8.3 ms -- the task graph removes launch
+// gaps and re-reads from the latency-bound chain, but its tiles stream their operands past the L2s (coherent loads), which
+// costs more than it saves once the trailing updates dominate.  AGP_CHOL_DAG=0 / 1 forces one or the other.
+constexpr int64_t DAG_MAX_NT = 32;
+static bool chol_use_dag(int64_t nt) {
+  static const int v = []() {
     const char* e = getenv("AGP_CHOL_DAG");
-    return !(e && e[0] == '0');
+    return e ? (e[0] == '0' ? 0 : 1) : -1;
   }();
-  return v;
+  return v < 0 ? nt <= DAG_MAX_NT : v == 1;
 }
 
 template <typename T>
@@ -159,7 +164,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
   }
   // default: the whole factorisation as ONE launch of the tile task graph (k_chol_dag); AGP_CHOL_DAG=0 falls back to one
   // launch per block column (k_chol_step), which is also what several problems sharing their launches use
-  const bool use_dag = chol_use_dag();
+  const bool use_dag = chol_use_dag(nt);
   if (use_dag && X) {
     const int64_t nf = ((nt + ne) * nt + 3 * nt + 1) * DAG_FS;
     if (c->dag_cap < nf) {
@@ -1026,7 +1031,7 @@ struct Svgp : SvgpBase {
         else
           AGPCHK(potrf_fused_batch<T>(ctx, bt, nb, mp, mp, mp, mp, Bq / TILE + 1, info_dev, m));
       }
-      if (!todo.empty()) AGPCHK(timing_end(todo.size() == 1 && chol_use_dag() ? 1 : mp / TILE));
+      if (!todo.empty()) AGPCHK(timing_end(todo.size() == 1 && chol_use_dag(mp / TILE) ? 1 : mp / TILE));
     }
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
@@ -1653,7 +1658,7 @@ struct Svgp : SvgpBase {
     hipLaunchKernelGGL((k_set_ext_rows<T>), grid1(TILE * mp), dim3(256), 0, st(), ext, mp, mp, (const T*)g.eta1);
     AGPCHK(timing_begin());
     AGPCHK(potrf_fused<T>(ctx, g.La, mp, mp, g.Xa, mp, g.DgA, g.Wbuf, mp, Bq / TILE + 1, with_x, info_dev, m));
-    AGPCHK(timing_end(chol_use_dag() ? 1 : mp / TILE));
+    AGPCHK(timing_end(chol_use_dag(mp / TILE) ? 1 : mp / TILE));
     g.la_state = 1;
     g.xa_valid = with_x != 0;
     return AGP_OK;

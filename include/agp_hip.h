@@ -261,7 +261,7 @@ agp_status agp_svgp_step_stats(agp_svgp* h);
 agp_status agp_svgp_stats_ptr(agp_svgp* h, void** ptr, int64_t* count);
 agp_status agp_svgp_step_global(agp_svgp* h);
 /* Measurement hook (bench.py roofline): when enabled, every factorisation sequence of a CAVI step (the launches of
- * the dominant kernel k_potrf_trtri_step) is bracketed by HIP events recorded on the ctx stream.  timing_read
+ * the dominant kernel: k_chol_dag, or the launches of k_chol_step) is bracketed by HIP events recorded on the ctx stream.  timing_read
  * synchronises, returns the number of bracketed kernel launches and their summed duration, and resets. */
 agp_status agp_svgp_timing_enable(agp_svgp* h, int32_t on);
 agp_status agp_svgp_timing_read(agp_svgp* h, int64_t* n_launches_host, double* total_ms_host);

@@ -505,6 +505,21 @@ struct Svgp : SvgpBase {
   int gh_cap = 0, gh_n = 0;  // Gauss-Hermite nodes | weights (agp_svgp_set_quadrature / proba_y)
   T* lam_dev = nullptr;       // Poisson / heteroscedastic lambda (state re-estimated by every local update)
   double* lam_part = nullptr; // per-workgroup partial sums of the lambda update
+  double* frob_part = nullptr;  // row partial sums of frob_dot
+  int64_t frob_cap = 0;
+  agp_status frob_dot(const T* A, const T* Bm, int64_t ld, int64_t n, double* out) {
+    if (n > frob_cap) {
+      if (frob_part) (void)hipFree(frob_part);
+      frob_part = nullptr;
+      frob_cap = 0;
+      AGPCHK(dmalloc(ctx, &frob_part, n));
+      frob_cap = n;
+    }
+    hipLaunchKernelGGL((k_frob_dot_rows<T>), dim3((unsigned)n), dim3(256), 0, st(), A, Bm, ld, n, frob_part);
+    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(1024), 0, st(), (const double*)frob_part, n, out);
+    LAUNCHCHK(ctx);
+    return AGP_OK;
+  }
   // last step
   const void* x_last = nullptr;
   const void* y_last = nullptr;
@@ -653,6 +668,7 @@ struct Svgp : SvgpBase {
     if (gh_dev) dfree(gh_dev);
     if (lam_dev) dfree(lam_dev);
     if (lam_part) dfree(lam_part);
+    if (frob_part) dfree(frob_part);
   }
 
   agp_status upload_scales(Latent& g) {
@@ -921,15 +937,14 @@ struct Svgp : SvgpBase {
     AGPCHK(materialize(g));
     hipLaunchKernelGGL((k_gemv_rows<T>), grid1(ma * 64), dim3(256), 0, st(), (const T*)g.kappa_a, mp, ma, mp, (const T*)g.mu,
                        g.ov0);                                                     // kappa_a mu
-    hipLaunchKernelGGL((k_frob_dot<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.invDa, (const T*)g.Kta, map, ma,
-                       scal_dev + 48);                                           // tr(invD_a K~_a)
+    AGPCHK(frob_dot((const T*)g.invDa, (const T*)g.Kta, map, ma,
+                    scal_dev + 48));  // tr(invD_a K~_a)
     LAUNCHCHK(ctx);
     AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.kappa_a, mp, g.Sigma, mp, map, mp, mp, 0, g.onT, mp, nullptr, 0, nullptr, nullptr,
                                   nullptr, 0)));                                 // kappa_a Sigma
     AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.onT, mp, g.kappa_a, mp, map, map, mp, 0, g.onQ, map, nullptr, 0, nullptr, nullptr,
                                   nullptr, 0)));                                 // (kappa_a Sigma) kappa_a'
-    hipLaunchKernelGGL((k_frob_dot<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.invDa, (const T*)g.onQ, map, ma,
-                       scal_dev + 49);
+    AGPCHK(frob_dot((const T*)g.invDa, (const T*)g.onQ, map, ma, scal_dev + 49));
     hipLaunchKernelGGL((k_dot<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.peta1, (const T*)g.ov0, ma, scal_dev + 50);
     hipLaunchKernelGGL((k_symv<T>), grid1(ma * 64), dim3(256), 0, st(), (const T*)g.invDa, map, ma, (const T*)g.ov0, g.ov1);
     hipLaunchKernelGGL((k_dot<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.ov0, (const T*)g.ov1, ma, scal_dev + 51);
@@ -1824,8 +1839,7 @@ struct Svgp : SvgpBase {
       Latent& g = lat[l];
       AGPCHK(materialize(g));
       hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.DgA, m, scal_dev + 2);
-      hipLaunchKernelGGL((k_frob_dot<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.Kinv, (const T*)g.Sigma, mp, m,
-                         scal_dev + 3);
+      AGPCHK(frob_dot((const T*)g.Kinv, (const T*)g.Sigma, mp, m, scal_dev + 3));
       hipLaunchKernelGGL((k_axpby<T>), grid1(mp), dim3(256), 0, st(), mp, T(1), (const T*)g.mu, T(-1), (const T*)g.mu0,
                          tmpv);
       hipLaunchKernelGGL((k_trmv_lower<T>), grid1(mp * 64), dim3(256), 0, st(), (const T*)g.Xk, mp, mp, (const T*)tmpv,

@@ -74,13 +74,7 @@ static agp_status dmalloc(agp_ctx* c, T** p, int64_t n) {
 
 // ---- linear-algebra drivers on padded matrices ---------------------------------------------------------------
 // Cholesky (lower, in place; diagonal factors in Dg) of the n x n (n = nt*64) matrix A with `ne` extension row blocks
-// E <- E L^-T (augmented Cholesky): nt launches of k_chol_step; do_x adds X = L^-1 (one extra row launch per column).
-// X = L^-1 (all off-diagonal tiles) from L and the diagonal inverses already in X: recursive doubling, 2 launches per level
-template <typename T>
-static agp_status trtri_levels(agp_ctx* c, const T* A, int64_t ld, T* X, int64_t ldx, int64_t nt) {
-  if (nt <= 1) return AGP_OK;
-  const int64_t n = nt * TILE;
-  const size_t need = sizeof(T) * (size_t)n * (size_t)n;
+static agp_status tri_scratch_ensure(agp_ctx* c, size_t need) {
   if (c->tri_bytes < need) {
     if (c->tri_scratch) {
       (void)hipStreamSynchronize(c->stream);
@@ -91,6 +85,16 @@ static agp_status trtri_levels(agp_ctx* c, const T* A, int64_t ld, T* X, int64_t
     if (hipMalloc(&c->tri_scratch, need) != hipSuccess) return AGP_ERR_NOMEM;
     c->tri_bytes = need;
   }
+  return AGP_OK;
+}
+
+// E <- E L^-T (augmented Cholesky): nt launches of k_chol_step; do_x adds X = L^-1 (one extra row launch per column).
+// X = L^-1 (all off-diagonal tiles) from L and the diagonal inverses already in X: recursive doubling, 2 launches per level
+template <typename T>
+static agp_status trtri_levels(agp_ctx* c, const T* A, int64_t ld, T* X, int64_t ldx, int64_t nt) {
+  if (nt <= 1) return AGP_OK;
+  const int64_t n = nt * TILE;
+  AGPCHK(tri_scratch_ensure(c, sizeof(T) * (size_t)n * (size_t)n));
   T* S = (T*)c->tri_scratch;
   for (int64_t bs = 1; bs < nt; bs *= 2) {
     const int64_t pairs = (nt + 2 * bs - 1) / (2 * bs);
@@ -166,7 +170,8 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
   // launch per block column (k_chol_step), which is also what several problems sharing their launches use
   const bool use_dag = chol_use_dag(nt);
   if (use_dag && X) {
-    const int64_t nf = ((nt + ne) * nt + 3 * nt + 1) * DAG_FS;
+    const int64_t nx = (do_x && nt > 1) ? nt : 0;  // the full inverse rides along as nt identity block rows
+    const int64_t nf = ((nt + ne + nx) * nt + 3 * nt + 1) * DAG_FS;
     if (c->dag_cap < nf) {
       if (c->dag_flags) (void)hipFree(c->dag_flags);
       c->dag_flags = nullptr;
@@ -177,7 +182,12 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       c->dag_epoch = 0;
     }
     c->dag_epoch += 1;
-    const int64_t ntiles = nt * (nt + 1) / 2 + ne * nt;
+    const int64_t ntiles = nt * (nt + 1) / 2 + ne * nt + (nx ? nt * (nt + 1) / 2 : 0);
+    T* XS = nullptr;
+    if (nx) {
+      AGPCHK(tri_scratch_ensure(c, sizeof(T) * (size_t)n * (size_t)n));
+      XS = (T*)c->tri_scratch;
+    }
     unsigned long long* trace = nullptr;
     static const char* trace_path = getenv("AGP_DAG_TRACE");  // development aid: per-tile timestamps of one launch
     if (trace_path && ne > 0) {
@@ -190,10 +200,10 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     }();
     if (fused)
       hipLaunchKernelGGL((k_chol_dag<T, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, A, ld, X, ldx, Dg, E,
-                         lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace);
+                         lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, XS, nx);
     else
       hipLaunchKernelGGL((k_chol_dag<T, false>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, A, ld, X, ldx, Dg, E,
-                         lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace);
+                         lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, XS, nx);
     LAUNCHCHK(c);
     if (trace) {
       std::vector<unsigned long long> h((size_t)ntiles * 8);
@@ -207,8 +217,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
         fclose(f);
       }
     }
-    if (do_x) AGPCHK(trtri_levels<T>(c, (const T*)A, ld, X, ldx, nt));
-    return AGP_OK;
+    return AGP_OK;  // X = L^-1 came out of the same launch
   }
   CholBatch<T> bt{};
   bt.A[0] = A;

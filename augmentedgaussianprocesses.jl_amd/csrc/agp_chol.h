@@ -796,8 +796,10 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_flow(T* A, int64_t ld, T*
 // flags: int32 [(nt + ne) * nt] tile-ready | [nt] x-ready | [1] abort, each on its own 256-byte line (stride DAG_FS)
 // ---------------------------------------------------------------------------------------------------
 constexpr long DAG_SPIN_LIMIT = 1L << 24;  // ~10 s of polling
-__device__ __forceinline__ int64_t chain_slot(int64_t col, int64_t nt, int64_t ne) {  // workgroup index of diagonal tile `col`
-  return col * (nt + ne) - col * (col - 1) / 2;
+// workgroup index of diagonal tile `col`: column c holds nt - c matrix tiles, ne extension tiles and, with the inverse
+// requested (nx), c + 1 identity-row tiles
+__device__ __forceinline__ int64_t chain_slot(int64_t col, int64_t nt, int64_t ne, int64_t nx) {
+  return nx ? col * (nt + ne + 1) : col * (nt + ne) - col * (col - 1) / 2;
 }
 constexpr int DAG_FS = 64;  // flag stride in int32: one 256-byte line per flag, so the pollers spread over the memory channels
 
@@ -954,7 +956,10 @@ template <typename T, bool FUSED>
 __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* X, int64_t ldx, T* __restrict__ Dg, T* E,
                                                            int64_t lde, int64_t ne, int64_t nt,
                                                            int32_t* __restrict__ info, int64_t nvalid, int32_t* flags,
-                                                           int32_t epoch, unsigned long long* trace) {
+                                                           int32_t epoch, unsigned long long* trace, T* XS, int64_t nx) {
+  // nx = nt: also X = L^-1 in full.  L^-T = I L^-T, so nt more extension block rows holding the identity give X' column by
+  // column with the same task graph and off the critical path (row i: tiles (i, c), c >= i; the others stay zero and have
+  // no workgroup).  They recurse through the row-major scratch XS (n x n) and are stored transposed into X.
   __shared__ __attribute__((aligned(16))) T sm[(FUSED ? 4 : 2) * TILE * LDP];
   __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
   __shared__ T piv[TILE];
@@ -964,26 +969,31 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* 
   const int tid = threadIdx.x;
   // column-major tile numbering: column c holds its diagonal tile, rows c+1..nt-1, then the ne extension blocks
   int64_t b = blockIdx.x, c = 0;
-  while (b >= nt - c + ne) {
-    b -= nt - c + ne;
+  while (b >= nt - c + ne + (nx ? c + 1 : 0)) {
+    b -= nt - c + ne + (nx ? c + 1 : 0);
     ++c;
   }
-  const bool diag = b == 0, ext = b >= nt - c;
-  const int64_t R = ext ? nt + (b - (nt - c)) : c + b;  // block-row index in [0, nt + ne)
-  T* rowp = ext ? E + (R - nt) * TILE * lde : A + R * TILE * ld;
-  const int64_t ldr = ext ? lde : ld, c0 = c * TILE;
+  const bool diag = b == 0, ext = b >= nt - c, idr = b >= nt - c + ne;  // idr: identity row i = b - (nt - c + ne) <= c
+  const int64_t R = idr ? nt + ne + (b - (nt - c + ne)) : ext ? nt + (b - (nt - c)) : c + b;  // block row in [0, nt+ne+nx)
+  T* rowp = idr ? XS + (R - nt - ne) * TILE * (nt * TILE) : ext ? E + (R - nt) * TILE * lde : A + R * TILE * ld;
+  const int64_t ldr = idr ? nt * TILE : ext ? lde : ld, c0 = c * TILE;
   int32_t* ready = flags;
-  int32_t* xready = flags + (nt + ne) * nt * DAG_FS;
+  int32_t* xready = flags + (nt + ne + nx) * nt * DAG_FS;
   int32_t* pre1 = xready + nt * DAG_FS;  // FUSED: tile (c, c-1) with all its pending updates is parked in place for the chain
   int32_t* pre2 = pre1 + nt * DAG_FS;    // FUSED: diagonal tile (c, c) with the updates of columns < c-1 parked in place
   int32_t* abortf = pre2 + nt * DAG_FS;
 #define DAG_TR(slot) \
   if (trace && tid == 0) trace[blockIdx.x * 8 + (slot)] = wall_clock64()
 #define DAG_TRC(col, slot) \
-  if (trace && tid == 0) trace[chain_slot(col, nt, ne) * 8 + (slot)] = wall_clock64()
+  if (trace && tid == 0) trace[chain_slot(col, nt, ne, nx) * 8 + (slot)] = wall_clock64()
   DAG_TR(0);
   Acc8<T> acc;
-  acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = rowp[r * ldr + c0 + cc]; });
+  if (idr) {
+    const bool on_diag = (R - nt - ne) == c;
+    acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = (on_diag && r == cc) ? T(1) : T(0); });
+  } else {
+    acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = rowp[r * ldr + c0 + cc]; });
+  }
   if (FUSED && blockIdx.x == 0) {
     // ---- the chain: ONE workgroup carries the critical path through all columns, so that per column only the tile
     // factorisation and two 64^3 products are serial:  factor(c) -> L(c+1,c) = T X_c' -> S = D - L L' -> factor(c+1).
@@ -1024,7 +1034,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* 
         load_tiles_lds_coh2<T>(trow + k0, ld, bufC, trow + k0 + TILE, ld, bufD);
         __syncthreads();
       }
-      if (trace && tid == 0) trace[chain_slot(k + 1, nt, ne) * 8 + 7] = (unsigned long long)pf_ok;
+      if (trace && tid == 0) trace[chain_slot(k + 1, nt, ne, nx) * 8 + 7] = (unsigned long long)pf_ok;
       DAG_TRC(k + 1, 4);
       // both products skip what the structure makes zero or redundant (a 64^3 f64 product is MFMA-throughput bound on one CU:
       // 2.2 us; these take 40/64 and 48/64 of it):
@@ -1091,7 +1101,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* 
   const bool f1 = FUSED && b == 1 && !ext;  // tile (c+1, c): feeds the chain instead of waiting for X_c itself
   const bool f2 = FUSED && diag;            // diagonal tile (c, c), c >= 1: the chain applies the last update itself
   const int64_t jend = f2 ? c - 1 : c;
-  for (int64_t j = 0; j < jend; ++j) {
+  for (int64_t j = idr ? R - nt - ne : 0; j < jend; ++j) {  // row i of the identity is zero left of block column i
     if (!dag_wait(ready + (R * nt + j) * DAG_FS, diag ? nullptr : ready + (c * nt + j) * DAG_FS, epoch, abortf, info, &wait_ok))
       return;
     if (j == c - 1) DAG_TR(4);
@@ -1137,6 +1147,10 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* 
   acc8_foreach<T>(out, [&](int r, int cc, T& val) {
     __hip_atomic_store(rowp + r * ldr + c0 + cc, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   });
+  if (idr) {  // (L^-T)(i, c) = X(c, i)': the tile of X proper, for the kernels that follow
+    const int64_t i0 = (R - nt - ne) * TILE;
+    acc8_foreach<T>(out, [&](int r, int cc, T& val) { X[(c0 + cc) * ldx + i0 + r] = val; });
+  }
   DAG_TR(7);
   dag_signal(ready + (R * nt + c) * DAG_FS, epoch);
   DAG_TR(3);

@@ -82,7 +82,7 @@ def test_kernelmatrix(env, kname, kid, dtype):
     assert _rel(out.cpu().numpy(), ref) < tol
 
 
-@pytest.mark.parametrize("n", [5, 64, 100, 257, 1024])
+@pytest.mark.parametrize("n", [5, 64, 100, 257, 1024, 2048, 2112])  # 2048: largest task-graph size; 2112: per-column launches
 def test_potrf_and_inverse(env, n):
     torch, L, ctx = env["torch"], env["L"], env["ctx"]
     rng = np.random.default_rng(n)
@@ -109,6 +109,27 @@ def test_potrf_and_inverse(env, n):
     st = L.agp_solve_right_spd(ctx, 0, a2.data_ptr(), n, n, bd.data_ptr(), n, r, xd.data_ptr(), n, C.byref(info))
     assert st == 0
     assert _rel(xd.cpu().numpy(), np.linalg.solve(A, Bm.T).T) < 1e-10
+
+
+def test_task_graph_cholesky_repeated(env):
+    """The one-launch task-graph factorisation hands tiles between workgroups with coherent stores / loads and flags instead of
+    fences: 60 different matrices through the same context (flags are epoch-stamped, never reset), factor and full inverse
+    checked every time -- a stale or torn tile would show as an O(1) error."""
+    torch, L, ctx = env["torch"], env["L"], env["ctx"]
+    rng = np.random.default_rng(77)
+    n = 1024
+    info = C.c_int32(-1)
+    ld = C.c_double()
+    inv = torch.empty(n, n, dtype=torch.float64, device="cuda")
+    for rep in range(60):
+        G = rng.standard_normal((n, n + 8))
+        A = G @ G.T / n + (0.2 + 0.01 * rep) * np.eye(n)
+        a = torch.tensor(A, dtype=torch.float64, device="cuda")
+        assert L.agp_spd_inverse(ctx, 0, a.data_ptr(), n, n, inv.data_ptr(), n, C.byref(ld), C.byref(info)) == 0
+        assert info.value == 0
+        got = inv.cpu().numpy()
+        assert _rel(got @ A, np.eye(n)) < 1e-9, rep
+        assert abs(ld.value - np.linalg.slogdet(A)[1]) < 1e-8 * abs(ld.value)
 
 
 def test_potrf_not_posdef(env):

@@ -121,7 +121,9 @@ static bool chol_use_dag(int64_t nt) {
 
 template <typename T>
 static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int64_t ldx, T* Dg, T* E, int64_t lde,
-                              int64_t ne, int do_x, int32_t* info_dev, int64_t nvalid) {
+                              int64_t ne, int do_x, int32_t* info_dev, int64_t nvalid, const T* erow = nullptr) {
+  // erow: the last extension block is [erow' ; 0] (not yet written to E: the task graph reads it in place; the per-column
+  // path needs it in E first)
   const int64_t nt = n / TILE;
   // experimental: AGP_CHOL_FLOW=1 runs the whole factorisation as one persistent dataflow launch (k_chol_flow).  Correct
   // (the GPU suite passes with it) but slower on MI355X than one launch per block column: see DESIGN.md section 4.
@@ -200,10 +202,10 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     }();
     if (fused)
       hipLaunchKernelGGL((k_chol_dag<T, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, A, ld, X, ldx, Dg, E,
-                         lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, XS, nx);
+                         lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, XS, nx, erow);
     else
       hipLaunchKernelGGL((k_chol_dag<T, false>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, A, ld, X, ldx, Dg, E,
-                         lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, XS, nx);
+                         lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, XS, nx, erow);
     LAUNCHCHK(c);
     if (trace) {
       std::vector<unsigned long long> h((size_t)ntiles * 8);
@@ -219,6 +221,9 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     }
     return AGP_OK;  // X = L^-1 came out of the same launch
   }
+  if (erow && ne > 0)
+    hipLaunchKernelGGL((k_set_ext_rows<T>), dim3((unsigned)((TILE * n + 255) / 256)), dim3(256), 0, c->stream,
+                       E + (ne - 1) * TILE * lde, lde, n, erow);
   CholBatch<T> bt{};
   bt.A[0] = A;
   bt.X[0] = X;
@@ -1028,8 +1033,9 @@ struct Svgp : SvgpBase {
         hipLaunchKernelGGL((k_copy2d<T>), grid2(mp, mp), blk2, 0, st(), (const T*)g.eta2, mp, mp, mp, g.La, mp, mp, mp,
                            T(1), T(-2));
       }
-      hipLaunchKernelGGL((k_set_ext_rows<T>), grid1(TILE * mp), dim3(256), 0, st(), g.Wbuf + Bq * mp, mp, mp,
-                         (const T*)g.eta1);
+      if (nl > 1)  // a single latent gets [eta1' ; 0] passed along instead (potrf_fused erow)
+        hipLaunchKernelGGL((k_set_ext_rows<T>), grid1(TILE * mp), dim3(256), 0, st(), g.Wbuf + Bq * mp, mp, mp,
+                           (const T*)g.eta1);
       LAUNCHCHK(ctx);
     }
     // the augmented Cholesky factorisations of the remaining latents share their launches (independent chains overlap)
@@ -1051,7 +1057,8 @@ struct Svgp : SvgpBase {
           g.xa_valid = false;
         }
         if (nb == 1)  // a single problem may take the one-launch task-graph path
-          AGPCHK(potrf_fused<T>(ctx, bt.A[0], mp, mp, bt.X[0], mp, bt.Dg[0], bt.E[0], mp, Bq / TILE + 1, 0, info_dev, m));
+          AGPCHK(potrf_fused<T>(ctx, bt.A[0], mp, mp, bt.X[0], mp, bt.Dg[0], bt.E[0], mp, Bq / TILE + 1, 0, info_dev, m,
+                                (const T*)lat[todo[l0]].eta1));
         else
           AGPCHK(potrf_fused_batch<T>(ctx, bt, nb, mp, mp, mp, mp, Bq / TILE + 1, info_dev, m));
       }
@@ -1678,10 +1685,9 @@ struct Svgp : SvgpBase {
                          T(1), T(-2));
       LAUNCHCHK(ctx);
     }
-    T* ext = g.Wbuf + Bq * mp;
-    hipLaunchKernelGGL((k_set_ext_rows<T>), grid1(TILE * mp), dim3(256), 0, st(), ext, mp, mp, (const T*)g.eta1);
     AGPCHK(timing_begin());
-    AGPCHK(potrf_fused<T>(ctx, g.La, mp, mp, g.Xa, mp, g.DgA, g.Wbuf, mp, Bq / TILE + 1, with_x, info_dev, m));
+    AGPCHK(potrf_fused<T>(ctx, g.La, mp, mp, g.Xa, mp, g.DgA, g.Wbuf, mp, Bq / TILE + 1, with_x, info_dev, m,
+                          (const T*)g.eta1));
     AGPCHK(timing_end(chol_use_dag(mp / TILE) ? 1 : mp / TILE));
     g.la_state = 1;
     g.xa_valid = with_x != 0;

@@ -956,7 +956,10 @@ template <typename T, bool FUSED>
 __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* X, int64_t ldx, T* __restrict__ Dg, T* E,
                                                            int64_t lde, int64_t ne, int64_t nt,
                                                            int32_t* __restrict__ info, int64_t nvalid, int32_t* flags,
-                                                           int32_t epoch, unsigned long long* trace, T* XS, int64_t nx) {
+                                                           int32_t epoch, unsigned long long* trace, T* XS, int64_t nx,
+                                                           const T* __restrict__ erow) {
+  // erow (optional): row 0 of the LAST extension block is taken from this vector and its rows 1-63 as zero, instead of being
+  // read from E (the CAVI step appends [eta1' ; 0]: saves the launch that used to write them)
   // nx = nt: also X = L^-1 in full.  L^-T = I L^-T, so nt more extension block rows holding the identity give X' column by
   // column with the same task graph and off the critical path (row i: tiles (i, c), c >= i; the others stay zero and have
   // no workgroup).  They recurse through the row-major scratch XS (n x n) and are stored transposed into X.
@@ -991,6 +994,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* 
   if (idr) {
     const bool on_diag = (R - nt - ne) == c;
     acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = (on_diag && r == cc) ? T(1) : T(0); });
+  } else if (erow && ext && R == nt + ne - 1) {
+    acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = r == 0 ? erow[c0 + cc] : T(0); });
   } else {
     acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = rowp[r * ldr + c0 + cc]; });
   }

@@ -270,14 +270,16 @@ static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* o
 // S = A' diag(w) A (lower tiles mirrored), two k-groups per workgroup when the tile count underfills the chip
 template <typename T, int MODE>
 static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_t Kdim, const T* w, int lower_a, T* out,
-                          int64_t ldo, T* eta2, const T* Kinv, int64_t ldm, T lr) {
-  const int64_t nt = n / TILE, tiles = nt * (nt + 1) / 2;
+                          int64_t ldo, T* eta2, const T* Kinv, int64_t ldm, T lr, const T* rvec = nullptr,
+                          T* eta1 = nullptr, const T* kinv_mu0 = nullptr) {
+  // rvec: nt rider workgroups also step eta1 (see k_syrk_tn)
+  const int64_t nt = n / TILE, tiles = nt * (nt + 1) / 2, grid = tiles + (rvec ? nt : 0);
   if (tiles <= 320 && Kdim >= 4 * BK)
-    hipLaunchKernelGGL((k_syrk_tn<T, MODE, 2>), dim3((unsigned)tiles), dim3(2 * NTHREADS), 0, c->stream, A, lda, Kdim, w,
-                       lower_a, out, ldo, eta2, Kinv, ldm, lr);
+    hipLaunchKernelGGL((k_syrk_tn<T, MODE, 2>), dim3((unsigned)grid), dim3(2 * NTHREADS), 0, c->stream, A, lda, Kdim, w,
+                       lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0);
   else
-    hipLaunchKernelGGL((k_syrk_tn<T, MODE, 1>), dim3((unsigned)tiles), dim3(NTHREADS), 0, c->stream, A, lda, Kdim, w,
-                       lower_a, out, ldo, eta2, Kinv, ldm, lr);
+    hipLaunchKernelGGL((k_syrk_tn<T, MODE, 1>), dim3((unsigned)grid), dim3(NTHREADS), 0, c->stream, A, lda, Kdim, w,
+                       lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0);
   LAUNCHCHK(c);
   return AGP_OK;
 }
@@ -1651,16 +1653,15 @@ struct Svgp : SvgpBase {
     const T lr = (T)cur_lr();
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
-      dim3 gc((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
-      hipLaunchKernelGGL((k_colsum_partial<T>), gc, dim3(NTHREADS), 0, st(), (const T*)g.kappa, mp,
-                         (const T*)(rbuf + l * Bp), cpart, mp);
       T* sl = stats + l * (mp + mp * mp);
-      if (fused) {
-        hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, (int)(Bq / TILE), (const T*)cpart, mp,
-                           (const T*)nullptr, (const T*)(g.on ? g.kinv_mu0_on : g.kinv_mu0), g.eta1, lr, (T*)nullptr);
+      if (fused) {  // one launch: eta2 step on the lower tiles, eta1 step on nt rider workgroups
         AGPCHK((syrk_tn<T, SY_ETA2>(ctx, g.kappa, mp, mp, Bq, wbuf + l * Bp, 0, g.La, mp, g.eta2,
-                                    g.on ? g.Kinv_on : g.Kinv, mp, lr)));
+                                    g.on ? g.Kinv_on : g.Kinv, mp, lr, (const T*)(rbuf + l * Bp), g.eta1,
+                                    (const T*)(g.on ? g.kinv_mu0_on : g.kinv_mu0))));
       } else {
+        dim3 gc((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
+        hipLaunchKernelGGL((k_colsum_partial<T>), gc, dim3(NTHREADS), 0, st(), (const T*)g.kappa, mp,
+                           (const T*)(rbuf + l * Bp), cpart, mp);
         hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, (int)(Bq / TILE), (const T*)cpart, mp,
                            (const T*)nullptr, (const T*)nullptr, (T*)nullptr, lr, sl);
         AGPCHK((syrk_tn<T, SY_STORE>(ctx, g.kappa, mp, mp, Bq, wbuf + l * Bp, 0, sl + mp, mp, (T*)nullptr,

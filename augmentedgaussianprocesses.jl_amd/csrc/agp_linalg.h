@@ -86,8 +86,28 @@ template <typename T, int MODE, int KG = 1>
 __global__ __launch_bounds__(NTHREADS * KG) void k_syrk_tn(const T* __restrict__ A, int64_t lda, int64_t Kdim,
                                                       const T* __restrict__ w, int lower_a, T* __restrict__ out,
                                                       int64_t ldo, T* __restrict__ eta2, const T* __restrict__ Kinv,
-                                                      int64_t ldm, T lr) {
+                                                      int64_t ldm, T lr, int64_t ntri = 0,
+                                                      const T* __restrict__ rvec = nullptr, T* __restrict__ eta1 = nullptr,
+                                                      const T* __restrict__ kinv_mu0 = nullptr) {
   __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
+  if (rvec && (int64_t)blockIdx.x >= ntri) {
+    // rider of the fused step: workgroup ntri + j also takes the natural-gradient step on eta1[64 j .. 64 j + 63]
+    //   t = A' r (column sums, analyticVI.jl:168) ; eta1 += lr (t + K^-1 mu0 - eta1)
+    // (these launches used to be k_colsum_partial + k_eta1_update: two kernels and two launch gaps on the step's critical path)
+    const int64_t c0 = ((int64_t)blockIdx.x - ntri) * TILE;
+    const int c = threadIdx.x & 63, grp = threadIdx.x >> 6, ngrp = blockDim.x >> 6;
+    T sum = T(0);
+    for (int64_t k = grp; k < Kdim; k += ngrp) sum += A[k * lda + c0 + c] * rvec[k];
+    smem[grp * TILE + c] = sum;
+    __syncthreads();
+    if (grp == 0) {
+      T t = T(0);
+      for (int q = 0; q < ngrp; ++q) t += smem[q * TILE + c];
+      const T e = eta1[c0 + c];
+      eta1[c0 + c] = e + lr * (t + (kinv_mu0 ? kinv_mu0[c0 + c] : T(0)) - e);
+    }
+    return;
+  }
   int64_t ta, tb;
   tri_index(blockIdx.x, ta, tb);
   const int64_t a0 = ta * TILE, b0 = tb * TILE;

@@ -22,8 +22,6 @@ struct agp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
-  int32_t* flow_flags = nullptr;  // dependency flags of the dataflow factorisation (k_chol_flow)
-  int64_t flow_cap = 0;
   int32_t* dag_flags = nullptr;   // tile / x-ready / abort flags of the task-graph factorisation (k_chol_dag), epoch-stamped
   int64_t dag_cap = 0;
   int32_t dag_epoch = 0;
@@ -125,51 +123,6 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
   // erow: the last extension block is [erow' ; 0] (not yet written to E: the task graph reads it in place; the per-column
   // path needs it in E first)
   const int64_t nt = n / TILE;
-  // experimental: AGP_CHOL_FLOW=1 runs the whole factorisation as one persistent dataflow launch (k_chol_flow).  Correct
-  // (the GPU suite passes with it) but slower on MI355X than one launch per block column: see DESIGN.md section 4.
-  static const bool use_flow = []() {
-    const char* e = getenv("AGP_CHOL_FLOW");
-    return e && e[0] == '1';
-  }();
-  if (use_flow) {
-    const int64_t nf = 2 * nt + 1;
-    if (c->flow_cap < nf) {
-      if (c->flow_flags) (void)hipFree(c->flow_flags);
-      c->flow_flags = nullptr;
-      c->flow_cap = 0;
-      if (hipMalloc((void**)&c->flow_flags, sizeof(int32_t) * (size_t)(nf + 64)) != hipSuccess) return AGP_ERR_NOMEM;
-      c->flow_cap = nf + 64;
-    }
-    HIPCHK(c, hipMemsetAsync(c->flow_flags, 0, sizeof(int32_t) * (size_t)nf, c->stream));
-    unsigned long long* trace = nullptr;
-    static const char* trace_path = getenv("AGP_FLOW_TRACE");  // development aid: per-row/column timestamps of one launch
-    const size_t ntr = (size_t)(nt + ne) * (nt + 1) * 4;
-    if (trace_path && ne > 0) {
-      if (hipMalloc((void**)&trace, ntr * 8) != hipSuccess) trace = nullptr;
-      if (trace) (void)hipMemsetAsync(trace, 0, ntr * 8, c->stream);
-    }
-    hipLaunchKernelGGL((k_chol_flow<T>), dim3((unsigned)(nt + ne)), dim3(CHOL_THREADS), 0, c->stream, A, ld, X, ldx, Dg, E, lde,
-                       ne, nt, info_dev, nvalid, c->flow_flags, trace);
-    if (trace) {
-      std::vector<unsigned long long> h(ntr);
-      (void)hipStreamSynchronize(c->stream);
-      (void)hipMemcpy(h.data(), trace, ntr * 8, hipMemcpyDeviceToHost);
-      (void)hipFree(trace);
-      FILE* f = fopen(trace_path, "w");
-      if (f) {
-        fprintf(f, "%lld %lld\n", (long long)nt, (long long)ne);
-        for (size_t i = 0; i < ntr; ++i) fprintf(f, "%llu\n", h[i]);
-        fclose(f);
-      }
-    }
-    if (do_x)
-      for (int64_t k = 1; k < nt; ++k)
-        hipLaunchKernelGGL((k_trtri_row<T>), dim3((unsigned)k), dim3(NTHREADS), 0, c->stream, (const T*)A, ld, X, ldx, k);
-    LAUNCHCHK(c);
-    return AGP_OK;
-  }
-  // default: the whole factorisation as ONE launch of the tile task graph (k_chol_dag); AGP_CHOL_DAG=0 falls back to one
-  // launch per block column (k_chol_step), which is also what several problems sharing their launches use
   const bool use_dag = chol_use_dag(nt);
   if (use_dag && X) {
     const int64_t nx = (do_x && nt > 1) ? nt : 0;  // the full inverse rides along as nt identity block rows
@@ -2270,9 +2223,8 @@ agp_status agp_ctx_create(int32_t device, void* hip_stream, agp_ctx** out) {
 }
 
 agp_status agp_ctx_destroy(agp_ctx* ctx) {
-  if (ctx && (ctx->flow_flags || ctx->tri_scratch || ctx->dag_flags)) {
+  if (ctx && (ctx->tri_scratch || ctx->dag_flags)) {
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->flow_flags) (void)hipFree(ctx->flow_flags);
     if (ctx->dag_flags) (void)hipFree(ctx->dag_flags);
     if (ctx->tri_scratch) (void)hipFree(ctx->tri_scratch);
   }

@@ -51,31 +51,6 @@ __device__ __forceinline__ void load_tile_lds(const T* __restrict__ G, int64_t l
   }
 }
 
-// split form of load_tile_lds for software pipelining: issue the global loads now, write LDS later
-template <typename T, int NT>
-struct TileRegs {
-  typedef typename Mfma<T>::vec_t vec_t;
-  static constexpr int VEC = Mfma<T>::VEC, NV = TILE / VEC, CNT = TILE * NV / NT;
-  vec_t v[CNT];
-  __device__ __forceinline__ void fetch(const T* G, int64_t ld) {
-#pragma unroll
-    for (int i = 0; i < CNT; ++i) {
-      int vi = threadIdx.x + i * NT;
-      int r = vi / NV, cv = vi % NV;
-      v[i] = *reinterpret_cast<const vec_t*>(G + (int64_t)r * ld + cv * VEC);
-    }
-  }
-  __device__ __forceinline__ void commit(T* S) const {
-#pragma unroll
-    for (int i = 0; i < CNT; ++i) {
-      int vi = threadIdx.x + i * NT;
-      int r = vi / NV, cv = vi % NV;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) S[r * LDP + cv * VEC + e] = v[i][e];
-    }
-  }
-};
-
 // ---- 8-wave 64x64x64 product from LDS: wave w owns rows (w>>2)*32 + {0,16} + .., cols (w&3)*16 + .. ----
 template <typename T>
 struct Acc8 {
@@ -600,185 +575,6 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(CholBatch<T> bt, int
   }
 }
 
-// Row q of X = L^-1 (on demand): X_qj = -X_qq sum_{i=j}^{q-1} L_qi X_ij, j < q.  grid = q, 256 threads.
-// Launched after S(q) (which stored X_qq); rows < q are complete by then.
-template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_trtri_row(const T* __restrict__ A, int64_t ld, T* __restrict__ X,
-                                                        int64_t ldx, int64_t q) {
-  __shared__ __attribute__((aligned(16))) T sm[2 * TILE * LDP];
-  static_assert(2 * TILE * LDP >= SMEM_ELEMS, "gemm staging must fit in bufA+bufB");
-  T* bufA = sm;
-  T* bufB = sm + TILE * LDP;
-  const int tid = threadIdx.x;
-  const int64_t j = blockIdx.x, q0 = q * TILE, j0 = j * TILE;
-  Acc<T> acc;
-  acc.zero();
-  gemm_tile<T, KC, RC>(A + q0 * ld, ld, X + j0, ldx, j0, q0, nullptr, acc, sm);
-  // stage S transposed (St[c][k]) and X_qq ([r][k]) for the 64-deep product
-  acc_foreach<T>(acc, [&](int r, int c, T val) { bufA[c * LDP + r] = val; });
-  for (int e = tid; e < TILE * TILE; e += NTHREADS) {
-    int R = e >> 6, Cc = e & 63;
-    bufB[R * LDP + Cc] = X[(q0 + R) * ldx + q0 + Cc];
-  }
-  __syncthreads();
-  Acc<T> out;
-  out.zero();
-  mma_lds64<T>(bufB, bufA, out);
-  acc_foreach<T>(out, [&](int r, int c, T val) { X[(q0 + r) * ldx + j0 + c] = -val; });
-}
-
-// ---------------------------------------------------------------------------------------------------
-// k_chol_flow: the whole augmented factorisation as ONE persistent dataflow launch (replaces nt launches of k_chol_step).
-//
-// One 512-thread workgroup per block row (nt matrix rows, then ne extension row blocks), each running the LEFT-looking
-// recurrence of its row:
-//     for j < row:   T = A(row, j) - sum_{j' < j} L(row, j') L(j, j')'      needs row j's finished tiles   -> flag rowdone[j]
-//                    L(row, j) = T X_j'                                      needs the factor of tile j      -> flag xready[j]
-//     matrix rows:   D = A(row,row) - sum_j L(row,j) L(row,j)' ; (L_kk, X_k) = factor(D) ; publish, set xready[row]
-// Dependencies only point to LOWER block indices and workgroups are dispatched in index order, so the spin waits cannot
-// deadlock even if the grid were not fully resident.  The critical path per block column is
-//     factor(k) -> [publish X_k] -> [row k+1: fetch X_k, one TRSM product, one rank-64 update of its diagonal tile] -> factor(k+1):
-// everything else a row needs for column j (its j left-looking products, and for row j+1 all but the last term of the
-// diagonal sum) is done while tile j is still being factored, so launch gaps, cold re-loads of the trailing matrix
-// and the right-looking update traffic of the per-column launches disappear from the chain.
-// Cross-workgroup visibility: producer = stores ; __threadfence() ; barrier ; release-store of the flag (agent scope);
-// consumer = acquire-poll by one thread ; barrier ; __threadfence().  A bounded spin count turns a lost dependency into an
-// error flag instead of a hang.
-// flags: int32 [2*nt + 1] zeroed before the launch: xready[nt] | rowdone[nt] | abort
-// ---------------------------------------------------------------------------------------------------
-constexpr long FLOW_SPIN_LIMIT = 1L << 24;
-
-__device__ __forceinline__ bool flow_wait(int32_t* flag, int32_t* abort_flag, int* lds_ok) {
-  if (threadIdx.x == 0) {
-    long spins = 0;
-    int ok = 1;
-    if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ok = 0;
-    // relaxed polling: an acquire load per spin would invalidate this XCD's L2 over and over (and with it the tiles the
-    // other workgroups of the XCD are streaming); the single acquire fence follows the barrier below
-    while (ok && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > FLOW_SPIN_LIMIT || ((spins & 255) == 0 &&
-                                        __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
-      }
-    }
-    *lds_ok = ok;
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  return *lds_ok != 0;
-}
-
-__device__ __forceinline__ void flow_signal(int32_t* flag) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // every thread publishes its own stores
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <typename T>
-__global__ __launch_bounds__(CHOL_THREADS) void k_chol_flow(T* A, int64_t ld, T* X, int64_t ldx,
-                                                            T* __restrict__ Dg, T* E, int64_t lde, int64_t ne,
-                                                            int64_t nt, int32_t* __restrict__ info, int64_t nvalid,
-                                                            int32_t* __restrict__ flags, unsigned long long* trace) {
-  __shared__ __attribute__((aligned(16))) T sm[4 * TILE * LDP];
-  __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
-  __shared__ T piv[TILE];
-  __shared__ int wait_ok;
-  T* bufA = sm;
-  T* bufB = sm + TILE * LDP;
-  T* bufT = sm + 2 * TILE * LDP;
-  T* bufX = sm + 3 * TILE * LDP;
-  int32_t* xready = flags;
-  int32_t* rowdone = flags + nt;
-  int32_t* abortf = flags + 2 * nt;
-  const int tid = threadIdx.x;
-  const int64_t bid = blockIdx.x;
-  const bool ext = bid >= nt;
-#define FLOW_TR(col, slot) \
-  if (trace && tid == 0) trace[(bid * (nt + 1) + (col)) * 4 + (slot)] = wall_clock64()
-  T* rowp = ext ? E + (bid - nt) * TILE * lde : A + bid * TILE * ld;
-  const int64_t ldr = ext ? lde : ld;
-  const int64_t jmax = ext ? nt : bid;
-  Acc8<T> accD;  // matrix rows: running diagonal tile A(k,k) - sum_j L(k,j) L(k,j)'
-  if (!ext) acc8_foreach<T>(accD, [&](int r, int c, T& val) { val = A[(bid * TILE + r) * ld + bid * TILE + c]; });
-  for (int64_t j = 0; j < jmax; ++j) {
-    const int64_t j0 = j * TILE;
-    Acc8<T> acc;
-    acc8_foreach<T>(acc, [&](int r, int c, T& val) { val = rowp[r * ldr + j0 + c]; });
-    if (j > 0) {
-      if (!flow_wait(rowdone + j, abortf, &wait_ok)) return;
-      FLOW_TR(j, 0);
-      // software-pipelined products: the tiles of term jp+2 are in flight while term jp is multiplied (two LDS pairs)
-      const bool ride = !ext && j == jmax - 1;  // the diagonal sum rides along on the last column
-      TileRegs<T, CHOL_THREADS> ra0, rb0, ra1, rb1;
-      ra0.fetch(rowp, ldr);
-      rb0.fetch(A + j0 * ld, ld);
-      if (j > 1) {
-        ra1.fetch(rowp + TILE, ldr);
-        rb1.fetch(A + j0 * ld + TILE, ld);
-      }
-      for (int64_t jp = 0; jp < j; jp += 2) {
-        ra0.commit(bufA);
-        rb0.commit(bufB);
-        if (jp + 2 < j) {
-          ra0.fetch(rowp + (jp + 2) * TILE, ldr);
-          rb0.fetch(A + j0 * ld + (jp + 2) * TILE, ld);
-        }
-        __syncthreads();
-        mma8_sub<T>(bufA, bufB, acc);
-        if (ride) mma8_sub<T>(bufA, bufA, accD);
-        if (jp + 1 < j) {
-          ra1.commit(bufT);
-          rb1.commit(bufX);
-          if (jp + 3 < j) {
-            ra1.fetch(rowp + (jp + 3) * TILE, ldr);
-            rb1.fetch(A + j0 * ld + (jp + 3) * TILE, ld);
-          }
-          __syncthreads();
-          mma8_sub<T>(bufT, bufX, acc);
-          if (ride) mma8_sub<T>(bufT, bufT, accD);
-        }
-      }
-      __syncthreads();
-    }
-    acc8_foreach<T>(acc, [&](int r, int c, T& val) { bufT[r * LDP + c] = val; });
-    FLOW_TR(j, 1);
-    if (!flow_wait(xready + j, abortf, &wait_ok)) return;
-    FLOW_TR(j, 2);
-    load_tile_lds<T, CHOL_THREADS>(X + j0 * ldx + j0, ldx, bufX);
-    __syncthreads();
-    Acc8<T> out;
-    out.zero();
-    mma8<T>(bufT, bufX, out);
-    acc8_foreach<T>(out, [&](int r, int c, T& val) { rowp[r * ldr + j0 + c] = val; });
-    if (!ext && j == jmax - 1) {  // L(k, k-1) straight from registers into the last term of the diagonal sum
-      __syncthreads();
-      acc8_foreach<T>(out, [&](int r, int c, T& val) { bufA[r * LDP + c] = val; });
-      __syncthreads();
-      mma8_sub<T>(bufA, bufA, accD);
-    }
-    __syncthreads();
-    FLOW_TR(j, 3);
-  }
-  if (ext) return;
-  flow_signal(rowdone + bid);  // this row's off-diagonal tiles are final
-  FLOW_TR(nt, 0);
-  acc8_foreach<T>(accD, [&](int r, int c, T& val) { bufA[r * LDP + c] = val; });
-  __syncthreads();
-  factor_diag_tile_2lvl<T>(bufA, bufB, sc, piv, info, bid * TILE, nvalid);
-  for (int e = tid; e < TILE * TILE; e += CHOL_THREADS) {
-    int R = e >> 6, Cc = e & 63;
-    Dg[bid * TILE * TILE + e] = bufA[R * LDP + Cc];
-    X[(bid * TILE + R) * ldx + bid * TILE + Cc] = bufB[R * LDP + Cc];
-  }
-  FLOW_TR(nt, 1);
-  flow_signal(xready + bid);
-  FLOW_TR(nt, 2);
-#undef FLOW_TR
-}
-
 // ---------------------------------------------------------------------------------------------------
 // k_chol_dag: the augmented factorisation as ONE launch of a tile task graph -- one 512-thread workgroup per 64x64 tile
 // (r, c), c <= r (matrix rows, then the extension row blocks), numbered column-major so that every dependency points to a
@@ -791,7 +587,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_flow(T* A, int64_t ld, T*
 // stores (sc1: write-through to the memory side), waits for their acknowledgement (s_waitcnt), barrier, then stores the flag;
 // consumers poll the flag with agent-scope loads and read the tile with agent-scope (sc1) loads.  Measured
 // (tools/ubench/hop.hip): 1.6 us per hop (0.4 publish + 0.4 flag + 0.8 fetch of 32 KB), independent of how much dirty data
-// the other workgroups keep in the L2s; the release / acquire fences of k_chol_flow cost 3.8 - 10 us for the same hop.
+// the other workgroups keep in the L2s; release / acquire fences (an earlier row-per-workgroup version) cost 3.8 - 10 us for the same hop.
 // Flags hold the launch's epoch (never reset); a bounded spin turns a lost dependency into info = -1 instead of a hang.
 // flags: int32 [(nt + ne) * nt] tile-ready | [nt] x-ready | [1] abort, each on its own 256-byte line (stride DAG_FS)
 // ---------------------------------------------------------------------------------------------------

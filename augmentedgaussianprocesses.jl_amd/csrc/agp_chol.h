@@ -587,9 +587,16 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(CholBatch<T> bt, int
 // stores (sc1: write-through to the memory side), waits for their acknowledgement (s_waitcnt), barrier, then stores the flag;
 // consumers poll the flag with agent-scope loads and read the tile with agent-scope (sc1) loads.  Measured
 // (tools/ubench/hop.hip): 1.6 us per hop (0.4 publish + 0.4 flag + 0.8 fetch of 32 KB), independent of how much dirty data
-// the other workgroups keep in the L2s; release / acquire fences (an earlier row-per-workgroup version) cost 3.8 - 10 us for the same hop.
+// the other workgroups keep in the L2s; release / acquire fences (an earlier row-per-workgroup version)
+// cost 3.8 - 10 us for the same hop.
+// FUSED (the version in use): workgroup 0 is the CHAIN -- it carries the critical path through all columns
+//     factor(k) -> L(k+1,k) = T X_k' -> S = D - L L' -> factor(k+1)
+// so that no hop is left on it; T = tile (k+1,k) and D = tile (k+1,k+1) are parked with all their other updates applied by
+// two feeder workgroups (the tile workgroups of those two positions) and prefetched into LDS by the chain's idle waves while
+// the elimination of column k is still running (ChainPrefetch, a hook called once per elimination round).
 // Flags hold the launch's epoch (never reset); a bounded spin turns a lost dependency into info = -1 instead of a hang.
-// flags: int32 [(nt + ne) * nt] tile-ready | [nt] x-ready | [1] abort, each on its own 256-byte line (stride DAG_FS)
+// flags: int32 [(nt + ne + nx) * nt] tile-ready | [nt] x-ready | [nt] T parked | [nt] D parked | [1] abort, each on its own
+// 256-byte line (stride DAG_FS)
 // ---------------------------------------------------------------------------------------------------
 constexpr long DAG_SPIN_LIMIT = 1L << 24;  // ~10 s of polling
 // workgroup index of diagonal tile `col`: column c holds nt - c matrix tiles, ne extension tiles and, with the inverse

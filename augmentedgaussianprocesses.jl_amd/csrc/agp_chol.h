@@ -31,6 +31,21 @@ __device__ __forceinline__ double rcp1(double p) {
   double r = __builtin_amdgcn_rcp(p);
   return fma(r, fma(-p, r, 1.0), r);
 }
+// 1 / sqrt(p), p > 0: hardware estimate + two Newton steps (the IEEE sqrt-then-divide sequence is ~3x longer and sits on the
+// critical path at the end of every 32x32 elimination); result within 1-2 ulp
+__device__ __forceinline__ double rsqrt1(double p) {
+  double y = __builtin_amdgcn_rsq(p);
+  const double h = 0.5 * p;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
+}
+__device__ __forceinline__ float rsqrt1(float p) {
+  float y = __builtin_amdgcn_rsqf(p);
+  const float h = 0.5f * p;
+  y = y * fmaf(-h * y, y, 1.5f);
+  return y;
+}
 __device__ __forceinline__ float rcp1(float p) {
   float r = __builtin_amdgcn_rcpf(p);
   return fmaf(r, fmaf(-p, r, 1.0f), r);
@@ -300,8 +315,8 @@ __device__ __forceinline__ void factor_diag_tile512(T* bufA, T* bufB, T* sc, T* 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       T pc = piv[tj + 16 * q], pr = piv[ti + 16 * q];
-      rsC[q] = T(1) / sqrt(pc > T(0) ? pc : T(1));
-      rsR[q] = T(1) / sqrt(pr > T(0) ? pr : T(1));
+      rsC[q] = rsqrt1(pc > T(0) ? pc : T(1));
+      rsR[q] = rsqrt1(pr > T(0) ? pr : T(1));
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -360,8 +375,8 @@ __device__ __forceinline__ void elim_block32(T* bufA, T* bufB, int o, T* sc, T* 
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       T pc = piv[o + tj + 16 * q], pr = piv[o + ti + 16 * q];
-      rsC[q] = T(1) / sqrt(pc > T(0) ? pc : T(1));
-      rsR[q] = T(1) / sqrt(pr > T(0) ? pr : T(1));
+      rsC[q] = rsqrt1(pc > T(0) ? pc : T(1));
+      rsR[q] = rsqrt1(pr > T(0) ? pr : T(1));
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r)

@@ -842,12 +842,26 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* 
       if (tid == 0) pf_ok = 0;
       factor_diag_tile_2lvl<T, ChainPrefetch<T>>(bufA, bufB, sc, piv, info, k0, nvalid, pf);
       DAG_TRC(k, 2);
-      for (int e = tid; e < TILE * TILE; e += CHOL_THREADS) {
-        const int r = e >> 6, cc = e & 63;
-        __hip_atomic_store(X + (k0 + r) * ldx + k0 + cc, bufB[r * LDP + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (k + 1 == nt) Dg[k * TILE * TILE + e] = bufA[r * LDP + cc];  // otherwise during the next factorisation
+      {  // X_k out (coherent): all LDS reads first, then the stores back to back (a read-store-read-store loop exposed the
+         // LDS latency eight times: 0.6 us on the chain)
+        T xv[TILE * TILE / CHOL_THREADS];
+        T* gx = X + k0 * ldx + k0;
+        const int ldx_i = (int)ldx;
+        int tl = tid;
+        asm volatile("" : "+v"(tl));  // keeps these addresses out of the registers that live through the factorisation
+#pragma unroll
+        for (int q = 0; q < TILE * TILE / CHOL_THREADS; ++q) {
+          const int e = tl + q * CHOL_THREADS;
+          xv[q] = bufB[(e >> 6) * LDP + (e & 63)];
+        }
+#pragma unroll
+        for (int q = 0; q < TILE * TILE / CHOL_THREADS; ++q) {
+          const int e = tl + q * CHOL_THREADS;
+          __hip_atomic_store(gx + ((e >> 6) * ldx_i + (e & 63)), xv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       if (k + 1 == nt) {
+        for (int e = tid; e < TILE * TILE; e += CHOL_THREADS) Dg[k * TILE * TILE + e] = bufA[(e >> 6) * LDP + (e & 63)];
         dag_signal(xready + k * DAG_FS, epoch);
         DAG_TRC(k, 3);
         return;

@@ -132,6 +132,26 @@ def test_task_graph_cholesky_repeated(env):
         assert abs(ld.value - np.linalg.slogdet(A)[1]) < 1e-8 * abs(ld.value)
 
 
+def test_training_is_bitwise_reproducible(env):
+    """Every reduction in the library has a fixed order, so the same run twice must agree BITWISE; with the fence-free tile
+    hand-over of the task-graph Cholesky this doubles as a race detector (tools/soak_determinism.py runs 2 x 20000 steps)."""
+    AGP = env["AGP"]
+    rng = np.random.default_rng(3)
+    N, D, m, B, iters = 4000, 8, 256, 256, 150
+    X = rng.random((N, D))
+    y = np.sign(np.sin(X @ rng.standard_normal(D)) + 0.1 * rng.standard_normal(N))
+    Z = X[rng.permutation(N)[:m]].copy()
+    idx = [rng.choice(N, B, replace=False) for _ in range(iters)]
+    res = []
+    for _ in range(2):
+        model = AGP.SVGP(AGP.with_lengthscale(AGP.SqExponentialKernel(), 0.7), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z,
+                         optimiser=False)
+        AGP.train_(model, X, y, iters, idx_stream=idx)
+        res.append(model.get_state(0))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+
+
 def test_potrf_not_posdef(env):
     torch, L, ctx, capi = env["torch"], env["L"], env["ctx"], env["capi"]
     n = 130

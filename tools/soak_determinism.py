@@ -1,0 +1,35 @@
+"""Soak / determinism check of the one-launch task-graph Cholesky: the same C2-shaped run twice (same index stream), `steps`
+CAVI steps each, final natural parameters compared BITWISE.  Every reduction in the library has a fixed order, so any difference
+would mean a tile was read before it was complete (the hand-over uses coherent stores / loads and flags instead of fences)."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import agp_amd as AGP
+from agp_amd import capi
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+m = B = 1024
+D, N = 32, 200000
+rng = np.random.default_rng(0)
+X = rng.random((N, D))
+y = np.sign(np.sin(X @ rng.standard_normal(D)) + 0.1 * rng.standard_normal(N))
+Z = X[rng.permutation(N)[:m]].copy()
+idx = np.stack([rng.choice(N, B, replace=False) for _ in range(256)])
+out = []
+for rep in range(2):
+    model = AGP.SVGP(AGP.with_lengthscale(AGP.SqExponentialKernel(), np.sqrt(D) / 4), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z, optimiser=False)
+    AGP.train_(model, X, y, 1, idx_stream=idx[:1])
+    L, h = capi.lib(), model._h
+    Xd, yd, _ = model._data
+    ia = torch.as_tensor(idx, device="cuda")
+    for i in range(steps):
+        j = i % 256
+        assert L.agp_svgp_cavi_step(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(yd.data_ptr()), C.c_void_p(ia[j].data_ptr()), B, N / B) == 0
+        L.agp_svgp_prefetch(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(ia[(j + 1) % 256].data_ptr()), B)
+    model._chk(L.agp_svgp_check_status(h))
+    mu, Sig, e1, e2 = model.get_state(0)
+    out.append((e1.copy(), e2.copy(), mu.copy()))
+    print(f"run {rep}: {steps} steps, |eta1| = {np.linalg.norm(e1):.6e}, finite = {np.isfinite(e2).all()}")
+same = all(np.array_equal(a, b) for a, b in zip(out[0], out[1]))
+print("bitwise identical:", same, " max |d eta2| =", np.max(np.abs(out[0][1] - out[1][1])))
+sys.exit(0 if same else 1)

@@ -1602,7 +1602,6 @@ struct Svgp : SvgpBase {
   agp_status step_stats(bool fused) override {
     AGPCHK(lsm_finish());
     const int64_t Bq = rup64(B_last);
-    const int64_t nt = mp / TILE;
     const T lr = (T)cur_lr();
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
@@ -1725,7 +1724,6 @@ struct Svgp : SvgpBase {
   agp_status elbo(const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B, double rho, int fresh,
                   double* out) override {
     AGPCHK(check_batch(B));
-    const int ns = (int)(2 * mp / TILE);
     const bool lsm = lp.kind == AGP_LIK_LOGISTICSOFTMAX;
     const T* mf;
     const T* vf;

@@ -955,8 +955,11 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* 
       __hip_atomic_store(rowp + r * ldr + c0 + cc, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     });
     dag_signal((f1 ? pre1 + (c + 1) * DAG_FS : pre2 + c * DAG_FS), epoch);
-    if (f2) DAG_TR(6);
-    else DAG_TR(3);
+    if (f2) {
+      DAG_TR(6);
+    } else {
+      DAG_TR(3);
+    }
     return;
   }
   acc8_foreach<T>(acc, [&](int r, int cc, T& val) { bufA[r * LDP + cc] = val; });

@@ -82,6 +82,8 @@ def main():
     share = os.environ.get("AGP_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
+        # several processes on one device: their one-launch task-graph factorisations must not overlap
+        os.environ.setdefault("AGP_CHOL_DAG", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None

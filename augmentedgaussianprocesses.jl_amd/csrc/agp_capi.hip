@@ -153,12 +153,17 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       const char* e = getenv("AGP_CHOL_DAG_FUSED");
       return !(e && e[0] == '0');
     }();
+    CholBatch<T> one{};
+    one.A[0] = A;
+    one.X[0] = X;
+    one.Dg[0] = Dg;
+    one.E[0] = E;
     if (fused)
-      hipLaunchKernelGGL((k_chol_dag<T, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, A, ld, X, ldx, Dg, E,
-                         lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, XS, nx, erow);
+      hipLaunchKernelGGL((k_chol_dag<T, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0, ld,
+                         ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, XS, nx, erow);
     else
-      hipLaunchKernelGGL((k_chol_dag<T, false>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, A, ld, X, ldx, Dg, E,
-                         lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, XS, nx, erow);
+      hipLaunchKernelGGL((k_chol_dag<T, false>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0, ld,
+                         ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, XS, nx, erow);
     LAUNCHCHK(c);
     if (trace) {
       std::vector<unsigned long long> h((size_t)ntiles * 8);
@@ -191,6 +196,32 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
   }
   LAUNCHCHK(c);
   if (do_x) AGPCHK(trtri_levels<T>(c, (const T*)A, ld, X, ldx, nt));
+  return AGP_OK;
+}
+
+// nb <= DAG_MAX_NB independent problems of identical shape as ONE interleaved task-graph launch (see k_chol_dag): their chains
+// run side by side on nb CUs.  The bound keeps every chain's next feeder tile among the workgroups an XCD can hold.
+constexpr int DAG_MAX_NB = 6;
+template <typename T>
+static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, int64_t ld, int64_t n, int64_t ldx, int64_t lde,
+                                  int64_t ne, int32_t* info_dev, int64_t nvalid) {
+  const int64_t nt = n / TILE;
+  const int64_t fstride = ((nt + ne) * nt + 3 * nt + 1) * DAG_FS, nf = fstride * nb;
+  if (c->dag_cap < nf) {
+    if (c->dag_flags) (void)hipFree(c->dag_flags);
+    c->dag_flags = nullptr;
+    c->dag_cap = 0;
+    if (hipMalloc((void**)&c->dag_flags, sizeof(int32_t) * (size_t)(nf + 1024)) != hipSuccess) return AGP_ERR_NOMEM;
+    c->dag_cap = nf + 1024;
+    HIPCHK(c, hipMemsetAsync(c->dag_flags, 0, sizeof(int32_t) * (size_t)c->dag_cap, c->stream));
+    c->dag_epoch = 0;
+  }
+  c->dag_epoch += 1;
+  const int64_t ntiles = nt * (nt + 1) / 2 + ne * nt;
+  hipLaunchKernelGGL((k_chol_dag<T, true, true>), dim3((unsigned)(ntiles * nb)), dim3(CHOL_THREADS), 0, c->stream, bt, nb, fstride, ld,
+                     ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, (unsigned long long*)nullptr, (T*)nullptr,
+                     (int64_t)0, (const T*)nullptr);
+  LAUNCHCHK(c);
   return AGP_OK;
 }
 
@@ -1014,10 +1045,13 @@ struct Svgp : SvgpBase {
         if (nb == 1)  // a single problem may take the one-launch task-graph path
           AGPCHK(potrf_fused<T>(ctx, bt.A[0], mp, mp, bt.X[0], mp, bt.Dg[0], bt.E[0], mp, Bq / TILE + 1, 0, info_dev, m,
                                 (const T*)lat[todo[l0]].eta1));
+        else if (nb <= DAG_MAX_NB && chol_use_dag(mp / TILE))
+          AGPCHK(potrf_dag_batch<T>(ctx, bt, nb, mp, mp, mp, mp, Bq / TILE + 1, info_dev, m));
         else
           AGPCHK(potrf_fused_batch<T>(ctx, bt, nb, mp, mp, mp, mp, Bq / TILE + 1, info_dev, m));
       }
-      if (!todo.empty()) AGPCHK(timing_end(todo.size() == 1 && chol_use_dag(mp / TILE) ? 1 : mp / TILE));
+      if (!todo.empty())
+        AGPCHK(timing_end((int)todo.size() <= DAG_MAX_NB && chol_use_dag(mp / TILE) ? 1 : mp / TILE));
     }
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];

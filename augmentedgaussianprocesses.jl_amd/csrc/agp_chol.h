@@ -770,12 +770,24 @@ struct ChainPrefetch {
   }
 };
 
-template <typename T, bool FUSED>
-__global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* X, int64_t ldx, T* __restrict__ Dg, T* E,
+template <typename T, bool FUSED, bool BATCH = false>
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ldx,
                                                            int64_t lde, int64_t ne, int64_t nt,
                                                            int32_t* __restrict__ info, int64_t nvalid, int32_t* flags,
                                                            int32_t epoch, unsigned long long* trace, T* XS, int64_t nx,
                                                            const T* __restrict__ erow) {
+  // nb > 1: nb independent problems of the same shape (the latents of a small multi-class model) in ONE launch, their
+  // workgroups interleaved (linear index = tile * nb + problem) so that the chains of all problems start at once and the
+  // per-XCD dispatch order stays a topological order of every graph.  Each problem has its own flags (fstride apart).  Safe
+  // while the unretired workgroups below a chain's next feeder fit into an XCD's share of the slots: nb <= 6.
+  // (BATCH is a template parameter so that the single-problem instantiation keeps constant kernel-argument offsets)
+  const int prob = BATCH ? (int)(blockIdx.x % (unsigned)nb) : 0;
+  const int64_t bidx = BATCH ? (int64_t)(blockIdx.x / (unsigned)nb) : (int64_t)blockIdx.x;
+  T* A = bt.A[prob];
+  T* X = bt.X[prob];
+  T* __restrict__ Dg = bt.Dg[prob];
+  T* E = bt.E[prob];
+  flags += prob * fstride;
   // erow (optional): row 0 of the LAST extension block is taken from this vector and its rows 1-63 as zero, instead of being
   // read from E (the CAVI step appends [eta1' ; 0]: saves the launch that used to write them)
   // nx = nt: also X = L^-1 in full.  L^-T = I L^-T, so nt more extension block rows holding the identity give X' column by
@@ -789,7 +801,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* 
   T* bufB = sm + TILE * LDP;
   const int tid = threadIdx.x;
   // column-major tile numbering: column c holds its diagonal tile, rows c+1..nt-1, then the ne extension blocks
-  int64_t b = blockIdx.x, c = 0;
+  int64_t b = bidx, c = 0;
   while (b >= nt - c + ne + (nx ? c + 1 : 0)) {
     b -= nt - c + ne + (nx ? c + 1 : 0);
     ++c;
@@ -804,7 +816,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* 
   int32_t* pre2 = pre1 + nt * DAG_FS;    // FUSED: diagonal tile (c, c) with the updates of columns < c-1 parked in place
   int32_t* abortf = pre2 + nt * DAG_FS;
 #define DAG_TR(slot) \
-  if (trace && tid == 0) trace[blockIdx.x * 8 + (slot)] = wall_clock64()
+  if (trace && tid == 0) trace[bidx * 8 + (slot)] = wall_clock64()
 #define DAG_TRC(col, slot) \
   if (trace && tid == 0) trace[chain_slot(col, nt, ne, nx) * 8 + (slot)] = wall_clock64()
   DAG_TR(0);
@@ -817,7 +829,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(T* A, int64_t ld, T* 
   } else {
     acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = rowp[r * ldr + c0 + cc]; });
   }
-  if (FUSED && blockIdx.x == 0) {
+  if (FUSED && bidx == 0) {
     // ---- the chain: ONE workgroup carries the critical path through all columns, so that per column only the tile
     // factorisation and two 64^3 products are serial:  factor(c) -> L(c+1,c) = T X_c' -> S = D - L L' -> factor(c+1).
     // T = tile (c+1, c) and D = tile (c+1, c+1) arrive with all their other updates already applied by feeder workgroups.

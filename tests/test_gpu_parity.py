@@ -132,6 +132,26 @@ def test_task_graph_cholesky_repeated(env):
         assert abs(ld.value - np.linalg.slogdet(A)[1]) < 1e-8 * abs(ld.value)
 
 
+@pytest.mark.parametrize("likname", ["logisticsoftmax", "heteroscedastic"])
+def test_multi_latent_task_graph_matches_oracle(env, likname):
+    """Several latents (3-class LogisticSoftMax, the two heteroscedastic latents) with m = 150 inducing points: three block
+    columns, so their factorisations run as ONE interleaved task-graph launch with dependencies between tiles (the toy models
+    of the other tests have a single block column)."""
+    AGP, R = env["AGP"], env["R"]
+    rng = np.random.default_rng(17)
+    B, iters = 100, 5
+    X, y, ma, mr = _models(env, likname, rng, True, B, m=150, N=500)
+    idx = [rng.choice(len(X), B, replace=False) for _ in range(iters)]
+    AGP.train_(ma, X, y, iters, idx_stream=idx)
+    mr.train(X, y, iters, idx_stream=idx)
+    assert ma.n_latent >= 2
+    for k in range(ma.n_latent):
+        mu, Sig, e1, e2 = ma.get_state(k)
+        g = mr.latents[k]
+        assert _rel(e1, g.eta1) < 1e-8 and _rel(e2, g.eta2) < 1e-8
+        assert _rel(mu, g.mu) < 1e-7 and _rel(np.diag(Sig), np.diag(g.Sigma)) < 1e-7
+
+
 def test_training_is_bitwise_reproducible(env):
     """Every reduction in the library has a fixed order, so the same run twice must agree BITWISE; with the fence-free tile
     hand-over of the task-graph Cholesky this doubles as a race detector (tools/soak_determinism.py runs 2 x 20000 steps)."""

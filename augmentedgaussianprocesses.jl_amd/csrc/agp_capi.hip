@@ -108,12 +108,16 @@ static agp_status trtri_levels(agp_ctx* c, const T* A, int64_t ld, T* X, int64_t
 // m = 1024 f64 0.39 vs 0.52 ms, m = 2048 f32 0.80 vs 1.05 ms, m = 4096 f64 11.6 vs 8.3 ms -- the task graph removes launch
 // gaps and re-reads from the latency-bound chain, but its tiles stream their operands past the L2s (coherent loads), which
 // costs more than it saves once the trailing updates dominate.  AGP_CHOL_DAG=0 / 1 forces one or the other.
-constexpr int64_t DAG_MAX_NT = 32;
-static bool chol_use_dag(int64_t nt) {
+// Residency bound (never overridden): the chain of a task graph waits for feeder tiles with HIGHER workgroup indices; they are
+// guaranteed to be resident only while the unretired workgroups before them -- one block column of every problem, nb * (nt + ne
+// [+ 1 with the inverse rows]) tiles, an eighth of them per XCD -- fit into an XCD's 32 workgroup slots with room to spare.
+constexpr int64_t DAG_MAX_NT = 32, DAG_MAX_COLUMN_TILES = 208;
+static bool chol_use_dag(int64_t nt, int64_t ne = 0, int64_t nb = 1) {
   static const int v = []() {
     const char* e = getenv("AGP_CHOL_DAG");
     return e ? (e[0] == '0' ? 0 : 1) : -1;
   }();
+  if (nb * (nt + ne + 1) > DAG_MAX_COLUMN_TILES) return false;
   return v < 0 ? nt <= DAG_MAX_NT : v == 1;
 }
 
@@ -123,7 +127,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
   // erow: the last extension block is [erow' ; 0] (not yet written to E: the task graph reads it in place; the per-column
   // path needs it in E first)
   const int64_t nt = n / TILE;
-  const bool use_dag = chol_use_dag(nt);
+  const bool use_dag = chol_use_dag(nt, ne);
   if (use_dag && X) {
     const int64_t nx = (do_x && nt > 1) ? nt : 0;  // the full inverse rides along as nt identity block rows
     const int64_t nf = ((nt + ne + nx) * nt + 3 * nt + 1) * DAG_FS;
@@ -1045,13 +1049,15 @@ struct Svgp : SvgpBase {
         if (nb == 1)  // a single problem may take the one-launch task-graph path
           AGPCHK(potrf_fused<T>(ctx, bt.A[0], mp, mp, bt.X[0], mp, bt.Dg[0], bt.E[0], mp, Bq / TILE + 1, 0, info_dev, m,
                                 (const T*)lat[todo[l0]].eta1));
-        else if (nb <= DAG_MAX_NB && chol_use_dag(mp / TILE))
+        else if (nb <= DAG_MAX_NB && chol_use_dag(mp / TILE, Bq / TILE + 1, nb))
           AGPCHK(potrf_dag_batch<T>(ctx, bt, nb, mp, mp, mp, mp, Bq / TILE + 1, info_dev, m));
         else
           AGPCHK(potrf_fused_batch<T>(ctx, bt, nb, mp, mp, mp, mp, Bq / TILE + 1, info_dev, m));
       }
       if (!todo.empty())
-        AGPCHK(timing_end((int)todo.size() <= DAG_MAX_NB && chol_use_dag(mp / TILE) ? 1 : mp / TILE));
+        AGPCHK(timing_end((int)todo.size() <= DAG_MAX_NB && chol_use_dag(mp / TILE, Bq / TILE + 1, (int64_t)todo.size())
+                              ? 1
+                              : mp / TILE));
     }
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
@@ -1675,7 +1681,7 @@ struct Svgp : SvgpBase {
     AGPCHK(timing_begin());
     AGPCHK(potrf_fused<T>(ctx, g.La, mp, mp, g.Xa, mp, g.DgA, g.Wbuf, mp, Bq / TILE + 1, with_x, info_dev, m,
                           (const T*)g.eta1));
-    AGPCHK(timing_end(chol_use_dag(mp / TILE) ? 1 : mp / TILE));
+    AGPCHK(timing_end(chol_use_dag(mp / TILE, Bq / TILE + 1) ? 1 : mp / TILE));
     g.la_state = 1;
     g.xa_valid = with_x != 0;
     return AGP_OK;

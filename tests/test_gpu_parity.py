@@ -152,6 +152,21 @@ def test_multi_latent_task_graph_matches_oracle(env, likname):
         assert _rel(mu, g.mu) < 1e-7 and _rel(np.diag(Sig), np.diag(g.Sigma)) < 1e-7
 
 
+@pytest.mark.parametrize("B", [12800, 16000])
+def test_large_minibatch_either_cholesky_driver(env, B):
+    """m = 64 with a very large minibatch: B = 12800 still runs the task-graph Cholesky (203 tiles in its single block column),
+    B = 16000 exceeds the residency bound and takes the per-column launches; both against the oracle."""
+    AGP, R = env["AGP"], env["R"]
+    rng = np.random.default_rng(5)
+    X, y, ma, mr = _models(env, "logistic", rng, True, B, m=64, N=20000)
+    idx = [rng.choice(len(X), B, replace=False) for _ in range(2)]
+    AGP.train_(ma, X, y, 2, idx_stream=idx)
+    mr.train(X, y, 2, idx_stream=idx)
+    mu, Sig, e1, e2 = ma.get_state(0)
+    g = mr.latents[0]
+    assert _rel(e1, g.eta1) < 1e-8 and _rel(e2, g.eta2) < 1e-8 and _rel(mu, g.mu) < 1e-7
+
+
 def test_training_is_bitwise_reproducible(env):
     """Every reduction in the library has a fixed order, so the same run twice must agree BITWISE; with the fence-free tile
     hand-over of the task-graph Cholesky this doubles as a race detector (tools/soak_determinism.py runs 2 x 20000 steps)."""

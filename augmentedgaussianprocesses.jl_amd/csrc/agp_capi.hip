@@ -1034,8 +1034,20 @@ struct Svgp : SvgpBase {
       for (int l = 0; l < nl; ++l)
         if (!lat[l].via_inverse) todo.push_back(l);
       if (!todo.empty()) AGPCHK(timing_begin());
-      for (size_t l0 = 0; l0 < todo.size(); l0 += CHOL_MAXB) {
-        const int nb = (int)std::min<size_t>(CHOL_MAXB, todo.size() - l0);
+      // chunking: task graphs take as many problems per launch as the residency bound allows (balanced chunks, e.g. 8 latents
+      // as 4 + 4); if not even one fits, all of them share per-column launches
+      const int64_t ntl = mp / TILE, nel = Bq / TILE + 1;
+      int dag_nb = 0;
+      for (int q = DAG_MAX_NB; q >= 1 && !dag_nb; --q)
+        if (chol_use_dag(ntl, nel, q)) dag_nb = q;
+      size_t chunk = CHOL_MAXB;
+      if (dag_nb > 0 && !todo.empty()) {
+        const size_t nchunks = (todo.size() + dag_nb - 1) / dag_nb;
+        chunk = (todo.size() + nchunks - 1) / nchunks;
+      }
+      int64_t launches = 0;
+      for (size_t l0 = 0; l0 < todo.size(); l0 += chunk) {
+        const int nb = (int)std::min<size_t>(chunk, todo.size() - l0);
         CholBatch<T> bt{};
         for (int q = 0; q < nb; ++q) {
           Latent& g = lat[todo[l0 + q]];
@@ -1046,18 +1058,19 @@ struct Svgp : SvgpBase {
           g.la_state = 1;
           g.xa_valid = false;
         }
-        if (nb == 1)  // a single problem may take the one-launch task-graph path
-          AGPCHK(potrf_fused<T>(ctx, bt.A[0], mp, mp, bt.X[0], mp, bt.Dg[0], bt.E[0], mp, Bq / TILE + 1, 0, info_dev, m,
+        if (nb == 1) {  // also writes the [eta1' ; 0] block when it falls back to per-column launches
+          AGPCHK(potrf_fused<T>(ctx, bt.A[0], mp, mp, bt.X[0], mp, bt.Dg[0], bt.E[0], mp, nel, 0, info_dev, m,
                                 (const T*)lat[todo[l0]].eta1));
-        else if (nb <= DAG_MAX_NB && chol_use_dag(mp / TILE, Bq / TILE + 1, nb))
-          AGPCHK(potrf_dag_batch<T>(ctx, bt, nb, mp, mp, mp, mp, Bq / TILE + 1, info_dev, m));
-        else
-          AGPCHK(potrf_fused_batch<T>(ctx, bt, nb, mp, mp, mp, mp, Bq / TILE + 1, info_dev, m));
+          launches += dag_nb > 0 ? 1 : ntl;
+        } else if (dag_nb > 0) {
+          AGPCHK(potrf_dag_batch<T>(ctx, bt, nb, mp, mp, mp, mp, nel, info_dev, m));
+          launches += 1;
+        } else {
+          AGPCHK(potrf_fused_batch<T>(ctx, bt, nb, mp, mp, mp, mp, nel, info_dev, m));
+          launches += ntl;
+        }
       }
-      if (!todo.empty())
-        AGPCHK(timing_end((int)todo.size() <= DAG_MAX_NB && chol_use_dag(mp / TILE, Bq / TILE + 1, (int64_t)todo.size())
-                              ? 1
-                              : mp / TILE));
+      if (!todo.empty()) AGPCHK(timing_end(launches));
     }
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];

@@ -686,7 +686,10 @@ __device__ __forceinline__ bool dag_wait(const int32_t* f0, const int32_t* f1, i
 
 // every thread's coherent stores acknowledged -> barrier -> flag
 __device__ __forceinline__ void dag_signal(int32_t* flag, int32_t epoch) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt vmcnt(0): no L2 write-back
+  // agent-scope release: s_waitcnt alone (acknowledgement by the L2) proved NOT enough -- with several task graphs in flight
+  // a consumer occasionally (about once in 10^4 launches) saw the flag before a write-through store had reached the memory side
+  // and read the tile's previous content (tools/soak_multilatent.py: runs no longer bitwise reproducible)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

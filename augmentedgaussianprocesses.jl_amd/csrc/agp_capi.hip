@@ -25,6 +25,14 @@ struct agp_ctx {
   int32_t* dag_flags = nullptr;   // tile / x-ready / abort flags of the task-graph factorisation (k_chol_dag), epoch-stamped
   int64_t dag_cap = 0;
   int32_t dag_epoch = 0;
+  // sentinel-filled hand-over areas of the task graph: two sets used alternately; the set a launch used is refilled on a side
+  // stream right behind it and is ready again for the launch after next
+  void* hset[2] = {nullptr, nullptr};
+  size_t hbytes = 0;
+  int htype = -1;  // sizeof(T) the sets were filled for
+  hipStream_t hfill = nullptr;
+  hipEvent_t h_used = nullptr, h_done[2] = {nullptr, nullptr};
+  bool h_pending[2] = {false, false};
   void* tri_scratch = nullptr;    // n x n scratch of the recursive-doubling triangular inverse
   size_t tri_bytes = 0;
 };
@@ -104,6 +112,50 @@ static agp_status trtri_levels(agp_ctx* c, const T* A, int64_t ld, T* X, int64_t
   return AGP_OK;
 }
 
+// hand-over area for the next task-graph launch (`elems` elements of T): waits for the pending refill of the set, returns it;
+// dag_handover_release() schedules the refill behind the launch
+template <typename T>
+static agp_status dag_handover_acquire(agp_ctx* c, int64_t elems, int set, T** out) {
+  const size_t need = sizeof(T) * (size_t)elems;
+  if (!c->hfill) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->hfill, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->h_used, hipEventDisableTiming));
+    for (int q = 0; q < 2; ++q) HIPCHK(c, hipEventCreateWithFlags(&c->h_done[q], hipEventDisableTiming));
+  }
+  if (c->hbytes < need || c->htype != (int)sizeof(T)) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->hfill);
+    for (int q = 0; q < 2; ++q) {
+      if (c->hset[q]) (void)hipFree(c->hset[q]);
+      c->hset[q] = nullptr;
+      c->h_pending[q] = false;
+    }
+    c->hbytes = 0;
+    const size_t cap = need + need / 4;
+    for (int q = 0; q < 2; ++q) {
+      if (hipMalloc(&c->hset[q], cap) != hipSuccess) return AGP_ERR_NOMEM;
+      hipLaunchKernelGGL((k_fill_sent<T>), dim3(2048), dim3(256), 0, c->stream, (T*)c->hset[q], (int64_t)(cap / sizeof(T)));
+    }
+    c->hbytes = cap;
+    c->htype = (int)sizeof(T);
+  }
+  if (c->h_pending[set]) {
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->h_done[set], 0));
+    c->h_pending[set] = false;
+  }
+  *out = (T*)c->hset[set];
+  return AGP_OK;
+}
+template <typename T>
+static agp_status dag_handover_release(agp_ctx* c, int64_t elems, int set) {
+  HIPCHK(c, hipEventRecord(c->h_used, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->hfill, c->h_used, 0));
+  hipLaunchKernelGGL((k_fill_sent<T>), dim3(1024), dim3(256), 0, c->hfill, (T*)c->hset[set], elems);
+  HIPCHK(c, hipEventRecord(c->h_done[set], c->hfill));
+  c->h_pending[set] = true;
+  return AGP_OK;
+}
+
 // One-launch task graph (k_chol_dag) or one launch per block column (k_chol_step)?  Measured on MI355X, whole CAVI step:
 // m = 1024 f64 0.39 vs 0.52 ms, m = 2048 f32 0.80 vs 1.05 ms, m = 4096 f64 11.6 vs 8.3 ms -- the task graph removes launch
 // gaps and re-reads from the latency-bound chain, but its tiles stream their operands past the L2s (coherent loads), which
@@ -142,11 +194,10 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     }
     c->dag_epoch += 1;
     const int64_t ntiles = nt * (nt + 1) / 2 + ne * nt + (nx ? nt * (nt + 1) / 2 : 0);
-    T* XS = nullptr;
-    if (nx) {
-      AGPCHK(tri_scratch_ensure(c, sizeof(T) * (size_t)n * (size_t)n));
-      XS = (T*)c->tri_scratch;
-    }
+    const int64_t hstride = ((2 * nt + ne) * nt + 3 * nt) * TILE * TILE;
+    T* H = nullptr;
+    const int hs = c->dag_epoch & 1;
+    AGPCHK(dag_handover_acquire<T>(c, hstride, hs, &H));
     unsigned long long* trace = nullptr;
     static const char* trace_path = getenv("AGP_DAG_TRACE");  // development aid: per-tile timestamps of one launch
     if (trace_path && ne > 0) {
@@ -164,11 +215,12 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     one.E[0] = E;
     if (fused)
       hipLaunchKernelGGL((k_chol_dag<T, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0, ld,
-                         ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, XS, nx, erow);
+                         ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow);
     else
       hipLaunchKernelGGL((k_chol_dag<T, false>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0, ld,
-                         ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, XS, nx, erow);
+                         ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow);
     LAUNCHCHK(c);
+    AGPCHK(dag_handover_release<T>(c, hstride, hs));
     if (trace) {
       std::vector<unsigned long long> h((size_t)ntiles * 8);
       (void)hipStreamSynchronize(c->stream);
@@ -222,10 +274,15 @@ static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, in
   }
   c->dag_epoch += 1;
   const int64_t ntiles = nt * (nt + 1) / 2 + ne * nt;
+  const int64_t hstride = ((2 * nt + ne) * nt + 3 * nt) * TILE * TILE;
+  T* H = nullptr;
+  const int hs = c->dag_epoch & 1;
+  AGPCHK(dag_handover_acquire<T>(c, hstride * nb, hs, &H));
   hipLaunchKernelGGL((k_chol_dag<T, true, true>), dim3((unsigned)(ntiles * nb)), dim3(CHOL_THREADS), 0, c->stream, bt, nb, fstride, ld,
-                     ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, (unsigned long long*)nullptr, (T*)nullptr,
+                     ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, (unsigned long long*)nullptr, H, hstride,
                      (int64_t)0, (const T*)nullptr);
   LAUNCHCHK(c);
+  AGPCHK(dag_handover_release<T>(c, hstride * nb, hs));
   return AGP_OK;
 }
 
@@ -2277,6 +2334,14 @@ agp_status agp_ctx_destroy(agp_ctx* ctx) {
   if (ctx && (ctx->tri_scratch || ctx->dag_flags)) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->dag_flags) (void)hipFree(ctx->dag_flags);
+    if (ctx->hfill) {
+      (void)hipStreamSynchronize(ctx->hfill);
+      (void)hipStreamDestroy(ctx->hfill);
+      (void)hipEventDestroy(ctx->h_used);
+      for (int q = 0; q < 2; ++q) (void)hipEventDestroy(ctx->h_done[q]);
+    }
+    for (int q = 0; q < 2; ++q)
+      if (ctx->hset[q]) (void)hipFree(ctx->hset[q]);
     if (ctx->tri_scratch) (void)hipFree(ctx->tri_scratch);
   }
   delete ctx;

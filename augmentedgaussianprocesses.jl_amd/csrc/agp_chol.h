@@ -598,9 +598,10 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(CholBatch<T> bt, int
 //     for j < c :  wait L(r,j), L(c,j)          acc -= L(r,j) L(c,j)'
 //     r == c    :  factor the tile -> L_cc (Dg), X_c = L_cc^-1 (X) ; publish X_c
 //     r >  c    :  wait X_c ; L(r,c) = acc X_c' ; publish L(r,c)
-// Hand-over between workgroups WITHOUT cache-wide fences: the producer writes the tile with agent-scope relaxed atomic
-// stores (sc1: write-through to the memory side), waits for their acknowledgement (s_waitcnt), barrier, then stores the flag;
-// consumers poll the flag with agent-scope loads and read the tile with agent-scope (sc1) loads.  Measured
+// Hand-over between workgroups WITHOUT cache-wide fences, through a sentinel-filled hand-over area whose elements validate
+// themselves (see "self-validating hand-over" below): the producer writes the tile with agent-scope relaxed atomic stores (sc1:
+// write-through to the memory side), waits for their acknowledgement (s_waitcnt), barrier, then stores the flag; consumers poll
+// the flag with agent-scope loads and read the tile with agent-scope (sc1) loads, re-loading what is not there yet.  Measured
 // (tools/ubench/hop.hip): 1.6 us per hop (0.4 publish + 0.4 flag + 0.8 fetch of 32 KB), independent of how much dirty data
 // the other workgroups keep in the L2s; release / acquire fences (an earlier row-per-workgroup version)
 // cost 3.8 - 10 us for the same hop.
@@ -621,40 +622,71 @@ __device__ __forceinline__ int64_t chain_slot(int64_t col, int64_t nt, int64_t n
 }
 constexpr int DAG_FS = 64;  // flag stride in int32: one 256-byte line per flag, so the pollers spread over the memory channels
 
+// ---- self-validating hand-over -------------------------------------------------------------------------------------
+// Tiles travel between workgroups through a hand-over area H (one contiguous 64x64 slot per tile) that the host fills with a
+// SENTINEL bit pattern (a signalling-NaN payload no arithmetic produces) before the launch.  The producer stores the tile there
+// with coherent (sc1) 8-byte stores and then raises a flag; the flag is only a HINT that the data is on its way: the consumer
+// loads the slot with coherent loads and re-loads any element that still reads as the sentinel.  8-byte stores are single-copy
+// atomic, so an element is either the sentinel or final -- no ordering between the data stores and the flag store is needed,
+// hence no cache-wide release fence (measured: the fence costs 18 % of the step; without fence AND without validation a consumer
+// read a stale tile about once in 10^4 launches under load).
 template <typename T>
-__device__ __forceinline__ void load_tile_lds_coh(const T* G, int64_t ld, T* S) {
-  // all loads are issued before the first LDS write: the compiler keeps an atomic load ordered against a following store, so
-  // the interleaved form ran the eight loads back to back (2.5 us per tile instead of 0.8 us)
+struct Sent;
+template <>
+struct Sent<double> {
+  typedef unsigned long long U;
+  static constexpr U bits = 0x7FF4DEADBEEF1234ull;
+};
+template <>
+struct Sent<float> {
+  typedef unsigned int U;
+  static constexpr U bits = 0x7FA5F00Du;
+};
+template <typename T>
+__device__ __forceinline__ bool is_sent(T v) {
+  return __builtin_bit_cast(typename Sent<T>::U, v) == Sent<T>::bits;
+}
+// re-load while the element still holds the sentinel (bounded: a producer that never arrives ends in the abort path)
+template <typename T>
+__device__ __forceinline__ T hv_settle(const T* p, T v) {
+  long spins = 0;
+  while (is_sent(v) && ++spins < (1L << 22)) {
+    __builtin_amdgcn_s_sleep(1);
+    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return v;
+}
+
+// hand-over slot (4096 contiguous elements) -> LDS tile; all loads are issued before the first use (the compiler keeps an
+// atomic load ordered against a following store: the interleaved form ran the eight loads back to back, 2.5 us instead of 0.8)
+template <typename T>
+__device__ __forceinline__ void load_tile_lds_hv(const T* Hs, T* S) {
   constexpr int Q = TILE * TILE / CHOL_THREADS;
   T v[Q];
 #pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const int e = threadIdx.x + q * CHOL_THREADS;
-    v[q] = __hip_atomic_load(G + (int64_t)(e >> 6) * ld + (e & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  for (int q = 0; q < Q; ++q) v[q] = __hip_atomic_load(Hs + threadIdx.x + q * CHOL_THREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     const int e = threadIdx.x + q * CHOL_THREADS;
-    S[(e >> 6) * LDP + (e & 63)] = v[q];
+    S[(e >> 6) * LDP + (e & 63)] = hv_settle<T>(Hs + e, v[q]);
   }
 }
 
-// two tiles at once (both operands of a pending update): 16 loads in flight per thread
+// two slots at once (both operands of a pending update): 16 loads in flight per thread
 template <typename T>
-__device__ __forceinline__ void load_tiles_lds_coh2(const T* G0, int64_t ld0, T* S0, const T* G1, int64_t ld1, T* S1) {
+__device__ __forceinline__ void load_tiles_lds_hv2(const T* H0, T* S0, const T* H1, T* S1) {
   constexpr int Q = TILE * TILE / CHOL_THREADS;
   T v[2 * Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
-    const int e = threadIdx.x + q * CHOL_THREADS;
-    v[q] = __hip_atomic_load(G0 + (int64_t)(e >> 6) * ld0 + (e & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    v[Q + q] = __hip_atomic_load(G1 + (int64_t)(e >> 6) * ld1 + (e & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v[q] = __hip_atomic_load(H0 + threadIdx.x + q * CHOL_THREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v[Q + q] = __hip_atomic_load(H1 + threadIdx.x + q * CHOL_THREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     const int e = threadIdx.x + q * CHOL_THREADS;
-    S0[(e >> 6) * LDP + (e & 63)] = v[q];
-    S1[(e >> 6) * LDP + (e & 63)] = v[Q + q];
+    S0[(e >> 6) * LDP + (e & 63)] = hv_settle<T>(H0 + e, v[q]);
+    S1[(e >> 6) * LDP + (e & 63)] = hv_settle<T>(H1 + e, v[Q + q]);
   }
 }
 
@@ -684,12 +716,11 @@ __device__ __forceinline__ bool dag_wait(const int32_t* f0, const int32_t* f1, i
   return *lds_ok != 0;
 }
 
-// every thread's coherent stores acknowledged -> barrier -> flag
+// every thread's hand-over stores acknowledged by the L2 -> barrier -> flag
 __device__ __forceinline__ void dag_signal(int32_t* flag, int32_t epoch) {
-  // agent-scope release: s_waitcnt alone (acknowledgement by the L2) proved NOT enough -- with several task graphs in flight
-  // a consumer occasionally (about once in 10^4 launches) saw the flag before a write-through store had reached the memory side
-  // and read the tile's previous content (tools/soak_multilatent.py: runs no longer bitwise reproducible)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  // the flag is a hint (see "self-validating hand-over"): waiting for the L2's acknowledgement of the stores just makes it a
+  // good one -- the consumer validates every element, so no agent-scope release is needed
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -724,9 +755,9 @@ __device__ __forceinline__ typename Mfma<T>::acc_t mma_tile16(const T* Ar, const
 // whether the two feeder tiles of the next column are parked, then move them into LDS one tile per round
 template <typename T>
 struct ChainPrefetch {
-  const T* src;  // tile (k+1, k) in A ; the diagonal tile (k+1, k+1) follows TILE columns to the right
-  int64_t ld;
+  const T* src;  // hand-over slot of the parked tile (k+1, k) ; the parked diagonal tile (k+1, k+1) is the next slot
   T *dT, *dD;    // LDS destinations
+  int* bad;      // LDS: set when a prefetched element still read as the sentinel (the chain then fetches again, blocking)
   const int32_t *f1, *f2;
   int32_t epoch;
   int* ok;       // LDS
@@ -759,16 +790,15 @@ struct ChainPrefetch {
 #pragma unroll
       for (int q = 0; q < TILE * TILE / 256; ++q) {
         const int e = t + q * 256;
+        if (is_sent<T>(v[q])) *bad = 1;
         d[(e >> 6) * LDP + (e & 63)] = v[q];
       }
     }
     if (round <= 5) {
-      const T* g = round == 4 ? src : src + TILE;
+      const T* g = round == 4 ? src : src + TILE * TILE;
 #pragma unroll
-      for (int q = 0; q < TILE * TILE / 256; ++q) {
-        const int e = t + q * 256;
-        v[q] = __hip_atomic_load(g + (int64_t)(e >> 6) * ld + (e & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      for (int q = 0; q < TILE * TILE / 256; ++q)
+        v[q] = __hip_atomic_load(g + t + q * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 };
@@ -777,8 +807,8 @@ template <typename T, bool FUSED, bool BATCH = false>
 __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ldx,
                                                            int64_t lde, int64_t ne, int64_t nt,
                                                            int32_t* __restrict__ info, int64_t nvalid, int32_t* flags,
-                                                           int32_t epoch, unsigned long long* trace, T* XS, int64_t nx,
-                                                           const T* __restrict__ erow) {
+                                                           int32_t epoch, unsigned long long* trace, T* H, int64_t hstride,
+                                                           int64_t nx, const T* __restrict__ erow) {
   // nb > 1: nb independent problems of the same shape (the latents of a small multi-class model) in ONE launch, their
   // workgroups interleaved (linear index = tile * nb + problem) so that the chains of all problems start at once and the
   // per-XCD dispatch order stays a topological order of every graph.  Each problem has its own flags (fstride apart).  Safe
@@ -791,15 +821,21 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   T* __restrict__ Dg = bt.Dg[prob];
   T* E = bt.E[prob];
   flags += prob * fstride;
+  // hand-over area of this problem (sentinel-filled by the host): slots of 64x64 elements
+  //   HL[(R * nt + c)] tile (R, c), R in [0, nt + ne + nt)  |  HX[k] = X_k  |  HP[2k] = parked (k, k-1), HP[2k + 1] = parked (k, k)
+  constexpr int64_t SLOT = TILE * TILE;
+  T* HL = H + prob * hstride;
+  T* HX = HL + (2 * nt + ne) * nt * SLOT;
+  T* HP = HX + nt * SLOT;
   // erow (optional): row 0 of the LAST extension block is taken from this vector and its rows 1-63 as zero, instead of being
   // read from E (the CAVI step appends [eta1' ; 0]: saves the launch that used to write them)
   // nx = nt: also X = L^-1 in full.  L^-T = I L^-T, so nt more extension block rows holding the identity give X' column by
   // column with the same task graph and off the critical path (row i: tiles (i, c), c >= i; the others stay zero and have
-  // no workgroup).  They recurse through the row-major scratch XS (n x n) and are stored transposed into X.
+  // no workgroup).  They recurse through their hand-over slots (rows nt + ne + i) and are stored transposed into X.
   __shared__ __attribute__((aligned(16))) T sm[(FUSED ? 4 : 2) * TILE * LDP];
   __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
   __shared__ T piv[TILE];
-  __shared__ int wait_ok, pf_ok;
+  __shared__ int wait_ok, pf_ok, pf_bad;
   T* bufA = sm;
   T* bufB = sm + TILE * LDP;
   const int tid = threadIdx.x;
@@ -811,8 +847,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   }
   const bool diag = b == 0, ext = b >= nt - c, idr = b >= nt - c + ne;  // idr: identity row i = b - (nt - c + ne) <= c
   const int64_t R = idr ? nt + ne + (b - (nt - c + ne)) : ext ? nt + (b - (nt - c)) : c + b;  // block row in [0, nt+ne+nx)
-  T* rowp = idr ? XS + (R - nt - ne) * TILE * (nt * TILE) : ext ? E + (R - nt) * TILE * lde : A + R * TILE * ld;
-  const int64_t ldr = idr ? nt * TILE : ext ? lde : ld, c0 = c * TILE;
+  T* rowp = idr ? nullptr : ext ? E + (R - nt) * TILE * lde : A + R * TILE * ld;  // the block row's real home (none for idr)
+  const int64_t ldr = ext ? lde : ld, c0 = c * TILE;
   int32_t* ready = flags;
   int32_t* xready = flags + (nt + ne + nx) * nt * DAG_FS;
   int32_t* pre1 = xready + nt * DAG_FS;  // FUSED: tile (c, c-1) with all its pending updates is parked in place for the chain
@@ -844,8 +880,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
       const int64_t k0 = k * TILE;
       T* trow = A + (k + 1) * TILE * ld;  // block row k+1 (only touched while k + 1 < nt)
       ChainPrefetch<T> pf;
-      pf.src = k + 1 < nt ? trow + k0 : nullptr;
-      pf.ld = ld;
+      pf.src = k + 1 < nt ? HP + 2 * (k + 1) * SLOT : nullptr;
+      pf.bad = &pf_bad;
       pf.dT = bufC;
       pf.dD = bufD;
       pf.f1 = pre1 + (k + 1) * DAG_FS;
@@ -854,7 +890,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
       pf.ok = &pf_ok;
       pf.dgsrc = k >= 1 ? bufD : nullptr;  // after the swap below bufD is where L_{k-1,k-1} still sits
       pf.gDg = Dg + (k - 1) * TILE * TILE;
-      if (tid == 0) pf_ok = 0;
+      if (tid == 0) pf_ok = pf_bad = 0;
       factor_diag_tile_2lvl<T, ChainPrefetch<T>>(bufA, bufB, sc, piv, info, k0, nvalid, pf);
       DAG_TRC(k, 2);
       {  // X_k out (coherent): all LDS reads first, then the stores back to back (a read-store-read-store loop exposed the
@@ -872,7 +908,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
 #pragma unroll
         for (int q = 0; q < TILE * TILE / CHOL_THREADS; ++q) {
           const int e = tl + q * CHOL_THREADS;
-          __hip_atomic_store(gx + ((e >> 6) * ldx_i + (e & 63)), xv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(HX + k * SLOT + e, xv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gx[(e >> 6) * ldx_i + (e & 63)] = xv[q];  // for the kernels that follow
         }
       }
       if (k + 1 == nt) {
@@ -881,9 +918,9 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
         DAG_TRC(k, 3);
         return;
       }
-      if (!pf_ok) {  // the feeders were not done when the side job looked: fetch now
+      if (!pf_ok || pf_bad) {  // the feeders were not done (or not yet visible) when the side job looked: fetch now
         if (!dag_wait(pf.f1, pf.f2, epoch, abortf, info, &wait_ok)) return;
-        load_tiles_lds_coh2<T>(trow + k0, ld, bufC, trow + k0 + TILE, ld, bufD);
+        load_tiles_lds_hv2<T>(HP + 2 * (k + 1) * SLOT, bufC, HP + (2 * (k + 1) + 1) * SLOT, bufD);
         __syncthreads();
       }
       if (trace && tid == 0) trace[chain_slot(k + 1, nt, ne, nx) * 8 + 7] = (unsigned long long)pf_ok;
@@ -910,8 +947,11 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
           const int row = 16 * ri + Mfma<T>::row(lane, r);
           bufC[row * LDP + 16 * cA + (lane & 15)] = oa[r];  // in place of T (every wave is past the barrier above)
           bufC[row * LDP + 16 * cB + (lane & 15)] = ob[r];
-          __hip_atomic_store(trow + row * ld + k0 + 16 * cA + (lane & 15), oa[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(trow + row * ld + k0 + 16 * cB + (lane & 15), ob[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          T* hl = HL + ((k + 1) * nt + k) * SLOT + row * TILE + (lane & 15);
+          __hip_atomic_store(hl + 16 * cA, oa[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(hl + 16 * cB, ob[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          trow[row * ld + k0 + 16 * cA + (lane & 15)] = oa[r];  // the factor's real home, for the kernels that follow
+          trow[row * ld + k0 + 16 * cB + (lane & 15)] = ob[r];
         }
       }
       __syncthreads();
@@ -957,8 +997,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
     if (!dag_wait(ready + (R * nt + j) * DAG_FS, diag ? nullptr : ready + (c * nt + j) * DAG_FS, epoch, abortf, info, &wait_ok))
       return;
     if (j == c - 1) DAG_TR(4);
-    if (diag) load_tile_lds_coh<T>(rowp + j * TILE, ldr, bufA);
-    else load_tiles_lds_coh2<T>(rowp + j * TILE, ldr, bufA, A + c0 * ld + j * TILE, ld, bufB);
+    if (diag) load_tile_lds_hv<T>(HL + (R * nt + j) * SLOT, bufA);
+    else load_tiles_lds_hv2<T>(HL + (R * nt + j) * SLOT, bufA, HL + (c * nt + j) * SLOT, bufB);
     __syncthreads();
     if (j == c - 1) DAG_TR(5);
     mma8_sub<T>(bufA, diag ? bufA : bufB, acc);
@@ -966,8 +1006,9 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   }
   if (!f2) DAG_TR(1);
   if (f1 || f2) {
+    T* park = f1 ? HP + 2 * (c + 1) * SLOT : HP + (2 * c + 1) * SLOT;
     acc8_foreach<T>(acc, [&](int r, int cc, T& val) {
-      __hip_atomic_store(rowp + r * ldr + c0 + cc, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(park + r * TILE + cc, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     });
     dag_signal((f1 ? pre1 + (c + 1) * DAG_FS : pre2 + c * DAG_FS), epoch);
     if (f2) {
@@ -984,7 +1025,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
     DAG_TR(2);
     for (int e = tid; e < TILE * TILE; e += CHOL_THREADS) {
       const int r = e >> 6, cc = e & 63;
-      __hip_atomic_store(X + (c0 + r) * ldx + c0 + cc, bufB[r * LDP + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(HX + c * SLOT + e, bufB[r * LDP + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      X[(c0 + r) * ldx + c0 + cc] = bufB[r * LDP + cc];
     }
     dag_signal(xready + c * DAG_FS, epoch);
     for (int e = tid; e < TILE * TILE; e += CHOL_THREADS) Dg[c * TILE * TILE + e] = bufA[(e >> 6) * LDP + (e & 63)];
@@ -993,24 +1035,36 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   }
   if (!dag_wait(xready + c * DAG_FS, nullptr, epoch, abortf, info, &wait_ok)) return;
   DAG_TR(2);
-  load_tile_lds_coh<T>(X + c0 * ldx + c0, ldx, bufB);
+  load_tile_lds_hv<T>(HX + c * SLOT, bufB);
   __syncthreads();
   DAG_TR(6);
   Acc8<T> out;
   out.zero();
   mma8<T>(bufA, bufB, out);
-  acc8_foreach<T>(out, [&](int r, int cc, T& val) {
-    __hip_atomic_store(rowp + r * ldr + c0 + cc, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  });
+  {
+    T* hs = HL + (R * nt + c) * SLOT;
+    acc8_foreach<T>(out, [&](int r, int cc, T& val) {
+      __hip_atomic_store(hs + r * TILE + cc, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    });
+  }
   if (idr) {  // (L^-T)(i, c) = X(c, i)': the tile of X proper, for the kernels that follow
     const int64_t i0 = (R - nt - ne) * TILE;
     acc8_foreach<T>(out, [&](int r, int cc, T& val) { X[(c0 + cc) * ldx + i0 + r] = val; });
+  } else {  // the factor / W in its real home, for the kernels that follow
+    acc8_foreach<T>(out, [&](int r, int cc, T& val) { rowp[r * ldr + c0 + cc] = val; });
   }
   DAG_TR(7);
   dag_signal(ready + (R * nt + c) * DAG_FS, epoch);
   DAG_TR(3);
 #undef DAG_TR
 #undef DAG_TRC
+}
+
+// fills the hand-over area with the sentinel (host side: after every task-graph launch, on a side stream, for the launch after next)
+template <typename T>
+__global__ void k_fill_sent(T* __restrict__ p, int64_t n) {
+  const T sv = __builtin_bit_cast(T, Sent<T>::bits);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = sv;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -763,6 +763,9 @@ struct ChainPrefetch {
   int* ok;       // LDS
   const T* dgsrc;  // LDS: factor of the previous column, still to be stored to Dg (nullptr: none)
   T* gDg;
+  const T* lsrc;   // LDS: L(k, k-1), still to be stored to its real home in A (nullptr: none)
+  T* gL;           // A + (k * TILE) * ld + (k - 1) * TILE
+  int ld_i;
   T v[TILE * TILE / 256];
   __device__ __forceinline__ void operator()(int round) {
     const int t = (int)threadIdx.x - 256;
@@ -776,6 +779,13 @@ struct ChainPrefetch {
         }
       }
       return;
+    }
+    if (round < 4 && lsrc) {  // L(k, k-1) -> A, half per round
+#pragma unroll
+      for (int q = 0; q < TILE * TILE / 512; ++q) {
+        const int e = t + (2 * q + (round - 2)) * 256;
+        gL[(e >> 6) * ld_i + (e & 63)] = lsrc[(e >> 6) * LDP + (e & 63)];
+      }
     }
     if (!src) return;
     if (round == 3) {
@@ -808,7 +818,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
                                                            int64_t lde, int64_t ne, int64_t nt,
                                                            int32_t* __restrict__ info, int64_t nvalid, int32_t* flags,
                                                            int32_t epoch, unsigned long long* trace, T* H, int64_t hstride,
-                                                           int64_t nx, const T* __restrict__ erow) {
+                                                           int64_t nx, const T* __restrict__ erow, int write_x) {
+  // write_x: the chain also stores X_k to its real home (a single block column wanting its inverse: no identity rows run)
   // nb > 1: nb independent problems of the same shape (the latents of a small multi-class model) in ONE launch, their
   // workgroups interleaved (linear index = tile * nb + problem) so that the chains of all problems start at once and the
   // per-XCD dispatch order stays a topological order of every graph.  Each problem has its own flags (fstride apart).  Safe
@@ -890,14 +901,15 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
       pf.ok = &pf_ok;
       pf.dgsrc = k >= 1 ? bufD : nullptr;  // after the swap below bufD is where L_{k-1,k-1} still sits
       pf.gDg = Dg + (k - 1) * TILE * TILE;
+      pf.lsrc = k >= 1 ? bufC : nullptr;  // L(k, k-1) stays in bufC until the prefetch of round 5 overwrites it
+      pf.gL = A + k0 * ld + (k0 - TILE);
+      pf.ld_i = (int)ld;
       if (tid == 0) pf_ok = pf_bad = 0;
       factor_diag_tile_2lvl<T, ChainPrefetch<T>>(bufA, bufB, sc, piv, info, k0, nvalid, pf);
       DAG_TRC(k, 2);
       {  // X_k out (coherent): all LDS reads first, then the stores back to back (a read-store-read-store loop exposed the
          // LDS latency eight times: 0.6 us on the chain)
         T xv[TILE * TILE / CHOL_THREADS];
-        T* gx = X + k0 * ldx + k0;
-        const int ldx_i = (int)ldx;
         int tl = tid;
         asm volatile("" : "+v"(tl));  // keeps these addresses out of the registers that live through the factorisation
 #pragma unroll
@@ -909,8 +921,9 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
         for (int q = 0; q < TILE * TILE / CHOL_THREADS; ++q) {
           const int e = tl + q * CHOL_THREADS;
           __hip_atomic_store(HX + k * SLOT + e, xv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          gx[(e >> 6) * ldx_i + (e & 63)] = xv[q];  // for the kernels that follow
+          if (write_x) X[(k0 + (e >> 6)) * ldx + k0 + (e & 63)] = xv[q];
         }
+        // (the real X block is only read when the full inverse was requested, and then the identity-row tile (k, k) writes it)
       }
       if (k + 1 == nt) {
         for (int e = tid; e < TILE * TILE; e += CHOL_THREADS) Dg[k * TILE * TILE + e] = bufA[(e >> 6) * LDP + (e & 63)];
@@ -950,8 +963,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
           T* hl = HL + ((k + 1) * nt + k) * SLOT + row * TILE + (lane & 15);
           __hip_atomic_store(hl + 16 * cA, oa[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(hl + 16 * cB, ob[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          trow[row * ld + k0 + 16 * cA + (lane & 15)] = oa[r];  // the factor's real home, for the kernels that follow
-          trow[row * ld + k0 + 16 * cB + (lane & 15)] = ob[r];
+          // (its real home in A is written by the idle waves during the next factorisation: ChainPrefetch rounds 2, 3)
         }
       }
       __syncthreads();

@@ -140,7 +140,9 @@ static agp_status dag_handover_acquire(agp_ctx* c, int64_t elems, int set, T** o
     c->htype = (int)sizeof(T);
   }
   if (c->h_pending[set]) {
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->h_done[set], 0));
+    // the refill was queued two launches ago: normally long finished, and then the host knows it -- no wait packet in front of the
+    // factorisation (it would cost the stream ~15 us per step)
+    if (hipEventQuery(c->h_done[set]) != hipSuccess) HIPCHK(c, hipStreamWaitEvent(c->stream, c->h_done[set], 0));
     c->h_pending[set] = false;
   }
   *out = (T*)c->hset[set];
@@ -175,7 +177,9 @@ static bool chol_use_dag(int64_t nt, int64_t ne = 0, int64_t nb = 1) {
 
 template <typename T>
 static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int64_t ldx, T* Dg, T* E, int64_t lde,
-                              int64_t ne, int do_x, int32_t* info_dev, int64_t nvalid, const T* erow = nullptr) {
+                              int64_t ne, int do_x, int32_t* info_dev, int64_t nvalid, const T* erow = nullptr,
+                              bool want_l = true) {
+  // want_l = false: the caller never reads the factor L itself (only E L^-T, X, Dg): the task graph skips those stores
   // erow: the last extension block is [erow' ; 0] (not yet written to E: the task graph reads it in place; the per-column
   // path needs it in E first)
   const int64_t nt = n / TILE;
@@ -215,10 +219,12 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     one.E[0] = E;
     if (fused)
       hipLaunchKernelGGL((k_chol_dag<T, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0, ld,
-                         ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow, (int)(do_x && nx == 0));
+                         ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
+                         (int)(do_x && nx == 0) | (want_l ? 2 : 0));
     else
       hipLaunchKernelGGL((k_chol_dag<T, false>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0, ld,
-                         ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow, (int)(do_x && nx == 0));
+                         ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
+                         (int)(do_x && nx == 0) | (want_l ? 2 : 0));
     LAUNCHCHK(c);
     AGPCHK(dag_handover_release<T>(c, hstride, hs));
     if (trace) {
@@ -1117,7 +1123,7 @@ struct Svgp : SvgpBase {
         }
         if (nb == 1) {  // also writes the [eta1' ; 0] block when it falls back to per-column launches
           AGPCHK(potrf_fused<T>(ctx, bt.A[0], mp, mp, bt.X[0], mp, bt.Dg[0], bt.E[0], mp, nel, 0, info_dev, m,
-                                (const T*)lat[todo[l0]].eta1));
+                                (const T*)lat[todo[l0]].eta1, false));
           launches += dag_nb > 0 ? 1 : ntl;
         } else if (dag_nb > 0) {
           AGPCHK(potrf_dag_batch<T>(ctx, bt, nb, mp, mp, mp, mp, nel, info_dev, m));
@@ -1750,7 +1756,7 @@ struct Svgp : SvgpBase {
     }
     AGPCHK(timing_begin());
     AGPCHK(potrf_fused<T>(ctx, g.La, mp, mp, g.Xa, mp, g.DgA, g.Wbuf, mp, Bq / TILE + 1, with_x, info_dev, m,
-                          (const T*)g.eta1));
+                          (const T*)g.eta1, false));
     AGPCHK(timing_end(chol_use_dag(mp / TILE, Bq / TILE + 1) ? 1 : mp / TILE));
     g.la_state = 1;
     g.xa_valid = with_x != 0;

@@ -818,8 +818,12 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
                                                            int64_t lde, int64_t ne, int64_t nt,
                                                            int32_t* __restrict__ info, int64_t nvalid, int32_t* flags,
                                                            int32_t epoch, unsigned long long* trace, T* H, int64_t hstride,
-                                                           int64_t nx, const T* __restrict__ erow, int write_x) {
-  // write_x: the chain also stores X_k to its real home (a single block column wanting its inverse: no identity rows run)
+                                                           int64_t nx, const T* __restrict__ erow, int opts) {
+  // opts bit 0: the chain also stores X_k to its real home (a single block column wanting its inverse: no identity rows run)
+  //      bit 1: the factor L is wanted in its real home A as well (K's factor, the potrf entry points); the CAVI step only
+  //             consumes the extension rows W, v and never reads L itself, so its launches skip those stores
+  const int write_x = opts & 1;
+  const bool store_l = (opts & 2) != 0;
   // nb > 1: nb independent problems of the same shape (the latents of a small multi-class model) in ONE launch, their
   // workgroups interleaved (linear index = tile * nb + problem) so that the chains of all problems start at once and the
   // per-XCD dispatch order stays a topological order of every graph.  Each problem has its own flags (fstride apart).  Safe
@@ -901,7 +905,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
       pf.ok = &pf_ok;
       pf.dgsrc = k >= 1 ? bufD : nullptr;  // after the swap below bufD is where L_{k-1,k-1} still sits
       pf.gDg = Dg + (k - 1) * TILE * TILE;
-      pf.lsrc = k >= 1 ? bufC : nullptr;  // L(k, k-1) stays in bufC until the prefetch of round 5 overwrites it
+      pf.lsrc = (k >= 1 && store_l) ? bufC : nullptr;  // L(k, k-1) stays in bufC until the prefetch of round 5 overwrites it
       pf.gL = A + k0 * ld + (k0 - TILE);
       pf.ld_i = (int)ld;
       if (tid == 0) pf_ok = pf_bad = 0;
@@ -1062,7 +1066,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   if (idr) {  // (L^-T)(i, c) = X(c, i)': the tile of X proper, for the kernels that follow
     const int64_t i0 = (R - nt - ne) * TILE;
     acc8_foreach<T>(out, [&](int r, int cc, T& val) { X[(c0 + cc) * ldx + i0 + r] = val; });
-  } else {  // the factor / W in its real home, for the kernels that follow
+  } else if (ext || store_l) {  // W (always) / the factor (when wanted) in its real home, for the kernels that follow
     acc8_foreach<T>(out, [&](int r, int cc, T& val) { rowp[r * ldr + c0 + cc] = val; });
   }
   DAG_TR(7);

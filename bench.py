@@ -172,7 +172,7 @@ def main():
     avg_launch_s = (kms.value * 1e-3) / max(nl.value, 1)
     achieved = (flops_seq / launches_per_step) / avg_launch_s / 1e12 if nl.value else 0.0
     roofline = {
-        "kernel": "k_chol_dag<double, true>" if launches_per_step < 1.5 else "k_chol_step<double>",
+        "kernel": "k_chol_dag<double, true, false>" if launches_per_step < 1.5 else "k_chol_step<double>",
         "bound": "mfma",
         "achieved": round(achieved, 3),
         "peak": FP64_MFMA_PEAK_TFLOPS,
@@ -212,10 +212,10 @@ def main():
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE as
     # MI355X_MICROARCH.md prescribes for gfx950); rocprofv3 cannot wrap bench.py from inside, so this is not live
     try:
-        with open(os.path.join(ROOT, "profiles", "r01f_pmc_hbm_bytes.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r01g_pmc_hbm_bytes.json")) as fh:
             pm = json.load(fh)
         roofline["traffic"] = pm["kernels"][roofline["kernel"]]["hbm_bytes_per_launch_corrected"]
-        roofline["traffic_source"] = "profiles/r01f_pmc_hbm_bytes.json (rocprofv3 --pmc, separate passes, same command)"
+        roofline["traffic_source"] = "profiles/r01g_pmc_hbm_bytes.json (rocprofv3 --pmc, separate passes, same command)"
     except Exception:
         pass
 

@@ -134,7 +134,8 @@ static agp_status dag_handover_acquire(agp_ctx* c, int64_t elems, int set, T** o
     const size_t cap = need + need / 4;
     for (int q = 0; q < 2; ++q) {
       if (hipMalloc(&c->hset[q], cap) != hipSuccess) return AGP_ERR_NOMEM;
-      hipLaunchKernelGGL((k_fill_sent<T>), dim3(2048), dim3(256), 0, c->stream, (T*)c->hset[q], (int64_t)(cap / sizeof(T)));
+      hipLaunchKernelGGL((k_fill_sent<T>), dim3(2048), dim3(256), 0, c->stream, (T*)c->hset[q], (int64_t)(cap / sizeof(T)),
+                         (int64_t)0);
     }
     c->hbytes = cap;
     c->htype = (int)sizeof(T);
@@ -149,10 +150,12 @@ static agp_status dag_handover_acquire(agp_ctx* c, int64_t elems, int set, T** o
   return AGP_OK;
 }
 template <typename T>
-static agp_status dag_handover_release(agp_ctx* c, int64_t elems, int set) {
+static agp_status dag_handover_release(agp_ctx* c, int64_t used, int64_t stride, int nb, int set) {
+  // refill what the launch could have written: the first `used` elements of each of the nb problem regions
   HIPCHK(c, hipEventRecord(c->h_used, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->hfill, c->h_used, 0));
-  hipLaunchKernelGGL((k_fill_sent<T>), dim3(1024), dim3(256), 0, c->hfill, (T*)c->hset[set], elems);
+  hipLaunchKernelGGL((k_fill_sent<T>), dim3((unsigned)std::max<int64_t>(1, 512 / nb), (unsigned)nb), dim3(256), 0, c->hfill,
+                     (T*)c->hset[set], used, stride);
   HIPCHK(c, hipEventRecord(c->h_done[set], c->hfill));
   c->h_pending[set] = true;
   return AGP_OK;
@@ -226,7 +229,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
                          ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
                          (int)(do_x && nx == 0) | (want_l ? 2 : 0));
     LAUNCHCHK(c);
-    AGPCHK(dag_handover_release<T>(c, hstride, hs));
+    AGPCHK(dag_handover_release<T>(c, (3 * nt + (nt + ne + nx) * nt) * TILE * TILE, hstride, 1, hs));
     if (trace) {
       std::vector<unsigned long long> h((size_t)ntiles * 8);
       (void)hipStreamSynchronize(c->stream);
@@ -288,7 +291,7 @@ static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, in
                      ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, (unsigned long long*)nullptr, H, hstride,
                      (int64_t)0, (const T*)nullptr, 0);
   LAUNCHCHK(c);
-  AGPCHK(dag_handover_release<T>(c, hstride * nb, hs));
+  AGPCHK(dag_handover_release<T>(c, (3 * nt + (nt + ne) * nt) * TILE * TILE, hstride, nb, hs));
   return AGP_OK;
 }
 

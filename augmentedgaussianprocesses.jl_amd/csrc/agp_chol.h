@@ -837,11 +837,12 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   T* E = bt.E[prob];
   flags += prob * fstride;
   // hand-over area of this problem (sentinel-filled by the host): slots of 64x64 elements
-  //   HL[(R * nt + c)] tile (R, c), R in [0, nt + ne + nt)  |  HX[k] = X_k  |  HP[2k] = parked (k, k-1), HP[2k + 1] = parked (k, k)
+  //   HX[k] = X_k  |  HP[2k] = parked (k, k-1), HP[2k + 1] = parked (k, k)  |  HL[(R * nt + c)] tile (R, c), R in [0, nt + ne + nx)
+  // (the part a launch can touch is a prefix of the problem's region: only that much is refilled afterwards)
   constexpr int64_t SLOT = TILE * TILE;
-  T* HL = H + prob * hstride;
-  T* HX = HL + (2 * nt + ne) * nt * SLOT;
+  T* HX = H + prob * hstride;
   T* HP = HX + nt * SLOT;
+  T* HL = HP + 2 * nt * SLOT;
   // erow (optional): row 0 of the LAST extension block is taken from this vector and its rows 1-63 as zero, instead of being
   // read from E (the CAVI step appends [eta1' ; 0]: saves the launch that used to write them)
   // nx = nt: also X = L^-1 in full.  L^-T = I L^-T, so nt more extension block rows holding the identity give X' column by
@@ -1077,10 +1078,12 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
 }
 
 // fills the hand-over area with the sentinel (host side: after every task-graph launch, on a side stream, for the launch after next)
+// blockIdx.y = problem: the first n elements of each problem's region (stride elements apart)
 template <typename T>
-__global__ void k_fill_sent(T* __restrict__ p, int64_t n) {
+__global__ void k_fill_sent(T* __restrict__ p, int64_t n, int64_t stride) {
   const T sv = __builtin_bit_cast(T, Sent<T>::bits);
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = sv;
+  T* q = p + blockIdx.y * stride;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) q[i] = sv;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -25,14 +25,20 @@ struct agp_ctx {
   int32_t* dag_flags = nullptr;   // tile / x-ready / abort flags of the task-graph factorisation (k_chol_dag), epoch-stamped
   int64_t dag_cap = 0;
   int32_t dag_epoch = 0;
-  // sentinel-filled hand-over areas of the task graph: two sets used alternately; the set a launch used is refilled on a side
-  // stream right behind it and is ready again for the launch after next
+  // sentinel-filled hand-over area of the task graph (set 0; see Dirty below for how it gets refilled)
   void* hset[2] = {nullptr, nullptr};
   size_t hbytes = 0;
   int htype = -1;  // sizeof(T) the sets were filled for
   hipStream_t hfill = nullptr;
   hipEvent_t h_used = nullptr, h_done[2] = {nullptr, nullptr};
   bool h_pending[2] = {false, false};
+  // lazy refill: a launch leaves its set "dirty"; the next fused kappa' diag(w) kappa launch on the same stream refills it with
+  // rider workgroups (no extra launch, stream or event); whoever needs a dirty set before that refills it inline
+  struct Dirty {
+    bool on = false;
+    int64_t used = 0, stride = 0;
+    int nb = 0;
+  } h_dirty[2];
   void* tri_scratch = nullptr;    // n x n scratch of the recursive-doubling triangular inverse
   size_t tri_bytes = 0;
 };
@@ -129,10 +135,11 @@ static agp_status dag_handover_acquire(agp_ctx* c, int64_t elems, int set, T** o
       if (c->hset[q]) (void)hipFree(c->hset[q]);
       c->hset[q] = nullptr;
       c->h_pending[q] = false;
+      c->h_dirty[q].on = false;
     }
     c->hbytes = 0;
     const size_t cap = need + need / 4;
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < 1; ++q) {  // one set suffices since the refill rides on the same stream (set 1 is unused)
       if (hipMalloc(&c->hset[q], cap) != hipSuccess) return AGP_ERR_NOMEM;
       hipLaunchKernelGGL((k_fill_sent<T>), dim3(2048), dim3(256), 0, c->stream, (T*)c->hset[q], (int64_t)(cap / sizeof(T)),
                          (int64_t)0);
@@ -141,23 +148,26 @@ static agp_status dag_handover_acquire(agp_ctx* c, int64_t elems, int set, T** o
     c->htype = (int)sizeof(T);
   }
   if (c->h_pending[set]) {
-    // the refill was queued two launches ago: normally long finished, and then the host knows it -- no wait packet in front of the
-    // factorisation (it would cost the stream ~15 us per step)
     if (hipEventQuery(c->h_done[set]) != hipSuccess) HIPCHK(c, hipStreamWaitEvent(c->stream, c->h_done[set], 0));
     c->h_pending[set] = false;
+  }
+  if (c->h_dirty[set].on) {  // nobody refilled it in passing: do it now, on this stream
+    const auto& d = c->h_dirty[set];
+    hipLaunchKernelGGL((k_fill_sent<T>), dim3((unsigned)std::max<int64_t>(1, 512 / d.nb), (unsigned)d.nb), dim3(256), 0, c->stream,
+                       (T*)c->hset[set], d.used, d.stride);
+    c->h_dirty[set].on = false;
   }
   *out = (T*)c->hset[set];
   return AGP_OK;
 }
 template <typename T>
 static agp_status dag_handover_release(agp_ctx* c, int64_t used, int64_t stride, int nb, int set) {
-  // refill what the launch could have written: the first `used` elements of each of the nb problem regions
-  HIPCHK(c, hipEventRecord(c->h_used, c->stream));
-  HIPCHK(c, hipStreamWaitEvent(c->hfill, c->h_used, 0));
-  hipLaunchKernelGGL((k_fill_sent<T>), dim3((unsigned)std::max<int64_t>(1, 512 / nb), (unsigned)nb), dim3(256), 0, c->hfill,
-                     (T*)c->hset[set], used, stride);
-  HIPCHK(c, hipEventRecord(c->h_done[set], c->hfill));
-  c->h_pending[set] = true;
+  // what the launch could have written (the first `used` elements of each of the nb problem regions) must hold the sentinel
+  // again before the set's next use: left to the next fused syrk launch (riders) or, failing that, to the next acquire
+  c->h_dirty[set].on = true;
+  c->h_dirty[set].used = used;
+  c->h_dirty[set].stride = stride;
+  c->h_dirty[set].nb = nb;
   return AGP_OK;
 }
 
@@ -203,7 +213,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     const int64_t ntiles = nt * (nt + 1) / 2 + ne * nt + (nx ? nt * (nt + 1) / 2 : 0);
     const int64_t hstride = ((2 * nt + ne) * nt + 3 * nt) * TILE * TILE;
     T* H = nullptr;
-    const int hs = c->dag_epoch & 1;
+    const int hs = 0;
     AGPCHK(dag_handover_acquire<T>(c, hstride, hs, &H));
     unsigned long long* trace = nullptr;
     static const char* trace_path = getenv("AGP_DAG_TRACE");  // development aid: per-tile timestamps of one launch
@@ -285,7 +295,7 @@ static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, in
   const int64_t ntiles = nt * (nt + 1) / 2 + ne * nt;
   const int64_t hstride = ((2 * nt + ne) * nt + 3 * nt) * TILE * TILE;
   T* H = nullptr;
-  const int hs = c->dag_epoch & 1;
+  const int hs = 0;
   AGPCHK(dag_handover_acquire<T>(c, hstride * nb, hs, &H));
   hipLaunchKernelGGL((k_chol_dag<T, true, true>), dim3((unsigned)(ntiles * nb)), dim3(CHOL_THREADS), 0, c->stream, bt, nb, fstride, ld,
                      ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, (unsigned long long*)nullptr, H, hstride,
@@ -326,14 +336,29 @@ template <typename T, int MODE>
 static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_t Kdim, const T* w, int lower_a, T* out,
                           int64_t ldo, T* eta2, const T* Kinv, int64_t ldm, T lr, const T* rvec = nullptr,
                           T* eta1 = nullptr, const T* kinv_mu0 = nullptr) {
-  // rvec: nt rider workgroups also step eta1 (see k_syrk_tn)
-  const int64_t nt = n / TILE, tiles = nt * (nt + 1) / 2, grid = tiles + (rvec ? nt : 0);
+  // rvec: nt rider workgroups also step eta1 (see k_syrk_tn); a dirty hand-over set of the task-graph Cholesky is refilled by
+  // further riders (only from the fused step: MODE == SY_ETA2 with rvec)
+  const int64_t nt = n / TILE, tiles = nt * (nt + 1) / 2, nrider = rvec ? nt : 0;
+  T* fillp = nullptr;
+  int64_t fused_used = 0, fstride = 0, nfill = 0;
+  int fnb = 0;
+  if (MODE == SY_ETA2 && rvec && c->h_dirty[0].on && c->htype == (int)sizeof(T) && !c->h_pending[0]) {
+    fillp = (T*)c->hset[0];
+    fused_used = c->h_dirty[0].used;
+    fstride = c->h_dirty[0].stride;
+    fnb = c->h_dirty[0].nb;
+    nfill = 96;
+    c->h_dirty[0].on = false;
+  }
+  const int64_t grid = tiles + nrider + nfill;
   if (tiles <= 320 && Kdim >= 4 * BK)
     hipLaunchKernelGGL((k_syrk_tn<T, MODE, 2>), dim3((unsigned)grid), dim3(2 * NTHREADS), 0, c->stream, A, lda, Kdim, w,
-                       lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0);
+                       lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0, nrider, fillp, fused_used, fstride,
+                       fnb);
   else
     hipLaunchKernelGGL((k_syrk_tn<T, MODE, 1>), dim3((unsigned)grid), dim3(NTHREADS), 0, c->stream, A, lda, Kdim, w,
-                       lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0);
+                       lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0, nrider, fillp, fused_used, fstride,
+                       fnb);
   LAUNCHCHK(c);
   return AGP_OK;
 }

@@ -624,7 +624,8 @@ constexpr int DAG_FS = 64;  // flag stride in int32: one 256-byte line per flag,
 
 // ---- self-validating hand-over -------------------------------------------------------------------------------------
 // Tiles travel between workgroups through a hand-over area H (one contiguous 64x64 slot per tile) that the host fills with a
-// SENTINEL bit pattern (a signalling-NaN payload no arithmetic produces) before the launch.  The producer stores the tile there
+// SENTINEL bit pattern (a signalling-NaN payload no arithmetic produces) before the launch (and again after it: see Dirty in
+// agp_capi.hip).  The producer stores the tile there
 // with coherent (sc1) 8-byte stores and then raises a flag; the flag is only a HINT that the data is on its way: the consumer
 // loads the slot with coherent loads and re-loads any element that still reads as the sentinel.  8-byte stores are single-copy
 // atomic, so an element is either the sentinel or final -- no ordering between the data stores and the flag store is needed,
@@ -1077,7 +1078,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
 #undef DAG_TRC
 }
 
-// fills the hand-over area with the sentinel (host side: after every task-graph launch, on a side stream, for the launch after next)
+// fills the hand-over area with the sentinel (normally rider workgroups of the next k_syrk_tn launch do this; this kernel is the
+// fallback for callers that factor again before such a launch comes by, and the initial fill)
 // blockIdx.y = problem: the first n elements of each problem's region (stride elements apart)
 template <typename T>
 __global__ void k_fill_sent(T* __restrict__ p, int64_t n, int64_t stride) {

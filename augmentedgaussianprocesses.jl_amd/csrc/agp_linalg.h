@@ -88,8 +88,21 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_syrk_tn(const T* __restrict__
                                                       int64_t ldo, T* __restrict__ eta2, const T* __restrict__ Kinv,
                                                       int64_t ldm, T lr, int64_t ntri = 0,
                                                       const T* __restrict__ rvec = nullptr, T* __restrict__ eta1 = nullptr,
-                                                      const T* __restrict__ kinv_mu0 = nullptr) {
+                                                      const T* __restrict__ kinv_mu0 = nullptr, int64_t nrider = 0,
+                                                      T* __restrict__ fillp = nullptr, int64_t fill_used = 0,
+                                                      int64_t fill_stride = 0, int fill_nb = 0) {
   __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
+  if (fillp && (int64_t)blockIdx.x >= ntri + nrider) {
+    // second kind of rider: refill the hand-over slots the factorisation before this launch wrote (agp_chol.h, "self-validating
+    // hand-over") with the sentinel, in the shadow of the tile workgroups -- half the chip is idle during this launch anyway
+    const int64_t nfb = (int64_t)gridDim.x - ntri - nrider, fb = (int64_t)blockIdx.x - ntri - nrider;
+    const T sv = __builtin_bit_cast(T, Sent<T>::bits);
+    for (int q = 0; q < fill_nb; ++q) {
+      T* dst = fillp + q * fill_stride;
+      for (int64_t i = fb * blockDim.x + threadIdx.x; i < fill_used; i += nfb * blockDim.x) dst[i] = sv;
+    }
+    return;
+  }
   if (rvec && (int64_t)blockIdx.x >= ntri) {
     // rider of the fused step: workgroup ntri + j also takes the natural-gradient step on eta1[64 j .. 64 j + 63]
     //   t = A' r (column sums, analyticVI.jl:168) ; eta1 += lr (t + K^-1 mu0 - eta1)

@@ -29,9 +29,6 @@ struct agp_ctx {
   void* hset[2] = {nullptr, nullptr};
   size_t hbytes = 0;
   int htype = -1;  // sizeof(T) the sets were filled for
-  hipStream_t hfill = nullptr;
-  hipEvent_t h_used = nullptr, h_done[2] = {nullptr, nullptr};
-  bool h_pending[2] = {false, false};
   // lazy refill: a launch leaves its set "dirty"; the next fused kappa' diag(w) kappa launch on the same stream refills it with
   // rider workgroups (no extra launch, stream or event); whoever needs a dirty set before that refills it inline
   struct Dirty {
@@ -123,18 +120,11 @@ static agp_status trtri_levels(agp_ctx* c, const T* A, int64_t ld, T* X, int64_t
 template <typename T>
 static agp_status dag_handover_acquire(agp_ctx* c, int64_t elems, int set, T** out) {
   const size_t need = sizeof(T) * (size_t)elems;
-  if (!c->hfill) {
-    HIPCHK(c, hipStreamCreateWithFlags(&c->hfill, hipStreamNonBlocking));
-    HIPCHK(c, hipEventCreateWithFlags(&c->h_used, hipEventDisableTiming));
-    for (int q = 0; q < 2; ++q) HIPCHK(c, hipEventCreateWithFlags(&c->h_done[q], hipEventDisableTiming));
-  }
   if (c->hbytes < need || c->htype != (int)sizeof(T)) {
     (void)hipStreamSynchronize(c->stream);
-    (void)hipStreamSynchronize(c->hfill);
     for (int q = 0; q < 2; ++q) {
       if (c->hset[q]) (void)hipFree(c->hset[q]);
       c->hset[q] = nullptr;
-      c->h_pending[q] = false;
       c->h_dirty[q].on = false;
     }
     c->hbytes = 0;
@@ -146,10 +136,6 @@ static agp_status dag_handover_acquire(agp_ctx* c, int64_t elems, int set, T** o
     }
     c->hbytes = cap;
     c->htype = (int)sizeof(T);
-  }
-  if (c->h_pending[set]) {
-    if (hipEventQuery(c->h_done[set]) != hipSuccess) HIPCHK(c, hipStreamWaitEvent(c->stream, c->h_done[set], 0));
-    c->h_pending[set] = false;
   }
   if (c->h_dirty[set].on) {  // nobody refilled it in passing: do it now, on this stream
     const auto& d = c->h_dirty[set];
@@ -342,7 +328,7 @@ static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_
   T* fillp = nullptr;
   int64_t fused_used = 0, fstride = 0, nfill = 0;
   int fnb = 0;
-  if (MODE == SY_ETA2 && rvec && c->h_dirty[0].on && c->htype == (int)sizeof(T) && !c->h_pending[0]) {
+  if (MODE == SY_ETA2 && rvec && c->h_dirty[0].on && c->htype == (int)sizeof(T)) {
     fillp = (T*)c->hset[0];
     fused_used = c->h_dirty[0].used;
     fstride = c->h_dirty[0].stride;
@@ -2365,15 +2351,9 @@ agp_status agp_ctx_create(int32_t device, void* hip_stream, agp_ctx** out) {
 }
 
 agp_status agp_ctx_destroy(agp_ctx* ctx) {
-  if (ctx && (ctx->tri_scratch || ctx->dag_flags)) {
+  if (ctx && (ctx->tri_scratch || ctx->dag_flags || ctx->hset[0])) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->dag_flags) (void)hipFree(ctx->dag_flags);
-    if (ctx->hfill) {
-      (void)hipStreamSynchronize(ctx->hfill);
-      (void)hipStreamDestroy(ctx->hfill);
-      (void)hipEventDestroy(ctx->h_used);
-      for (int q = 0; q < 2; ++q) (void)hipEventDestroy(ctx->h_done[q]);
-    }
     for (int q = 0; q < 2; ++q)
       if (ctx->hset[q]) (void)hipFree(ctx->hset[q]);
     if (ctx->tri_scratch) (void)hipFree(ctx->tri_scratch);

@@ -212,10 +212,10 @@ def main():
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE as
     # MI355X_MICROARCH.md prescribes for gfx950); rocprofv3 cannot wrap bench.py from inside, so this is not live
     try:
-        with open(os.path.join(ROOT, "profiles", "r01g_pmc_hbm_bytes.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r01h_pmc_hbm_bytes.json")) as fh:
             pm = json.load(fh)
         roofline["traffic"] = pm["kernels"][roofline["kernel"]]["hbm_bytes_per_launch_corrected"]
-        roofline["traffic_source"] = "profiles/r01g_pmc_hbm_bytes.json (rocprofv3 --pmc, separate passes, same command)"
+        roofline["traffic_source"] = "profiles/r01h_pmc_hbm_bytes.json (rocprofv3 --pmc, separate passes, same command)"
     except Exception:
         pass
 

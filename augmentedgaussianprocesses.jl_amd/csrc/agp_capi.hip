@@ -216,7 +216,11 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     one.X[0] = X;
     one.Dg[0] = Dg;
     one.E[0] = E;
-    if (fused)
+    if (fused && trace)
+      hipLaunchKernelGGL((k_chol_dag<T, true, false, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1,
+                         (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
+                         (int)(do_x && nx == 0) | (want_l ? 2 : 0));
+    else if (fused)
       hipLaunchKernelGGL((k_chol_dag<T, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0, ld,
                          ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
                          (int)(do_x && nx == 0) | (want_l ? 2 : 0));

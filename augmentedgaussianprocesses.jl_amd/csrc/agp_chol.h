@@ -814,7 +814,7 @@ struct ChainPrefetch {
   }
 };
 
-template <typename T, bool FUSED, bool BATCH = false>
+template <typename T, bool FUSED, bool BATCH = false, bool TRACE = false>
 __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ldx,
                                                            int64_t lde, int64_t ne, int64_t nt,
                                                            int32_t* __restrict__ info, int64_t nvalid, int32_t* flags,
@@ -872,9 +872,9 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   int32_t* pre2 = pre1 + nt * DAG_FS;    // FUSED: diagonal tile (c, c) with the updates of columns < c-1 parked in place
   int32_t* abortf = pre2 + nt * DAG_FS;
 #define DAG_TR(slot) \
-  if (trace && tid == 0) trace[bidx * 8 + (slot)] = wall_clock64()
+  if (TRACE && tid == 0) trace[bidx * 8 + (slot)] = wall_clock64()
 #define DAG_TRC(col, slot) \
-  if (trace && tid == 0) trace[chain_slot(col, nt, ne, nx) * 8 + (slot)] = wall_clock64()
+  if (TRACE && tid == 0) trace[chain_slot(col, nt, ne, nx) * 8 + (slot)] = wall_clock64()
   DAG_TR(0);
   Acc8<T> acc;
   if (idr) {
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
         load_tiles_lds_hv2<T>(HP + 2 * (k + 1) * SLOT, bufC, HP + (2 * (k + 1) + 1) * SLOT, bufD);
         __syncthreads();
       }
-      if (trace && tid == 0) trace[chain_slot(k + 1, nt, ne, nx) * 8 + 7] = (unsigned long long)pf_ok;
+      if (TRACE && tid == 0) trace[chain_slot(k + 1, nt, ne, nx) * 8 + 7] = (unsigned long long)pf_ok;
       DAG_TRC(k + 1, 4);
       // both products skip what the structure makes zero or redundant (a 64^3 f64 product is MFMA-throughput bound on one CU:
       // 2.2 us; these take 40/64 and 48/64 of it):

@@ -1,6 +1,9 @@
 // Producer -> consumer hand-over of one 64x64 f64 tile (32 KB) between two workgroups on different XCDs.
 // variant 0: plain stores + agent release fence ; plain loads after an agent acquire fence   (what k_chol_flow does)
 // variant 1: relaxed agent-scope atomic (sc1) stores + s_waitcnt ; relaxed agent-scope atomic (sc1) loads, no fences
+//            (NOT sufficient on its own: the flag can overtake a write-through store)
+// variant 2: variant 1 + the tile slot is pre-filled with a sentinel and the consumer re-loads every element that still reads as
+//            the sentinel (what k_chol_dag does)
 // Reports (wall_clock64 ticks = 10 ns): publish = producer start -> flag stored ; seen = flag stored -> consumer saw it ;
 // fetch = consumer saw it -> tile in registers.  A third "noise" set of workgroups streams memory to keep the L2s dirty.
 #include <hip/hip_runtime.h>
@@ -59,6 +62,12 @@ __global__ __launch_bounds__(512) void k_hop(double* tile, int* flags, long* sta
       } else {
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = __hip_atomic_load(t + tid + q * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (VAR == 2) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            while (__builtin_bit_cast(unsigned long long, v[q]) == 0x7FF4DEADBEEF1234ull)
+              v[q] = __hip_atomic_load(t + tid + q * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       double s = 0;
 #pragma unroll
@@ -82,11 +91,16 @@ int main(int argc, char** argv) {
   CHECK(hipMalloc(&flags, sizeof(int) * 32 * rounds));
   CHECK(hipMalloc(&stamps, sizeof(long) * 4 * rounds));
   CHECK(hipMemset(noise, 0, sizeof(double) * nnoise * (nnoiseWG + 1)));
-  for (int var = 0; var < 2; ++var) {
+  for (int var = 0; var < 3; ++var) {
     for (int rep = 0; rep < 2; ++rep) {
       CHECK(hipMemset(flags, 0, sizeof(int) * 32 * rounds));
       CHECK(hipMemset(tile, 0, sizeof(double) * 4096 * rounds));
-      if (var == 0) hipLaunchKernelGGL(k_hop<0>, dim3(2 + nnoiseWG), dim3(512), 0, 0, tile, flags, stamps, sink, noise, nnoise, rounds);
+      if (var == 2) {
+        std::vector<unsigned long long> sv(4096 * rounds, 0x7FF4DEADBEEF1234ull);
+        CHECK(hipMemcpy(tile, sv.data(), sizeof(double) * 4096 * rounds, hipMemcpyHostToDevice));
+      }
+      if (var == 2) hipLaunchKernelGGL(k_hop<2>, dim3(2 + nnoiseWG), dim3(512), 0, 0, tile, flags, stamps, sink, noise, nnoise, rounds);
+      else if (var == 0) hipLaunchKernelGGL(k_hop<0>, dim3(2 + nnoiseWG), dim3(512), 0, 0, tile, flags, stamps, sink, noise, nnoise, rounds);
       else hipLaunchKernelGGL(k_hop<1>, dim3(2 + nnoiseWG), dim3(512), 0, 0, tile, flags, stamps, sink, noise, nnoise, rounds);
       CHECK(hipDeviceSynchronize());
     }

@@ -27,6 +27,11 @@ K_SQEXP, K_MATERN52, K_MATERN32, K_EXPONENTIAL = 0, 1, 2, 3
 LIK_GAUSSIAN, LIK_LOGISTIC, LIK_STUDENTT, LIK_LOGISTICSOFTMAX, LIK_MULTIOUTPUT = 0, 1, 2, 3, 4
 LIK_LAPLACE, LIK_BAYESIANSVM, LIK_POISSON, LIK_NEGBINOMIAL, LIK_HETEROSCEDASTIC = 5, 6, 7, 8, 9
 ELBO_CORRECTED, ELBO_REFERENCE = 0, 1
+FLAG_STALE_K = 1  # reference_compat_stale_K
+SHARD_LATENT, SHARD_BATCH = 0, 1
+COMM_ID_BYTES = 128
+# int32_t (*agp_allreduce_fn)(void* user, void* buf, int64_t count, int32_t dtype, void* hip_stream)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
 MAT_L, MAT_KINV, MAT_KNM, MAT_KAPPA, VEC_KTILDE, VEC_MEAN_F, VEC_VAR_F, VEC_THETA, VEC_C, VEC_GAMMA, VEC_ALPHA = range(11)
 
 
@@ -37,6 +42,8 @@ class KernelDesc(C.Structure):
         ("variance", C.c_double),
         ("scale", C.c_double),
         ("ard_scales_host", C.POINTER(C.c_double)),
+        ("has_variance", C.c_int32),   # the kernel object is `sigma2 * k`  (what update_kernel! may step)
+        ("has_transform", C.c_int32),  # the kernel object is `k o ScaleTransform / ARDTransform`
     ]
 
 
@@ -58,7 +65,7 @@ class SvgpDesc(C.Structure):
         ("rm_kappa", C.c_double),
         ("rm_tau", C.c_double),
         ("elbo_mode", C.c_int32),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 
@@ -114,7 +121,23 @@ SYMBOLS = {
     "agp_svgp_elbo": (_I32, [_VP, _VP, _I64, _VP, _VP, _I64, _DBL, _I32, _PDBL]),
     "agp_svgp_get_state": (_I32, [_VP, _I32, _VP, _VP, _VP, _VP]),
     "agp_svgp_set_state": (_I32, [_VP, _I32, _VP, _VP]),
-    "agp_svgp_get_matrix": (_I32, [_VP, _I32, _I32, _VP, _I64]),
+    "agp_svgp_get_matrix": (_I32, [_VP, _I32, _I32, _VP, _I64, _I64]),
+    "agp_svgp_last_batch": (_I32, [_VP, _PI64]),
+    "agp_svgp_invalidate_data": (_I32, [_VP]),
+    "agp_svgp_init_state": (_I32, [_VP]),
+    "agp_svgp_predict_f_cov": (_I32, [_VP, _VP, _I64, _I64, _VP, _VP]),
+    "agp_comm_unique_id": (_I32, [C.POINTER(C.c_uint8)]),
+    "agp_comm_init": (_I32, [_VP, _I32, _I32, C.POINTER(C.c_uint8), _PVP]),
+    "agp_comm_init_callback": (_I32, [_VP, _I32, _I32, ALLREDUCE_FN, _VP, _PVP]),
+    "agp_comm_destroy": (_I32, [_VP]),
+    "agp_comm_info": (_I32, [_VP, _PI32, _PI32, _PI32]),
+    "agp_comm_allreduce": (_I32, [_VP, _VP, _I64, _I32]),
+    "agp_comm_timing": (_I32, [_VP, _I32]),
+    "agp_comm_stats": (_I32, [_VP, _PI64, _PI64, _PDBL]),
+    "agp_svgp_cavi_step_multi": (_I32, [_VP, _VP, _I32, _VP, _I64, _VP, _VP, _I64, _DBL]),
+    "agp_svgp_elbo_multi": (_I32, [_VP, _VP, _I32, _PDBL]),
+    "agp_svgp_hyper_step_multi": (_I32, [_VP, _VP, _I32]),
+    "agp_svgp_predict_multi": (_I32, [_VP, _VP, _I32, _VP, _I64, _I64, _VP, _VP, _PDBL, _PDBL, _I32]),
     "agp_svgp_predict_f": (_I32, [_VP, _VP, _I64, _I64, _VP, _VP]),
     "agp_svgp_predict_y": (_I32, [_VP, _VP, _I64, _I64, _VP]),
     "agp_svgp_proba_y": (_I32, [_VP, _VP, _I64, _I64, _PDBL, _PDBL, _I32, _VP, _VP]),

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "agp_cavi.h"
+#include "agp_comm.h"
 #include "agp_hyper.h"
 #include "agp_kmeans.h"
 #include "agp_linalg.h"
@@ -63,6 +64,23 @@ struct agp_ctx {
     agp_status _s = (expr);            \
     if (_s != AGP_OK) return _s;       \
   } while (0)
+
+// Every entry point runs with the ctx's device current and restores the caller's on the way out: the caller's thread may
+// have another device selected (two models on two GPUs in one process, torch.cuda.set_device between calls), and a library
+// must not change it behind the caller's back.
+struct DevGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DevGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DevGuard() {
+    if (switched && prev >= 0) (void)hipSetDevice(prev);
+  }
+  DevGuard(const DevGuard&) = delete;
+  DevGuard& operator=(const DevGuard&) = delete;
+};
 
 static inline int64_t rup64(int64_t x) { return (x + 63) / 64 * 64; }
 static inline dim3 grid1(int64_t n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
@@ -374,6 +392,7 @@ struct KernelHost {
   int kind = AGP_K_SQEXP;
   double variance = 1.0;
   bool ard = false;
+  bool has_variance = true, has_transform = true;  // structure of the kernel object (agp_kernel_desc): what update_kernel! steps
   std::vector<double> scales;  // length D
 };
 
@@ -417,7 +436,19 @@ struct SvgpBase {
   virtual agp_status set_batch_shard(int rank, int world) = 0;
   virtual agp_status get_state(int l, void* mu, void* sigma, void* eta1, void* eta2) = 0;
   virtual agp_status set_state(int l, const void* eta1, const void* eta2) = 0;
-  virtual agp_status get_matrix(int l, int which, void* out, int64_t ldo) = 0;
+  virtual agp_status get_matrix(int l, int which, void* out, int64_t ldo, int64_t cap) = 0;
+  virtual int64_t last_batch() = 0;
+  virtual agp_status init_state() = 0;
+  virtual agp_status invalidate_data() = 0;
+  virtual agp_status predict_f_cov(const void* xt, int64_t ldx, int64_t nt, void* mu, void* cov) = 0;
+  virtual agp_status refresh_K_explicit() = 0;
+  // multi-GPU (agp_comm.h)
+  virtual agp_status cavi_step_multi(agp_comm* cm, int mode, const void* x, int64_t ldx, const void* y, const int64_t* idx,
+                                     int64_t B, double rho) = 0;
+  virtual agp_status elbo_multi(agp_comm* cm, int mode, double* out) = 0;
+  virtual agp_status hyper_step_multi(agp_comm* cm, int tied) = 0;
+  virtual agp_status predict_multi(agp_comm* cm, int what, const void* xt, int64_t ldx, int64_t nt, void* mu, void* var,
+                                   const double* nodes, const double* weights, int nn) = 0;
   virtual agp_status predict_f(const void* xt, int64_t ldx, int64_t nt, void* mu, void* var) = 0;
   virtual agp_status predict_y(const void* xt, int64_t ldx, int64_t nt, void* out) = 0;
   virtual agp_status proba_y(const void* xt, int64_t ldx, int64_t nt, const double* nodes, const double* weights,
@@ -521,6 +552,11 @@ struct Svgp : SvgpBase {
     int la_state = 0;
     bool xa_valid = false;
     double half_logdetK = 0.0;
+    // AGP_FLAG_STALE_K: the step-side copies of (inv(K), L^-1, K\mu0, logdet K) frozen at the first hyper step of a train! --
+    // what the reference keeps using until train! ends (training.jl:187-208); the members above are always the fresh ones
+    T *sKinv = nullptr, *sXk = nullptr, *skinv_mu0 = nullptr;
+    double s_half_logdetK = 0.0;
+    bool stale_on = false;
     // OnlineSVGP streaming prior (onlinetraining.jl:170-180, latentgp.jl:217-237): the previous posterior enters through
     // Z_a, invD_a = Sigma_a^-1 - K_a^-1, eta1_a ; kappa_a = K_ab K^-1, K~_a = K_a - kappa_a K_ab'
     bool on = false, on_dirty = false, on_first = false;
@@ -540,6 +576,7 @@ struct Svgp : SvgpBase {
   // hyper-parameter step (update_hyperparameters!, autotuning.jl:86-140)
   bool hy_k = false, hy_z = false;
   double hy_keta = 0.01, hy_zeta = 0.001, hy_b1 = 0.9, hy_b2 = 0.999, hy_eps = 1e-8;
+  T *hyKap = nullptr, *hyKnm = nullptr;  // kappa (Knm) under the fresh inv(K) (kernel) for the hyper-gradient, AGP_FLAG_STALE_K
   T *hyH1 = nullptr, *hyH2 = nullptr, *hyH3 = nullptr, *hy_gmu = nullptr, *hy_gs = nullptr, *hy_muf = nullptr,
     *hy_pZ = nullptr, *hy_dZ = nullptr;
   double *hy_pvar = nullptr, *hy_pscale = nullptr, *hy_g = nullptr;
@@ -575,7 +612,8 @@ struct Svgp : SvgpBase {
   T *alpha = nullptr, *beta = nullptr, *gsum = nullptr, *alpha_save = nullptr;  // [Bp]
   T *emuf = nullptr, *evarf = nullptr;             // ELBO-time mean_f / var_f [nl][Bp]
   T* cpart = nullptr;                              // [Bp/64][mp]
-  T* stats = nullptr;                              // [nl][mp + mp*mp]
+  T* stats = nullptr;                              // [nl][mp + nt(nt+1)/2 * 64*64]: kappa' r, then the lower tiles of kappa' diag(w) kappa
+  int64_t stats_stride() const { return mp + (mp / TILE) * (mp / TILE + 1) / 2 * TILE * TILE; }
   T* Tw = nullptr;                                 // mp x mp scratch
   T* Tw2 = nullptr;                                // mp x mp scratch (predict)
   T* tmpv = nullptr;                               // mp
@@ -692,7 +730,7 @@ struct Svgp : SvgpBase {
     AGPCHK(dmalloc(ctx, &gsum, Bp));
     AGPCHK(dmalloc(ctx, &alpha_save, Bp));
     AGPCHK(dmalloc(ctx, &cpart, (Bp / TILE) * mp));
-    AGPCHK(dmalloc(ctx, &stats, nl * (mp + mm)));
+    AGPCHK(dmalloc(ctx, &stats, nl * stats_stride()));
     AGPCHK(dmalloc(ctx, &Tw, mm));
     AGPCHK(dmalloc(ctx, &Tw2, mm));
     AGPCHK(dmalloc(ctx, &tmpv, mp));
@@ -730,14 +768,17 @@ struct Svgp : SvgpBase {
                evarf, cpart, stats, Tw, Tw2, tmpv, lr_dev, Kstar, ppm, ppv, pmu, pvar};
     for (T* p : ps)
       if (p) dfree(p);
-    T* hps[] = {hyH1, hyH2, hyH3, hy_gmu, hy_gs, hy_muf, hy_pZ, hy_dZ};
+    T* hps[] = {hyH1, hyH2, hyH3, hy_gmu, hy_gs, hy_muf, hy_pZ, hy_dZ, hyKap, hyKnm};
     for (T* p : hps)
       if (p) dfree(p);
-    double* hds[] = {hy_pvar, hy_pscale, hy_g};
+    double* hds[] = {hy_pvar, hy_pscale, hy_g, hy_tied};
     for (double* p : hds)
       if (p) dfree(p);
     for (auto& g : lat) {
       free_online(g);
+      T* sp[] = {g.sKinv, g.sXk, g.skinv_mu0};
+      for (T* q : sp)
+        if (q) dfree(q);
       if (g.z_am) dfree(g.z_am);
       if (g.z_av) dfree(g.z_av);
     }
@@ -786,6 +827,8 @@ struct Svgp : SvgpBase {
     g.k.kind = k->kind;
     g.k.variance = k->variance;
     g.k.ard = k->ard != 0;
+    g.k.has_variance = k->has_variance != 0;
+    g.k.has_transform = k->has_transform != 0 || k->ard != 0;
     for (int64_t d = 0; d < D; ++d) g.k.scales[d] = k->ard ? k->ard_scales_host[d] : k->scale;
     g.K_stale = true;
     g.kappa_valid = false;
@@ -835,6 +878,11 @@ struct Svgp : SvgpBase {
   // compute_K : cholesky(kernelmatrix(k, Z) + jitt*I) ; inv(K)      latentgp.jl:205-207, analyticVI.jl:179
   agp_status refresh_K() override {
     bool any = false;
+    for (auto& g : lat) any = any || g.K_stale;
+    // this call synchronises and reads the failure latch: anything an earlier asynchronous step latched (K~ <= 0, a non-SPD
+    // -2*eta2) is reported first and as what it is, not as a failure of K_ZZ
+    if (any) AGPCHK(check_status());
+    any = false;
     for (auto& g : lat) {
       if (!g.K_stale) continue;
       any = true;
@@ -1041,6 +1089,19 @@ struct Svgp : SvgpBase {
     return AGP_OK;
   }
 
+  // which K-derived matrices the STEP uses (online prior folded in > frozen copies of AGP_FLAG_STALE_K > the fresh ones)
+  const T* kinv_kappa(const Latent& g) const { return g.stale_on ? g.sKinv : g.Kinv; }
+  const T* kinv_step(const Latent& g) const { return g.on ? g.Kinv_on : (g.stale_on ? g.sKinv : g.Kinv); }
+  const T* kinv_mu0_step(const Latent& g) const { return g.on ? g.kinv_mu0_on : (g.stale_on ? g.skinv_mu0 : g.kinv_mu0); }
+  bool stale_mode() const { return (desc.flags & AGP_FLAG_STALE_K) != 0; }
+
+  // compute_K where train! starts and ends (training.jl:41-43,107): with AGP_FLAG_STALE_K this is the only thing that ends
+  // the staleness; without the flag it is plain refresh_K
+  agp_status refresh_K_explicit() override {
+    for (auto& g : lat) g.stale_on = false;
+    return refresh_K();
+  }
+
   agp_status check_batch(int64_t B) {
     if (B <= 0 || B > Bmax) {  // training.jl:27-29
       ctx->err = "The size of mini-batch " + std::to_string(B) + " is incorrect (negative or bigger than max_batch)";
@@ -1081,8 +1142,8 @@ struct Svgp : SvgpBase {
                            D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Knm, mp, Bq, mp, 0, T(0),
                            (const T*)nullptr, (T*)nullptr, (int64_t)0);
         LAUNCHCHK(ctx);
-        AGPCHK((gemm_nt<T, EPI_KAPPA>(ctx, g.Knm, mp, g.Kinv, mp, Bq, mp, mp, 0, g.kappa, mp, g.Knm, mp, nullptr, g.pk,
-                                      g.Wbuf, ldp)));
+        AGPCHK((gemm_nt<T, EPI_KAPPA>(ctx, g.Knm, mp, kinv_kappa(g), mp, Bq, mp, mp, 0, g.kappa, mp, g.Knm, mp, nullptr,
+                                      g.pk, g.Wbuf, ldp)));
         g.kappa_valid = !desc.stochastic && !fresh;
       } else {
         HIPCHK(ctx, hipMemcpyAsync(g.Wbuf, g.kappa, sizeof(T) * Bq * mp, hipMemcpyDeviceToDevice, st()));
@@ -1247,10 +1308,38 @@ struct Svgp : SvgpBase {
     const int64_t B = B_last, Bq = rup64(B);
     const T rho = (T)rho_last;
     AGPCHK(ensure_pred(g, true));  // Sigma, mu, K^-1 mu, Apred = K^-1 - K^-1 Sigma K^-1
+    // AGP_FLAG_STALE_K: the step's kappa mixes the new Knm with the frozen inv(K); the differentiated ELBO recomputes the
+    // kernel matrices (ELBO.jl:15-21), so the gradient takes kappa = Knm K^-1 with the FRESH inverse
+    if (g.stale_on && lp.kind == AGP_LIK_HETEROSCEDASTIC) {
+      ctx->err = "reference_compat_stale_K is not wired for the heteroscedastic hyper-gradient";
+      return AGP_ERR_UNSUPPORTED;
+    }
+    // (a full-batch AnalyticVI run does not even recompute Knm after a hyper step -- its kappa cache stays valid,
+    //  training.jl:196-204 -- so there the gradient also needs Knm under the current kernel and Z)
+    auto knm_for_grad = [&](Latent& q) -> const T* {
+      if (!q.stale_on || desc.stochastic) return q.Knm;
+      if (!hyKnm && dmalloc(ctx, &hyKnm, Bp * mp) != AGP_OK) return nullptr;
+      dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
+      hipLaunchKernelGGL((k_kernelmatrix<T>), gk, dim3(NTHREADS), 0, st(), (const T*)x_last, ldx_last, idx_last, B,
+                         (const T*)q.Z, D, m, D, (const T*)q.scales, q.k.kind, (T)q.k.variance, hyKnm, mp, Bq, mp, 0, T(0),
+                         (const T*)nullptr, (T*)nullptr, (int64_t)0);
+      return hyKnm;
+    };
+    auto kappa_for_grad = [&](Latent& q) -> const T* {
+      if (!q.stale_on) return q.kappa;
+      const T* kn = knm_for_grad(q);
+      if (!kn) return nullptr;
+      if (!hyKap && dmalloc(ctx, &hyKap, Bp * mp) != AGP_OK) return nullptr;
+      if (gemm_nt<T, EPI_STORE>(ctx, kn, mp, q.Kinv, mp, Bq, mp, mp, 0, hyKap, mp, nullptr, 0, nullptr, nullptr, nullptr,
+                                0) != AGP_OK)
+        return nullptr;
+      return hyKap;
+    };
+    const T* kap = kappa_for_grad(g);
+    if (!kap) return AGP_ERR_NOMEM;
     // mean_f with the current posterior, then g_mu / g_sigma from the step's local variables
-    hipLaunchKernelGGL((k_gemv_rows<T>), grid1(B * 64), dim3(256), 0, st(), (const T*)g.kappa, mp, B, mp, (const T*)g.mu,
-                       hy_muf);
-    AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.kappa, mp, g.Sigma, mp, Bq, mp, mp, 0, hyH1, mp, nullptr, 0, nullptr, nullptr,
+    hipLaunchKernelGGL((k_gemv_rows<T>), grid1(B * 64), dim3(256), 0, st(), kap, mp, B, mp, (const T*)g.mu, hy_muf);
+    AGPCHK((gemm_nt<T, EPI_STORE>(ctx, kap, mp, g.Sigma, mp, Bq, mp, mp, 0, hyH1, mp, nullptr, 0, nullptr, nullptr,
                                   nullptr, 0)));
     if (mo) {
       // mixed means under the current posterior need every latent's mean_f on this batch
@@ -1261,8 +1350,14 @@ struct Svgp : SvgpBase {
       }
       for (int q = 0; q < nl && !mo_sharded; ++q) {
         AGPCHK(materialize(lat[q]));
-        hipLaunchKernelGGL((k_gemv_rows<T>), grid1(B * 64), dim3(256), 0, st(), (const T*)lat[q].kappa, mp, B, mp,
-                           (const T*)lat[q].mu, emuf + q * Bp);
+        const T* kq = q == l ? kap : kappa_for_grad(lat[q]);
+        if (!kq) return AGP_ERR_NOMEM;
+        hipLaunchKernelGGL((k_gemv_rows<T>), grid1(B * 64), dim3(256), 0, st(), kq, mp, B, mp, (const T*)lat[q].mu,
+                           emuf + q * Bp);
+      }
+      if (g.stale_on && nl > 1 && !mo_sharded) {  // the scratch now holds another latent's kappa
+        kap = kappa_for_grad(g);
+        if (!kap) return AGP_ERR_NOMEM;
       }
       hipLaunchKernelGGL((k_mo_hyper_gvec<T>), grid1(B), dim3(256), 0, st(), B, Qa(), Bp, mocfg, (const T*)A_dev,
                          (const T*)y_last, ystride, idx_last, mo_sharded ? (const T*)fall : (const T*)emuf,
@@ -1277,28 +1372,28 @@ struct Svgp : SvgpBase {
       if (lp.kind == AGP_LIK_HETEROSCEDASTIC && l == 0) {
         gmode = 3;  // needs var_f under the current posterior: rowdot(kappa Sigma, kappa) + K~
         hipLaunchKernelGGL((k_hyper_varf<T>), grid1(B * 64), dim3(256), 0, st(), B, mp, mp, (const T*)hyH1,
-                           (const T*)g.kappa, (const T*)(Kt + l * Bp), pw0);
+                           kap, (const T*)(Kt + l * Bp), pw0);
       }
       hipLaunchKernelGGL((k_hyper_gvec<T>), grid1(B), dim3(256), 0, st(), B, rho, gmode, (const T*)(rbuf + l * Bp),
                          (const T*)(theta + l * Bp), (const T*)hy_muf, (const T*)y_last, idx_last, (const T*)pw0,
                          (const T*)gamma, (const T*)lam_dev, hy_gmu, hy_gs);
       LAUNCHCHK(ctx);
     }
+    const T* knm = knm_for_grad(g);  // (the scratch is per handle: recomputed after the loop over the other latents)
+    if (!knm) return AGP_ERR_NOMEM;
     hipLaunchKernelGGL((k_hyper_gkappa<T>), grid2(Bq, mp), blk2, 0, st(), B, Bq, mp, mp, rho, (const T*)hy_gmu,
-                       (const T*)hy_gs, (const T*)g.mu, (const T*)g.Knm, hyH1);
+                       (const T*)hy_gs, (const T*)g.mu, knm, hyH1);
     LAUNCHCHK(ctx);
     AGPCHK((gemm_nt<T, EPI_STORE>(ctx, hyH1, mp, g.Kinv, mp, Bq, mp, mp, 0, hyH2, mp, nullptr, 0, nullptr, nullptr,
                                   nullptr, 0)));
     hipLaunchKernelGGL((k_hyper_gknm<T>), grid2(Bq, mp), blk2, 0, st(), B, Bq, mp, mp, rho, (const T*)hy_gs,
-                       (const T*)hyH2, (const T*)g.kappa, hyH3);
+                       (const T*)hyH2, kap, hyH3);
     {
       dim3 gt((unsigned)(mp / TILE), (unsigned)(mp / TILE));
       if ((mp / TILE) * (mp / TILE) <= 320)
-        hipLaunchKernelGGL((k_gemm_tn<T, 2>), gt, dim3(2 * NTHREADS), 0, st(), (const T*)g.kappa, mp, (const T*)hyH2, mp,
-                           Bq, Tw, mp);
+        hipLaunchKernelGGL((k_gemm_tn<T, 2>), gt, dim3(2 * NTHREADS), 0, st(), kap, mp, (const T*)hyH2, mp, Bq, Tw, mp);
       else
-        hipLaunchKernelGGL((k_gemm_tn<T, 1>), gt, dim3(NTHREADS), 0, st(), (const T*)g.kappa, mp, (const T*)hyH2, mp, Bq,
-                           Tw, mp);
+        hipLaunchKernelGGL((k_gemm_tn<T, 1>), gt, dim3(NTHREADS), 0, st(), kap, mp, (const T*)hyH2, mp, Bq, Tw, mp);
     }
     hipLaunchKernelGGL((k_axpby<T>), grid1(mp), dim3(256), 0, st(), mp, T(1), (const T*)g.apred, T(-1),
                        (const T*)g.kinv_mu0, tmpv);
@@ -1456,9 +1551,16 @@ struct Svgp : SvgpBase {
       }
       g.k_step += 1;
       // variance and scale(s) are separate parameter arrays in the reference: separate ADAM states, same step count
+      // the reference's gradient is structural (a Zygote NamedTuple over the kernel object, autotuning.jl:99-118): a
+      // parameter that does not exist in the object -- the variance of a kernel that is not `sigma2 * k`, the scale of one
+      // without a transform -- has no gradient entry, no optimiser state, and is never stepped
+      if (!g.k.has_variance) gl[0] = 0.0;
+      if (!g.k.has_transform)
+        for (size_t j = 1; j < np; ++j) gl[j] = 0.0;
       adam_host(g.k_m, g.k_v, g.k_step, gl, hy_keta, hy_b1, hy_b2, hy_eps, delta);
-      g.k.variance = std::exp(std::log(p[0]) + delta[0]);
-      for (int64_t d = 0; d < D; ++d) {
+      if (g.k.has_variance) g.k.variance = std::exp(std::log(p[0]) + delta[0]);
+      else g.k_m[0] = g.k_v[0] = 0.0;
+      for (int64_t d = 0; d < D && g.k.has_transform; ++d) {
         const size_t j = g.k.ard ? 1 + (size_t)d : 1;
         g.k.scales[d] = std::exp(std::log(p[j]) + delta[j]);
       }
@@ -1480,9 +1582,26 @@ struct Svgp : SvgpBase {
 
   agp_status hyper_finish() {
     for (auto& g : lat) {
+      if (stale_mode() && !g.stale_on && !g.on && !g.K_stale) {
+        // reference_compat_stale_K: freeze what the step uses before the kernel / Z move
+        const int64_t mm = mp * mp;
+        if (!g.sKinv) {
+          AGPCHK(dmalloc(ctx, &g.sKinv, mm));
+          AGPCHK(dmalloc(ctx, &g.sXk, mm));
+        }
+        HIPCHK(ctx, hipMemcpyAsync(g.sKinv, g.Kinv, sizeof(T) * mm, hipMemcpyDeviceToDevice, st()));
+        HIPCHK(ctx, hipMemcpyAsync(g.sXk, g.Xk, sizeof(T) * mm, hipMemcpyDeviceToDevice, st()));
+        if (g.kinv_mu0) {
+          if (!g.skinv_mu0) AGPCHK(dmalloc(ctx, &g.skinv_mu0, mp));
+          HIPCHK(ctx, hipMemcpyAsync(g.skinv_mu0, g.kinv_mu0, sizeof(T) * mp, hipMemcpyDeviceToDevice, st()));
+        }
+        g.s_half_logdetK = g.half_logdetK;
+        g.stale_on = true;
+      }
       if (hy_k) AGPCHK(upload_scales(g));
       g.K_stale = true;
-      g.kappa_valid = false;
+      // (the reference's full-batch path keeps its kernel matrices across a hyper step, training.jl:196-204)
+      if (!(g.stale_on && !desc.stochastic)) g.kappa_valid = false;
       g.pred_valid = g.predvar_valid = false;
     }
     pf_valid = false;
@@ -1686,7 +1805,7 @@ struct Svgp : SvgpBase {
       hipLaunchKernelGGL((k_kernelmatrix<T>), gk, dim3(NTHREADS), 0, pf_stream, (const T*)x, ldx, idx, B, (const T*)g.Z,
                          D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Knm_alt, mp, Bq, mp, 0, T(0),
                          (const T*)nullptr, (T*)nullptr, (int64_t)0);
-      rc = gemm_nt<T, EPI_KAPPA>(ctx, g.Knm_alt, mp, g.Kinv, mp, Bq, mp, mp, 0, g.kappa_alt, mp, g.Knm_alt, mp, nullptr,
+      rc = gemm_nt<T, EPI_KAPPA>(ctx, g.Knm_alt, mp, kinv_kappa(g), mp, Bq, mp, mp, 0, g.kappa_alt, mp, g.Knm_alt, mp, nullptr,
                                  g.pk_alt, g.Wbuf_alt, ldp);
       if (rc != AGP_OK) break;
     }
@@ -1723,7 +1842,7 @@ struct Svgp : SvgpBase {
     if (lp.kind != AGP_LIK_LOGISTICSOFTMAX) return AGP_OK;
     hipLaunchKernelGGL((k_lsm_finish<T>), grid1(B_last), dim3(256), 0, st(), B_last, nl, Bp, desc.latent_offset,
                        (T)rho_last, (const int32_t*)y_last, idx_last, (const T*)cbuf, (const T*)gamma, theta, rbuf,
-                       wbuf);
+                       wbuf, (int)desc.lik.n_class, flags_dev);
     LAUNCHCHK(ctx);
     return AGP_OK;
   }
@@ -1739,19 +1858,18 @@ struct Svgp : SvgpBase {
     const T lr = (T)cur_lr();
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
-      T* sl = stats + l * (mp + mp * mp);
+      T* sl = stats + l * stats_stride();
       if (fused) {  // one launch: eta2 step on the lower tiles, eta1 step on nt rider workgroups
         AGPCHK((syrk_tn<T, SY_ETA2>(ctx, g.kappa, mp, mp, Bq, wbuf + l * Bp, 0, g.La, mp, g.eta2,
-                                    g.on ? g.Kinv_on : g.Kinv, mp, lr, (const T*)(rbuf + l * Bp), g.eta1,
-                                    (const T*)(g.on ? g.kinv_mu0_on : g.kinv_mu0))));
+                                    kinv_step(g), mp, lr, (const T*)(rbuf + l * Bp), g.eta1, kinv_mu0_step(g))));
       } else {
         dim3 gc((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
         hipLaunchKernelGGL((k_colsum_partial<T>), gc, dim3(NTHREADS), 0, st(), (const T*)g.kappa, mp,
                            (const T*)(rbuf + l * Bp), cpart, mp);
         hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, (int)(Bq / TILE), (const T*)cpart, mp,
                            (const T*)nullptr, (const T*)nullptr, (T*)nullptr, lr, sl);
-        AGPCHK((syrk_tn<T, SY_STORE>(ctx, g.kappa, mp, mp, Bq, wbuf + l * Bp, 0, sl + mp, mp, (T*)nullptr,
-                                     (const T*)nullptr, (int64_t)0, T(0))));
+        AGPCHK((syrk_tn<T, SY_PACK>(ctx, g.kappa, mp, mp, Bq, wbuf + l * Bp, 0, sl + mp, mp, (T*)nullptr,
+                                    (const T*)nullptr, (int64_t)0, T(0))));
       }
       LAUNCHCHK(ctx);
     }
@@ -1759,7 +1877,7 @@ struct Svgp : SvgpBase {
   }
   agp_status stats_ptr(void** p, int64_t* n) override {
     *p = stats;
-    *n = (int64_t)nl * (mp + mp * mp);
+    *n = (int64_t)nl * stats_stride();
     return AGP_OK;
   }
 
@@ -1796,11 +1914,11 @@ struct Svgp : SvgpBase {
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
       if (!fused) {
-        const T* sl = stats + l * (mp + mp * mp);
+        const T* sl = stats + l * stats_stride();
         hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, 0, (const T*)nullptr, (int64_t)0, sl,
-                           (const T*)(g.on ? g.kinv_mu0_on : g.kinv_mu0), g.eta1, lr, (T*)nullptr);
-        hipLaunchKernelGGL((k_eta2_from_stats<T>), grid1(mp * mp), dim3(256), 0, st(), sl + mp, mp, g.eta2,
-                           (const T*)(g.on ? g.Kinv_on : g.Kinv), g.La, lr);
+                           kinv_mu0_step(g), g.eta1, lr, (T*)nullptr);
+        hipLaunchKernelGGL((k_eta2_from_packed<T>), dim3((unsigned)((mp / TILE) * (mp / TILE + 1) / 2)), dim3(256), 0, st(),
+                           sl + mp, mp, g.eta2, kinv_step(g), g.La, lr);
         LAUNCHCHK(ctx);
       }
       g.la_state = 0;  // La now holds the new -2*eta2 (unfactored); it is factored inside the next local phase
@@ -1829,6 +1947,10 @@ struct Svgp : SvgpBase {
     if (flags & FLAG_NEG_KTILDE) {
       ctx->err = "K~ has negative values";  // latentgp.jl:213
       return AGP_ERR_NEG_KTILDE;
+    }
+    if (flags & FLAG_BAD_LABEL) {
+      ctx->err = "class label outside the likelihood's classes";  // multiclass.jl:81-83
+      return AGP_ERR_LABELS;
     }
     if (info < 0) {
       ctx->err = "task-graph factorisation aborted: a tile dependency never arrived (spin limit)";
@@ -1940,11 +2062,14 @@ struct Svgp : SvgpBase {
       Latent& g = lat[l];
       AGPCHK(materialize(g));
       hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.DgA, m, scal_dev + 2);
-      AGPCHK(frob_dot((const T*)g.Kinv, (const T*)g.Sigma, mp, m, scal_dev + 3));
+      // objective(model, state, y) reads the state's kernel matrices -- the frozen ones under AGP_FLAG_STALE_K; the external
+      // ELBO(model, X, y) recomputes them (ELBO.jl:32-47)
+      const bool use_stale = g.stale_on && !fresh;
+      AGPCHK(frob_dot((const T*)(use_stale ? g.sKinv : g.Kinv), (const T*)g.Sigma, mp, m, scal_dev + 3));
       hipLaunchKernelGGL((k_axpby<T>), grid1(mp), dim3(256), 0, st(), mp, T(1), (const T*)g.mu, T(-1), (const T*)g.mu0,
                          tmpv);
-      hipLaunchKernelGGL((k_trmv_lower<T>), grid1(mp * 64), dim3(256), 0, st(), (const T*)g.Xk, mp, mp, (const T*)tmpv,
-                         pw0);
+      hipLaunchKernelGGL((k_trmv_lower<T>), grid1(mp * 64), dim3(256), 0, st(), (const T*)(use_stale ? g.sXk : g.Xk), mp, mp,
+                         (const T*)tmpv, pw0);
       hipLaunchKernelGGL((k_sumsq<T>), dim3(1), dim3(1024), 0, st(), (const T*)pw0, mp, scal_dev + 4);
       LAUNCHCHK(ctx);
       double h[5];
@@ -1954,7 +2079,7 @@ struct Svgp : SvgpBase {
         e_data = mo ? mo_e : h[0];
         kl_aug = mo ? mo_kl : h[1];
       }
-      const double logdetK = 2.0 * g.half_logdetK, logdetS = -2.0 * h[2];
+      const double logdetK = 2.0 * (use_stale ? g.s_half_logdetK : g.half_logdetK), logdetS = -2.0 * h[2];
       kl_gauss += 0.5 * (logdetK - logdetS + h[3] + h[4] - (double)m);
       if (g.on) {
         double ek = 0.0;
@@ -2012,10 +2137,46 @@ struct Svgp : SvgpBase {
     return refactor(g);
   }
 
-  agp_status get_matrix(int l, int which, void* out, int64_t ldo) override {
-    if (l < 0 || l >= nl || !out) return AGP_ERR_INVALID;
+  int64_t last_batch() override { return B_last; }
+  // init_state(model) (src/training/states.jl:1-9), what train! does when called without a state: fresh local variables
+  // (LogisticSoftMax alpha = K, states.jl:11-31 -> logisticsoftmax.jl:43-53), RobbinsMonro counters back to 1 (states.jl:61-84,
+  // optimisers.jl:12) and new hyper-optimiser states.  The posterior (eta1, eta2) belongs to the model, not the state: kept.
+  agp_status init_state() override {
+    n_opt = 1;
+    const T kk = (T)(lp.kind == AGP_LIK_LOGISTICSOFTMAX ? desc.lik.n_class : 1);
+    hipLaunchKernelGGL((k_fill<T>), grid1(Bp), dim3(256), 0, st(), alpha, Bp, kk);
+    LAUNCHCHK(ctx);
+    for (auto& g : lat) {
+      g.k_m.clear();
+      g.k_v.clear();
+      g.k_step = 0;
+      g.z_step = 0;
+      if (g.z_am) {
+        HIPCHK(ctx, hipMemsetAsync(g.z_am, 0, sizeof(double) * m * D, st()));
+        HIPCHK(ctx, hipMemsetAsync(g.z_av, 0, sizeof(double) * m * D, st()));
+      }
+    }
+    return invalidate_data();
+  }
+  // the caller refilled / mutated X (or y) in place: nothing cached from it may be reused (AnalyticVI kappa cache, look-ahead)
+  agp_status invalidate_data() override {
+    for (auto& g : lat) g.kappa_valid = false;
+    pf_valid = false;
+    x_last = nullptr;
+    idx_last = nullptr;
+    return AGP_OK;
+  }
+
+  agp_status get_matrix(int l, int which, void* out, int64_t ldo, int64_t cap) override {
+    if (l < 0 || l >= nl || !out || cap <= 0) return AGP_ERR_INVALID;
     Latent& g = lat[l];
     const int64_t B = B_last;
+    const bool m_sized = which == AGP_MAT_L || which == AGP_MAT_KINV;
+    if (m_sized ? cap < m : (which != AGP_VEC_ALPHA && (B <= 0 || cap < B))) {
+      ctx->err = "agp_svgp_get_matrix: output capacity " + std::to_string(cap) + " is smaller than what the last batch left (" +
+                 std::to_string(m_sized ? m : B) + ")";
+      return AGP_ERR_INVALID;
+    }
     auto copy2 = [&](const T* src, int64_t lds, int64_t rows, int64_t cols) -> agp_status {
       if (ldo < cols) return AGP_ERR_INVALID;
       HIPCHK(ctx, hipMemcpy2DAsync(out, sizeof(T) * ldo, src, sizeof(T) * lds, sizeof(T) * cols, rows,
@@ -2056,8 +2217,8 @@ struct Svgp : SvgpBase {
         return copy1(cbuf + l * Bp, B);
       case AGP_VEC_GAMMA:
         return copy1(gamma + l * Bp, B);
-      case AGP_VEC_ALPHA:
-        return copy1(alpha, B);
+      case AGP_VEC_ALPHA:  // state carried across minibatches: exported by capacity, not by the last batch
+        return copy1(alpha, std::min<int64_t>(cap, Bmax));
       default:
         return AGP_ERR_INVALID;
     }
@@ -2294,6 +2455,172 @@ struct Svgp : SvgpBase {
     }
   }
 
+
+  // ---- full predictive covariance (predict_f(...; cov=true, diag=false), predictions.jl:45-49) ------------------------
+  //   cov = K** + jitt I - K*m (K^-1 - K^-1 Sigma K^-1) Km*      (K*m materialised: meant for small n_t)
+  agp_status predict_f_cov(const void* xt, int64_t ldx, int64_t nt, void* mu_out, void* cov_out) override {
+    if (!xt || nt <= 0 || nt > 8192 || ldx < D || !mu_out || !cov_out) return AGP_ERR_INVALID;
+    if (mo) {
+      ctx->err = "full predictive covariance is per latent: not defined for the mixed outputs of a multi-output model here";
+      return AGP_ERR_UNSUPPORTED;
+    }
+    AGPCHK(predict_f_latent(xt, ldx, nt, mu_out, nullptr));
+    const int64_t nq = rup64(nt);
+    T *Ks = nullptr, *T1 = nullptr, *Kss = nullptr, *Cq = nullptr;
+    AGPCHK(dmalloc(ctx, &Ks, nq * mp));
+    AGPCHK(dmalloc(ctx, &T1, nq * mp));
+    AGPCHK(dmalloc(ctx, &Kss, nq * nq));
+    AGPCHK(dmalloc(ctx, &Cq, nq * nq));
+    agp_status rc = AGP_OK;
+    for (int l = 0; l < nl && rc == AGP_OK; ++l) {
+      Latent& g = lat[l];
+      rc = ensure_pred(g, true);
+      if (rc != AGP_OK) break;
+      dim3 gk((unsigned)(mp / TILE), (unsigned)(nq / TILE));
+      hipLaunchKernelGGL((k_kernelmatrix<T>), gk, dim3(NTHREADS), 0, st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt,
+                         (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, Ks, mp, nq, mp, 0, T(0),
+                         (const T*)nullptr, (T*)nullptr, (int64_t)0);
+      dim3 gs((unsigned)(nq / TILE), (unsigned)(nq / TILE));
+      hipLaunchKernelGGL((k_kernelmatrix<T>), gs, dim3(NTHREADS), 0, st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt,
+                         (const T*)xt, ldx, nt, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, Kss, nq, nq, nq, 1,
+                         (T)jitter, (const T*)nullptr, (T*)nullptr, (int64_t)0);
+      rc = gemm_nt<T, EPI_STORE>(ctx, Ks, mp, g.Apred, mp, nq, mp, mp, 0, T1, mp, nullptr, 0, nullptr, nullptr, nullptr, 0);
+      if (rc != AGP_OK) break;
+      rc = gemm_nt<T, EPI_EMINUS>(ctx, T1, mp, Ks, mp, nq, nq, mp, 0, Cq, nq, Kss, nq, nullptr, nullptr, nullptr, 0);
+      if (rc != AGP_OK) break;
+      if (hipMemcpy2DAsync((T*)cov_out + (int64_t)l * nt * nt, sizeof(T) * nt, Cq, sizeof(T) * nq, sizeof(T) * nt, nt,
+                           hipMemcpyDeviceToDevice, st()) != hipSuccess)
+        rc = AGP_ERR_HIP;
+    }
+    (void)hipStreamSynchronize(st());
+    dfree(Ks);
+    dfree(T1);
+    dfree(Kss);
+    dfree(Cq);
+    return rc;
+  }
+
+  // ---- multi-GPU drivers behind the ABI (include/agp_hip.h "multi-GPU") -----------------------
+  agp_status comm_sum(agp_comm* cm, void* buf, int64_t count) {
+    if (!cm || cm->world <= 1) return AGP_OK;
+    if (cm->ctx != ctx) {
+      ctx->err = "agp_comm belongs to another ctx (its collectives would run on another stream)";
+      return AGP_ERR_INVALID;
+    }
+    return agp_comm_allreduce(cm, buf, count, sizeof(T) == 8 ? AGP_F64 : AGP_F32);
+  }
+
+  agp_status cavi_step_multi(agp_comm* cm, int mode, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B,
+                             double rho) override {
+    if (mode != AGP_SHARD_LATENT && mode != AGP_SHARD_BATCH) return AGP_ERR_INVALID;
+    const bool multi = cm && cm->world > 1;
+    if (multi && (lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_HETEROSCEDASTIC)) {
+      // their lambda update (poisson.jl:78, heteroscedastic.jl:95) is a reduction over the whole minibatch that is not
+      // exchanged; the two heteroscedastic latents are coupled point-wise and stay on one handle
+      ctx->err = "Poisson / Heteroscedastic likelihoods are not wired for multi-GPU sharding";
+      return AGP_ERR_UNSUPPORTED;
+    }
+    if (mode == AGP_SHARD_BATCH && mo_sharded) return AGP_ERR_INVALID;
+    AGPCHK(step_local(x, ldx, y, idx, B, rho, false));
+    const bool lsm = lp.kind == AGP_LIK_LOGISTICSOFTMAX;
+    if (mode == AGP_SHARD_LATENT) {
+      if (lsm) {
+        for (int it = 0; it < 2; ++it) {  // the (gamma, alpha) fixed point needs sum_k gamma_k over ALL latents
+          AGPCHK(lsm_gamma());
+          AGPCHK(comm_sum(cm, gsum, B_last));
+          AGPCHK(lsm_alpha());
+        }
+      }
+      if (mo_sharded) {
+        AGPCHK(comm_sum(cm, fall, (int64_t)2 * qtot * Bp));
+        AGPCHK(mo_mix());
+      }
+      AGPCHK(step_stats(true));  // each latent is whole on its rank: the fused natural-gradient step applies
+      return step_global(true);
+    }
+    if (lsm) {
+      for (int it = 0; it < 2; ++it) {  // all latents are local: the fixed point is per point, nothing to exchange
+        AGPCHK(lsm_gamma());
+        AGPCHK(lsm_alpha());
+      }
+    }
+    if (!multi) {
+      AGPCHK(step_stats(true));
+      return step_global(true);
+    }
+    AGPCHK(step_stats(false));
+    AGPCHK(comm_sum(cm, stats, (int64_t)nl * stats_stride()));
+    return step_global(false);
+  }
+
+  agp_status elbo_multi(agp_comm* cm, int mode, double* out) override {
+    if (!out || !x_last || B_last <= 0) return AGP_ERR_INVALID;
+    if (mo_sharded) {
+      AGPCHK(mo_refresh_f());
+      AGPCHK(comm_sum(cm, fall, (int64_t)2 * qtot * Bp));
+    }
+    double mine = 0.0;
+    AGPCHK(elbo(x_last, ldx_last, y_last, idx_last, B_last, rho_last, 0, &mine));
+    if (!cm || cm->world <= 1) {
+      *out = mine;
+      return AGP_OK;
+    }
+    // scalars travel as doubles through a small device buffer (scal_dev[56..59])
+    double h[2] = {mode == AGP_SHARD_LATENT ? mine : e_data, mode == AGP_SHARD_LATENT ? 0.0 : kl_aug};
+    HIPCHK(ctx, hipMemcpyAsync(scal_dev + 56, h, sizeof(double) * 2, hipMemcpyHostToDevice, st()));
+    AGPCHK(agp_comm_allreduce(cm, scal_dev + 56, 2, AGP_F64));
+    HIPCHK(ctx, hipMemcpyAsync(h, scal_dev + 56, sizeof(double) * 2, hipMemcpyDeviceToHost, st()));
+    HIPCHK(ctx, hipStreamSynchronize(st()));
+    *out = mode == AGP_SHARD_LATENT ? h[0] : rho_last * h[0] - kl_gauss_last - rho_last * h[1];
+    return AGP_OK;
+  }
+
+  double* hy_tied = nullptr;  // [1 + D + m*D] doubles: summed gradient of the tied-Z mode
+  agp_status hyper_step_multi(agp_comm* cm, int tied) override {
+    if (!hy_k && !hy_z) return AGP_OK;
+    if (!tied) {
+      if (mo_sharded) {  // the mixed data term of the gradient reads every latent's mean_f under the updated posterior
+        AGPCHK(mo_refresh_f());
+        AGPCHK(comm_sum(cm, fall, (int64_t)2 * qtot * Bp));
+      }
+      return hyper_step();
+    }
+    const int64_t ng = 1 + D + m * D;
+    if (!hy_tied) AGPCHK(dmalloc(ctx, &hy_tied, ng));
+    HIPCHK(ctx, hipMemsetAsync(hy_tied, 0, sizeof(double) * ng, st()));
+    std::vector<double> hs(1 + D, 0.0);
+    for (int l = 0; l < nl; ++l) {
+      AGPCHK(hypergrad(l, nullptr, nullptr, nullptr));
+      for (int64_t i = 0; i < 1 + D; ++i) hs[i] += hy_last[i];
+      hipLaunchKernelGGL((k_acc_to_double<T>), grid1(m * D), dim3(256), 0, st(), m * D, (const T*)hy_dZ, hy_tied + 1 + D);
+      LAUNCHCHK(ctx);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(hy_tied, hs.data(), sizeof(double) * (1 + D), hipMemcpyHostToDevice, st()));
+    if (cm && cm->world > 1) AGPCHK(agp_comm_allreduce(cm, hy_tied, ng, AGP_F64));
+    HIPCHK(ctx, hipMemcpyAsync(hs.data(), hy_tied, sizeof(double) * (1 + D), hipMemcpyDeviceToHost, st()));
+    hipLaunchKernelGGL((k_double_to<T>), grid1(m * D), dim3(256), 0, st(), m * D, (const double*)(hy_tied + 1 + D), hy_dZ);
+    LAUNCHCHK(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(st()));
+    for (int l = 0; l < nl; ++l) AGPCHK(hyper_apply_one(l, hs, (const T*)hy_dZ));
+    return hyper_finish();
+  }
+
+  agp_status predict_multi(agp_comm* cm, int what, const void* xt, int64_t ldx, int64_t nt, void* mu, void* var,
+                           const double* nodes, const double* weights, int nn) override {
+    if (what < 0 || what > 2 || !mu || (what == 2 && !var)) return AGP_ERR_INVALID;
+    if (!mo_sharded) {  // nothing is sharded on the prediction side: the plain calls apply
+      if (what == 0) return predict_f(xt, ldx, nt, mu, var);
+      if (what == 1) return predict_y(xt, ldx, nt, mu);
+      return proba_y(xt, ldx, nt, nodes, weights, nn, mu, var);
+    }
+    void* v = what == 1 ? nullptr : var;
+    AGPCHK(predict_f(xt, ldx, nt, mu, v));  // partial mix over the owned columns of A
+    AGPCHK(comm_sum(cm, mu, (int64_t)nT * nt));
+    if (v) AGPCHK(comm_sum(cm, v, (int64_t)nT * nt));
+    if (what == 0) return AGP_OK;
+    return mo_predict_from_f(nt, what == 1 ? 0 : 1, mu, var, nodes, weights, nn);
+  }
+
   agp_status proba_y_single(const void* xt, int64_t ldx, int64_t nt, const double* nodes, const double* weights, int nn,
                             void* o0, void* o1) {
     AGPCHK(predict_f(xt, ldx, nt, pmu, pvar));
@@ -2346,7 +2673,11 @@ agp_status agp_ctx_create(int32_t device, void* hip_stream, agp_ctx** out) {
   *out = nullptr;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return AGP_ERR_HIP;
-  if (hipSetDevice(device) != hipSuccess) return AGP_ERR_HIP;
+  {
+    DevGuard guard(device);  // touches the device once (creates its primary context) and puts the caller's back
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != device) return AGP_ERR_HIP;
+  }
   agp_ctx* c = new agp_ctx();
   c->device = device;
   c->stream = (hipStream_t)hip_stream;
@@ -2355,7 +2686,9 @@ agp_status agp_ctx_create(int32_t device, void* hip_stream, agp_ctx** out) {
 }
 
 agp_status agp_ctx_destroy(agp_ctx* ctx) {
-  if (ctx && (ctx->tri_scratch || ctx->dag_flags || ctx->hset[0])) {
+  if (!ctx) return AGP_OK;
+  DevGuard guard(ctx->device);
+  if (ctx->tri_scratch || ctx->dag_flags || ctx->hset[0]) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->dag_flags) (void)hipFree(ctx->dag_flags);
     for (int q = 0; q < 2; ++q)
@@ -2368,6 +2701,7 @@ agp_status agp_ctx_destroy(agp_ctx* ctx) {
 
 agp_status agp_ctx_sync(agp_ctx* ctx) {
   if (!ctx) return AGP_ERR_INVALID;
+  DevGuard guard(ctx->device);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return AGP_OK;
 }
@@ -2709,6 +3043,7 @@ static agp_status bb_kmeans(agp_ctx* ctx, const void* xv, int64_t n, int64_t ldx
 
 #define DISPATCH(dtype, call_f64, call_f32)        \
   do {                                             \
+    DevGuard _dev_guard(ctx->device);              \
     if ((dtype) == AGP_F64) return call_f64;       \
     if ((dtype) == AGP_F32) return call_f32;       \
     return AGP_ERR_INVALID;                        \
@@ -2770,12 +3105,14 @@ agp_status agp_kmeans(agp_ctx* ctx, int32_t dtype, const void* x, int64_t n, int
 
 agp_status agp_dev_diag_bench(agp_ctx* ctx, int32_t dtype, int32_t variant, int32_t blocks, int32_t reps, double* us) {
   if (!ctx || !us) return AGP_ERR_INVALID;
+  DevGuard guard(ctx->device);
   if (dtype == AGP_F64) return variant ? bb_diag_bench<double, 1>(ctx, blocks, reps, us) : bb_diag_bench<double, 0>(ctx, blocks, reps, us);
   return variant ? bb_diag_bench<float, 1>(ctx, blocks, reps, us) : bb_diag_bench<float, 0>(ctx, blocks, reps, us);
 }
 
 agp_status agp_svgp_create(agp_ctx* ctx, const agp_svgp_desc* desc, agp_svgp** out) {
   if (!ctx || !desc || !out) return AGP_ERR_INVALID;
+  DevGuard guard(ctx->device);
   *out = nullptr;
   SvgpBase* impl = nullptr;
   if (desc->dtype == AGP_F64) impl = new Svgp<double>();
@@ -2796,14 +3133,16 @@ agp_status agp_svgp_create(agp_ctx* ctx, const agp_svgp_desc* desc, agp_svgp** o
 
 agp_status agp_svgp_destroy(agp_svgp* h) {
   if (!h) return AGP_OK;
+  DevGuard guard(h->impl->ctx->device);
   (void)hipStreamSynchronize(h->impl->ctx->stream);
   delete h->impl;
   delete h;
   return AGP_OK;
 }
 
-#define HCHK(h) \
-  if (!(h) || !(h)->impl) return AGP_ERR_INVALID
+#define HCHK(h)                                    \
+  if (!(h) || !(h)->impl) return AGP_ERR_INVALID;  \
+  DevGuard _dev_guard((h)->impl->ctx->device)
 
 agp_status agp_svgp_set_kernel(agp_svgp* h, int32_t latent, const agp_kernel_desc* k) {
   HCHK(h);
@@ -2823,7 +3162,7 @@ agp_status agp_svgp_set_prior_mean(agp_svgp* h, int32_t latent, const void* mu0)
 }
 agp_status agp_svgp_refresh_K(agp_svgp* h) {
   HCHK(h);
-  return h->impl->refresh_K();
+  return h->impl->refresh_K_explicit();
 }
 agp_status agp_svgp_set_opt_state(agp_svgp* h, int64_t n) {
   HCHK(h);
@@ -2968,9 +3307,27 @@ agp_status agp_svgp_set_state(agp_svgp* h, int32_t latent, const void* eta1, con
   HCHK(h);
   return h->impl->set_state(latent, eta1, eta2);
 }
-agp_status agp_svgp_get_matrix(agp_svgp* h, int32_t latent, int32_t which, void* out, int64_t ldo) {
+agp_status agp_svgp_get_matrix(agp_svgp* h, int32_t latent, int32_t which, void* out, int64_t ldo, int64_t cap) {
   HCHK(h);
-  return h->impl->get_matrix(latent, which, out, ldo);
+  return h->impl->get_matrix(latent, which, out, ldo, cap);
+}
+agp_status agp_svgp_last_batch(agp_svgp* h, int64_t* B_host) {
+  HCHK(h);
+  if (!B_host) return AGP_ERR_INVALID;
+  *B_host = h->impl->last_batch();
+  return AGP_OK;
+}
+agp_status agp_svgp_invalidate_data(agp_svgp* h) {
+  HCHK(h);
+  return h->impl->invalidate_data();
+}
+agp_status agp_svgp_init_state(agp_svgp* h) {
+  HCHK(h);
+  return h->impl->init_state();
+}
+agp_status agp_svgp_predict_f_cov(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* mu_out, void* cov_out) {
+  HCHK(h);
+  return h->impl->predict_f_cov(xt, ldx, n_t, mu_out, cov_out);
 }
 agp_status agp_svgp_predict_f(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* mu_out, void* var_out) {
   HCHK(h);
@@ -2992,13 +3349,13 @@ agp_status agp_svgp_online_snapshot(agp_svgp* h, int32_t latent, void* invDa_out
 }
 agp_status agp_svgp_adopt_local(agp_svgp* dst, agp_svgp* src) {
   HCHK(dst);
-  HCHK(src);
+  if (!src || !src->impl) return AGP_ERR_INVALID;
   return dst->impl->adopt_local(src->impl);
 }
 agp_status agp_svgp_online_first_step(agp_svgp* h_new, agp_svgp* h_old, const void* x, int64_t ldx, const void* y,
                                       int64_t B) {
   HCHK(h_new);
-  HCHK(h_old);
+  if (!h_old || !h_old->impl) return AGP_ERR_INVALID;
   SvgpBase *n = h_new->impl, *o = h_old->impl;
   // local update of the new batch under the OLD inducing points and posterior (compute_old_matrices, onlinetraining.jl:80-89)
   AGPCHK(o->step_local(x, ldx, y, nullptr, B, 1.0, true));
@@ -3041,6 +3398,170 @@ agp_status agp_svgp_get_lik_param(agp_svgp* h, double* out) {
 agp_status agp_svgp_set_lik_param(agp_svgp* h, double value) {
   HCHK(h);
   return h->impl->set_lik_param(value);
+}
+
+
+// ---- collectives (agp_comm.h) ------------------------------------------------------------------------------------
+agp_status agp_comm_unique_id(uint8_t* id_host) {
+  if (!id_host) return AGP_ERR_INVALID;
+  std::string why;
+  RcclApi* api = rccl_api(why);
+  if (!api) return AGP_ERR_UNSUPPORTED;
+  ncclUniqueId id;
+  if (api->GetUniqueId(&id) != ncclSuccess) return AGP_ERR_HIP;
+  static_assert(sizeof(id) == AGP_COMM_ID_BYTES, "ncclUniqueId size");
+  memcpy(id_host, &id, sizeof(id));
+  return AGP_OK;
+}
+
+agp_status agp_comm_init(agp_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id_host, agp_comm** out) {
+  if (!ctx || !out || !id_host || world < 1 || rank < 0 || rank >= world) return AGP_ERR_INVALID;
+  *out = nullptr;
+  DevGuard guard(ctx->device);
+  std::string why;
+  RcclApi* api = rccl_api(why);
+  if (!api) {
+    ctx->err = "agp_comm_init: " + why;
+    return AGP_ERR_UNSUPPORTED;
+  }
+  ncclUniqueId id;
+  memcpy(&id, id_host, sizeof(id));
+  ncclComm_t c = nullptr;
+  ncclResult_t r = api->CommInitRank(&c, world, id, rank);  // binds to the current device = ctx->device
+  if (r != ncclSuccess) {
+    ctx->err = std::string("ncclCommInitRank : ") + api->GetErrorString(r) + " [" + api->where + "]";
+    return AGP_ERR_HIP;
+  }
+  agp_comm* cm = new agp_comm();
+  cm->ctx = ctx;
+  cm->rank = rank;
+  cm->world = world;
+  cm->kind = 0;
+  cm->nccl = c;
+  *out = cm;
+  return AGP_OK;
+}
+
+agp_status agp_comm_init_callback(agp_ctx* ctx, int32_t rank, int32_t world, agp_allreduce_fn fn, void* user,
+                                  agp_comm** out) {
+  if (!ctx || !out || !fn || world < 1 || rank < 0 || rank >= world) return AGP_ERR_INVALID;
+  agp_comm* cm = new agp_comm();
+  cm->ctx = ctx;
+  cm->rank = rank;
+  cm->world = world;
+  cm->kind = 1;
+  cm->fn = fn;
+  cm->user = user;
+  *out = cm;
+  return AGP_OK;
+}
+
+agp_status agp_comm_destroy(agp_comm* cm) {
+  if (!cm) return AGP_OK;
+  DevGuard guard(cm->ctx->device);
+  (void)hipStreamSynchronize(cm->ctx->stream);
+  for (auto e : cm->ev) (void)hipEventDestroy(e);
+  if (cm->kind == 0 && cm->nccl) {
+    std::string why;
+    RcclApi* api = rccl_api(why);
+    if (api) (void)api->CommDestroy(cm->nccl);
+  }
+  delete cm;
+  return AGP_OK;
+}
+
+agp_status agp_comm_info(agp_comm* cm, int32_t* rank_host, int32_t* world_host, int32_t* is_rccl_host) {
+  if (!cm) return AGP_ERR_INVALID;
+  if (rank_host) *rank_host = cm->rank;
+  if (world_host) *world_host = cm->world;
+  if (is_rccl_host) *is_rccl_host = cm->kind == 0;
+  return AGP_OK;
+}
+
+agp_status agp_comm_allreduce(agp_comm* cm, void* buf, int64_t count, int32_t dtype) {
+  if (!cm || !buf || count <= 0 || (dtype != AGP_F64 && dtype != AGP_F32)) return AGP_ERR_INVALID;
+  agp_ctx* ctx = cm->ctx;
+  DevGuard guard(ctx->device);
+  cm->n_calls += 1;
+  cm->bytes += count * (dtype == AGP_F64 ? 8 : 4);
+  if (cm->timing) {
+    if (cm->ev_used + 2 > cm->ev.size())
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t e;
+        HIPCHK(ctx, hipEventCreate(&e));
+        cm->ev.push_back(e);
+      }
+    HIPCHK(ctx, hipEventRecord(cm->ev[cm->ev_used], ctx->stream));
+  }
+  if (cm->kind == 0) {
+    std::string why;
+    RcclApi* api = rccl_api(why);
+    if (!api) return AGP_ERR_UNSUPPORTED;
+    ncclResult_t r = api->AllReduce(buf, buf, (size_t)count, dtype == AGP_F64 ? ncclFloat64 : ncclFloat32, ncclSum, cm->nccl,
+                                    ctx->stream);
+    if (r != ncclSuccess) {
+      ctx->err = std::string("ncclAllReduce : ") + api->GetErrorString(r);
+      return AGP_ERR_HIP;
+    }
+  } else {
+    const int32_t r = cm->fn(cm->user, buf, count, dtype, (void*)ctx->stream);
+    if (r != 0) {
+      ctx->err = "agp_comm: the host all-reduce callback failed with code " + std::to_string(r);
+      return AGP_ERR_HIP;
+    }
+  }
+  if (cm->timing) {
+    HIPCHK(ctx, hipEventRecord(cm->ev[cm->ev_used + 1], ctx->stream));
+    cm->ev_used += 2;
+  }
+  return AGP_OK;
+}
+
+agp_status agp_comm_timing(agp_comm* cm, int32_t on) {
+  if (!cm) return AGP_ERR_INVALID;
+  cm->timing = on != 0;
+  return AGP_OK;
+}
+
+agp_status agp_comm_stats(agp_comm* cm, int64_t* n_calls_host, int64_t* bytes_host, double* ms_host) {
+  if (!cm) return AGP_ERR_INVALID;
+  agp_ctx* ctx = cm->ctx;
+  DevGuard guard(ctx->device);
+  if (n_calls_host) *n_calls_host = cm->n_calls;
+  if (bytes_host) *bytes_host = cm->bytes;
+  double ms = 0.0;
+  if (cm->ev_used) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i + 1 < cm->ev_used; i += 2) {
+      float t = 0;
+      HIPCHK(ctx, hipEventElapsedTime(&t, cm->ev[i], cm->ev[i + 1]));
+      ms += t;
+    }
+  }
+  if (ms_host) *ms_host = ms;
+  cm->n_calls = cm->bytes = 0;
+  cm->ev_used = 0;
+  return AGP_OK;
+}
+
+agp_status agp_svgp_cavi_step_multi(agp_svgp* h, agp_comm* comm, int32_t mode, const void* x, int64_t ldx, const void* y,
+                                    const int64_t* idx, int64_t B, double rho) {
+  HCHK(h);
+  return h->impl->cavi_step_multi(comm, mode, x, ldx, y, idx, B, rho);
+}
+agp_status agp_svgp_elbo_multi(agp_svgp* h, agp_comm* comm, int32_t mode, double* elbo_host) {
+  HCHK(h);
+  return h->impl->elbo_multi(comm, mode, elbo_host);
+}
+agp_status agp_svgp_hyper_step_multi(agp_svgp* h, agp_comm* comm, int32_t tied) {
+  HCHK(h);
+  return h->impl->hyper_step_multi(comm, tied);
+}
+agp_status agp_svgp_predict_multi(agp_svgp* h, agp_comm* comm, int32_t what, const void* xt, int64_t ldx, int64_t n_t,
+                                  void* mu_out, void* var_out, const double* gh_nodes_host, const double* gh_weights_host,
+                                  int32_t n_nodes) {
+  HCHK(h);
+  return h->impl->predict_multi(comm, what, xt, ldx, n_t, mu_out, var_out, gh_nodes_host, gh_weights_host, n_nodes);
 }
 
 agp_status agp_svgp_proba_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, const double* gh_nodes_host,

@@ -20,7 +20,7 @@ enum {
   LIK_NEGBIN = 8,   // p0 = r
   LIK_HETERO = 9    // two latents (f, g) ; lambda in device memory
 };
-enum { FLAG_NEG_KTILDE = 1 };
+enum { FLAG_NEG_KTILDE = 1, FLAG_BAD_LABEL = 2 };
 
 template <typename T>
 __device__ __forceinline__ T kernel_base(int kind, T d2) {
@@ -404,10 +404,12 @@ template <typename T>
 __global__ void k_lsm_finish(int64_t B, int nl, int64_t ldb, int latent_offset, T rho,
                              const int32_t* __restrict__ ycls, const int64_t* __restrict__ idx,
                              const T* __restrict__ c, const T* __restrict__ gamma, T* __restrict__ theta,
-                             T* __restrict__ r, T* __restrict__ w) {
+                             T* __restrict__ r, T* __restrict__ w, int n_class, int* __restrict__ flags) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= B) return;
   int cls = ycls[idx ? idx[i] : i];
+  // a class index outside the likelihood's K classes has no one-hot row (multiclass.jl:81-83 throws on it)
+  if (cls < 0 || cls >= n_class) atomicOr(flags, FLAG_BAD_LABEL);
   for (int k = 0; k < nl; ++k) {
     T yk = (cls == latent_offset + k) ? T(1) : T(0);
     T g = gamma[k * ldb + i];

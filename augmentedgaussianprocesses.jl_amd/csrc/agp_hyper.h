@@ -273,6 +273,18 @@ __global__ void k_hyper_sum(int64_t B, const T* __restrict__ x, double wgt, doub
   if (threadIdx.x == 0) out[0] += wgt * s;
 }
 
+// tied-Z mode: gradients of several latents are summed (and all-reduced across ranks) in double
+template <typename T>
+__global__ void k_acc_to_double(int64_t n, const T* __restrict__ g, double* __restrict__ acc) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) acc[i] += (double)g[i];
+}
+template <typename T>
+__global__ void k_double_to(int64_t n, const double* __restrict__ a, T* __restrict__ out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (T)a[i];
+}
+
 // ADAM ascent on Z (update_Z!, autotuning_utils.jl:70-76): z += eta * mhat / (sqrt(vhat) + eps)
 template <typename T>
 __global__ void k_adam_ascent(int64_t n, T* __restrict__ z, const T* __restrict__ g, double* __restrict__ am,

@@ -80,7 +80,9 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_gemm_nt(const T* __restrict__
 //                g = -(S + Kinv/2) - eta2 ; eta2 += lr*g ; out(=Amat) = -2*eta2     (both triangles)
 //              lr = RobbinsMonro step (or 1 for AnalyticVI), passed by value.
 // ---------------------------------------------------------------------------------------------------
-enum { SY_STORE = 0, SY_ETA2 = 1 };
+//   SY_PACK  : S -> out as packed lower tiles: tile (ta, tb <= ta) at out + (ta(ta+1)/2 + tb) * 64*64, row-major inside the
+//              tile (the batch-parallel statistics buffer: one triangle travels over xGMI)
+enum { SY_STORE = 0, SY_ETA2 = 1, SY_PACK = 2 };
 
 template <typename T, int MODE, int KG = 1>
 __global__ __launch_bounds__(NTHREADS * KG) void k_syrk_tn(const T* __restrict__ A, int64_t lda, int64_t Kdim,
@@ -129,7 +131,10 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_syrk_tn(const T* __restrict__
   int64_t kBegin = lower_a ? a0 : 0;
   gemm_tile<T, RC, RC, KG>(A + a0, lda, A + b0, lda, kBegin, Kdim, w, acc, smem);
   if (KG > 1 && threadIdx.x >= NTHREADS) return;
-  if (MODE == SY_STORE) {
+  if (MODE == SY_PACK) {
+    T* tp = out + (int64_t)blockIdx.x * (TILE * TILE);
+    acc_foreach<T>(acc, [&](int r, int c, T val) { tp[r * TILE + c] = val; });
+  } else if (MODE == SY_STORE) {
     acc_foreach<T>(acc, [&](int r, int c, T val) {
       int64_t gr = a0 + r, gc = b0 + c;
       if (ta != tb) {
@@ -156,17 +161,28 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_syrk_tn(const T* __restrict__
   }
 }
 
-// eta2 step from an already reduced statistic S (batch-parallel multi-GPU path: S was all-reduced)
+// eta2 step from an already reduced statistic S (batch-parallel multi-GPU path: S was all-reduced), stored as packed lower
+// tiles (SY_PACK layout): grid = nt(nt+1)/2 workgroups of 256 threads.  Diagonal tiles take
+// their lower half as the truth and mirror it, exactly like the fused SY_ETA2 epilogue, so a one-rank run of the phase-split
+// path lands on the fused path's eta2 bit for bit.
 template <typename T>
-__global__ void k_eta2_from_stats(const T* __restrict__ S, int64_t n, T* __restrict__ eta2,
-                                  const T* __restrict__ Kinv, T* __restrict__ Amat, T lr) {
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n * n) return;
-  T e2 = eta2[i];
-  T g = -(S[i] + T(0.5) * Kinv[i]) - e2;
-  e2 += lr * g;
-  eta2[i] = e2;
-  Amat[i] = T(-2) * e2;
+__global__ __launch_bounds__(256) void k_eta2_from_packed(const T* __restrict__ Sp, int64_t ld, T* __restrict__ eta2,
+                                                          const T* __restrict__ Kinv, T* __restrict__ Amat, T lr) {
+  int64_t ta, tb;
+  tri_index(blockIdx.x, ta, tb);
+  const T* tp = Sp + (int64_t)blockIdx.x * (TILE * TILE);
+  for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    if (ta == tb && c > r) continue;
+    const int64_t gr = ta * TILE + r, gc = tb * TILE + c;
+    T e2 = eta2[gr * ld + gc];
+    const T g = -(tp[e] + T(0.5) * Kinv[gr * ld + gc]) - e2;
+    e2 += lr * g;
+    eta2[gr * ld + gc] = e2;
+    eta2[gc * ld + gr] = e2;
+    Amat[gr * ld + gc] = T(-2) * e2;
+    Amat[gc * ld + gr] = T(-2) * e2;
+  }
 }
 
 // W row statistics: out0[i] = sum_j W[i][j]^2 ; out1[i] = sum_j W[i][j] v[j]   (one wave per row)

@@ -39,6 +39,9 @@ class Kernel:
     def __init__(self):
         self.variance = 1.0
         self.transform = None
+        # structure of the Julia object this stands for: `sigma2 * k` is a ScaledKernel with a trainable sigma2, a bare kernel
+        # has none (the reference's hyper step is structural: autotuning.jl:99-118, autotuning_utils.jl:47-67)
+        self.has_variance = False
 
     def __matmul__(self, t):  # k ∘ t
         if not isinstance(t, (ScaleTransform, ARDTransform)):
@@ -54,6 +57,7 @@ class Kernel:
             raise ValueError("kernel variance must be a positive scalar")
         k = copy.deepcopy(self)
         k.variance = k.variance * float(a)
+        k.has_variance = True
         return k
 
     def scales(self, D: int) -> np.ndarray:
@@ -70,6 +74,8 @@ class Kernel:
         d = capi.KernelDesc()
         d.kind = self._kind
         d.variance = self.variance
+        d.has_variance = 1 if self.has_variance else 0
+        d.has_transform = 0 if self.transform is None else 1
         keep = None
         if isinstance(self.transform, ARDTransform):
             keep = (C.c_double * D)(*self.scales(D))

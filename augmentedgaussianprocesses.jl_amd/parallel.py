@@ -15,9 +15,15 @@ The path shards in two ways:
   batch statistics [kappa'(rho g1) | rho kappa' diag(g2) kappa] couple the shards: one all-reduce per step
   (src/inference/analyticVI.jl:168,179), after which every rank applies the identical global step.
 
-The drivers below are backend-agnostic: they talk to an *engine* exposing the phase-split step of the C ABI
-(step_local / lsm_gamma / lsm_alpha / step_stats / step_global) and two tensors (`gsum`, `stats`) that live where the
-process group can reduce them.  `HipEngine` is the product engine (device buffers of libagp_hip.so, zero-copy).
+The product path is behind the C ABI: `Comm` wraps an `agp_comm` (RCCL bound directly by libagp_hip.so, or a host-supplied
+all-reduce) and `HipEngine.step_multi / elbo_multi / hyper_step_multi / predict_multi` are one `agp_svgp_*_multi` call each --
+what a Julia / C host calls too (include/agp_hip.h).  torch.distributed is only the bootstrap channel that
+carries the 128-byte RCCL id from rank 0 to the others (`Comm.rccl_from_torch`), or -- for gloo groups in CPU tests and
+in-process thread groups -- the transport behind a callback communicator (`Comm.from_group`).
+
+The phase-level drivers further down (latent_parallel_step, batch_parallel_step, ...) spell the same plans out over an
+*engine* exposing the phase-split step (step_local / lsm_gamma / lsm_alpha / step_stats / step_global) and the exchange
+tensors; they are what the world_size-2 gloo tests run against a CPU reference engine, and they accept a HipEngine too.
 """
 from __future__ import annotations
 
@@ -27,6 +33,132 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import capi
+
+
+class Comm:
+    """An `agp_comm` (include/agp_hip.h): sum all-reduce across the ranks of a run, enqueued on the model's HIP stream."""
+
+    def __init__(self, model, handle, rank, world, keep=None):
+        self.model, self.h, self.rank, self.world = model, handle, rank, world
+        self._keep = keep  # ctypes callback object must outlive the communicator
+
+    @staticmethod
+    def unique_id() -> bytes:
+        """ncclGetUniqueId through the library (rank 0 calls this; ship the bytes to the other ranks)."""
+        buf = (C.c_uint8 * capi.COMM_ID_BYTES)()
+        st = capi.lib().agp_comm_unique_id(buf)
+        if st != capi.AGP_OK:
+            raise capi.AGPError(st, "agp_comm_unique_id failed (librccl not found?)")
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, model, rank: int, world: int, unique_id: bytes) -> "Comm":
+        """ncclCommInitRank on the model's device; `unique_id` from rank 0's Comm.unique_id()."""
+        ctx = model._ensure_ctx()
+        buf = (C.c_uint8 * capi.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        model._chk(capi.lib().agp_comm_init(ctx, rank, world, buf, C.byref(h)))
+        return cls(model, h, rank, world)
+
+    @classmethod
+    def rccl_from_torch(cls, model, group=None) -> "Comm":
+        """RCCL communicator bootstrapped over an initialised torch.distributed group (any backend): the group only
+        broadcasts the 128-byte id; every collective of the data path is then issued by libagp_hip.so itself."""
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls.rccl(model, rank, world, box[0])
+
+    @classmethod
+    def from_callback(cls, model, rank: int, world: int, fn) -> "Comm":
+        """fn(ptr: int, count: int, dtype: int, stream: int) -> None sums `count` elements in place at the device pointer."""
+        def _cb(user, buf, count, dtype, stream):
+            try:
+                fn(buf, count, dtype, stream)
+                return 0
+            except BaseException as e:  # never unwind through the C frames
+                _cb.error = e
+                return 1
+
+        cb = capi.ALLREDUCE_FN(_cb)
+        ctx = model._ensure_ctx()
+        h = C.c_void_p()
+        model._chk(capi.lib().agp_comm_init_callback(ctx, rank, world, cb, None, C.byref(h)))
+        c = cls(model, h, rank, world, keep=(cb, _cb))
+        return c
+
+    @classmethod
+    def from_group(cls, model, group=None, rank: Optional[int] = None, world: Optional[int] = None) -> "Comm":
+        """Callback communicator over a torch.distributed group (gloo or nccl) or an in-process group exposing
+        all_reduce_sum(tensor) (tests: ranks as threads)."""
+        import torch
+
+        dev = model._dev()
+
+        def view(ptr, count, dtype):
+            ts = "<f8" if dtype == capi.F64 else "<f4"
+            return torch.as_tensor(_DevBuf(ptr, count, ts), device=dev)
+
+        if group is not None and hasattr(group, "all_reduce_sum"):
+            def fn(ptr, count, dtype, stream):
+                group.all_reduce_sum(view(ptr, count, dtype))
+            return cls.from_callback(model, rank, world, fn)
+        import torch.distributed as dist
+
+        r, w = dist.get_rank(group), dist.get_world_size(group)
+        gloo = dist.get_backend(group) == "gloo"
+
+        def fn(ptr, count, dtype, stream):
+            t = view(ptr, count, dtype)
+            if gloo:  # host-staged: gloo reduces host memory
+                hbuf = t.cpu()
+                dist.all_reduce(hbuf, op=dist.ReduceOp.SUM, group=group)
+                t.copy_(hbuf)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return cls.from_callback(model, r, w, fn)
+
+    @property
+    def is_rccl(self) -> bool:
+        f = C.c_int32()
+        capi.lib().agp_comm_info(self.h, None, None, C.byref(f))
+        return bool(f.value)
+
+    def timing(self, on: bool = True):
+        self.model._chk(capi.lib().agp_comm_timing(self.h, 1 if on else 0))
+
+    def stats(self):
+        """(collectives, bytes reduced per rank, summed milliseconds if timing was on) since the last call"""
+        n, b, ms = C.c_int64(), C.c_int64(), C.c_double()
+        self.model._chk(capi.lib().agp_comm_stats(self.h, C.byref(n), C.byref(b), C.byref(ms)))
+        return n.value, b.value, ms.value
+
+    def all_reduce(self, t):
+        """in-place sum of a device tensor (float64 / float32) on the model's stream"""
+        import torch
+
+        dt = capi.F64 if t.dtype == torch.float64 else capi.F32
+        self.model._chk(capi.lib().agp_comm_allreduce(self.h, C.c_void_p(t.data_ptr()), t.numel(), dt))
+        return t
+
+    def _raise_pending(self):
+        if self._keep is not None and getattr(self._keep[1], "error", None) is not None:
+            e = self._keep[1].error
+            self._keep[1].error = None
+            raise e
+
+    def destroy(self):
+        if self.h is not None:
+            capi.lib().agp_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 def latent_slice(n_latent: int, world: int, rank: int):
@@ -335,16 +467,75 @@ class HipEngine:
     def check(self):
         self.model._chk(self.L.agp_svgp_check_status(self.h))
 
+    # ---- the sharded step / ELBO / hyper step / prediction as ONE C-ABI call each (collectives inside the library) ----
+    def _mchk(self, st, comm):
+        if st != capi.AGP_OK and comm is not None:
+            comm._raise_pending()  # a Python exception raised inside the all-reduce callback
+        self.model._chk(st)
+
+    def step_multi(self, idx, rho: float, mode: int, comm: Optional["Comm"] = None):
+        """agp_svgp_cavi_step_multi: mode = capi.SHARD_LATENT (idx = the whole minibatch) or capi.SHARD_BATCH (idx = this
+        rank's share, rho = N / B_total)"""
+        import torch
+
+        idx_t = idx if isinstance(idx, torch.Tensor) else torch.as_tensor(np.asarray(idx, dtype=np.int64),
+                                                                          device=self.model._dev())
+        self._keep = idx_t
+        self._B = idx_t.numel()
+        self.rho = float(rho)
+        st = self.L.agp_svgp_cavi_step_multi(self.h, comm.h if comm is not None else None, mode,
+                                             C.c_void_p(self._X.data_ptr()), self._X.stride(0),
+                                             C.c_void_p(self._y.data_ptr()), C.c_void_p(idx_t.data_ptr()), self._B,
+                                             float(rho))
+        self._mchk(st, comm)
+
+    def elbo_multi(self, mode: int, comm: Optional["Comm"] = None) -> float:
+        out = C.c_double()
+        self._mchk(self.L.agp_svgp_elbo_multi(self.h, comm.h if comm is not None else None, mode, C.byref(out)), comm)
+        return out.value
+
+    def hyper_step_multi(self, comm: Optional["Comm"] = None, tied: bool = False):
+        self._mchk(self.L.agp_svgp_hyper_step_multi(self.h, comm.h if comm is not None else None, 1 if tied else 0), comm)
+
+    def predict_multi(self, X_test, what: str = "f", comm: Optional["Comm"] = None):
+        """predict_f / predict_y / proba_y of a latent-sharded multi-output model (partial mixes all-reduced inside)"""
+        import torch
+
+        from .svgp import _gauss_hermite as _gh
+
+        mdl = self.model
+        Xt = mdl._upload(X_test, 1)
+        nt = Xt.shape[0]
+        mu = torch.empty(mdl.n_task, nt, dtype=mdl.tdtype, device=mdl._dev())
+        var = torch.empty_like(mu) if what != "y" else None
+        nodes, weights = _gh()
+        code = {"f": 0, "y": 1, "proba": 2}[what]
+        st = self.L.agp_svgp_predict_multi(self.h, comm.h if comm is not None else None, code, C.c_void_p(Xt.data_ptr()),
+                                           Xt.stride(0), nt, C.c_void_p(mu.data_ptr()),
+                                           C.c_void_p(var.data_ptr()) if var is not None else None,
+                                           nodes.ctypes.data_as(C.POINTER(C.c_double)),
+                                           weights.ctypes.data_as(C.POINTER(C.c_double)), len(nodes))
+        self._mchk(st, comm)
+        mdl._chk(self.L.agp_ctx_sync(mdl._ctx))
+        if what == "y":
+            return mu.cpu().numpy()
+        return mu.cpu().numpy(), var.cpu().numpy()
+
 
 def train_parallel(model, X, y, iterations: int, idx_stream: Sequence, *, mode: str = "latent", group=None,
-                   obsdim: int = 1) -> HipEngine:
+                   obsdim: int = 1, comm: Optional[Comm] = None) -> HipEngine:
     """train! for a sharded model.  mode="latent": `model` was built with latent_slice=latent_slice(K, world, rank) and
     every rank passes the same idx_stream.  mode="batch": every rank holds the full model and idx_stream entries are the
-    FULL minibatches (each rank takes its share)."""
+    FULL minibatches (each rank takes its share).
+    comm: a `Comm` -- every step is then one agp_svgp_cavi_step_multi call with the collectives inside the library (RCCL);
+    without it the phase-level drivers below run over `group` (torch.distributed)."""
     import torch.distributed as dist
 
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if comm is not None:
+        world, rank = comm.world, comm.rank
+    else:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world > 1 and type(model.likelihood).__name__ in ("PoissonLikelihood", "HeteroscedasticLikelihood"):
         # their lambda update (poisson.jl:78, heteroscedastic.jl:95) is a reduction over the whole minibatch that the sharded
         # drivers do not exchange; the two heteroscedastic latents are coupled point-wise and stay on one handle
@@ -359,7 +550,12 @@ def train_parallel(model, X, y, iterations: int, idx_stream: Sequence, *, mode: 
     model.inference.batchsize = B_local
     for it in range(iterations):
         idx = np.asarray(idx_stream[it])
-        if mode == "latent":
+        if comm is not None:
+            if mode == "latent":
+                eng.step_multi(idx, N / B_total, capi.SHARD_LATENT, comm)
+            else:
+                eng.step_multi(shard_batch(idx, world, rank), N / B_total, capi.SHARD_BATCH, comm)
+        elif mode == "latent":
             latent_parallel_step(eng, idx, N / B_total, group)
         else:
             batch_parallel_step(eng, shard_batch(idx, world, rank), N / B_total, group)

@@ -24,13 +24,15 @@ def _kernel_spec(k):
         raise TypeError(f"cannot serialise kernel {type(k).__name__}")
     ard = isinstance(tr, K.ARDTransform)
     scale = tr.v.tolist() if ard else (float(tr.s) if tr is not None else 1.0)
-    return {"base": type(k).__name__, "variance": float(k.variance), "ard": ard, "scale": scale}
+    return {"base": type(k).__name__, "variance": float(k.variance), "ard": ard, "scale": scale,
+            "has_variance": bool(k.has_variance), "has_transform": tr is not None}
 
 
 def _kernel_from(spec):
     k = _KERNELS[spec["base"]]()
-    k = k @ (K.ARDTransform(np.asarray(spec["scale"])) if spec["ard"] else K.ScaleTransform(spec["scale"]))
-    return spec["variance"] * k
+    if spec.get("has_transform", True):
+        k = k @ (K.ARDTransform(np.asarray(spec["scale"])) if spec["ard"] else K.ScaleTransform(spec["scale"]))
+    return spec["variance"] * k if spec.get("has_variance", True) else k
 
 
 def _lik_spec(l):
@@ -96,7 +98,8 @@ def save_trained_model(filename: str, model: SVGP) -> None:
     if mo:
         arrays["A"] = model.get_A()
     if isinstance(model.likelihood, LK.LogisticSoftMaxLikelihood) and inf.batchsize > 0:
-        arrays["lsm_alpha"] = model.get_matrix(capi.VEC_ALPHA, 0, int(inf.batchsize))  # carried between minibatches
+        # carried between minibatches; exported by capacity (it is state, not a view of the last batch)
+        arrays["lsm_alpha"] = model.get_matrix(capi.VEC_ALPHA, 0, min(int(inf.batchsize), model._max_batch))
     if isinstance(model.mean, (list, np.ndarray)):
         arrays["mean_vec"] = np.asarray(model.mean, dtype=np.float64)
     np.savez_compressed(filename, **arrays)

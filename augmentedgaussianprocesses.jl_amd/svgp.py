@@ -123,10 +123,14 @@ class SVGP:
 
     def __init__(self, kernel, likelihood, inference, Z, *, verbose: int = 0, optimiser=None, atfrequency: int = 1,
                  mean=None, Zoptimiser=False, T=np.float64, device: Optional[int] = None, seed: Optional[int] = None,
-                 elbo_mode: str = "corrected", latent_slice: Optional[tuple] = None):
+                 elbo_mode: str = "corrected", latent_slice: Optional[tuple] = None,
+                 reference_compat_stale_K: bool = False):
         if not isinstance(inference, AnalyticVI):
             raise TypeError("The inference object should be of type `VariationalInference` : either `AnalyticVI` or "
                             "`NumericalVI`")  # SVGP.jl:45-47 (only AnalyticVI exists on this path)
+        # inside one train! the reference keeps the Cholesky of K_ZZ of the first iteration even after
+        # hyper-parameter steps (training.jl:187-208).  False (default): K is refreshed; True: mirror the reference.
+        self.reference_compat_stale_K = bool(reference_compat_stale_K)
         if not isinstance(likelihood, (GaussianLikelihood, LogisticLikelihood, StudentTLikelihood,
                                        LogisticSoftMaxLikelihood, _MultiOutputLikelihood, LaplaceLikelihood,
                                        BayesianSVM, PoissonLikelihood, NegBinomialLikelihood,
@@ -142,6 +146,12 @@ class SVGP:
             if o is not None and not isinstance(o, ADAM):
                 raise NotImplementedError("only ADAM is wired as hyper-parameter optimiser")
         self.k_opt, self.z_opt = optimiser, Zoptimiser
+        if mean is not None and (optimiser is not None or Zoptimiser is not None):
+            # the reference would also step the prior mean here (autotuning.jl:104-106), but calls update!(mu0, grad, state)
+            # against the method update!(mu0, state, grad) (src/mean/constantmean.jl:31): it cannot run.  Not guessed at.
+            raise NotImplementedError("a non-zero prior mean together with hyper-parameter optimisation is not wired: the "
+                                      "reference's prior-mean update (autotuning.jl:104-106) is broken; pass optimiser=False, "
+                                      "Zoptimiser=False or mean=None")
         if mean is not None and not (np.isscalar(mean) or isinstance(mean, (list, np.ndarray))):
             raise TypeError("mean must be None (ZeroMean), a Real (ConstantMean) or a vector (EmpiricalMean)")
         self.likelihood = likelihood
@@ -222,11 +232,22 @@ class SVGP:
         if self._h is not None and max_batch <= self._max_batch:
             return self._h
         old = None
+        carry = {}
         if self._h is not None:
             old = [self.get_state(i) for i in range(self.n_latent)]
             self._pre_destroy()
             n_opt = C.c_int64()
             self._chk(L.agp_svgp_get_opt_state(self._h, C.byref(n_opt)))
+            # the rest of the training state travels too: LogisticSoftMax alpha (carried between minibatches) and the ADAM
+            # moments of the kernel-parameter optimisers (the Z optimiser's device state restarts, like a new parameter array)
+            if isinstance(self.likelihood, LogisticSoftMaxLikelihood):
+                carry["alpha"] = self.get_matrix(capi.VEC_ALPHA, 0, self._max_batch)
+            if self.k_opt is not None:
+                carry["adam"] = []
+                for i in range(self.n_latent):
+                    km, kv, ks = (C.c_double * (1 + self.D))(), (C.c_double * (1 + self.D))(), C.c_int32()
+                    self._chk(L.agp_svgp_hyper_opt_state(self._h, i, 0, km, kv, C.byref(ks)))
+                    carry["adam"].append((km, kv, ks))
             L.agp_svgp_destroy(self._h)
             self._h = None
         d = capi.SvgpDesc()
@@ -240,6 +261,7 @@ class SVGP:
         opt = self.inference.optimiser or RobbinsMonro()
         d.rm_kappa, d.rm_tau = opt.kappa, opt.tau
         d.elbo_mode = capi.ELBO_REFERENCE if self.elbo_mode == "reference" else capi.ELBO_CORRECTED
+        d.flags = capi.FLAG_STALE_K if self.reference_compat_stale_K else 0
         h = C.c_void_p()
         self._chk(L.agp_svgp_create(ctx, C.byref(d), C.byref(h)))
         self._h = h
@@ -260,6 +282,13 @@ class SVGP:
             for i, (mu, Sig, e1, e2) in enumerate(old):
                 self.set_state(i, e1, e2)
             self._chk(L.agp_svgp_set_opt_state(h, n_opt.value))
+            if "alpha" in carry:
+                a = torch.as_tensor(carry["alpha"], dtype=self.tdtype, device=dev).contiguous()
+                self._chk(L.agp_svgp_set_lsm_alpha(h, C.c_void_p(a.data_ptr()), a.numel()))
+                self._chk(L.agp_ctx_sync(ctx))
+            for i, (km, kv, ks) in enumerate(carry.get("adam", [])):
+                if ks.value > 0:
+                    self._chk(L.agp_svgp_hyper_opt_state(h, i, 1, km, kv, C.byref(ks)))
         return h
 
     def _post_create(self, h):
@@ -297,10 +326,11 @@ class SVGP:
             sc = (C.c_double * self.D)()
             self._chk(L.agp_svgp_get_kernel(self._h, i, C.byref(var), sc))
             k = self.kernels[i]
-            k.variance = var.value
+            if k.has_variance:  # only parameters that exist in the kernel object are ever stepped (and written back)
+                k.variance = var.value
             if isinstance(k.transform, ARDTransform):
                 k.transform = ARDTransform(list(sc))
-            else:
+            elif k.transform is not None:
                 k.transform = ScaleTransform(sc[0])
             z = torch.empty(self.m, self.D, dtype=self.tdtype, device=self._dev())
             self._chk(L.agp_svgp_get_Z(self._h, i, C.c_void_p(z.data_ptr()), self.D))
@@ -381,19 +411,26 @@ class SVGP:
         self._chk(capi.lib().agp_svgp_check_status(self._h))
 
     def get_matrix(self, which: int, latent: int = 0, rows: Optional[int] = None):
+        """rows: how many rows / elements of a batch-sized output to fetch (default: the whole last batch).  The library
+        refuses a buffer smaller than the batch the handle last saw (an ELBO on a larger set also counts)."""
         torch = _torch()
         dev = self._dev()
         m = self.m
+        if rows is None and which not in (capi.MAT_L, capi.MAT_KINV):
+            nb = C.c_int64()
+            self._chk(capi.lib().agp_svgp_last_batch(self._h, C.byref(nb)))
+            rows = int(nb.value) if which != capi.VEC_ALPHA else self._max_batch
         if which in (capi.MAT_L, capi.MAT_KINV):
             out = torch.empty(m, m, dtype=self.tdtype, device=dev)
             ld = m
+            rows = m
         elif which in (capi.MAT_KNM, capi.MAT_KAPPA):
             out = torch.empty(rows, m, dtype=self.tdtype, device=dev)
             ld = m
         else:
             out = torch.empty(rows, dtype=self.tdtype, device=dev)
             ld = 1
-        self._chk(capi.lib().agp_svgp_get_matrix(self._h, latent, which, C.c_void_p(out.data_ptr()), ld))
+        self._chk(capi.lib().agp_svgp_get_matrix(self._h, latent, which, C.c_void_p(out.data_ptr()), ld, int(rows)))
         self._chk(capi.lib().agp_ctx_sync(self._ctx))
         return out.cpu().numpy()
 
@@ -510,6 +547,9 @@ def train_(model: SVGP, X, y, iterations: int = 100, *, callback: Optional[Calla
     dev = model._dev()
     if state is None:
         inf.HyperParametersUpdated = True
+        model._chk(L.agp_svgp_init_state(h))  # init_state(model), training.jl:41-45: counters, local variables, optimiser states
+    else:
+        model._chk(L.agp_svgp_invalidate_data(h))  # X / y may be the caller's buffers, possibly refilled since the last call
     model._chk(L.agp_svgp_refresh_K(h))
     local_iter = 1
 
@@ -567,6 +607,7 @@ def train_(model: SVGP, X, y, iterations: int = 100, *, callback: Optional[Calla
         if local_iter > iterations:
             break
     model._chk(L.agp_svgp_check_status(h))
+    model._chk(L.agp_svgp_refresh_K(h))  # compute_Ks(model), training.jl:107: final kernel matrices for predictions
     model._pull_hypers()
     model._pull_lik_state()
     return model, State(model)
@@ -616,12 +657,34 @@ def _predict_f(model: SVGP, X_test, cov: bool, obsdim: int = 1):
     return mu, var
 
 
+def _predict_f_fullcov(model: SVGP, X_test, obsdim: int = 1):
+    """predict_f(...; cov=true, diag=false)  predictions.jl:45-49: (mu_f, Sigma_f) with the full n_t x n_t covariance per
+    latent (K*m is materialised on the device: small n_t only)."""
+    torch = _torch()
+    L = capi.lib()
+    if isinstance(model, MOSVGP):
+        raise NotImplementedError("full predictive covariance of the mixed outputs is not wired")
+    Xd = model._upload(X_test, obsdim)
+    nt = Xd.shape[0]
+    h = model._ensure_handle(max(model._max_batch, 1))
+    dev = model._dev()
+    mu = torch.empty(model.n_latent, nt, dtype=model.tdtype, device=dev)
+    cov = torch.empty(model.n_latent, nt, nt, dtype=model.tdtype, device=dev)
+    model._chk(L.agp_svgp_predict_f_cov(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), nt, C.c_void_p(mu.data_ptr()),
+                                        C.c_void_p(cov.data_ptr())))
+    model._chk(L.agp_ctx_sync(model._ctx))
+    mu_np, cov_np = mu.cpu().numpy(), cov.cpu().numpy()
+    if model.n_latent > 1:
+        return tuple(mu_np), tuple(cov_np)
+    return mu_np[0], cov_np[0]
+
+
 def predict_f(model: SVGP, X_test, state: Optional[State] = None, *, cov: bool = False, diag: bool = True,
               obsdim: int = 1):
-    """predict_f(model, X_test; cov=false, diag=true)  predictions.jl:141-164.  Full covariances (diag=false) are
-    not on the streaming path."""
+    """predict_f(model, X_test; cov=false, diag=true)  predictions.jl:141-164.  diag=False returns the full covariance
+    (not streamed: K*m is materialised, n_t <= 8192)."""
     if cov and not diag:
-        raise NotImplementedError("full predictive covariance (diag=false) is not on the streaming path")
+        return _predict_f_fullcov(model, X_test, obsdim)
     mu, var = _predict_f(model, X_test, cov, obsdim)
     mu_np = mu.cpu().numpy()
     if model.n_out > 1 or isinstance(model, MOSVGP):

@@ -63,6 +63,18 @@ enum {
 /* ELBO variants: Appendix-A Q2 of SURVEY.md (src/likelihood/logistic.jl:82 uses dot(theta, mu)) */
 enum { AGP_ELBO_CORRECTED = 0, AGP_ELBO_REFERENCE = 1 };
 
+/* agp_svgp_desc.flags.
+ * AGP_FLAG_STALE_K ("reference_compat_stale_K"): inside one train! the reference never recomputes
+ * the Cholesky of K_ZZ after a hyper-parameter step -- compute_kernel_matrices (src/training/training.jl:187-208) only does
+ * so while isHPupdated(inference), which update_hyperparameters! for sparse models never sets again (the call is commented
+ * out, src/hyperparameter/autotuning.jl:41-46).  kappa = Knm / K then mixes the NEW kernel and Z (Knm, kdiag) with the OLD
+ * factor, and natural_gradient! uses the old inv(K), until train! ends (compute_Ks, training.jl:107) or restarts without a
+ * state.  The hyper-gradient itself is taken with fresh matrices (ELBO(m, x, y, mu0, ks, Zs, state) recomputes them,
+ * src/functions/ELBO.jl:15-21).  With the flag a hyper step leaves the step-side matrices (L, inv(K), K\mu0) as they are and
+ * only an explicit agp_svgp_refresh_K (what the host calls where train! starts and ends) recomputes them; without it
+ * (default) K is refreshed before the next step. */
+enum { AGP_FLAG_STALE_K = 1 };
+
 /* matrices readable through agp_svgp_get_matrix (for parity tests and the shim's state export) */
 enum {
   AGP_MAT_L = 0,      /* m x m lower Cholesky factor of K_ZZ + jitter I          (state.kernel_matrices.K) */
@@ -87,6 +99,13 @@ typedef struct {
   double variance;             /* sigma2 of `sigma2 * k` (1 if none) */
   double scale;                /* s of ScaleTransform(s) ; with_lengthscale(k, l) == scale 1/l */
   const double* ard_scales_host; /* host pointer, length D, read at call time (only if ard) */
+  /* Structure of the kernel OBJECT, which decides what the hyper-parameter step may touch: the reference differentiates the
+   * kernel structurally (Zygote NamedTuple, autotuning.jl:99-118 -> update_kernel!, autotuning_utils.jl:47-67), so only
+   * parameters that exist are stepped.  has_variance: the kernel is `sigma2 * k` (a ScaledKernel); has_transform: it is
+   * `k o ScaleTransform / ARDTransform` (with_lengthscale included).  A bare SqExponentialKernel() has neither: its
+   * hyper step leaves the kernel untouched (Z may still move).  Evaluation ignores both flags. */
+  int32_t has_variance;
+  int32_t has_transform;
 } agp_kernel_desc;
 
 typedef struct {
@@ -109,7 +128,7 @@ typedef struct {
   double rm_kappa;     /* RobbinsMonro kappa (0.51)  src/inference/optimisers.jl:6 */
   double rm_tau;       /* RobbinsMonro tau   (1)     */
   int32_t elbo_mode;   /* AGP_ELBO_* */
-  int32_t reserved;
+  int32_t flags;       /* AGP_FLAG_* */
 } agp_svgp_desc;
 
 /* ---- context ------------------------------------------------------------------------------------- */
@@ -190,7 +209,8 @@ agp_status agp_svgp_cavi_step(agp_svgp* h, const void* x, int64_t ldx, const voi
  *                 the caller all-reduces gsum across latent-parallel ranks; lsm_alpha sets alpha = 1 + gsum.
  *                 (called twice, as the reference loops twice)
  *   step_stats  : theta, grad_E_mu, grad_E_Sigma and the batch statistics
- *                 stats = [ kappa'(rho g1) (mp) | rho kappa' diag(g2) kappa (mp x mp) ] per latent
+ *                 stats = [ kappa'(rho g1) (mp) | rho kappa' diag(g2) kappa, lower 64x64 tiles packed row by row of tiles:
+ *                 tile (i, j <= i) at offset mp + (i(i+1)/2 + j) * 4096, row-major inside the tile ] per latent
  *                 -- the buffer a batch-parallel run all-reduces (analyticVI.jl:168,179)
  *   step_global : natural-gradient step + (mu, Sigma) refresh      analyticVI.jl:229-246, inference.jl:25-28 */
 agp_status agp_svgp_step_local(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx,
@@ -288,11 +308,29 @@ agp_status agp_svgp_set_batch_shard(agp_svgp* h, int32_t rank, int32_t world);
  * may be NULL.  set_state installs (eta1, eta2) and re-derives (mu, Sigma) (inference.jl:25-28). */
 agp_status agp_svgp_get_state(agp_svgp* h, int32_t latent, void* mu, void* sigma, void* eta1, void* eta2);
 agp_status agp_svgp_set_state(agp_svgp* h, int32_t latent, const void* eta1, const void* eta2);
-agp_status agp_svgp_get_matrix(agp_svgp* h, int32_t latent, int32_t which, void* out, int64_t ldo);
+/* `cap`: capacity of `out` in rows (AGP_MAT_*) or elements (AGP_VEC_*).  The B-sized outputs refer to the batch of the LAST
+ * step / ELBO evaluation (agp_svgp_last_batch) and are refused (AGP_ERR_INVALID) when cap is smaller than that batch;
+ * AGP_VEC_ALPHA is state that outlives a batch: min(cap, max_batch) elements are copied. */
+agp_status agp_svgp_get_matrix(agp_svgp* h, int32_t latent, int32_t which, void* out, int64_t ldo, int64_t cap);
+/* number of points of the last step_local / cavi_step / elbo batch (0 before the first) */
+agp_status agp_svgp_last_batch(agp_svgp* h, int64_t* B_host);
+/* Data contract of the AnalyticVI (full-batch) kappa cache: Knm / kappa of the last step are reused when the next step is
+ * called with the same (x, ldx, idx, B) POINTERS, so X[idx] must not change in place while cached.  A host that refills a
+ * buffer (streaming batches through one allocation, mutating a tensor) calls this first.  Stochastic handles never cache. */
+agp_status agp_svgp_invalidate_data(agp_svgp* h);
+/* init_state(model)  src/training/states.jl:1-9 -- what train! does when it is called WITHOUT a state (training.jl:41-45):
+ * local variables as new (LogisticSoftMax alpha = K), RobbinsMonro counters back to 1, new hyper-optimiser (ADAM) states, data
+ * caches dropped.  The posterior (eta1, eta2), kernels and Z belong to the model and are kept.  A host that resumes with the
+ * state of a previous train! simply does not call it. */
+agp_status agp_svgp_init_state(agp_svgp* h);
 
 /* _predict_f (sparse)  src/training/predictions.jl:25-50 : streams over n_t test points without materialising
  * K_*m.  mu_out / var_out : T[n_latent][n_t] (var_out NULL -> cov=false). */
 agp_status agp_svgp_predict_f(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* mu_out, void* var_out);
+/* predict_f(model, X_test; cov=true, diag=false)  predictions.jl:45-49 : full posterior covariance
+ *   cov = K** + jitt I - K*m (K^-1 - K^-1 Sigma K^-1) Km*   per latent, cov_out : T[n_latent][n_t][n_t] row-major (mu_out as
+ * predict_f).  K*m IS materialised here (n_t x m), so n_t <= 8192 (AGP_ERR_INVALID beyond). */
+agp_status agp_svgp_predict_f_cov(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* mu_out, void* cov_out);
 /* predict_y  predictions.jl:178-198 : regression (Gaussian, StudentT, Laplace, Heteroscedastic) -> T[n_t] mean ;
  * logistic / BayesianSVM -> int32[n_t] (mu_f > 0) ; Poisson / NegBinomial -> T[n_t] expected count (predictions.jl:211) ;
  * LogisticSoftMax -> int32[n_t] argmax_k mu_f,k (0-based LOCAL latent index + latent_offset) */
@@ -342,6 +380,63 @@ agp_status agp_svgp_set_lik_param(agp_svgp* h, double value);
  * LogisticSoftMax -> out0 = T[n_t][K] normalised logistic(mu_f) (multiclass.jl:96-117), out1 unused. */
 agp_status agp_svgp_proba_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, const double* gh_nodes_host,
                             const double* gh_weights_host, int32_t n_nodes, void* out0, void* out1);
+
+/* ---- multi-GPU: one process per GPU, collectives behind the ABI --------------------------------
+ * The path shards in two ways and both reduce to in-place SUM all-reduces of library-owned device buffers:
+ *   AGP_SHARD_LATENT : this handle holds the latent slice [latent_offset, latent_offset + n_latent) of the model, every rank
+ *                      sees the same minibatch.  LogisticSoftMax: sum_k gamma_k (a B-vector) twice per step
+ *                      (src/likelihood/logisticsoftmax.jl:65-72); latent-sharded multi-output: the (mean_f, var_f) exchange
+ *                      buffer once per step (src/models/single_and_multi_output_utils.jl:24-84); otherwise no collective.
+ *   AGP_SHARD_BATCH  : every rank holds all latents and sees ITS SHARE of the minibatch (idx, B are the local share,
+ *                      rho = N / B_total); the batch statistics [kappa'(rho g1) | rho kappa' diag(g2) kappa] (one triangle,
+ *                      packed as 64x64 tiles: mp + nt(nt+1)/2 * 4096 elements per latent, 4.46 MB at m = 1024 f64) are
+ *                      all-reduced once per step (src/inference/analyticVI.jl:168,179), then every rank applies the identical
+ *                      global step.
+ * agp_comm_unique_id : rank 0 draws the id (ncclGetUniqueId) and hands the 128 bytes to the other ranks over whatever host
+ *                      channel exists (MPI, a file, Julia's Distributed, torch.distributed's store).
+ * agp_comm_init      : ncclCommInitRank on ctx's device; collectives are enqueued on ctx's stream (RCCL over xGMI).
+ * agp_comm_init_callback : the host supplies the all-reduce instead (must sum `count` elements of `dtype` in place at the
+ *                      DEVICE pointer `buf`, ordered after the work already enqueued on `hip_stream`; return 0 on success).
+ * All ranks must issue the same sequence of *_multi calls. */
+typedef struct agp_comm agp_comm;
+enum { AGP_COMM_ID_BYTES = 128 };
+enum { AGP_SHARD_LATENT = 0, AGP_SHARD_BATCH = 1 };
+typedef int32_t (*agp_allreduce_fn)(void* user, void* buf, int64_t count, int32_t dtype, void* hip_stream);
+agp_status agp_comm_unique_id(uint8_t* id_host /* [AGP_COMM_ID_BYTES] */);
+agp_status agp_comm_init(agp_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id_host, agp_comm** out);
+agp_status agp_comm_init_callback(agp_ctx* ctx, int32_t rank, int32_t world, agp_allreduce_fn fn, void* user,
+                                  agp_comm** out);
+agp_status agp_comm_destroy(agp_comm* comm);
+agp_status agp_comm_info(agp_comm* comm, int32_t* rank_host, int32_t* world_host, int32_t* is_rccl_host);
+/* sum all-reduce of a device buffer in place on the ctx stream (what the *_multi calls use; exposed for host drivers) */
+agp_status agp_comm_allreduce(agp_comm* comm, void* buf, int64_t count, int32_t dtype);
+/* accounting since the last read: number of collectives, bytes reduced (per rank), and -- when timing was enabled with
+ * agp_comm_timing(comm, 1) -- their summed duration from HIP events on the ctx stream (synchronises). */
+agp_status agp_comm_timing(agp_comm* comm, int32_t on);
+agp_status agp_comm_stats(agp_comm* comm, int64_t* n_calls_host, int64_t* bytes_host, double* ms_host);
+
+/* update_parameters!(model, state, x, y) (src/training/training.jl:140-158) of a sharded model: agp_svgp_cavi_step with the
+ * exchange points above carried out on `comm`.  comm == NULL or world == 1 degenerates to the single-GPU step through the
+ * same phase sequence. */
+agp_status agp_svgp_cavi_step_multi(agp_svgp* h, agp_comm* comm, int32_t mode, const void* x, int64_t ldx, const void* y,
+                                    const int64_t* idx, int64_t B, double rho);
+/* ELBO(model, state, y) of the last minibatch of a sharded run, identical on every rank (analyticVI.jl:255-297):
+ * latent mode sums the ranks' shares (shared per-point terms are counted by the owner of latent 0); batch mode sums the data
+ * and augmented-KL terms of the shards and counts the replicated Gaussian KL once (call agp_svgp_set_batch_shard first). */
+agp_status agp_svgp_elbo_multi(agp_svgp* h, agp_comm* comm, int32_t mode, double* elbo_host);
+/* update_hyperparameters! (src/hyperparameter/autotuning.jl:86-140) of a latent-sharded model.
+ *   tied = 0 : every latent optimises its own kernel and Z (the reference's deep copies, latentgp.jl:63-68): no collective,
+ *              except that a sharded multi-output model first re-exchanges mean_f under the updated posterior.
+ *   tied = 1 : ONE kernel and ONE Z shared by all latents (an opt-in extension; BASELINE.json config 4's "all-reduce on the
+ *              Z hyper-grad"): the gradients of the local latents are summed, all-reduced (1 + D + m*D doubles), and the same
+ *              ADAM step is applied to every latent on every rank. */
+agp_status agp_svgp_hyper_step_multi(agp_svgp* h, agp_comm* comm, int32_t tied);
+/* predict_f / predict_y / proba_y of a latent-sharded multi-output model: partial mixes all-reduced (n_task x n_t each), the
+ * task likelihoods finished in place.  what: 0 predict_f (mu_out, var_out nullable), 1 predict_y (mu_out), 2 proba_y
+ * (mu_out, var_out; Gauss-Hermite rule as in agp_svgp_proba_y).  Outputs T[n_task][n_t]. */
+agp_status agp_svgp_predict_multi(agp_svgp* h, agp_comm* comm, int32_t what, const void* xt, int64_t ldx, int64_t n_t,
+                                  void* mu_out, void* var_out, const double* gh_nodes_host, const double* gh_weights_host,
+                                  int32_t n_nodes);
 
 #ifdef __cplusplus
 }

@@ -171,6 +171,11 @@ class Kernel:
     kind: str = "sqexponential"
     scale: object = 1.0
     sigma2: float = 1.0
+    # structure of the Julia kernel object: `sigma2 * k` (ScaledKernel) / `k o ScaleTransform|ARDTransform`.  The reference's
+    # hyper step is structural (Zygote NamedTuple over the object, autotuning.jl:99-118 -> update_kernel!,
+    # autotuning_utils.jl:47-67): a parameter that is not part of the object is never stepped.
+    has_variance: bool = True
+    has_transform: bool = True
 
     def _scaled(self, X):
         return np.asarray(X, dtype=np.float64) * np.asarray(self.scale, dtype=np.float64)
@@ -781,6 +786,7 @@ class SVGP:
     ard: bool = False          # True: the scale is an ARDTransform vector (one parameter per dim), else ScaleTransform
     atfrequency: int = 1
     hyper_state: list = None
+    reference_compat_stale_K: bool = False
 
     def __post_init__(self):
         import copy
@@ -839,7 +845,7 @@ class SVGP:
 
     # -- training.jl:13-111 (fixed iteration count, indices supplied by the caller) ------------
     def train(self, X, y, iterations, idx_stream: Optional[Sequence[np.ndarray]] = None, callback=None,
-              labels_treated=False):
+              labels_treated=False, fresh_state=True):
         X = np.asarray(X, dtype=np.float64)
         y = y if labels_treated else treat_labels(y, self.likelihood)
         N = len(X)
@@ -850,6 +856,8 @@ class SVGP:
         else:
             self.batchsize = N
             self.rho = 1.0
+        if fresh_state:
+            self.hp_updated = True  # training.jl:41-43 (state === nothing)
         for it in range(iterations):
             if self.stochastic:
                 idx = np.asarray(idx_stream[it])
@@ -885,10 +893,13 @@ class SVGP:
                 }
             st = self.hyper_state[k]
             if self.k_opt:
-                v = np.array([gp.kernel.sigma2])
-                st["var"], dv = self.k_opt.apply(st["var"], v * np.array([g["dvariance"]]))
-                gp.kernel.sigma2 = float(np.exp(np.log(v) + dv)[0])
-                if self.ard:
+                if getattr(gp.kernel, "has_variance", True):
+                    v = np.array([gp.kernel.sigma2])
+                    st["var"], dv = self.k_opt.apply(st["var"], v * np.array([g["dvariance"]]))
+                    gp.kernel.sigma2 = float(np.exp(np.log(v) + dv)[0])
+                if not getattr(gp.kernel, "has_transform", True):
+                    pass  # a bare kernel: no scale parameter exists
+                elif self.ard:
                     st["scale"], ds = self.k_opt.apply(st["scale"], sc * g["dscale"])
                     gp.kernel.scale = np.exp(np.log(sc) + ds)
                 else:
@@ -898,7 +909,10 @@ class SVGP:
             if self.z_opt:
                 st["Z"], dz = self.z_opt.apply(st["Z"], g["dZ"])
                 gp.Z = gp.Z + dz
-        self.hp_updated = True  # refresh K next step (the reference leaves it stale, Appendix A Q1: corrected here)
+        # the reference never sets HyperParametersUpdated again inside train! (the call is commented out, autotuning.jl:41-46),
+        # so K = chol(K_ZZ) stays the one of the first iteration until train! ends (Appendix A Q1).  Corrected by default.
+        if not self.reference_compat_stale_K:
+            self.hp_updated = True
 
     # -- analyticVI.jl:255-274 ----------------------------------------------------------
     def elbo(self, y, rho=None):
@@ -925,7 +939,8 @@ class SVGP:
         return val
 
     # -- predictions.jl:25-50 -----------------------------------------------------------
-    def predict_f(self, Xt, cov=False):
+    def predict_f(self, Xt, cov=False, diag=True):
+        """_predict_f (sparse) predictions.jl:25-50.  diag=False: full covariance k** + jitt I - k* A k*' (lines 45-49)."""
         Xt = np.asarray(Xt, dtype=np.float64)
         mus, vars_ = [], []
         for gp in self.latents:
@@ -936,6 +951,10 @@ class SVGP:
                 m = len(gp.Z)
                 SK = sla.cho_solve((L, True), gp.Sigma.T).T  # Sigma / K
                 A = sla.cho_solve((L, True), np.eye(m) - SK)  # K \ (I - Sigma/K)
+                if not diag:
+                    kss_full = gp.kernel.matrix(Xt) + self.jitter * np.eye(len(Xt))
+                    vars_.append(kss_full - ks @ A @ ks.T)
+                    continue
                 kss = gp.kernel.diag(Xt) + self.jitter
                 vars_.append(kss - diag_ABt(ks @ A, ks))
         if cov:
@@ -1249,10 +1268,13 @@ class MOSVGP:
                                        "Z": self.z_opt.init(np.zeros_like(gp.Z)) if self.z_opt else None}
             st = self.hyper_state[q]
             if self.k_opt:
-                v = np.array([gp.kernel.sigma2])
-                st["var"], dv = self.k_opt.apply(st["var"], v * np.array([g["dvariance"]]))
-                gp.kernel.sigma2 = float(np.exp(np.log(v) + dv)[0])
-                if self.ard:
+                if getattr(gp.kernel, "has_variance", True):
+                    v = np.array([gp.kernel.sigma2])
+                    st["var"], dv = self.k_opt.apply(st["var"], v * np.array([g["dvariance"]]))
+                    gp.kernel.sigma2 = float(np.exp(np.log(v) + dv)[0])
+                if not getattr(gp.kernel, "has_transform", True):
+                    pass  # a bare kernel: no scale parameter exists
+                elif self.ard:
                     st["scale"], ds = self.k_opt.apply(st["scale"], sc * g["dscale"])
                     gp.kernel.scale = np.exp(np.log(sc) + ds)
                 else:

@@ -31,7 +31,7 @@ def _check_latent(AGP, capi, model, l, variance, tol):
     Lk = torch.as_tensor(model.get_matrix(capi.MAT_L, l), device="cuda")
     R2 = Kinv @ (Lk @ Lk.T)
     assert float((R2 - torch.eye(m, device="cuda", dtype=R2.dtype)).abs().max()) < tol  # K^-1 (L L') = I
-    kt = model.get_matrix(capi.VEC_KTILDE, l, model.inference.batchsize)
+    kt = model.get_matrix(capi.VEC_KTILDE, l)  # of the last batch the handle saw (a step or an ELBO evaluation)
     assert np.all(kt > 0) and np.all(kt <= variance + 2e-3)
 
 

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_struct_layouts_match_header():
     from agp_amd import capi
 
-    assert C.sizeof(capi.KernelDesc) == 32
+    assert C.sizeof(capi.KernelDesc) == 40  # + has_variance / has_transform
     assert C.sizeof(capi.LikDesc) == 24
     assert C.sizeof(capi.SvgpDesc) == 4 * 4 + 3 * 8 + 24 + 3 * 8 + 8
 
@@ -62,6 +62,12 @@ def test_kernel_objects():
     assert k.variance == 2.0 and np.allclose(k.scales(3), 10.0)
     d, keep = k.desc(3)
     assert (d.kind, d.ard, d.variance, d.scale) == (0, 0, 2.0, 10.0)
+    # the structure of the kernel object decides what the hyper step may touch (autotuning.jl:99-118)
+    assert (d.has_variance, d.has_transform) == (1, 1)
+    bare, _ = AGP.SqExponentialKernel().desc(3)
+    assert (bare.has_variance, bare.has_transform, bare.variance, bare.scale) == (0, 0, 1.0, 1.0)
+    wl, _ = AGP.with_lengthscale(AGP.Matern32Kernel(), 2.0).desc(3)
+    assert (wl.has_variance, wl.has_transform) == (0, 1)
     ka = AGP.Matern52Kernel() @ AGP.ARDTransform([1.0, 2.0])
     d, keep = ka.desc(2)
     assert d.kind == 1 and d.ard == 1 and [d.ard_scales_host[i] for i in range(2)] == [1.0, 2.0]

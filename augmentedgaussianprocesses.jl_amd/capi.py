@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libagp_hip.so")
+# AGP_HIP_LIB: an alternative build of the same library (kernel experiments are compared as two .so files in one GPU session)
+LIB_PATH = os.environ.get("AGP_HIP_LIB") or os.path.join(_HERE, "libagp_hip.so")
 
 AGP_OK = 0
 ERR_NAMES = {

@@ -39,6 +39,13 @@ struct agp_ctx {
   } h_dirty[2];
   void* tri_scratch = nullptr;    // n x n scratch of the recursive-doubling triangular inverse
   size_t tri_bytes = 0;
+  // fallback of the task-graph factorisation (k_chol_safe): grid-barrier words, retry counter, number of CUs; once a retry has
+  // been seen by the host (any synchronising call) the task graph is not used again on this context
+  unsigned* safe_bar = nullptr;
+  int32_t* safe_retries = nullptr;
+  int n_cu = 0;
+  bool dag_off = false;
+  int64_t dag_retries_seen = 0;
 };
 
 #define HIPCHK(ctx, expr)                                                                       \
@@ -183,24 +190,63 @@ static agp_status dag_handover_release(agp_ctx* c, int64_t used, int64_t stride,
 // guaranteed to be resident only while the unretired workgroups before them -- one block column of every problem, nb * (nt + ne
 // [+ 1 with the inverse rows]) tiles, an eighth of them per XCD -- fit into an XCD's 32 workgroup slots with room to spare.
 constexpr int64_t DAG_MAX_NT = 32, DAG_MAX_COLUMN_TILES = 208;
-static bool chol_use_dag(int64_t nt, int64_t ne = 0, int64_t nb = 1) {
+static bool chol_use_dag(const agp_ctx* c, int64_t nt, int64_t ne = 0, int64_t nb = 1) {
   static const int v = []() {
     const char* e = getenv("AGP_CHOL_DAG");
     return e ? (e[0] == '0' ? 0 : 1) : -1;
   }();
+  if (c->dag_off) return false;  // a lost dependency was seen on this context (two processes sharing the device): stay safe
   if (nb * (nt + ne + 1) > DAG_MAX_COLUMN_TILES) return false;
   return v < 0 ? nt <= DAG_MAX_NT : v == 1;
+}
+
+// the fallback behind a task-graph launch (see k_chol_safe): one launch that returns at once unless the latch reads -1
+template <typename T>
+static agp_status launch_chol_safe(agp_ctx* c, const CholBatch<T>& bt, const SafeSrc<T>& src, int nb, int64_t ld, int64_t ldx,
+                                   int64_t lde, int64_t ne, int64_t nt, int32_t* info_dev, int64_t nvalid) {
+  if (!c->safe_bar) {
+    if (hipMalloc((void**)&c->safe_bar, 2 * sizeof(unsigned)) != hipSuccess) return AGP_ERR_NOMEM;
+    if (hipMalloc((void**)&c->safe_retries, sizeof(int32_t)) != hipSuccess) return AGP_ERR_NOMEM;
+    HIPCHK(c, hipMemsetAsync(c->safe_bar, 0, 2 * sizeof(unsigned), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->safe_retries, 0, sizeof(int32_t), c->stream));
+    hipDeviceProp_t pr;
+    HIPCHK(c, hipGetDeviceProperties(&pr, c->device));
+    c->n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 64;
+  }
+  // one workgroup per CU at most (each needs ~110 KB of LDS, so one fits per CU): all of them become resident, whatever else runs
+  const int64_t most = (nt + ne + nt * (nt + 1) / 2 + ne * nt) * nb;
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(c->n_cu, most));
+  hipLaunchKernelGGL((k_chol_safe<T>), dim3(grid), dim3(CHOL_THREADS), 0, c->stream, bt, src, nb, ld, ldx, lde, ne, nt, info_dev,
+                     nvalid, c->safe_bar, c->safe_retries);
+  LAUNCHCHK(c);
+  return AGP_OK;
+}
+
+// host side of the latch: called where the stream has just been synchronised anyway
+static void dag_retry_check(agp_ctx* c) {
+  if (!c->safe_retries || c->dag_off) return;
+  int32_t r = 0;
+  if (hipMemcpy(&r, c->safe_retries, sizeof(r), hipMemcpyDeviceToHost) != hipSuccess) return;
+  if (r > 0) {
+    c->dag_off = true;
+    c->dag_retries_seen = r;
+    fprintf(stderr,
+            "[agp_hip] warning: %d task-graph factorisation(s) lost a tile dependency (is another process using this GPU?) and were "
+            "re-run by the in-stream fallback; this context now uses per-column launches\n", (int)r);
+  }
 }
 
 template <typename T>
 static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int64_t ldx, T* Dg, T* E, int64_t lde,
                               int64_t ne, int do_x, int32_t* info_dev, int64_t nvalid, const T* erow = nullptr,
-                              bool want_l = true) {
+                              bool want_l = true, const SafeSrc<T>* safe = nullptr) {
+  // safe: sources the inputs can be restored from (A = -2 eta2, E = [kappa ; eta1' ; 0]): the in-stream fallback k_chol_safe is
+  // then enqueued behind the task graph; without it a lost dependency surfaces as an error at the caller's next check
   // want_l = false: the caller never reads the factor L itself (only E L^-T, X, Dg): the task graph skips those stores
   // erow: the last extension block is [erow' ; 0] (not yet written to E: the task graph reads it in place; the per-column
   // path needs it in E first)
   const int64_t nt = n / TILE;
-  const bool use_dag = chol_use_dag(nt, ne);
+  const bool use_dag = chol_use_dag(c, nt, ne);
   if (use_dag && X) {
     const int64_t nx = (do_x && nt > 1) ? nt : 0;  // the full inverse rides along as nt identity block rows
     const int64_t nf = ((nt + ne + nx) * nt + 3 * nt + 1) * DAG_FS;
@@ -248,6 +294,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
                          (int)(do_x && nx == 0) | (want_l ? 2 : 0));
     LAUNCHCHK(c);
     AGPCHK(dag_handover_release<T>(c, (3 * nt + (nt + ne + nx) * nt) * TILE * TILE, hstride, 1, hs));
+    if (safe && !do_x) AGPCHK(launch_chol_safe<T>(c, one, *safe, 1, ld, ldx, lde, ne, nt, info_dev, nvalid));
     if (trace) {
       std::vector<unsigned long long> h((size_t)ntiles * 8);
       (void)hipStreamSynchronize(c->stream);
@@ -282,12 +329,31 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
   return AGP_OK;
 }
 
+// Task-graph launches whose inputs cannot be restored on the device (the factor is written in place: K_ZZ, the building blocks;
+// or the inverse rides along) are checked on the host instead: synchronise, and if the latch reads -1 stop using the task graph
+// on this context and tell the caller to rebuild its input and factor again (now with per-column launches).
+static agp_status dag_lost_dependency(agp_ctx* c, int32_t* info_dev, bool* lost) {
+  *lost = false;
+  int32_t info = 0;
+  HIPCHK(c, hipMemcpyAsync(&info, info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (info == -1) {
+    HIPCHK(c, hipMemsetAsync(info_dev, 0, sizeof(int32_t), c->stream));
+    if (!c->dag_off)
+      fprintf(stderr, "[agp_hip] warning: a task-graph factorisation lost a tile dependency (is another process using this GPU?); "
+                      "re-running it with per-column launches, which this context uses from now on\n");
+    c->dag_off = true;
+    *lost = true;
+  }
+  return AGP_OK;
+}
+
 // nb <= DAG_MAX_NB independent problems of identical shape as ONE interleaved task-graph launch (see k_chol_dag): their chains
 // run side by side on nb CUs.  The bound keeps every chain's next feeder tile among the workgroups an XCD can hold.
 constexpr int DAG_MAX_NB = 6;
 template <typename T>
 static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, int64_t ld, int64_t n, int64_t ldx, int64_t lde,
-                                  int64_t ne, int32_t* info_dev, int64_t nvalid) {
+                                  int64_t ne, int32_t* info_dev, int64_t nvalid, const SafeSrc<T>* safe = nullptr) {
   const int64_t nt = n / TILE;
   const int64_t fstride = ((nt + ne) * nt + 3 * nt + 1) * DAG_FS, nf = fstride * nb;
   if (c->dag_cap < nf) {
@@ -310,6 +376,7 @@ static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, in
                      (int64_t)0, (const T*)nullptr, 0);
   LAUNCHCHK(c);
   AGPCHK(dag_handover_release<T>(c, (3 * nt + (nt + ne) * nt) * TILE * TILE, hstride, nb, hs));
+  if (safe) AGPCHK(launch_chol_safe<T>(c, bt, *safe, nb, ld, ldx, lde, ne, nt, info_dev, nvalid));
   return AGP_OK;
 }
 
@@ -385,6 +452,43 @@ static agp_status gemm_nt(agp_ctx* c, const T* A, int64_t lda, const T* B, int64
                        v, p0, p1, ldp);
   LAUNCHCHK(c);
   return AGP_OK;
+}
+
+
+// kernelmatrix launch: the MFMA form (k_kernelmatrix_mma) up to D = KMM_MAXD, the direct-difference VALU kernel beyond (or with
+// AGP_KERNELMATRIX_VALU=1).  Same arguments as the kernels; `cgroups` = number of column groups a fused row-dot is split into
+// (<= 0: one group per column tile, like the VALU kernel; 1: the whole row in one workgroup -- streaming prediction).  Returns
+// the number of partial slices the row-dot consumer has to sum.
+template <typename T>
+static int launch_kernelmatrix(hipStream_t stream, const T* X, int64_t ldx, const int64_t* idx, int64_t n, const T* Y, int64_t ldy,
+                               int64_t p, int64_t D, const T* scales, int kind, T variance, T* out, int64_t ldo, int64_t n_out,
+                               int64_t p_out, int sym, T diag_add, const T* alpha, T* part, int64_t ldp, int64_t cgroups = 0) {
+  const int64_t nct = (p_out + TILE - 1) / TILE, nrt = (n_out + TILE - 1) / TILE;
+  static const bool force_valu = []() {
+    const char* e = getenv("AGP_KERNELMATRIX_VALU");
+    return e && e[0] == '1';
+  }();
+  if (D > KMM_MAXD || force_valu) {
+    hipLaunchKernelGGL((k_kernelmatrix<T>), dim3((unsigned)nct, (unsigned)nrt), dim3(NTHREADS), 0, stream, X, ldx, idx, n, Y, ldy, p,
+                       D, scales, kind, variance, out, ldo, n_out, p_out, sym, diag_add, alpha, part, ldp);
+    return (int)nct;
+  }
+  const int Dp = (int)((D + 7) / 8 * 8);
+  const size_t sh = kmm_smem_bytes<T>(Dp);
+  if (sh > 64 * 1024) {  // more than 64 KB of dynamic LDS has to be requested once per kernel
+    static size_t asked = 0;
+    if (sh > asked) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kernelmatrix_mma<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      asked = sh;
+    }
+  }
+  const int64_t groups = cgroups <= 0 ? nct : std::min<int64_t>(cgroups, nct);
+  const int64_t ctiles = (nct + groups - 1) / groups;
+  const int64_t g_eff = (nct + ctiles - 1) / ctiles;
+  hipLaunchKernelGGL((k_kernelmatrix_mma<T>), dim3((unsigned)g_eff, (unsigned)nrt), dim3(NTHREADS), sh, stream, X, ldx, idx, n, Y,
+                     ldy, p, D, Dp, scales, kind, variance, out, ldo, n_out, p_out, sym, diag_add, alpha, part, ldp, ctiles);
+  return (int)g_eff;
 }
 
 // ---- model ---------------------------------------------------------------------------------------------------
@@ -887,11 +991,17 @@ struct Svgp : SvgpBase {
       if (!g.K_stale) continue;
       any = true;
       dim3 gk((unsigned)(mp / TILE), (unsigned)(mp / TILE));
-      hipLaunchKernelGGL((k_kernelmatrix<T>), gk, dim3(NTHREADS), 0, st(), (const T*)g.Z, D, (const int64_t*)nullptr, m,
-                         (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.L, mp, mp, mp, 1,
-                         (T)jitter, (const T*)nullptr, (T*)nullptr, (int64_t)0);
-      LAUNCHCHK(ctx);
-      AGPCHK(potrf_fused<T>(ctx, g.L, mp, mp, g.Xk, mp, g.DgK, (T*)nullptr, 0, 0, 1, info_dev, m));
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        (void)launch_kernelmatrix<T>(st(), (const T*)g.Z, D, (const int64_t*)nullptr, m, (const T*)g.Z, D, m, D,
+                                     (const T*)g.scales, g.k.kind, (T)g.k.variance, g.L, mp, mp, mp, 1, (T)jitter,
+                                     (const T*)nullptr, (T*)nullptr, (int64_t)0);
+        LAUNCHCHK(ctx);
+        const bool dag = chol_use_dag(ctx, mp / TILE);
+        AGPCHK(potrf_fused<T>(ctx, g.L, mp, mp, g.Xk, mp, g.DgK, (T*)nullptr, 0, 0, 1, info_dev, m));
+        bool lost = false;
+        if (dag) AGPCHK(dag_lost_dependency(ctx, info_dev, &lost));  // (this function synchronises below anyway)
+        if (!lost) break;
+      }
       AGPCHK(xtx_padded<T>(ctx, g.Xk, mp, mp, g.Kinv, mp));
       hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.DgK, m, scal_dev);
       LAUNCHCHK(ctx);
@@ -905,7 +1015,8 @@ struct Svgp : SvgpBase {
         LAUNCHCHK(ctx);
       }
       g.K_stale = false;
-      g.kappa_valid = false;
+      // (under AGP_FLAG_STALE_K a full-batch run keeps the step's kernel matrices across the refresh of the fresh set)
+      if (!(g.stale_on && !desc.stochastic)) g.kappa_valid = false;
       g.pred_valid = g.predvar_valid = false;
     }
     if (any) {
@@ -986,14 +1097,14 @@ struct Svgp : SvgpBase {
       hipLaunchKernelGGL((k_add_diag<T>), grid1(ma), dim3(256), 0, st(), g.kappa_a, mp, ma, T(1));
     } else {
       dim3 gk((unsigned)(mp / TILE), (unsigned)(map / TILE));
-      hipLaunchKernelGGL((k_kernelmatrix<T>), gk, dim3(NTHREADS), 0, st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
+      (void)launch_kernelmatrix<T>(st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
                          (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Kab, mp, map, mp, 0, T(0),
                          (const T*)nullptr, (T*)nullptr, (int64_t)0);
       LAUNCHCHK(ctx);
       AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.Kab, mp, g.Kinv, mp, map, mp, mp, 0, g.kappa_a, mp, nullptr, 0, nullptr, nullptr,
                                     nullptr, 0)));
       dim3 ga((unsigned)(map / TILE), (unsigned)(map / TILE));
-      hipLaunchKernelGGL((k_kernelmatrix<T>), ga, dim3(NTHREADS), 0, st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
+      (void)launch_kernelmatrix<T>(st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
                          (const T*)g.Za, D, ma, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Kta, map, map, map, 0,
                          T(0), (const T*)nullptr, (T*)nullptr, (int64_t)0);
       hipLaunchKernelGGL((k_add_diag<T>), grid1(ma), dim3(256), 0, st(), g.Kta, map, ma, (T)jitter);
@@ -1138,7 +1249,7 @@ struct Svgp : SvgpBase {
         // nothing to compute
       } else if (!keep) {
         dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
-        hipLaunchKernelGGL((k_kernelmatrix<T>), gk, dim3(NTHREADS), 0, st(), (const T*)x, ldx, idx, B, (const T*)g.Z,
+        (void)launch_kernelmatrix<T>(st(), (const T*)x, ldx, idx, B, (const T*)g.Z,
                            D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Knm, mp, Bq, mp, 0, T(0),
                            (const T*)nullptr, (T*)nullptr, (int64_t)0);
         LAUNCHCHK(ctx);
@@ -1181,7 +1292,7 @@ struct Svgp : SvgpBase {
       const int64_t ntl = mp / TILE, nel = Bq / TILE + 1;
       int dag_nb = 0;
       for (int q = DAG_MAX_NB; q >= 1 && !dag_nb; --q)
-        if (chol_use_dag(ntl, nel, q)) dag_nb = q;
+        if (chol_use_dag(ctx, ntl, nel, q)) dag_nb = q;
       size_t chunk = CHOL_MAXB;
       if (dag_nb > 0 && !todo.empty()) {
         const size_t nchunks = (todo.size() + dag_nb - 1) / dag_nb;
@@ -1200,12 +1311,20 @@ struct Svgp : SvgpBase {
           g.la_state = 1;
           g.xa_valid = false;
         }
+        SafeSrc<T> src{};  // where the in-stream fallback of the task graph finds the inputs again
+        src.Bq = Bq;
+        for (int q = 0; q < nb; ++q) {
+          Latent& g = lat[todo[l0 + q]];
+          src.kappa[q] = g.kappa;
+          src.eta1[q] = g.eta1;
+          src.eta2[q] = g.eta2;
+        }
         if (nb == 1) {  // also writes the [eta1' ; 0] block when it falls back to per-column launches
           AGPCHK(potrf_fused<T>(ctx, bt.A[0], mp, mp, bt.X[0], mp, bt.Dg[0], bt.E[0], mp, nel, 0, info_dev, m,
-                                (const T*)lat[todo[l0]].eta1, false));
+                                (const T*)lat[todo[l0]].eta1, false, &src));
           launches += dag_nb > 0 ? 1 : ntl;
         } else if (dag_nb > 0) {
-          AGPCHK(potrf_dag_batch<T>(ctx, bt, nb, mp, mp, mp, mp, nel, info_dev, m));
+          AGPCHK(potrf_dag_batch<T>(ctx, bt, nb, mp, mp, mp, mp, nel, info_dev, m, &src));
           launches += 1;
         } else {
           AGPCHK(potrf_fused_batch<T>(ctx, bt, nb, mp, mp, mp, mp, nel, info_dev, m));
@@ -1320,7 +1439,7 @@ struct Svgp : SvgpBase {
       if (!q.stale_on || desc.stochastic) return q.Knm;
       if (!hyKnm && dmalloc(ctx, &hyKnm, Bp * mp) != AGP_OK) return nullptr;
       dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
-      hipLaunchKernelGGL((k_kernelmatrix<T>), gk, dim3(NTHREADS), 0, st(), (const T*)x_last, ldx_last, idx_last, B,
+      (void)launch_kernelmatrix<T>(st(), (const T*)x_last, ldx_last, idx_last, B,
                          (const T*)q.Z, D, m, D, (const T*)q.scales, q.k.kind, (T)q.k.variance, hyKnm, mp, Bq, mp, 0, T(0),
                          (const T*)nullptr, (T*)nullptr, (int64_t)0);
       return hyKnm;
@@ -1802,7 +1921,7 @@ struct Svgp : SvgpBase {
     agp_status rc = AGP_OK;
     for (auto& g : lat) {
       dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
-      hipLaunchKernelGGL((k_kernelmatrix<T>), gk, dim3(NTHREADS), 0, pf_stream, (const T*)x, ldx, idx, B, (const T*)g.Z,
+      (void)launch_kernelmatrix<T>(pf_stream, (const T*)x, ldx, idx, B, (const T*)g.Z,
                          D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Knm_alt, mp, Bq, mp, 0, T(0),
                          (const T*)nullptr, (T*)nullptr, (int64_t)0);
       rc = gemm_nt<T, EPI_KAPPA>(ctx, g.Knm_alt, mp, kinv_kappa(g), mp, Bq, mp, mp, 0, g.kappa_alt, mp, g.Knm_alt, mp, nullptr,
@@ -1891,9 +2010,27 @@ struct Svgp : SvgpBase {
       LAUNCHCHK(ctx);
     }
     AGPCHK(timing_begin());
+    SafeSrc<T> src{};
+    src.Bq = Bq;
+    src.kappa[0] = g.kappa;  // every caller copies kappa into Wbuf first (or passes Bq = 0)
+    src.eta1[0] = g.eta1;
+    src.eta2[0] = g.eta2;
+    const bool dag = chol_use_dag(ctx, mp / TILE, Bq / TILE + 1);
     AGPCHK(potrf_fused<T>(ctx, g.La, mp, mp, g.Xa, mp, g.DgA, g.Wbuf, mp, Bq / TILE + 1, with_x, info_dev, m,
-                          (const T*)g.eta1, false));
-    AGPCHK(timing_end(chol_use_dag(mp / TILE, Bq / TILE + 1) ? 1 : mp / TILE));
+                          (const T*)g.eta1, false, &src));
+    if (dag && with_x) {  // the inverse rides along: no in-stream fallback, checked here (these callers synchronise soon anyway)
+      bool lost = false;
+      AGPCHK(dag_lost_dependency(ctx, info_dev, &lost));
+      if (lost) {
+        hipLaunchKernelGGL((k_copy2d<T>), grid2(mp, mp), blk2, 0, st(), (const T*)g.eta2, mp, mp, mp, g.La, mp, mp, mp, T(1),
+                           T(-2));
+        if (Bq > 0) HIPCHK(ctx, hipMemcpyAsync(g.Wbuf, g.kappa, sizeof(T) * Bq * mp, hipMemcpyDeviceToDevice, st()));
+        LAUNCHCHK(ctx);
+        AGPCHK(potrf_fused<T>(ctx, g.La, mp, mp, g.Xa, mp, g.DgA, g.Wbuf, mp, Bq / TILE + 1, with_x, info_dev, m,
+                              (const T*)g.eta1, false));
+      }
+    }
+    AGPCHK(timing_end(chol_use_dag(ctx, mp / TILE, Bq / TILE + 1) ? 1 : mp / TILE));
     g.la_state = 1;
     g.xa_valid = with_x != 0;
     return AGP_OK;
@@ -1940,6 +2077,7 @@ struct Svgp : SvgpBase {
     HIPCHK(ctx, hipMemcpyAsync(&info, info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st()));
     HIPCHK(ctx, hipMemcpyAsync(&flags, flags_dev, sizeof(int), hipMemcpyDeviceToHost, st()));
     HIPCHK(ctx, hipStreamSynchronize(st()));
+    dag_retry_check(ctx);  // steps the in-stream fallback had to re-run: warn once, stop using the task graph
     if (info != 0 || flags != 0) {
       HIPCHK(ctx, hipMemsetAsync(info_dev, 0, sizeof(int32_t), st()));
       HIPCHK(ctx, hipMemsetAsync(flags_dev, 0, sizeof(int), st()));
@@ -2300,19 +2438,28 @@ struct Svgp : SvgpBase {
     const int64_t CH = pred_chunk;
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
+      if (!need_var) {
+        // means only: ONE launch over all test points, every workgroup carries its 64 rows through all inducing-point tiles with
+        // the row-dot against K^-1 mu in registers -- K*m and per-tile partial sums never reach memory (predictions.jl:33-34)
+        const int slices = launch_kernelmatrix<T>(st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt, (const T*)g.Z, D, m, D,
+                                                  (const T*)g.scales, g.k.kind, (T)g.k.variance, (T*)nullptr, mp, nt, mp, 0, T(0),
+                                                  (const T*)g.apred, (T*)mu_out + (int64_t)l * nt, nt, 1);
+        LAUNCHCHK(ctx);
+        if (slices == 1) continue;
+        // (D beyond the MFMA kernel's limit: the VALU kernel left one slice per column tile -- redo chunked below)
+      }
       for (int64_t s = 0; s < nt; s += CH) {
         const int64_t nc = (nt - s) < CH ? (nt - s) : CH;
         const int64_t nq = rup64(nc);
         const T* xs = (const T*)xt + s * ldx;
-        dim3 gk((unsigned)(mp / TILE), (unsigned)(nq / TILE));
-        hipLaunchKernelGGL((k_kernelmatrix<T>), gk, dim3(NTHREADS), 0, st(), xs, ldx, (const int64_t*)nullptr, nc,
-                           (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance,
-                           need_var ? Kstar : (T*)nullptr, mp, nq, mp, 0, T(0), (const T*)g.apred, ppm, CH);
+        const int slices = launch_kernelmatrix<T>(st(), xs, ldx, (const int64_t*)nullptr, nc, (const T*)g.Z, D, m, D,
+                                                  (const T*)g.scales, g.k.kind, (T)g.k.variance, need_var ? Kstar : (T*)nullptr, mp,
+                                                  nq, mp, 0, T(0), (const T*)g.apred, ppm, CH);
         LAUNCHCHK(ctx);
         if (need_var)
           AGPCHK((gemm_nt<T, EPI_ROWDOT>(ctx, Kstar, mp, g.Apred, mp, nq, mp, mp, 0, nullptr, 0, Kstar, mp, nullptr, ppv,
                                          nullptr, CH)));
-        hipLaunchKernelGGL((k_predict_finish<T>), grid1(nc), dim3(256), 0, st(), nc, (int)(mp / TILE), (const T*)ppm,
+        hipLaunchKernelGGL((k_predict_finish<T>), grid1(nc), dim3(256), 0, st(), nc, slices, (const T*)ppm,
                            (int)(2 * mp / TILE), (const T*)ppv, CH, (T)g.k.variance, (T)jitter,
                            (T*)mu_out + (int64_t)l * nt + s, need_var ? (T*)var_out + (int64_t)l * nt + s : (T*)nullptr);
         LAUNCHCHK(ctx);
@@ -2477,11 +2624,11 @@ struct Svgp : SvgpBase {
       rc = ensure_pred(g, true);
       if (rc != AGP_OK) break;
       dim3 gk((unsigned)(mp / TILE), (unsigned)(nq / TILE));
-      hipLaunchKernelGGL((k_kernelmatrix<T>), gk, dim3(NTHREADS), 0, st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt,
+      (void)launch_kernelmatrix<T>(st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt,
                          (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, Ks, mp, nq, mp, 0, T(0),
                          (const T*)nullptr, (T*)nullptr, (int64_t)0);
       dim3 gs((unsigned)(nq / TILE), (unsigned)(nq / TILE));
-      hipLaunchKernelGGL((k_kernelmatrix<T>), gs, dim3(NTHREADS), 0, st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt,
+      (void)launch_kernelmatrix<T>(st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt,
                          (const T*)xt, ldx, nt, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, Kss, nq, nq, nq, 1,
                          (T)jitter, (const T*)nullptr, (T*)nullptr, (int64_t)0);
       rc = gemm_nt<T, EPI_STORE>(ctx, Ks, mp, g.Apred, mp, nq, mp, mp, 0, T1, mp, nullptr, 0, nullptr, nullptr, nullptr, 0);
@@ -2695,6 +2842,8 @@ agp_status agp_ctx_destroy(agp_ctx* ctx) {
       if (ctx->hset[q]) (void)hipFree(ctx->hset[q]);
     if (ctx->tri_scratch) (void)hipFree(ctx->tri_scratch);
   }
+  if (ctx->safe_bar) (void)hipFree(ctx->safe_bar);
+  if (ctx->safe_retries) (void)hipFree(ctx->safe_retries);
   delete ctx;
   return AGP_OK;
 }
@@ -2724,7 +2873,7 @@ static agp_status bb_kernelmatrix(agp_ctx* ctx, const agp_kernel_desc* k, const 
   const void* yy = sym ? x : y;
   const int64_t pp = sym ? n : p, ldyy = sym ? ldx : ldy;
   dim3 g((unsigned)((pp + TILE - 1) / TILE), (unsigned)((n + TILE - 1) / TILE));
-  hipLaunchKernelGGL((k_kernelmatrix<T>), g, dim3(NTHREADS), 0, ctx->stream, (const T*)x, ldx, idx, n, (const T*)yy, ldyy,
+  (void)launch_kernelmatrix<T>(ctx->stream, (const T*)x, ldx, idx, n, (const T*)yy, ldyy,
                      pp, D, (const T*)ds, k->kind, (T)k->variance, (T*)out, ldo, n, pp, 0, T(0), (const T*)nullptr,
                      (T*)nullptr, (int64_t)0);
   hipError_t e = hipGetLastError();
@@ -2762,6 +2911,15 @@ static agp_status bb_potrf(agp_ctx* ctx, void* a, int64_t lda, int64_t n, double
   T* Dg = nullptr;
   AGPCHK(dmalloc(ctx, &Dg, np * TILE));
   AGPCHK(potrf_fused<T>(ctx, Ap, np, np, X, np, Dg, (T*)nullptr, 0, 0, 0, info, n));
+  if (chol_use_dag(ctx, np / TILE)) {
+    bool lost = false;
+    AGPCHK(dag_lost_dependency(ctx, info, &lost));
+    if (lost) {  // the input is still intact in `a`: pad it again and factor with per-column launches
+      hipLaunchKernelGGL((k_copy2d<T>), grid2(np, np), blk2, 0, ctx->stream, (const T*)a, lda, n, n, Ap, np, np, np, T(1), T(1));
+      if (jitter != 0.0) hipLaunchKernelGGL((k_add_diag<T>), grid1(n), dim3(256), 0, ctx->stream, Ap, np, n, (T)jitter);
+      AGPCHK(potrf_fused<T>(ctx, Ap, np, np, X, np, Dg, (T*)nullptr, 0, 0, 0, info, n));
+    }
+  }
   hipLaunchKernelGGL((k_publish_diag<T>), dim3((unsigned)(np / TILE)), dim3(256), 0, ctx->stream, Ap, np, (const T*)Dg);
   HIPCHK(ctx, hipMemcpy2DAsync(a, sizeof(T) * lda, Ap, sizeof(T) * np, sizeof(T) * n, n, hipMemcpyDeviceToDevice,
                                ctx->stream));
@@ -2796,6 +2954,14 @@ static agp_status bb_spd_inverse(agp_ctx* ctx, const void* a, int64_t lda, int64
   AGPCHK(dmalloc(ctx, &sc, 1));
   HIPCHK(ctx, hipMemsetAsync(info, 0, sizeof(int32_t), ctx->stream));
   AGPCHK(potrf_fused<T>(ctx, Ap, np, np, X, np, Tw, (T*)nullptr, 0, 0, 1, info, n));
+  if (chol_use_dag(ctx, np / TILE)) {
+    bool lost = false;
+    AGPCHK(dag_lost_dependency(ctx, info, &lost));
+    if (lost) {
+      hipLaunchKernelGGL((k_copy2d<T>), grid2(np, np), blk2, 0, ctx->stream, (const T*)a, lda, n, n, Ap, np, np, np, T(1), T(1));
+      AGPCHK(potrf_fused<T>(ctx, Ap, np, np, X, np, Tw, (T*)nullptr, 0, 0, 1, info, n));
+    }
+  }
   AGPCHK(xtx_padded<T>(ctx, X, np, np, Inv, np));
   hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, ctx->stream, (const T*)Tw, n, sc);
   LAUNCHCHK(ctx);
@@ -3106,8 +3272,11 @@ agp_status agp_kmeans(agp_ctx* ctx, int32_t dtype, const void* x, int64_t n, int
 agp_status agp_dev_diag_bench(agp_ctx* ctx, int32_t dtype, int32_t variant, int32_t blocks, int32_t reps, double* us) {
   if (!ctx || !us) return AGP_ERR_INVALID;
   DevGuard guard(ctx->device);
-  if (dtype == AGP_F64) return variant ? bb_diag_bench<double, 1>(ctx, blocks, reps, us) : bb_diag_bench<double, 0>(ctx, blocks, reps, us);
-  return variant ? bb_diag_bench<float, 1>(ctx, blocks, reps, us) : bb_diag_bench<float, 0>(ctx, blocks, reps, us);
+  if (dtype == AGP_F64)
+    return variant == 2 ? bb_diag_bench<double, 2>(ctx, blocks, reps, us)
+                        : variant ? bb_diag_bench<double, 1>(ctx, blocks, reps, us) : bb_diag_bench<double, 0>(ctx, blocks, reps, us);
+  return variant == 2 ? bb_diag_bench<float, 2>(ctx, blocks, reps, us)
+                      : variant ? bb_diag_bench<float, 1>(ctx, blocks, reps, us) : bb_diag_bench<float, 0>(ctx, blocks, reps, us);
 }
 
 agp_status agp_svgp_create(agp_ctx* ctx, const agp_svgp_desc* desc, agp_svgp** out) {

@@ -129,6 +129,165 @@ __global__ __launch_bounds__(NTHREADS) void k_kernelmatrix(const T* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The same kernel matrix on the matrix cores (the default up to D = KMM_MAXD): squared distances in GEMM form
+//     d2(i, j) = ||s.x_i||^2 + ||s.y_j||^2 - 2 (s.x_i).(s.y_j)
+// with the cross term on v_mfma 16x16x4 (4 waves as 2 x 2, each a 32 x 32 sub-tile), operands staged ONCE per tile through LDS
+// with 16-byte coalesced loads (a gathered minibatch row is one contiguous segment) and the scale folded in on the way.
+// The GEMM form loses digits when two points (nearly) coincide -- K_ZZ's diagonal, inducing points picked from the data --
+// which the first-order kernels (Exponential, Matern) would amplify through sqrt: every element with
+// d2 < KMM_CLOSE (||x||^2 + ||y||^2) is recomputed by direct differences from the tiles still in LDS (rare, so the divergent
+// branch costs little); everything else carries an absolute error of a few ulp(||x||^2 + ||y||^2) in d2.
+// One workgroup = one 64-row tile x `ctiles` consecutive column tiles (grid.x = column groups).  With alpha, the fused row-dot
+// sum_j out[i][j] alpha[j] is accumulated in registers over all column tiles of the group and leaves ONE partial slice per
+// group (part[blockIdx.x][i]): streaming prediction runs with a single group -- K*m and per-tile partials never reach memory.
+// ---------------------------------------------------------------------------------------------------
+constexpr int KMM_MAXD = 128;
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_kernelmatrix_mma(const T* __restrict__ X, int64_t ldx,
+                                                               const int64_t* __restrict__ idx, int64_t n,
+                                                               const T* __restrict__ Y, int64_t ldy, int64_t p, int64_t D,
+                                                               int Dp, const T* __restrict__ scales, int kind, T variance,
+                                                               T* __restrict__ out, int64_t ldo, int64_t n_out,
+                                                               int64_t p_out, int sym, T diag_add,
+                                                               const T* __restrict__ alpha, T* __restrict__ part,
+                                                               int64_t ldp, int64_t ctiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char kmm_smem[];
+  const int LDX = Dp + 2;  // 16 rows x {k, k+1} land on distinct banks (same stride rule as LDK in agp_device.h)
+  T* Xs = reinterpret_cast<T*>(kmm_smem);  // [64][LDX]
+  T* Ys = Xs + TILE * LDX;                 // [64][LDX]
+  T* xn = Ys + TILE * LDX;                 // [64]
+  T* yn = xn + TILE;                       // [64]
+  T* sc = yn + TILE;                       // [Dp]
+  T* red = sc + Dp;                        // [2][64] row-dot hand-over between the two column waves
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  typedef typename Mfma<T>::vec_t vec_t;
+  constexpr int VEC = Mfma<T>::VEC;
+  const int nv = Dp / VEC;  // vectors per staged row
+  const int64_t i0 = blockIdx.y * (int64_t)TILE;
+  const bool vec_ok_x = (ldx % VEC) == 0 && (D % VEC) == 0 && ((uintptr_t)X % (sizeof(T) * VEC)) == 0;
+  const bool vec_ok_y = (ldy % VEC) == 0 && (D % VEC) == 0 && ((uintptr_t)Y % (sizeof(T) * VEC)) == 0;
+  for (int d = tid; d < Dp; d += NTHREADS) sc[d] = d < D ? (scales ? scales[d] : T(1)) : T(0);
+  __syncthreads();
+  // stage one 64-row tile (rows r0.., `rows` valid, optional gather) scaled into S, then its squared norms into nrm
+  auto stage = [&](const T* __restrict__ P, int64_t ld, const int64_t* __restrict__ gidx, int64_t r0, int64_t rows, bool vec_ok,
+                   T* S, T* nrm) {
+    for (int e = tid; e < TILE * nv; e += NTHREADS) {
+      const int r = e / nv, dv = (e % nv) * VEC;
+      const int64_t gr = r0 + r;
+      T v[VEC];
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) v[q] = T(0);
+      if (gr < rows) {
+        const int64_t src = gidx ? gidx[gr] : gr;
+        const T* row = P + src * ld;
+        if (vec_ok && dv + VEC <= D) {
+          const vec_t x = *reinterpret_cast<const vec_t*>(row + dv);
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) v[q] = x[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < VEC; ++q)
+            if (dv + q < D) v[q] = row[dv + q];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) S[r * LDX + dv + q] = v[q] * sc[dv + q];
+    }
+    __syncthreads();
+    {  // squared norms: four lanes per row, combined in a fixed order
+      const int r = tid >> 2, q4 = tid & 3;
+      T s = T(0);
+      for (int d = q4; d < Dp; d += 4) s += S[r * LDX + d] * S[r * LDX + d];
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      if (q4 == 0) nrm[r] = s;
+    }
+    __syncthreads();
+  };
+  stage(X, ldx, idx, i0, n, vec_ok_x, Xs, xn);
+  const T close_thr = sizeof(T) == 8 ? T(1e-3) : T(3e-2);
+  T rs[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rs[mi][r] = T(0);
+  const int64_t ct0 = blockIdx.x * ctiles;
+  const int64_t nct = (p_out + TILE - 1) / TILE;
+  for (int64_t ct = ct0; ct < ct0 + ctiles && ct < nct; ++ct) {
+    const int64_t j0 = ct * TILE;
+    if (ct != ct0) __syncthreads();  // the previous tile's epilogue is done with Ys / yn
+    stage(Y, ldy, nullptr, j0, p, vec_ok_y, Ys, yn);
+    typename Mfma<T>::acc_t acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][ni][r] = T(0);
+    const T* pa = Xs + (wm * 32 + (lane & 15)) * LDX + (lane >> 4);
+    const T* pb = Ys + (wn * 32 + (lane & 15)) * LDX + (lane >> 4);
+#pragma unroll 4
+    for (int kk = 0; kk < Dp / 4; ++kk) {
+      const T a0 = pa[kk * 4], a1 = pa[16 * LDX + kk * 4];
+      const T b0 = pb[kk * 4], b1 = pb[16 * LDX + kk * 4];
+      acc[0][0] = Mfma<T>::mma(a0, b0, acc[0][0]);
+      acc[0][1] = Mfma<T>::mma(a0, b1, acc[0][1]);
+      acc[1][0] = Mfma<T>::mma(a1, b0, acc[1][0]);
+      acc[1][1] = Mfma<T>::mma(a1, b1, acc[1][1]);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = wm * 32 + mi * 16 + Mfma<T>::row(lane, r);
+        const int64_t gi = i0 + rl;
+        const T xnv = xn[rl];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int cl = wn * 32 + ni * 16 + (lane & 15);
+          const int64_t gj = j0 + cl;
+          T val = T(0);
+          if (gi < n && gj < p) {
+            const T s2 = xnv + yn[cl];
+            T d2 = s2 - T(2) * acc[mi][ni][r];
+            if (d2 < close_thr * s2) {  // (nearly) coincident points: direct differences, no cancellation
+              T t = T(0);
+              for (int d = 0; d < Dp; ++d) {
+                const T df = Xs[rl * LDX + d] - Ys[cl * LDX + d];
+                t += df * df;
+              }
+              d2 = t;
+            }
+            val = variance * kernel_base<T>(kind, d2);
+            if (sym && gi == gj) val += diag_add;
+          } else if (sym && gi == gj) {
+            val = T(1);
+          }
+          if (out && gi < n_out && gj < p_out) out[gi * ldo + gj] = val;
+          if (alpha && gj < p) rs[mi][r] += val * alpha[gj];
+        }
+      }
+  }
+  if (alpha) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const T s = row16_sum(rs[mi][r]);
+        if ((lane & 15) == 0) red[wn * TILE + wm * 32 + mi * 16 + Mfma<T>::row(lane, r)] = s;
+      }
+    __syncthreads();
+    if (tid < TILE && i0 + tid < n_out) part[blockIdx.x * ldp + i0 + tid] = red[tid] + red[TILE + tid];
+  }
+}
+
+template <typename T>
+inline size_t kmm_smem_bytes(int Dp) {
+  return sizeof(T) * (size_t)(2 * TILE * (Dp + 2) + 2 * TILE + Dp + 2 * TILE);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // special functions
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double digamma_d(double x) {

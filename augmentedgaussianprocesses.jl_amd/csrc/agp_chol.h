@@ -25,6 +25,9 @@
 namespace agp {
 
 constexpr int LDP = TILE + 2;   // 66: [r][k] stride for 64-deep LDS tiles (conflict-free MFMA fragment reads)
+#ifndef AGP_PIVOT_ALG
+#define AGP_PIVOT_ALG 0  // how the 4x4 pivot blocks of the tile factorisation are factored (see chol_rounds)
+#endif
 constexpr int CHOL_THREADS = 512;
 
 __device__ __forceinline__ double rcp1(double p) {
@@ -158,7 +161,12 @@ struct NoHook {
   __device__ __forceinline__ void operator()(int) const {}
 };
 
-template <typename T, int J, int NS, typename H>
+// PIV selects how the 4x4 pivot block is factored (identical results up to rounding):
+//   0  LDL' column by column: every reciprocal waits for the previous column's update (dependent depth ~22 operations)
+//   1  fraction-free (Bareiss) minors: n_ij = d00 d_ij - d_i0 d_j0, p_ij = (n11 n_ij - n_i1 n_j1) / d00, M4 = (p22 p33 - p32^2) / n11
+//      are the leading-minor numerators of the same elimination, so the four reciprocals 1/d00, 1/M2, 1/M3, 1/M4 no longer wait
+//      for one another's multipliers (depth ~13); pivots = M_q / M_(q-1), multipliers l21 = n21 / M2, l32 = p32 / M3, ...
+template <typename T, int J, int NS, typename H, int PIV = 0>
 __device__ __forceinline__ void chol_rounds(T (&a)[NS][NS], T (&g)[NS][NS], T* sc, T* piv, const bool act, const int ti,
                                             const int tj, H& hook, const int hbase) {
 #pragma unroll 1
@@ -188,23 +196,51 @@ __device__ __forceinline__ void chol_rounds(T (&a)[NS][NS], T (&g)[NS][NS], T* s
     const T d00 = P[j0], d10 = P[j0 + 1], d20 = P[j0 + 2], d30 = P[j0 + 3];
     T d11 = P[TILE + j0 + 1], d21 = P[TILE + j0 + 2], d31 = P[TILE + j0 + 3];
     T d22 = P[2 * TILE + j0 + 2], d32 = P[2 * TILE + j0 + 3], d33 = P[3 * TILE + j0 + 3];
-    const T r0 = rcp1(d00);
-    const T l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
-    d11 = fma(-l10, d10, d11);
-    d21 = fma(-l20, d10, d21);
-    d31 = fma(-l30, d10, d31);
-    d22 = fma(-l20, d20, d22);
-    d32 = fma(-l30, d20, d32);
-    d33 = fma(-l30, d30, d33);
-    const T r1 = rcp1(d11);
-    const T l21 = d21 * r1, l31 = d31 * r1;
-    d22 = fma(-l21, d21, d22);
-    d32 = fma(-l31, d21, d32);
-    d33 = fma(-l31, d31, d33);
-    const T r2 = rcp1(d22);
-    const T l32 = d32 * r2;
-    d33 = fma(-l32, d32, d33);
-    const T r3 = rcp1(d33);
+    T r0, r1, r2, r3, l10, l20, l30, l21, l31, l32;
+    if (PIV == 1) {
+      r0 = rcp1(d00);
+      const T n11 = fma(d00, d11, -(d10 * d10)), n21 = fma(d00, d21, -(d20 * d10)), n31 = fma(d00, d31, -(d30 * d10));
+      const T n22 = fma(d00, d22, -(d20 * d20)), n32 = fma(d00, d32, -(d30 * d20)), n33 = fma(d00, d33, -(d30 * d30));
+      const T rm2 = rcp1(n11);
+      const T p22 = fma(n11, n22, -(n21 * n21)) * r0, p32 = fma(n11, n32, -(n31 * n21)) * r0;
+      const T p33 = fma(n11, n33, -(n31 * n31)) * r0;
+      const T rm3 = rcp1(p22);
+      const T m4 = fma(p22, p33, -(p32 * p32)) * rm2;
+      const T rm4 = rcp1(m4);
+      l10 = d10 * r0;
+      l20 = d20 * r0;
+      l30 = d30 * r0;
+      l21 = n21 * rm2;
+      l31 = n31 * rm2;
+      l32 = p32 * rm3;
+      r1 = d00 * rm2;
+      r2 = n11 * rm3;
+      r3 = p22 * rm4;
+      d11 = n11 * r0;   // the pivots themselves (positivity check, final scaling)
+      d22 = p22 * rm2;
+      d33 = m4 * rm3;
+    } else {
+      r0 = rcp1(d00);
+      l10 = d10 * r0;
+      l20 = d20 * r0;
+      l30 = d30 * r0;
+      d11 = fma(-l10, d10, d11);
+      d21 = fma(-l20, d10, d21);
+      d31 = fma(-l30, d10, d31);
+      d22 = fma(-l20, d20, d22);
+      d32 = fma(-l30, d20, d32);
+      d33 = fma(-l30, d30, d33);
+      r1 = rcp1(d11);
+      l21 = d21 * r1;
+      l31 = d31 * r1;
+      d22 = fma(-l21, d21, d22);
+      d32 = fma(-l31, d21, d32);
+      d33 = fma(-l31, d31, d33);
+      r2 = rcp1(d22);
+      l32 = d32 * r2;
+      d33 = fma(-l32, d32, d33);
+      r3 = rcp1(d33);
+    }
     if (ti == 0 && tj == 0) {
       piv[j0] = d00;
       piv[j0 + 1] = d11;
@@ -353,7 +389,7 @@ __device__ __forceinline__ typename Mfma<T>::acc_t mma_blk32(const T* As, const 
 }
 
 // eliminate the 32x32 block at (o, o) of bufA (lower valid): L -> bufA block, L^-1 -> bufB block ; all threads call
-template <typename T, typename H>
+template <typename T, typename H, int PIV = 0>
 __device__ __forceinline__ void elim_block32(T* bufA, T* bufB, int o, T* sc, T* piv, const bool act, const int ti,
                                              const int tj, H& hook) {
   T a[2][2], g[2][2];
@@ -367,8 +403,8 @@ __device__ __forceinline__ void elim_block32(T* bufA, T* bufB, int o, T* sc, T* 
       g[r][c] = (R == Cc) ? T(1) : T(0);
     }
   __syncthreads();
-  chol_rounds<T, 0, 2, H>(a, g, sc, piv + o, act, ti, tj, hook, 0);
-  chol_rounds<T, 1, 2, H>(a, g, sc, piv + o, act, ti, tj, hook, 4);
+  chol_rounds<T, 0, 2, H, PIV>(a, g, sc, piv + o, act, ti, tj, hook, 0);
+  chol_rounds<T, 1, 2, H, PIV>(a, g, sc, piv + o, act, ti, tj, hook, 4);
   __syncthreads();
   if (act) {
     T rsC[2], rsR[2];
@@ -390,7 +426,7 @@ __device__ __forceinline__ void elim_block32(T* bufA, T* bufB, int o, T* sc, T* 
   __syncthreads();
 }
 
-template <typename T, typename H>
+template <typename T, typename H, int PIV = AGP_PIVOT_ALG>
 __device__ __forceinline__ void factor_diag_tile_2lvl(T* bufA, T* bufB, T* sc, T* piv, int32_t* info, int64_t col0,
                                                       int64_t nvalid, H& hook) {
   const int tid = threadIdx.x;
@@ -400,7 +436,7 @@ __device__ __forceinline__ void factor_diag_tile_2lvl(T* bufA, T* bufB, T* sc, T
   const bool mw = wave < 4;  // the four waves that run the 32^3 MFMA products (one 16x16 result tile each)
   typedef typename Mfma<T>::acc_t acc_t;
   NoHook nohook;
-  elim_block32<T, NoHook>(bufA, bufB, 0, sc, piv, act, ti, tj, nohook);
+  elim_block32<T, NoHook, PIV>(bufA, bufB, 0, sc, piv, act, ti, tj, nohook);
   // L21 = A21 X11'   (in place in bufA[32:64, 0:32])
   acc_t acc;
 #pragma unroll
@@ -432,7 +468,7 @@ __device__ __forceinline__ void factor_diag_tile_2lvl(T* bufA, T* bufB, T* sc, T
       bufA[(32 + wr * 16 + Mfma<T>::row(lane, r)) * LDP + 32 + wc * 16 + (lane & 15)] = acc[r];
   }
   __syncthreads();
-  elim_block32<T, H>(bufA, bufB, 32, sc, piv, act, ti, tj, hook);  // hook rounds 0..7 of the second half
+  elim_block32<T, H, PIV>(bufA, bufB, 32, sc, piv, act, ti, tj, hook);  // hook rounds 0..7 of the second half
   // P = L21 X11  -> scratch bufB[0:32, 32:64]
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = T(0);
@@ -505,24 +541,19 @@ struct CholBatch {
 //   nP = nt - k + ne  (block rows k..nt-1 of A, then the ne extension blocks)
 //   nU = k >= 1 ? T(nt-k-1) + ne*(nt-k-1) : 0
 // ---------------------------------------------------------------------------------------------------
+// one workgroup's share of launch S(k): `bid` in [0, nP + nU) selects the role and the tile.  A device function so that the
+// per-column launches (k_chol_step) and the single-launch fallback with grid barriers (k_chol_safe) run the same code.
 template <typename T>
-__global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(CholBatch<T> bt, int64_t ld, int64_t ldx, int64_t lde,
-                                                            int64_t ne, int do_x, int64_t k, int64_t nt,
-                                                            int32_t* __restrict__ info, int64_t nvalid) {
-  T* __restrict__ A = bt.A[blockIdx.y];
-  T* __restrict__ X = bt.X[blockIdx.y];
-  T* __restrict__ Dg = bt.Dg[blockIdx.y];
-  T* __restrict__ E = bt.E[blockIdx.y];
-  __shared__ __attribute__((aligned(16))) T sm[3 * TILE * LDP];
-  __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
-  __shared__ T piv[TILE];
+__device__ __forceinline__ void chol_step_body(T* __restrict__ A, T* __restrict__ X, T* __restrict__ Dg, T* __restrict__ E,
+                                               int64_t bid, int64_t ld, int64_t ldx, int64_t lde, int64_t ne, int do_x,
+                                               int64_t k, int64_t nt, int32_t* __restrict__ info, int64_t nvalid, T* sm, T* sc,
+                                               T* piv) {
   T* bufA = sm;
   T* bufB = sm + TILE * LDP;
   T* bufC = sm + 2 * TILE * LDP;
   const int tid = threadIdx.x;
   const int64_t nP = nt - k + ne;
   const int64_t nr = nt - k - 1;
-  int64_t bid = blockIdx.x;
   const int64_t d0 = k * TILE, p0 = (k - 1) * TILE;
   if (bid < nP) {
     // ---------------- P: panel of block column k ----------------
@@ -590,6 +621,91 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(CholBatch<T> bt, int
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(CholBatch<T> bt, int64_t ld, int64_t ldx, int64_t lde,
+                                                            int64_t ne, int do_x, int64_t k, int64_t nt,
+                                                            int32_t* __restrict__ info, int64_t nvalid) {
+  __shared__ __attribute__((aligned(16))) T sm[3 * TILE * LDP];
+  __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
+  __shared__ T piv[TILE];
+  chol_step_body<T>(bt.A[blockIdx.y], bt.X[blockIdx.y], bt.Dg[blockIdx.y], bt.E[blockIdx.y], (int64_t)blockIdx.x, ld, ldx, lde,
+                    ne, do_x, k, nt, info, nvalid, sm, sc, piv);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_chol_safe: the fallback behind every task-graph launch of the CAVI step.  The task graph (k_chol_dag below) relies on
+// workgroups being dispatched in index order; when that assumption breaks (a second PROCESS running its own task graph on the
+// same device is the known way) a dependency never arrives, the bounded spin gives up and latches info = -1.  This kernel is
+// enqueued right behind the task graph on the same stream: its workgroups look at the latch and return at once when all is
+// well (one empty launch per step, ~2 us); on -1 it restores the inputs from their sources (A = -2 eta2, E = [kappa ; eta1' ; 0])
+// and runs the per-column algorithm (chol_step_body) for all columns in this ONE launch, separated by grid barriers.  The grid
+// is at most one workgroup per CU, so every workgroup gets a slot without any assumption about order, and the barriers cannot
+// deadlock.  The step itself never fails; `retries` counts the events so that the host can warn and stop using the task graph.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+struct SafeSrc {
+  const T* kappa[CHOL_MAXB];  // Bq x n rows of E (leading dimension lde)
+  const T* eta1[CHOL_MAXB];   // first row of the last extension block (the others are zero)
+  const T* eta2[CHOL_MAXB];   // A = -2 eta2
+  int64_t Bq;
+};
+
+__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();  // agent-scope release: this workgroup's plain stores reach memory before it is counted
+    atomicAdd(ctr, 1u);
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
+    __threadfence();  // agent-scope acquire: drop what this XCD's L2 may still hold of the others' tiles
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_safe(CholBatch<T> bt, SafeSrc<T> src, int nb, int64_t ld, int64_t ldx,
+                                                            int64_t lde, int64_t ne, int64_t nt,
+                                                            int32_t* __restrict__ info, int64_t nvalid,
+                                                            unsigned* __restrict__ bar, int32_t* __restrict__ retries) {
+  if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != -1) return;
+  __shared__ __attribute__((aligned(16))) T sm[3 * TILE * LDP];
+  __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
+  __shared__ T piv[TILE];
+  const unsigned nwg = gridDim.x;
+  const int64_t n = nt * TILE, gsz = (int64_t)nwg * CHOL_THREADS, g0 = (int64_t)blockIdx.x * CHOL_THREADS + threadIdx.x;
+  unsigned phase = 0;
+  for (int q = 0; q < nb; ++q) {  // inputs back from their sources (the aborted launch left E half overwritten)
+    T* A = bt.A[q];
+    T* E = bt.E[q];
+    for (int64_t e = g0; e < n * n; e += gsz) A[(e / n) * ld + (e % n)] = T(-2) * src.eta2[q][(e / n) * ld + (e % n)];
+    for (int64_t e = g0; e < src.Bq * n; e += gsz) E[(e / n) * lde + (e % n)] = src.kappa[q][(e / n) * lde + (e % n)];
+    for (int64_t e = g0; e < TILE * n; e += gsz)
+      E[(src.Bq + e / n) * lde + (e % n)] = (e / n) == 0 ? src.eta1[q][e % n] : T(0);
+  }
+  grid_barrier(bar, ++phase * nwg);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // every workgroup has seen the -1 by now: the latch goes back to "no failure",
+    atomicExch(info, 0);                      // so that a non-positive pivot of THIS run is reported like any other
+    atomicAdd(retries, 1);
+  }
+  grid_barrier(bar, ++phase * nwg);
+  for (int64_t k = 0; k < nt; ++k) {
+    const int64_t nP = nt - k + ne, nr = nt - k - 1;
+    const int64_t nU = (k >= 1 && nr > 0) ? nr * (nr + 1) / 2 + ne * nr : 0;
+    for (int64_t v = blockIdx.x; v < (nP + nU) * nb; v += nwg) {
+      const int q = (int)(v % nb);
+      chol_step_body<T>(bt.A[q], bt.X[q], bt.Dg[q], bt.E[q], v / nb, ld, ldx, lde, ne, 0, k, nt, info, nvalid, sm, sc, piv);
+      __syncthreads();  // the next share reuses the LDS tiles
+    }
+    grid_barrier(bar, ++phase * nwg);
+  }
+  // leave the barrier words at zero for the next use: arrivals are counted on a second word, the last one to arrive resets both
+  if (threadIdx.x == 0) {
+    if (atomicAdd(bar + 1, 1u) == nwg - 1) {
+      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // k_chol_dag: the augmented factorisation as ONE launch of a tile task graph -- one 512-thread workgroup per 64x64 tile
 // (r, c), c <= r (matrix rows, then the extension row blocks), numbered column-major so that every dependency points to a
@@ -614,7 +730,9 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(CholBatch<T> bt, int
 // flags: int32 [(nt + ne + nx) * nt] tile-ready | [nt] x-ready | [nt] T parked | [nt] D parked | [1] abort, each on its own
 // 256-byte line (stride DAG_FS)
 // ---------------------------------------------------------------------------------------------------
-constexpr long DAG_SPIN_LIMIT = 1L << 24;  // ~10 s of polling
+constexpr long DAG_SPIN_LIMIT = 1L << 17;  // ~50-100 ms of polling: far beyond any real wait (a whole factorisation takes < 15 ms
+                                           // at the largest size the task graph is used for), short enough that a lost dependency is
+                                           // handed to k_chol_safe before anybody notices
 // workgroup index of diagonal tile `col`: column c holds nt - c matrix tiles, ne extension tiles and, with the inverse
 // requested (nx), c + 1 identity-row tiles
 __device__ __forceinline__ int64_t chain_slot(int64_t col, int64_t nt, int64_t ne, int64_t nx) {
@@ -1140,8 +1258,10 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_diag_bench(const T* __restrict
   for (int it = 0; it < reps; ++it) {
     for (int e = threadIdx.x; e < TILE * TILE; e += CHOL_THREADS) bufA[(e >> 6) * LDP + (e & 63)] = A[e];
     __syncthreads();
+    NoHook nh;
     if (VAR == 0) factor_diag_tile512<T>(bufA, bufB, sc, piv, info, 0, 64);
-    else factor_diag_tile_2lvl<T>(bufA, bufB, sc, piv, info, 0, 64);
+    else if (VAR == 1) factor_diag_tile_2lvl<T, NoHook, 0>(bufA, bufB, sc, piv, info, 0, 64, nh);
+    else factor_diag_tile_2lvl<T, NoHook, 1>(bufA, bufB, sc, piv, info, 0, 64, nh);
   }
   for (int e = threadIdx.x; e < TILE * TILE; e += CHOL_THREADS) {
     out[blockIdx.x * 2 * TILE * TILE + e] = bufA[(e >> 6) * LDP + (e & 63)];

@@ -547,8 +547,13 @@ def cpu_baseline(a, cfg, ell, Z, X, yh, idx_np, out):
 
     def one(r, q):
         ib = remap[idx_np[q % total][:B]]
-        if lik == "mo":
-            r.update_parameters(Xh[ib], [np.asarray(t)[ib] for t in yt])
+        if lik == "mo":  # update_parameters!(::MOSVGP) training.jl:153-158, spelled out by the oracle's train loop
+            if r.local_vars is None:
+                r.local_vars = [R.init_local_vars_single(l, B) for l in r.likelihoods]
+            yb = [np.asarray(t, dtype=np.float64)[ib] for t in yt]
+            r.compute_kernel_matrices(Xh[ib])
+            r.update_A(yb)
+            r.variational_updates(yb)
         else:
             r.update_parameters(Xh[ib], ytr[ib])
 

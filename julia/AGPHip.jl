@@ -1,32 +1,50 @@
-# AGPHip.jl -- thin Julia shim over libagp_hip.so (include/agp_hip.h).
+# AGPHip.jl -- Julia shim over libagp_hip.so (include/agp_hip.h).
 #
-# NOT EXECUTED IN THE BUILD ENVIRONMENT (no julia binary there); it documents, in the reference's own language, the
-# exact binding a maintainer of AugmentedGaussianProcesses.jl would add so that SVGP / AnalyticVI / AnalyticSVI models
-# run their hot path on an MI355X.  AMDGPU.jl is used ONLY for device / stream / buffer handles (ROCArray, stream
-# pointer); there is no KernelAbstractions and no CUDA.jl compatibility layer: every numeric operation is a `ccall`
-# into hand-written HIP.
+# NOT EXECUTED IN THE BUILD ENVIRONMENT (no julia binary there or on the GPU box); it is the binding a maintainer of
+# AugmentedGaussianProcesses.jl would add so that SVGP / MOSVGP models with AnalyticVI / AnalyticSVI run their hot path on an
+# MI355X, written against the reference's own internals (file:line cited at every method).  AMDGPU.jl is used ONLY for device /
+# stream / buffer handles (ROCArray, the stream pointer); there is no KernelAbstractions and no CUDA.jl compatibility layer:
+# every numeric operation is a `ccall` into hand-written HIP.
+#
+# Usage (the reference API, unchanged, on a wrapped model):
+#
+#     m  = SVGP(kernel, LogisticLikelihood(), AnalyticSVI(1024), Z; optimiser=false)     # the reference constructor
+#     hm = AGPHip.HipModel(m)                                                              # device twin
+#     hm, state = train!(hm, X, y, 1000)                                                  # src/training/training.jl:13-111
+#     ŷ = predict_y(hm, X_test); p = proba_y(hm, X_test); μ, σ² = predict_f(hm, X_test; cov=true)
+#     ELBO(hm, X, y); objective(hm, state, y)
 #
 # Seams replaced (SURVEY.md section 8b):
-#   update_parameters!(model::SVGP, state, x, y)          src/training/training.jl:140-144  -> agp_svgp_cavi_step
-#   compute_K / compute_κ                                  src/gpblocks/latentgp.jl:205-215  -> inside cavi_step / agp_svgp_refresh_K
-#   ELBO(model, state, y) / ELBO(model, X, y)              src/inference/analyticVI.jl:255-274, src/functions/ELBO.jl:32-47 -> agp_svgp_elbo
-#   _predict_f / predict_y / proba_y                       src/training/predictions.jl:25-50,178-247 -> agp_svgp_predict_f / _predict_y / _proba_y
+#   update_parameters!(model::SVGP / ::MOSVGP, state, x, y)   src/training/training.jl:140-158        -> agp_svgp_cavi_step[_multi]
+#   compute_K / compute_κ                                     src/gpblocks/latentgp.jl:205-215         -> inside the step / agp_svgp_refresh_K
+#   update_hyperparameters!(m, state, x, y)                   src/hyperparameter/autotuning.jl:86-140  -> agp_svgp_hyper_step[_multi]
+#   ELBO(model, state, y) / ELBO(model, X, y)                 src/inference/analyticVI.jl:255-297, src/functions/ELBO.jl:32-47 -> agp_svgp_elbo
+#   _predict_f / predict_y / proba_y                          src/training/predictions.jl:25-92,178-247 -> agp_svgp_predict_f / _predict_y / _proba_y
+#   init_state                                                src/training/states.jl:1-9               -> agp_svgp_init_state
+# Multi-GPU (one Julia process per GPU, e.g. under MPI.jl or Distributed): agp_comm_* binds RCCL inside the library; the host only
+# ships the 128-byte id from rank 0 to the others (section "multi-GPU" below).
 module AGPHip
 
 using AMDGPU
 using AugmentedGaussianProcesses
 using KernelFunctions
+using LinearAlgebra
+using StatsBase: sample
 const AGP = AugmentedGaussianProcesses
 
-const libagp = joinpath(@__DIR__, "..", "augmentedgaussianprocesses.jl_amd", "libagp_hip.so")
+import AugmentedGaussianProcesses: train!, predict_f, predict_y, proba_y, ELBO, objective
 
-# ---- POD mirrors of include/agp_hip.h ---------------------------------------------------------------------------
+const libagp = get(ENV, "AGP_HIP_LIB", joinpath(@__DIR__, "..", "augmentedgaussianprocesses.jl_amd", "libagp_hip.so"))
+
+# ---- POD mirrors of include/agp_hip.h (field order and widths are checked by tests/test_host_abi.py on the Python mirror) -------
 struct KernelDesc
     kind::Int32
     ard::Int32
     variance::Float64
     scale::Float64
     ard_scales_host::Ptr{Float64}
+    has_variance::Int32          # the kernel object is `σ² * k`            (what update_kernel! may step,
+    has_transform::Int32         # the kernel object is `k ∘ Scale/ARDTransform`   autotuning_utils.jl:47-67)
 end
 struct LikDesc
     kind::Int32
@@ -47,41 +65,63 @@ struct SvgpDesc
     rm_kappa::Float64
     rm_tau::Float64
     elbo_mode::Int32
-    reserved::Int32
+    flags::Int32                 # AGP_FLAG_STALE_K = 1 : reference_compat_stale_K (training.jl:187-208, SURVEY Appendix A Q1)
 end
+const AGP_FLAG_STALE_K = Int32(1)
+const AGP_SHARD_LATENT, AGP_SHARD_BATCH = Int32(0), Int32(1)
 
 struct AGPError <: Exception
     status::Int32
     msg::String
 end
-function check(ctx, st::Int32)
+function check(ctx, st::Integer)
     st == 0 && return nothing
     msg = unsafe_string(ccall((:agp_last_error, libagp), Cstring, (Ptr{Cvoid},), ctx))
-    st == 2 && throw(PosDefException(0))                       # cholesky failure, latentgp.jl:206
-    st == 3 && error("K̃ has negative values")                  # latentgp.jl:213
-    throw(AGPError(st, msg))
+    if st == 2                                                   # cholesky failure, latentgp.jl:206
+        mt = match(r"leading minor (\d+)", msg)
+        throw(PosDefException(mt === nothing ? 0 : parse(Int, mt.captures[1])))
+    end
+    st == 3 && error("K̃ has negative values")                    # latentgp.jl:213
+    st == 4 && error(msg)                                        # batch-size check, training.jl:27-29
+    st == 6 && throw(ArgumentError(msg))                         # treat_labels!, classification.jl:36-44 / multiclass.jl:81-83
+    throw(AGPError(Int32(st), msg))
 end
 
-# ---- KernelFunctions.jl objects -> agp_kernel_desc ----------------------------------------------------------------
+# ---- KernelFunctions.jl objects -> agp_kernel_desc ----------------------------------------------------------------------------
 kind(::SqExponentialKernel) = Int32(0)
 kind(::Matern52Kernel) = Int32(1)
 kind(::Matern32Kernel) = Int32(2)
 kind(::ExponentialKernel) = Int32(3)
 function kernel_desc(k::Kernel, D::Int)
-    σ² = 1.0
+    σ², hasv = 1.0, Int32(0)
     if k isa ScaledKernel
-        σ² = only(k.σ²); k = k.kernel
+        σ² = only(k.σ²); k = k.kernel; hasv = Int32(1)
     end
     if k isa TransformedKernel
         t = k.transform; b = k.kernel
         if t isa ScaleTransform
-            return KernelDesc(kind(b), 0, σ², only(t.s), C_NULL), nothing
+            return KernelDesc(kind(b), 0, σ², only(t.s), C_NULL, hasv, 1), nothing
         elseif t isa ARDTransform
             v = Vector{Float64}(t.v)
-            return KernelDesc(kind(b), 1, σ², 1.0, pointer(v)), v      # keep v alive (GC.@preserve at the call)
+            length(v) == D || throw(DimensionMismatch("ARDTransform has $(length(v)) scales, the data $D dimensions"))
+            return KernelDesc(kind(b), 1, σ², 1.0, pointer(v), hasv, 1), v   # keep v alive (GC.@preserve at the call)
         end
+        error("only ScaleTransform / ARDTransform are wired on the HIP path")
     end
-    return KernelDesc(kind(k), 0, σ², 1.0, C_NULL), nothing
+    return KernelDesc(kind(k), 0, σ², 1.0, C_NULL, hasv, 0), nothing
+end
+
+# write the (possibly optimised) parameters back into the reference's kernel object (what update_kernel! mutates in place)
+function pull_kernel!(k::Kernel, σ²::Float64, scales::Vector{Float64})
+    if k isa ScaledKernel
+        k.σ² .= σ²; k = k.kernel
+    end
+    if k isa TransformedKernel
+        t = k.transform
+        t isa ScaleTransform && (t.s .= scales[1])
+        t isa ARDTransform && (t.v .= scales)
+    end
+    return nothing
 end
 
 lik_desc(l::GaussianLikelihood) = LikDesc(0, 1, AGP.noise(l), 0.0)
@@ -90,99 +130,455 @@ lik_desc(l::StudentTLikelihood) = LikDesc(2, 1, l.ν, l.σ)
 lik_desc(l::AGP.MultiClassLikelihood{<:AGP.LogisticSoftMaxLink}) = LikDesc(3, AGP.n_class(l), 0.0, 0.0)
 lik_desc(l::LaplaceLikelihood) = LikDesc(5, 1, l.β, 0.0)
 lik_desc(::AGP.BernoulliLikelihood{<:AGP.SVMLink}) = LikDesc(6, 1, 0.0, 0.0)
-lik_desc(l::AGP.PoissonLikelihood{<:AGP.ScaledLogistic}) = LikDesc(7, 1, only(l.invlink.λ), 0.0)   # λ is state: see pull_lik_state!
+lik_desc(l::AGP.PoissonLikelihood{<:AGP.ScaledLogistic}) = LikDesc(7, 1, only(l.invlink.λ), 0.0)   # λ is state: pull_lik_state!
 lik_desc(l::NegBinomialLikelihood) = LikDesc(8, 1, Float64(l.r), 0.0)
 lik_desc(l::AGP.HeteroscedasticGaussianLikelihood{<:AGP.InvScaledLogistic}) = LikDesc(9, 1, only(l.invlink.λ), 0.0)
+lik_desc(l) = error("The $l is not compatible or implemented with AnalyticVI on the HIP path")     # SVGP.jl:48-49
 
-# λ of Poisson / Heteroscedastic is re-estimated on the device by every local update (poisson.jl:78, heteroscedastic.jl:95);
-# copy it back into the reference object after training / before predicting with reference-side code.
-function pull_lik_state!(s, l::Union{AGP.PoissonLikelihood,AGP.HeteroscedasticGaussianLikelihood})
-    v = Ref{Float64}()
-    check(s.ctx, ccall((:agp_svgp_get_lik_param, libagp), Int32, (Ptr{Cvoid}, Ref{Float64}), s.h, v))
-    l.invlink.λ .= v[]
-    return l
-end
-pull_lik_state!(s, l) = l
+is_multiclass(l) = l isa AGP.MultiClassLikelihood
+is_bernoulli(l) = l isa AGP.BernoulliLikelihood
+is_event(l) = l isa AGP.PoissonLikelihood || l isa NegBinomialLikelihood
 
-# ---- device handle living next to the reference model -----------------------------------------------------------------
-mutable struct HipState{T}
+# ---- the device twin of a reference model -------------------------------------------------------------------------------------
+mutable struct HipModel{T,M<:AGP.AbstractGPModel{T}}
+    model::M                       # the reference object: kernels, Z, likelihood, inference, posterior live on in it
     ctx::Ptr{Cvoid}
     h::Ptr{Cvoid}
-    X::ROCMatrix{T}          # D x N (ColVecs memory order == the ABI's point-major layout)
-    y::ROCVector              # T (±1 / real) or Int32 class index
+    comm::Ptr{Cvoid}               # agp_comm* (C_NULL: single GPU)
+    shard::Int32                   # AGP_SHARD_LATENT / AGP_SHARD_BATCH when comm is set
+    latent_range::UnitRange{Int}   # latents of model.f held by this rank (all of them unless latent-parallel)
     maxbatch::Int
+    X::Union{Nothing,ROCMatrix{T}} # D x N (ColVecs memory order == the ABI's point-major layout)
+    y::Any                         # ROCVector{T} / ROCVector{Int32} (class index) / ROCMatrix{T} (n_task x N, multi-output)
+    N::Int
+    last_idx::Any                  # device indices of the last minibatch (kept alive: the step is asynchronous)
+    stale_K::Bool
 end
 
-function make_handle(model::SVGP{T}, X::AbstractMatrix, y, maxbatch::Int; obsdim=1) where {T}
+is_mo(hm::HipModel) = hm.model isa AGP.MOSVGP
+nlat(hm::HipModel) = length(hm.latent_range)
+
+"""
+    HipModel(model::Union{SVGP,MOSVGP}; device=AMDGPU.device_id()-1, reference_compat_stale_K=false,
+             latent_range=1:length(model.f))
+
+Wrap a reference model.  Nothing is allocated on the device until data arrive (`train!`, `ELBO`, `predict_*`).
+"""
+function HipModel(model::M; reference_compat_stale_K::Bool=false,
+                  latent_range::UnitRange{Int}=1:length(model.f)) where {T,M<:AGP.AbstractGPModel{T}}
+    model isa Union{SVGP,AGP.MOSVGP} || error("only SVGP / MOSVGP run on the HIP path")
+    AGP.inference(model) isa AnalyticVI || error("The inference object should be of type `AnalyticVI`")   # SVGP.jl:45-47
+    return HipModel{T,M}(model, C_NULL, C_NULL, C_NULL, AGP_SHARD_LATENT, latent_range, 0, nothing, nothing, 0, nothing,
+                         reference_compat_stale_K)
+end
+
+function ensure_ctx!(hm::HipModel)
+    hm.ctx == C_NULL || return hm.ctx
     ctx = Ref{Ptr{Cvoid}}()
-    stream = AMDGPU.stream().stream                         # share AMDGPU.jl's HIP stream with the library
+    stream = AMDGPU.stream().stream                          # share AMDGPU.jl's HIP stream with the library
     st = ccall((:agp_ctx_create, libagp), Int32, (Int32, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), AMDGPU.device_id() - 1, stream, ctx)
     st == 0 || throw(AGPError(st, "agp_ctx_create"))
-    Xd = ROCArray{T}(obsdim == 1 ? permutedims(X) : X)      # one-time RowVecs -> point-major permutation
+    hm.ctx = ctx[]
+    finalizer(destroy!, hm)
+    return hm.ctx
+end
+
+function destroy!(hm::HipModel)
+    hm.h == C_NULL || ccall((:agp_svgp_destroy, libagp), Int32, (Ptr{Cvoid},), hm.h)
+    hm.comm == C_NULL || ccall((:agp_comm_destroy, libagp), Int32, (Ptr{Cvoid},), hm.comm)
+    hm.ctx == C_NULL || ccall((:agp_ctx_destroy, libagp), Int32, (Ptr{Cvoid},), hm.ctx)
+    hm.h = hm.comm = hm.ctx = C_NULL
+    return nothing
+end
+
+# (re)create the device handle for batches up to `maxbatch`; the posterior and the optimiser counters travel (get/set_state)
+function ensure_handle!(hm::HipModel{T}, maxbatch::Int) where {T}
+    (hm.h != C_NULL && maxbatch <= hm.maxbatch) && return hm.h
+    ctx = ensure_ctx!(hm)
+    model = hm.model
+    old = hm.h == C_NULL ? nothing : (pull_posterior!(hm); opt_state(hm))
+    hm.h == C_NULL || ccall((:agp_svgp_destroy, libagp), Int32, (Ptr{Cvoid},), hm.h)
     inf = AGP.inference(model)
-    D, N = size(Xd)
-    m = AGP.dim(model.f[1])
-    desc = SvgpDesc(T == Float64 ? 0 : 1, AGP.n_latent(model), 0, AGP.is_stochastic(inf) ? 1 : 0, m, D, maxbatch,
-                    lik_desc(AGP.likelihood(model)), 0.0,
-                    AGP.is_stochastic(inf) ? inf.vi_opt.optimiser.κ : 0.51, AGP.is_stochastic(inf) ? inf.vi_opt.optimiser.τ : 1.0,
-                    0, 0)
+    gp1 = model.f[first(hm.latent_range)]
+    D = length(first(AGP.Zview(gp1)))
+    m = AGP.dim(gp1)
+    stoch = AGP.is_stochastic(inf)
+    rm = stoch ? inf.vi_opt.optimiser : nothing             # RobbinsMonro(κ, τ), optimisers.jl:1-19
+    stoch && !(rm isa AGP.RobbinsMonro) && error("only RobbinsMonro is wired on this path (ALRSVI is dead code in the reference)")
+    ld = is_mo(hm) ? LikDesc(4, 1, 0.0, 0.0) : lik_desc(AGP.likelihood(model))
+    desc = SvgpDesc(T == Float64 ? 0 : 1, nlat(hm), first(hm.latent_range) - 1, stoch ? 1 : 0, m, D, maxbatch, ld, 0.0,
+                    stoch ? rm.κ : 0.51, stoch ? rm.τ : 1.0, 0, hm.stale_K ? AGP_FLAG_STALE_K : Int32(0))
     h = Ref{Ptr{Cvoid}}()
-    check(ctx[], ccall((:agp_svgp_create, libagp), Int32, (Ptr{Cvoid}, Ref{SvgpDesc}, Ptr{Ptr{Cvoid}}), ctx[], desc, h))
-    for (i, gp) in enumerate(model.f)
+    check(ctx, ccall((:agp_svgp_create, libagp), Int32, (Ptr{Cvoid}, Ref{SvgpDesc}, Ptr{Ptr{Cvoid}}), ctx, desc, h))
+    hm.h, hm.maxbatch = h[], maxbatch
+    for (i, q) in enumerate(hm.latent_range)
+        gp = model.f[q]
         kd, keep = kernel_desc(AGP.kernel(gp), D)
-        GC.@preserve keep check(ctx[], ccall((:agp_svgp_set_kernel, libagp), Int32, (Ptr{Cvoid}, Int32, Ref{KernelDesc}), h[], i - 1, kd))
+        GC.@preserve keep check(ctx, ccall((:agp_svgp_set_kernel, libagp), Int32, (Ptr{Cvoid}, Int32, Ref{KernelDesc}), hm.h, i - 1, kd))
         Zd = ROCArray{T}(reduce(hcat, AGP.Zview(gp)))       # D x m, point-major
-        check(ctx[], ccall((:agp_svgp_set_Z, libagp), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64), h[], i - 1, pointer(Zd), D))
+        check(ctx, ccall((:agp_svgp_set_Z, libagp), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64), hm.h, i - 1, pointer(Zd), D))
+        μ₀ = AGP.pr_mean(gp)
+        if !(μ₀ isa AGP.ZeroMean)
+            (AGP.opt(gp) === nothing && AGP.Zopt(gp) === nothing) ||
+                error("a non-zero prior mean with hyper-parameter optimisation is not wired (the reference's own update, autotuning.jl:104-106, cannot run)")
+            v = ROCArray{T}(μ₀(AGP.Zview(gp)))
+            check(ctx, ccall((:agp_svgp_set_prior_mean, libagp), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}), hm.h, i - 1, pointer(v)))
+        end
+        AMDGPU.synchronize()
     end
-    if AGP.likelihood(model) isa AGP.PoissonLikelihood       # the λ update integrates logistic by Gauss-Hermite (utils.jl:16-19)
-        check(ctx[], ccall((:agp_svgp_set_quadrature, libagp), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int32),
-                           h[], AGP.pred_nodes, AGP.pred_weights, length(AGP.pred_nodes)))
+    if is_mo(hm)
+        liks = collect(AGP.likelihood(model))
+        lds = [lik_desc(l) for l in liks]
+        Q = length(model.f)
+        A = Matrix{Float64}(undef, length(liks), Q)          # model.A[t][j][q]; nf_per_task == 1 on this path
+        for t in 1:length(liks), q in 1:Q
+            A[t, q] = model.A[t][1][q]
+        end
+        Aopt = model.A_opt
+        nlat(hm) == Q || check(ctx, ccall((:agp_svgp_mo_shard, libagp), Int32, (Ptr{Cvoid}, Int32), hm.h, Q))
+        check(ctx, ccall((:agp_svgp_set_multioutput, libagp), Int32,
+                         (Ptr{Cvoid}, Int32, Ptr{LikDesc}, Ptr{Float64}, Float64, Float64, Float64, Float64),
+                         hm.h, length(liks), lds, permutedims(A), Aopt === nothing ? 0.0 : Aopt.eta, 0.9, 0.999, 1e-8))
+    elseif AGP.likelihood(model) isa AGP.PoissonLikelihood    # the λ update integrates logistic by Gauss-Hermite (utils.jl:16-19)
+        check(ctx, ccall((:agp_svgp_set_quadrature, libagp), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int32),
+                         hm.h, AGP.pred_nodes, AGP.pred_weights, length(AGP.pred_nodes)))
     end
-    yd = AGP.likelihood(model) isa AGP.MultiClassLikelihood ? ROCArray(Int32.(map(r -> findfirst(r) - 1, eachrow(y)))) : ROCArray{T}(y)
-    return HipState{T}(ctx[], h[], Xd, yd, maxbatch)
+    # hyper-parameter optimisers: SVGP(...; optimiser, Zoptimiser) (SVGP.jl:39-42, default ADAM(0.01) / nothing)
+    ko, zo = AGP.opt(gp1), AGP.Zopt(gp1)
+    if ko !== nothing || zo !== nothing
+        o = ko === nothing ? zo : ko
+        check(ctx, ccall((:agp_svgp_hyper_configure, libagp), Int32,
+                         (Ptr{Cvoid}, Int32, Float64, Int32, Float64, Float64, Float64, Float64),
+                         hm.h, ko === nothing ? 0 : 1, ko === nothing ? 0.0 : ko.eta, zo === nothing ? 0 : 1,
+                         zo === nothing ? 0.0 : zo.eta, o.beta[1], o.beta[2], 1e-8))
+    end
+    if old !== nothing
+        push_posterior!(hm)
+        check(ctx, ccall((:agp_svgp_set_opt_state, libagp), Int32, (Ptr{Cvoid}, Int64), hm.h, old))
+    end
+    return hm.h
 end
 
-# ---- update_parameters!(model::SVGP, state, x, y) replacement (training.jl:140-144) ------------------------------------
-# `idx` is the minibatch drawn by train! (StatsBase.sample, training.jl:51-53); it is uploaded instead of a view of X.
-function update_parameters_hip!(s::HipState{T}, idx::Union{Nothing,Vector{Int}}, ρ::Real) where {T}
-    D = size(s.X, 1)
-    if idx === nothing
-        B = size(s.X, 2); idp = C_NULL
-        st = ccall((:agp_svgp_cavi_step, libagp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int64, Float64),
-                   s.h, pointer(s.X), D, pointer(s.y), idp, B, ρ)
-    else
-        idd = ROCArray(Int64.(idx .- 1))                     # 0-based on the device
-        st = ccall((:agp_svgp_cavi_step, libagp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int64, Float64),
-                   s.h, pointer(s.X), D, pointer(s.y), pointer(idd), length(idx), ρ)
-    end
-    check(s.ctx, st)
-end
+opt_state(hm::HipModel) = (n = Ref{Int64}(); ccall((:agp_svgp_get_opt_state, libagp), Int32, (Ptr{Cvoid}, Ref{Int64}), hm.h, n); n[])
 
-# pull (μ, Σ, η₁, η₂) back into the reference's VarPosterior (posterior.jl:21-27), e.g. at the end of train!
-function sync_posterior!(model::SVGP{T}, s::HipState{T}) where {T}
-    for (i, gp) in enumerate(model.f)
+# (μ, Σ, η₁, η₂) device -> the reference's VarPosterior (posterior.jl:21-27), e.g. at the end of train!
+function pull_posterior!(hm::HipModel{T}) where {T}
+    for (i, q) in enumerate(hm.latent_range)
+        gp = hm.model.f[q]
         m = AGP.dim(gp)
         μ = ROCVector{T}(undef, m); η₁ = ROCVector{T}(undef, m)
         Σ = ROCMatrix{T}(undef, m, m); η₂ = ROCMatrix{T}(undef, m, m)
-        check(s.ctx, ccall((:agp_svgp_get_state, libagp), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-                           s.h, i - 1, pointer(μ), pointer(Σ), pointer(η₁), pointer(η₂)))
-        ccall((:agp_ctx_sync, libagp), Int32, (Ptr{Cvoid},), s.ctx)
+        check(hm.ctx, ccall((:agp_svgp_get_state, libagp), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                            hm.h, i - 1, pointer(μ), pointer(Σ), pointer(η₁), pointer(η₂)))
+        ccall((:agp_ctx_sync, libagp), Int32, (Ptr{Cvoid},), hm.ctx)
         gp.post.μ .= Array(μ); gp.post.η₁ .= Array(η₁)
         gp.post.Σ.data .= Array(Σ); gp.post.η₂.data .= Array(η₂)   # symmetric: row-major == column-major
     end
-    return model
+    return hm
+end
+# the reference's (η₁, η₂) -> device (a model trained on the CPU continues on the GPU)
+function push_posterior!(hm::HipModel{T}) where {T}
+    for (i, q) in enumerate(hm.latent_range)
+        gp = hm.model.f[q]
+        η₁ = ROCArray{T}(AGP.nat1(gp)); η₂ = ROCArray{T}(Matrix(AGP.nat2(gp)))
+        check(hm.ctx, ccall((:agp_svgp_set_state, libagp), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}), hm.h, i - 1, pointer(η₁), pointer(η₂)))
+    end
+    return hm
 end
 
-# predict_f(model, X_test; cov) replacement (predictions.jl:25-50): streams over the test points on the device
-function predict_f_hip(s::HipState{T}, Xt::AbstractMatrix; cov::Bool=false, obsdim=1, n_latent=1) where {T}
+# kernel parameters / Z (device, after hyper steps) -> the reference objects; λ of Poisson / Heteroscedastic likewise
+function pull_hypers!(hm::HipModel{T}) where {T}
+    for (i, q) in enumerate(hm.latent_range)
+        gp = hm.model.f[q]
+        (AGP.opt(gp) === nothing && AGP.Zopt(gp) === nothing) && continue
+        D = length(first(AGP.Zview(gp))); m = AGP.dim(gp)
+        σ² = Ref{Float64}(); sc = Vector{Float64}(undef, D)
+        check(hm.ctx, ccall((:agp_svgp_get_kernel, libagp), Int32, (Ptr{Cvoid}, Int32, Ref{Float64}, Ptr{Float64}), hm.h, i - 1, σ², sc))
+        pull_kernel!(AGP.kernel(gp), σ²[], sc)
+        Zd = ROCMatrix{T}(undef, D, m)
+        check(hm.ctx, ccall((:agp_svgp_get_Z, libagp), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64), hm.h, i - 1, pointer(Zd), D))
+        Zh = Array(Zd)
+        for j in 1:m
+            AGP.Zview(gp)[j] .= view(Zh, :, j)
+        end
+    end
+    l = AGP.likelihood(hm.model)
+    if l isa Union{AGP.PoissonLikelihood,AGP.HeteroscedasticGaussianLikelihood}
+        v = Ref{Float64}()
+        check(hm.ctx, ccall((:agp_svgp_get_lik_param, libagp), Int32, (Ptr{Cvoid}, Ref{Float64}), hm.h, v))
+        l.invlink.λ .= v[]                                   # poisson.jl:78, heteroscedastic.jl:95 mutate it in place
+    end
+    if is_mo(hm)
+        liks = AGP.likelihood(hm.model); Q = length(hm.model.f)
+        A = Matrix{Float64}(undef, Q, length(liks))          # row-major n_task x Q on the C side
+        check(hm.ctx, ccall((:agp_svgp_get_A, libagp), Int32, (Ptr{Cvoid}, Ptr{Float64}), hm.h, A))
+        for t in 1:length(liks), q in 1:Q
+            hm.model.A[t][1][q] = A[q, t]
+        end
+    end
+    return hm
+end
+
+# ---- data ---------------------------------------------------------------------------------------------------------------------
+# wrap_X / wrap_data (src/data/datacontainer.jl:18-74, src/data/utils.jl:16-30): labels are normalised by the reference's own
+# treat_labels!, then laid out for the device: ±1 / real T[N]; class index Int32[N] (0-based row-wise findfirst of the one-hot
+# BitMatrix, multiclass.jl:81-94); multi-output T[n_task x N] (point-major)
+function upload!(hm::HipModel{T}, X::AbstractMatrix, y; obsdim::Int=1) where {T}
+    Xv, _ = AGP.wrap_X(X, obsdim)
+    data = AGP.wrap_data(Xv, y, AGP.likelihood(hm.model))     # runs treat_labels! (ArgumentErrors surface here)
+    yt = AGP.output(data)
+    hm.X = ROCArray{T}(obsdim == 1 ? permutedims(X) : X)      # one-time RowVecs -> point-major permutation
+    hm.N = size(hm.X, 2)
+    if is_mo(hm)
+        hm.y = ROCArray{T}(permutedims(reduce(hcat, yt)))     # n_task x N
+    elseif is_multiclass(AGP.likelihood(hm.model))
+        hm.y = ROCArray(Int32.(map(r -> findfirst(r) - 1, eachrow(yt))))
+    else
+        hm.y = ROCArray{T}(yt)
+    end
+    return data
+end
+
+# ---- update_parameters!(model, state, x, y) (training.jl:140-158) ---------------------------------------------------------------
+# `idx` is the minibatch drawn by train! (StatsBase.sample, training.jl:51-53), 1-based; nothing = full batch.
+function update_parameters!(hm::HipModel{T}, idx::Union{Nothing,AbstractVector{<:Integer}}, ρ::Real) where {T}
+    D = size(hm.X, 1)
+    idd = idx === nothing ? nothing : ROCArray(Int64.(idx .- 1))    # 0-based on the device
+    hm.last_idx = idd
+    B = idx === nothing ? hm.N : length(idx)
+    idp = idd === nothing ? Ptr{Int64}(C_NULL) : pointer(idd)
+    st = if hm.comm == C_NULL && nlat(hm) == length(hm.model.f)
+        ccall((:agp_svgp_cavi_step, libagp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int64, Float64),
+              hm.h, pointer(hm.X), D, pointer(hm.y), idp, B, ρ)
+    else
+        ccall((:agp_svgp_cavi_step_multi, libagp), Int32,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int64, Float64),
+              hm.h, hm.comm, hm.shard, pointer(hm.X), D, pointer(hm.y), idp, B, ρ)
+    end
+    check(hm.ctx, st)
+    return nothing
+end
+
+# update_hyperparameters!(m, state, x, y) (autotuning.jl:86-140) on the minibatch of the last step
+function update_hyperparameters!(hm::HipModel; tied::Bool=false)
+    st = hm.comm == C_NULL && !tied ? ccall((:agp_svgp_hyper_step, libagp), Int32, (Ptr{Cvoid},), hm.h) :
+         ccall((:agp_svgp_hyper_step_multi, libagp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32), hm.h, hm.comm, tied ? 1 : 0)
+    check(hm.ctx, st)
+end
+
+"""
+    train!(hm::HipModel, X, y, iterations=100; callback=nothing, state=nothing, obsdim=1, idx_stream=nothing)
+
+`train!` of the reference (src/training/training.jl:13-111) with the step on the device: same checks, same ρ = N/B, same
+`StatsBase.sample(1:N, B; replace=false)` per iteration (or the caller's `idx_stream`, one index vector per iteration, so that
+runs are reproducible across back-ends), same hyper-step gating (`n_iter % atfrequency == 0 && n_iter >= 3 &&
+local_iter != iterations`, :65-69), fixed iteration count (the reference never reads `convergence` / ϵ, :48,93-94), final
+`compute_Ks` (:107).  Returns `(hm, state)`; the state is the device-resident one: pass it back (`state=state`) to continue, or
+omit it to restart counters and local variables like the reference's `init_state` (states.jl:1-9).
+"""
+function train!(hm::HipModel{T}, X::AbstractArray, y, iterations::Int=100; callback=nothing, convergence=nothing,
+                state=nothing, obsdim=1, idx_stream=nothing) where {T}
+    iterations > 0 || error("Number of iterations should be positive")
+    model = hm.model
+    inf = AGP.inference(model)
+    data = upload!(hm, X isa AbstractMatrix ? X : reduce(hcat, X)', y; obsdim)
+    N = hm.N
+    if AGP.is_stochastic(model)
+        0 < AGP.batchsize(inf) <= N || error(
+            "The size of mini-batch $(AGP.batchsize(inf)) is incorrect (negative or bigger than number of samples), please set `batchsize` correctly in the inference object")
+        AGP.set_ρ!(model, N / AGP.batchsize(inf))
+    else
+        AGP.set_batchsize!(inf, N)
+    end
+    B = AGP.batchsize(inf)
+    Blocal = (hm.comm != C_NULL && hm.shard == AGP_SHARD_BATCH) ? B ÷ comm_world(hm) : B
+    ensure_handle!(hm, Blocal)
+    if state === nothing
+        AGP.setHPupdated!(inf, true)
+        check(hm.ctx, ccall((:agp_svgp_init_state, libagp), Int32, (Ptr{Cvoid},), hm.h))      # init_state(model), training.jl:41-45
+    else
+        check(hm.ctx, ccall((:agp_svgp_invalidate_data, libagp), Int32, (Ptr{Cvoid},), hm.h)) # the buffers were re-uploaded
+    end
+    check(hm.ctx, ccall((:agp_svgp_refresh_K, libagp), Int32, (Ptr{Cvoid},), hm.h))
+    ρ = AGP.is_stochastic(model) ? N / B : 1.0
+    hyper_on = any(gp -> AGP.opt(gp) !== nothing || AGP.Zopt(gp) !== nothing, model.f)
+    local_iter = 1
+    while true
+        idx = nothing
+        if AGP.is_stochastic(model)
+            idx = idx_stream === nothing ? sample(1:N, B; replace=false) : idx_stream[local_iter]
+            if hm.comm != C_NULL && hm.shard == AGP_SHARD_BATCH    # this rank's share of the minibatch (rho stays N / B_total)
+                r = comm_rank(hm)
+                idx = idx[(r * Blocal + 1):((r + 1) * Blocal)]
+            end
+        end
+        update_parameters!(hm, idx, ρ)
+        AGP.set_trained!(model, true)
+        callback === nothing || callback(hm, hm, AGP.n_iter(model))
+        if hyper_on && (AGP.n_iter(model) % model.atfrequency == 0) && (AGP.n_iter(model) >= 3) && (local_iter != iterations)
+            update_hyperparameters!(hm)
+        end
+        local_iter += 1
+        inf.n_iter += 1
+        (local_iter <= iterations) || break
+    end
+    check(hm.ctx, ccall((:agp_svgp_check_status, libagp), Int32, (Ptr{Cvoid},), hm.h))
+    check(hm.ctx, ccall((:agp_svgp_refresh_K, libagp), Int32, (Ptr{Cvoid},), hm.h))            # compute_Ks, training.jl:107
+    pull_posterior!(hm)                                       # the reference object is usable on the CPU again
+    pull_hypers!(hm)
+    AGP.set_trained!(model, true)
+    return hm, hm
+end
+
+# ---- ELBO ------------------------------------------------------------------------------------------------------------------------
+# objective(model, state, y) = ELBO(model, state, y) on the last minibatch (SVGP.jl:90, analyticVI.jl:255-297)
+function objective(hm::HipModel, state=nothing, y=nothing)
+    out = Ref{Float64}()
+    if hm.comm != C_NULL
+        check(hm.ctx, ccall((:agp_svgp_elbo_multi, libagp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ref{Float64}), hm.h, hm.comm, hm.shard, out))
+        return out[]
+    end
+    B = hm.last_idx === nothing ? hm.N : length(hm.last_idx)
+    ρ = AGP.is_stochastic(hm.model) ? hm.N / B : 1.0
+    idp = hm.last_idx === nothing ? Ptr{Int64}(C_NULL) : pointer(hm.last_idx)
+    check(hm.ctx, ccall((:agp_svgp_elbo, libagp), Int32,
+                        (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int64, Float64, Int32, Ref{Float64}),
+                        hm.h, pointer(hm.X), size(hm.X, 1), pointer(hm.y), idp, B, ρ, 0, out))
+    return out[]
+end
+
+# external ELBO(model, X, y) (src/functions/ELBO.jl:28-47): kernel matrices recomputed on (X, y), fresh local variables, one local
+# update.  The reference keeps ρ = N/B of the last train! here (Appendix A Q13); pass ρ = 1 for the properly scaled value.
+function ELBO(hm::HipModel{T}, X::AbstractMatrix, y::AbstractArray; obsdim=1, ρ::Real=AGP.ρ(AGP.inference(hm.model))) where {T}
+    twin = HipModel{T,typeof(hm.model)}(hm.model, hm.ctx, hm.h, C_NULL, hm.shard, hm.latent_range, hm.maxbatch, nothing, nothing,
+                                        0, nothing, hm.stale_K)                        # same handle, its own data buffers
+    upload!(twin, X, y; obsdim)
+    n = twin.N
+    if n > hm.maxbatch
+        ensure_handle!(hm, n); twin.h = hm.h
+    end
+    out = Ref{Float64}()
+    check(hm.ctx, ccall((:agp_svgp_elbo, libagp), Int32,
+                        (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int64, Float64, Int32, Ref{Float64}),
+                        hm.h, pointer(twin.X), size(twin.X, 1), pointer(twin.y), C_NULL, n, ρ, 1, out))
+    return out[]
+end
+
+# ---- prediction (src/training/predictions.jl) --------------------------------------------------------------------------------------
+function _predict_f_dev(hm::HipModel{T}, Xt::AbstractMatrix; cov::Bool, obsdim::Int=1) where {T}
+    ensure_handle!(hm, max(hm.maxbatch, 1))
     Xd = ROCArray{T}(obsdim == 1 ? permutedims(Xt) : Xt)
     D, nt = size(Xd)
-    μ = ROCMatrix{T}(undef, nt, n_latent)                  # column l == latent l  (ABI: T[n_latent][n_t])
-    v = cov ? ROCMatrix{T}(undef, nt, n_latent) : nothing
-    check(s.ctx, ccall((:agp_svgp_predict_f, libagp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
-                       s.h, pointer(Xd), D, nt, pointer(μ), cov ? pointer(v) : C_NULL))
-    ccall((:agp_ctx_sync, libagp), Int32, (Ptr{Cvoid},), s.ctx)
-    return cov ? (Array(μ), Array(v)) : Array(μ)
+    nout = is_mo(hm) ? length(AGP.likelihood(hm.model)) : nlat(hm)
+    μ = ROCMatrix{T}(undef, nt, nout)                        # column l == latent / task l  (ABI: T[n_out][n_t])
+    v = cov ? ROCMatrix{T}(undef, nt, nout) : nothing
+    check(hm.ctx, ccall((:agp_svgp_predict_f, libagp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+                        hm.h, pointer(Xd), D, nt, pointer(μ), cov ? pointer(v) : C_NULL))
+    ccall((:agp_ctx_sync, libagp), Int32, (Ptr{Cvoid},), hm.ctx)
+    return Array(μ), (cov ? Array(v) : nothing), Xd
+end
+
+# predict_f(model, X_test; cov=false, diag=true) predictions.jl:141-164: Vector (one latent) or Tuple of Vectors
+function predict_f(hm::HipModel{T}, X_test::AbstractMatrix, state=nothing; cov::Bool=false, diag::Bool=true, obsdim::Int=1) where {T}
+    if cov && !diag                                           # full covariance, predictions.jl:45-49 (K*m materialised: small n_t)
+        Xd = ROCArray{T}(obsdim == 1 ? permutedims(X_test) : X_test)
+        D, nt = size(Xd); L = nlat(hm)
+        μ = ROCMatrix{T}(undef, nt, L); Σ = ROCArray{T}(undef, nt, nt, L)
+        check(hm.ctx, ccall((:agp_svgp_predict_f_cov, libagp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+                            ensure_handle!(hm, max(hm.maxbatch, 1)), pointer(Xd), D, nt, pointer(μ), pointer(Σ)))
+        ccall((:agp_ctx_sync, libagp), Int32, (Ptr{Cvoid},), hm.ctx)
+        μh, Σh = Array(μ), Array(Σ)
+        return L == 1 ? (μh[:, 1], Symmetric(Σh[:, :, 1])) : (Tuple(μh[:, l] for l in 1:L), Tuple(Symmetric(Σh[:, :, l]) for l in 1:L))
+    end
+    μ, v, _ = _predict_f_dev(hm, X_test; cov, obsdim)
+    n = size(μ, 2)
+    if n == 1 && !is_mo(hm)
+        return cov ? (μ[:, 1], v[:, 1]) : μ[:, 1]
+    end
+    μt = Tuple(μ[:, l] for l in 1:n)
+    return cov ? (μt, Tuple(v[:, l] for l in 1:n)) : μt
+end
+
+# predict_y predictions.jl:178-198: regression mean / Bool / most likely class label / expected count
+function predict_y(hm::HipModel{T}, X_test::AbstractMatrix, state=nothing; obsdim::Int=1) where {T}
+    ensure_handle!(hm, max(hm.maxbatch, 1))
+    Xd = ROCArray{T}(obsdim == 1 ? permutedims(X_test) : X_test)
+    D, nt = size(Xd)
+    l = AGP.likelihood(hm.model)
+    if is_mo(hm)
+        out = ROCMatrix{T}(undef, nt, length(l))
+        check(hm.ctx, ccall((:agp_svgp_predict_y, libagp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}), hm.h, pointer(Xd), D, nt, pointer(out)))
+        o = Array(out)
+        return [is_bernoulli(lt) ? o[:, t] .> 0.5 : o[:, t] for (t, lt) in enumerate(l)]
+    elseif is_bernoulli(l) || is_multiclass(l)
+        out = ROCVector{Int32}(undef, nt)
+        check(hm.ctx, ccall((:agp_svgp_predict_y, libagp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}), hm.h, pointer(Xd), D, nt, pointer(out)))
+        o = Array(out)
+        return is_bernoulli(l) ? o .== 1 : [l.class_mapping[i + 1] for i in o]     # multiclass.jl:96-99 / predictions.jl:200-202
+    else
+        out = ROCVector{T}(undef, nt)
+        check(hm.ctx, ccall((:agp_svgp_predict_y, libagp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}), hm.h, pointer(Xd), D, nt, pointer(out)))
+        return Array(out)
+    end
+end
+
+# proba_y predictions.jl:225-247 + compute_proba: (mean, var) for regression, p for Bernoulli, per-class probabilities
+function proba_y(hm::HipModel{T}, X_test::AbstractMatrix, state=nothing; obsdim::Int=1) where {T}
+    ensure_handle!(hm, max(hm.maxbatch, 1))
+    Xd = ROCArray{T}(obsdim == 1 ? permutedims(X_test) : X_test)
+    D, nt = size(Xd)
+    l = AGP.likelihood(hm.model)
+    nout = is_mo(hm) ? length(l) : 1
+    o0 = is_multiclass(l) ? ROCMatrix{T}(undef, nlat(hm), nt) : ROCMatrix{T}(undef, nt, nout)
+    o1 = is_multiclass(l) ? nothing : ROCMatrix{T}(undef, nt, nout)
+    check(hm.ctx, ccall((:agp_svgp_proba_y, libagp), Int32,
+                        (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Cvoid}, Ptr{Cvoid}),
+                        hm.h, pointer(Xd), D, nt, AGP.pred_nodes, AGP.pred_weights, length(AGP.pred_nodes), pointer(o0),
+                        o1 === nothing ? C_NULL : pointer(o1)))
+    ccall((:agp_ctx_sync, libagp), Int32, (Ptr{Cvoid},), hm.ctx)
+    if is_multiclass(l)
+        p = Array(o0)                                        # K x n_t (ABI: T[n_t][K] row-major)
+        return NamedTuple{Tuple(Symbol.(l.class_mapping))}(Tuple(p[k, :] for k in 1:size(p, 1)))   # multiclass.jl:101-117
+    end
+    a, b = Array(o0), Array(o1)
+    is_mo(hm) && return [(a[:, t], b[:, t]) for t in 1:nout]
+    return is_bernoulli(l) ? a[:, 1] : (a[:, 1], b[:, 1])
+end
+
+# ---- multi-GPU: one Julia process per GPU ---------------------------------------------------------------------------------------
+# rank 0:  id = AGPHip.comm_unique_id()  -> broadcast the 128 bytes (MPI.Bcast!, Distributed, a file ...)
+# all:     AGPHip.comm_init!(hm, rank, world, id; shard=:batch | :latent)
+# then train! / objective / update_hyperparameters! route through the *_multi entry points; RCCL runs on the model's stream.
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    st = ccall((:agp_comm_unique_id, libagp), Int32, (Ptr{UInt8},), id)
+    st == 0 || throw(AGPError(st, "agp_comm_unique_id (librccl not found? set AGP_RCCL_PATH)"))
+    return id
+end
+function comm_init!(hm::HipModel, rank::Integer, world::Integer, id::Vector{UInt8}; shard::Symbol=:batch)
+    length(id) == 128 || throw(ArgumentError("the RCCL id has 128 bytes"))
+    c = Ref{Ptr{Cvoid}}()
+    check(ensure_ctx!(hm), ccall((:agp_comm_init, libagp), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}, Ptr{Ptr{Cvoid}}),
+                                 hm.ctx, rank, world, id, c))
+    hm.comm = c[]
+    hm.shard = shard === :batch ? AGP_SHARD_BATCH : AGP_SHARD_LATENT
+    if shard === :batch && hm.h != C_NULL
+        check(hm.ctx, ccall((:agp_svgp_set_batch_shard, libagp), Int32, (Ptr{Cvoid}, Int32, Int32), hm.h, rank, world))
+    end
+    return hm
+end
+function comm_info(hm::HipModel)
+    r, w, k = Ref{Int32}(), Ref{Int32}(), Ref{Int32}()
+    ccall((:agp_comm_info, libagp), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}, Ref{Int32}), hm.comm, r, w, k)
+    return Int(r[]), Int(w[]), k[] == 1
+end
+comm_rank(hm::HipModel) = comm_info(hm)[1]
+comm_world(hm::HipModel) = comm_info(hm)[2]
+# latent-parallel: build every rank's twin with HipModel(model; latent_range = latent_slice(length(model.f), world, rank))
+function latent_slice(n::Int, world::Int, rank::Int)
+    base, rem = divrem(n, world)
+    lo = rank * base + min(rank, rem)
+    return (lo + 1):(lo + base + (rank < rem ? 1 : 0))
 end
 
 end # module

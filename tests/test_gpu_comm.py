@@ -43,6 +43,9 @@ class ThreadGroup:
         self.bar.wait()
 
 
+BIG = dict(N=20000, D=8, m=1024)  # C2-sized factorisations (16 block columns, 408-workgroup task graphs)
+
+
 def _data(rng, N=400, D=3, m=70, K=1):
     X = rng.random((N, D))
     f = np.sin(3 * X[:, 0]) + X[:, 1] ** 2 - 0.7
@@ -225,9 +228,11 @@ def _proc_rank(rank, world, shm_name, nbytes, bar, q, mode):
         shm = shared_memory.SharedMemory(name=shm_name)
         slots = np.ndarray((world, nbytes // 8), dtype=np.float64, buffer=shm.buf)
         rng = np.random.default_rng(6)
+        big = mode.endswith("-big")
+        mode = mode.split("-")[0]
         K = 1 if mode == "batch" else 3
-        X, y, Z = _data(rng, K=K)
-        B, iters = 128, 4
+        X, y, Z = _data(rng, K=K, **(BIG if big else {}))
+        B, iters = (2048, 12) if big else (128, 4)
         idx = [rng.choice(len(X), B, replace=False) for _ in range(iters)]
         lik = AGP.LogisticLikelihood() if K == 1 else AGP.LogisticSoftMaxLikelihood(3)
         sl = None if mode == "batch" else P.latent_slice(3, world, rank)
@@ -262,16 +267,20 @@ def _proc_rank(rank, world, shm_name, nbytes, bar, q, mode):
             pass
 
 
-@pytest.mark.parametrize("mode", ["batch", "latent"])
+@pytest.mark.parametrize("mode", ["batch", "latent", "batch-big"])
 def test_two_processes_share_one_gpu_without_torch_distributed(built, mode):
     """Two host processes, each with its own ctx / handle on GPU 0, drive a sharded run through the C ABI only; the
     all-reduce is a host callback over POSIX shared memory.  Doubles as the "second process on the same GPU" check: both
-    processes factor with the one-launch task graph at the same time."""
+    processes factor with the one-launch task graph at the same time.  At the C2 size ("batch-big") the two 408-workgroup task
+    graphs can starve each other of a dependency (their deadlock-freedom argument holds for one graph per device): the bounded
+    spin then hands the factorisation to the in-stream fallback k_chol_safe, and the run must still land on the
+    single-process result -- a Cholesky either succeeds or throws PosDefException, it never stalls or fails the step."""
     from multiprocessing import shared_memory
 
     import agp_amd as AGP
 
-    world, nbytes = 2, 8 * (1 << 16)
+    big = mode.endswith("-big")
+    world, nbytes = 2, 8 * ((1 << 20) if big else (1 << 16))
     ctx = mp.get_context("spawn")
     shm = shared_memory.SharedMemory(create=True, size=world * nbytes)
     try:
@@ -288,9 +297,10 @@ def test_two_processes_share_one_gpu_without_torch_distributed(built, mode):
     for r in range(world):
         assert not isinstance(got[r], str), got[r]
     rng = np.random.default_rng(6)
+    mode = mode.split("-")[0]
     K = 1 if mode == "batch" else 3
-    X, y, Z = _data(rng, K=K)
-    B, iters = 128, 4
+    X, y, Z = _data(rng, K=K, **(BIG if big else {}))
+    B, iters = (2048, 12) if big else (128, 4)
     idx = [rng.choice(len(X), B, replace=False) for _ in range(iters)]
     lik = AGP.LogisticLikelihood() if K == 1 else AGP.LogisticSoftMaxLikelihood(3)
     ref = AGP.SVGP(_kernel(AGP), lik, AGP.AnalyticSVI(B), Z, optimiser=False)

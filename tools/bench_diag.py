@@ -10,10 +10,10 @@ f.restype = C.c_int32
 f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
 ctx = C.c_void_p()
 assert L.agp_ctx_create(0, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ctx)) == 0
-names = {0: "1-level", 1: "2-level"}
+names = {0: "1-level", 1: "2-level", 2: "2-level+minors"}
 for dt, dn in ((0, "f64"), (1, "f32")):
     for blocks in (1, 16):
-        for v in (0, 1):
+        for v in (0, 1, 2):
             us = C.c_double()
             rc = f(ctx, dt, v, blocks, 50, C.byref(us))
             if rc: print("FAILED residual check", dn, names[v])

@@ -41,6 +41,8 @@ struct agp_ctx {
   size_t tri_bytes = 0;
   // fallback of the task-graph factorisation (k_chol_safe): grid-barrier words, retry counter, number of CUs; once a retry has
   // been seen by the host (any synchronising call) the task graph is not used again on this context
+  void* kmm_scratch = nullptr;  // scaled copy + squared norms of the Y side of a kernel matrix whose Y is not a cached Z
+  size_t kmm_bytes = 0;
   unsigned* safe_bar = nullptr;
   int32_t* safe_retries = nullptr;
   int n_cu = 0;
@@ -459,21 +461,48 @@ static agp_status gemm_nt(agp_ctx* c, const T* A, int64_t lda, const T* B, int64
 // AGP_KERNELMATRIX_VALU=1).  Same arguments as the kernels; `cgroups` = number of column groups a fused row-dot is split into
 // (<= 0: one group per column tile, like the VALU kernel; 1: the whole row in one workgroup -- streaming prediction).  Returns
 // the number of partial slices the row-dot consumer has to sum.
-template <typename T>
-static int launch_kernelmatrix(hipStream_t stream, const T* X, int64_t ldx, const int64_t* idx, int64_t n, const T* Y, int64_t ldy,
-                               int64_t p, int64_t D, const T* scales, int kind, T variance, T* out, int64_t ldo, int64_t n_out,
-                               int64_t p_out, int sym, T diag_add, const T* alpha, T* part, int64_t ldp, int64_t cgroups = 0) {
-  const int64_t nct = (p_out + TILE - 1) / TILE, nrt = (n_out + TILE - 1) / TILE;
+// The MFMA kernel reads the Y side as ready-made tiles (scaled, zero-padded, with squared norms: k_scale_rows).  Callers whose Y
+// is a latent's inducing points pass the cached copy (ysc / ysn, see Svgp::ensure_zsc); otherwise the copy is made here into a
+// per-context scratch on the same stream (c may be null only together with a cached copy).
+static inline int kmm_dp(int64_t D) { return (int)((D + 7) / 8 * 8); }
+static inline bool kmm_usable(int64_t D) {
   static const bool force_valu = []() {
     const char* e = getenv("AGP_KERNELMATRIX_VALU");
     return e && e[0] == '1';
   }();
-  if (D > KMM_MAXD || force_valu) {
+  return D <= KMM_MAXD && !force_valu;
+}
+template <typename T>
+static int launch_kernelmatrix(agp_ctx* c, hipStream_t stream, const T* X, int64_t ldx, const int64_t* idx, int64_t n, const T* Y,
+                               int64_t ldy, int64_t p, int64_t D, const T* scales, int kind, T variance, T* out, int64_t ldo,
+                               int64_t n_out, int64_t p_out, int sym, T diag_add, const T* alpha, T* part, int64_t ldp,
+                               int64_t cgroups = 0, const T* ysc = nullptr, const T* ysn = nullptr) {
+  const int64_t nct = (p_out + TILE - 1) / TILE, nrt = (n_out + TILE - 1) / TILE;
+  if (!kmm_usable(D)) {
     hipLaunchKernelGGL((k_kernelmatrix<T>), dim3((unsigned)nct, (unsigned)nrt), dim3(NTHREADS), 0, stream, X, ldx, idx, n, Y, ldy, p,
                        D, scales, kind, variance, out, ldo, n_out, p_out, sym, diag_add, alpha, part, ldp);
     return (int)nct;
   }
-  const int Dp = (int)((D + 7) / 8 * 8);
+  const int Dp = kmm_dp(D);
+  const int64_t p_pad = nct * TILE;
+  if (!ysc) {
+    const size_t need = sizeof(T) * (size_t)(p_pad * Dp + p_pad);
+    if (c->kmm_bytes < need) {
+      if (c->kmm_scratch) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(c->kmm_scratch);
+      }
+      c->kmm_scratch = nullptr;
+      c->kmm_bytes = 0;
+      if (hipMalloc(&c->kmm_scratch, need + need / 4) != hipSuccess) return -1;
+      c->kmm_bytes = need + need / 4;
+    }
+    T* sc0 = (T*)c->kmm_scratch;
+    hipLaunchKernelGGL((k_scale_rows<T>), dim3((unsigned)((p_pad + 3) / 4)), dim3(256), 0, stream, Y, ldy, p, p_pad, D, Dp, scales, sc0,
+                       sc0 + p_pad * Dp);
+    ysc = sc0;
+    ysn = sc0 + p_pad * Dp;
+  }
   const size_t sh = kmm_smem_bytes<T>(Dp);
   if (sh > 64 * 1024) {  // more than 64 KB of dynamic LDS has to be requested once per kernel
     static size_t asked = 0;
@@ -486,8 +515,8 @@ static int launch_kernelmatrix(hipStream_t stream, const T* X, int64_t ldx, cons
   const int64_t groups = cgroups <= 0 ? nct : std::min<int64_t>(cgroups, nct);
   const int64_t ctiles = (nct + groups - 1) / groups;
   const int64_t g_eff = (nct + ctiles - 1) / ctiles;
-  hipLaunchKernelGGL((k_kernelmatrix_mma<T>), dim3((unsigned)g_eff, (unsigned)nrt), dim3(NTHREADS), sh, stream, X, ldx, idx, n, Y,
-                     ldy, p, D, Dp, scales, kind, variance, out, ldo, n_out, p_out, sym, diag_add, alpha, part, ldp, ctiles);
+  hipLaunchKernelGGL((k_kernelmatrix_mma<T>), dim3((unsigned)g_eff, (unsigned)nrt), dim3(NTHREADS), sh, stream, X, ldx, idx, n, ysc,
+                     ysn, p, D, Dp, scales, kind, variance, out, ldo, n_out, p_out, sym, diag_add, alpha, part, ldp, ctiles);
   return (int)g_eff;
 }
 
@@ -624,6 +653,8 @@ struct Svgp : SvgpBase {
     KernelHost k;
     T* scales = nullptr;  // device, D
     T* Z = nullptr;       // m x D
+    T *Zsc = nullptr, *zn = nullptr;  // scaled, tile-padded copy of Z (mp x Dp) and its squared norms: the Y side of the MFMA
+    bool zsc_valid = false;           // kernel matrix (k_scale_rows); redone when Z or the scales change
     T* L = nullptr;       // mp x mp : K then chol(K) (lower)
     T* Xk = nullptr;      // L^-1
     T* Kinv = nullptr;
@@ -859,7 +890,7 @@ struct Svgp : SvgpBase {
   ~Svgp() override {
     for (auto e : ev) dcheck(hipEventDestroy(e), __LINE__);
     for (auto& g : lat) {
-      T* ps[] = {g.scales, g.Z, g.L, g.Xk, g.Kinv, g.mu0, g.kinv_mu0, g.eta1, g.eta2, g.La, g.Xa, g.v,
+      T* ps[] = {g.Zsc, g.zn, g.scales, g.Z, g.L, g.Xk, g.Kinv, g.mu0, g.kinv_mu0, g.eta1, g.eta2, g.La, g.Xa, g.v,
                  g.Sigma, g.mu, g.Knm, g.kappa, g.Apred, g.apred, g.Wbuf, g.DgK, g.DgA, g.pk, g.Knm_alt, g.kappa_alt, g.Wbuf_alt, g.pk_alt};
       for (T* p : ps)
         if (p) dfree(p);
@@ -936,6 +967,7 @@ struct Svgp : SvgpBase {
     for (int64_t d = 0; d < D; ++d) g.k.scales[d] = k->ard ? k->ard_scales_host[d] : k->scale;
     g.K_stale = true;
     g.kappa_valid = false;
+    g.zsc_valid = false;
     pf_valid = false;
     g.pred_valid = g.predvar_valid = false;
     return upload_scales(g);
@@ -948,6 +980,7 @@ struct Svgp : SvgpBase {
                                  st()));
     g.K_stale = true;
     g.kappa_valid = false;
+    g.zsc_valid = false;
     pf_valid = false;
     g.pred_valid = g.predvar_valid = false;
     return AGP_OK;
@@ -992,9 +1025,10 @@ struct Svgp : SvgpBase {
       any = true;
       dim3 gk((unsigned)(mp / TILE), (unsigned)(mp / TILE));
       for (int attempt = 0; attempt < 2; ++attempt) {
-        (void)launch_kernelmatrix<T>(st(), (const T*)g.Z, D, (const int64_t*)nullptr, m, (const T*)g.Z, D, m, D,
+        AGPCHK(ensure_zsc(g));
+        (void)launch_kernelmatrix<T>(ctx, st(), (const T*)g.Z, D, (const int64_t*)nullptr, m, (const T*)g.Z, D, m, D,
                                      (const T*)g.scales, g.k.kind, (T)g.k.variance, g.L, mp, mp, mp, 1, (T)jitter,
-                                     (const T*)nullptr, (T*)nullptr, (int64_t)0);
+                                     (const T*)nullptr, (T*)nullptr, (int64_t)0, 0, (const T*)g.Zsc, (const T*)g.zn);
         LAUNCHCHK(ctx);
         const bool dag = chol_use_dag(ctx, mp / TILE);
         AGPCHK(potrf_fused<T>(ctx, g.L, mp, mp, g.Xk, mp, g.DgK, (T*)nullptr, 0, 0, 1, info_dev, m));
@@ -1097,14 +1131,14 @@ struct Svgp : SvgpBase {
       hipLaunchKernelGGL((k_add_diag<T>), grid1(ma), dim3(256), 0, st(), g.kappa_a, mp, ma, T(1));
     } else {
       dim3 gk((unsigned)(mp / TILE), (unsigned)(map / TILE));
-      (void)launch_kernelmatrix<T>(st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
+      (void)launch_kernelmatrix<T>(ctx, st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
                          (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Kab, mp, map, mp, 0, T(0),
-                         (const T*)nullptr, (T*)nullptr, (int64_t)0);
+                         (const T*)nullptr, (T*)nullptr, (int64_t)0, 0, (const T*)g.Zsc, (const T*)g.zn);
       LAUNCHCHK(ctx);
       AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.Kab, mp, g.Kinv, mp, map, mp, mp, 0, g.kappa_a, mp, nullptr, 0, nullptr, nullptr,
                                     nullptr, 0)));
       dim3 ga((unsigned)(map / TILE), (unsigned)(map / TILE));
-      (void)launch_kernelmatrix<T>(st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
+      (void)launch_kernelmatrix<T>(ctx, st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
                          (const T*)g.Za, D, ma, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Kta, map, map, map, 0,
                          T(0), (const T*)nullptr, (T*)nullptr, (int64_t)0);
       hipLaunchKernelGGL((k_add_diag<T>), grid1(ma), dim3(256), 0, st(), g.Kta, map, ma, (T)jitter);
@@ -1200,6 +1234,21 @@ struct Svgp : SvgpBase {
     return AGP_OK;
   }
 
+  // the ready-made Y tiles of every kernel matrix against this latent's inducing points (k_kernelmatrix_mma)
+  agp_status ensure_zsc(Latent& g) {
+    if (g.zsc_valid || !kmm_usable(D)) return AGP_OK;
+    const int Dp = kmm_dp(D);
+    if (!g.Zsc) {
+      AGPCHK(dmalloc(ctx, &g.Zsc, mp * Dp));
+      AGPCHK(dmalloc(ctx, &g.zn, mp));
+    }
+    hipLaunchKernelGGL((k_scale_rows<T>), dim3((unsigned)((mp + 3) / 4)), dim3(256), 0, st(), (const T*)g.Z, D, m, mp, D, Dp,
+                       (const T*)g.scales, g.Zsc, g.zn);
+    LAUNCHCHK(ctx);
+    g.zsc_valid = true;
+    return AGP_OK;
+  }
+
   // which K-derived matrices the STEP uses (online prior folded in > frozen copies of AGP_FLAG_STALE_K > the fresh ones)
   const T* kinv_kappa(const Latent& g) const { return g.stale_on ? g.sKinv : g.Kinv; }
   const T* kinv_step(const Latent& g) const { return g.on ? g.Kinv_on : (g.stale_on ? g.sKinv : g.Kinv); }
@@ -1248,10 +1297,11 @@ struct Svgp : SvgpBase {
       if (prefetched) {
         // nothing to compute
       } else if (!keep) {
+        AGPCHK(ensure_zsc(g));
         dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
-        (void)launch_kernelmatrix<T>(st(), (const T*)x, ldx, idx, B, (const T*)g.Z,
+        (void)launch_kernelmatrix<T>(ctx, st(), (const T*)x, ldx, idx, B, (const T*)g.Z,
                            D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Knm, mp, Bq, mp, 0, T(0),
-                           (const T*)nullptr, (T*)nullptr, (int64_t)0);
+                           (const T*)nullptr, (T*)nullptr, (int64_t)0, 0, (const T*)g.Zsc, (const T*)g.zn);
         LAUNCHCHK(ctx);
         AGPCHK((gemm_nt<T, EPI_KAPPA>(ctx, g.Knm, mp, kinv_kappa(g), mp, Bq, mp, mp, 0, g.kappa, mp, g.Knm, mp, nullptr,
                                       g.pk, g.Wbuf, ldp)));
@@ -1439,9 +1489,9 @@ struct Svgp : SvgpBase {
       if (!q.stale_on || desc.stochastic) return q.Knm;
       if (!hyKnm && dmalloc(ctx, &hyKnm, Bp * mp) != AGP_OK) return nullptr;
       dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
-      (void)launch_kernelmatrix<T>(st(), (const T*)x_last, ldx_last, idx_last, B,
+      (void)launch_kernelmatrix<T>(ctx, st(), (const T*)x_last, ldx_last, idx_last, B,
                          (const T*)q.Z, D, m, D, (const T*)q.scales, q.k.kind, (T)q.k.variance, hyKnm, mp, Bq, mp, 0, T(0),
-                         (const T*)nullptr, (T*)nullptr, (int64_t)0);
+                         (const T*)nullptr, (T*)nullptr, (int64_t)0, 0, (const T*)q.Zsc, (const T*)q.zn);
       return hyKnm;
     };
     auto kappa_for_grad = [&](Latent& q) -> const T* {
@@ -1719,6 +1769,7 @@ struct Svgp : SvgpBase {
       }
       if (hy_k) AGPCHK(upload_scales(g));
       g.K_stale = true;
+      g.zsc_valid = false;
       // (the reference's full-batch path keeps its kernel matrices across a hyper step, training.jl:196-204)
       if (!(g.stale_on && !desc.stochastic)) g.kappa_valid = false;
       g.pred_valid = g.predvar_valid = false;
@@ -1921,9 +1972,9 @@ struct Svgp : SvgpBase {
     agp_status rc = AGP_OK;
     for (auto& g : lat) {
       dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
-      (void)launch_kernelmatrix<T>(pf_stream, (const T*)x, ldx, idx, B, (const T*)g.Z,
+      (void)launch_kernelmatrix<T>(ctx, pf_stream, (const T*)x, ldx, idx, B, (const T*)g.Z,
                          D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Knm_alt, mp, Bq, mp, 0, T(0),
-                         (const T*)nullptr, (T*)nullptr, (int64_t)0);
+                         (const T*)nullptr, (T*)nullptr, (int64_t)0, 0, (const T*)g.Zsc, (const T*)g.zn);
       rc = gemm_nt<T, EPI_KAPPA>(ctx, g.Knm_alt, mp, kinv_kappa(g), mp, Bq, mp, mp, 0, g.kappa_alt, mp, g.Knm_alt, mp, nullptr,
                                  g.pk_alt, g.Wbuf_alt, ldp);
       if (rc != AGP_OK) break;
@@ -2434,16 +2485,20 @@ struct Svgp : SvgpBase {
     if (!xt || nt <= 0 || ldx < D || !mu_out) return AGP_ERR_INVALID;
     const bool need_var = var_out != nullptr;
     AGPCHK(ensure_pred_ws(0, need_var));
-    for (auto& g : lat) AGPCHK(ensure_pred(g, need_var));
+    for (auto& g : lat) {
+      AGPCHK(ensure_pred(g, need_var));
+      AGPCHK(ensure_zsc(g));
+    }
     const int64_t CH = pred_chunk;
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
       if (!need_var) {
         // means only: ONE launch over all test points, every workgroup carries its 64 rows through all inducing-point tiles with
         // the row-dot against K^-1 mu in registers -- K*m and per-tile partial sums never reach memory (predictions.jl:33-34)
-        const int slices = launch_kernelmatrix<T>(st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt, (const T*)g.Z, D, m, D,
+        const int slices = launch_kernelmatrix<T>(ctx, st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt, (const T*)g.Z, D, m, D,
                                                   (const T*)g.scales, g.k.kind, (T)g.k.variance, (T*)nullptr, mp, nt, mp, 0, T(0),
-                                                  (const T*)g.apred, (T*)mu_out + (int64_t)l * nt, nt, 1);
+                                                  (const T*)g.apred, (T*)mu_out + (int64_t)l * nt, nt, 1, (const T*)g.Zsc,
+                                                  (const T*)g.zn);
         LAUNCHCHK(ctx);
         if (slices == 1) continue;
         // (D beyond the MFMA kernel's limit: the VALU kernel left one slice per column tile -- redo chunked below)
@@ -2452,9 +2507,9 @@ struct Svgp : SvgpBase {
         const int64_t nc = (nt - s) < CH ? (nt - s) : CH;
         const int64_t nq = rup64(nc);
         const T* xs = (const T*)xt + s * ldx;
-        const int slices = launch_kernelmatrix<T>(st(), xs, ldx, (const int64_t*)nullptr, nc, (const T*)g.Z, D, m, D,
+        const int slices = launch_kernelmatrix<T>(ctx, st(), xs, ldx, (const int64_t*)nullptr, nc, (const T*)g.Z, D, m, D,
                                                   (const T*)g.scales, g.k.kind, (T)g.k.variance, need_var ? Kstar : (T*)nullptr, mp,
-                                                  nq, mp, 0, T(0), (const T*)g.apred, ppm, CH);
+                                                  nq, mp, 0, T(0), (const T*)g.apred, ppm, CH, 0, (const T*)g.Zsc, (const T*)g.zn);
         LAUNCHCHK(ctx);
         if (need_var)
           AGPCHK((gemm_nt<T, EPI_ROWDOT>(ctx, Kstar, mp, g.Apred, mp, nq, mp, mp, 0, nullptr, 0, Kstar, mp, nullptr, ppv,
@@ -2624,11 +2679,11 @@ struct Svgp : SvgpBase {
       rc = ensure_pred(g, true);
       if (rc != AGP_OK) break;
       dim3 gk((unsigned)(mp / TILE), (unsigned)(nq / TILE));
-      (void)launch_kernelmatrix<T>(st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt,
+      (void)launch_kernelmatrix<T>(ctx, st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt,
                          (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, Ks, mp, nq, mp, 0, T(0),
-                         (const T*)nullptr, (T*)nullptr, (int64_t)0);
+                         (const T*)nullptr, (T*)nullptr, (int64_t)0, 0, (const T*)g.Zsc, (const T*)g.zn);
       dim3 gs((unsigned)(nq / TILE), (unsigned)(nq / TILE));
-      (void)launch_kernelmatrix<T>(st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt,
+      (void)launch_kernelmatrix<T>(ctx, st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt,
                          (const T*)xt, ldx, nt, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, Kss, nq, nq, nq, 1,
                          (T)jitter, (const T*)nullptr, (T*)nullptr, (int64_t)0);
       rc = gemm_nt<T, EPI_STORE>(ctx, Ks, mp, g.Apred, mp, nq, mp, mp, 0, T1, mp, nullptr, 0, nullptr, nullptr, nullptr, 0);
@@ -2842,6 +2897,7 @@ agp_status agp_ctx_destroy(agp_ctx* ctx) {
       if (ctx->hset[q]) (void)hipFree(ctx->hset[q]);
     if (ctx->tri_scratch) (void)hipFree(ctx->tri_scratch);
   }
+  if (ctx->kmm_scratch) (void)hipFree(ctx->kmm_scratch);
   if (ctx->safe_bar) (void)hipFree(ctx->safe_bar);
   if (ctx->safe_retries) (void)hipFree(ctx->safe_retries);
   delete ctx;
@@ -2873,7 +2929,7 @@ static agp_status bb_kernelmatrix(agp_ctx* ctx, const agp_kernel_desc* k, const 
   const void* yy = sym ? x : y;
   const int64_t pp = sym ? n : p, ldyy = sym ? ldx : ldy;
   dim3 g((unsigned)((pp + TILE - 1) / TILE), (unsigned)((n + TILE - 1) / TILE));
-  (void)launch_kernelmatrix<T>(ctx->stream, (const T*)x, ldx, idx, n, (const T*)yy, ldyy,
+  (void)launch_kernelmatrix<T>(ctx, ctx->stream, (const T*)x, ldx, idx, n, (const T*)yy, ldyy,
                      pp, D, (const T*)ds, k->kind, (T)k->variance, (T*)out, ldo, n, pp, 0, T(0), (const T*)nullptr,
                      (T*)nullptr, (int64_t)0);
   hipError_t e = hipGetLastError();

@@ -143,22 +143,42 @@ __global__ __launch_bounds__(NTHREADS) void k_kernelmatrix(const T* __restrict__
 // ---------------------------------------------------------------------------------------------------
 constexpr int KMM_MAXD = 128;
 
+// Y side of k_kernelmatrix_mma, prepared once per (kernel, Y): Ysc[j][d] = s_d Y[j][d] (rows padded to a multiple of 64 and
+// columns to Dp with zeros) and yn[j] = ||s . y_j||^2.  For the inducing points this is done at every K refresh, so the step
+// and the streaming predictor copy ready-made tiles.  One wave per row.
+template <typename T>
+__global__ void k_scale_rows(const T* __restrict__ Y, int64_t ldy, int64_t p, int64_t p_pad, int64_t D, int Dp,
+                             const T* __restrict__ scales, T* __restrict__ Ysc, T* __restrict__ yn) {
+  const int64_t row = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= p_pad) return;
+  T s = T(0);
+  for (int d = lane; d < Dp; d += 64) {
+    T v = T(0);
+    if (row < p && d < D) v = Y[row * ldy + d] * (scales ? scales[d] : T(1));
+    Ysc[row * Dp + d] = v;
+    s += v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if (lane == 0) yn[row] = s;
+}
+
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void k_kernelmatrix_mma(const T* __restrict__ X, int64_t ldx,
                                                                const int64_t* __restrict__ idx, int64_t n,
-                                                               const T* __restrict__ Y, int64_t ldy, int64_t p, int64_t D,
-                                                               int Dp, const T* __restrict__ scales, int kind, T variance,
-                                                               T* __restrict__ out, int64_t ldo, int64_t n_out,
-                                                               int64_t p_out, int sym, T diag_add,
+                                                               const T* __restrict__ Ysc, const T* __restrict__ yng,
+                                                               int64_t p, int64_t D, int Dp, const T* __restrict__ scales,
+                                                               int kind, T variance, T* __restrict__ out, int64_t ldo,
+                                                               int64_t n_out, int64_t p_out, int sym, T diag_add,
                                                                const T* __restrict__ alpha, T* __restrict__ part,
                                                                int64_t ldp, int64_t ctiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char kmm_smem[];
   const int LDX = Dp + 2;  // 16 rows x {k, k+1} land on distinct banks (same stride rule as LDK in agp_device.h)
   T* Xs = reinterpret_cast<T*>(kmm_smem);  // [64][LDX]
-  T* Ys = Xs + TILE * LDX;                 // [64][LDX]
-  T* xn = Ys + TILE * LDX;                 // [64]
-  T* yn = xn + TILE;                       // [64]
-  T* sc = yn + TILE;                       // [Dp]
+  T* Ys0 = Xs + TILE * LDX;                // [2][64][LDX]: column tiles double-buffered
+  T* xn = Ys0 + 2 * TILE * LDX;            // [64]
+  T* yn = xn + TILE;                       // [2][64]
+  T* sc = yn + 2 * TILE;                   // [Dp]
   T* red = sc + Dp;                        // [2][64] row-dot hand-over between the two column waves
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   typedef typename Mfma<T>::vec_t vec_t;
@@ -166,58 +186,88 @@ __global__ __launch_bounds__(NTHREADS) void k_kernelmatrix_mma(const T* __restri
   const int nv = Dp / VEC;  // vectors per staged row
   const int64_t i0 = blockIdx.y * (int64_t)TILE;
   const bool vec_ok_x = (ldx % VEC) == 0 && (D % VEC) == 0 && ((uintptr_t)X % (sizeof(T) * VEC)) == 0;
-  const bool vec_ok_y = (ldy % VEC) == 0 && (D % VEC) == 0 && ((uintptr_t)Y % (sizeof(T) * VEC)) == 0;
   for (int d = tid; d < Dp; d += NTHREADS) sc[d] = d < D ? (scales ? scales[d] : T(1)) : T(0);
   __syncthreads();
-  // stage one 64-row tile (rows r0.., `rows` valid, optional gather) scaled into S, then its squared norms into nrm
-  auto stage = [&](const T* __restrict__ P, int64_t ld, const int64_t* __restrict__ gidx, int64_t r0, int64_t rows, bool vec_ok,
-                   T* S, T* nrm) {
-    for (int e = tid; e < TILE * nv; e += NTHREADS) {
-      const int r = e / nv, dv = (e % nv) * VEC;
-      const int64_t gr = r0 + r;
-      T v[VEC];
+  // X tile (gathered, scaled) -> LDS, then its squared norms
+  for (int e = tid; e < TILE * nv; e += NTHREADS) {
+    const int r = e / nv, dv = (e % nv) * VEC;
+    const int64_t gr = i0 + r;
+    T v[VEC];
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) v[q] = T(0);
-      if (gr < rows) {
-        const int64_t src = gidx ? gidx[gr] : gr;
-        const T* row = P + src * ld;
-        if (vec_ok && dv + VEC <= D) {
-          const vec_t x = *reinterpret_cast<const vec_t*>(row + dv);
+    for (int q = 0; q < VEC; ++q) v[q] = T(0);
+    if (gr < n) {
+      const int64_t src = idx ? idx[gr] : gr;
+      const T* row = X + src * ldx;
+      if (vec_ok_x && dv + VEC <= D) {
+        const vec_t x = *reinterpret_cast<const vec_t*>(row + dv);
 #pragma unroll
-          for (int q = 0; q < VEC; ++q) v[q] = x[q];
-        } else {
+        for (int q = 0; q < VEC; ++q) v[q] = x[q];
+      } else {
 #pragma unroll
-          for (int q = 0; q < VEC; ++q)
-            if (dv + q < D) v[q] = row[dv + q];
-        }
+        for (int q = 0; q < VEC; ++q)
+          if (dv + q < D) v[q] = row[dv + q];
       }
+    }
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) S[r * LDX + dv + q] = v[q] * sc[dv + q];
-    }
-    __syncthreads();
-    {  // squared norms: four lanes per row, combined in a fixed order
-      const int r = tid >> 2, q4 = tid & 3;
-      T s = T(0);
-      for (int d = q4; d < Dp; d += 4) s += S[r * LDX + d] * S[r * LDX + d];
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      if (q4 == 0) nrm[r] = s;
-    }
-    __syncthreads();
-  };
-  stage(X, ldx, idx, i0, n, vec_ok_x, Xs, xn);
+    for (int q = 0; q < VEC; ++q) Xs[r * LDX + dv + q] = v[q] * sc[dv + q];
+  }
+  __syncthreads();
+  {  // squared norms: four lanes per row, combined in a fixed order
+    const int r = tid >> 2, q4 = tid & 3;
+    T s = T(0);
+    for (int d = q4; d < Dp; d += 4) s += Xs[r * LDX + d] * Xs[r * LDX + d];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (q4 == 0) xn[r] = s;
+  }
   const T close_thr = sizeof(T) == 8 ? T(1e-3) : T(3e-2);
   T rs[2][4];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int r = 0; r < 4; ++r) rs[mi][r] = T(0);
-  const int64_t ct0 = blockIdx.x * ctiles;
   const int64_t nct = (p_out + TILE - 1) / TILE;
-  for (int64_t ct = ct0; ct < ct0 + ctiles && ct < nct; ++ct) {
+  const int64_t ct0 = blockIdx.x * ctiles;
+  const int64_t ct1 = (ct0 + ctiles < nct) ? ct0 + ctiles : nct;
+  // column tiles: ready-made (pre-scaled, zero-padded) 64 x Dp blocks of Ysc; tile t+1 is fetched into registers while tile t
+  // is multiplied and evaluated, and lands in the other LDS buffer afterwards -- one barrier per tile
+  constexpr int KMM_PF = (TILE * (KMM_MAXD / Mfma<T>::VEC) + NTHREADS - 1) / NTHREADS;  // vectors per thread at Dp = KMM_MAXD
+  vec_t pf[KMM_PF];
+  T pfn = T(0);
+  auto fetch = [&](int64_t ct) {
+    const T* src = Ysc + ct * TILE * Dp;  // contiguous 64 x Dp block
+#pragma unroll
+    for (int q = 0; q < KMM_PF; ++q) {
+      const int e = tid + q * NTHREADS;
+      if (e < TILE * nv) pf[q] = *reinterpret_cast<const vec_t*>(src + (int64_t)e * VEC);
+    }
+    if (tid < TILE) pfn = yng[ct * TILE + tid];
+  };
+  auto land = [&](int buf) {
+    T* S = Ys0 + buf * TILE * LDX;
+#pragma unroll
+    for (int q = 0; q < KMM_PF; ++q) {
+      const int e = tid + q * NTHREADS;
+      if (e < TILE * nv) {
+        const int r = e / nv, dv = (e % nv) * VEC;
+#pragma unroll
+        for (int w = 0; w < VEC; ++w) S[r * LDX + dv + w] = pf[q][w];
+      }
+    }
+    if (tid < TILE) yn[buf * TILE + tid] = pfn;
+  };
+  if (ct0 < ct1) {
+    fetch(ct0);
+    land(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int64_t ct = ct0; ct < ct1; ++ct) {
     const int64_t j0 = ct * TILE;
-    if (ct != ct0) __syncthreads();  // the previous tile's epilogue is done with Ys / yn
-    stage(Y, ldy, nullptr, j0, p, vec_ok_y, Ys, yn);
+    const bool more = ct + 1 < ct1;
+    if (more) fetch(ct + 1);
+    const T* Ys = Ys0 + cur * TILE * LDX;
+    const T* ynb = yn + cur * TILE;
     typename Mfma<T>::acc_t acc[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -249,7 +299,7 @@ __global__ __launch_bounds__(NTHREADS) void k_kernelmatrix_mma(const T* __restri
           const int64_t gj = j0 + cl;
           T val = T(0);
           if (gi < n && gj < p) {
-            const T s2 = xnv + yn[cl];
+            const T s2 = xnv + ynb[cl];
             T d2 = s2 - T(2) * acc[mi][ni][r];
             if (d2 < close_thr * s2) {  // (nearly) coincident points: direct differences, no cancellation
               T t = T(0);
@@ -268,6 +318,9 @@ __global__ __launch_bounds__(NTHREADS) void k_kernelmatrix_mma(const T* __restri
           if (alpha && gj < p) rs[mi][r] += val * alpha[gj];
         }
       }
+    if (more) land(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
   }
   if (alpha) {
 #pragma unroll
@@ -284,7 +337,7 @@ __global__ __launch_bounds__(NTHREADS) void k_kernelmatrix_mma(const T* __restri
 
 template <typename T>
 inline size_t kmm_smem_bytes(int Dp) {
-  return sizeof(T) * (size_t)(2 * TILE * (Dp + 2) + 2 * TILE + Dp + 2 * TILE);
+  return sizeof(T) * (size_t)(3 * TILE * (Dp + 2) + 3 * TILE + Dp + 2 * TILE);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,7 +1,8 @@
 """HBM traffic per kernel launch from rocprofv3 PMC passes (run on the GPU box).
 
-  python tools/pmc_traffic.py collect   # two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over a short bench.py run
-  python tools/pmc_traffic.py parse     # -> gpurun_out/pmc/r01_pmc_hbm_bytes.json  (copy it to profiles/)
+  python tools/pmc_traffic.py collect [config] [tag]  # two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over a short bench.py run
+  python tools/pmc_traffic.py parse   [config] [tag]  # -> gpurun_out/pmc_<tag>/<tag>_pmc_hbm_bytes.json  (copy it to profiles/)
+  config: c2 (default) | c3 | c4 | c5 (bench.py --config); tag: default r02_<config>
 
 Units / corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): the counters are in KB and
 FETCH_SIZE reports half of the bytes actually fetched on gfx950, so bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  The
@@ -17,8 +18,11 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "gpurun_out", "pmc")
-CMD = ["python", os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-elbo-tol", "--steps", "40", "--warmup", "10"]
+CFG = sys.argv[2] if len(sys.argv) > 2 else "c2"
+TAG = sys.argv[3] if len(sys.argv) > 3 else f"r02_{CFG}"
+OUT = os.path.join(ROOT, "gpurun_out", f"pmc_{TAG}")
+CMD = ["python", os.path.join(ROOT, "bench.py"), "--config", CFG, "--no-cpu-baseline", "--no-elbo-tol", "--steps",
+       "10" if CFG == "c5" else "40", "--warmup", "4" if CFG == "c5" else "10"]
 CAL = ["python", "-c", "import torch; x=torch.empty(1000000,32,dtype=torch.float64,device='cuda'); x.fill_(1.0); "
        "v=torch.ones(32,dtype=torch.float64,device='cuda'); y=x@v; torch.cuda.synchronize()"]
 
@@ -63,7 +67,7 @@ def parse():
     res["calibration"] = {"note": "fill of 1e6x32 f64 (256.0 MB written) and gemv over it (256.0 MB read)",
                           "WRITE_SIZE_KB_largest_launch": {k: round(v[2], 1) for k, v in cw.items() if v[2] > 1e5},
                           "FETCH_SIZE_KB_largest_launch": {k: round(v[2], 1) for k, v in cf.items() if v[2] > 5e4}}
-    with open(os.path.join(OUT, "r01_pmc_hbm_bytes.json"), "w") as fh:
+    with open(os.path.join(OUT, f"{TAG}_pmc_hbm_bytes.json"), "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps({k: v["hbm_bytes_per_launch_corrected"] for k, v in res["kernels"].items()}, indent=1))
     print(json.dumps(res["calibration"], indent=1))

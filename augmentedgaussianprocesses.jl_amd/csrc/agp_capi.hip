@@ -202,6 +202,8 @@ static bool chol_use_dag(const agp_ctx* c, int64_t nt, int64_t ne = 0, int64_t n
   return v < 0 ? nt <= DAG_MAX_NT : v == 1;
 }
 
+__global__ void k_set_i32(int32_t* p, int32_t v) { *p = v; }
+
 // the fallback behind a task-graph launch (see k_chol_safe): one launch that returns at once unless the latch reads -1
 template <typename T>
 static agp_status launch_chol_safe(agp_ctx* c, const CholBatch<T>& bt, const SafeSrc<T>& src, int nb, int64_t ld, int64_t ldx,
@@ -296,7 +298,14 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
                          (int)(do_x && nx == 0) | (want_l ? 2 : 0));
     LAUNCHCHK(c);
     AGPCHK(dag_handover_release<T>(c, (3 * nt + (nt + ne + nx) * nt) * TILE * TILE, hstride, 1, hs));
-    if (safe && !do_x) AGPCHK(launch_chol_safe<T>(c, one, *safe, 1, ld, ldx, lde, ne, nt, info_dev, nvalid));
+    static const bool test_abort = []() {  // test hook: pretend every task-graph launch of a CAVI step lost a dependency
+      const char* e = getenv("AGP_DAG_TEST_ABORT");
+      return e && e[0] == '1';
+    }();
+    if (safe && !do_x) {
+      if (test_abort) hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, c->stream, info_dev, -1);
+      AGPCHK(launch_chol_safe<T>(c, one, *safe, 1, ld, ldx, lde, ne, nt, info_dev, nvalid));
+    }
     if (trace) {
       std::vector<unsigned long long> h((size_t)ntiles * 8);
       (void)hipStreamSynchronize(c->stream);
@@ -378,7 +387,14 @@ static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, in
                      (int64_t)0, (const T*)nullptr, 0);
   LAUNCHCHK(c);
   AGPCHK(dag_handover_release<T>(c, (3 * nt + (nt + ne) * nt) * TILE * TILE, hstride, nb, hs));
-  if (safe) AGPCHK(launch_chol_safe<T>(c, bt, *safe, nb, ld, ldx, lde, ne, nt, info_dev, nvalid));
+  if (safe) {
+    static const bool test_abort = []() {
+      const char* e = getenv("AGP_DAG_TEST_ABORT");
+      return e && e[0] == '1';
+    }();
+    if (test_abort) hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, c->stream, info_dev, -1);
+    AGPCHK(launch_chol_safe<T>(c, bt, *safe, nb, ld, ldx, lde, ne, nt, info_dev, nvalid));
+  }
   return AGP_OK;
 }
 
@@ -3325,14 +3341,37 @@ agp_status agp_kmeans(agp_ctx* ctx, int32_t dtype, const void* x, int64_t n, int
                             objective_host, converged_host));
 }
 
+// development / test hook (not part of include/agp_hip.h): how many task-graph factorisations the in-stream fallback re-ran
+agp_status agp_dev_dag_retries(agp_ctx* ctx, int64_t* n) {
+  if (!ctx || !n) return AGP_ERR_INVALID;
+  DevGuard guard(ctx->device);
+  *n = 0;
+  if (ctx->safe_retries) {
+    int32_t r = 0;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(&r, ctx->safe_retries, sizeof(r), hipMemcpyDeviceToHost));
+    *n = r;
+  }
+  return AGP_OK;
+}
+
 agp_status agp_dev_diag_bench(agp_ctx* ctx, int32_t dtype, int32_t variant, int32_t blocks, int32_t reps, double* us) {
   if (!ctx || !us) return AGP_ERR_INVALID;
   DevGuard guard(ctx->device);
-  if (dtype == AGP_F64)
-    return variant == 2 ? bb_diag_bench<double, 2>(ctx, blocks, reps, us)
-                        : variant ? bb_diag_bench<double, 1>(ctx, blocks, reps, us) : bb_diag_bench<double, 0>(ctx, blocks, reps, us);
-  return variant == 2 ? bb_diag_bench<float, 2>(ctx, blocks, reps, us)
-                      : variant ? bb_diag_bench<float, 1>(ctx, blocks, reps, us) : bb_diag_bench<float, 0>(ctx, blocks, reps, us);
+  switch (variant * 2 + (dtype == AGP_F64 ? 0 : 1)) {
+    case 0: return bb_diag_bench<double, 0>(ctx, blocks, reps, us);
+    case 1: return bb_diag_bench<float, 0>(ctx, blocks, reps, us);
+    case 2: return bb_diag_bench<double, 1>(ctx, blocks, reps, us);
+    case 3: return bb_diag_bench<float, 1>(ctx, blocks, reps, us);
+    case 4: return bb_diag_bench<double, 2>(ctx, blocks, reps, us);
+    case 5: return bb_diag_bench<float, 2>(ctx, blocks, reps, us);
+    case 6: return bb_diag_bench<double, 3>(ctx, blocks, reps, us);  // timing experiments (residual check fails by design)
+    case 8: return bb_diag_bench<double, 4>(ctx, blocks, reps, us);
+    case 10: return bb_diag_bench<double, 5>(ctx, blocks, reps, us);
+    case 12: return bb_diag_bench<double, 6>(ctx, blocks, reps, us);
+    case 14: return bb_diag_bench<double, 7>(ctx, blocks, reps, us);
+    default: return AGP_ERR_INVALID;
+  }
 }
 
 agp_status agp_svgp_create(agp_ctx* ctx, const agp_svgp_desc* desc, agp_svgp** out) {

@@ -175,10 +175,10 @@ __global__ __launch_bounds__(NTHREADS) void k_kernelmatrix_mma(const T* __restri
   extern __shared__ __attribute__((aligned(16))) unsigned char kmm_smem[];
   const int LDX = Dp + 2;  // 16 rows x {k, k+1} land on distinct banks (same stride rule as LDK in agp_device.h)
   T* Xs = reinterpret_cast<T*>(kmm_smem);  // [64][LDX]
-  T* Ys0 = Xs + TILE * LDX;                // [2][64][LDX]: column tiles double-buffered
-  T* xn = Ys0 + 2 * TILE * LDX;            // [64]
-  T* yn = xn + TILE;                       // [2][64]
-  T* sc = yn + 2 * TILE;                   // [Dp]
+  T* Ys = Xs + TILE * LDX;                 // [64][LDX]
+  T* xn = Ys + TILE * LDX;                 // [64]
+  T* yn = xn + TILE;                       // [64]
+  T* sc = yn + TILE;                       // [Dp]
   T* red = sc + Dp;                        // [2][64] row-dot hand-over between the two column waves
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   typedef typename Mfma<T>::vec_t vec_t;
@@ -229,45 +229,25 @@ __global__ __launch_bounds__(NTHREADS) void k_kernelmatrix_mma(const T* __restri
   const int64_t nct = (p_out + TILE - 1) / TILE;
   const int64_t ct0 = blockIdx.x * ctiles;
   const int64_t ct1 = (ct0 + ctiles < nct) ? ct0 + ctiles : nct;
-  // column tiles: ready-made (pre-scaled, zero-padded) 64 x Dp blocks of Ysc; tile t+1 is fetched into registers while tile t
-  // is multiplied and evaluated, and lands in the other LDS buffer afterwards -- one barrier per tile
-  constexpr int KMM_PF = (TILE * (KMM_MAXD / Mfma<T>::VEC) + NTHREADS - 1) / NTHREADS;  // vectors per thread at Dp = KMM_MAXD
-  vec_t pf[KMM_PF];
-  T pfn = T(0);
-  auto fetch = [&](int64_t ct) {
-    const T* src = Ysc + ct * TILE * Dp;  // contiguous 64 x Dp block
-#pragma unroll
-    for (int q = 0; q < KMM_PF; ++q) {
-      const int e = tid + q * NTHREADS;
-      if (e < TILE * nv) pf[q] = *reinterpret_cast<const vec_t*>(src + (int64_t)e * VEC);
-    }
-    if (tid < TILE) pfn = yng[ct * TILE + tid];
-  };
-  auto land = [&](int buf) {
-    T* S = Ys0 + buf * TILE * LDX;
-#pragma unroll
-    for (int q = 0; q < KMM_PF; ++q) {
-      const int e = tid + q * NTHREADS;
-      if (e < TILE * nv) {
-        const int r = e / nv, dv = (e % nv) * VEC;
-#pragma unroll
-        for (int w = 0; w < VEC; ++w) S[r * LDX + dv + w] = pf[q][w];
-      }
-    }
-    if (tid < TILE) yn[buf * TILE + tid] = pfn;
-  };
-  if (ct0 < ct1) {
-    fetch(ct0);
-    land(0);
-  }
-  __syncthreads();
-  int cur = 0;
+  // column tiles: ready-made (pre-scaled, zero-padded) 64 x Dp blocks of Ysc, copied as they are.  No software pipelining here:
+  // measured (r02), fetching tile t+1 into registers under tile t's products cost more than it hid -- the third LDS tile and the
+  // prefetch registers take a workgroup per CU away, and four co-resident workgroups already overlap each other's loads
+  // (C2 streaming prediction: 5.2 ms like this, 8.5 ms double-buffered, 8.0 ms with the VALU kernel)
   for (int64_t ct = ct0; ct < ct1; ++ct) {
     const int64_t j0 = ct * TILE;
-    const bool more = ct + 1 < ct1;
-    if (more) fetch(ct + 1);
-    const T* Ys = Ys0 + cur * TILE * LDX;
-    const T* ynb = yn + cur * TILE;
+    if (ct != ct0) __syncthreads();  // the previous tile's epilogue is done with Ys / yn
+    {
+      const T* src = Ysc + ct * TILE * Dp;  // contiguous 64 x Dp block
+      for (int e = tid; e < TILE * nv; e += NTHREADS) {
+        const vec_t x = *reinterpret_cast<const vec_t*>(src + (int64_t)e * VEC);
+        const int r = e / nv, dv = (e % nv) * VEC;
+#pragma unroll
+        for (int w = 0; w < VEC; ++w) Ys[r * LDX + dv + w] = x[w];
+      }
+      if (tid < TILE) yn[tid] = yng[ct * TILE + tid];
+    }
+    __syncthreads();
+    const T* ynb = yn;
     typename Mfma<T>::acc_t acc[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -318,9 +298,6 @@ __global__ __launch_bounds__(NTHREADS) void k_kernelmatrix_mma(const T* __restri
           if (alpha && gj < p) rs[mi][r] += val * alpha[gj];
         }
       }
-    if (more) land(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
   }
   if (alpha) {
 #pragma unroll
@@ -337,7 +314,7 @@ __global__ __launch_bounds__(NTHREADS) void k_kernelmatrix_mma(const T* __restri
 
 template <typename T>
 inline size_t kmm_smem_bytes(int Dp) {
-  return sizeof(T) * (size_t)(3 * TILE * (Dp + 2) + 3 * TILE + Dp + 2 * TILE);
+  return sizeof(T) * (size_t)(2 * TILE * (Dp + 2) + 2 * TILE + Dp + 2 * TILE);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -174,7 +174,7 @@ __device__ __forceinline__ void chol_rounds(T (&a)[NS][NS], T (&g)[NS][NS], T* s
     const int jj0 = rr * 4, j0 = J * 16 + jj0;
     T* P = sc + (rr & 1) * 4 * TILE;
     T* Mw = sc + 2 * 4 * TILE + (rr & 1) * 4 * TILE;
-    if (act) {
+    if (act && PIV != 4) {  // (PIV 4, 5: timing experiments -- barrier only / publish + barrier only)
       const int qc = tj - jj0, qr = ti - jj0;
       if (qc >= 0 && qc < 4) {
 #pragma unroll
@@ -192,12 +192,21 @@ __device__ __forceinline__ void chol_rounds(T (&a)[NS][NS], T (&g)[NS][NS], T* s
     __syncthreads();
     hook(hbase + rr);
     if (!act) continue;
+    if (PIV == 4 || PIV == 5) continue;
     // ---- 4x4 pivot block, LDL' (every active thread, redundantly) ----
     const T d00 = P[j0], d10 = P[j0 + 1], d20 = P[j0 + 2], d30 = P[j0 + 3];
     T d11 = P[TILE + j0 + 1], d21 = P[TILE + j0 + 2], d31 = P[TILE + j0 + 3];
     T d22 = P[2 * TILE + j0 + 2], d32 = P[2 * TILE + j0 + 3], d33 = P[3 * TILE + j0 + 3];
     T r0, r1, r2, r3, l10, l20, l30, l21, l31, l32;
-    if (PIV == 1) {
+    if (PIV == 2) {  // TIMING EXPERIMENT ONLY (wrong results): no pivot-block factorisation at all -- what the rest of a round costs
+      r0 = r1 = r2 = r3 = T(1);
+      l10 = d10;
+      l20 = d20;
+      l30 = d30;
+      l21 = d21;
+      l31 = d31;
+      l32 = d32;
+    } else if (PIV == 1) {
       r0 = rcp1(d00);
       const T n11 = fma(d00, d11, -(d10 * d10)), n21 = fma(d00, d21, -(d20 * d10)), n31 = fma(d00, d31, -(d30 * d10));
       const T n22 = fma(d00, d22, -(d20 * d20)), n32 = fma(d00, d32, -(d30 * d20)), n33 = fma(d00, d33, -(d30 * d30));
@@ -246,6 +255,10 @@ __device__ __forceinline__ void chol_rounds(T (&a)[NS][NS], T (&g)[NS][NS], T* s
       piv[j0 + 1] = d11;
       piv[j0 + 2] = d22;
       piv[j0 + 3] = d33;
+    }
+    if (PIV == 3) {  // TIMING EXPERIMENT ONLY (wrong results): publish + barrier + pivot-block LDL', no transforms / updates
+      a[J][J] += r3 * T(1e-30) + l32 * T(1e-30);
+      continue;
     }
     // ---- panel transforms for my columns / my M columns, then row by row: multipliers + rank-4 update ----
     T u[4][NS], mw[4][NS];  // [q][c]
@@ -1261,7 +1274,13 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_diag_bench(const T* __restrict
     NoHook nh;
     if (VAR == 0) factor_diag_tile512<T>(bufA, bufB, sc, piv, info, 0, 64);
     else if (VAR == 1) factor_diag_tile_2lvl<T, NoHook, 0>(bufA, bufB, sc, piv, info, 0, 64, nh);
-    else factor_diag_tile_2lvl<T, NoHook, 1>(bufA, bufB, sc, piv, info, 0, 64, nh);
+    else if (VAR == 2) factor_diag_tile_2lvl<T, NoHook, 1>(bufA, bufB, sc, piv, info, 0, 64, nh);
+    else if (VAR == 3) factor_diag_tile_2lvl<T, NoHook, 2>(bufA, bufB, sc, piv, info, 0, 64, nh);
+    else if (VAR == 4) factor_diag_tile_2lvl<T, NoHook, 3>(bufA, bufB, sc, piv, info, 0, 64, nh);
+    else if (VAR == 5) factor_diag_tile_2lvl<T, NoHook, 4>(bufA, bufB, sc, piv, info, 0, 64, nh);
+    else if (VAR == 6) factor_diag_tile_2lvl<T, NoHook, 5>(bufA, bufB, sc, piv, info, 0, 64, nh);
+    else {  // VAR 7: the harness alone (tile reload + barrier)
+    }
   }
   for (int e = threadIdx.x; e < TILE * TILE; e += CHOL_THREADS) {
     out[blockIdx.x * 2 * TILE * TILE + e] = bufA[(e >> 6) * LDP + (e & 63)];

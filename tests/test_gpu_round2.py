@@ -9,6 +9,7 @@
 * the K = 8 multi-latent soak (bitwise), shortened from tools/soak_multilatent.py.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -390,3 +391,60 @@ def test_multilatent_task_graph_soak_bitwise(mods):
         del model
     for k in range(K):
         assert np.array_equal(out[0][k], out[1][k]), f"latent {k}: runs differ"
+
+
+def _fallback_child(q, K):
+    """runs in a fresh process: AGP_DAG_TEST_ABORT=1 makes every task-graph launch of a CAVI step look like it lost a dependency"""
+    try:
+        import sys
+
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import agp_amd as AGP
+        from agp_amd import capi
+
+        rng = np.random.default_rng(31)
+        N, D, m, B, iters = 3000, 4, 200, 256, 6
+        X = rng.random((N, D))
+        f = np.sin(4 * X[:, 0]) + X[:, 1]
+        y = (f > f.mean()).astype(int) if K == 1 else 1 + np.digitize(f, np.quantile(f, [0.33, 0.66]))
+        Z = X[rng.permutation(N)[:m]].copy()
+        idx = [rng.choice(N, B, replace=False) for _ in range(iters)]
+        lik = AGP.LogisticLikelihood() if K == 1 else AGP.LogisticSoftMaxLikelihood(3)
+        ma = AGP.SVGP(1.5 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0)), lik, AGP.AnalyticSVI(B), Z, optimiser=False)
+        AGP.train_(ma, X, y, iters, idx_stream=idx)
+        n = C.c_int64()
+        f_ = capi.lib().agp_dev_dag_retries
+        f_.restype, f_.argtypes = C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)]
+        assert f_(ma._ctx, C.byref(n)) == 0
+        q.put((int(n.value), [ma.get_state(k)[3] for k in range(ma.n_latent)], X, y, Z, idx))
+    except BaseException as e:
+        q.put(repr(e))
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_task_graph_fallback_reruns_the_factorisation_in_stream(mods, K):
+    """a task-graph launch that loses a dependency (info = -1) is re-run by k_chol_safe on the same stream --
+    inputs restored from eta2 / kappa / eta1, per-column algorithm with grid barriers -- so the step neither fails nor stalls.
+    The loss is simulated after every launch (AGP_DAG_TEST_ABORT=1, read at library load: hence a child process); several block
+    columns (m = 200 -> 4) and, for K = 3, the interleaved multi-problem graph.  The result must match the oracle."""
+    import multiprocessing as mp
+
+    AGP, R, capi, torch = mods
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    os.environ["AGP_DAG_TEST_ABORT"] = "1"
+    try:
+        p = ctx.Process(target=_fallback_child, args=(q, K))
+        p.start()
+        got = q.get(timeout=600)
+        p.join(timeout=60)
+    finally:
+        del os.environ["AGP_DAG_TEST_ABORT"]
+    assert not isinstance(got, str), got
+    retries, eta2, X, y, Z, idx = got
+    assert retries >= 6  # every step went through the fallback
+    lik = R.LogisticLikelihood() if K == 1 else R.LogisticSoftMaxLikelihood(3)
+    mr = R.SVGP(R.Kernel("sqexponential", 2.0, 1.5), lik, Z, stochastic=True, batchsize=256)
+    mr.train(X, y, len(idx), idx_stream=idx)
+    for k in range(len(eta2)):
+        assert _rel(eta2[k], mr.latents[k].eta2) < 1e-8

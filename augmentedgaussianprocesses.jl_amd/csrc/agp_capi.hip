@@ -2042,6 +2042,42 @@ struct Svgp : SvgpBase {
     AGPCHK(lsm_finish());
     const int64_t Bq = rup64(B_last);
     const T lr = (T)cur_lr();
+    if (fused && nl > 1 && nl <= SYRK_MAXB) {
+      // all latents of the handle in ONE launch (blockIdx.y = latent): a single latent's tiles fill about half the chip
+      SyrkBatch<T> b{};
+      for (int l = 0; l < nl; ++l) {
+        Latent& g = lat[l];
+        b.A[l] = g.kappa;
+        b.w[l] = wbuf + l * Bp;
+        b.out[l] = g.La;
+        b.eta2[l] = g.eta2;
+        b.Kinv[l] = kinv_step(g);
+        b.rvec[l] = rbuf + l * Bp;
+        b.eta1[l] = g.eta1;
+        b.kinv_mu0[l] = kinv_mu0_step(g);
+      }
+      const int64_t nt = mp / TILE, tiles = nt * (nt + 1) / 2, nrider = nt;
+      T* fillp = nullptr;
+      int64_t fused_used = 0, fstride = 0, nfill = 0;
+      int fnb = 0;
+      if (ctx->h_dirty[0].on && ctx->htype == (int)sizeof(T)) {  // hand-over refill riders, as in syrk_tn()
+        fillp = (T*)ctx->hset[0];
+        fused_used = ctx->h_dirty[0].used;
+        fstride = ctx->h_dirty[0].stride;
+        fnb = ctx->h_dirty[0].nb;
+        nfill = 96;
+        ctx->h_dirty[0].on = false;
+      }
+      dim3 grid((unsigned)(tiles + nrider + nfill), (unsigned)nl);
+      if (tiles * nl <= 320 && Bq >= 4 * BK)
+        hipLaunchKernelGGL((k_syrk_eta_batch<T, 2>), grid, dim3(2 * NTHREADS), 0, st(), b, mp, Bq, mp, mp, lr, tiles, nrider, fillp,
+                           fused_used, fstride, fnb);
+      else
+        hipLaunchKernelGGL((k_syrk_eta_batch<T, 1>), grid, dim3(NTHREADS), 0, st(), b, mp, Bq, mp, mp, lr, tiles, nrider, fillp,
+                           fused_used, fstride, fnb);
+      LAUNCHCHK(ctx);
+      return AGP_OK;
+    }
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
       T* sl = stats + l * stats_stride();

@@ -85,15 +85,12 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_gemm_nt(const T* __restrict__
 enum { SY_STORE = 0, SY_ETA2 = 1, SY_PACK = 2 };
 
 template <typename T, int MODE, int KG = 1>
-__global__ __launch_bounds__(NTHREADS * KG) void k_syrk_tn(const T* __restrict__ A, int64_t lda, int64_t Kdim,
-                                                      const T* __restrict__ w, int lower_a, T* __restrict__ out,
-                                                      int64_t ldo, T* __restrict__ eta2, const T* __restrict__ Kinv,
-                                                      int64_t ldm, T lr, int64_t ntri = 0,
-                                                      const T* __restrict__ rvec = nullptr, T* __restrict__ eta1 = nullptr,
-                                                      const T* __restrict__ kinv_mu0 = nullptr, int64_t nrider = 0,
-                                                      T* __restrict__ fillp = nullptr, int64_t fill_used = 0,
-                                                      int64_t fill_stride = 0, int fill_nb = 0) {
-  __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
+__device__ __forceinline__ void syrk_tn_body(const T* __restrict__ A, int64_t lda, int64_t Kdim, const T* __restrict__ w,
+                                             int lower_a, T* __restrict__ out, int64_t ldo, T* __restrict__ eta2,
+                                             const T* __restrict__ Kinv, int64_t ldm, T lr, int64_t ntri,
+                                             const T* __restrict__ rvec, T* __restrict__ eta1,
+                                             const T* __restrict__ kinv_mu0, int64_t nrider, T* __restrict__ fillp,
+                                             int64_t fill_used, int64_t fill_stride, int fill_nb, T* smem) {
   if (fillp && (int64_t)blockIdx.x >= ntri + nrider) {
     // second kind of rider: refill the hand-over slots the factorisation before this launch wrote (agp_chol.h, "self-validating
     // hand-over") with the sentinel, in the shadow of the tile workgroups -- half the chip is idle during this launch anyway
@@ -159,6 +156,49 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_syrk_tn(const T* __restrict__
       }
     });
   }
+}
+
+template <typename T, int MODE, int KG = 1>
+__global__ __launch_bounds__(NTHREADS * KG) void k_syrk_tn(const T* __restrict__ A, int64_t lda, int64_t Kdim,
+                                                      const T* __restrict__ w, int lower_a, T* __restrict__ out,
+                                                      int64_t ldo, T* __restrict__ eta2, const T* __restrict__ Kinv,
+                                                      int64_t ldm, T lr, int64_t ntri = 0,
+                                                      const T* __restrict__ rvec = nullptr, T* __restrict__ eta1 = nullptr,
+                                                      const T* __restrict__ kinv_mu0 = nullptr, int64_t nrider = 0,
+                                                      T* __restrict__ fillp = nullptr, int64_t fill_used = 0,
+                                                      int64_t fill_stride = 0, int fill_nb = 0) {
+  __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
+  syrk_tn_body<T, MODE, KG>(A, lda, Kdim, w, lower_a, out, ldo, eta2, Kinv, ldm, lr, ntri, rvec, eta1, kinv_mu0, nrider, fillp,
+                            fill_used, fill_stride, fill_nb, smem);
+}
+
+// The fused natural-gradient step of SEVERAL latents (multi-class, multi-output, heteroscedastic models on one GPU) as one
+// launch: blockIdx.y selects the latent.  One latent alone fills only ~136 of 256 CUs (m = 1024: nt (nt + 1) / 2 tiles) and
+// eight launches in a row cost 8 x 89 us at C4; together the tiles of all latents keep the whole chip busy.
+constexpr int SYRK_MAXB = 16;
+template <typename T>
+struct SyrkBatch {
+  const T* A[SYRK_MAXB];      // kappa
+  const T* w[SYRK_MAXB];      // rho g2
+  T* out[SYRK_MAXB];          // -2 eta2 for the next factorisation
+  T* eta2[SYRK_MAXB];
+  const T* Kinv[SYRK_MAXB];
+  const T* rvec[SYRK_MAXB];   // rho g1
+  T* eta1[SYRK_MAXB];
+  const T* kinv_mu0[SYRK_MAXB];
+};
+template <typename T, int KG>
+__global__ __launch_bounds__(NTHREADS * KG) void k_syrk_eta_batch(SyrkBatch<T> b, int64_t lda, int64_t Kdim, int64_t ldo,
+                                                             int64_t ldm, T lr, int64_t ntri, int64_t nrider,
+                                                             T* __restrict__ fillp, int64_t fill_used,
+                                                             int64_t fill_stride, int fill_nb) {
+  __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
+  const int q = blockIdx.y;
+  // the hand-over refill riders exist once (in the slice of latent 0)
+  if (q != 0 && (int64_t)blockIdx.x >= ntri + nrider) return;
+  syrk_tn_body<T, SY_ETA2, KG>(b.A[q], lda, Kdim, b.w[q], 0, b.out[q], ldo, b.eta2[q], b.Kinv[q], ldm, lr, ntri, b.rvec[q],
+                               b.eta1[q], b.kinv_mu0[q], nrider, q == 0 ? fillp : (T*)nullptr, fill_used, fill_stride, fill_nb,
+                               smem);
 }
 
 // eta2 step from an already reduced statistic S (batch-parallel multi-GPU path: S was all-reduced), stored as packed lower

@@ -769,7 +769,8 @@ struct Svgp : SvgpBase {
   T* Tw2 = nullptr;                                // mp x mp scratch (predict)
   T* tmpv = nullptr;                               // mp
   T* lr_dev = nullptr;
-  int32_t* info_dev = nullptr;
+  int32_t* info_dev = nullptr;   // failure latch of the factorisations of -2*eta2 (asynchronous steps)
+  int32_t* infoK_dev = nullptr;  // ... and of K_ZZ (read where it is produced: refresh_K synchronises)
   int* flags_dev = nullptr;
   double* scal_dev = nullptr;                      // 16 doubles
   // prediction workspace
@@ -887,12 +888,14 @@ struct Svgp : SvgpBase {
     AGPCHK(dmalloc(ctx, &tmpv, mp));
     AGPCHK(dmalloc(ctx, &lr_dev, 1));
     AGPCHK(dmalloc(ctx, &info_dev, 1));
+    AGPCHK(dmalloc(ctx, &infoK_dev, 1));
     AGPCHK(dmalloc(ctx, &flags_dev, 1));
     AGPCHK(dmalloc(ctx, &scal_dev, 64));
     AGPCHK(dmalloc(ctx, &lam_dev, 1));
     AGPCHK(dmalloc(ctx, &lam_part, 2 * (Bp / 256 + 1)));
     hipLaunchKernelGGL((k_fill<T>), dim3(1), dim3(64), 0, st(), lam_dev, (int64_t)1, (T)(desc.lik.p0 > 0 ? desc.lik.p0 : 1.0));
     HIPCHK(ctx, hipMemsetAsync(info_dev, 0, sizeof(int32_t), st()));
+    HIPCHK(ctx, hipMemsetAsync(infoK_dev, 0, sizeof(int32_t), st()));
     HIPCHK(ctx, hipMemsetAsync(flags_dev, 0, sizeof(int), st()));
     // LogisticSoftMax state: alpha = beta = K (total classes)  logisticsoftmax.jl:43-53
     const T kk = (T)(lp.kind == AGP_LIK_LOGISTICSOFTMAX ? desc.lik.n_class : 1);
@@ -940,6 +943,7 @@ struct Svgp : SvgpBase {
     for (double* p : dps)
       if (p) dfree(p);
     if (info_dev) dfree(info_dev);
+    if (infoK_dev) dfree(infoK_dev);
     if (flags_dev) dfree(flags_dev);
     if (scal_dev) dfree(scal_dev);
     if (gh_dev) dfree(gh_dev);
@@ -1031,34 +1035,45 @@ struct Svgp : SvgpBase {
   // compute_K : cholesky(kernelmatrix(k, Z) + jitt*I) ; inv(K)      latentgp.jl:205-207, analyticVI.jl:179
   agp_status refresh_K() override {
     bool any = false;
-    for (auto& g : lat) any = any || g.K_stale;
-    // this call synchronises and reads the failure latch: anything an earlier asynchronous step latched (K~ <= 0, a non-SPD
-    // -2*eta2) is reported first and as what it is, not as a failure of K_ZZ
-    if (any) AGPCHK(check_status());
-    any = false;
     for (auto& g : lat) {
       if (!g.K_stale) continue;
       any = true;
-      dim3 gk((unsigned)(mp / TILE), (unsigned)(mp / TILE));
+      // the factorisations of K_ZZ latch their failures in a word of their own (infoK_dev): what an earlier asynchronous step
+      // latched (K~ <= 0, a non-SPD -2*eta2) stays in info_dev / flags_dev and is reported as what it is by check_status
       for (int attempt = 0; attempt < 2; ++attempt) {
         AGPCHK(ensure_zsc(g));
         (void)launch_kernelmatrix<T>(ctx, st(), (const T*)g.Z, D, (const int64_t*)nullptr, m, (const T*)g.Z, D, m, D,
                                      (const T*)g.scales, g.k.kind, (T)g.k.variance, g.L, mp, mp, mp, 1, (T)jitter,
                                      (const T*)nullptr, (T*)nullptr, (int64_t)0, 0, (const T*)g.Zsc, (const T*)g.zn);
         LAUNCHCHK(ctx);
-        const bool dag = chol_use_dag(ctx, mp / TILE);
-        AGPCHK(potrf_fused<T>(ctx, g.L, mp, mp, g.Xk, mp, g.DgK, (T*)nullptr, 0, 0, 1, info_dev, m));
-        bool lost = false;
-        if (dag) AGPCHK(dag_lost_dependency(ctx, info_dev, &lost));  // (this function synchronises below anyway)
-        if (!lost) break;
+        AGPCHK(potrf_fused<T>(ctx, g.L, mp, mp, g.Xk, mp, g.DgK, (T*)nullptr, 0, 0, 1, infoK_dev, m));
+        AGPCHK(xtx_padded<T>(ctx, g.Xk, mp, mp, g.Kinv, mp));
+        hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.DgK, m, scal_dev);
+        LAUNCHCHK(ctx);
+        double hl = 0;
+        int32_t info = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&hl, scal_dev, sizeof(double), hipMemcpyDeviceToHost, st()));
+        HIPCHK(ctx, hipMemcpyAsync(&info, infoK_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st()));
+        HIPCHK(ctx, hipStreamSynchronize(st()));  // one synchronisation per refreshed latent: log det K and the status together
+        if (info != 0) HIPCHK(ctx, hipMemsetAsync(infoK_dev, 0, sizeof(int32_t), st()));
+        if (info == -1 && attempt == 0) {  // the task graph lost a dependency: recompute K and factor with per-column launches
+          if (!ctx->dag_off)
+            fprintf(stderr, "[agp_hip] warning: a task-graph factorisation lost a tile dependency (is another process using this "
+                            "GPU?); re-running it with per-column launches, which this context uses from now on\n");
+          ctx->dag_off = true;
+          continue;
+        }
+        if (info != 0) {
+          for (auto& q : lat) q.K_stale = true;
+          // a failure an earlier asynchronous step latched (K~ <= 0 makes everything after it NaN, kernel parameters included)
+          // is the root cause and is what the reference would have thrown first
+          AGPCHK(check_status());
+          ctx->err = "PosDefException: K_ZZ + jitter*I is not positive definite; leading minor " + std::to_string(info);
+          return AGP_ERR_NOT_POSDEF;
+        }
+        g.half_logdetK = hl;
+        break;
       }
-      AGPCHK(xtx_padded<T>(ctx, g.Xk, mp, mp, g.Kinv, mp));
-      hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.DgK, m, scal_dev);
-      LAUNCHCHK(ctx);
-      double hl = 0;
-      HIPCHK(ctx, hipMemcpyAsync(&hl, scal_dev, sizeof(double), hipMemcpyDeviceToHost, st()));
-      HIPCHK(ctx, hipStreamSynchronize(st()));
-      g.half_logdetK = hl;
       if (g.mu0) {
         hipLaunchKernelGGL((k_symv<T>), grid1(mp * 64), dim3(256), 0, st(), (const T*)g.Kinv, mp, mp, (const T*)g.mu0,
                            g.kinv_mu0);
@@ -1068,17 +1083,6 @@ struct Svgp : SvgpBase {
       // (under AGP_FLAG_STALE_K a full-batch run keeps the step's kernel matrices across the refresh of the fresh set)
       if (!(g.stale_on && !desc.stochastic)) g.kappa_valid = false;
       g.pred_valid = g.predvar_valid = false;
-    }
-    if (any) {
-      int32_t info = 0;
-      HIPCHK(ctx, hipMemcpyAsync(&info, info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st()));
-      HIPCHK(ctx, hipStreamSynchronize(st()));
-      if (info != 0) {
-        HIPCHK(ctx, hipMemsetAsync(info_dev, 0, sizeof(int32_t), st()));
-        for (auto& g : lat) g.K_stale = true;
-        ctx->err = "PosDefException: K_ZZ + jitter*I is not positive definite; leading minor " + std::to_string(info);
-        return AGP_ERR_NOT_POSDEF;
-      }
     }
     for (auto& g : lat)
       if (g.on && (g.on_dirty || any)) AGPCHK(online_refresh(g));

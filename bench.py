@@ -591,9 +591,12 @@ def cpu_baseline(a, cfg, ell, Z, X, yh, idx_np, out):
                   f"(GEMM-form distances, best of {{8,16,32,64,all}} BLAS threads; host has {avail} cores), {tcpu:.1f} s of CPU "
                   f"work" + (f"; {min(cfg['K'], cfg['c5_latents'])} of the 16 latents, like the GPU line" if lik == "mo" else ""),
     }
+    # the same rule on the same index stream needs the same number of iterations: extrapolated, not run (it would take minutes)
     if out.get("iters_to_elbo_tol"):
-        # the same rule on the same index stream needs the same number of iterations: extrapolated, not run (it would take minutes)
         res["time_to_elbo_tol_s_extrapolated"] = round(out["iters_to_elbo_tol"] / rate, 1)
+    sm = (out.get("time_to_elbo_tol_smoothed") or {}).get("iters")
+    if sm:
+        res["time_to_elbo_tol_smoothed_s_extrapolated"] = round(sm / rate, 1)
     return res
 
 

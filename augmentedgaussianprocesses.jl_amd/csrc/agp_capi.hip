@@ -2924,7 +2924,7 @@ struct Svgp : SvgpBase {
 // ================================================================================================================
 extern "C" {
 
-int32_t agp_version(void) { return 100; }
+int32_t agp_version(void) { return 200; }  // 2xx: round-2 ABI (agp_comm_*, *_multi, get_matrix capacity, kernel structure flags)
 
 agp_status agp_ctx_create(int32_t device, void* hip_stream, agp_ctx** out) {
   if (!out) return AGP_ERR_INVALID;

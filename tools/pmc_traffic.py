@@ -73,5 +73,40 @@ def parse():
     print(json.dumps(res["calibration"], indent=1))
 
 
+def mfma():
+    """MFMA utilisation per kernel: one more --pmc pass with SQ_VALU_MFMA_BUSY_CYCLES; the counter sums busy cycles over all SIMDs,
+    so it is put in proportion to the kernel's duration and to the same ratio of k_mfma_peak (back-to-back MFMAs on every SIMD of
+    the chip, part of every bench.py run) instead of to an assumed clock: util = (busy / us) / (busy / us of k_mfma_peak)."""
+    env = dict(os.environ, TMPDIR="/tmp")
+    ctr = "SQ_VALU_MFMA_BUSY_CYCLES"
+    d = os.path.join(OUT, f"bench_{ctr}")
+    os.makedirs(d, exist_ok=True)
+    subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"]
+                   + [c for c in CMD if c not in ("--no-extras",)], check=True, env=env, cwd="/tmp", stdout=subprocess.DEVNULL)
+    acc = {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != ctr:
+                continue
+            name = re.sub(r"\(.*$", "", re.sub(r"^void agp::", "", r["Kernel_Name"]))
+            a = acc.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+            a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+    peak = [v for k, v in acc.items() if k.startswith("k_mfma_peak")]
+    ref = max(v[1] / v[2] for v in peak) if peak else None
+    res = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace -- python bench.py --config " + CFG + " ...",
+           "reference": "k_mfma_peak (back-to-back v_mfma 16x16x4 on every SIMD): busy cycles per microsecond = " + (f"{ref:.1f}" if ref else "n/a"),
+           "kernels": {}}
+    for k, (n, busy, us) in sorted(acc.items(), key=lambda kv: -kv[1][2]):
+        if not k.startswith("k_") or us <= 0:
+            continue
+        res["kernels"][k] = {"launches": n, "avg_us": round(us / n, 2), "mfma_busy_cycles_per_launch": round(busy / n, 1),
+                             "mfma_util_vs_k_mfma_peak": round(busy / us / ref, 4) if ref else None}
+    with open(os.path.join(OUT, f"{TAG}_pmc_mfma_util.json"), "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps({k: (v["avg_us"], v["mfma_util_vs_k_mfma_peak"]) for k, v in list(res["kernels"].items())[:12]}, indent=1))
+
+
 if __name__ == "__main__":
-    {"collect": collect, "parse": parse}[sys.argv[1]]()
+    {"collect": collect, "parse": parse, "mfma": mfma}[sys.argv[1]]()

@@ -1,3 +1,5 @@
+# Collects the rocprofv3 evidence kept under profiles/ (run on the GPU box through gpurun): bench lines, kernel statistics for c2..c5,
+# PMC traffic for c2 and c3.  Outputs land in gpurun_out/; copy what is to be kept into profiles/.
 export TMPDIR=/tmp
 R=$PWD
 for c in c2 c3 c4 c5; do

@@ -556,17 +556,28 @@ struct CholBatch {
 // ---------------------------------------------------------------------------------------------------
 // one workgroup's share of launch S(k): `bid` in [0, nP + nU) selects the role and the tile.  A device function so that the
 // per-column launches (k_chol_step) and the single-launch fallback with grid barriers (k_chol_safe) run the same code.
+// Panel groups (large matrices): with k0 <= k < jmax the launches S(k0) .. S(jmax - 1) only touch block columns [k0, jmax) -- the
+// pending update of column k - 1 exists only for k > k0, and the U role is restricted to columns (k, jmax) -- and everything to the
+// right of the group receives the group's jmax - k0 columns at once from k_chol_trail (one read-modify-write of the trailing
+// matrix per group instead of one per column).  k0 = 0, jmax = nt is the plain right-looking algorithm.
+__host__ __device__ __forceinline__ int64_t chol_nU(int64_t k, int64_t k0, int64_t jmax, int64_t nt, int64_t ne) {
+  if (k <= k0) return 0;
+  int64_t n = 0;
+  for (int64_t j = k + 1; j < jmax; ++j) n += (nt - j) + ne;  // tiles (i >= j, j) and the extension tiles of column j
+  return n;
+}
 template <typename T>
 __device__ __forceinline__ void chol_step_body(T* __restrict__ A, T* __restrict__ X, T* __restrict__ Dg, T* __restrict__ E,
                                                int64_t bid, int64_t ld, int64_t ldx, int64_t lde, int64_t ne, int do_x,
                                                int64_t k, int64_t nt, int32_t* __restrict__ info, int64_t nvalid, T* sm, T* sc,
-                                               T* piv) {
+                                               T* piv, int64_t k0 = 0, int64_t jmax = -1, T* __restrict__ li = nullptr) {
+  if (jmax < 0) jmax = nt;
   T* bufA = sm;
   T* bufB = sm + TILE * LDP;
   T* bufC = sm + 2 * TILE * LDP;
   const int tid = threadIdx.x;
   const int64_t nP = nt - k + ne;
-  const int64_t nr = nt - k - 1;
+  const bool pending = k > k0;
   const int64_t d0 = k * TILE, p0 = (k - 1) * TILE;
   if (bid < nP) {
     // ---------------- P: panel of block column k ----------------
@@ -579,7 +590,7 @@ __device__ __forceinline__ void chol_step_body(T* __restrict__ A, T* __restrict_
     // and products of the pending update instead of following them
     acc8_foreach<T>(accD, [&](int r, int c, T& val) { val = A[(d0 + r) * ld + d0 + c]; });
     if (b > 0) acc8_foreach<T>(accT, [&](int r, int c, T& val) { val = rowp[r * ldr + d0 + c]; });
-    if (k >= 1) {  // pending rank-64 update from column k-1: acc = tile - L L'
+    if (pending) {  // pending rank-64 update from column k-1: acc = tile - L L'
       load_tile_lds<T, CHOL_THREADS>(A + d0 * ld + p0, ld, bufA);
       if (b > 0) load_tile_lds<T, CHOL_THREADS>(rowp + p0, ldr, bufC);
       __syncthreads();
@@ -597,6 +608,7 @@ __device__ __forceinline__ void chol_step_body(T* __restrict__ A, T* __restrict_
         int R = e >> 6, Cc = e & 63;
         Dg[k * TILE * TILE + e] = bufA[R * LDP + Cc];
         if (do_x) X[(d0 + R) * ldx + d0 + Cc] = bufB[R * LDP + Cc];
+        if (li) li[e] = bufB[R * LDP + Cc];  // the tile's inverse, for the panel solve of a blocked factorisation
       }
       return;
     }
@@ -608,21 +620,23 @@ __device__ __forceinline__ void chol_step_body(T* __restrict__ A, T* __restrict_
   }
   bid -= nP;
   {
-    // ---------------- U: trailing update from column k-1, tiles (i, j) with j > k ----------------
-    const int64_t ntri = nr * (nr + 1) / 2;
+    // ---------------- U: trailing update from column k-1, tiles (i, j) with k < j < jmax ----------------
+    // column by column: nt - j matrix tiles (i = j .. nt-1), then the ne extension tiles
+    int64_t j = k + 1;
+    while (j < jmax && bid >= (nt - j) + ne) {
+      bid -= (nt - j) + ne;
+      ++j;
+    }
+    if (j >= jmax) return;
     T* rowp;
-    int64_t ldr, j0;
-    if (bid < ntri) {
-      int64_t ii, jj;
-      tri_index(bid, ii, jj);
-      rowp = A + (k + 1 + ii) * TILE * ld;
+    int64_t ldr;
+    const int64_t j0 = j * TILE;
+    if (bid < nt - j) {
+      rowp = A + (j + bid) * TILE * ld;
       ldr = ld;
-      j0 = (k + 1 + jj) * TILE;
     } else {
-      const int64_t t = bid - ntri, e = t / nr, jj = t % nr;
-      rowp = E + e * TILE * lde;
+      rowp = E + (bid - (nt - j)) * TILE * lde;
       ldr = lde;
-      j0 = (k + 1 + jj) * TILE;
     }
     Acc8<T> acc;
     acc8_foreach<T>(acc, [&](int r, int c, T& val) { val = rowp[r * ldr + j0 + c]; });
@@ -637,12 +651,116 @@ __device__ __forceinline__ void chol_step_body(T* __restrict__ A, T* __restrict_
 template <typename T>
 __global__ __launch_bounds__(CHOL_THREADS) void k_chol_step(CholBatch<T> bt, int64_t ld, int64_t ldx, int64_t lde,
                                                             int64_t ne, int do_x, int64_t k, int64_t nt,
-                                                            int32_t* __restrict__ info, int64_t nvalid) {
+                                                            int32_t* __restrict__ info, int64_t nvalid, int64_t k0 = 0,
+                                                            int64_t jmax = -1, T* __restrict__ li = nullptr,
+                                                            int64_t li_stride = 0) {
   __shared__ __attribute__((aligned(16))) T sm[3 * TILE * LDP];
   __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
   __shared__ T piv[TILE];
   chol_step_body<T>(bt.A[blockIdx.y], bt.X[blockIdx.y], bt.Dg[blockIdx.y], bt.E[blockIdx.y], (int64_t)blockIdx.x, ld, ldx, lde,
-                    ne, do_x, k, nt, info, nvalid, sm, sc, piv);
+                    ne, do_x, k, nt, info, nvalid, sm, sc, piv, k0, jmax,
+                    li ? li + blockIdx.y * li_stride + (k - k0) * TILE * TILE : nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Blocked factorisation of large matrices (nt beyond the task graph): block columns in groups of G,
+//   D(g): the G x G diagonal block alone       -- G small launches of k_chol_step restricted to the block (nt := k1, ne := 0),
+//                                                 which also leave the inverses of the G diagonal tiles in `li`
+//   P(g): the rows below it (and the extension) -- k_chol_panel: one workgroup per block row solves its G tiles against the block
+//   T(g): everything right of the group         -- k_chol_trail: each tile receives the group's G rank-64 updates in one pass
+// so that the serial part touches G tiles per group and the O(m^3) part is the trail kernel, which runs at the MFMA ceiling.
+// The host splits T(g) into the next group's columns and the rest, and runs the rest on a second stream next to D(g+1), P(g+1).
+//
+// k_chol_panel: X(R, k0..k1-1) = A(R, k0..k1-1) Lblk^-T by forward substitution over the block's columns,
+//   X_c = (A_c - sum_{c' < c} X_c' L(c, c')') Linv_c',
+// right-looking inside the workgroup: the G tiles of the row stay in MFMA accumulators, X_c goes through LDS into the updates of
+// the tiles right of it.  grid = (nt - k1 + ne, n_problems).
+template <typename T, int G>
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_panel(CholBatch<T> bt, int64_t ld, int64_t lde, int64_t ne, int64_t k0,
+                                                             int64_t nt, const T* __restrict__ li, int64_t li_stride, int g) {
+  T* __restrict__ A = bt.A[blockIdx.y];
+  T* __restrict__ E = bt.E[blockIdx.y];
+  li += blockIdx.y * li_stride;
+  __shared__ __attribute__((aligned(16))) T sm[2 * TILE * LDP];
+  T* bufA = sm;
+  T* bufB = sm + TILE * LDP;
+  const int64_t k1 = k0 + g, b = blockIdx.x;
+  const bool ext = b >= nt - k1;
+  T* rowp = ext ? E + (b - (nt - k1)) * TILE * lde : A + (k1 + b) * TILE * ld;
+  const int64_t ldr = ext ? lde : ld;
+  Acc8<T> acc[G];
+#pragma unroll
+  for (int c = 0; c < G; ++c)
+    if (c < g) acc8_foreach<T>(acc[c], [&](int r, int cc, T& val) { val = rowp[r * ldr + (k0 + c) * TILE + cc]; });
+#pragma unroll
+  for (int c = 0; c < G; ++c) {
+    if (c >= g) break;
+    if (c > 0) __syncthreads();
+    acc8_foreach<T>(acc[c], [&](int r, int cc, T& val) { bufA[r * LDP + cc] = val; });
+    load_tile_lds<T, CHOL_THREADS>(li + c * TILE * TILE, TILE, bufB);
+    __syncthreads();
+    Acc8<T> x;
+    x.zero();
+    mma8<T>(bufA, bufB, x);
+    acc8_foreach<T>(x, [&](int r, int cc, T& val) { rowp[r * ldr + (k0 + c) * TILE + cc] = val; });
+    if (c + 1 < g) {
+      __syncthreads();
+      acc8_foreach<T>(x, [&](int r, int cc, T& val) { bufA[r * LDP + cc] = val; });
+#pragma unroll
+      for (int c2 = c + 1; c2 < G; ++c2) {
+        if (c2 >= g) break;
+        if (c2 > c + 1) __syncthreads();
+        load_tile_lds<T, CHOL_THREADS>(A + (k0 + c2) * TILE * ld + (k0 + c) * TILE, ld, bufB);
+        __syncthreads();
+        mma8_sub<T>(bufA, bufB, acc[c2]);
+      }
+    }
+  }
+}
+
+// Trailing update of a panel group: every tile (i, j) with block column j in [j_lo, j_hi) (matrix tiles i >= j, then the ne
+// extension rows, column by column) receives
+//   tile -= sum_{c = k0}^{k1 - 1} L(i, c) L(j, c)'
+// in ONE pass: the tile stays in the MFMA accumulators across the k1 - k0 rank-64 products, so the trailing matrix is read and
+// written once per group instead of once per block column (at m = 4096 the per-column launches are bound by exactly that
+// stream: ~0.4 GB per launch at the start of a C5 factorisation).  grid = (sum_j (nt - j + ne), n_problems), 512 threads.
+__host__ __device__ __forceinline__ int64_t chol_trail_tiles(int64_t j_lo, int64_t j_hi, int64_t nt, int64_t ne) {
+  const int64_t w = j_hi - j_lo;  // sum_{j = j_lo}^{j_hi - 1} (nt - j + ne)
+  return w <= 0 ? 0 : w * (nt + ne) - (j_lo + j_hi - 1) * w / 2;
+}
+template <typename T>
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_trail(CholBatch<T> bt, int64_t ld, int64_t lde, int64_t ne, int64_t k0,
+                                                             int64_t k1, int64_t nt, int64_t j_lo, int64_t j_hi) {
+  T* __restrict__ A = bt.A[blockIdx.y];
+  T* __restrict__ E = bt.E[blockIdx.y];
+  __shared__ __attribute__((aligned(16))) T sm[2 * TILE * LDP];  // 68 KB in f64: two workgroups per CU hide each other's loads
+  int64_t bid = blockIdx.x, j = j_lo;
+  while (j < j_hi && bid >= (nt - j) + ne) {
+    bid -= (nt - j) + ne;
+    ++j;
+  }
+  if (j >= j_hi) return;
+  T* rowp;
+  int64_t ldr;
+  if (bid < nt - j) {
+    rowp = A + (j + bid) * TILE * ld;
+    ldr = ld;
+  } else {
+    rowp = E + (bid - (nt - j)) * TILE * lde;
+    ldr = lde;
+  }
+  const int64_t j0 = j * TILE;
+  const T* colp = A + j0 * ld;  // block row j of L: the second operand
+  Acc8<T> acc;
+  acc8_foreach<T>(acc, [&](int r, int c, T& val) { val = rowp[r * ldr + j0 + c]; });
+  for (int64_t c = k0; c < k1; ++c) {
+    if (c > k0) __syncthreads();
+    load_tile_lds<T, CHOL_THREADS>(rowp + c * TILE, ldr, sm);
+    load_tile_lds<T, CHOL_THREADS>(colp + c * TILE, ld, sm + TILE * LDP);
+    __syncthreads();
+    mma8_sub<T>(sm, sm + TILE * LDP, acc);
+  }
+  acc8_foreach<T>(acc, [&](int r, int c, T& val) { rowp[r * ldr + j0 + c] = val; });
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -701,8 +819,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_safe(CholBatch<T> bt, Saf
   }
   grid_barrier(bar, ++phase * nwg);
   for (int64_t k = 0; k < nt; ++k) {
-    const int64_t nP = nt - k + ne, nr = nt - k - 1;
-    const int64_t nU = (k >= 1 && nr > 0) ? nr * (nr + 1) / 2 + ne * nr : 0;
+    const int64_t nP = nt - k + ne;
+    const int64_t nU = chol_nU(k, 0, nt, nt, ne);
     for (int64_t v = blockIdx.x; v < (nP + nU) * nb; v += nwg) {
       const int q = (int)(v % nb);
       chol_step_body<T>(bt.A[q], bt.X[q], bt.Dg[q], bt.E[q], v / nb, ld, ldx, lde, ne, 0, k, nt, info, nvalid, sm, sc, piv);

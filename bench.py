@@ -58,6 +58,9 @@ CONFIGS = {
 }
 
 
+NO_PREFETCH = os.environ.get("AGP_BENCH_NO_PREFETCH") == "1"  # diagnostic: every step computes its own kappa in-stream
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -261,7 +264,7 @@ def main():
             st = L.agp_svgp_hyper_step_multi(h, comm.h if comm is not None else None, 1)
             if st != 0:
                 capi.check(model._ctx, st)
-        elif i + 1 < total:  # look-ahead: kappa of the next minibatch on the library's second stream
+        elif i + 1 < total and not NO_PREFETCH:  # look-ahead: kappa of the next minibatch on the library's second stream
             L.agp_svgp_prefetch(h, xp, ld, C.c_void_p(idx_all[i + 1].data_ptr()), B)
 
     for i in range(warm):
@@ -307,7 +310,31 @@ def main():
     flops_per_launch = flops_fact * n_lat_local / max(launches_per_step, 1e-9)
     achieved = flops_per_launch / avg_launch_s / 1e12 if nl.value else 0.0
     dag = launches_per_step <= n_lat_local + 0.5
-    kernel_name = (f"k_chol_dag<{tname}, true, {'true' if n_lat_local > 1 else 'false'}>" if dag else f"k_chol_step<{tname}>")
+    per_fact = launches_per_step / max(1, -(-n_lat_local // 16))  # latents share launches in chunks of up to 16
+    blocked = (not dag) and abs(per_fact - mp // 64) > 0.5
+    kernel_name = (f"k_chol_dag<{tname}, true, {'true' if n_lat_local > 1 else 'false'}>" if dag else
+                   f"blocked factorisation: k_chol_step + k_chol_panel + k_chol_trail <{tname}>" if blocked else
+                   f"k_chol_step<{tname}>")
+    # beyond the task graph the live number above is taken while the next minibatch's kappa GEMM runs on the prefetch stream
+    # (the two share the CUs): a few extra steps without the prefetch give the factorisation on its own
+    isolated = None
+    if not dag and comm is None:
+        model._chk(L.agp_svgp_timing_enable(h, 1))
+        for j in range(3):
+            if use_multi:
+                st = L.agp_svgp_cavi_step_multi(h, None, smode, xp, ld, yp, C.c_void_p(idx_all[j % total].data_ptr()), B, rho)
+            else:
+                st = L.agp_svgp_cavi_step(h, xp, ld, yp, C.c_void_p(idx_all[j % total].data_ptr()), B, rho)
+            if st != 0:
+                capi.check(model._ctx, st)
+        nl2, kms2 = C.c_int64(), C.c_double()
+        model._chk(L.agp_svgp_timing_read(h, C.byref(nl2), C.byref(kms2)))
+        model._chk(L.agp_svgp_timing_enable(h, 0))
+        if nl2.value:
+            a2 = kms2.value * 1e-3 / nl2.value
+            isolated = {"avg_launch_us": round(a2 * 1e6, 2), "achieved": round(flops_per_launch / a2 / 1e12, 3),
+                        "frac": round(flops_per_launch / a2 / 1e12 / peak, 4),
+                        "note": "same sequence with the prefetch stream idle (3 extra steps after the timed region)"}
     roofline = {
         "kernel": kernel_name,
         "bound": "mfma",
@@ -321,6 +348,8 @@ def main():
         "launches_per_step": round(launches_per_step, 2),
         "algorithmic_flops_per_launch": flops_per_launch,
     }
+    if isolated:
+        roofline["isolated"] = isolated
     # whole-iteration algorithmic rate (F_iter = 6 B m^2 + m^3 + B m (3D + 12) per latent)
     f_iter = (6.0 * B * m * m + m ** 3 + B * m * (3 * D + 12)) * n_lat_local
     # executed flops (the step does less than the credited count: the kappa Sigma GEMM is replaced by the panel solves and the

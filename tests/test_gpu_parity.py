@@ -82,7 +82,8 @@ def test_kernelmatrix(env, kname, kid, dtype):
     assert _rel(out.cpu().numpy(), ref) < tol
 
 
-@pytest.mark.parametrize("n", [5, 64, 100, 257, 1024, 2048, 2112])  # 2048: largest task-graph size; 2112: per-column launches
+# 2048: largest task-graph size; 2112: per-column launches; 6144: blocked (diagonal block / panel / trailing launches, look-ahead)
+@pytest.mark.parametrize("n", [5, 64, 100, 257, 1024, 2048, 2112, 6144])
 def test_potrf_and_inverse(env, n):
     torch, L, ctx = env["torch"], env["L"], env["ctx"]
     rng = np.random.default_rng(n)

@@ -538,6 +538,52 @@ __device__ __forceinline__ void tri_index(int64_t idx, int64_t& ti, int64_t& tj)
   tj = idx - t * (t + 1) / 2;
 }
 
+// ---- XCD-aware workgroup -> tile maps (speed only: the dispatcher is observed to place workgroup b on XCD b % 8, and each XCD
+// has its own 4 MiB L2; nothing depends on it for correctness).  With the launch order as tile order every XCD ends up reading
+// ALL operand panels (C2's kappa GEMM: 72 MB through the fabric for a 16 MB operand set); giving each XCD a contiguous range of
+// a locality-preserving tile order cuts that to what a compact block of tiles needs.
+constexpr int N_XCD = 8;
+// logical id of workgroup `bid` of `nwg`: XCD x = bid % 8 gets the contiguous range of ids it would own in a blocked split
+// (bijective for any nwg)
+__device__ __forceinline__ int64_t xcd_contiguous(int64_t bid, int64_t nwg) {
+  const int64_t q = nwg / N_XCD, r = nwg % N_XCD, x = bid % N_XCD, s = bid / N_XCD;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}
+// id -> tile (bm, bn) of a gy x gx grid in bands of GM tile rows, column-major inside a band: a contiguous id range is a compact
+// rectangle of about GM x (range / GM) tiles
+// (GM: the power of two with GM^2 >= tiles per XCD / 2, so an XCD's range is about square: 4 for 256 tiles, 8 for 1024)
+__device__ __forceinline__ void banded_tile(int64_t id, int64_t gx, int64_t gy, int64_t& bm, int64_t& bn) {
+  int64_t GM = 2;
+  while (2 * GM * GM * N_XCD < gx * gy) GM *= 2;
+  const int64_t per = GM * gx, band = id / per, first = band * GM, loc = id - band * per;
+  const int64_t h = (gy - first) < GM ? (gy - first) : GM;
+  bm = first + loc % h;
+  bn = loc / h;
+}
+// id -> lower-triangular tile (ta, tb <= ta) of an nt x nt tile grid, ordered by 4 x 4 blocks of tiles (block rows ascending,
+// inside a block row the off-diagonal blocks left to right, then the diagonal block): 17 consecutive ids touch ~8 operand
+// panels instead of the 16 a row-major triangle order does
+__device__ __forceinline__ void tri_blocked_index(int64_t id, int64_t nt, int64_t& ta, int64_t& tb) {
+  int64_t I = 0, hI = 0;
+  for (;;) {
+    hI = (nt - 4 * I) < 4 ? (nt - 4 * I) : 4;
+    const int64_t cnt = 4 * hI * I + hI * (hI + 1) / 2;
+    if (id < cnt) break;
+    id -= cnt;
+    ++I;
+  }
+  if (id < 4 * hI * I) {
+    const int64_t J = id / (4 * hI), loc = id % (4 * hI);
+    ta = 4 * I + loc / 4;
+    tb = 4 * J + loc % 4;
+  } else {
+    int64_t a, b;
+    tri_index(id - 4 * hI * I, a, b);
+    ta = 4 * I + a;
+    tb = 4 * I + b;
+  }
+}
+
 // Independent factorisations of equal shape (the latent GPs of a multi-class / multi-output / heteroscedastic model) share
 // the launches: blockIdx.y selects the problem, so their latency-bound chains overlap instead of queueing.
 constexpr int CHOL_MAXB = 16;

@@ -32,7 +32,9 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_gemm_nt(const T* __restrict__
                                                       const T* __restrict__ v, T* __restrict__ part0,
                                                       T* __restrict__ part1, int64_t ldp) {
   __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
-  const int64_t bn = blockIdx.x, bm = blockIdx.y;
+  int64_t bn, bm;  // XCD-aware: every XCD works on a compact block of C tiles (agp_chol.h, xcd_contiguous)
+  banded_tile(xcd_contiguous((int64_t)blockIdx.x + (int64_t)blockIdx.y * gridDim.x, (int64_t)gridDim.x * gridDim.y),
+                 (int64_t)gridDim.x, (int64_t)gridDim.y, bm, bn);
   const int64_t r0 = bm * TILE, c0 = bn * TILE;
   Acc<T> acc;
   acc.zero();
@@ -90,7 +92,8 @@ __device__ __forceinline__ void syrk_tn_body(const T* __restrict__ A, int64_t ld
                                              const T* __restrict__ Kinv, int64_t ldm, T lr, int64_t ntri,
                                              const T* __restrict__ rvec, T* __restrict__ eta1,
                                              const T* __restrict__ kinv_mu0, int64_t nrider, T* __restrict__ fillp,
-                                             int64_t fill_used, int64_t fill_stride, int fill_nb, T* smem) {
+                                             int64_t fill_used, int64_t fill_stride, int fill_nb, T* smem,
+                                             int64_t tile_id = -1) {
   if (fillp && (int64_t)blockIdx.x >= ntri + nrider) {
     // second kind of rider: refill the hand-over slots the factorisation before this launch wrote (agp_chol.h, "self-validating
     // hand-over") with the sentinel, in the shadow of the tile workgroups -- half the chip is idle during this launch anyway
@@ -120,8 +123,15 @@ __device__ __forceinline__ void syrk_tn_body(const T* __restrict__ A, int64_t ld
     }
     return;
   }
+  // XCD-aware tile order (agp_chol.h): the tiles an XCD works on share operand panels.  tile_id: the caller's logical id when the
+  // launch batches several problems (its dispatch order runs over both grid dimensions)
   int64_t ta, tb;
-  tri_index(blockIdx.x, ta, tb);
+  const int64_t ntile = ntri > 0 ? ntri : (int64_t)gridDim.x;
+  {
+    int64_t nt_ = (int64_t)((sqrt(8.0 * (double)ntile + 1.0) - 1.0) * 0.5);
+    while (nt_ * (nt_ + 1) / 2 < ntile) ++nt_;
+    tri_blocked_index(tile_id >= 0 ? tile_id : xcd_contiguous((int64_t)blockIdx.x, ntile), nt_, ta, tb);
+  }
   const int64_t a0 = ta * TILE, b0 = tb * TILE;
   Acc<T> acc;
   acc.zero();
@@ -129,7 +139,7 @@ __device__ __forceinline__ void syrk_tn_body(const T* __restrict__ A, int64_t ld
   gemm_tile<T, RC, RC, KG>(A + a0, lda, A + b0, lda, kBegin, Kdim, w, acc, smem);
   if (KG > 1 && threadIdx.x >= NTHREADS) return;
   if (MODE == SY_PACK) {
-    T* tp = out + (int64_t)blockIdx.x * (TILE * TILE);
+    T* tp = out + (ta * (ta + 1) / 2 + tb) * (TILE * TILE);
     acc_foreach<T>(acc, [&](int r, int c, T val) { tp[r * TILE + c] = val; });
   } else if (MODE == SY_STORE) {
     acc_foreach<T>(acc, [&](int r, int c, T val) {

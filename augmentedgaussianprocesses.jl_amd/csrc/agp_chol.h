@@ -541,7 +541,8 @@ __device__ __forceinline__ void tri_index(int64_t idx, int64_t& ti, int64_t& tj)
 // ---- XCD-aware workgroup -> tile maps (speed only: the dispatcher is observed to place workgroup b on XCD b % 8, and each XCD
 // has its own 4 MiB L2; nothing depends on it for correctness).  With the launch order as tile order every XCD ends up reading
 // ALL operand panels (C2's kappa GEMM: 72 MB through the fabric for a 16 MB operand set); giving each XCD a contiguous range of
-// a locality-preserving tile order cuts that to what a compact block of tiles needs.
+// a locality-preserving tile order cuts that to what a compact block of tiles needs (used by k_gemm_nt; measured neutral to
+// slightly faster there, and slower for the symmetric product, which keeps its launch order -- see syrk_tn_body).
 constexpr int N_XCD = 8;
 // logical id of workgroup `bid` of `nwg`: XCD x = bid % 8 gets the contiguous range of ids it would own in a blocked split
 // (bijective for any nwg)
@@ -560,30 +561,6 @@ __device__ __forceinline__ void banded_tile(int64_t id, int64_t gx, int64_t gy, 
   bm = first + loc % h;
   bn = loc / h;
 }
-// id -> lower-triangular tile (ta, tb <= ta) of an nt x nt tile grid, ordered by 4 x 4 blocks of tiles (block rows ascending,
-// inside a block row the off-diagonal blocks left to right, then the diagonal block): 17 consecutive ids touch ~8 operand
-// panels instead of the 16 a row-major triangle order does
-__device__ __forceinline__ void tri_blocked_index(int64_t id, int64_t nt, int64_t& ta, int64_t& tb) {
-  int64_t I = 0, hI = 0;
-  for (;;) {
-    hI = (nt - 4 * I) < 4 ? (nt - 4 * I) : 4;
-    const int64_t cnt = 4 * hI * I + hI * (hI + 1) / 2;
-    if (id < cnt) break;
-    id -= cnt;
-    ++I;
-  }
-  if (id < 4 * hI * I) {
-    const int64_t J = id / (4 * hI), loc = id % (4 * hI);
-    ta = 4 * I + loc / 4;
-    tb = 4 * J + loc % 4;
-  } else {
-    int64_t a, b;
-    tri_index(id - 4 * hI * I, a, b);
-    ta = 4 * I + a;
-    tb = 4 * I + b;
-  }
-}
-
 // Independent factorisations of equal shape (the latent GPs of a multi-class / multi-output / heteroscedastic model) share
 // the launches: blockIdx.y selects the problem, so their latency-bound chains overlap instead of queueing.
 constexpr int CHOL_MAXB = 16;

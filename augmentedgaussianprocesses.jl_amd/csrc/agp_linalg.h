@@ -92,8 +92,7 @@ __device__ __forceinline__ void syrk_tn_body(const T* __restrict__ A, int64_t ld
                                              const T* __restrict__ Kinv, int64_t ldm, T lr, int64_t ntri,
                                              const T* __restrict__ rvec, T* __restrict__ eta1,
                                              const T* __restrict__ kinv_mu0, int64_t nrider, T* __restrict__ fillp,
-                                             int64_t fill_used, int64_t fill_stride, int fill_nb, T* smem,
-                                             int64_t tile_id = -1) {
+                                             int64_t fill_used, int64_t fill_stride, int fill_nb, T* smem) {
   if (fillp && (int64_t)blockIdx.x >= ntri + nrider) {
     // second kind of rider: refill the hand-over slots the factorisation before this launch wrote (agp_chol.h, "self-validating
     // hand-over") with the sentinel, in the shadow of the tile workgroups -- half the chip is idle during this launch anyway
@@ -123,15 +122,11 @@ __device__ __forceinline__ void syrk_tn_body(const T* __restrict__ A, int64_t ld
     }
     return;
   }
-  // XCD-aware tile order (agp_chol.h): the tiles an XCD works on share operand panels.  tile_id: the caller's logical id when the
-  // launch batches several problems (its dispatch order runs over both grid dimensions)
+  // (launch order = row-major triangle order.  An XCD-aware order -- contiguous id ranges per XCD over 4 x 4 blocks of tiles --
+  // was measured: 25 % less fabric traffic, but the f32 m = 2048 product got 9 % SLOWER and f64 m = 1024 did not move; the
+  // operands sit in the Infinity Cache either way, and with the plain order all XCDs stream the same panels at the same time)
   int64_t ta, tb;
-  const int64_t ntile = ntri > 0 ? ntri : (int64_t)gridDim.x;
-  {
-    int64_t nt_ = (int64_t)((sqrt(8.0 * (double)ntile + 1.0) - 1.0) * 0.5);
-    while (nt_ * (nt_ + 1) / 2 < ntile) ++nt_;
-    tri_blocked_index(tile_id >= 0 ? tile_id : xcd_contiguous((int64_t)blockIdx.x, ntile), nt_, ta, tb);
-  }
+  tri_index(blockIdx.x, ta, tb);
   const int64_t a0 = ta * TILE, b0 = tb * TILE;
   Acc<T> acc;
   acc.zero();

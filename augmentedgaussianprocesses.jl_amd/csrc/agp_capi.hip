@@ -541,12 +541,13 @@ static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_
                           int64_t ldo, T* eta2, const T* Kinv, int64_t ldm, T lr, const T* rvec = nullptr,
                           T* eta1 = nullptr, const T* kinv_mu0 = nullptr) {
   // rvec: nt rider workgroups also step eta1 (see k_syrk_tn); a dirty hand-over set of the task-graph Cholesky is refilled by
-  // further riders (only from the fused step: MODE == SY_ETA2 with rvec)
+  // further riders (from the fused step, MODE == SY_ETA2 with rvec, and from the packed statistics of the batch-parallel step,
+  // MODE == SY_PACK with rvec, whose riders store t = A' rvec into `eta1` instead of stepping it)
   const int64_t nt = n / TILE, tiles = nt * (nt + 1) / 2, nrider = rvec ? nt : 0;
   T* fillp = nullptr;
   int64_t fused_used = 0, fstride = 0, nfill = 0;
   int fnb = 0;
-  if (MODE == SY_ETA2 && rvec && c->h_dirty[0].on && c->htype == (int)sizeof(T)) {
+  if ((MODE == SY_ETA2 || MODE == SY_PACK) && rvec && c->h_dirty[0].on && c->htype == (int)sizeof(T)) {
     fillp = (T*)c->hset[0];
     fused_used = c->h_dirty[0].used;
     fstride = c->h_dirty[0].stride;
@@ -2200,16 +2201,14 @@ struct Svgp : SvgpBase {
         AGPCHK((syrk_tn<T, SY_ETA2>(ctx, g.kappa, mp, mp, Bq, wbuf + l * Bp, 0, g.La, mp, g.eta2,
                                     kinv_step(g), mp, lr, (const T*)(rbuf + l * Bp), g.eta1, kinv_mu0_step(g))));
       } else {
-        dim3 gc((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
-        hipLaunchKernelGGL((k_colsum_partial<T>), gc, dim3(NTHREADS), 0, st(), (const T*)g.kappa, mp,
-                           (const T*)(rbuf + l * Bp), cpart, mp);
-        hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, (int)(Bq / TILE), (const T*)cpart, mp,
-                           (const T*)nullptr, (const T*)nullptr, (T*)nullptr, lr, sl);
+        // ONE launch: the packed lower tiles of kappa' diag(w) kappa, t = kappa' (rho g1) by rider workgroups (the same riders
+        // as the fused step, so a one-rank run sums in the same order), and the hand-over refill in its shadow
         AGPCHK((syrk_tn<T, SY_PACK>(ctx, g.kappa, mp, mp, Bq, wbuf + l * Bp, 0, sl + mp, mp, (T*)nullptr,
-                                    (const T*)nullptr, (int64_t)0, T(0))));
+                                    (const T*)nullptr, (int64_t)0, T(0), (const T*)(rbuf + l * Bp), sl, (const T*)nullptr)));
       }
       LAUNCHCHK(ctx);
     }
+    if (!fused) AGPCHK(kappa_released());
     return AGP_OK;
   }
   agp_status stats_ptr(void** p, int64_t* n) override {
@@ -2270,10 +2269,9 @@ struct Svgp : SvgpBase {
       Latent& g = lat[l];
       if (!fused) {
         const T* sl = stats + l * stats_stride();
-        hipLaunchKernelGGL((k_eta1_update<T>), grid1(mp), dim3(256), 0, st(), mp, 0, (const T*)nullptr, (int64_t)0, sl,
-                           kinv_mu0_step(g), g.eta1, lr, (T*)nullptr);
-        hipLaunchKernelGGL((k_eta2_from_packed<T>), dim3((unsigned)((mp / TILE) * (mp / TILE + 1) / 2)), dim3(256), 0, st(),
-                           sl + mp, mp, g.eta2, kinv_step(g), g.La, lr);
+        const int64_t ntri = (mp / TILE) * (mp / TILE + 1) / 2;
+        hipLaunchKernelGGL((k_eta2_from_packed<T>), dim3((unsigned)(4 * ntri + (mp + 255) / 256)), dim3(256), 0, st(), sl + mp, mp,
+                           g.eta2, kinv_step(g), g.La, lr, ntri, sl, kinv_mu0_step(g), g.eta1, mp);
         LAUNCHCHK(ctx);
       }
       g.la_state = 0;  // La now holds the new -2*eta2 (unfactored); it is factored inside the next local phase
@@ -2282,7 +2280,13 @@ struct Svgp : SvgpBase {
       g.pred_valid = g.predvar_valid = false;
     }
     n_opt += 1;
-    if (pf_stream) {  // marks the last use of this step's kappa buffers (they become the next prefetch target)
+    if (fused) AGPCHK(kappa_released());
+    return AGP_OK;
+  }
+  // marks the last use of this step's kappa buffers (they become the next prefetch target): after the fused step, or -- phase-split
+  // path -- right after the packed statistics, so that the next look-ahead does not wait for the all-reduce and the eta step
+  agp_status kappa_released() {
+    if (pf_stream) {
       step_parity ^= 1;
       HIPCHK(ctx, hipEventRecord(step_done[step_parity ^ 1], st()));
     }
@@ -2882,7 +2886,13 @@ struct Svgp : SvgpBase {
   agp_status cavi_step_multi(agp_comm* cm, int mode, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B,
                              double rho) override {
     if (mode != AGP_SHARD_LATENT && mode != AGP_SHARD_BATCH) return AGP_ERR_INVALID;
-    const bool multi = cm && cm->world > 1;
+    // AGP_FORCE_SPLIT=1 (diagnostic): take the phase-split path (statistics -> all-reduce -> eta step) with a one-rank
+    // communicator too, so that its cost next to the fused step can be measured on a single GPU
+    static const bool force_split = []() {
+      const char* e = getenv("AGP_FORCE_SPLIT");
+      return e && e[0] == '1';
+    }();
+    const bool multi = cm && (cm->world > 1 || (force_split && mode == AGP_SHARD_BATCH));
     if (multi && (lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_HETEROSCEDASTIC)) {
       // their lambda update (poisson.jl:78, heteroscedastic.jl:95) is a reduction over the whole minibatch that is not
       // exchanged; the two heteroscedastic latents are coupled point-wise and stay on one handle

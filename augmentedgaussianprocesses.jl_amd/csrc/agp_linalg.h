@@ -117,8 +117,12 @@ __device__ __forceinline__ void syrk_tn_body(const T* __restrict__ A, int64_t ld
     if (grp == 0) {
       T t = T(0);
       for (int q = 0; q < ngrp; ++q) t += smem[q * TILE + c];
-      const T e = eta1[c0 + c];
-      eta1[c0 + c] = e + lr * (t + (kinv_mu0 ? kinv_mu0[c0 + c] : T(0)) - e);
+      if (MODE == SY_PACK) {  // batch-parallel statistics: t itself travels (it is all-reduced before the step is taken)
+        eta1[c0 + c] = t;
+      } else {
+        const T e = eta1[c0 + c];
+        eta1[c0 + c] = e + lr * (t + (kinv_mu0 ? kinv_mu0[c0 + c] : T(0)) - e);
+      }
     }
     return;
   }
@@ -212,11 +216,26 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_syrk_eta_batch(SyrkBatch<T> b
 // path lands on the fused path's eta2 bit for bit.
 template <typename T>
 __global__ __launch_bounds__(256) void k_eta2_from_packed(const T* __restrict__ Sp, int64_t ld, T* __restrict__ eta2,
-                                                          const T* __restrict__ Kinv, T* __restrict__ Amat, T lr) {
+                                                          const T* __restrict__ Kinv, T* __restrict__ Amat, T lr, int64_t ntri,
+                                                          const T* __restrict__ t_red, const T* __restrict__ kinv_mu0,
+                                                          T* __restrict__ eta1, int64_t mp) {
+  // grid = 4 ntri + ceil(mp / 256): workgroup 4 q + s takes rows 16 s .. 16 s + 15 of tile q (four workgroups per tile: 136
+  // tiles alone leave half the chip idle on a kernel that only streams); the last ones take the eta1 step from the reduced
+  // t = kappa' (rho g1):  eta1 += lr (t + K^-1 mu0 - eta1)   (analyticVI.jl:160-169, 229-246)
+  if ((int64_t)blockIdx.x >= 4 * ntri) {
+    const int64_t a = ((int64_t)blockIdx.x - 4 * ntri) * 256 + threadIdx.x;
+    if (a < mp) {
+      const T e = eta1[a];
+      eta1[a] = e + lr * (t_red[a] + (kinv_mu0 ? kinv_mu0[a] : T(0)) - e);
+    }
+    return;
+  }
+  const int64_t q = blockIdx.x >> 2;
+  const int sub = blockIdx.x & 3;
   int64_t ta, tb;
-  tri_index(blockIdx.x, ta, tb);
-  const T* tp = Sp + (int64_t)blockIdx.x * (TILE * TILE);
-  for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
+  tri_index(q, ta, tb);
+  const T* tp = Sp + q * (TILE * TILE);
+  for (int e = sub * 1024 + threadIdx.x; e < (sub + 1) * 1024; e += 256) {
     const int r = e >> 6, c = e & 63;
     if (ta == tb && c > r) continue;
     const int64_t gr = ta * TILE + r, gc = tb * TILE + c;

@@ -247,10 +247,21 @@ def main():
         if mode == "batch":
             eng.set_batch_shard(rank, world)
         comm.timing(True)
+    elif os.environ.get("AGP_FORCE_SPLIT") == "1" and mode == "batch":
+        # diagnostic: the N > 1 step sequence (packed statistics -> all-reduce -> eta step) with a one-rank RCCL communicator
+        comm = P.Comm.rccl(model, 0, 1, P.Comm.unique_id())
+        coll = "rccl via agp_comm (one rank, AGP_FORCE_SPLIT)"
+        comm.timing(True)
     smode = capi.SHARD_BATCH if mode == "batch" else capi.SHARD_LATENT
     tied = cfg["hyper_every"] > 0
     # a latent slice of the multi-output model goes through the sharded step even on one GPU (its exchange buffer is mixed there)
     use_multi = comm is not None or bool(getattr(model, "sharded", False))
+
+    # The look-ahead pays where the step is one fused sequence (0.434 -> 0.392 ms at C2).  In the phase-split batch-parallel step
+    # (packed statistics -> all-reduce -> eta step) the two streams' event hand-overs cost more than the overlap gains (measured
+    # with a one-rank communicator, AGP_FORCE_SPLIT=1: 0.61 ms with, 0.435 ms without), so there every step computes its kappa
+    # in-stream.
+    use_prefetch = not NO_PREFETCH and not (comm is not None and mode == "batch")
 
     def step(i):
         if not use_multi:
@@ -264,7 +275,7 @@ def main():
             st = L.agp_svgp_hyper_step_multi(h, comm.h if comm is not None else None, 1)
             if st != 0:
                 capi.check(model._ctx, st)
-        elif i + 1 < total and not NO_PREFETCH:  # look-ahead: kappa of the next minibatch on the library's second stream
+        elif i + 1 < total and use_prefetch:  # look-ahead: kappa of the next minibatch on the library's second stream
             L.agp_svgp_prefetch(h, xp, ld, C.c_void_p(idx_all[i + 1].data_ptr()), B)
 
     for i in range(warm):
@@ -279,11 +290,13 @@ def main():
     t0 = time.perf_counter()
     for i in range(warm, total):
         step(i)
+    t_enq = time.perf_counter()  # host side done enqueueing (diagnostic: a host-bound loop shows up as t_enq ~ t1)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t1 = time.perf_counter()
     dt = t1 - t0
+    host_enqueue_ms_per_step = (t_enq - t0) * 1e3 / max(steps, 1)
     nl, kms = C.c_int64(), C.c_double()
     model._chk(L.agp_svgp_timing_read(h, C.byref(nl), C.byref(kms)))
     model._chk(L.agp_svgp_timing_enable(h, 0))
@@ -375,6 +388,7 @@ def main():
         "steps": steps,
         "warmup": warm,
         "ms_per_step": round(dt / steps * 1e3, 4),
+        "host_enqueue_ms_per_step": round(host_enqueue_ms_per_step, 4),
         "higher_is_better": True,
         "scaling": scaling,
         "vs_baseline": None,
@@ -414,7 +428,9 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", pf)) as fh:
                     pm = json.load(fh)
-                roofline["traffic"] = pm["kernels"][roofline["kernel"]]["hbm_bytes_per_launch_corrected"]
+                # (rocprofv3 prints every template argument, the TRACE flag included: match on the name without its closing '>')
+                key = [k for k in pm["kernels"] if k.startswith(roofline["kernel"][:-1])][0]
+                roofline["traffic"] = pm["kernels"][key]["hbm_bytes_per_launch_corrected"]
                 roofline["traffic_source"] = f"profiles/{pf} (rocprofv3 --pmc, separate passes, same command)"
                 break
             except Exception:
@@ -522,13 +538,20 @@ def main():
     if not a.no_cpu_baseline and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(a, cfg, ell, Z, X, yh, idx_np, out)
 
-    if rank == 0:
-        print(json.dumps(out))
+    # the JSON line goes out LAST: RCCL writes its version banner through C stdio (buffered when stdout is a pipe), so the
+    # communicators are torn down and that buffer flushed first
     if comm is not None:
         comm.destroy()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(a, cfg, ell, Z, X, yh, idx_np, out):

@@ -727,11 +727,14 @@ struct SvgpBase {
   int64_t n_opt = 1;  // RobbinsMonro counter (optimisers.jl:12)
   // HIP-event timing of the dominant kernel sequence (agp_svgp_timing_*)
   bool timing = false;
+  int timing_every = 1, timing_ctr = 0;  // every n-th sequence is bracketed (the two event records cost the step ~16 us at C2)
+  bool timing_now = false;
   std::vector<hipEvent_t> ev;
   std::vector<int64_t> ev_launches;
   size_t ev_used = 0;
   agp_status timing_begin() {
-    if (!timing) return AGP_OK;
+    timing_now = timing && (timing_ctr++ % timing_every) == 0;
+    if (!timing_now) return AGP_OK;
     if (ev_used + 2 > ev.size()) {
       for (int i = 0; i < 2; ++i) {
         hipEvent_t e;
@@ -743,7 +746,8 @@ struct SvgpBase {
     return AGP_OK;
   }
   agp_status timing_end(int64_t launches) {
-    if (!timing) return AGP_OK;
+    if (!timing_now) return AGP_OK;
+    timing_now = false;
     HIPCHK(ctx, hipEventRecord(ev[ev_used + 1], ctx->stream));
     ev_used += 2;
     ev_launches.push_back(launches);
@@ -3711,6 +3715,8 @@ agp_status agp_svgp_step_global(agp_svgp* h) {
 agp_status agp_svgp_timing_enable(agp_svgp* h, int32_t on) {
   HCHK(h);
   h->impl->timing = on != 0;
+  h->impl->timing_every = on > 1 ? on : 1;
+  h->impl->timing_ctr = 0;
   return AGP_OK;
 }
 agp_status agp_svgp_timing_read(agp_svgp* h, int64_t* n_launches_host, double* total_ms_host) {

@@ -33,8 +33,16 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_gemm_nt(const T* __restrict__
                                                       T* __restrict__ part1, int64_t ldp) {
   __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
   int64_t bn, bm;  // XCD-aware: every XCD works on a compact block of C tiles (agp_chol.h, xcd_contiguous)
-  banded_tile(xcd_contiguous((int64_t)blockIdx.x + (int64_t)blockIdx.y * gridDim.x, (int64_t)gridDim.x * gridDim.y),
-                 (int64_t)gridDim.x, (int64_t)gridDim.y, bm, bn);
+#ifndef AGP_GEMM_XCD
+#define AGP_GEMM_XCD 1
+#endif
+  if (AGP_GEMM_XCD) {
+    banded_tile(xcd_contiguous((int64_t)blockIdx.x + (int64_t)blockIdx.y * gridDim.x, (int64_t)gridDim.x * gridDim.y),
+                (int64_t)gridDim.x, (int64_t)gridDim.y, bm, bn);
+  } else {
+    bn = blockIdx.x;
+    bm = blockIdx.y;
+  }
   const int64_t r0 = bm * TILE, c0 = bn * TILE;
   Acc<T> acc;
   acc.zero();

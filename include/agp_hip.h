@@ -282,7 +282,8 @@ agp_status agp_svgp_stats_ptr(agp_svgp* h, void** ptr, int64_t* count);
 agp_status agp_svgp_step_global(agp_svgp* h);
 /* Measurement hook (bench.py roofline): when enabled, every factorisation sequence of a CAVI step (the launches of
  * the dominant kernel: k_chol_dag, or the launches of k_chol_step) is bracketed by HIP events recorded on the ctx stream.  timing_read
- * synchronises, returns the number of bracketed kernel launches and their summed duration, and resets. */
+ * synchronises, returns the number of bracketed kernel launches and their summed duration, and resets.
+ * on = 1: every sequence; on = n > 1: every n-th sequence (the two event records cost a C2 step about 16 us). */
 agp_status agp_svgp_timing_enable(agp_svgp* h, int32_t on);
 agp_status agp_svgp_timing_read(agp_svgp* h, int64_t* n_launches_host, double* total_ms_host);
 /* returns and clears the latched asynchronous failure (synchronises) */

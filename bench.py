@@ -61,6 +61,14 @@ CONFIGS = {
 NO_PREFETCH = os.environ.get("AGP_BENCH_NO_PREFETCH") == "1"  # diagnostic: every step computes its own kappa in-stream
 
 
+def flush_c_stdio():
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -252,6 +260,7 @@ def main():
         comm = P.Comm.rccl(model, 0, 1, P.Comm.unique_id())
         coll = "rccl via agp_comm (one rank, AGP_FORCE_SPLIT)"
         comm.timing(True)
+    flush_c_stdio()  # RCCL's init banner, if any, goes out now
     smode = capi.SHARD_BATCH if mode == "batch" else capi.SHARD_LATENT
     tied = cfg["hyper_every"] > 0
     # a latent slice of the multi-output model goes through the sharded step even on one GPU (its exchange buffer is mixed there)
@@ -542,20 +551,20 @@ def main():
     if not a.no_cpu_baseline and rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(a, cfg, ell, Z, X, yh, idx_np, out)
 
-    # the JSON line goes out LAST: RCCL writes its version banner through C stdio (buffered when stdout is a pipe), so the
-    # communicators are torn down and that buffer flushed first
+    # RCCL writes its version banner through C stdio (buffered when stdout is a pipe; it would come out at exit, after the JSON
+    # line): flush that buffer first, print the line, and only then tear the communicators down (a teardown that hangs must not
+    # cost the result)
+    if dist is not None:
+        dist.barrier()
+    flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if comm is not None:
         comm.destroy()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    try:
-        C.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    sys.stdout.flush()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    flush_c_stdio()
 
 
 def cpu_baseline(a, cfg, ell, Z, X, yh, idx_np, out):

@@ -3762,14 +3762,17 @@ agp_status agp_svgp_init_state(agp_svgp* h) {
 }
 agp_status agp_svgp_predict_f_cov(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* mu_out, void* cov_out) {
   HCHK(h);
+  if (n_t == 0) return AGP_OK;  // no test points: nothing to write (the reference returns empty arrays)
   return h->impl->predict_f_cov(xt, ldx, n_t, mu_out, cov_out);
 }
 agp_status agp_svgp_predict_f(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* mu_out, void* var_out) {
   HCHK(h);
+  if (n_t == 0) return AGP_OK;  // no test points: nothing to write (the reference returns empty arrays)
   return h->impl->predict_f(xt, ldx, n_t, mu_out, var_out);
 }
 agp_status agp_svgp_predict_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* y_out) {
   HCHK(h);
+  if (n_t == 0) return AGP_OK;  // no test points: nothing to write (the reference returns empty arrays)
   return h->impl->predict_y(xt, ldx, n_t, y_out);
 }
 agp_status agp_svgp_set_online_prior(agp_svgp* h, int32_t latent, const void* za, int64_t ldza, int64_t ma, const void* invDa,
@@ -3996,12 +3999,14 @@ agp_status agp_svgp_predict_multi(agp_svgp* h, agp_comm* comm, int32_t what, con
                                   void* mu_out, void* var_out, const double* gh_nodes_host, const double* gh_weights_host,
                                   int32_t n_nodes) {
   HCHK(h);
+  if (n_t == 0) return AGP_OK;  // no test points: nothing to write (the reference returns empty arrays)
   return h->impl->predict_multi(comm, what, xt, ldx, n_t, mu_out, var_out, gh_nodes_host, gh_weights_host, n_nodes);
 }
 
 agp_status agp_svgp_proba_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, const double* gh_nodes_host,
                             const double* gh_weights_host, int32_t n_nodes, void* out0, void* out1) {
   HCHK(h);
+  if (n_t == 0) return AGP_OK;  // no test points: nothing to write (the reference returns empty arrays)
   return h->impl->proba_y(xt, ldx, n_t, gh_nodes_host, gh_weights_host, n_nodes, out0, out1);
 }
 

@@ -326,7 +326,8 @@ agp_status agp_svgp_invalidate_data(agp_svgp* h);
 agp_status agp_svgp_init_state(agp_svgp* h);
 
 /* _predict_f (sparse)  src/training/predictions.jl:25-50 : streams over n_t test points without materialising
- * K_*m.  mu_out / var_out : T[n_latent][n_t] (var_out NULL -> cov=false). */
+ * K_*m.  mu_out / var_out : T[n_latent][n_t] (var_out NULL -> cov=false).  n_t = 0 is a successful no-op in every predict_* /
+ * proba_y entry point (the reference returns empty arrays). */
 agp_status agp_svgp_predict_f(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* mu_out, void* var_out);
 /* predict_f(model, X_test; cov=true, diag=false)  predictions.jl:45-49 : full posterior covariance
  *   cov = K** + jitt I - K*m (K^-1 - K^-1 Sigma K^-1) Km*   per latent, cov_out : T[n_latent][n_t][n_t] row-major (mu_out as

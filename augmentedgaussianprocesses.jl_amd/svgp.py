@@ -163,9 +163,13 @@ class SVGP:
         if self.T not in (np.dtype(np.float64), np.dtype(np.float32)):
             raise TypeError("T must be Float64 or Float32")
         Zlist = None
-        if isinstance(Z, (list, tuple)):  # one set of inducing points per latent (MOSVGP)
-            Zlist = [np.asarray(z, dtype=np.float64) for z in Z]
-            Z = Zlist[0]
+        if isinstance(Z, (list, tuple)):
+            arrs = [np.asarray(z, dtype=np.float64) for z in Z]
+            if arrs and all(a.ndim == 1 for a in arrs):  # the reference's own form: a vector of m points (SVGP.jl:36)
+                Z = np.stack(arrs)
+            else:                                          # one set of inducing points per latent (MOSVGP)
+                Zlist = arrs
+                Z = Zlist[0]
         Z = np.asarray(Z, dtype=np.float64)
         if Z.ndim != 2:
             raise ValueError("Z must be an (m, D) array of inducing points")

@@ -79,6 +79,27 @@ def _oips_remove(alg: OIPS, rng, Z, Kmat):
     return Z
 
 
+_FAR = 1.0e6  # spacing of the neutral padding points (see _pad_inducing)
+
+
+def _pad_inducing(Zs):
+    """The latents of one device handle share m, the reference's OnlineVarLatents do not (every latent runs its own OIPS with its own
+    kernel, onlinetraining.jl:153-160).  Latents with fewer inducing points are filled up with points that are far from the data
+    and from one another: every kernel value that involves such a point is exactly 0 in floating point, so K is block diagonal
+    with 1x1 blocks for them, their kappa columns vanish, their q(u) stays at the prior (KL contribution 0, no contribution to any
+    prediction, statistic or gradient; their own Z-gradient is 0 as well).  The real points come first; the counts are kept."""
+    m_real = [len(z) for z in Zs]
+    m_max = max(m_real)
+    out = []
+    for z in Zs:
+        z = np.asarray(z, dtype=np.float64)
+        if len(z) < m_max:
+            pad = np.array([[_FAR * (j + 1)] * z.shape[1] for j in range(m_max - len(z))], dtype=np.float64)
+            z = np.vstack([z, pad])
+        out.append(z)
+    return out, m_real
+
+
 class OnlineSVGP:
     """OnlineSVGP(kernel, likelihood, AnalyticVI(), Zalg=OIPS(0.9); optimiser=false, T=Float64)  OnlineSVGP.jl:33-72."""
 
@@ -110,18 +131,23 @@ class OnlineSVGP:
         self._cur: Optional[SVGP] = None   # SVGP wrapper owning the current device handle
         self._data = None
         self._max_batch = 0
+        self._m_real: list = []            # inducing points per latent without the neutral padding (_pad_inducing)
 
     # ---- views the reference exposes -------------------------------------------------------------------------------
     @property
     def Zs(self):
-        return self._cur.Zs if self._cur is not None else []
+        if self._cur is None:
+            return []
+        return [np.asarray(z)[:n] for z, n in zip(self._cur.Zs, self._m_real)]
 
     @property
     def n_latent(self):
         return self.likelihood.n_latent
 
     def get_state(self, latent: int = 0):
-        return self._cur.get_state(latent)
+        mu, Sig, e1, e2 = self._cur.get_state(latent)
+        n = self._m_real[latent]  # without the neutral padding
+        return mu[:n], Sig[:n, :n], e1[:n], e2[:n, :n]
 
     def _new_svgp(self, Zs, max_batch):
         m = SVGP(self.kernel if self._cur is None else self._cur.kernels, self.likelihood, AnalyticVI(), list(Zs),
@@ -152,16 +178,16 @@ def train_online(model: OnlineSVGP, X, y, state=None, *, iterations: int = 20, c
     if first:  # init_online_model onlinetraining.jl:182-197
         probe = SVGP(model.kernel, model.likelihood, AnalyticVI(), Xh[:1], optimiser=False, T=model.T, device=model.device)
         Zs = [_oips_update(model.Zalg, probe, k, Xh[:1].copy(), Xh[1:]) for k in probe.kernels]
-        if any(len(z) != len(Zs[0]) for z in Zs):
-            raise NotImplementedError("latents with different numbers of inducing points share one handle here")
+        Zs, m_real = _pad_inducing(Zs)
         new = model._new_svgp(Zs, mb)
         yt = new._treat(y)
         Xd, yd = new._upload(Xh), new._upload_y(yt)
         dev = new._dev()
         m = new.m
-        eye = torch.eye(m, dtype=new.tdtype, device=dev)
         zero = torch.zeros(m, dtype=new.tdtype, device=dev)
         for l in range(new.n_latent):  # init_opt_state(::OnlineVarLatent) states.jl:85-97 ; Z_a empty
+            eye = torch.eye(m, dtype=new.tdtype, device=dev)
+            eye[m_real[l]:, m_real[l]:] = 0  # padding points carry no prior term either (they have to stay neutral)
             new._chk(L.agp_svgp_set_online_prior(new._h, l, None, 0, m, C.c_void_p(eye.data_ptr()), m,
                                                  C.c_void_p(zero.data_ptr()), 0.0))
         start = 0
@@ -178,15 +204,27 @@ def train_online(model: OnlineSVGP, X, y, state=None, *, iterations: int = 20, c
             pl = C.c_double()
             old._chk(L.agp_svgp_online_snapshot(old._h, l, C.c_void_p(iD.data_ptr()), old.m, C.c_void_p(e1.data_ptr()),
                                                 C.byref(pl)))
-            snaps.append((iD, e1, pl.value))
+            pla = pl.value
+            n = model._m_real[l]
+            if n < old.m:
+                # The padding points must hand NOTHING on.  Their q(u) sits at the prior of the last CAVI step, the hyper step
+                # after it moved K: D_a^-1 = -2 eta2 - K^-1 would carry 1/K_old - 1/K_new on their diagonal and the constant
+                # (-logdet Sigma + logdet K)/2 the matching log ratio -- a spurious kernel-variance gradient in extraKL.
+                sig_pad = np.diag(np.asarray(old.get_state(l)[1]))[n:]
+                jit = 1e-4 if old.T == np.dtype(np.float64) else 1e-3
+                k_pad = float(old.kernels[l].variance) + jit
+                pla -= 0.5 * float(np.sum(-np.log(sig_pad) + np.log(k_pad)))
+                iD[n:, :] = 0
+                iD[:, n:] = 0
+                e1[n:] = 0
+            snaps.append((iD, e1, pla))
         Zs = []
         for l, k in enumerate(old.kernels):  # remove_point (needs K) then updateZ  onlinetraining.jl:153-160,172
-            Z = old.Zs[l]
+            Z = np.asarray(old.Zs[l])[:model._m_real[l]]  # without the padding
             if model.Zalg.rho_remove < 1.0:
                 Z = _oips_remove(model.Zalg, model.rng, Z, _kmat(old, k, Z, Z))
             Zs.append(_oips_update(model.Zalg, old, k, Z, Xh))
-        if any(len(z) != len(Zs[0]) for z in Zs):
-            raise NotImplementedError("latents with different numbers of inducing points share one handle here")
+        Zs, m_real = _pad_inducing(Zs)
         new = model._new_svgp(Zs, mb)
         yt = new._treat(y)
         Xd, yd = new._upload(Xh), new._upload_y(yt)
@@ -207,7 +245,7 @@ def train_online(model: OnlineSVGP, X, y, state=None, *, iterations: int = 20, c
                                               C.c_void_p(yd.data_ptr()), B))
         new._chk(L.agp_ctx_sync(new._ctx))
         start = 1
-    model._cur, model._max_batch = new, mb
+    model._cur, model._max_batch, model._m_real = new, mb, m_real
     model._data = new._data = (Xd, yd, B)
     new.inference.batchsize, new.inference.rho = B, 1.0
     model.trained = True

@@ -121,3 +121,41 @@ def test_online_hyper_steps_match_oracle(env, likname, ard, zopt):
         assert len(ma.Zs[0]) == len(g["Z"]) and _rel(ma.Zs[0], g["Z"]) < 1e-7
         mu, Sig, e1, e2 = ma.get_state(0)
         assert _rel(e2, g["eta2"]) < 1e-6 and _rel(mu, g["mu"]) < 1e-6
+
+
+def test_online_multilatent_with_different_inducing_counts(env):
+    """A multi-class streaming model with hyper-optimisation on: every latent runs OIPS with its own (diverging) kernel, so the
+    latents end up with different numbers of inducing points (onlinetraining.jl:153-160).  The device handle shares m; the host
+    mirror fills the shorter latents with neutral far-away points (online.py, _pad_inducing), which must not change anything:
+    same Z, eta, posterior and predictions as the oracle, whose latents simply have different sizes."""
+    from _liks import agp_lik, labels, oracle_lik
+
+    AGP, R = env["AGP"], env["R"]
+    rng = np.random.default_rng(5)
+    X, f = _stream(rng, N=240)
+    y = labels("logisticsoftmax", f, X, rng)
+    ka = 1.0 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0))
+    ma = AGP.OnlineSVGP(ka, agp_lik(AGP, "logisticsoftmax"), AGP.AnalyticVI(), AGP.OIPS(0.8), optimiser=AGP.ADAM(0.02))
+    mr = R.OnlineSVGP(R.Kernel("sqexponential", 2.0, 1.0), oracle_lik(R, "logisticsoftmax"), R.OIPS(0.8), k_opt=R.Adam(0.02))
+    differed = False
+    lr_ = mr.likelihood
+    for b in range(0, len(X), 40):
+        ea, er = [], []
+        AGP.train_online(ma, X[b:b + 40], y[b:b + 40], iterations=6, callback=lambda m, cur, i: ea.append(AGP.online_objective(m)))
+        ybt = R.treat_labels(y[b:b + 40], lr_)
+        mr.train(X[b:b + 40], y[b:b + 40], 6, callback=lambda m, it, xx, yy: er.append(m.elbo(ybt)))
+        assert np.allclose(ea, er, rtol=1e-6, atol=1e-5), (b, ea, er)  # ELBO incl. extraKL: the padding adds no constant either
+        counts = [len(g["Z"]) for g in mr.latents]
+        differed |= len(set(counts)) > 1
+        assert [len(z) for z in ma.Zs] == counts, b
+        for l, g in enumerate(mr.latents):
+            assert _rel(ma.Zs[l], g["Z"]) < 1e-7
+            mu, Sig, e1, e2 = ma.get_state(l)
+            assert _rel(e2, g["eta2"]) < 1e-8 and _rel(mu, g["mu"]) < 1e-8 and _rel(Sig, g["Sigma"]) < 1e-8, (b, l)
+            assert ma._cur.kernels[l].variance == pytest.approx(g["kernel"].sigma2, rel=1e-9)
+    assert differed, "the set-up no longer makes the latents' inducing-point counts diverge: the padding path was not exercised"
+    Xt = rng.random((50, X.shape[1]))
+    pa, pr = AGP.online_predict_f(ma, Xt, cov=True), mr.predict_f(Xt, cov=True)
+    for l in range(3):
+        assert _rel(pa[0][l], pr[0][l]) < 1e-6 and _rel(pa[1][l], pr[1][l]) < 1e-6
+    assert np.array_equal(AGP.online_predict_y(ma, Xt), mr.predict_y(Xt))

@@ -162,15 +162,9 @@ def test_osvgp_rows_of_the_reference_likelihood_suite(AGP, name):
         model = AGP.OnlineSVGP(var * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(10.0)), copy.deepcopy(lik), AGP.AnalyticVI(),
                                AGP.OIPS(), optimiser=optimiser, seed=7)
         state = None
-        try:
-            for b in range(0, len(X), 10):
-                state = AGP.train_online(model, X[b:b + 10], y[b:b + 10], state, iterations=5)
-                assert np.isfinite(AGP.online_objective(model))
-        except NotImplementedError as e:
-            # known gap: the latents of one handle share m; with hyper-optimisation on, OIPS (which selects by
-            # kernel similarity) may give the two heteroscedastic latents different numbers of inducing points
-            assert name == "heteroscedastic" and optimiser and "different numbers of inducing points" in str(e)
-            pytest.xfail("multi-latent OnlineSVGP with per-latent inducing-point counts is not wired")
+        for b in range(0, len(X), 10):
+            state = AGP.train_online(model, X[b:b + 10], y[b:b + 10], state, iterations=5)
+            assert np.isfinite(AGP.online_objective(model))
         assert model.n_latent == (3 if name == "logisticsoftmax" else 2 if name == "heteroscedastic" else 1)
         assert conv_ok(on, model, problem, X, f, y)
         assert proba_var_positive(on, model, X, problem)

@@ -270,7 +270,7 @@ def main():
     # (packed statistics -> all-reduce -> eta step) the two streams' event hand-overs cost more than the overlap gains (measured
     # with a one-rank communicator, AGP_FORCE_SPLIT=1: 0.61 ms with, 0.435 ms without), so there every step computes its kappa
     # in-stream.
-    use_prefetch = not NO_PREFETCH and not (comm is not None and mode == "batch")
+    use_prefetch = not NO_PREFETCH and (not (comm is not None and mode == "batch") or os.environ.get("AGP_BENCH_FORCE_PREFETCH") == "1")
 
     def step(i):
         if not use_multi:

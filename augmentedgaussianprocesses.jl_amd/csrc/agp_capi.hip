@@ -525,6 +525,17 @@ static agp_status potrf_fused_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, 
   return AGP_OK;
 }
 
+// Up to this many C tiles a GEMM / symmetric-product launch uses two k-groups per workgroup (512 threads, two waves per SIMD):
+// one four-wave workgroup reaches about half of a CU's MFMA rate, and up to ~4 workgroups per CU the second k-group is worth
+// more than the extra tiles in flight (measured, step times with 320 -> 1100: fp32 m = B = 2048 0.821 -> 0.789 ms, fp64 m = B =
+// 1536 0.703 -> 0.687 ms, 2048 1.37 -> 1.33 ms; C2's 256 / 136 tiles were below the old limit already).  AGP_KG2_LIMIT overrides.
+static int64_t kg2_limit() {
+  static const int64_t v = []() {
+    const char* e = getenv("AGP_KG2_LIMIT");
+    return e ? (int64_t)atoll(e) : (int64_t)1100;
+  }();
+  return v;
+}
 // out = X' X for lower-triangular X  (A^-1 from its inverse Cholesky factor)
 template <typename T>
 static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* out, int64_t ldo) {
@@ -556,7 +567,7 @@ static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_
     c->h_dirty[0].on = false;
   }
   const int64_t grid = tiles + nrider + nfill;
-  if (tiles <= 320 && Kdim >= 4 * BK)
+  if (tiles <= kg2_limit() && Kdim >= 4 * BK)
     hipLaunchKernelGGL((k_syrk_tn<T, MODE, 2>), dim3((unsigned)grid), dim3(2 * NTHREADS), 0, c->stream, A, lda, Kdim, w,
                        lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0, nrider, fillp, fused_used, fstride,
                        fnb);
@@ -574,7 +585,7 @@ static agp_status gemm_nt(agp_ctx* c, const T* A, int64_t lda, const T* B, int64
                           int64_t ldp) {
   dim3 g((unsigned)(N / TILE), (unsigned)(M / TILE));
   // fewer tiles than ~1.25 waves of CUs: two k-groups per workgroup (2 waves per SIMD) instead of idle SIMD slots
-  if ((N / TILE) * (M / TILE) <= 320 && K >= 4 * BK)
+  if ((N / TILE) * (M / TILE) <= kg2_limit() && K >= 4 * BK)
     hipLaunchKernelGGL((k_gemm_nt<T, EPI, 2>), g, dim3(2 * NTHREADS), 0, c->stream, A, lda, B, ldb, K, tri_b, C, ldc, E,
                        lde, v, p0, p1, ldp);
   else

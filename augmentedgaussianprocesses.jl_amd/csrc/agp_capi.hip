@@ -567,7 +567,17 @@ static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_
     c->h_dirty[0].on = false;
   }
   const int64_t grid = tiles + nrider + nfill;
-  if (tiles <= kg2_limit() && Kdim >= 4 * BK)
+  // up to 160 tiles (C2: 136 on 256 CUs, one workgroup per CU) four k-groups: 16 waves per CU instead of 8 -- 58 -> 52 us at C2
+  // (step 0.379 -> 0.3735 ms); AGP_SYRK_KG4=0 switches it off
+  static const bool kg4 = []() {
+    const char* e = getenv("AGP_SYRK_KG4");
+    return !(e && e[0] == '0');
+  }();
+  if (kg4 && tiles <= 160 && Kdim >= 8 * BK)
+    hipLaunchKernelGGL((k_syrk_tn<T, MODE, 4>), dim3((unsigned)grid), dim3(4 * NTHREADS), 0, c->stream, A, lda, Kdim, w,
+                       lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0, nrider, fillp, fused_used, fstride,
+                       fnb);
+  else if (tiles <= kg2_limit() && Kdim >= 4 * BK)
     hipLaunchKernelGGL((k_syrk_tn<T, MODE, 2>), dim3((unsigned)grid), dim3(2 * NTHREADS), 0, c->stream, A, lda, Kdim, w,
                        lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0, nrider, fillp, fused_used, fstride,
                        fnb);
@@ -2200,7 +2210,7 @@ struct Svgp : SvgpBase {
         ctx->h_dirty[0].on = false;
       }
       dim3 grid((unsigned)(tiles + nrider + nfill), (unsigned)nl);
-      if (tiles * nl <= 320 && Bq >= 4 * BK)
+      if (tiles * nl <= kg2_limit() && Bq >= 4 * BK)
         hipLaunchKernelGGL((k_syrk_eta_batch<T, 2>), grid, dim3(2 * NTHREADS), 0, st(), b, mp, Bq, mp, mp, lr, tiles, nrider, fillp,
                            fused_used, fstride, fnb);
       else

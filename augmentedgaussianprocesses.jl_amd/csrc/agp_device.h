@@ -202,9 +202,11 @@ __device__ __forceinline__ void gemm_tile(const T* __restrict__ A, int64_t lda, 
     cur ^= 1;
   }
   if (KG > 1) {
-    // group 1 -> LDS -> group 0 (64x64 values fit in one staging area)
-    T* red = smem_all;
-    if (grp == 1) {
+    // groups 1 .. KG-1 -> LDS -> group 0, added in group order (64x64 values fit in one staging area; group g uses area g - 1,
+    // all of them free after the last barrier of the loop)
+    static_assert(SMEM_ELEMS >= TILE * TILE, "one staging area must hold a 64x64 partial result");
+    if (grp >= 1) {
+      T* red = smem_all + (grp - 1) * SMEM_ELEMS;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -215,11 +217,15 @@ __device__ __forceinline__ void gemm_tile(const T* __restrict__ A, int64_t lda, 
     __syncthreads();
     if (grp == 0) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int g = 1; g < KG; ++g) {
+        const T* red = smem_all + (g - 1) * SMEM_ELEMS;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc.a[mi][ni][r] += red[((mi * 2 + ni) * 4 + r) * NTHREADS + tid];
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc.a[mi][ni][r] += red[((mi * 2 + ni) * 4 + r) * NTHREADS + tid];
+      }
     }
   }
 }

@@ -175,7 +175,8 @@ def test_predict_f_full_covariance(mods):
             mk, ck = (mu, cov) if K == 1 else (mu[k], cov[k])
             vk = var if K == 1 else var[k]
             assert ck.shape == (77, 77) and _rel(mk, rmu[k]) < 1e-8 and _rel(ck, rcov[k]) < 1e-8
-            assert _rel(np.diag(ck), vk) < 1e-9 and np.max(np.abs(ck - ck.T)) < 1e-12
+            # (symmetric up to the rounding of k** - k* A k*': two GEMM results of O(1) subtracted, entries of O(0.1))
+            assert _rel(np.diag(ck), vk) < 1e-9 and np.max(np.abs(ck - ck.T)) < 1e-11
 
 
 @pytest.mark.parametrize("stochastic", [True, False])

@@ -417,10 +417,28 @@ __global__ void k_rowstats_local(int64_t B, int nslices, const T* __restrict__ p
   const int lane = threadIdx.x & 63;
   if (i >= B) return;
   T s0 = T(0), s1 = T(0), sk = T(0);
-  for (int64_t j = lane; j < cols; j += 64) {
-    T wv = W[i * ldw + j];
-    s0 += wv * wv;
-    s1 += wv * v[j];
+  {
+    // 16-byte loads, four independent accumulator pairs (cols is a multiple of 64 and the rows are 512-byte aligned: padded layout)
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    const T2* Wr = reinterpret_cast<const T2*>(W + i * ldw);
+    const T2* vr = reinterpret_cast<const T2*>(v);
+    T a0 = T(0), a1 = T(0), b0 = T(0), b1 = T(0);
+    const int64_t n2 = cols >> 1;
+    int64_t j = lane;
+    for (; j + 64 < n2; j += 128) {
+      const T2 w0 = Wr[j], w1 = Wr[j + 64], v0 = vr[j], v1 = vr[j + 64];
+      a0 += w0.x * w0.x + w0.y * w0.y;
+      b0 += w0.x * v0.x + w0.y * v0.y;
+      a1 += w1.x * w1.x + w1.y * w1.y;
+      b1 += w1.x * v1.x + w1.y * v1.y;
+    }
+    for (; j < n2; j += 64) {
+      const T2 w0 = Wr[j], v0 = vr[j];
+      a0 += w0.x * w0.x + w0.y * w0.y;
+      b0 += w0.x * v0.x + w0.y * v0.y;
+    }
+    s0 = a0 + a1;
+    s1 = b0 + b1;
   }
   if (!use_kt)
     for (int s = lane; s < nslices; s += 64) sk += pk[s * ldp + i];

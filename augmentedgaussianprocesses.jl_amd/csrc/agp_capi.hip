@@ -536,16 +536,6 @@ static int64_t kg2_limit() {
   }();
   return v;
 }
-// out = X' X for lower-triangular X  (A^-1 from its inverse Cholesky factor)
-template <typename T>
-static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* out, int64_t ldo) {
-  const int64_t nt = n / TILE;
-  hipLaunchKernelGGL((k_syrk_tn<T, SY_STORE>), dim3((unsigned)(nt * (nt + 1) / 2)), dim3(NTHREADS), 0, c->stream, X, ld,
-                     n, (const T*)nullptr, 1, out, ldo, (T*)nullptr, (const T*)nullptr, (int64_t)0, T(0));
-  LAUNCHCHK(c);
-  return AGP_OK;
-}
-
 // S = A' diag(w) A (lower tiles mirrored), two k-groups per workgroup when the tile count underfills the chip
 template <typename T, int MODE>
 static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_t Kdim, const T* w, int lower_a, T* out,
@@ -587,6 +577,13 @@ static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_
                        fnb);
   LAUNCHCHK(c);
   return AGP_OK;
+}
+
+// out = X' X for lower-triangular X  (A^-1 from its inverse Cholesky factor): the symmetric product with the k range of every
+// tile starting at its first row, k-groups chosen like everywhere else (it ran with one k-group on 136 tiles: 60 us at m = 1024)
+template <typename T>
+static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* out, int64_t ldo) {
+  return syrk_tn<T, SY_STORE>(c, X, ld, n, n, (const T*)nullptr, 1, out, ldo, (T*)nullptr, (const T*)nullptr, (int64_t)0, T(0));
 }
 
 template <typename T, int EPI>

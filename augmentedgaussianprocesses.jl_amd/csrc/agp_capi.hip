@@ -48,6 +48,9 @@ struct agp_ctx {
   int n_cu = 0;
   bool dag_off = false;
   int64_t dag_retries_seen = 0;
+  // probation: after a lost dependency the context factors by plain launches for `dag_cooldown` CAVI steps, then tries the task
+  // graph again (whoever shared the GPU may be gone); every further loss makes the next pause four times longer
+  int64_t dag_cooldown = 0, dag_backoff = 512;
   // blocked factorisation of large matrices: side stream of the look-ahead (trailing update of the far columns next to the next
   // group's diagonal block and panel), fork / join events, inverses of the current group's diagonal tiles
   hipStream_t side = nullptr;
@@ -349,17 +352,27 @@ static agp_status chol_columns(agp_ctx* c, const CholBatch<T>& bt, int nb, int64
 }
 
 
+static void dag_pause(agp_ctx* c) {
+  c->dag_off = true;
+  c->dag_cooldown = c->dag_backoff;
+  c->dag_backoff = std::min<int64_t>(c->dag_backoff * 4, (int64_t)1 << 20);
+}
+// once per CAVI step: end of the probation?
+static void dag_tick(agp_ctx* c) {
+  if (c->dag_off && --c->dag_cooldown <= 0) c->dag_off = false;
+}
 // host side of the latch: called where the stream has just been synchronised anyway
 static void dag_retry_check(agp_ctx* c) {
   if (!c->safe_retries || c->dag_off) return;
   int32_t r = 0;
   if (hipMemcpy(&r, c->safe_retries, sizeof(r), hipMemcpyDeviceToHost) != hipSuccess) return;
-  if (r > 0) {
-    c->dag_off = true;
-    c->dag_retries_seen = r;
+  if (r > c->dag_retries_seen) {
     fprintf(stderr,
             "[agp_hip] warning: %d task-graph factorisation(s) lost a tile dependency (is another process using this GPU?) and were "
-            "re-run by the in-stream fallback; this context now uses per-column launches\n", (int)r);
+            "re-run by the in-stream fallback; this context uses plain launches for the next %lld steps\n",
+            (int)(r - c->dag_retries_seen), (long long)c->dag_backoff);
+    c->dag_retries_seen = r;
+    dag_pause(c);
   }
 }
 
@@ -469,8 +482,9 @@ static agp_status dag_lost_dependency(agp_ctx* c, int32_t* info_dev, bool* lost)
     HIPCHK(c, hipMemsetAsync(info_dev, 0, sizeof(int32_t), c->stream));
     if (!c->dag_off)
       fprintf(stderr, "[agp_hip] warning: a task-graph factorisation lost a tile dependency (is another process using this GPU?); "
-                      "re-running it with per-column launches, which this context uses from now on\n");
-    c->dag_off = true;
+                      "re-running it with plain launches, which this context uses for the next %lld steps\n",
+              (long long)c->dag_backoff);
+    dag_pause(c);
     *lost = true;
   }
   return AGP_OK;
@@ -1429,6 +1443,7 @@ struct Svgp : SvgpBase {
                         bool fresh) override {
     AGPCHK(check_batch(B));
     if (!x || !y || ldx < D) return AGP_ERR_INVALID;
+    dag_tick(ctx);
     AGPCHK(refresh_K());
     const int64_t Bq = rup64(B);
     const int ns = (int)(2 * mp / TILE);

@@ -449,3 +449,63 @@ def test_task_graph_fallback_reruns_the_factorisation_in_stream(mods, K):
     mr.train(X, y, len(idx), idx_stream=idx)
     for k in range(len(eta2)):
         assert _rel(eta2[k], mr.latents[k].eta2) < 1e-8
+
+
+def _probation_child(q):
+    """fresh process with AGP_DAG_TEST_ABORT=1: every task-graph launch 'loses a dependency'; the host notices at the end of each
+    train_ call (its status check) and pauses the task graph for 512 steps"""
+    try:
+        import sys
+
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import agp_amd as AGP
+        from agp_amd import capi
+
+        rng = np.random.default_rng(32)
+        N, D, m, B = 2000, 3, 130, 128
+        X = rng.random((N, D))
+        y = (np.sin(4 * X[:, 0]) + X[:, 1] > 1.0).astype(int)
+        Z = X[rng.permutation(N)[:m]].copy()
+        idx = [rng.choice(N, B, replace=False) for _ in range(6 + 500 + 40)]
+        ma = AGP.SVGP(1.5 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0)), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z,
+                      optimiser=False)
+        f_ = capi.lib().agp_dev_dag_retries
+        f_.restype, f_.argtypes = C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)]
+        counts, st = [], None
+        for lo, hi in ((0, 6), (6, 506), (506, 546)):
+            _, st = AGP.train_(ma, X, y, hi - lo, idx_stream=idx[lo:hi], state=st)
+            n = C.c_int64()
+            assert f_(ma._ctx, C.byref(n)) == 0
+            counts.append(int(n.value))
+        q.put((counts, ma.get_state(0)[3], X, y, Z, idx))
+    except BaseException as e:
+        import traceback
+
+        q.put(repr(e) + traceback.format_exc())
+
+
+def test_task_graph_is_tried_again_after_a_pause(mods):
+    """A lost dependency no longer switches the context to plain launches for good: after 512 steps the task graph is tried again
+    (here it 'fails' again, by construction, and the next pause is four times longer).  Counts of in-stream re-runs after 6, 506
+    and 546 steps: the first call's six, nothing during the pause, again from step 513 on.  The posterior still matches the oracle."""
+    import multiprocessing as mp
+
+    AGP, R, capi, torch = mods
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    os.environ["AGP_DAG_TEST_ABORT"] = "1"
+    try:
+        p = ctx.Process(target=_probation_child, args=(q,))
+        p.start()
+        got = q.get(timeout=900)
+        p.join(timeout=60)
+    finally:
+        del os.environ["AGP_DAG_TEST_ABORT"]
+    assert not isinstance(got, str), got
+    counts, eta2, X, y, Z, idx = got
+    assert counts[0] == 6                      # every step of the first call went through the fallback
+    assert counts[1] == counts[0]              # paused: 500 steps of plain launches, no task graph, nothing to re-run
+    assert counts[2] > counts[1]               # steps 513.. use the task graph again (and lose it again)
+    mr = R.SVGP(R.Kernel("sqexponential", 2.0, 1.5), R.LogisticLikelihood(), Z, stochastic=True, batchsize=128)
+    mr.train(X, y, len(idx), idx_stream=idx)
+    assert _rel(eta2, mr.latents[0].eta2) < 1e-7

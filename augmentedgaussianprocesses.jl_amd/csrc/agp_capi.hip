@@ -2912,7 +2912,11 @@ struct Svgp : SvgpBase {
 
   // ---- multi-GPU drivers behind the ABI (include/agp_hip.h "multi-GPU") -----------------------
   agp_status comm_sum(agp_comm* cm, void* buf, int64_t count) {
-    if (!cm || cm->world <= 1) return AGP_OK;
+    static const bool force = []() {  // AGP_FORCE_SPLIT=1 (diagnostic): issue the collective of a one-rank communicator too
+      const char* e = getenv("AGP_FORCE_SPLIT");
+      return e && e[0] == '1';
+    }();
+    if (!cm || (cm->world <= 1 && !force)) return AGP_OK;
     if (cm->ctx != ctx) {
       ctx->err = "agp_comm belongs to another ctx (its collectives would run on another stream)";
       return AGP_ERR_INVALID;

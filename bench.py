@@ -257,8 +257,30 @@ def main():
         comm.timing(True)
     elif os.environ.get("AGP_FORCE_SPLIT") == "1" and mode == "batch":
         # diagnostic: the N > 1 step sequence (packed statistics -> all-reduce -> eta step) with a one-rank RCCL communicator
-        comm = P.Comm.rccl(model, 0, 1, P.Comm.unique_id())
-        coll = "rccl via agp_comm (one rank, AGP_FORCE_SPLIT)"
+        fake_us = float(os.environ.get("AGP_BENCH_FAKE_ALLREDUCE_US", "0"))
+        if fake_us > 0:
+            # stand-in for the xGMI all-reduce on a one-GPU box: a kernel that just occupies the stream for about that long
+            cyc = int(fake_us * 900)  # torch.cuda._sleep: ~1.1 ns per count here (the JSON line carries the measured us per call)
+            exts = {}
+
+            def _fake(ptr, count, dtype, stream):
+                try:
+                    if stream is None:  # the ctx runs on the default stream, which is torch's current one here
+                        torch.cuda._sleep(cyc)
+                    else:
+                        if stream not in exts:
+                            exts[stream] = torch.cuda.ExternalStream(int(stream))
+                        with torch.cuda.stream(exts[stream]):
+                            torch.cuda._sleep(cyc)
+                except BaseException as e:
+                    print("[bench] fake all-reduce failed:", repr(e), file=sys.stderr)
+                    raise
+
+            comm = P.Comm.from_callback(model, 0, 1, _fake)
+            coll = f"callback: ~{fake_us:.0f} us sleep kernel per call (AGP_BENCH_FAKE_ALLREDUCE_US)"
+        else:
+            comm = P.Comm.rccl(model, 0, 1, P.Comm.unique_id())
+            coll = "rccl via agp_comm (one rank, AGP_FORCE_SPLIT)"
         comm.timing(True)
     flush_c_stdio()  # RCCL's init banner, if any, goes out now
     smode = capi.SHARD_BATCH if mode == "batch" else capi.SHARD_LATENT
@@ -266,11 +288,13 @@ def main():
     # a latent slice of the multi-output model goes through the sharded step even on one GPU (its exchange buffer is mixed there)
     use_multi = comm is not None or bool(getattr(model, "sharded", False))
 
-    # The look-ahead pays where the step is one fused sequence (0.434 -> 0.392 ms at C2).  In the phase-split batch-parallel step
-    # (packed statistics -> all-reduce -> eta step) the two streams' event hand-overs cost more than the overlap gains (measured
-    # with a one-rank communicator, AGP_FORCE_SPLIT=1: 0.61 ms with, 0.435 ms without), so there every step computes its kappa
-    # in-stream.
-    use_prefetch = not NO_PREFETCH and (not (comm is not None and mode == "batch") or os.environ.get("AGP_BENCH_FORCE_PREFETCH") == "1")
+    # The look-ahead (kappa of the next minibatch on the library's second stream) is used in every mode.  In the phase-split
+    # batch-parallel step the kappa buffers are released right after the packed statistics, so the look-ahead runs next to the
+    # all-reduce.  Measured on one GPU with a stand-in kernel of 27 / 43 / 65 us in the all-reduce's place (AGP_FORCE_SPLIT=1
+    # AGP_BENCH_FAKE_ALLREDUCE_US=..): 0.422 / 0.4225 / 0.438 ms per step with the look-ahead, 0.455 / 0.469 / 0.488 without.
+    # (With NO kernel between the statistics and the eta step -- a one-rank communicator, whose collective is skipped -- the two
+    # streams' event hand-overs collide and the look-ahead costs 0.15 ms; that case does not occur with more than one rank.)
+    use_prefetch = not NO_PREFETCH
 
     def step(i):
         if not use_multi:
@@ -418,7 +442,7 @@ def main():
         "iter_executed_frac_mfma_peak": round(f_exec * steps / dt / 1e12 / peak, 4),
         "roofline": roofline,
     }
-    if world > 1:
+    if comm is not None:
         ncalls, nbytes, cms = coll_stats
         out["value_definition"] = ("batch-parallel weak scaling: one step consumes the global minibatch of B x n_gpus points and counts "
                                    "as n_gpus minibatch-iterations; global steps/s = value / n_gpus" if mode == "batch" else

@@ -1459,6 +1459,10 @@ struct Svgp : SvgpBase {
       }
       pf_valid = false;
     }
+    // how many problems one task-graph launch may take (0: none fits, plain launches)
+    int dag_nb = 0;
+    for (int q = DAG_MAX_NB; q >= 1 && !dag_nb; --q)
+      if (chol_use_dag(ctx, mp / TILE, Bq / TILE + 1, q)) dag_nb = q;
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
       const bool keep = reuse && g.kappa_valid;
@@ -1495,7 +1499,7 @@ struct Svgp : SvgpBase {
         hipLaunchKernelGGL((k_copy2d<T>), grid2(mp, mp), blk2, 0, st(), (const T*)g.eta2, mp, mp, mp, g.La, mp, mp, mp,
                            T(1), T(-2));
       }
-      if (nl > 1)  // a single latent gets [eta1' ; 0] passed along instead (potrf_fused erow)
+      if (nl > 1 && dag_nb == 0)  // the task graphs take [eta1' ; 0] from eta1 itself (erow / CholBatch::R): only the plain launches need it in E
         hipLaunchKernelGGL((k_set_ext_rows<T>), grid1(TILE * mp), dim3(256), 0, st(), g.Wbuf + Bq * mp, mp, mp,
                            (const T*)g.eta1);
       LAUNCHCHK(ctx);
@@ -1509,9 +1513,6 @@ struct Svgp : SvgpBase {
       // chunking: task graphs take as many problems per launch as the residency bound allows (balanced chunks, e.g. 8 latents
       // as 4 + 4); if not even one fits, all of them share per-column launches
       const int64_t ntl = mp / TILE, nel = Bq / TILE + 1;
-      int dag_nb = 0;
-      for (int q = DAG_MAX_NB; q >= 1 && !dag_nb; --q)
-        if (chol_use_dag(ctx, ntl, nel, q)) dag_nb = q;
       size_t chunk = CHOL_MAXB;
       if (dag_nb > 0 && !todo.empty()) {
         const size_t nchunks = (todo.size() + dag_nb - 1) / dag_nb;
@@ -1527,6 +1528,7 @@ struct Svgp : SvgpBase {
           bt.X[q] = g.Xa;
           bt.Dg[q] = g.DgA;
           bt.E[q] = g.Wbuf;
+          bt.R[q] = g.eta1;
           g.la_state = 1;
           g.xa_valid = false;
         }
@@ -1552,13 +1554,21 @@ struct Svgp : SvgpBase {
       }
       if (!todo.empty()) AGPCHK(timing_end(launches));
     }
-    for (int l = 0; l < nl; ++l) {
-      Latent& g = lat[l];
-      const bool keep = g.keep_last;
-      hipLaunchKernelGGL((k_rowstats_local<T>), grid1(B * 64), dim3(256), 0, st(), B, ns, (const T*)g.pk, ldp,
-                         (const T*)g.Wbuf, mp, mp, (const T*)(g.Wbuf + Bq * mp), (T)g.k.variance, (T)jitter, (T)rho, lp,
-                         (const T*)y, idx, Kt + l * Bp, muf + l * Bp, varf + l * Bp, cbuf + l * Bp, theta + l * Bp,
-                         rbuf + l * Bp, wbuf + l * Bp, flags_dev, (int)keep, (const T*)lam_dev, gamma + l * Bp);
+    for (int l0 = 0; l0 < nl; l0 += ROWSTATS_MAXB) {  // row statistics + local update of all latents in one launch
+      const int nb = std::min(ROWSTATS_MAXB, nl - l0);
+      RowstatsBatch<T> rb{};
+      for (int q = 0; q < nb; ++q) {
+        Latent& g = lat[l0 + q];
+        rb.pk[q] = g.pk;
+        rb.W[q] = g.Wbuf;
+        rb.v[q] = g.Wbuf + Bq * mp;
+        rb.kdiag[q] = (T)g.k.variance;
+        rb.use_kt[q] = g.keep_last ? 1 : 0;
+      }
+      const dim3 grid((unsigned)((B * 64 + 255) / 256), (unsigned)nb);
+      hipLaunchKernelGGL((k_rowstats_local<T>), grid, dim3(256), 0, st(), B, ns, rb, ldp, mp, mp, (T)jitter, (T)rho, lp,
+                         (const T*)y, idx, Kt + l0 * Bp, muf + l0 * Bp, varf + l0 * Bp, cbuf + l0 * Bp, theta + l0 * Bp,
+                         rbuf + l0 * Bp, wbuf + l0 * Bp, Bp, flags_dev, (const T*)lam_dev, gamma + l0 * Bp);
       LAUNCHCHK(ctx);
     }
     if (lp.kind == AGP_LIK_POISSON) {  // lambda <- sum(y) / sum E[logistic(f)]   poisson.jl:78

@@ -405,14 +405,38 @@ __device__ __forceinline__ void lik_point(int kind, T p0, T p1, T m, T v, T yi, 
 
 // One wave per minibatch row i: row statistics of W (s0 = sum_j W_ij^2, s1 = sum_j W_ij v_j), the K~ slice sum, then
 // lane 0 finishes K~ / mean_f / var_f and runs the likelihood update -- rowstats and local update in ONE launch.
+// All latents of a handle in one launch: blockIdx.y = latent; the per-latent inputs come from the struct, the per-latent outputs
+// sit `ostride` elements apart.
+constexpr int ROWSTATS_MAXB = 16;
 template <typename T>
-__global__ void k_rowstats_local(int64_t B, int nslices, const T* __restrict__ pk, int64_t ldp,
-                                 const T* __restrict__ W, int64_t ldw, int64_t cols, const T* __restrict__ v,
-                                 T kdiag, T jitter, T rho, LikParams<T> lp, const T* __restrict__ y,
+struct RowstatsBatch {
+  const T* pk[ROWSTATS_MAXB];  // K~ partial slices
+  const T* W[ROWSTATS_MAXB];   // kappa L_A^-T
+  const T* v[ROWSTATS_MAXB];   // L_A^-1 eta1
+  T kdiag[ROWSTATS_MAXB];      // kernel variance (diagonal of the kernel matrix)
+  int use_kt[ROWSTATS_MAXB];   // K~ kept from the previous full-batch step
+};
+template <typename T>
+__global__ void k_rowstats_local(int64_t B, int nslices, RowstatsBatch<T> rb, int64_t ldp, int64_t ldw, int64_t cols,
+                                 T jitter, T rho, LikParams<T> lp, const T* __restrict__ y,
                                  const int64_t* __restrict__ idx, T* __restrict__ Kt, T* __restrict__ muf,
                                  T* __restrict__ varf, T* __restrict__ c, T* __restrict__ theta, T* __restrict__ r,
-                                 T* __restrict__ w, int* __restrict__ flags, int use_kt, const T* __restrict__ lam,
+                                 T* __restrict__ w, int64_t ostride, int* __restrict__ flags, const T* __restrict__ lam,
                                  T* __restrict__ gamma) {
+  const int q = blockIdx.y;
+  const T* __restrict__ pk = rb.pk[q];
+  const T* __restrict__ W = rb.W[q];
+  const T* __restrict__ v = rb.v[q];
+  const T kdiag = rb.kdiag[q];
+  const int use_kt = rb.use_kt[q];
+  Kt += q * ostride;
+  muf += q * ostride;
+  varf += q * ostride;
+  c += q * ostride;
+  theta += q * ostride;
+  r += q * ostride;
+  w += q * ostride;
+  gamma += q * ostride;
   const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= B) return;

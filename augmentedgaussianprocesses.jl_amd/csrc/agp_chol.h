@@ -570,6 +570,7 @@ struct CholBatch {
   T* X[CHOL_MAXB];
   T* Dg[CHOL_MAXB];
   T* E[CHOL_MAXB];
+  const T* R[CHOL_MAXB];  // task graph only, optional: row 0 of the problem's LAST extension block ([eta1' ; 0], see erow)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -1108,6 +1109,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   T* X = bt.X[prob];
   T* __restrict__ Dg = bt.Dg[prob];
   T* E = bt.E[prob];
+  if (BATCH) erow = bt.R[prob];
   flags += prob * fstride;
   // hand-over area of this problem (sentinel-filled by the host): slots of 64x64 elements
   //   HX[k] = X_k  |  HP[2k] = parked (k, k-1), HP[2k + 1] = parked (k, k)  |  HL[(R * nt + c)] tile (R, c), R in [0, nt + ne + nx)

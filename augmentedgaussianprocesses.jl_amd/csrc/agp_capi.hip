@@ -910,7 +910,6 @@ struct Svgp : SvgpBase {
     *rbuf = nullptr, *wbuf = nullptr;              // [nl][Bp]
   T *alpha = nullptr, *beta = nullptr, *gsum = nullptr, *alpha_save = nullptr;  // [Bp]
   T *emuf = nullptr, *evarf = nullptr;             // ELBO-time mean_f / var_f [nl][Bp]
-  T* cpart = nullptr;                              // [Bp/64][mp]
   T* stats = nullptr;                              // [nl][mp + nt(nt+1)/2 * 64*64]: kappa' r, then the lower tiles of kappa' diag(w) kappa
   int64_t stats_stride() const { return mp + (mp / TILE) * (mp / TILE + 1) / 2 * TILE * TILE; }
   T* Tw = nullptr;                                 // mp x mp scratch
@@ -1029,7 +1028,6 @@ struct Svgp : SvgpBase {
     AGPCHK(dmalloc(ctx, &beta, Bp));
     AGPCHK(dmalloc(ctx, &gsum, Bp));
     AGPCHK(dmalloc(ctx, &alpha_save, Bp));
-    AGPCHK(dmalloc(ctx, &cpart, (Bp / TILE) * mp));
     AGPCHK(dmalloc(ctx, &stats, nl * stats_stride()));
     AGPCHK(dmalloc(ctx, &Tw, mm));
     AGPCHK(dmalloc(ctx, &Tw2, mm));
@@ -1067,7 +1065,7 @@ struct Svgp : SvgpBase {
     for (auto e : step_done)
       if (e) dcheck(hipEventDestroy(e), __LINE__);
     T* ps[] = {pw0, pw1, Kt, muf, varf, cbuf, theta, gamma, rbuf, wbuf, alpha, beta, gsum, alpha_save, emuf,
-               evarf, cpart, stats, Tw, Tw2, tmpv, lr_dev, Kstar, ppm, ppv, pmu, pvar};
+               evarf, stats, Tw, Tw2, tmpv, lr_dev, Kstar, ppm, ppv, pmu, pvar};
     for (T* p : ps)
       if (p) dfree(p);
     T* hps[] = {hyH1, hyH2, hyH3, hy_gmu, hy_gs, hy_muf, hy_pZ, hy_dZ, hyKap, hyKnm};

@@ -819,50 +819,6 @@ __global__ void k_mo_mix(int64_t n, int Q, int nT, const T* __restrict__ A, int 
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// t = kappa' r  (analyticVI.jl:168): column sums in two deterministic stages.
-// stage 1: grid (mp/64, Bp/64): part[by][col] = sum over the 64 rows of this row block
-// stage 2 lives in k_eta1_update / k_stats_t.
-// ---------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_colsum_partial(const T* __restrict__ kappa, int64_t ld,
-                                                             const T* __restrict__ r, T* __restrict__ part,
-                                                             int64_t ldp) {
-  __shared__ T red[4][TILE];
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int64_t c0 = blockIdx.x * (int64_t)TILE, r0 = blockIdx.y * (int64_t)TILE;
-  T s = T(0);
-#pragma unroll 4
-  for (int q = 0; q < 16; ++q) {
-    int64_t row = r0 + grp * 16 + q;
-    s += kappa[row * ld + c0 + col] * r[row];
-  }
-  red[grp][col] = s;
-  __syncthreads();
-  if (grp == 0) part[blockIdx.y * ldp + c0 + col] = red[0][col] + red[1][col] + red[2][col] + red[3][col];
-}
-
-// eta1 += lr * ( sum_parts t + K^-1 mu0 - eta1 )    (analyticVI.jl:160-169, 229-246)
-// t_in != nullptr: t already reduced (multi-GPU stats path) ; else sum nparts slices of part.
-template <typename T>
-__global__ void k_eta1_update(int64_t mp, int nparts, const T* __restrict__ part, int64_t ldp,
-                              const T* __restrict__ t_in, const T* __restrict__ kinv_mu0, T* __restrict__ eta1, T lr,
-                              T* __restrict__ t_out) {
-  int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (a >= mp) return;
-  T t = T(0);
-  if (t_in) t = t_in[a];
-  else
-    for (int s = 0; s < nparts; ++s) t += part[s * ldp + a];
-  if (t_out) {
-    t_out[a] = t;
-    return;
-  }
-  T e = eta1[a];
-  T g = t + (kinv_mu0 ? kinv_mu0[a] : T(0)) - e;
-  eta1[a] = e + lr * g;
-}
-
 // mean_f / var_f only (ELBO with the updated posterior): mu = sum pw1 ; var = sum pw0 + K~
 template <typename T>
 __global__ void k_meanvar_finish(int64_t B, int nslices, const T* __restrict__ pw0, const T* __restrict__ pw1,

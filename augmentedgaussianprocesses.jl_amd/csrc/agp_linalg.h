@@ -115,7 +115,7 @@ __device__ __forceinline__ void syrk_tn_body(const T* __restrict__ A, int64_t ld
   if (rvec && (int64_t)blockIdx.x >= ntri) {
     // rider of the fused step: workgroup ntri + j also takes the natural-gradient step on eta1[64 j .. 64 j + 63]
     //   t = A' r (column sums, analyticVI.jl:168) ; eta1 += lr (t + K^-1 mu0 - eta1)
-    // (these launches used to be k_colsum_partial + k_eta1_update: two kernels and two launch gaps on the step's critical path)
+    // (these used to be two kernels of their own, and two launch gaps, on the step's critical path)
     const int64_t c0 = ((int64_t)blockIdx.x - ntri) * TILE;
     const int c = threadIdx.x & 63, grp = threadIdx.x >> 6, ngrp = blockDim.x >> 6;
     T sum = T(0);

@@ -122,3 +122,63 @@ def test_failed_cholesky_reports_the_pivot(mods, n, bad):
         assert st == 2 and info.value == bad + 1, (st, info.value, L.agp_last_error(ctx))
     finally:
         L.agp_ctx_destroy(ctx)
+
+
+@pytest.mark.parametrize("n", [300, 2112, 6144])  # task graph / per-column launches / blocked, in fp32
+def test_fp32_factorisation_paths(mods, n):
+    AGP, R, capi, torch = mods
+    L = capi.lib()
+    ctx = C.c_void_p()
+    assert L.agp_ctx_create(0, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ctx)) == 0
+    try:
+        g = torch.Generator(device="cuda").manual_seed(n)
+        G = torch.randn(n, n + 8, dtype=torch.float64, device="cuda", generator=g)
+        A64 = G @ G.T / n + 0.5 * torch.eye(n, dtype=torch.float64, device="cuda")
+        A = A64.to(torch.float32).contiguous()
+        info = C.c_int32(-7)
+        assert L.agp_potrf_jitter(ctx, 1, C.c_void_p(A.data_ptr()), n, n, 1e-3, C.byref(info)) == 0 and info.value == 0
+        Lf = torch.tril(A).to(torch.float64)
+        ref = A64 + 1e-3 * torch.eye(n, dtype=torch.float64, device="cuda")
+        err = (Lf @ Lf.T - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-5, err
+    finally:
+        L.agp_ctx_destroy(ctx)
+
+
+def test_fp32_hyper_gradient_and_multiclass(mods):
+    """T = Float32 beyond the plain step: the hand-derived hyper-gradient and a three-class LogisticSoftMax trajectory against the
+    fp64 oracle (tolerances of single precision: gradients 2e-2 relative to their largest entry, predictive means 5e-3)."""
+    AGP, R, capi, torch = mods
+    rng = np.random.default_rng(77)
+    N, D, m, B, iters = 240, 3, 16, 80, 4
+    X = rng.random((N, D))
+    f = np.sin(4 * X[:, 0]) + X[:, 1] * X[:, 2]
+    idx = [rng.choice(N, B, replace=False) for _ in range(iters)]
+    Z = X[rng.permutation(N)[:m]].copy()
+    # hyper-gradient, logistic
+    y = (f > f.mean()).astype(int)
+    ma = AGP.SVGP(1.3 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.5)), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z,
+                  optimiser=False, T=np.float32)
+    AGP.train_(ma, X, y, iters, idx_stream=idx)
+    mr = R.SVGP(R.Kernel("sqexponential", 2.5, 1.3), R.LogisticLikelihood(), Z, stochastic=True, batchsize=B, jitter=1e-3)
+    yt = R.treat_labels(y, mr.likelihood)
+    mr.train(X, yt, iters, idx_stream=idx, labels_treated=True)
+    mr.hp_updated = True
+    mr.compute_kernel_matrices(X[idx[-1]])
+    g = R.hyper_gradient(mr, X[idx[-1]], yt[idx[-1]], 0, N / B)
+    dv, ds, dz = ma.hypergrad(0)
+    assert abs(dv - g["dvariance"]) < 2e-2 * max(1.0, abs(g["dvariance"]))
+    assert np.max(np.abs(np.asarray(ds) - g["dscale"])) < 2e-2 * max(1.0, np.max(np.abs(g["dscale"])))
+    assert np.max(np.abs(np.asarray(dz) - g["dZ"])) < 2e-2 * max(1.0, np.max(np.abs(g["dZ"])))
+    # three classes
+    y3 = 1 + np.digitize(f, np.quantile(f, [0.33, 0.66]))
+    m3 = AGP.SVGP(1.5 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0)), AGP.LogisticSoftMaxLikelihood(3), AGP.AnalyticSVI(B),
+                  Z, optimiser=False, T=np.float32)
+    r3 = R.SVGP(R.Kernel("sqexponential", 2.0, 1.5), R.LogisticSoftMaxLikelihood(3), Z, stochastic=True, batchsize=B, jitter=1e-3)
+    AGP.train_(m3, X, y3, iters, idx_stream=idx)
+    r3.train(X, y3, iters, idx_stream=idx)
+    Xt = rng.random((60, D))
+    pa, pr = AGP.predict_f(m3, Xt), r3.predict_f(Xt)
+    for k in range(3):
+        assert np.max(np.abs(np.asarray(pa[k]) - pr[k])) < 5e-3 * max(1.0, np.max(np.abs(pr[k])))
+    assert np.mean(AGP.predict_y(m3, Xt) == r3.predict_y(Xt)) > 0.95

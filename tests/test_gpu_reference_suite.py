@@ -168,3 +168,35 @@ def test_osvgp_rows_of_the_reference_likelihood_suite(AGP, name):
         assert model.n_latent == (3 if name == "logisticsoftmax" else 2 if name == "heteroscedastic" else 1)
         assert conv_ok(on, model, problem, X, f, y)
         assert proba_var_positive(on, model, X, problem)
+
+
+def test_mosvgp_testset(AGP):
+    """test/models/MOSVGP.jl: two tasks (Logistic, Laplace(2)), one latent per task, N = 20, d = 2, KmeansAlg(5),
+    MOSVGP(k, likelihoods, AnalyticVI(), [Z, Z]); train! 10 iterations, then predict_y and proba_y must run."""
+    rng = np.random.default_rng(42)
+    X, f = generate_f(rng, 20, 2, 10.0, 1.0)
+    _, f2 = generate_f(rng, 20, 2, 10.0, 1.0, X)
+    ys = [f > 0, f2 + rng.laplace(0.0, 2.0, 20)]
+    Z = AGP.inducingpoints(AGP.KmeansAlg(5), X)
+    model = AGP.MOSVGP(AGP.SqExponentialKernel() @ AGP.ScaleTransform(10.0), [AGP.LogisticLikelihood(), AGP.LaplaceLikelihood(2.0)],
+                       AGP.AnalyticVI(), [Z, Z])
+    AGP.train_(model, X, ys, 10)
+    yp = AGP.predict_y(model, X)
+    pp = AGP.proba_y(model, X)
+    assert len(yp) == 2 and len(pp) == 2
+    assert np.asarray(yp[0]).shape == (20,) and np.asarray(yp[1]).shape == (20,)
+    assert np.all(np.isfinite(np.asarray(yp[1], dtype=float)))
+    A = model.get_A()
+    assert np.allclose(np.linalg.norm(A, axis=1), 1.0)  # update_A! keeps the rows on the unit sphere (utils :110-112)
+
+
+def test_analyticvi_object(AGP):
+    """test/inference/analyticVI.jl: what the inference object reports before and after set_rho."""
+    i = AGP.AnalyticVI()
+    assert repr(i) == "Analytic Variational Inference"
+    assert i.rho == 1.0 and i.stoch is False
+    i = AGP.AnalyticSVI(5)
+    assert i.stoch is True and i.batchsize == 5
+    i.rho = 20 / 5
+    assert i.rho == 4.0
+    assert repr(i) == "Analytic Stochastic Variational Inference"

@@ -200,3 +200,36 @@ def test_analyticvi_object(AGP):
     i.rho = 20 / 5
     assert i.rho == 4.0
     assert repr(i) == "Analytic Stochastic Variational Inference"
+
+
+def test_data_wrapping_like_the_reference(AGP):
+    """test/data/datacontainer.jl, test/data/utils.jl on the host mirror: a label vector of the wrong length is an error
+    (wrap_data), obsdim = 2 takes the observations from the columns (wrap_X), a plain vector is N one-dimensional points, the
+    multi-output container takes one label vector per task and rejects a ragged one."""
+    rng = np.random.default_rng(3)
+    X = rng.random((30, 2))
+    y = np.sin(3 * X[:, 0]) + 0.1 * rng.standard_normal(30)
+    Z = X[:6].copy()
+
+    def model():
+        return AGP.SVGP(AGP.SqExponentialKernel(), AGP.GaussianLikelihood(0.1), AGP.AnalyticVI(), Z, optimiser=False)
+
+    with pytest.raises((ValueError, RuntimeError)):
+        AGP.train_(model(), X, np.append(y, 0.0), 2)
+    m1, m2 = model(), model()
+    AGP.train_(m1, X, y, 3)
+    AGP.train_(m2, X.T.copy(), y, 3, obsdim=2)
+    assert np.array_equal(m1.get_state(0)[3], m2.get_state(0)[3])
+    assert np.allclose(AGP.predict_f(m1, X), AGP.predict_f(m2, X.T.copy(), obsdim=2), rtol=0, atol=0)
+    # a vector of N scalars = N one-dimensional points
+    x1 = rng.random(25)
+    y1 = np.cos(4 * x1)
+    mv = AGP.SVGP(AGP.SqExponentialKernel(), AGP.GaussianLikelihood(0.1), AGP.AnalyticVI(), x1[:5, None].copy(), optimiser=False)
+    AGP.train_(mv, x1, y1, 3)
+    assert AGP.predict_f(mv, x1).shape == (25,)
+    # multi-output: one label vector per task, all of the data's length
+    ys = [y, (y > 0)]
+    mo = AGP.MOSVGP(AGP.SqExponentialKernel(), [AGP.GaussianLikelihood(0.1), AGP.LogisticLikelihood()], AGP.AnalyticVI(), [Z, Z])
+    with pytest.raises((ValueError, RuntimeError)):
+        AGP.train_(mo, X, [y, np.append(y > 0, True)], 2)
+    AGP.train_(mo, X, ys, 2)

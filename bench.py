@@ -460,8 +460,8 @@ def main():
 
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE as
     # MI355X_MICROARCH.md prescribes for gfx950); rocprofv3 cannot wrap bench.py from inside, so this is not live
-    if a.config == "c2" and world == 1:
-        for pf in ("r02_pmc_hbm_bytes.json", "r01h_pmc_hbm_bytes.json"):
+    if a.config in ("c2", "c3") and world == 1 and comm is None:
+        for pf in (("r02_pmc_hbm_bytes.json", "r01h_pmc_hbm_bytes.json") if a.config == "c2" else ("r02_c3_pmc_hbm_bytes.json",)):
             try:
                 with open(os.path.join(ROOT, "profiles", pf)) as fh:
                     pm = json.load(fh)

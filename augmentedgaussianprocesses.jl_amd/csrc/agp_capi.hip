@@ -664,19 +664,30 @@ static int launch_kernelmatrix(agp_ctx* c, hipStream_t stream, const T* X, int64
     ysn = sc0 + p_pad * Dp;
   }
   const size_t sh = kmm_smem_bytes<T>(Dp);
-  if (sh > 64 * 1024) {  // more than 64 KB of dynamic LDS has to be requested once per kernel
-    static size_t asked = 0;
-    if (sh > asked) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kernelmatrix_mma<T>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-      asked = sh;
-    }
-  }
   const int64_t groups = cgroups <= 0 ? nct : std::min<int64_t>(cgroups, nct);
   const int64_t ctiles = (nct + groups - 1) / groups;
   const int64_t g_eff = (nct + ctiles - 1) / ctiles;
-  hipLaunchKernelGGL((k_kernelmatrix_mma<T>), dim3((unsigned)g_eff, (unsigned)nrt), dim3(NTHREADS), sh, stream, X, ldx, idx, n, ysc,
-                     ysn, p, D, Dp, scales, kind, variance, out, ldo, n_out, p_out, sym, diag_add, alpha, part, ldp, ctiles);
+  const dim3 grid((unsigned)g_eff, (unsigned)nrt);
+#define AGP_KMM_LAUNCH(KIND)                                                                                                  \
+  do {                                                                                                                        \
+    if (sh > 64 * 1024) { /* more than 64 KB of dynamic LDS has to be requested once per kernel */                            \
+      static size_t asked = 0;                                                                                                \
+      if (sh > asked) {                                                                                                       \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kernelmatrix_mma<T, KIND>),                                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);                                       \
+        asked = sh;                                                                                                           \
+      }                                                                                                                       \
+    }                                                                                                                         \
+    hipLaunchKernelGGL((k_kernelmatrix_mma<T, KIND>), grid, dim3(NTHREADS), sh, stream, X, ldx, idx, n, ysc, ysn, p, D, Dp,  \
+                       scales, variance, out, ldo, n_out, p_out, sym, diag_add, alpha, part, ldp, ctiles);                    \
+  } while (0)
+  switch (kind) {
+    case AGP_K_SQEXP: AGP_KMM_LAUNCH(K_SQEXP); break;
+    case AGP_K_MATERN52: AGP_KMM_LAUNCH(K_MATERN52); break;
+    case AGP_K_MATERN32: AGP_KMM_LAUNCH(K_MATERN32); break;
+    default: AGP_KMM_LAUNCH(K_EXPONENTIAL); break;
+  }
+#undef AGP_KMM_LAUNCH
   return (int)g_eff;
 }
 

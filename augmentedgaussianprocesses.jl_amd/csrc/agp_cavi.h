@@ -163,12 +163,17 @@ __global__ void k_scale_rows(const T* __restrict__ Y, int64_t ldy, int64_t p, in
   if (lane == 0) yn[row] = s;
 }
 
-template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_kernelmatrix_mma(const T* __restrict__ X, int64_t ldx,
+// KIND: the kernel function as a template parameter (K_SQEXP .. K_EXPONENTIAL).  With a run-time kind all four bodies were inlined
+// into every one of the 16 values a lane finishes per tile: 223 VGPRs + 32 AGPRs, two waves per SIMD, and the accumulators were
+// copied between AGPRs and VGPRs around every k-step.  With one body and __launch_bounds__(256, 4): 128 VGPRs, MFMA on VGPRs, four
+// workgroups per CU (the LDS allows exactly that up to D = 32 in fp64) -- streaming prediction 4.8 -> 3.5 ms at C2 (a hand-written
+// exp for non-positive arguments was also tried: no different from the library's).
+template <typename T, int KIND>
+__global__ __launch_bounds__(NTHREADS, 4) void k_kernelmatrix_mma(const T* __restrict__ X, int64_t ldx,
                                                                const int64_t* __restrict__ idx, int64_t n,
                                                                const T* __restrict__ Ysc, const T* __restrict__ yng,
                                                                int64_t p, int64_t D, int Dp, const T* __restrict__ scales,
-                                                               int kind, T variance, T* __restrict__ out, int64_t ldo,
+                                                               T variance, T* __restrict__ out, int64_t ldo,
                                                                int64_t n_out, int64_t p_out, int sym, T diag_add,
                                                                const T* __restrict__ alpha, T* __restrict__ part,
                                                                int64_t ldp, int64_t ctiles) {
@@ -226,6 +231,7 @@ __global__ __launch_bounds__(NTHREADS) void k_kernelmatrix_mma(const T* __restri
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int r = 0; r < 4; ++r) rs[mi][r] = T(0);
+  const int cp_r0 = tid / nv, cp_v0 = tid % nv, cp_dr = NTHREADS / nv, cp_dv = NTHREADS % nv;
   const int64_t nct = (p_out + TILE - 1) / TILE;
   const int64_t ct0 = blockIdx.x * ctiles;
   const int64_t ct1 = (ct0 + ctiles < nct) ? ct0 + ctiles : nct;
@@ -238,11 +244,20 @@ __global__ __launch_bounds__(NTHREADS) void k_kernelmatrix_mma(const T* __restri
     if (ct != ct0) __syncthreads();  // the previous tile's epilogue is done with Ys / yn
     {
       const T* src = Ysc + ct * TILE * Dp;  // contiguous 64 x Dp block
+      // (row, vector) of element e = tid + 256 q advanced incrementally: two integer divisions per element and tile showed up as
+      // ~300 VALU instructions per wave and tile in the PMC instruction counts
+      int r = cp_r0, v = cp_v0;
       for (int e = tid; e < TILE * nv; e += NTHREADS) {
         const vec_t x = *reinterpret_cast<const vec_t*>(src + (int64_t)e * VEC);
-        const int r = e / nv, dv = (e % nv) * VEC;
+        T* dst = Ys + r * LDX + v * VEC;
 #pragma unroll
-        for (int w = 0; w < VEC; ++w) Ys[r * LDX + dv + w] = x[w];
+        for (int w = 0; w < VEC; ++w) dst[w] = x[w];
+        r += cp_dr;
+        v += cp_dv;
+        if (v >= nv) {
+          v -= nv;
+          ++r;
+        }
       }
       if (tid < TILE) yn[tid] = yng[ct * TILE + tid];
     }
@@ -266,36 +281,55 @@ __global__ __launch_bounds__(NTHREADS) void k_kernelmatrix_mma(const T* __restri
       acc[1][0] = Mfma<T>::mma(a1, b0, acc[1][0]);
       acc[1][1] = Mfma<T>::mma(a1, b1, acc[1][1]);
     }
+    // epilogue.  Everything that depends on the column only (two columns per lane and tile) or on the row only is taken out of the
+    // element loop: PMC showed ~96 VALU instructions per kernel value with the bounds checks, the 64-bit index arithmetic and the
+    // alpha loads inside it -- the VALU, not the MFMA or the exp, bounded the streaming predictor.
+    int cl_[2];
+    bool cok[2], cout_[2];
+    T ynv[2], al[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      cl_[ni] = wn * 32 + ni * 16 + (lane & 15);
+      const int64_t gj = j0 + cl_[ni];
+      cok[ni] = gj < p;
+      cout_[ni] = out != nullptr && gj < p_out;
+      ynv[ni] = ynb[cl_[ni]];
+      al[ni] = (alpha != nullptr && cok[ni]) ? alpha[gj] : T(0);
+    }
+    const int64_t dgi = sym ? (j0 - i0) : (int64_t)1 << 40;  // gi == gj  <=>  rl - cl == j0 - i0 (only tiles on the diagonal can hit)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rl = wm * 32 + mi * 16 + Mfma<T>::row(lane, r);
         const int64_t gi = i0 + rl;
+        const bool rok = gi < n, rout = gi < n_out;
         const T xnv = xn[rl];
+        T* orow = out ? out + gi * ldo + j0 : nullptr;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          const int cl = wn * 32 + ni * 16 + (lane & 15);
-          const int64_t gj = j0 + cl;
+          const int cl = cl_[ni];
+          const bool diag = sym && (int64_t)(rl - cl) == dgi;
           T val = T(0);
-          if (gi < n && gj < p) {
-            const T s2 = xnv + ynb[cl];
+          if (rok && cok[ni]) {
+            const T s2 = xnv + ynv[ni];
             T d2 = s2 - T(2) * acc[mi][ni][r];
             if (d2 < close_thr * s2) {  // (nearly) coincident points: direct differences, no cancellation
               T t = T(0);
-              for (int d = 0; d < Dp; ++d) {
+#pragma unroll 1
+              for (int d = 0; d < Dp; ++d) {  // rare path: kept rolled (unrolled it cost registers on the common one)
                 const T df = Xs[rl * LDX + d] - Ys[cl * LDX + d];
                 t += df * df;
               }
               d2 = t;
             }
-            val = variance * kernel_base<T>(kind, d2);
-            if (sym && gi == gj) val += diag_add;
-          } else if (sym && gi == gj) {
+            val = variance * kernel_base<T>(KIND, d2);
+            if (diag) val += diag_add;
+          } else if (diag) {
             val = T(1);
           }
-          if (out && gi < n_out && gj < p_out) out[gi * ldo + gj] = val;
-          if (alpha && gj < p) rs[mi][r] += val * alpha[gj];
+          if (cout_[ni] && rout) orow[cl] = val;
+          rs[mi][r] += val * al[ni];
         }
       }
   }

@@ -540,6 +540,8 @@ def main():
                 if st != 0:
                     capi.check(model2._ctx, st)
                 it += 1
+                if use_prefetch:  # the same look-ahead as in the timed loop (the ELBO evaluation in between leaves it valid)
+                    L.agp_svgp_prefetch(h2, xp, ld, C.c_void_p(chunk[it % chunk.shape[0]].data_ptr()), B)
             model2._chk(L.agp_svgp_elbo(h2, xp, ld, yp, C.c_void_p(eval_idx.data_ptr()), EVAL, rho_e, 1, C.byref(e)))
             hist.append(e.value)
             now = time.perf_counter() - ts

@@ -341,9 +341,15 @@ end
 
 # ---- update_parameters!(model, state, x, y) (training.jl:140-158) ---------------------------------------------------------------
 # `idx` is the minibatch drawn by train! (StatsBase.sample, training.jl:51-53), 1-based; nothing = full batch.
-function update_parameters!(hm::HipModel{T}, idx::Union{Nothing,AbstractVector{<:Integer}}, ρ::Real) where {T}
+# minibatch indices on the device, 0-based (an already uploaded vector is taken as it is: the look-ahead and the step that
+# consumes it must see the same buffer)
+device_indices(idx::Nothing) = nothing
+device_indices(idx::ROCArray{Int64}) = idx
+device_indices(idx::AbstractVector{<:Integer}) = ROCArray(Int64.(idx .- 1))
+
+function update_parameters!(hm::HipModel{T}, idx, ρ::Real) where {T}
     D = size(hm.X, 1)
-    idd = idx === nothing ? nothing : ROCArray(Int64.(idx .- 1))    # 0-based on the device
+    idd = device_indices(idx)
     hm.last_idx = idd
     B = idx === nothing ? hm.N : length(idx)
     idp = idd === nothing ? Ptr{Int64}(C_NULL) : pointer(idd)
@@ -356,6 +362,16 @@ function update_parameters!(hm::HipModel{T}, idx::Union{Nothing,AbstractVector{<
               hm.h, hm.comm, hm.shard, pointer(hm.X), D, pointer(hm.y), idp, B, ρ)
     end
     check(hm.ctx, st)
+    return nothing
+end
+
+# Look-ahead: Knm / kappa of the NEXT minibatch on the library's second stream, next to the current step's factorisation
+# (agp_svgp_prefetch; a no-op while K is stale, i.e. right after a hyper-parameter step).  `idd` must be the very buffer the next
+# update_parameters! passes.
+function prefetch!(hm::HipModel, idd::ROCArray{Int64})
+    D = size(hm.X, 1)
+    check(hm.ctx, ccall((:agp_svgp_prefetch, libagp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Int64}, Int64),
+                        hm.h, pointer(hm.X), D, pointer(idd), length(idd)))
     return nothing
 end
 
@@ -402,17 +418,21 @@ function train!(hm::HipModel{T}, X::AbstractArray, y, iterations::Int=100; callb
     check(hm.ctx, ccall((:agp_svgp_refresh_K, libagp), Int32, (Ptr{Cvoid},), hm.h))
     ρ = AGP.is_stochastic(model) ? N / B : 1.0
     hyper_on = any(gp -> AGP.opt(gp) !== nothing || AGP.Zopt(gp) !== nothing, model.f)
-    local_iter = 1
-    while true
-        idx = nothing
-        if AGP.is_stochastic(model)
-            idx = idx_stream === nothing ? sample(1:N, B; replace=false) : idx_stream[local_iter]
-            if hm.comm != C_NULL && hm.shard == AGP_SHARD_BATCH    # this rank's share of the minibatch (rho stays N / B_total)
-                r = comm_rank(hm)
-                idx = idx[(r * Blocal + 1):((r + 1) * Blocal)]
-            end
+    # minibatch of iteration `it` on the device: the reference's sample(1:N, B; replace=false) (training.jl:51-53), drawn in the
+    # same order, one iteration ahead of its use so that the look-ahead can run next to the current step
+    function draw(it)
+        AGP.is_stochastic(model) || return nothing
+        idx = idx_stream === nothing ? sample(1:N, B; replace=false) : idx_stream[it]
+        if hm.comm != C_NULL && hm.shard == AGP_SHARD_BATCH    # this rank's share of the minibatch (rho stays N / B_total)
+            r = comm_rank(hm)
+            idx = idx[(r * Blocal + 1):((r + 1) * Blocal)]
         end
-        update_parameters!(hm, idx, ρ)
+        return device_indices(idx)
+    end
+    local_iter = 1
+    idd = draw(1)
+    while true
+        update_parameters!(hm, idd, ρ)
         AGP.set_trained!(model, true)
         callback === nothing || callback(hm, hm, AGP.n_iter(model))
         if hyper_on && (AGP.n_iter(model) % model.atfrequency == 0) && (AGP.n_iter(model) >= 3) && (local_iter != iterations)
@@ -421,6 +441,8 @@ function train!(hm::HipModel{T}, X::AbstractArray, y, iterations::Int=100; callb
         local_iter += 1
         inf.n_iter += 1
         (local_iter <= iterations) || break
+        idd = draw(local_iter)
+        idd === nothing || prefetch!(hm, idd)
     end
     check(hm.ctx, ccall((:agp_svgp_check_status, libagp), Int32, (Ptr{Cvoid},), hm.h))
     check(hm.ctx, ccall((:agp_svgp_refresh_K, libagp), Int32, (Ptr{Cvoid},), hm.h))            # compute_Ks, training.jl:107

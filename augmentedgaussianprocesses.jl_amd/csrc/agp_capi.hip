@@ -213,10 +213,9 @@ static bool chol_use_dag(const agp_ctx* c, int64_t nt, int64_t ne = 0, int64_t n
 
 __global__ void k_set_i32(int32_t* p, int32_t v) { *p = v; }
 
-// the fallback behind a task-graph launch (see k_chol_safe): one launch that returns at once unless the latch reads -1
+// grid-barrier words, retry counter and the CU count of the fallback (allocated on first use)
 template <typename T>
-static agp_status launch_chol_safe(agp_ctx* c, const CholBatch<T>& bt, const SafeSrc<T>& src, int nb, int64_t ld, int64_t ldx,
-                                   int64_t lde, int64_t ne, int64_t nt, int32_t* info_dev, int64_t nvalid) {
+static agp_status ensure_safe_words(agp_ctx* c) {
   if (!c->safe_bar) {
     if (hipMalloc((void**)&c->safe_bar, 2 * sizeof(unsigned)) != hipSuccess) return AGP_ERR_NOMEM;
     if (hipMalloc((void**)&c->safe_retries, sizeof(int32_t)) != hipSuccess) return AGP_ERR_NOMEM;
@@ -226,6 +225,14 @@ static agp_status launch_chol_safe(agp_ctx* c, const CholBatch<T>& bt, const Saf
     HIPCHK(c, hipGetDeviceProperties(&pr, c->device));
     c->n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 64;
   }
+  return AGP_OK;
+}
+
+// the fallback behind a task-graph launch (see k_chol_safe): one launch that returns at once unless the latch reads -1
+template <typename T>
+static agp_status launch_chol_safe(agp_ctx* c, const CholBatch<T>& bt, const SafeSrc<T>& src, int nb, int64_t ld, int64_t ldx,
+                                   int64_t lde, int64_t ne, int64_t nt, int32_t* info_dev, int64_t nvalid) {
+  AGPCHK(ensure_safe_words<T>(c));
   // one workgroup per CU at most (each needs ~110 KB of LDS, so one fits per CU): all of them become resident, whatever else runs
   const int64_t most = (nt + ne + nt * (nt + 1) / 2 + ne * nt) * nb;
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(c->n_cu, most));
@@ -234,6 +241,32 @@ static agp_status launch_chol_safe(agp_ctx* c, const CholBatch<T>& bt, const Saf
   LAUNCHCHK(c);
   return AGP_OK;
 }
+// The kernel behind the task graph of a single-latent CAVI step: the fallback of k_chol_safe (a no-op unless the latch reads -1)
+// and then the row statistics + local update, in ONE launch -- the separate k_chol_safe launch cost the step ~5 us of kernel and a
+// launch gap on its critical path.  grid <= n_cu workgroups of 512 threads (all resident: the fallback uses grid barriers); the
+// rows are taken wave by wave, grid-stride.
+template <typename T>
+__global__ __launch_bounds__(CHOL_THREADS) void k_safe_rowstats(CholBatch<T> bt, SafeSrc<T> src, int64_t ld, int64_t ldx, int64_t lde,
+                                                                int64_t ne, int64_t nt, int32_t* __restrict__ info, int64_t nvalid,
+                                                                unsigned* __restrict__ bar, int32_t* __restrict__ retries,
+                                                                int64_t B, int nslices, RowstatsBatch<T> rb, int64_t ldp,
+                                                                int64_t ldw, int64_t cols, T jitter, T rho, LikParams<T> lp,
+                                                                const T* __restrict__ y, const int64_t* __restrict__ idx,
+                                                                T* __restrict__ Kt, T* __restrict__ muf, T* __restrict__ varf,
+                                                                T* __restrict__ cb, T* __restrict__ theta, T* __restrict__ r,
+                                                                T* __restrict__ w, int* __restrict__ flags,
+                                                                const T* __restrict__ lam, T* __restrict__ gamma) {
+  __shared__ __attribute__((aligned(16))) T sm[3 * TILE * LDP];
+  __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
+  __shared__ T piv[TILE];
+  (void)chol_safe_body<T>(bt, src, 1, ld, ldx, lde, ne, nt, info, nvalid, bar, retries, sm, sc, piv);
+  // (after a fallback the last grid barrier of the column loop has made every workgroup's tiles visible)
+  const int64_t wpb = CHOL_THREADS / 64, nwave = (int64_t)gridDim.x * wpb;
+  for (int64_t i = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); i < B; i += nwave)
+    rowstats_row<T>(i, threadIdx.x & 63, 0, B, nslices, rb, ldp, ldw, cols, jitter, rho, lp, y, idx, Kt, muf, varf, cb, theta, r, w,
+                    (int64_t)0, flags, lam, gamma);
+}
+
 // Factorisation by plain launches (matrices beyond the task graph, and the task graph's fallback).  From 8 block columns on it is
 // blocked (agp_chol.h, k_chol_panel): groups of G block columns -- the G x G diagonal block by G small launches, the rows below it
 // by one panel-solve launch, everything to the right by one trailing launch per group; the part of the trailing update that the
@@ -379,7 +412,10 @@ static void dag_retry_check(agp_ctx* c) {
 template <typename T>
 static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int64_t ldx, T* Dg, T* E, int64_t lde,
                               int64_t ne, int do_x, int32_t* info_dev, int64_t nvalid, const T* erow = nullptr,
-                              bool want_l = true, const SafeSrc<T>* safe = nullptr) {
+                              bool want_l = true, const SafeSrc<T>* safe = nullptr, bool* defer_safe = nullptr) {
+  // defer_safe (in: the caller can run the fallback itself, k_safe_rowstats; out: whether it has to -- the task graph was used)
+  const bool can_defer = defer_safe && *defer_safe;
+  if (defer_safe) *defer_safe = false;
   // safe: sources the inputs can be restored from (A = -2 eta2, E = [kappa ; eta1' ; 0]): the in-stream fallback k_chol_safe is
   // then enqueued behind the task graph; without it a lost dependency surfaces as an error at the caller's next check
   // want_l = false: the caller never reads the factor L itself (only E L^-T, X, Dg): the task graph skips those stores
@@ -440,7 +476,8 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     }();
     if (safe && !do_x) {
       if (test_abort) hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, c->stream, info_dev, -1);
-      AGPCHK(launch_chol_safe<T>(c, one, *safe, 1, ld, ldx, lde, ne, nt, info_dev, nvalid));
+      if (can_defer) *defer_safe = true;
+      else AGPCHK(launch_chol_safe<T>(c, one, *safe, 1, ld, ldx, lde, ne, nt, info_dev, nvalid));
     }
     if (trace) {
       std::vector<unsigned long long> h((size_t)ntiles * 8);
@@ -1468,6 +1505,9 @@ struct Svgp : SvgpBase {
       }
       pf_valid = false;
     }
+    CholBatch<T> merged_bt{};  // single latent on the task graph: fallback + row statistics share a launch (k_safe_rowstats)
+    SafeSrc<T> merged_src{};
+    bool merged_safe = false;
     // how many problems one task-graph launch may take (0: none fits, plain launches)
     int dag_nb = 0;
     for (int q = DAG_MAX_NB; q >= 1 && !dag_nb; --q)
@@ -1530,7 +1570,8 @@ struct Svgp : SvgpBase {
       int64_t launches = 0;
       for (size_t l0 = 0; l0 < todo.size(); l0 += chunk) {
         const int nb = (int)std::min<size_t>(chunk, todo.size() - l0);
-        CholBatch<T> bt{};
+        CholBatch<T>& bt = merged_bt;
+        bt = CholBatch<T>{};
         for (int q = 0; q < nb; ++q) {
           Latent& g = lat[todo[l0 + q]];
           bt.A[q] = g.La;
@@ -1541,7 +1582,8 @@ struct Svgp : SvgpBase {
           g.la_state = 1;
           g.xa_valid = false;
         }
-        SafeSrc<T> src{};  // where the in-stream fallback of the task graph finds the inputs again
+        SafeSrc<T>& src = merged_src;  // where the in-stream fallback of the task graph finds the inputs again
+        src = SafeSrc<T>{};
         src.Bq = Bq;
         for (int q = 0; q < nb; ++q) {
           Latent& g = lat[todo[l0 + q]];
@@ -1550,8 +1592,14 @@ struct Svgp : SvgpBase {
           src.eta2[q] = g.eta2;
         }
         if (nb == 1) {  // also writes the [eta1' ; 0] block when it falls back to per-column launches
+          static const bool merge_ok = []() {  // AGP_MERGE_SAFE=0: keep k_chol_safe a launch of its own (A/B measurements)
+            const char* e = getenv("AGP_MERGE_SAFE");
+            return !(e && e[0] == '0');
+          }();
+          bool defer = nl == 1 && merge_ok;  // single latent: the row-statistics launch below carries the fallback (k_safe_rowstats)
           AGPCHK(potrf_fused<T>(ctx, bt.A[0], mp, mp, bt.X[0], mp, bt.Dg[0], bt.E[0], mp, nel, 0, info_dev, m,
-                                (const T*)lat[todo[l0]].eta1, false, &src));
+                                (const T*)lat[todo[l0]].eta1, false, &src, &defer));
+          merged_safe = defer;
           launches += dag_nb > 0 ? 1 : chol_launch_count(ntl, nel);
         } else if (dag_nb > 0) {
           AGPCHK(potrf_dag_batch<T>(ctx, bt, nb, mp, mp, mp, mp, nel, info_dev, m, &src));
@@ -1573,6 +1621,17 @@ struct Svgp : SvgpBase {
         rb.v[q] = g.Wbuf + Bq * mp;
         rb.kdiag[q] = (T)g.k.variance;
         rb.use_kt[q] = g.keep_last ? 1 : 0;
+      }
+      if (merged_safe) {  // nl == 1
+        AGPCHK(ensure_safe_words<T>(ctx));
+        const int64_t nt_ = mp / TILE, ne_ = Bq / TILE + 1;
+        const int64_t most = std::max<int64_t>(nt_ + ne_ + nt_ * (nt_ + 1) / 2 + ne_ * nt_, (B + 7) / 8);
+        const unsigned g1 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ctx->n_cu, most));
+        hipLaunchKernelGGL((k_safe_rowstats<T>), dim3(g1), dim3(CHOL_THREADS), 0, st(), merged_bt, merged_src, mp, mp, mp, ne_, nt_,
+                           info_dev, m, ctx->safe_bar, ctx->safe_retries, B, ns, rb, ldp, mp, mp, (T)jitter, (T)rho, lp, (const T*)y,
+                           idx, Kt, muf, varf, cbuf, theta, rbuf, wbuf, flags_dev, (const T*)lam_dev, gamma);
+        LAUNCHCHK(ctx);
+        continue;
       }
       const dim3 grid((unsigned)((B * 64 + 255) / 256), (unsigned)nb);
       hipLaunchKernelGGL((k_rowstats_local<T>), grid, dim3(256), 0, st(), B, ns, rb, ldp, mp, mp, (T)jitter, (T)rho, lp,

@@ -450,14 +450,14 @@ struct RowstatsBatch {
   T kdiag[ROWSTATS_MAXB];      // kernel variance (diagonal of the kernel matrix)
   int use_kt[ROWSTATS_MAXB];   // K~ kept from the previous full-batch step
 };
+// one wave's work on row i of latent q (shared by k_rowstats_local and the kernel that also carries the task graph's fallback)
 template <typename T>
-__global__ void k_rowstats_local(int64_t B, int nslices, RowstatsBatch<T> rb, int64_t ldp, int64_t ldw, int64_t cols,
-                                 T jitter, T rho, LikParams<T> lp, const T* __restrict__ y,
-                                 const int64_t* __restrict__ idx, T* __restrict__ Kt, T* __restrict__ muf,
-                                 T* __restrict__ varf, T* __restrict__ c, T* __restrict__ theta, T* __restrict__ r,
-                                 T* __restrict__ w, int64_t ostride, int* __restrict__ flags, const T* __restrict__ lam,
-                                 T* __restrict__ gamma) {
-  const int q = blockIdx.y;
+__device__ __forceinline__ void rowstats_row(int64_t i, int lane, int q, int64_t B, int nslices, const RowstatsBatch<T>& rb,
+                                             int64_t ldp, int64_t ldw, int64_t cols, T jitter, T rho, const LikParams<T>& lp,
+                                             const T* __restrict__ y, const int64_t* __restrict__ idx, T* __restrict__ Kt,
+                                             T* __restrict__ muf, T* __restrict__ varf, T* __restrict__ c,
+                                             T* __restrict__ theta, T* __restrict__ r, T* __restrict__ w, int64_t ostride,
+                                             int* __restrict__ flags, const T* __restrict__ lam, T* __restrict__ gamma) {
   const T* __restrict__ pk = rb.pk[q];
   const T* __restrict__ W = rb.W[q];
   const T* __restrict__ v = rb.v[q];
@@ -471,8 +471,6 @@ __global__ void k_rowstats_local(int64_t B, int nslices, RowstatsBatch<T> rb, in
   r += q * ostride;
   w += q * ostride;
   gamma += q * ostride;
-  const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
   if (i >= B) return;
   T s0 = T(0), s1 = T(0), sk = T(0);
   {
@@ -533,6 +531,17 @@ __global__ void k_rowstats_local(int64_t B, int nslices, RowstatsBatch<T> rb, in
   theta[i] = th;
   r[i] = rho * g1;
   w[i] = rho * th / T(2);
+}
+
+template <typename T>
+__global__ void k_rowstats_local(int64_t B, int nslices, RowstatsBatch<T> rb, int64_t ldp, int64_t ldw, int64_t cols,
+                                 T jitter, T rho, LikParams<T> lp, const T* __restrict__ y,
+                                 const int64_t* __restrict__ idx, T* __restrict__ Kt, T* __restrict__ muf,
+                                 T* __restrict__ varf, T* __restrict__ c, T* __restrict__ theta, T* __restrict__ r,
+                                 T* __restrict__ w, int64_t ostride, int* __restrict__ flags, const T* __restrict__ lam,
+                                 T* __restrict__ gamma) {
+  rowstats_row<T>(blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6), threadIdx.x & 63, (int)blockIdx.y, B, nslices, rb,
+                  ldp, ldw, cols, jitter, rho, lp, y, idx, Kt, muf, varf, c, theta, r, w, ostride, flags, lam, gamma);
 }
 
 // Poisson: lambda <- sum(y) / sum_i E_{N(mu_i, var_i)}[logistic]  (poisson.jl:78 ; expectation = Gauss-Hermite, utils.jl:16-19)

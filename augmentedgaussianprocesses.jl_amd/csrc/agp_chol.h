@@ -816,15 +816,14 @@ __device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
   __syncthreads();
 }
 
+// (a device function so that the kernel which follows the task graph in a single-latent step -- row statistics and local
+//  update -- can carry the fallback itself instead of waiting behind an extra launch: k_safe_rowstats in agp_capi.hip.
+//  Returns whether the fallback ran; every thread of every workgroup of a <= n_cu grid must call.)
 template <typename T>
-__global__ __launch_bounds__(CHOL_THREADS) void k_chol_safe(CholBatch<T> bt, SafeSrc<T> src, int nb, int64_t ld, int64_t ldx,
-                                                            int64_t lde, int64_t ne, int64_t nt,
-                                                            int32_t* __restrict__ info, int64_t nvalid,
-                                                            unsigned* __restrict__ bar, int32_t* __restrict__ retries) {
-  if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != -1) return;
-  __shared__ __attribute__((aligned(16))) T sm[3 * TILE * LDP];
-  __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
-  __shared__ T piv[TILE];
+__device__ __forceinline__ bool chol_safe_body(const CholBatch<T>& bt, const SafeSrc<T>& src, int nb, int64_t ld, int64_t ldx,
+                                               int64_t lde, int64_t ne, int64_t nt, int32_t* __restrict__ info, int64_t nvalid,
+                                               unsigned* __restrict__ bar, int32_t* __restrict__ retries, T* sm, T* sc, T* piv) {
+  if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != -1) return false;
   const unsigned nwg = gridDim.x;
   const int64_t n = nt * TILE, gsz = (int64_t)nwg * CHOL_THREADS, g0 = (int64_t)blockIdx.x * CHOL_THREADS + threadIdx.x;
   unsigned phase = 0;
@@ -859,6 +858,18 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_safe(CholBatch<T> bt, Saf
       __hip_atomic_store(bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  return true;
+}
+
+template <typename T>
+__global__ __launch_bounds__(CHOL_THREADS) void k_chol_safe(CholBatch<T> bt, SafeSrc<T> src, int nb, int64_t ld, int64_t ldx,
+                                                            int64_t lde, int64_t ne, int64_t nt,
+                                                            int32_t* __restrict__ info, int64_t nvalid,
+                                                            unsigned* __restrict__ bar, int32_t* __restrict__ retries) {
+  __shared__ __attribute__((aligned(16))) T sm[3 * TILE * LDP];
+  __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
+  __shared__ T piv[TILE];
+  (void)chol_safe_body<T>(bt, src, nb, ld, ldx, lde, ne, nt, info, nvalid, bar, retries, sm, sc, piv);
 }
 
 // ---------------------------------------------------------------------------------------------------

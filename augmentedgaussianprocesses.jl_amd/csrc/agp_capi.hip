@@ -1253,8 +1253,9 @@ struct Svgp : SvgpBase {
         if (info == -1 && attempt == 0) {  // the task graph lost a dependency: recompute K and factor with per-column launches
           if (!ctx->dag_off)
             fprintf(stderr, "[agp_hip] warning: a task-graph factorisation lost a tile dependency (is another process using this "
-                            "GPU?); re-running it with per-column launches, which this context uses from now on\n");
-          ctx->dag_off = true;
+                            "GPU?); re-running it with plain launches, which this context uses for the next %lld steps\n",
+                    (long long)ctx->dag_backoff);
+          dag_pause(ctx);
           continue;
         }
         if (info != 0) {

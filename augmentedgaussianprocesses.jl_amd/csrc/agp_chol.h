@@ -792,10 +792,11 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_trail(CholBatch<T> bt, in
 // workgroups being dispatched in index order; when that assumption breaks (a second PROCESS running its own task graph on the
 // same device is the known way) a dependency never arrives, the bounded spin gives up and latches info = -1.  This kernel is
 // enqueued right behind the task graph on the same stream: its workgroups look at the latch and return at once when all is
-// well (one empty launch per step, ~2 us); on -1 it restores the inputs from their sources (A = -2 eta2, E = [kappa ; eta1' ; 0])
+// well (one empty launch per step, ~2 us; in a single-latent step it is the prologue of the row-statistics launch instead,
+// k_safe_rowstats); on -1 it restores the inputs from their sources (A = -2 eta2, E = [kappa ; eta1' ; 0])
 // and runs the per-column algorithm (chol_step_body) for all columns in this ONE launch, separated by grid barriers.  The grid
 // is at most one workgroup per CU, so every workgroup gets a slot without any assumption about order, and the barriers cannot
-// deadlock.  The step itself never fails; `retries` counts the events so that the host can warn and stop using the task graph.
+// deadlock.  The step itself never fails; `retries` counts the events so that the host can warn and pause the task graph.
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
 struct SafeSrc {

@@ -27,6 +27,7 @@ from .likelihoods import (  # noqa: F401
     NegBinomialLikelihood,
     PoissonLikelihood,
     StudentTLikelihood,
+    loglikelihood,
 )
 from .svgp import (  # noqa: F401
     ADAM,

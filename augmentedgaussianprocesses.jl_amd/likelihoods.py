@@ -287,3 +287,60 @@ def treat_labels(y, l: AbstractLikelihood):
 def class_indices(Y_onehot: np.ndarray) -> np.ndarray:
     """0-based class index per row of a one-hot matrix (device representation of the BitMatrix)."""
     return np.argmax(Y_onehot, axis=1).astype(np.int32)
+
+
+# ---- point likelihoods p(y | f): `l(y, f)` and `loglikelihood(l, y, f)` of the reference ------------------------------------------
+# Host-side scalars, not on the device path (the CAVI step works with the augmented expectations); kept because the reference's
+# likelihood test-sets pin them (test/likelihood/gaussian.jl:9-10 and the definitions cited below).
+import math as _math
+
+
+def _logistic(x):
+    return 1.0 / (1.0 + _math.exp(-x)) if x >= 0 else _math.exp(x) / (1.0 + _math.exp(x))
+
+
+def likelihood_value(l: AbstractLikelihood, y, f) -> float:
+    """l(y, f) (for the heteroscedastic model the reference's argument order is l(f, y) with f = (f, g): pass f as a pair)."""
+    if isinstance(l, GaussianLikelihood):        # gaussian.jl:27-29: pdf(Normal(y, sqrt(sigma2)), f)
+        return _math.exp(-0.5 * (f - y) ** 2 / l.sigma2) / _math.sqrt(2.0 * _math.pi * l.sigma2)
+    if isinstance(l, LogisticLikelihood):        # classification.jl:6-8: pdf(Bernoulli(logistic(f)), y), y in {0, 1}
+        p = _logistic(f)
+        return p if y in (1, True) else (1.0 - p if y in (0, False) else 0.0)
+    if isinstance(l, BayesianSVM):               # bayesiansvm.jl:25-38: Bernoulli(pos / (pos + neg)), pseudo-likelihood exp(-2 max(1 - f, 0))
+        pos, neg = _math.exp(-2.0 * max(1.0 - f, 0.0)), _math.exp(-2.0 * max(1.0 + f, 0.0))
+        p = pos / (pos + neg)
+        return p if y in (1, True) else (1.0 - p if y in (0, False) else 0.0)
+    if isinstance(l, StudentTLikelihood):        # studentt.jl:43-46 (as written there: no 1/nu inside, no 1/sigma in front)
+        return (_math.gamma(l.alpha) / (_math.sqrt(l.nu * _math.pi) * _math.gamma(l.nu / 2.0))
+                * (1.0 + ((y - f) / l.sigma) ** 2) ** (-l.alpha))
+    if isinstance(l, LaplaceLikelihood):         # laplace.jl:36-38: pdf(Laplace(f, beta), y)
+        return _math.exp(-abs(y - f) / l.beta) / (2.0 * l.beta)
+    if isinstance(l, PoissonLikelihood):         # poisson.jl:26,34-36: pdf(Poisson(lambda logistic(f)), y)
+        mu = l.lam * _logistic(f)
+        return _math.exp(y * _math.log(mu) - mu - _math.lgamma(y + 1.0)) if y >= 0 and float(y).is_integer() else 0.0
+    if isinstance(l, NegBinomialLikelihood):     # negativebinomial.jl:29,33-35: pdf(NegativeBinomial(r, logistic(-f)), y)
+        if y < 0 or not float(y).is_integer():
+            return 0.0
+        pr = _logistic(-f)
+        return _math.exp(_math.lgamma(y + l.r) - _math.lgamma(y + 1.0) - _math.lgamma(l.r) + l.r * _math.log(pr)
+                         + y * _math.log1p(-pr))
+    if isinstance(l, HeteroscedasticLikelihood):  # heteroscedastic.jl:25,34-36: Normal(f, sqrt(1 / (lambda logistic(g)))), called l(f, y)
+        (ff, g), yy = y, f
+        var = 1.0 / (l.lam * _logistic(g))
+        return _math.exp(-0.5 * (yy - ff) ** 2 / var) / _math.sqrt(2.0 * _math.pi * var)
+    if isinstance(l, LogisticSoftMaxLikelihood):  # logisticsoftmax.jl:29-31, multiclass.jl:31-33: normalize(logistic.(f), 1)[y]
+        s = [_logistic(v) for v in f]
+        return s[int(y) - 1] / sum(s)
+    raise TypeError(f"no point likelihood for {l!r}")
+
+
+def loglikelihood(l: AbstractLikelihood, y, f) -> float:
+    """Distributions.loglikelihood(l, y, f) of the reference."""
+    if isinstance(l, LogisticLikelihood):        # logistic.jl:28-32: -log(1 + exp(-y f)) with y in {-1, 1}
+        z = -float(y) * float(f)
+        return -(z + _math.log1p(_math.exp(-z))) if z > 0 else -_math.log1p(_math.exp(z))
+    v = likelihood_value(l, y, f)
+    return _math.log(v) if v > 0 else -_math.inf
+
+
+AbstractLikelihood.__call__ = lambda self, y, f: likelihood_value(self, y, f)

@@ -40,3 +40,41 @@ def test_neutral_padding_of_the_streaming_model():
     d2 = ((pad[:, None, :] - np.vstack([Zs[1], rng.random((50, 2))])[None, :, :]) ** 2).sum(-1)
     assert np.all(np.exp(-0.5 * d2 * 0.01 ** 2) == 0.0)           # even with a lengthscale of 100
     assert np.exp(-0.5 * ((pad[0] - pad[1]) ** 2).sum() * 0.01 ** 2) == 0.0
+
+
+def test_point_likelihoods_like_the_reference_likelihood_testsets():
+    """test/likelihood/gaussian.jl:8-13 (`l(y, f) == pdf(Normal(f, sqrt(σ²)), y)`, `loglikelihood`, `repr`, `n_latent`) and the same
+    identities for the other likelihoods of the path, each against scipy.stats' density of the distribution the reference builds."""
+    import math
+
+    from scipy import stats
+
+    y, f = 0.2, 0.5
+    l = AGP.GaussianLikelihood(1e-3)
+    assert l.sigma2 == 1e-3 and l.n_latent == 1
+    assert l(y, f) == pytest.approx(stats.norm.pdf(y, f, math.sqrt(1e-3)), rel=1e-13)
+    assert AGP.loglikelihood(l, y, f) == pytest.approx(stats.norm.logpdf(y, f, math.sqrt(1e-3)), rel=1e-13)
+    assert repr(l) == "Gaussian likelihood (σ² = 0.001)"
+    sig = 1.0 / (1.0 + math.exp(-f))
+    lg = AGP.LogisticLikelihood()
+    assert lg(1, f) == pytest.approx(sig) and lg(0, f) == pytest.approx(1 - sig)
+    assert AGP.loglikelihood(lg, 1, f) == pytest.approx(math.log(sig)) and AGP.loglikelihood(lg, -1, f) == pytest.approx(math.log(1 - sig))
+    assert AGP.loglikelihood(lg, 1, -800.0) == pytest.approx(-800.0)  # no overflow
+    st = AGP.StudentTLikelihood(3.0)  # as the reference writes it (studentt.jl:43-46)
+    assert st(y, f) == pytest.approx(math.gamma(2.0) / (math.sqrt(3 * math.pi) * math.gamma(1.5)) * (1 + (y - f) ** 2) ** -2.0)
+    la = AGP.LaplaceLikelihood(3.0)
+    assert la(y, f) == pytest.approx(stats.laplace.pdf(y, f, 3.0)) and AGP.loglikelihood(la, y, f) == pytest.approx(stats.laplace.logpdf(y, f, 3.0))
+    po = AGP.PoissonLikelihood(5.0)
+    assert po(3, f) == pytest.approx(stats.poisson.pmf(3, 5.0 * sig)) and po(2.5, f) == 0.0
+    nb = AGP.NegBinomialLikelihood(10.0)
+    assert nb(4, f) == pytest.approx(stats.nbinom.pmf(4, 10.0, 1.0 - sig))  # NegativeBinomial(r, logistic(-f))
+    sv = AGP.BayesianSVM()
+    pos, neg = math.exp(-2 * max(1 - f, 0)), math.exp(-2 * max(1 + f, 0))
+    assert sv(1, f) == pytest.approx(pos / (pos + neg)) and sv(0, f) == pytest.approx(neg / (pos + neg))
+    he = AGP.HeteroscedasticLikelihood(2.0)
+    assert he((f, -1.0), y) == pytest.approx(stats.norm.pdf(y, f, math.sqrt(1.0 / (2.0 / (1.0 + math.e)))))
+    ls = AGP.LogisticSoftMaxLikelihood(3)
+    fs = [0.3, -1.0, 2.0]
+    s = [1 / (1 + math.exp(-v)) for v in fs]
+    assert [ls(k, fs) for k in (1, 2, 3)] == pytest.approx([v / sum(s) for v in s])
+    assert sum(ls(k, fs) for k in (1, 2, 3)) == pytest.approx(1.0)

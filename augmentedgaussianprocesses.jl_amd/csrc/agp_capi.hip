@@ -712,14 +712,19 @@ static int launch_kernelmatrix(agp_ctx* c, hipStream_t stream, const T* X, int64
       if (sh > asked) {                                                                                                       \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kernelmatrix_mma<T, KIND>),                                \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);                                       \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kernelmatrix_mma<T, KIND, true>),                          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kernelmatrix_mma<T, KIND, 1>),                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);                                       \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kernelmatrix_mma<T, KIND, 2>),                             \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);                                       \
         asked = sh;                                                                                                           \
       }                                                                                                                       \
     }                                                                                                                         \
     if (out == nullptr && !sym && alpha != nullptr)                                                                           \
-      hipLaunchKernelGGL((k_kernelmatrix_mma<T, KIND, true>), grid, dim3(NTHREADS), sh, stream, X, ldx, idx, n, ysc, ysn, p, \
-                         D, Dp, scales, variance, out, ldo, n_out, p_out, sym, diag_add, alpha, part, ldp, ctiles);          \
+      hipLaunchKernelGGL((k_kernelmatrix_mma<T, KIND, 1>), grid, dim3(NTHREADS), sh, stream, X, ldx, idx, n, ysc, ysn, p, D, \
+                         Dp, scales, variance, out, ldo, n_out, p_out, sym, diag_add, alpha, part, ldp, ctiles);              \
+    else if (out != nullptr && !sym && alpha == nullptr)                                                                      \
+      hipLaunchKernelGGL((k_kernelmatrix_mma<T, KIND, 2>), grid, dim3(NTHREADS), sh, stream, X, ldx, idx, n, ysc, ysn, p, D, \
+                         Dp, scales, variance, out, ldo, n_out, p_out, sym, diag_add, alpha, part, ldp, ctiles);              \
     else                                                                                                                      \
       hipLaunchKernelGGL((k_kernelmatrix_mma<T, KIND>), grid, dim3(NTHREADS), sh, stream, X, ldx, idx, n, ysc, ysn, p, D,    \
                          Dp, scales, variance, out, ldo, n_out, p_out, sym, diag_add, alpha, part, ldp, ctiles);              \

@@ -168,18 +168,20 @@ __global__ void k_scale_rows(const T* __restrict__ Y, int64_t ldy, int64_t p, in
 // copied between AGPRs and VGPRs around every k-step.  With one body and __launch_bounds__(256, 4): 128 VGPRs, MFMA on VGPRs, four
 // workgroups per CU (the LDS allows exactly that up to D = 32 in fp64) -- streaming prediction 4.8 -> 3.5 ms at C2 (a hand-written
 // exp for non-positive arguments was also tried: no different from the library's).
-// RD: row-dot only (streaming prediction: no matrix output, not symmetric) -- the store / diagonal code and its registers go.
-template <typename T, int KIND, bool RD = false>
+// SPEC 1: row-dot only (streaming prediction: no matrix output, not symmetric); SPEC 2: store only (Knm of the step: not
+// symmetric, no row-dot); SPEC 0: everything at run time.  The specialised forms drop the unused code and its registers.
+template <typename T, int KIND, int SPEC = 0>
 __global__ __launch_bounds__(NTHREADS, 4) void k_kernelmatrix_mma(const T* __restrict__ X, int64_t ldx,
                                                                const int64_t* __restrict__ idx, int64_t n,
                                                                const T* __restrict__ Ysc, const T* __restrict__ yng,
                                                                int64_t p, int64_t D, int Dp, const T* __restrict__ scales,
                                                                T variance, T* __restrict__ out_, int64_t ldo,
                                                                int64_t n_out, int64_t p_out, int sym_, T diag_add,
-                                                               const T* __restrict__ alpha, T* __restrict__ part,
+                                                               const T* __restrict__ alpha_, T* __restrict__ part,
                                                                int64_t ldp, int64_t ctiles) {
-  T* __restrict__ out = RD ? nullptr : out_;
-  const int sym = RD ? 0 : sym_;
+  T* __restrict__ out = SPEC == 1 ? nullptr : out_;
+  const int sym = SPEC != 0 ? 0 : sym_;
+  const T* __restrict__ alpha = SPEC == 2 ? nullptr : alpha_;
   extern __shared__ __attribute__((aligned(16))) unsigned char kmm_smem[];
   const int LDX = Dp + 2;  // 16 rows x {k, k+1} land on distinct banks (same stride rule as LDK in agp_device.h)
   T* Xs = reinterpret_cast<T*>(kmm_smem);  // [64][LDX]

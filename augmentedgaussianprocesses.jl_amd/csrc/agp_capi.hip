@@ -460,6 +460,10 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       hipLaunchKernelGGL((k_chol_dag<T, true, false, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1,
                          (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
                          (int)(do_x && nx == 0) | (want_l ? 2 : 0));
+    else if (fused && nx == 0 && !do_x && !want_l)  // the CAVI step's launch: specialised instantiation
+      hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1,
+                         (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
+                         0);
     else if (fused)
       hipLaunchKernelGGL((k_chol_dag<T, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0, ld,
                          ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
@@ -550,7 +554,7 @@ static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, in
   T* H = nullptr;
   const int hs = 0;
   AGPCHK(dag_handover_acquire<T>(c, hstride * nb, hs, &H));
-  hipLaunchKernelGGL((k_chol_dag<T, true, true>), dim3((unsigned)(ntiles * nb)), dim3(CHOL_THREADS), 0, c->stream, bt, nb, fstride, ld,
+  hipLaunchKernelGGL((k_chol_dag<T, true, true, false, true>), dim3((unsigned)(ntiles * nb)), dim3(CHOL_THREADS), 0, c->stream, bt, nb, fstride, ld,
                      ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, (unsigned long long*)nullptr, H, hstride,
                      (int64_t)0, (const T*)nullptr, 0);
   LAUNCHCHK(c);

@@ -1099,17 +1099,20 @@ struct ChainPrefetch {
   }
 };
 
-template <typename T, bool FUSED, bool BATCH = false, bool TRACE = false>
+// STEP: the launch of a CAVI step (no identity rows, X_k and L not wanted in their real homes) with those three facts known at
+// compile time -- the general form carries the code and the registers of all of them through the chain.
+template <typename T, bool FUSED, bool BATCH = false, bool TRACE = false, bool STEP = false>
 __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ldx,
                                                            int64_t lde, int64_t ne, int64_t nt,
                                                            int32_t* __restrict__ info, int64_t nvalid, int32_t* flags,
                                                            int32_t epoch, unsigned long long* trace, T* H, int64_t hstride,
-                                                           int64_t nx, const T* __restrict__ erow, int opts) {
+                                                           int64_t nx_, const T* __restrict__ erow, int opts) {
   // opts bit 0: the chain also stores X_k to its real home (a single block column wanting its inverse: no identity rows run)
   //      bit 1: the factor L is wanted in its real home A as well (K's factor, the potrf entry points); the CAVI step only
   //             consumes the extension rows W, v and never reads L itself, so its launches skip those stores
-  const int write_x = opts & 1;
-  const bool store_l = (opts & 2) != 0;
+  const int64_t nx = STEP ? 0 : nx_;
+  const int write_x = STEP ? 0 : (opts & 1);
+  const bool store_l = STEP ? false : (opts & 2) != 0;
   // nb > 1: nb independent problems of the same shape (the latents of a small multi-class model) in ONE launch, their
   // workgroups interleaved (linear index = tile * nb + problem) so that the chains of all problems start at once and the
   // per-XCD dispatch order stays a topological order of every graph.  Each problem has its own flags (fstride apart).  Safe

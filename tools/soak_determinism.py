@@ -8,7 +8,8 @@ import agp_amd as AGP
 from agp_amd import capi
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
-m = B = 1024
+m = B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024          # 2048 with fp32 = the C3 shape (32 block columns)
+TT = np.float32 if (len(sys.argv) > 3 and sys.argv[3] == "f32") else np.float64
 D, N = 32, 200000
 rng = np.random.default_rng(0)
 X = rng.random((N, D))
@@ -17,7 +18,7 @@ Z = X[rng.permutation(N)[:m]].copy()
 idx = np.stack([rng.choice(N, B, replace=False) for _ in range(256)])
 out = []
 for rep in range(2):
-    model = AGP.SVGP(AGP.with_lengthscale(AGP.SqExponentialKernel(), np.sqrt(D) / 4), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z, optimiser=False)
+    model = AGP.SVGP(AGP.with_lengthscale(AGP.SqExponentialKernel(), np.sqrt(D) / 4), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z, optimiser=False, T=TT)
     AGP.train_(model, X, y, 1, idx_stream=idx[:1])
     L, h = capi.lib(), model._h
     Xd, yd, _ = model._data

@@ -3670,6 +3670,12 @@ agp_status agp_dev_diag_bench(agp_ctx* ctx, int32_t dtype, int32_t variant, int3
     case 10: return bb_diag_bench<double, 5>(ctx, blocks, reps, us);
     case 12: return bb_diag_bench<double, 6>(ctx, blocks, reps, us);
     case 14: return bb_diag_bench<double, 7>(ctx, blocks, reps, us);
+    case 16: return bb_diag_bench<double, 8>(ctx, blocks, reps, us);
+    case 17: return bb_diag_bench<float, 8>(ctx, blocks, reps, us);
+    case 18: return bb_diag_bench<double, 9>(ctx, blocks, reps, us);
+    case 20: return bb_diag_bench<double, 10>(ctx, blocks, reps, us);
+    case 22: return bb_diag_bench<double, 11>(ctx, blocks, reps, us);
+    case 24: return bb_diag_bench<double, 12>(ctx, blocks, reps, us);
     default: return AGP_ERR_INVALID;
   }
 }

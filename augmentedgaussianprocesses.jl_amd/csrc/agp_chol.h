@@ -529,6 +529,223 @@ __device__ __forceinline__ void factor_diag_tile_2lvl(T* bufA, T* bufB, T* sc, T
   factor_diag_tile_2lvl<T, NoHook>(bufA, bufB, sc, piv, info, col0, nvalid, nohook);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Panel variant of the diagonal-tile factorisation (round 2): the dependent chain runs in ONE wave with the tile's rows in its
+// lanes, no LDS round trip and no barrier inside a 16-column panel.
+//   for each 16-column panel s (c0 = 16 s):
+//     wave 0, lane r = row r, a[0..15] = its entries of the panel columns.  Column j: the pivot and the entries of column j
+//       that the rank-1 update needs come out of the lanes with v_readlane (wave-uniform SGPR operands of the v_fma);
+//       a[c] -= (a[j] / d_j) * a_j(row c0 + c).  The raw column u_j (= L_j sqrt(d_j)) goes to bufA as soon as it is final,
+//       1 / d_j to rinv.
+//     barrier ; the other waves apply the panel to the remaining columns, one 16x16 MFMA tile each (k = 16) ; barrier
+//   L^-1 = D^-1/2 (U D^-1)^-1: the four 16x16 unit-triangular diagonal blocks by substitution (one wave each, a column per
+//   lane), the off-diagonal blocks by the usual two-level products on MFMA, then the scaling of L and L^-1.
+// Same arithmetic as the rounds above up to the order of the updates (LDL' without pivoting, raw pivots in piv).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lane_bcast(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float lane_bcast(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// one 16x16 result tile: acc += (neg ? -1 : 1) * sum_{k < kend} A(r, k) sa[k] B(k, c)
+//   A(r, k) = Ar[r*LDP + k] ; sa == nullptr: no scaling ; B(k, c) = NN ? Bp[k*LDP + c] : Bp[c*LDP + k] ; kend a multiple of 8
+template <typename T, bool NN>
+__device__ __forceinline__ typename Mfma<T>::acc_t mma16(const T* Ar, const T* sa, const T* Bp, int kend,
+                                                         typename Mfma<T>::acc_t acc, bool neg, int lane) {
+  const int lr = lane & 15, lk = lane >> 4;
+  typename Mfma<T>::acc_t p1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) p1[r] = T(0);
+#pragma unroll 2
+  for (int kk = 0; kk < kend; kk += 8) {
+    T a0 = Ar[lr * LDP + kk + lk], a1 = Ar[lr * LDP + kk + 4 + lk];
+    if (sa) {
+      a0 *= sa[kk + lk];
+      a1 *= sa[kk + 4 + lk];
+    }
+    if (neg) {
+      a0 = -a0;
+      a1 = -a1;
+    }
+    const T b0 = NN ? Bp[(kk + lk) * LDP + lr] : Bp[lr * LDP + kk + lk];
+    const T b1 = NN ? Bp[(kk + 4 + lk) * LDP + lr] : Bp[lr * LDP + kk + 4 + lk];
+    acc = Mfma<T>::mma(a0, b0, acc);
+    p1 = Mfma<T>::mma(a1, b1, p1);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] += p1[r];
+  return acc;
+}
+
+template <typename T>
+__device__ __forceinline__ typename Mfma<T>::acc_t acc_load16(const T* P, int lane) {
+  typename Mfma<T>::acc_t acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = P[Mfma<T>::row(lane, r) * LDP + (lane & 15)];
+  return acc;
+}
+template <typename T>
+__device__ __forceinline__ void acc_store16(T* P, typename Mfma<T>::acc_t acc, int lane) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) P[Mfma<T>::row(lane, r) * LDP + (lane & 15)] = acc[r];
+}
+
+// sc layout of this variant: rinv[64] | rs[64]
+template <typename T, typename H, int CUT = 0>
+__device__ __forceinline__ void factor_diag_tile_panel(T* bufA, T* bufB, T* sc, T* piv, int32_t* info, int64_t col0,
+                                                       int64_t nvalid, H& hook) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  T* rinv = sc;
+  T* rs = sc + TILE;
+  typedef typename Mfma<T>::acc_t acc_t;
+#pragma unroll 1
+  for (int s = 0; s < 4; ++s) {
+    const int c0 = 16 * s;
+    if (wave == 0 && CUT != 2) {
+      // no masks anywhere: rows above the pivot and the upper triangle of the diagonal block carry garbage that nothing
+      // reads (the lanes read below are those of rows >= c0 + j ; the final scaling selects the lower triangle)
+      T a[16], dv[16], rv[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = bufA[lane * LDP + c0 + c];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const T d = lane_bcast(a[j], c0 + j);
+        const T r = rcp1(d);
+        const T l = a[j] * r;
+        bufA[lane * LDP + c0 + j] = a[j];
+        dv[j] = d;
+        rv[j] = r;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) a[c] = fma(-l, lane_bcast(a[j], c0 + c), a[c]);
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          piv[c0 + j] = dv[j];
+          rinv[c0 + j] = rv[j];
+        }
+      }
+    }
+    __syncthreads();
+    hook(2 * s);
+    if (s == 3) break;
+    {  // trailing tiles (tr, tc), s < tc <= tr <= 3, next panel's first
+      const int nrem = 3 - s;  // remaining 16-blocks
+      const int ntile = nrem * (nrem + 1) / 2;
+      if (wave < ntile) {
+        int tc = s + 1, tr = s + 1 + wave;  // column-major order over the lower triangle
+        if (tr > 3) {
+          int w = wave - nrem;
+          tc = s + 2;
+          tr = s + 2 + w;
+          if (tr > 3) {
+            tc = s + 3;
+            tr = 3;
+          }
+        }
+        T* Ct = bufA + (tr * 16) * LDP + tc * 16;
+        acc_t acc = acc_load16<T>(Ct, lane);
+        acc = mma16<T, false>(bufA + (tr * 16) * LDP + c0, rinv + c0, bufA + (tc * 16) * LDP + c0, 16, acc, true, lane);
+        acc_store16<T>(Ct, acc, lane);
+      }
+    }
+    __syncthreads();
+    hook(2 * s + 1);
+  }
+  if (CUT == 1 || CUT == 2) return;  // timing experiments: panels + trailing updates only / without the eliminations
+  // ---- inverse of the unit-triangular factor U D^-1: diagonal 16x16 blocks by substitution, column lane & 15 per lane ----
+  if (wave < 4) {
+    const int o = 16 * wave, c = lane & 15;
+    T m[16], w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      T acc = (i == c) ? T(1) : T(0);
+#pragma unroll
+      for (int k = 0; k < i; ++k) acc = fma(-bufA[(o + i) * LDP + o + k], w[k], acc);
+      m[i] = acc;
+      w[i] = acc * rinv[o + i];
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bufB[(o + i) * LDP + o + c] = m[i];
+    }
+  } else {
+    // blocks (0,1) and (2,3) of the inverse are read as zeros by the 32-level products ; rs = 1 / sqrt(pivot)
+    const int t = tid - 256;
+    for (int e = t; e < 2 * 256; e += 256) {
+      const int b = e >> 8, r = (e >> 4) & 15, cc = e & 15;
+      bufB[(32 * b + r) * LDP + 32 * b + 16 + cc] = T(0);
+    }
+    if (t < TILE) {
+      const T pv = piv[t];
+      rs[t] = rsqrt1(pv > T(0) ? pv : T(1));
+    }
+  }
+  __syncthreads();
+  hook(7);
+  if (CUT == 3) return;  // timing experiment: up to the substitutions
+  // M_10 = -M_11 (L1_10 M_00), M_32 = -M_33 (L1_32 M_22) ; Q in the upper-right corner of bufB (scratch)
+  acc_t acc;
+  if (wave < 2) {
+    const int o = 32 * wave;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = T(0);
+    acc = mma16<T, true>(bufA + (o + 16) * LDP + o, rinv + o, bufB + o * LDP + o, 16, acc, false, lane);
+    acc_store16<T>(bufB + 32 + 16 * wave, acc, lane);
+  }
+  __syncthreads();
+  if (wave < 2) {
+    const int o = 32 * wave;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = T(0);
+    acc = mma16<T, true>(bufB + (o + 16) * LDP + o + 16, (const T*)nullptr, bufB + 32 + 16 * wave, 16, acc, true, lane);
+    acc_store16<T>(bufB + (o + 16) * LDP + o, acc, lane);
+  }
+  __syncthreads();
+  // P = L1_[2:4][0:2] M_[0:2][0:2] -> bufB[0:32, 32:64] ; M_[2:4][0:2] = -M_[2:4][2:4] P
+  const int wr = (wave >> 1) & 1, wc = wave & 1;
+  if (wave < 4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = T(0);
+    acc = mma16<T, true>(bufA + (32 + 16 * wr) * LDP, rinv, bufB + 16 * wc, 32, acc, false, lane);
+    acc_store16<T>(bufB + (16 * wr) * LDP + 32 + 16 * wc, acc, lane);
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = T(0);
+    acc = mma16<T, true>(bufB + (32 + 16 * wr) * LDP + 32, (const T*)nullptr, bufB + 32 + 16 * wc, 32, acc, true, lane);
+    acc_store16<T>(bufB + (32 + 16 * wr) * LDP + 16 * wc, acc, lane);
+  }
+  __syncthreads();
+  if (CUT == 4) return;  // timing experiment: without the final scaling
+  // scaling: L = U D^-1/2 (columns), L^-1 = D^-1/2 M (rows) ; strict upper parts zero ; bad pivots
+  for (int e = tid; e < TILE * TILE; e += CHOL_THREADS) {
+    const int R = e >> 6, Cc = e & 63;
+    const bool low = R >= Cc;
+    bufA[R * LDP + Cc] = low ? bufA[R * LDP + Cc] * rs[Cc] : T(0);
+    bufB[R * LDP + Cc] = low ? bufB[R * LDP + Cc] * rs[R] : T(0);
+  }
+  if (tid < TILE) {
+    const T p = piv[tid];
+    const bool bad = !(p > T(0)) && (col0 + tid) < nvalid;
+    const unsigned long long mask = __ballot(bad);
+    if (mask != 0ull && tid == 0) {
+      int32_t want = (int32_t)(col0 + (__ffsll((long long)mask) - 1) + 1);
+      int32_t old = atomicCAS(info, 0, want);
+      while (old != 0 && old > want) {
+        int32_t prev = atomicCAS(info, old, want);
+        if (prev == old) break;
+        old = prev;
+      }
+    }
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ void tri_index(int64_t idx, int64_t& ti, int64_t& tj) {
   // idx = ti*(ti+1)/2 + tj, tj <= ti
   int64_t t = (int64_t)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
@@ -1437,6 +1654,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_diag_bench(const T* __restrict
     else if (VAR == 4) factor_diag_tile_2lvl<T, NoHook, 3>(bufA, bufB, sc, piv, info, 0, 64, nh);
     else if (VAR == 5) factor_diag_tile_2lvl<T, NoHook, 4>(bufA, bufB, sc, piv, info, 0, 64, nh);
     else if (VAR == 6) factor_diag_tile_2lvl<T, NoHook, 5>(bufA, bufB, sc, piv, info, 0, 64, nh);
+    else if (VAR == 8) factor_diag_tile_panel<T, NoHook>(bufA, bufB, sc, piv, info, 0, 64, nh);
+    else if (VAR >= 9 && VAR <= 12) factor_diag_tile_panel<T, NoHook, VAR - 8>(bufA, bufB, sc, piv, info, 0, 64, nh);
     else {  // VAR 7: the harness alone (tile reload + barrier)
     }
   }

@@ -409,10 +409,18 @@ static void dag_retry_check(agp_ctx* c) {
   }
 }
 
+// what a CAVI step hands to its factorisation about the look-ahead stream (see DagSync, agp_chol.h)
+struct StepSync {
+  DagSync ds{};
+  bool used = false;  // out: the task-graph launch took `ds`
+};
+
 template <typename T>
 static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int64_t ldx, T* Dg, T* E, int64_t lde,
                               int64_t ne, int do_x, int32_t* info_dev, int64_t nvalid, const T* erow = nullptr,
-                              bool want_l = true, const SafeSrc<T>* safe = nullptr, bool* defer_safe = nullptr) {
+                              bool want_l = true, const SafeSrc<T>* safe = nullptr, bool* defer_safe = nullptr,
+                              StepSync* ssync = nullptr) {
+  // ssync (CAVI step next to a look-ahead stream): the step's task-graph instantiation stores its `started` number (`used` is set)
   // defer_safe (in: the caller can run the fallback itself, k_safe_rowstats; out: whether it has to -- the task graph was used)
   const bool can_defer = defer_safe && *defer_safe;
   if (defer_safe) *defer_safe = false;
@@ -451,6 +459,14 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       const char* e = getenv("AGP_CHOL_DAG_FUSED");
       return !(e && e[0] == '0');
     }();
+    const bool step_inst = fused && !trace && nx == 0 && !do_x && !want_l;
+    DagSync ds{};
+    if (ssync) {
+      if (step_inst) {
+        ds = ssync->ds;
+        ssync->used = true;
+      }
+    }
     CholBatch<T> one{};
     one.A[0] = A;
     one.X[0] = X;
@@ -459,19 +475,19 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     if (fused && trace)
       hipLaunchKernelGGL((k_chol_dag<T, true, false, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1,
                          (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
-                         (int)(do_x && nx == 0) | (want_l ? 2 : 0));
-    else if (fused && nx == 0 && !do_x && !want_l)  // the CAVI step's launch: specialised instantiation
+                         (int)(do_x && nx == 0) | (want_l ? 2 : 0), DagSync{});
+    else if (step_inst)  // the CAVI step's launch: specialised instantiation
       hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1,
                          (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
-                         0);
+                         0, ds);
     else if (fused)
       hipLaunchKernelGGL((k_chol_dag<T, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0, ld,
                          ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
-                         (int)(do_x && nx == 0) | (want_l ? 2 : 0));
+                         (int)(do_x && nx == 0) | (want_l ? 2 : 0), DagSync{});
     else
       hipLaunchKernelGGL((k_chol_dag<T, false>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0, ld,
                          ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
-                         (int)(do_x && nx == 0) | (want_l ? 2 : 0));
+                         (int)(do_x && nx == 0) | (want_l ? 2 : 0), DagSync{});
     LAUNCHCHK(c);
     AGPCHK(dag_handover_release<T>(c, (3 * nt + (nt + ne + nx) * nt) * TILE * TILE, hstride, 1, hs));
     static const bool test_abort = []() {  // test hook: pretend every task-graph launch of a CAVI step lost a dependency
@@ -556,7 +572,7 @@ static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, in
   AGPCHK(dag_handover_acquire<T>(c, hstride * nb, hs, &H));
   hipLaunchKernelGGL((k_chol_dag<T, true, true, false, true>), dim3((unsigned)(ntiles * nb)), dim3(CHOL_THREADS), 0, c->stream, bt, nb, fstride, ld,
                      ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, (unsigned long long*)nullptr, H, hstride,
-                     (int64_t)0, (const T*)nullptr, 0);
+                     (int64_t)0, (const T*)nullptr, 0, DagSync{});
   LAUNCHCHK(c);
   AGPCHK(dag_handover_release<T>(c, (3 * nt + (nt + ne) * nt) * TILE * TILE, hstride, nb, hs));
   if (safe) {
@@ -755,6 +771,7 @@ struct KernelHost {
 struct SvgpBase {
   agp_ctx* ctx = nullptr;
   agp_svgp_desc desc{};
+  bool in_fused_step = false;  // inside agp_svgp_cavi_step (local + statistics + global update in one call)
   virtual ~SvgpBase() {}
   virtual agp_status init() = 0;
   virtual agp_status set_kernel(int l, const agp_kernel_desc* k) = 0;
@@ -965,6 +982,16 @@ struct Svgp : SvgpBase {
   hipEvent_t pf_done = nullptr, step_done[2] = {nullptr, nullptr};
   int step_parity = 0;
   bool pf_valid = false;
+  // hand-over word with the look-ahead stream (DagSync): sig[0] = "started" (written by the step's task graph).  The release of
+  // a step's kappa buffers -- what the NEXT look-ahead but one waits for -- is either an event recorded on the stream
+  // (slot_kind 0) or, when the step after it starts with a task graph that stores its `started` number, that number (slot_kind
+  // 1: nothing is enqueued on the stream).  Which one is only known when the next step is enqueued, hence rel_pending.
+  int32_t* sig[1] = {nullptr};
+  int sig_state = 0;  // 0 not tried, 1 usable, -1 not available / switched off (AGP_PF_INKERNEL=0)
+  int32_t started_seq = 0;
+  bool rel_pending = false;
+  int rel_slot = 0, slot_kind[2] = {0, 0};
+  int32_t slot_seq[2] = {0, 0};
   const void* pf_x = nullptr;
   const int64_t* pf_idx = nullptr;
   int64_t pf_B = 0, pf_ldx = 0;
@@ -1123,7 +1150,15 @@ struct Svgp : SvgpBase {
       for (T* p : ps)
         if (p) dfree(p);
     }
+    if (pf_stream && sig[0]) {
+      // a look-ahead still waiting for a step that was never launched must not outlive the handle
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipMemcpy(sig[0], &started_seq, sizeof(int32_t), hipMemcpyHostToDevice);
+      (void)hipStreamSynchronize(pf_stream);
+    }
     if (pf_stream) dcheck(hipStreamDestroy(pf_stream), __LINE__);
+    for (auto q : sig)
+      if (q) dcheck(hipFree(q), __LINE__);
     if (pf_done) dcheck(hipEventDestroy(pf_done), __LINE__);
     for (auto e : step_done)
       if (e) dcheck(hipEventDestroy(e), __LINE__);
@@ -1511,6 +1546,25 @@ struct Svgp : SvgpBase {
     const int ns = (int)(2 * mp / TILE);
     const bool reuse = !desc.stochastic && !fresh && x == x_last && idx == idx_last && B == B_last && ldx == ldx_last;
     const bool prefetched = pf_valid && !fresh && x == pf_x && idx == pf_idx && B == pf_B && ldx == pf_ldx;
+    // how many problems one task-graph launch may take (0: none fits, plain launches)
+    int dag_nb = 0;
+    for (int q = DAG_MAX_NB; q >= 1 && !dag_nb; --q)
+      if (chol_use_dag(ctx, mp / TILE, Bq / TILE + 1, q)) dag_nb = q;
+    // single latent on the task graph inside agp_svgp_cavi_step: the launch itself tells the look-ahead stream that the step
+    // before has released its kappa buffers (DagSync) -- no event record on this stream
+    StepSync ssync{};
+    const bool sync_step = sig_state == 1 && in_fused_step && !fresh && nl == 1 && dag_nb > 0 &&
+                           !(lat[0].la_state == 1 && lat[0].xa_valid);
+    if (sync_step) {
+      ssync.ds.started = sig[0];
+      ssync.ds.seq = started_seq + 1;
+    } else if (rel_pending) {
+      // the release of the previous step's kappa buffers becomes an event here, before anything of this step is enqueued (the
+      // look-ahead waiting for it is meant to run next to this step's factorisation)
+      slot_kind[rel_slot] = 0;
+      HIPCHK(ctx, hipEventRecord(step_done[rel_slot], st()));
+      rel_pending = false;
+    }
     if (prefetched) {  // kappa of this minibatch was produced on the prefetch stream: adopt those buffers
       HIPCHK(ctx, hipStreamWaitEvent(st(), pf_done, 0));
       for (auto& g : lat) {
@@ -1524,10 +1578,6 @@ struct Svgp : SvgpBase {
     CholBatch<T> merged_bt{};  // single latent on the task graph: fallback + row statistics share a launch (k_safe_rowstats)
     SafeSrc<T> merged_src{};
     bool merged_safe = false;
-    // how many problems one task-graph launch may take (0: none fits, plain launches)
-    int dag_nb = 0;
-    for (int q = DAG_MAX_NB; q >= 1 && !dag_nb; --q)
-      if (chol_use_dag(ctx, mp / TILE, Bq / TILE + 1, q)) dag_nb = q;
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
       const bool keep = reuse && g.kappa_valid;
@@ -1614,7 +1664,7 @@ struct Svgp : SvgpBase {
           }();
           bool defer = nl == 1 && merge_ok;  // single latent: the row-statistics launch below carries the fallback (k_safe_rowstats)
           AGPCHK(potrf_fused<T>(ctx, bt.A[0], mp, mp, bt.X[0], mp, bt.Dg[0], bt.E[0], mp, nel, 0, info_dev, m,
-                                (const T*)lat[todo[l0]].eta1, false, &src, &defer));
+                                (const T*)lat[todo[l0]].eta1, false, &src, &defer, sync_step ? &ssync : nullptr));
           merged_safe = defer;
           launches += dag_nb > 0 ? 1 : chol_launch_count(ntl, nel);
         } else if (dag_nb > 0) {
@@ -1626,6 +1676,13 @@ struct Svgp : SvgpBase {
         }
       }
       if (!todo.empty()) AGPCHK(timing_end(launches));
+    }
+    if (ssync.used) started_seq = ssync.ds.seq;
+    if (rel_pending) {  // the release of the previous step's kappa buffers: this step's `started` number, or an event now
+      slot_kind[rel_slot] = ssync.used ? 1 : 0;
+      slot_seq[rel_slot] = ssync.ds.seq;
+      if (!ssync.used) HIPCHK(ctx, hipEventRecord(step_done[rel_slot], st()));
+      rel_pending = false;
     }
     for (int l0 = 0; l0 < nl; l0 += ROWSTATS_MAXB) {  // row statistics + local update of all latents in one launch
       const int nb = std::min(ROWSTATS_MAXB, nl - l0);
@@ -2220,6 +2277,23 @@ struct Svgp : SvgpBase {
       for (auto& e : step_done) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
       HIPCHK(ctx, hipEventRecord(step_done[0], st()));
       HIPCHK(ctx, hipEventRecord(step_done[1], st()));
+      {
+        // hand-over word (AGP_PF_INKERNEL=0 keeps the event)
+        const char* e = getenv("AGP_PF_INKERNEL");
+        sig_state = -1;
+        if (!(e && e[0] == '0')) {
+          bool ok = true;
+          for (auto& q : sig)
+            ok = ok && hipExtMallocWithFlags((void**)&q, 8, hipMallocSignalMemory) == hipSuccess && hipMemset(q, 0, 8) == hipSuccess;
+          if (ok) sig_state = 1;
+          else
+            for (auto& q : sig) {
+              if (q) (void)hipFree(q);
+              q = nullptr;
+            }
+        }
+        (void)hipGetLastError();
+      }
       for (auto& g : lat) {
         AGPCHK(dmalloc(ctx, &g.Knm_alt, Bp * mp));
         AGPCHK(dmalloc(ctx, &g.kappa_alt, Bp * mp));
@@ -2228,7 +2302,11 @@ struct Svgp : SvgpBase {
       }
     }
     // the alternate buffers were "current" in the step before the last enqueued one
-    HIPCHK(ctx, hipStreamWaitEvent(pf_stream, step_done[step_parity], 0));
+    if (slot_kind[step_parity] == 1) {
+      hipLaunchKernelGGL(k_wait_ge, dim3(1), dim3(64), 0, pf_stream, (const int32_t*)sig[0], slot_seq[step_parity], info_dev);
+      LAUNCHCHK(ctx);
+    } else
+      HIPCHK(ctx, hipStreamWaitEvent(pf_stream, step_done[step_parity], 0));
     const int64_t Bq = rup64(B);
     hipStream_t keep_stream = ctx->stream;
     ctx->stream = pf_stream;  // reuse the launch helpers on the prefetch stream
@@ -2418,8 +2496,19 @@ struct Svgp : SvgpBase {
   // path -- right after the packed statistics, so that the next look-ahead does not wait for the all-reduce and the eta step
   agp_status kappa_released() {
     if (pf_stream) {
+      if (rel_pending) {  // (two releases without a step in between: cannot happen through the ABI's step sequence, but be safe)
+        slot_kind[rel_slot] = 0;
+        HIPCHK(ctx, hipEventRecord(step_done[rel_slot], st()));
+        rel_pending = false;
+      }
       step_parity ^= 1;
-      HIPCHK(ctx, hipEventRecord(step_done[step_parity ^ 1], st()));
+      if (sig_state == 1 && in_fused_step) {  // decided when the next step is enqueued (step_local)
+        rel_pending = true;
+        rel_slot = step_parity ^ 1;
+      } else {
+        slot_kind[step_parity ^ 1] = 0;
+        HIPCHK(ctx, hipEventRecord(step_done[step_parity ^ 1], st()));
+      }
     }
     return AGP_OK;
   }
@@ -3750,6 +3839,11 @@ agp_status agp_svgp_cavi_step(agp_svgp* h, const void* x, int64_t ldx, const voi
                               double rho) {
   HCHK(h);
   SvgpBase* s = h->impl;
+  struct Scope {
+    SvgpBase* s;
+    ~Scope() { s->in_fused_step = false; }
+  } scope{s};
+  s->in_fused_step = true;
   AGPCHK(s->step_local(x, ldx, y, idx, B, rho, false));
   if (s->desc.lik.kind == AGP_LIK_LOGISTICSOFTMAX) {
     for (int it = 0; it < 2; ++it) {  // logisticsoftmax.jl:65

@@ -1219,6 +1219,31 @@ __device__ __forceinline__ bool dag_wait(const int32_t* f0, const int32_t* f1, i
   return *lds_ok != 0;
 }
 
+// Hand-over from the CAVI step's task-graph launch to the look-ahead stream through a word in signal memory instead of an event
+// record on the step's own stream (which costs the in-order queue ~10 us per step): the chain workgroup stores `seq` as soon
+// as the launch runs -- everything enqueued before it is complete by then, so the look-ahead stream (k_wait_ge) may overwrite
+// the kappa buffers of the step before.  (The other direction stays a stream-level wait: letting the extension-row workgroups
+// poll for the look-ahead's kappa themselves saves 3 more us but can fill every CU with pollers while the look-ahead's GEMM
+// still needs one -- seen once in ~20 000 steps as a spin-limit abort)
+struct DagSync {
+  int32_t* started = nullptr;
+  int32_t seq = 0;
+};
+
+// the look-ahead stream's side: one wave polls `started` at a leisurely rate (hipStreamWaitValue32's polling kernel slowed the
+// task graph next to it when the wait was long: C3, 450 us).  The launch it waits for is always enqueued already.
+__global__ void k_wait_ge(const int32_t* __restrict__ p, int32_t want, int32_t* __restrict__ info) {
+  if (threadIdx.x != 0) return;
+  long spins = 0;
+  while ((int32_t)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+    __builtin_amdgcn_s_sleep(127);
+    if (++spins > (1L << 24)) {  // about a minute: the step this waits for never ran
+      atomicExch(info, -2);
+      break;
+    }
+  }
+}
+
 // every thread's hand-over stores acknowledged by the L2 -> barrier -> flag
 __device__ __forceinline__ void dag_signal(int32_t* flag, int32_t epoch) {
   // the flag is a hint (see "self-validating hand-over"): waiting for the L2's acknowledgement of the stores just makes it a
@@ -1323,7 +1348,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
                                                            int64_t lde, int64_t ne, int64_t nt,
                                                            int32_t* __restrict__ info, int64_t nvalid, int32_t* flags,
                                                            int32_t epoch, unsigned long long* trace, T* H, int64_t hstride,
-                                                           int64_t nx_, const T* __restrict__ erow, int opts) {
+                                                           int64_t nx_, const T* __restrict__ erow, int opts, DagSync sync) {
   // opts bit 0: the chain also stores X_k to its real home (a single block column wanting its inverse: no identity rows run)
   //      bit 1: the factor L is wanted in its real home A as well (K's factor, the potrf entry points); the CAVI step only
   //             consumes the extension rows W, v and never reads L itself, so its launches skip those stores
@@ -1382,6 +1407,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
 #define DAG_TRC(col, slot) \
   if (TRACE && tid == 0) trace[chain_slot(col, nt, ne, nx) * 8 + (slot)] = wall_clock64()
   DAG_TR(0);
+  if (STEP && !BATCH && sync.started && bidx == 0 && tid == 0)
+    __hip_atomic_store(sync.started, sync.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   Acc8<T> acc;
   if (idr) {
     const bool on_diag = (R - nt - ne) == c;

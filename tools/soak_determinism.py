@@ -30,7 +30,9 @@ for rep in range(2):
     model._chk(L.agp_svgp_check_status(h))
     mu, Sig, e1, e2 = model.get_state(0)
     out.append((e1.copy(), e2.copy(), mu.copy()))
-    print(f"run {rep}: {steps} steps, |eta1| = {np.linalg.norm(e1):.6e}, finite = {np.isfinite(e2).all()}")
+    import hashlib
+    print(f"run {rep}: {steps} steps, |eta1| = {np.linalg.norm(e1):.6e}, finite = {np.isfinite(e2).all()}, "
+          f"sha1(eta2) = {hashlib.sha1(np.ascontiguousarray(e2).tobytes()).hexdigest()[:16]}")
 same = all(np.array_equal(a, b) for a, b in zip(out[0], out[1]))
 print("bitwise identical:", same, " max |d eta2| =", np.max(np.abs(out[0][1] - out[1][1])))
 sys.exit(0 if same else 1)

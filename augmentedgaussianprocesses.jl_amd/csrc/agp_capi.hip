@@ -771,7 +771,6 @@ struct KernelHost {
 struct SvgpBase {
   agp_ctx* ctx = nullptr;
   agp_svgp_desc desc{};
-  bool in_fused_step = false;  // inside agp_svgp_cavi_step (local + statistics + global update in one call)
   virtual ~SvgpBase() {}
   virtual agp_status init() = 0;
   virtual agp_status set_kernel(int l, const agp_kernel_desc* k) = 0;
@@ -1550,10 +1549,10 @@ struct Svgp : SvgpBase {
     int dag_nb = 0;
     for (int q = DAG_MAX_NB; q >= 1 && !dag_nb; --q)
       if (chol_use_dag(ctx, mp / TILE, Bq / TILE + 1, q)) dag_nb = q;
-    // single latent on the task graph inside agp_svgp_cavi_step: the launch itself tells the look-ahead stream that the step
+    // single latent on the task graph: the launch itself tells the look-ahead stream that the step
     // before has released its kappa buffers (DagSync) -- no event record on this stream
     StepSync ssync{};
-    const bool sync_step = sig_state == 1 && in_fused_step && !fresh && nl == 1 && dag_nb > 0 &&
+    const bool sync_step = sig_state == 1 && !fresh && nl == 1 && dag_nb > 0 &&
                            !(lat[0].la_state == 1 && lat[0].xa_valid);
     if (sync_step) {
       ssync.ds.started = sig[0];
@@ -2502,7 +2501,7 @@ struct Svgp : SvgpBase {
         rel_pending = false;
       }
       step_parity ^= 1;
-      if (sig_state == 1 && in_fused_step) {  // decided when the next step is enqueued (step_local)
+      if (sig_state == 1 && nl == 1) {  // decided when the next step is enqueued (step_local)
         rel_pending = true;
         rel_slot = step_parity ^ 1;
       } else {
@@ -3839,11 +3838,6 @@ agp_status agp_svgp_cavi_step(agp_svgp* h, const void* x, int64_t ldx, const voi
                               double rho) {
   HCHK(h);
   SvgpBase* s = h->impl;
-  struct Scope {
-    SvgpBase* s;
-    ~Scope() { s->in_fused_step = false; }
-  } scope{s};
-  s->in_fused_step = true;
   AGPCHK(s->step_local(x, ldx, y, idx, B, rho, false));
   if (s->desc.lik.kind == AGP_LIK_LOGISTICSOFTMAX) {
     for (int it = 0; it < 2; ++it) {  // logisticsoftmax.jl:65

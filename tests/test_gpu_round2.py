@@ -509,3 +509,50 @@ def test_task_graph_is_tried_again_after_a_pause(mods):
     mr = R.SVGP(R.Kernel("sqexponential", 2.0, 1.5), R.LogisticLikelihood(), Z, stochastic=True, batchsize=128)
     mr.train(X, y, len(idx), idx_stream=idx)
     assert _rel(eta2, mr.latents[0].eta2) < 1e-7
+
+
+def test_lookahead_handover_word_equals_event_protocol(mods):
+    """The CAVI step's task graph tells the look-ahead stream through a word in signal memory that the previous step has released
+    its kappa buffers (DagSync, agp_chol.h) instead of recording an event on the step's stream.  Ordering only: the trajectory
+    must be bitwise the one of the event protocol (AGP_PF_INKERNEL=0, read when a handle creates its look-ahead stream), through
+    the fused step (train_) and through the phase API (step_local / step_stats / step_global with a prefetch in between)."""
+    AGP, R, capi, torch = mods
+    rng = np.random.default_rng(11)
+    N, D, m, B, it = 4000, 4, 256, 256, 60
+    X = rng.random((N, D))
+    y = np.sign(np.sin(X @ rng.standard_normal(D)) + 0.1 * rng.standard_normal(N))
+    Z = X[rng.permutation(N)[:m]].copy()
+    idx = [rng.choice(N, B, replace=False) for _ in range(it)]
+    L = capi.lib()
+
+    def run(word, phases):
+        os.environ["AGP_PF_INKERNEL"] = "1" if word else "0"
+        try:
+            ma = AGP.SVGP(AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z,
+                          optimiser=False)
+            AGP.train_(ma, X, y, 1, idx_stream=idx[:1])  # creates the handle and uploads the data
+            if not phases:
+                AGP.train_(ma, X, y, it - 1, idx_stream=idx[1:], state=True)
+            else:
+                h = ma._h
+                Xd, yd, _ = ma._data
+                ia = torch.as_tensor(np.stack(idx), device="cuda")
+                xp, yp, ld = C.c_void_p(Xd.data_ptr()), C.c_void_p(yd.data_ptr()), Xd.stride(0)
+                for i in range(1, it):
+                    ip = C.c_void_p(ia[i].data_ptr())
+                    assert L.agp_svgp_step_local(h, xp, ld, yp, ip, B, N / B) == 0
+                    assert L.agp_svgp_step_stats(h) == 0
+                    if i + 1 < it:  # the look-ahead between the statistics and the global step, as the batch-parallel driver does
+                        assert L.agp_svgp_prefetch(h, xp, ld, C.c_void_p(ia[i + 1].data_ptr()), B) == 0
+                    assert L.agp_svgp_step_global(h) == 0
+                ma._chk(L.agp_svgp_check_status(h))
+            return ma.get_state(0)
+        finally:
+            del os.environ["AGP_PF_INKERNEL"]
+
+    for phases in (False, True):
+        a, b = run(True, phases), run(False, phases)
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v), phases
+    # and the fused and the phase-split sequences agree with each other to rounding
+    assert _rel(run(True, False)[3], run(True, True)[3]) < 1e-10

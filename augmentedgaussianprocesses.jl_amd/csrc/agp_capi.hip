@@ -2284,6 +2284,20 @@ struct Svgp : SvgpBase {
           bool ok = true;
           for (auto& q : sig)
             ok = ok && hipExtMallocWithFlags((void**)&q, 8, hipMallocSignalMemory) == hipSuccess && hipMemset(q, 0, 8) == hipSuccess;
+          if (ok) {
+            // both streams must be able to run kernels at the same time (k_handshake, agp_chol.h)
+            int32_t* hs = nullptr;
+            ok = hipMalloc((void**)&hs, 4 * sizeof(int32_t)) == hipSuccess && hipMemset(hs, 0, 4 * sizeof(int32_t)) == hipSuccess;
+            if (ok) {
+              (void)hipStreamSynchronize(st());
+              hipLaunchKernelGGL(k_handshake, dim3(1), dim3(64), 0, pf_stream, hs, (const int32_t*)(hs + 1), hs + 2);
+              hipLaunchKernelGGL(k_handshake, dim3(1), dim3(64), 0, st(), hs + 1, (const int32_t*)hs, hs + 3);
+              int32_t res[4] = {0, 0, 0, 0};
+              ok = hipStreamSynchronize(pf_stream) == hipSuccess && hipStreamSynchronize(st()) == hipSuccess &&
+                   hipMemcpy(res, hs, sizeof(res), hipMemcpyDeviceToHost) == hipSuccess && res[2] == 1 && res[3] == 1;
+            }
+            if (hs) (void)hipFree(hs);
+          }
           if (ok) sig_state = 1;
           else
             for (auto& q : sig) {

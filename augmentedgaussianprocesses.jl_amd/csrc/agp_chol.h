@@ -1230,6 +1230,20 @@ struct DagSync {
   int32_t seq = 0;
 };
 
+// Self-test for the hand-over below, run once per handle on the two streams at the same time: each side raises its own word
+// and waits (bounded, ~2 ms) for the other's.  Both succeed only if kernels of the two streams really are in flight together;
+// where dispatches are serialised (counter collection by rocprofv3 --pmc, AMD_SERIALIZE_KERNEL, a single hardware queue) the
+// one that runs first times out -- and a polling kernel on one stream could then keep the launch it waits for on the other
+// from ever starting, so such a handle keeps the events.
+__global__ void k_handshake(int32_t* mine, const int32_t* theirs, int32_t* ok) {
+  if (threadIdx.x != 0) return;
+  __hip_atomic_store(mine, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  long spins = 0;
+  int seen = 0;
+  while (!(seen = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) && ++spins < 4000) __builtin_amdgcn_s_sleep(16);
+  *ok = seen;
+}
+
 // the look-ahead stream's side: one wave polls `started` at a leisurely rate (hipStreamWaitValue32's polling kernel slowed the
 // task graph next to it when the wait was long: C3, 450 us).  The launch it waits for is always enqueued already.
 __global__ void k_wait_ge(const int32_t* __restrict__ p, int32_t want, int32_t* __restrict__ info) {

@@ -316,7 +316,7 @@ def main():
     model._chk(L.agp_svgp_check_status(h))
     # HIP events around the dominant kernel sequence of every 4th step (every step at c5): bracketing every step costs the C2
     # step 16 us (0.375 -> 0.391 ms), every 4th 4 us
-    t_every = 1 if a.config == "c5" or steps < 40 else 4
+    t_every = 1 if a.config == "c5" or steps < 12 else 4
     model._chk(L.agp_svgp_timing_enable(h, 0 if os.environ.get("AGP_BENCH_NO_TIMING") == "1" else t_every))
     if comm is not None:
         comm.stats()  # reset the accounting

@@ -2545,6 +2545,10 @@ struct Svgp : SvgpBase {
       ctx->err = "class label outside the likelihood's classes";  // multiclass.jl:81-83
       return AGP_ERR_LABELS;
     }
+    if (info == -2) {
+      ctx->err = "the look-ahead stream waited about a minute for a CAVI step that never started (k_wait_ge)";
+      return AGP_ERR_HIP;
+    }
     if (info < 0) {
       ctx->err = "task-graph factorisation aborted: a tile dependency never arrived (spin limit)";
       return AGP_ERR_HIP;

@@ -386,16 +386,16 @@ __device__ __forceinline__ void factor_diag_tile512(T* bufA, T* bufB, T* sc, T* 
 // The two eliminations use the same 4-column rounds with 2x2 cyclic ownership (about half the per-round work of the
 // 4x4 ownership: the redundant per-thread transforms shrink with the sub-block count); the glue is four 32^3 MFMA products.
 // ---------------------------------------------------------------------------------------------------
-template <typename T, bool TB>
+template <typename T, bool TB, int LDB = LDP>
 __device__ __forceinline__ typename Mfma<T>::acc_t mma_blk32(const T* As, const T* Bs, typename Mfma<T>::acc_t acc,
                                                              int wr, int wc, int lane, bool negA) {
-  // acc(16x16 tile (wr, wc) of a 32x32 result) += sum_k A[r][k] * B(k, c) ; TB: B(k,c) = Bs[k*LDP + c] else Bs[c*LDP + k]
+  // acc(16x16 tile (wr, wc) of a 32x32 result) += sum_k A[r][k] * B(k, c) ; TB: B(k,c) = Bs[k*LDB + c] else Bs[c*LDB + k]
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) {
     T a = As[(wr * 16 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
     if (negA) a = -a;
-    T b = TB ? Bs[(kk * 4 + (lane >> 4)) * LDP + wc * 16 + (lane & 15)]
-             : Bs[(wc * 16 + (lane & 15)) * LDP + kk * 4 + (lane >> 4)];
+    T b = TB ? Bs[(kk * 4 + (lane >> 4)) * LDB + wc * 16 + (lane & 15)]
+             : Bs[(wc * 16 + (lane & 15)) * LDB + kk * 4 + (lane >> 4)];
     acc = Mfma<T>::mma(a, b, acc);
   }
   return acc;
@@ -450,60 +450,63 @@ __device__ __forceinline__ void factor_diag_tile_2lvl(T* bufA, T* bufB, T* sc, T
   typedef typename Mfma<T>::acc_t acc_t;
   NoHook nohook;
   elim_block32<T, NoHook, PIV>(bufA, bufB, 0, sc, piv, act, ti, tj, nohook);
-  // L21 = A21 X11'   (in place in bufA[32:64, 0:32])
+  // L21 = A21 X11' -> scratch in bufB[32:64, 0:32] (free until X21 is formed at the end): no barrier between reading A21 and
+  // writing the result.  The other waves clear the upper-right blocks meanwhile (input garbage in bufA, nothing yet in bufB).
   acc_t acc;
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = T(0);
-  if (mw) acc = mma_blk32<T, false>(bufA + 32 * LDP, bufB, acc, wr, wc, lane, false);
+  if (mw) {
+    acc = mma_blk32<T, false>(bufA + 32 * LDP, bufB, acc, wr, wc, lane, false);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      bufB[(32 + wr * 16 + Mfma<T>::row(lane, r)) * LDP + wc * 16 + (lane & 15)] = acc[r];
+  } else {  // (workgroups of 512 threads: all callers)
+    for (int e = tid - 256; e < 32 * 32; e += (int)blockDim.x - 256) {
+      bufA[(e >> 5) * LDP + 32 + (e & 31)] = T(0);
+      bufB[(e >> 5) * LDP + 32 + (e & 31)] = T(0);
+    }
+  }
   __syncthreads();
+  // L21 into its home, and S = A22 - L21 L21' in place on the three 16x16 tiles on and below the diagonal (the elimination reads
+  // the lower triangle only ; every wave reads and writes its own tile of A22, L21 comes from the scratch: no barrier in between)
   if (mw) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       bufA[(32 + wr * 16 + Mfma<T>::row(lane, r)) * LDP + wc * 16 + (lane & 15)] = acc[r];
-  }
-  __syncthreads();
-  // S = A22 - L21 L21'   (in place in bufA[32:64, 32:64]; the full block, symmetric up to rounding; the lower part is used)
-  if (mw) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      acc[r] = bufA[(32 + wr * 16 + Mfma<T>::row(lane, r)) * LDP + 32 + wc * 16 + (lane & 15)];
-    if (wr < wc) {  // upper tile of A22 was never valid input: mirror the lower one
+    if (wr >= wc) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        acc[r] = bufA[(32 + wc * 16 + (lane & 15)) * LDP + 32 + wr * 16 + Mfma<T>::row(lane, r)];
-    }
-    acc = mma_blk32<T, false>(bufA + 32 * LDP, bufA + 32 * LDP, acc, wr, wc, lane, true);
-  }
-  __syncthreads();
-  if (mw) {
+        acc[r] = bufA[(32 + wr * 16 + Mfma<T>::row(lane, r)) * LDP + 32 + wc * 16 + (lane & 15)];
+      acc = mma_blk32<T, false>(bufB + 32 * LDP, bufB + 32 * LDP, acc, wr, wc, lane, true);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      bufA[(32 + wr * 16 + Mfma<T>::row(lane, r)) * LDP + 32 + wc * 16 + (lane & 15)] = acc[r];
+      for (int r = 0; r < 4; ++r)
+        bufA[(32 + wr * 16 + Mfma<T>::row(lane, r)) * LDP + 32 + wc * 16 + (lane & 15)] = acc[r];
+    }
   }
   __syncthreads();
   elim_block32<T, H, PIV>(bufA, bufB, 32, sc, piv, act, ti, tj, hook);  // hook rounds 0..7 of the second half
-  // P = L21 X11  -> scratch bufB[0:32, 32:64]
+  // P = L21 X11  -> sc (32 x 32, free after the rounds)
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = T(0);
   if (mw) {
     acc = mma_blk32<T, true>(bufA + 32 * LDP, bufB, acc, wr, wc, lane, false);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bufB[(wr * 16 + Mfma<T>::row(lane, r)) * LDP + 32 + wc * 16 + (lane & 15)] = acc[r];
+    for (int r = 0; r < 4; ++r) sc[(wr * 16 + Mfma<T>::row(lane, r)) * 32 + wc * 16 + (lane & 15)] = acc[r];
   }
   __syncthreads();
-  // X21 = -X22 P   -> bufB[32:64, 0:32]
+  // X21 = -X22 P   -> bufB[32:64, 0:32] ; bad pivots reported next to it
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = T(0);
   if (mw) {
-    acc = mma_blk32<T, true>(bufB + 32 * LDP + 32, bufB + 32, acc, wr, wc, lane, true);
+    acc = mma_blk32<T, true, 32>(bufB + 32 * LDP + 32, sc, acc, wr, wc, lane, true);
 #pragma unroll
     for (int r = 0; r < 4; ++r) bufB[(32 + wr * 16 + Mfma<T>::row(lane, r)) * LDP + wc * 16 + (lane & 15)] = acc[r];
   }
-  __syncthreads();
-  // clear the upper-right blocks (input garbage in bufA, scratch P in bufB) and report bad pivots
-  for (int e = tid; e < 32 * 32; e += blockDim.x) {
-    bufA[(e >> 5) * LDP + 32 + (e & 31)] = T(0);
-    bufB[(e >> 5) * LDP + 32 + (e & 31)] = T(0);
+  if (blockDim.x <= 256) {  // nobody was free to clear the upper-right blocks earlier
+    for (int e = tid; e < 32 * 32; e += blockDim.x) {
+      bufA[(e >> 5) * LDP + 32 + (e & 31)] = T(0);
+      bufB[(e >> 5) * LDP + 32 + (e & 31)] = T(0);
+    }
   }
   if (tid < TILE) {
     const T p = piv[tid];

@@ -466,7 +466,10 @@ def main():
                 with open(os.path.join(ROOT, "profiles", pf)) as fh:
                     pm = json.load(fh)
                 # (rocprofv3 prints every template argument, the TRACE flag included: match on the name without its closing '>')
-                key = [k for k in pm["kernels"] if k.startswith(roofline["kernel"][:-1])][0]
+                # ... and take the CAVI step's own instantiation (last template argument STEP = true) when the file has it: the
+                # other launches of the same kernel in that run (K_ZZ, factorisations with the inverse) have no extension rows
+                keys = [k for k in pm["kernels"] if k.startswith(roofline["kernel"][:-1])]
+                key = ([k for k in keys if k.endswith(", true>")] or keys)[0]
                 roofline["traffic"] = pm["kernels"][key]["hbm_bytes_per_launch_corrected"]
                 roofline["traffic_source"] = f"profiles/{pf} (rocprofv3 --pmc, separate passes, same command)"
                 break

@@ -556,3 +556,50 @@ def test_lookahead_handover_word_equals_event_protocol(mods):
             assert np.array_equal(u, v), phases
     # and the fused and the phase-split sequences agree with each other to rounding
     assert _rel(run(True, False)[3], run(True, True)[3]) < 1e-10
+
+
+def test_two_handles_interleaved_with_lookahead(mods):
+    """Two models of one process share the context's stream, its task-graph flags and hand-over area, but each has its own
+    look-ahead stream and hand-over word.  Stepping them alternately (each announcing its own next minibatch) must give each
+    exactly the trajectory it has when trained alone."""
+    AGP, R, capi, torch = mods
+    rng = np.random.default_rng(21)
+    N, D, B, it = 6000, 5, 256, 40
+    X = rng.random((N, D))
+    y = np.sign(np.sin(X @ rng.standard_normal(D)) + 0.1 * rng.standard_normal(N))
+    L = capi.lib()
+    specs = [(256, 1.5), (384, 2.5)]
+    Zs = [X[rng.permutation(N)[:m]].copy() for m, _ in specs]
+    idx = np.stack([rng.choice(N, B, replace=False) for _ in range(it)])
+
+    def make(k):
+        m, sc = specs[k]
+        ma = AGP.SVGP(AGP.SqExponentialKernel() @ AGP.ScaleTransform(sc), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Zs[k],
+                      optimiser=False)
+        AGP.train_(ma, X, y, 1, idx_stream=list(idx[:1]))
+        Xd, yd, _ = ma._data
+        return ma, (C.c_void_p(Xd.data_ptr()), C.c_void_p(yd.data_ptr()), Xd.stride(0))
+
+    ia = torch.as_tensor(idx, device="cuda")
+
+    def step(ma, ptrs, i):
+        xp, yp, ld = ptrs
+        assert L.agp_svgp_cavi_step(ma._h, xp, ld, yp, C.c_void_p(ia[i].data_ptr()), B, N / B) == 0
+        if i + 1 < it:
+            assert L.agp_svgp_prefetch(ma._h, xp, ld, C.c_void_p(ia[i + 1].data_ptr()), B) == 0
+
+    solo = []
+    for k in range(2):
+        ma, ptrs = make(k)
+        for i in range(1, it):
+            step(ma, ptrs, i)
+        ma._chk(L.agp_svgp_check_status(ma._h))
+        solo.append(ma.get_state(0))
+    pair = [make(0), make(1)]
+    for i in range(1, it):
+        for ma, ptrs in pair:
+            step(ma, ptrs, i)
+    for k, (ma, _) in enumerate(pair):
+        ma._chk(L.agp_svgp_check_status(ma._h))
+        for u, v in zip(ma.get_state(0), solo[k]):
+            assert np.array_equal(u, v), k

@@ -10,6 +10,7 @@ from agp_amd import capi
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 m = B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024          # 2048 with fp32 = the C3 shape (32 block columns)
 TT = np.float32 if (len(sys.argv) > 3 and sys.argv[3] == "f32") else np.float64
+PHASES = len(sys.argv) > 4 and sys.argv[4] == "phases"  # step_local / step_stats / prefetch / step_global (the batch-parallel driver's sequence)
 D, N = 32, 200000
 rng = np.random.default_rng(0)
 X = rng.random((N, D))
@@ -25,6 +26,12 @@ for rep in range(2):
     ia = torch.as_tensor(idx, device="cuda")
     for i in range(steps):
         j = i % 256
+        if PHASES:
+            assert L.agp_svgp_step_local(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(yd.data_ptr()), C.c_void_p(ia[j].data_ptr()), B, N / B) == 0
+            assert L.agp_svgp_step_stats(h) == 0
+            L.agp_svgp_prefetch(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(ia[(j + 1) % 256].data_ptr()), B)
+            assert L.agp_svgp_step_global(h) == 0
+            continue
         assert L.agp_svgp_cavi_step(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(yd.data_ptr()), C.c_void_p(ia[j].data_ptr()), B, N / B) == 0
         L.agp_svgp_prefetch(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(ia[(j + 1) % 256].data_ptr()), B)
     model._chk(L.agp_svgp_check_status(h))

@@ -4165,7 +4165,8 @@ agp_status agp_comm_allreduce(agp_comm* cm, void* buf, int64_t count, int32_t dt
   DevGuard guard(ctx->device);
   cm->n_calls += 1;
   cm->bytes += count * (dtype == AGP_F64 ? 8 : 4);
-  if (cm->timing) {
+  cm->timing_now = cm->timing && ((cm->n_calls - 1) % cm->timing_every == 0);
+  if (cm->timing_now) {
     if (cm->ev_used + 2 > cm->ev.size())
       for (int i = 0; i < 2; ++i) {
         hipEvent_t e;
@@ -4191,9 +4192,10 @@ agp_status agp_comm_allreduce(agp_comm* cm, void* buf, int64_t count, int32_t dt
       return AGP_ERR_HIP;
     }
   }
-  if (cm->timing) {
+  if (cm->timing_now) {
     HIPCHK(ctx, hipEventRecord(cm->ev[cm->ev_used + 1], ctx->stream));
     cm->ev_used += 2;
+    cm->n_timed += 1;
   }
   return AGP_OK;
 }
@@ -4201,6 +4203,7 @@ agp_status agp_comm_allreduce(agp_comm* cm, void* buf, int64_t count, int32_t dt
 agp_status agp_comm_timing(agp_comm* cm, int32_t on) {
   if (!cm) return AGP_ERR_INVALID;
   cm->timing = on != 0;
+  cm->timing_every = on > 1 ? on : 1;
   return AGP_OK;
 }
 
@@ -4219,8 +4222,11 @@ agp_status agp_comm_stats(agp_comm* cm, int64_t* n_calls_host, int64_t* bytes_ho
       ms += t;
     }
   }
+  // with every n-th collective bracketed the sum is scaled to all of them
+  if (cm->n_timed > 0 && cm->n_timed < cm->n_calls) ms *= (double)cm->n_calls / (double)cm->n_timed;
   if (ms_host) *ms_host = ms;
   cm->n_calls = cm->bytes = 0;
+  cm->n_timed = 0;
   cm->ev_used = 0;
   return AGP_OK;
 }

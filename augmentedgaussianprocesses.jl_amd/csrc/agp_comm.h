@@ -89,6 +89,9 @@ struct agp_comm {
   // accounting for bench.py: bytes reduced and (optionally) HIP-event time of the collectives since the last read
   int64_t n_calls = 0, bytes = 0;
   bool timing = false;
+  int timing_every = 1;      // every n-th collective is bracketed by events (two records cost the stream ~20 us)
+  int64_t n_timed = 0;       // collectives bracketed since the last agp_comm_stats
+  bool timing_now = false;
   std::vector<hipEvent_t> ev;
   size_t ev_used = 0;
 };

@@ -126,8 +126,9 @@ class Comm:
         capi.lib().agp_comm_info(self.h, None, None, C.byref(f))
         return bool(f.value)
 
-    def timing(self, on: bool = True):
-        self.model._chk(capi.lib().agp_comm_timing(self.h, 1 if on else 0))
+    def timing(self, on=True):
+        """on: False / True (every collective bracketed by HIP events) / n > 1 (every n-th: the records cost stream time)"""
+        self.model._chk(capi.lib().agp_comm_timing(self.h, int(on)))
 
     def stats(self):
         """(collectives, bytes reduced per rank, summed milliseconds if timing was on) since the last call"""

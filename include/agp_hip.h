@@ -413,7 +413,8 @@ agp_status agp_comm_info(agp_comm* comm, int32_t* rank_host, int32_t* world_host
 /* sum all-reduce of a device buffer in place on the ctx stream (what the *_multi calls use; exposed for host drivers) */
 agp_status agp_comm_allreduce(agp_comm* comm, void* buf, int64_t count, int32_t dtype);
 /* accounting since the last read: number of collectives, bytes reduced (per rank), and -- when timing was enabled with
- * agp_comm_timing(comm, 1) -- their summed duration from HIP events on the ctx stream (synchronises). */
+ * agp_comm_timing(comm, n) -- their summed duration from HIP events on the ctx stream (synchronises).  n = 1 brackets every
+ * collective, n > 1 every n-th one (the two event records cost the stream ~20 us each time); the sum is scaled to all calls. */
 agp_status agp_comm_timing(agp_comm* comm, int32_t on);
 agp_status agp_comm_stats(agp_comm* comm, int64_t* n_calls_host, int64_t* bytes_host, double* ms_host);
 

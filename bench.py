@@ -260,7 +260,7 @@ def main():
         fake_us = float(os.environ.get("AGP_BENCH_FAKE_ALLREDUCE_US", "0"))
         if fake_us > 0:
             # stand-in for the xGMI all-reduce on a one-GPU box: a kernel that just occupies the stream for about that long
-            cyc = int(fake_us * 900)  # torch.cuda._sleep: ~1.1 ns per count here (the JSON line carries the measured us per call)
+            cyc = int(fake_us * 1700)  # torch.cuda._sleep: ~0.59 ns per count on MI355X (the JSON line carries the measured us per call)
             exts = {}
 
             def _fake(ptr, count, dtype, stream):

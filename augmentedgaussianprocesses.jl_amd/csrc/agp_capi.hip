@@ -37,6 +37,7 @@ struct agp_ctx {
     int64_t used = 0, stride = 0;
     int nb = 0;
   } h_dirty[2];
+  int h_step_set = 0;  // the CAVI-step launches with a prologue alternate between the sets and refill each other's (ProArgs::fill)
   void* tri_scratch = nullptr;    // n x n scratch of the recursive-doubling triangular inverse
   size_t tri_bytes = 0;
   // fallback of the task-graph factorisation (k_chol_safe): grid-barrier words, retry counter, number of CUs; once a retry has
@@ -165,13 +166,14 @@ static agp_status dag_handover_acquire(agp_ctx* c, int64_t elems, int set, T** o
     }
     c->hbytes = 0;
     const size_t cap = need + need / 4;
-    for (int q = 0; q < 1; ++q) {  // one set suffices since the refill rides on the same stream (set 1 is unused)
-      if (hipMalloc(&c->hset[q], cap) != hipSuccess) return AGP_ERR_NOMEM;
-      hipLaunchKernelGGL((k_fill_sent<T>), dim3(2048), dim3(256), 0, c->stream, (T*)c->hset[q], (int64_t)(cap / sizeof(T)),
-                         (int64_t)0);
-    }
     c->hbytes = cap;
     c->htype = (int)sizeof(T);
+  }
+  if (!c->hset[set]) {  // set 1 only exists once a step launch with a prologue asks for it (they alternate between the sets)
+    if (hipMalloc(&c->hset[set], c->hbytes) != hipSuccess) return AGP_ERR_NOMEM;
+    hipLaunchKernelGGL((k_fill_sent<T>), dim3(2048), dim3(256), 0, c->stream, (T*)c->hset[set], (int64_t)(c->hbytes / sizeof(T)),
+                       (int64_t)0);
+    c->h_dirty[set].on = false;
   }
   if (c->h_dirty[set].on) {  // nobody refilled it in passing: do it now, on this stream
     const auto& d = c->h_dirty[set];
@@ -415,11 +417,62 @@ struct StepSync {
   bool used = false;  // out: the task-graph launch took `ds`
 };
 
+// The pending natural-gradient step that a CAVI step's task-graph launch takes along as its prologue (ProArgs, agp_chol.h)
+template <typename T>
+struct ProHost {
+  const T* kap = nullptr;
+  int64_t ldk = 0, Kdim = 0;
+  const T *w = nullptr, *r = nullptr;
+  T* eta2 = nullptr;
+  const T* Kinv = nullptr;
+  int64_t ldm = 0;
+  T* eta1 = nullptr;
+  const T* kinv_mu0 = nullptr;
+  T lr = T(0);
+};
+// k-slices per block column of the prologue's product: a tile of block column c has to be there when the chain reaches the
+// column (about tau * c after the start, tau = 17.8 us f64 / 14 us f32 per block column), a 64-row chunk of the product costs a
+// workgroup about tc = 2.7 / 1.6 us; columns 0 and 1 feed the chain at once and are split as far as it pays (8).
+// AGP_PRO_KS="8,8,4,2,1" overrides (the last entry repeats).
+static void pro_ks_table(int64_t nt, int64_t nq, bool f64, unsigned char* ks) {
+  static const std::vector<int> env = []() {
+    std::vector<int> v;
+    if (const char* e = getenv("AGP_PRO_KS")) {
+      for (const char* p = e; *p;) {
+        v.push_back(atoi(p));
+        while (*p && *p != ',') ++p;
+        if (*p == ',') ++p;
+      }
+    }
+    return v;
+  }();
+  const double tc = f64 ? 2.7 : 1.6, tau = f64 ? 17.8 : 14.0;
+  for (int64_t c = 0; c < nt && c < 32; ++c) {
+    int want;
+    if (!env.empty()) want = env[std::min<size_t>((size_t)c, env.size() - 1)];
+    else if (c < 2) want = 8;
+    else want = (int)std::ceil((double)nq * tc / (tau * (double)c - 8.0));
+    want = std::max(1, std::min<int>(want, (int)std::min<int64_t>(8, nq)));
+    ks[c] = (unsigned char)want;
+  }
+}
+static bool dag_trace_on() {
+  static const bool on = getenv("AGP_DAG_TRACE") != nullptr;
+  return on;
+}
+static bool dag_fused_on() {
+  static const bool fused = []() {
+    const char* e = getenv("AGP_CHOL_DAG_FUSED");
+    return !(e && e[0] == '0');
+  }();
+  return fused;
+}
+
 template <typename T>
 static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int64_t ldx, T* Dg, T* E, int64_t lde,
                               int64_t ne, int do_x, int32_t* info_dev, int64_t nvalid, const T* erow = nullptr,
                               bool want_l = true, const SafeSrc<T>* safe = nullptr, bool* defer_safe = nullptr,
-                              StepSync* ssync = nullptr) {
+                              StepSync* ssync = nullptr, const ProHost<T>* pro = nullptr) {
   // ssync (CAVI step next to a look-ahead stream): the step's task-graph instantiation stores its `started` number (`used` is set)
   // defer_safe (in: the caller can run the fallback itself, k_safe_rowstats; out: whether it has to -- the task graph was used)
   const bool can_defer = defer_safe && *defer_safe;
@@ -431,9 +484,20 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
   // path needs it in E first)
   const int64_t nt = n / TILE;
   const bool use_dag = chol_use_dag(c, nt, ne);
+  if (pro && !(use_dag && X && dag_fused_on() && !dag_trace_on() && !do_x && !want_l && nt <= 32)) {
+    c->err = "potrf_fused: a pending natural-gradient step can only ride on the CAVI step's task-graph launch";
+    return AGP_ERR_INVALID;
+  }
   if (use_dag && X) {
     const int64_t nx = (do_x && nt > 1) ? nt : 0;  // the full inverse rides along as nt identity block rows
-    const int64_t nf = ((nt + ne + nx) * nt + 3 * nt + 1) * DAG_FS;
+    // prologue (pro): helper workgroups, their flags and hand-over slots
+    ProArgs<T> pa{};
+    int64_t nhelp = 0;
+    if (pro) {
+      pro_ks_table(nt, pro->Kdim / TILE, sizeof(T) == 8, pa.ks);
+      for (int64_t cc = 0; cc < nt; ++cc) nhelp += (nt - cc) * (pa.ks[cc] - 1);
+    }
+    const int64_t nf = ((nt + ne + nx) * nt + 3 * nt + 1 + nhelp) * DAG_FS;
     if (c->dag_cap < nf) {
       if (c->dag_flags) (void)hipFree(c->dag_flags);
       c->dag_flags = nullptr;
@@ -445,9 +509,10 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     }
     c->dag_epoch += 1;
     const int64_t ntiles = nt * (nt + 1) / 2 + ne * nt + (nx ? nt * (nt + 1) / 2 : 0);
-    const int64_t hstride = ((2 * nt + ne) * nt + 3 * nt) * TILE * TILE;
+    const int64_t hstride = ((2 * nt + ne) * nt + 3 * nt + nhelp) * TILE * TILE;
+    const int64_t hused = (3 * nt + (nt + ne + nx) * nt + nhelp) * TILE * TILE;
     T* H = nullptr;
-    const int hs = 0;
+    const int hs = pro ? c->h_step_set : 0;
     AGPCHK(dag_handover_acquire<T>(c, hstride, hs, &H));
     unsigned long long* trace = nullptr;
     static const char* trace_path = getenv("AGP_DAG_TRACE");  // development aid: per-tile timestamps of one launch
@@ -455,10 +520,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       if (hipMalloc((void**)&trace, (size_t)ntiles * 8 * 8) != hipSuccess) trace = nullptr;
       if (trace) (void)hipMemsetAsync(trace, 0, (size_t)ntiles * 8 * 8, c->stream);
     }
-    static const bool fused = []() {
-      const char* e = getenv("AGP_CHOL_DAG_FUSED");
-      return !(e && e[0] == '0');
-    }();
+    const bool fused = dag_fused_on();
     const bool step_inst = fused && !trace && nx == 0 && !do_x && !want_l;
     DagSync ds{};
     if (ssync) {
@@ -476,7 +538,32 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       hipLaunchKernelGGL((k_chol_dag<T, true, false, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1,
                          (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
                          (int)(do_x && nx == 0) | (want_l ? 2 : 0), DagSync{});
-    else if (step_inst)  // the CAVI step's launch: specialised instantiation
+    else if (step_inst && pro) {  // ... with the pending natural-gradient step as its prologue
+      pa.kap = pro->kap;
+      pa.ldk = pro->ldk;
+      pa.Kdim = pro->Kdim;
+      pa.w = pro->w;
+      pa.r = pro->r;
+      pa.eta2 = pro->eta2;
+      pa.Kinv = pro->Kinv;
+      pa.ldm = pro->ldm;
+      pa.eta1 = pro->eta1;
+      pa.kinv_mu0 = pro->kinv_mu0;
+      pa.lr = pro->lr;
+      pa.HS = H + (3 * nt + (nt + ne) * nt) * TILE * TILE;
+      pa.sflags = c->dag_flags + ((nt + ne) * nt + 3 * nt + 1) * DAG_FS;
+      const int other = hs ^ 1;
+      if (c->hset[other] && c->h_dirty[other].on && c->h_dirty[other].nb == 1 && c->htype == (int)sizeof(T)) {
+        pa.fill = (T*)c->hset[other];  // the set the launch before this one used: refilled in this launch's shadow
+        pa.fill_n = c->h_dirty[other].used;
+        pa.nfill = 64;
+        c->h_dirty[other].on = false;
+      }
+      hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, true>), dim3((unsigned)(ntiles + nhelp + pa.nfill)),
+                         dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags,
+                         c->dag_epoch, trace, H, hstride, nx, erow, 0, ds, pa);
+      c->h_step_set = other;
+    } else if (step_inst)  // the CAVI step's launch: specialised instantiation
       hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1,
                          (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
                          0, ds);
@@ -489,7 +576,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
                          ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
                          (int)(do_x && nx == 0) | (want_l ? 2 : 0), DagSync{});
     LAUNCHCHK(c);
-    AGPCHK(dag_handover_release<T>(c, (3 * nt + (nt + ne + nx) * nt) * TILE * TILE, hstride, 1, hs));
+    AGPCHK(dag_handover_release<T>(c, hused, hstride, 1, hs));
     static const bool test_abort = []() {  // test hook: pretend every task-graph launch of a CAVI step lost a dependency
       const char* e = getenv("AGP_DAG_TEST_ABORT");
       return e && e[0] == '1';
@@ -801,6 +888,11 @@ struct SvgpBase {
   virtual agp_status step_stats(bool fused) = 0;
   virtual agp_status stats_ptr(void** p, int64_t* n) = 0;
   virtual agp_status step_global(bool fused) = 0;
+  // tail of agp_svgp_cavi_step: the fused natural-gradient step now, or left pending for the next step's task-graph launch
+  virtual agp_status step_finish() = 0;
+  // applies a pending natural-gradient step with the stand-alone kernel (every entry point other than the CAVI step calls this
+  // first, so eta, Sigma, predictions, the ELBO and the hyper-gradient never see a half-taken step)
+  virtual agp_status flush() = 0;
   virtual agp_status check_status() = 0;
   virtual agp_status elbo(const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B, double rho,
                           int fresh, double* out) = 0;
@@ -915,6 +1007,7 @@ struct Svgp : SvgpBase {
     T* Wbuf = nullptr;    // (Bp + 64) x mp : [kappa ; eta1'] -> [W ; v'] by the augmented Cholesky
     T* pk = nullptr;      // K~ partial slices of this latent [2*mp/64][ldp]
     T *Knm_alt = nullptr, *kappa_alt = nullptr, *Wbuf_alt = nullptr, *pk_alt = nullptr;  // prefetch targets
+    T* kappa_old = nullptr;  // third kappa buffer: the minibatch whose natural-gradient step is still pending (see Pending)
     T* DgK = nullptr;     // diagonal 64x64 factors of chol(K)      (mp x 64)
     T* DgA = nullptr;     // diagonal 64x64 factors of chol(-2 eta2)
     T* Apred = nullptr;   // K^-1 - K^-1 Sigma K^-1
@@ -1031,6 +1124,59 @@ struct Svgp : SvgpBase {
     LAUNCHCHK(ctx);
     return AGP_OK;
   }
+  // The natural-gradient step of the last CAVI step, not taken yet: the next step's task-graph launch takes it as its prologue
+  // (ProArgs, agp_chol.h) -- the 53 us symmetric product then no longer sits between two factorisation chains.  Everything else
+  // that touches the posterior calls flush() first.  kap is the physical kappa buffer of that minibatch (it survives the rotation of
+  // the look-ahead buffers: kappa has three of them).
+  struct Pending {
+    bool on = false;
+    int64_t Bq = 0;
+    T lr = T(0);
+    const T* kap = nullptr;
+    const T *Kinv = nullptr, *kinv_mu0 = nullptr;
+  } pend;
+  bool pro_allowed() const {
+    static const bool off = []() {
+      const char* e = getenv("AGP_STEP_PROLOGUE");
+      return e && e[0] == '0';
+    }();
+    if (off || nl != 1 || mo || mo_sharded) return false;
+    const int k = lp.kind;
+    return k == AGP_LIK_GAUSSIAN || k == AGP_LIK_LOGISTIC || k == AGP_LIK_STUDENTT || k == AGP_LIK_LAPLACE ||
+           k == AGP_LIK_BAYESIANSVM || k == AGP_LIK_NEGBINOMIAL || k == AGP_LIK_POISSON;
+  }
+  agp_status flush() override {
+    if (!pend.on) return AGP_OK;
+    Latent& g = lat[0];
+    pend.on = false;
+    AGPCHK((syrk_tn<T, SY_ETA2>(ctx, pend.kap, mp, mp, pend.Bq, wbuf, 0, g.La, mp, g.eta2, pend.Kinv, mp, pend.lr, (const T*)rbuf,
+                                g.eta1, pend.kinv_mu0)));
+    LAUNCHCHK(ctx);
+    g.la_state = 0;  // the epilogue left La = -2 eta2
+    g.xa_valid = false;
+    return AGP_OK;
+  }
+  agp_status step_finish() override {
+    if (pro_allowed() && chol_use_dag(ctx, mp / TILE, rup64(B_last) / TILE + 1, 1) && mp / TILE <= 32 && dag_fused_on() &&
+        !dag_trace_on()) {
+      Latent& g = lat[0];
+      pend.on = true;
+      pend.Bq = rup64(B_last);
+      pend.lr = (T)cur_lr();
+      pend.kap = g.kappa;
+      pend.Kinv = kinv_step(g);
+      pend.kinv_mu0 = kinv_mu0_step(g);
+      // the bookkeeping of step_global: the posterior changes (as soon as the step is taken)
+      g.la_state = 1;  // La does not hold -2 eta2: whoever wants it rebuilds it from eta2 (after flush())
+      g.xa_valid = false;
+      g.post_valid = false;
+      g.pred_valid = g.predvar_valid = false;
+      n_opt += 1;
+      return kappa_released();
+    }
+    AGPCHK(step_stats(true));
+    return step_global(true);
+  }
   // last step
   const void* x_last = nullptr;
   const void* y_last = nullptr;
@@ -1145,7 +1291,7 @@ struct Svgp : SvgpBase {
     for (auto e : ev) dcheck(hipEventDestroy(e), __LINE__);
     for (auto& g : lat) {
       T* ps[] = {g.Zsc, g.zn, g.scales, g.Z, g.L, g.Xk, g.Kinv, g.mu0, g.kinv_mu0, g.eta1, g.eta2, g.La, g.Xa, g.v,
-                 g.Sigma, g.mu, g.Knm, g.kappa, g.Apred, g.apred, g.Wbuf, g.DgK, g.DgA, g.pk, g.Knm_alt, g.kappa_alt, g.Wbuf_alt, g.pk_alt};
+                 g.Sigma, g.mu, g.Knm, g.kappa, g.Apred, g.apred, g.Wbuf, g.DgK, g.DgA, g.pk, g.Knm_alt, g.kappa_alt, g.Wbuf_alt, g.pk_alt, g.kappa_old};
       for (T* p : ps)
         if (p) dfree(p);
     }
@@ -1278,6 +1424,12 @@ struct Svgp : SvgpBase {
   // compute_K : cholesky(kernelmatrix(k, Z) + jitt*I) ; inv(K)      latentgp.jl:205-207, analyticVI.jl:179
   agp_status refresh_K() override {
     bool any = false;
+    if (pend.on)  // the pending natural-gradient step belongs to the kernel matrices it was computed with
+      for (auto& g : lat)
+        if (g.K_stale) {
+          AGPCHK(flush());
+          break;
+        }
     for (auto& g : lat) {
       if (!g.K_stale) continue;
       any = true;
@@ -1564,13 +1716,26 @@ struct Svgp : SvgpBase {
       HIPCHK(ctx, hipEventRecord(step_done[rel_slot], st()));
       rel_pending = false;
     }
+    // a pending natural-gradient step rides on this step's task-graph launch when this is the steady state of a training loop
+    // (kappa of the minibatch already there -- look-ahead or kept --, one latent on the task graph); otherwise it is taken now
+    bool use_pro = false;
+    if (pend.on) {
+      use_pro = !fresh && nl == 1 && dag_nb > 0 && (prefetched || (reuse && lat[0].kappa_valid)) && pro_allowed() &&
+                mp / TILE <= 32 && dag_fused_on() && !dag_trace_on() && pend.Bq >= TILE;
+      if (!use_pro) AGPCHK(flush());
+    }
     if (prefetched) {  // kappa of this minibatch was produced on the prefetch stream: adopt those buffers
       HIPCHK(ctx, hipStreamWaitEvent(st(), pf_done, 0));
       for (auto& g : lat) {
         std::swap(g.Knm, g.Knm_alt);
-        std::swap(g.kappa, g.kappa_alt);
         std::swap(g.Wbuf, g.Wbuf_alt);
         std::swap(g.pk, g.pk_alt);
+        // kappa rotates through three buffers: the one just left may still be read by this step's prologue (pending step), so
+        // the next look-ahead target is the one before it
+        T* left = g.kappa;
+        g.kappa = g.kappa_alt;
+        g.kappa_alt = g.kappa_old;
+        g.kappa_old = left;
       }
       pf_valid = false;
     }
@@ -1609,7 +1774,7 @@ struct Svgp : SvgpBase {
         continue;
       }
       // pre-factorisation part of aug_factor: -2*eta2 back into La if it holds a factor, extension rows [eta1' ; 0]
-      if (g.la_state != 0) {
+      if (g.la_state != 0 && !use_pro) {  // (with the prologue, -2 eta2 is formed inside the launch and never stored)
         hipLaunchKernelGGL((k_copy2d<T>), grid2(mp, mp), blk2, 0, st(), (const T*)g.eta2, mp, mp, mp, g.La, mp, mp, mp,
                            T(1), T(-2));
       }
@@ -1662,8 +1827,25 @@ struct Svgp : SvgpBase {
             return !(e && e[0] == '0');
           }();
           bool defer = nl == 1 && merge_ok;  // single latent: the row-statistics launch below carries the fallback (k_safe_rowstats)
+          ProHost<T> ph{};
+          if (use_pro) {
+            Latent& g0 = lat[0];
+            ph.kap = pend.kap;
+            ph.ldk = mp;
+            ph.Kdim = pend.Bq;
+            ph.w = wbuf;
+            ph.r = rbuf;
+            ph.eta2 = g0.eta2;
+            ph.Kinv = pend.Kinv;
+            ph.ldm = mp;
+            ph.eta1 = g0.eta1;
+            ph.kinv_mu0 = pend.kinv_mu0;
+            ph.lr = pend.lr;
+            pend.on = false;
+          }
           AGPCHK(potrf_fused<T>(ctx, bt.A[0], mp, mp, bt.X[0], mp, bt.Dg[0], bt.E[0], mp, nel, 0, info_dev, m,
-                                (const T*)lat[todo[l0]].eta1, false, &src, &defer, sync_step ? &ssync : nullptr));
+                                (const T*)lat[todo[l0]].eta1, false, &src, &defer, sync_step ? &ssync : nullptr,
+                                use_pro ? &ph : nullptr));
           merged_safe = defer;
           launches += dag_nb > 0 ? 1 : chol_launch_count(ntl, nel);
         } else if (dag_nb > 0) {
@@ -2310,6 +2492,7 @@ struct Svgp : SvgpBase {
       for (auto& g : lat) {
         AGPCHK(dmalloc(ctx, &g.Knm_alt, Bp * mp));
         AGPCHK(dmalloc(ctx, &g.kappa_alt, Bp * mp));
+        AGPCHK(dmalloc(ctx, &g.kappa_old, Bp * mp));
         AGPCHK(dmalloc(ctx, &g.Wbuf_alt, (Bp + TILE) * mp));
         AGPCHK(dmalloc(ctx, &g.pk_alt, (2 * mp / TILE) * Bp));
       }
@@ -3819,25 +4002,29 @@ agp_status agp_svgp_destroy(agp_svgp* h) {
 #define HCHK(h)                                    \
   if (!(h) || !(h)->impl) return AGP_ERR_INVALID;  \
   DevGuard _dev_guard((h)->impl->ctx->device)
+// ... and, for every entry point outside the CAVI step / look-ahead pair: take a pending natural-gradient step first
+#define HCHKF(h) \
+  HCHK(h);       \
+  AGPCHK((h)->impl->flush())
 
 agp_status agp_svgp_set_kernel(agp_svgp* h, int32_t latent, const agp_kernel_desc* k) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->set_kernel(latent, k);
 }
 agp_status agp_svgp_set_Z(agp_svgp* h, int32_t latent, const void* z, int64_t ldz) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->set_Z(latent, z, ldz);
 }
 agp_status agp_svgp_get_Z(agp_svgp* h, int32_t latent, void* z, int64_t ldz) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->get_Z(latent, z, ldz);
 }
 agp_status agp_svgp_set_prior_mean(agp_svgp* h, int32_t latent, const void* mu0) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->set_mu0(latent, mu0);
 }
 agp_status agp_svgp_refresh_K(agp_svgp* h) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->refresh_K_explicit();
 }
 agp_status agp_svgp_set_opt_state(agp_svgp* h, int64_t n) {
@@ -3863,13 +4050,12 @@ agp_status agp_svgp_cavi_step(agp_svgp* h, const void* x, int64_t ldx, const voi
       AGPCHK(s->lsm_alpha());
     }
   }
-  AGPCHK(s->step_stats(true));
-  return s->step_global(true);
+  return s->step_finish();
 }
 
 agp_status agp_svgp_step_local(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B,
                                double rho) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->step_local(x, ldx, y, idx, B, rho, false);
 }
 agp_status agp_svgp_prefetch(agp_svgp* h, const void* x, int64_t ldx, const int64_t* idx, int64_t B) {
@@ -3878,81 +4064,81 @@ agp_status agp_svgp_prefetch(agp_svgp* h, const void* x, int64_t ldx, const int6
 }
 agp_status agp_svgp_set_multioutput(agp_svgp* h, int32_t n_task, const agp_lik_desc* liks_host, const double* A_host,
                                     double adam_eta, double adam_b1, double adam_b2, double adam_eps) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->set_multioutput(n_task, liks_host, A_host, adam_eta, adam_b1, adam_b2, adam_eps);
 }
 agp_status agp_svgp_get_A(agp_svgp* h, double* A_host) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->get_A(A_host);
 }
 agp_status agp_svgp_elbo_terms(agp_svgp* h, double* terms_host) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->elbo_terms(terms_host);
 }
 agp_status agp_svgp_set_batch_shard(agp_svgp* h, int32_t rank, int32_t world) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->set_batch_shard(rank, world);
 }
 agp_status agp_svgp_mo_shard(agp_svgp* h, int32_t q_total) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->mo_shard(q_total);
 }
 agp_status agp_svgp_mo_fbuf_ptr(agp_svgp* h, void** ptr, int64_t* count) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->mo_fbuf_ptr(ptr, count);
 }
 agp_status agp_svgp_mo_mix(agp_svgp* h) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->mo_mix();
 }
 agp_status agp_svgp_mo_refresh_f(agp_svgp* h) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->mo_refresh_f();
 }
 agp_status agp_svgp_mo_predict_from_f(agp_svgp* h, int64_t n_t, int32_t mode, void* out0, void* out1,
                                       const double* gh_nodes_host, const double* gh_weights_host, int32_t n_nodes) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->mo_predict_from_f(n_t, mode, out0, out1, gh_nodes_host, gh_weights_host, n_nodes);
 }
 agp_status agp_svgp_hyper_configure(agp_svgp* h, int32_t opt_kernel, double kernel_eta, int32_t opt_Z, double z_eta,
                                     double adam_b1, double adam_b2, double adam_eps) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->hyper_configure(opt_kernel, kernel_eta, opt_Z, z_eta, adam_b1, adam_b2, adam_eps);
 }
 agp_status agp_svgp_hypergrad(agp_svgp* h, int32_t latent, double* dvariance_host, double* dscale_host, void* dZ) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->hypergrad(latent, dvariance_host, dscale_host, dZ);
 }
 agp_status agp_svgp_hyper_step(agp_svgp* h) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->hyper_step();
 }
 agp_status agp_svgp_get_kernel(agp_svgp* h, int32_t latent, double* variance_host, double* scales_host) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->get_kernel(latent, variance_host, scales_host);
 }
 agp_status agp_svgp_lsm_gamma(agp_svgp* h) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->lsm_gamma();
 }
 agp_status agp_svgp_lsm_alpha(agp_svgp* h) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->lsm_alpha();
 }
 agp_status agp_svgp_lsm_gsum_ptr(agp_svgp* h, void** ptr, int64_t* count) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->lsm_gsum_ptr(ptr, count);
 }
 agp_status agp_svgp_step_stats(agp_svgp* h) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->step_stats(false);
 }
 agp_status agp_svgp_stats_ptr(agp_svgp* h, void** ptr, int64_t* count) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->stats_ptr(ptr, count);
 }
 agp_status agp_svgp_step_global(agp_svgp* h) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->step_global(false);
 }
 agp_status agp_svgp_timing_enable(agp_svgp* h, int32_t on) {
@@ -3968,25 +4154,25 @@ agp_status agp_svgp_timing_read(agp_svgp* h, int64_t* n_launches_host, double* t
   return h->impl->timing_read(n_launches_host, total_ms_host);
 }
 agp_status agp_svgp_check_status(agp_svgp* h) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->check_status();
 }
 agp_status agp_svgp_elbo(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B,
                          double rho, int32_t fresh_local, double* elbo_host) {
-  HCHK(h);
+  HCHKF(h);
   if (!elbo_host) return AGP_ERR_INVALID;
   return h->impl->elbo(x, ldx, y, idx, B, rho, fresh_local, elbo_host);
 }
 agp_status agp_svgp_get_state(agp_svgp* h, int32_t latent, void* mu, void* sigma, void* eta1, void* eta2) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->get_state(latent, mu, sigma, eta1, eta2);
 }
 agp_status agp_svgp_set_state(agp_svgp* h, int32_t latent, const void* eta1, const void* eta2) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->set_state(latent, eta1, eta2);
 }
 agp_status agp_svgp_get_matrix(agp_svgp* h, int32_t latent, int32_t which, void* out, int64_t ldo, int64_t cap) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->get_matrix(latent, which, out, ldo, cap);
 }
 agp_status agp_svgp_last_batch(agp_svgp* h, int64_t* B_host) {
@@ -3996,47 +4182,49 @@ agp_status agp_svgp_last_batch(agp_svgp* h, int64_t* B_host) {
   return AGP_OK;
 }
 agp_status agp_svgp_invalidate_data(agp_svgp* h) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->invalidate_data();
 }
 agp_status agp_svgp_init_state(agp_svgp* h) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->init_state();
 }
 agp_status agp_svgp_predict_f_cov(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* mu_out, void* cov_out) {
-  HCHK(h);
+  HCHKF(h);
   if (n_t == 0) return AGP_OK;  // no test points: nothing to write (the reference returns empty arrays)
   return h->impl->predict_f_cov(xt, ldx, n_t, mu_out, cov_out);
 }
 agp_status agp_svgp_predict_f(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* mu_out, void* var_out) {
-  HCHK(h);
+  HCHKF(h);
   if (n_t == 0) return AGP_OK;  // no test points: nothing to write (the reference returns empty arrays)
   return h->impl->predict_f(xt, ldx, n_t, mu_out, var_out);
 }
 agp_status agp_svgp_predict_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* y_out) {
-  HCHK(h);
+  HCHKF(h);
   if (n_t == 0) return AGP_OK;  // no test points: nothing to write (the reference returns empty arrays)
   return h->impl->predict_y(xt, ldx, n_t, y_out);
 }
 agp_status agp_svgp_set_online_prior(agp_svgp* h, int32_t latent, const void* za, int64_t ldza, int64_t ma, const void* invDa,
                                      int64_t ldi, const void* prev_eta1, double prevLa) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->set_online_prior(latent, za, ldza, ma, invDa, ldi, prev_eta1, prevLa);
 }
 agp_status agp_svgp_online_snapshot(agp_svgp* h, int32_t latent, void* invDa_out, int64_t ldi, void* eta1_out,
                                     double* prevLa_host) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->online_snapshot(latent, invDa_out, ldi, eta1_out, prevLa_host);
 }
 agp_status agp_svgp_adopt_local(agp_svgp* dst, agp_svgp* src) {
-  HCHK(dst);
+  HCHKF(dst);
   if (!src || !src->impl) return AGP_ERR_INVALID;
+  AGPCHK(src->impl->flush());
   return dst->impl->adopt_local(src->impl);
 }
 agp_status agp_svgp_online_first_step(agp_svgp* h_new, agp_svgp* h_old, const void* x, int64_t ldx, const void* y,
                                       int64_t B) {
-  HCHK(h_new);
+  HCHKF(h_new);
   if (!h_old || !h_old->impl) return AGP_ERR_INVALID;
+  AGPCHK(h_old->impl->flush());
   SvgpBase *n = h_new->impl, *o = h_old->impl;
   // local update of the new batch under the OLD inducing points and posterior (compute_old_matrices, onlinetraining.jl:80-89)
   AGPCHK(o->step_local(x, ldx, y, nullptr, B, 1.0, true));
@@ -4055,29 +4243,29 @@ agp_status agp_svgp_online_first_step(agp_svgp* h_new, agp_svgp* h_old, const vo
 
 agp_status agp_svgp_hyper_apply(agp_svgp* h, int32_t latent, const double* dvariance_host, const double* dscale_host,
                                 const void* dZ) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->hyper_apply(latent, dvariance_host, dscale_host, dZ);
 }
 agp_status agp_svgp_hyper_opt_state(agp_svgp* h, int32_t latent, int32_t set, double* k_m_host, double* k_v_host,
                                     int32_t* k_step_host) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->hyper_state(latent, set, k_m_host, k_v_host, k_step_host);
 }
 agp_status agp_svgp_set_quadrature(agp_svgp* h, const double* gh_nodes_host, const double* gh_weights_host,
                                    int32_t n_nodes) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->set_quadrature(gh_nodes_host, gh_weights_host, n_nodes);
 }
 agp_status agp_svgp_set_lsm_alpha(agp_svgp* h, const void* alpha, int64_t n) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->set_lsm_alpha(alpha, n);
 }
 agp_status agp_svgp_get_lik_param(agp_svgp* h, double* out) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->get_lik_param(out);
 }
 agp_status agp_svgp_set_lik_param(agp_svgp* h, double value) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->set_lik_param(value);
 }
 
@@ -4233,28 +4421,28 @@ agp_status agp_comm_stats(agp_comm* cm, int64_t* n_calls_host, int64_t* bytes_ho
 
 agp_status agp_svgp_cavi_step_multi(agp_svgp* h, agp_comm* comm, int32_t mode, const void* x, int64_t ldx, const void* y,
                                     const int64_t* idx, int64_t B, double rho) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->cavi_step_multi(comm, mode, x, ldx, y, idx, B, rho);
 }
 agp_status agp_svgp_elbo_multi(agp_svgp* h, agp_comm* comm, int32_t mode, double* elbo_host) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->elbo_multi(comm, mode, elbo_host);
 }
 agp_status agp_svgp_hyper_step_multi(agp_svgp* h, agp_comm* comm, int32_t tied) {
-  HCHK(h);
+  HCHKF(h);
   return h->impl->hyper_step_multi(comm, tied);
 }
 agp_status agp_svgp_predict_multi(agp_svgp* h, agp_comm* comm, int32_t what, const void* xt, int64_t ldx, int64_t n_t,
                                   void* mu_out, void* var_out, const double* gh_nodes_host, const double* gh_weights_host,
                                   int32_t n_nodes) {
-  HCHK(h);
+  HCHKF(h);
   if (n_t == 0) return AGP_OK;  // no test points: nothing to write (the reference returns empty arrays)
   return h->impl->predict_multi(comm, what, xt, ldx, n_t, mu_out, var_out, gh_nodes_host, gh_weights_host, n_nodes);
 }
 
 agp_status agp_svgp_proba_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, const double* gh_nodes_host,
                             const double* gh_weights_host, int32_t n_nodes, void* out0, void* out1) {
-  HCHK(h);
+  HCHKF(h);
   if (n_t == 0) return AGP_OK;  // no test points: nothing to write (the reference returns empty arrays)
   return h->impl->proba_y(xt, ldx, n_t, gh_nodes_host, gh_weights_host, n_nodes, out0, out1);
 }

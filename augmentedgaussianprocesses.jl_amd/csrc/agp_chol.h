@@ -1358,14 +1358,90 @@ struct ChainPrefetch {
   }
 };
 
+// ---- PRO: the natural-gradient step of the PREVIOUS minibatch as the prologue of the task graph (round 3) -------------------------
+// Until round 2 the fused product  S = kappa' diag(w) kappa  + eta2 step ran as a kernel of its own between two task graphs
+// (k_syrk_tn<SY_ETA2>, 53 us at C2, all 136 tiles finishing together) although the chain only needs block column 0 of the new
+// -2 eta2 at first and one more column every ~18 us.  With PRO the launch of step t+1 takes the pending step of minibatch t itself:
+//   * every matrix-tile workgroup (R, c) forms its own tile of S -- split along k over ks[c] workgroups for the first block
+//     columns (HELPER workgroups, dispatched right before the column's tile workgroups; they wait for nothing, so the dispatch-
+//     order argument of the task graph is untouched), whole for the later ones, which have tens of microseconds of slack;
+//   * it then applies  eta2 += lr (-(S + K^-1/2) - eta2)  (analyticVI.jl:172-180, 229-246), writes eta2 home (both triangles) and
+//     keeps A = -2 eta2 in its accumulators: the matrix never travels through memory between the step and the factorisation;
+//   * the tile of the [eta1' ; 0] extension row in block column c takes  eta1 += lr (kappa' r + K^-1 mu0 - eta1)  for its 64
+//     entries (analyticVI.jl:160-169) the same way.
+// The prologue of a workgroup finishes before its first abortable wait, and helpers never wait: eta1 / eta2 are completely
+// updated even when the factorisation behind them is aborted, so the in-stream fallback (k_chol_safe) finds its sources intact.
+// Partial tiles travel through sentinel-validated hand-over slots like every other tile; summation order is fixed (own slice,
+// then helpers 1, 2, ...), so results are bitwise reproducible.
+template <typename T>
+struct ProArgs {
+  const T* kap = nullptr;  // kappa of the minibatch whose natural-gradient step is pending (Kdim x ldk)
+  int64_t ldk = 0, Kdim = 0;
+  const T* w = nullptr;    // rho grad_E_Sigma   [Kdim]
+  const T* r = nullptr;    // rho grad_E_mu      [Kdim]
+  T* eta2 = nullptr;
+  const T* Kinv = nullptr;
+  int64_t ldm = 0;
+  T* eta1 = nullptr;
+  const T* kinv_mu0 = nullptr;
+  T lr = T(0);
+  T* HS = nullptr;           // hand-over slots of the helpers' partial tiles (sentinel-filled like the rest of the area)
+  int32_t* sflags = nullptr; // one flag per helper (stride DAG_FS)
+  T* fill = nullptr;         // hand-over set used by the PREVIOUS launch: refilled with the sentinel by the trailing workgroups
+  int64_t fill_n = 0;
+  int32_t nfill = 0;
+  unsigned char ks[32] = {};  // k-slices per block column (1: the tile workgroup forms the whole product itself)
+};
+
+// acc += sum over the 64-row chunks [q0, q1) of kappa of  (w .* kappa[:, R0 + .])' kappa[:, c0 + .]  -- 64-deep chunks staged in
+// LDS as [r][k] tiles (the layout mma8 reads), two buffer pairs alternating, the next chunk's global loads in flight during the
+// product.  sm: 4 * TILE * LDP elements.  All 512 threads; ends with a barrier (sm is free again).
+template <typename T>
+__device__ __forceinline__ void pro_slice(const T* __restrict__ kap, int64_t ldk, const T* __restrict__ w, int64_t R0, int64_t c0,
+                                          int64_t q0, int64_t q1, T* sm, Acc8<T>& acc) {
+  constexpr int Q = TILE * TILE / CHOL_THREADS;  // 8
+  const int r = threadIdx.x & 63, kb = threadIdx.x >> 6;
+  const bool dg = R0 == c0;
+  T va[Q], vb[Q], wv[Q];
+  auto ldg = [&](int64_t qc) {
+    const T* __restrict__ p = kap + (qc * TILE) * ldk;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int k = kb + 8 * q;
+      va[q] = p[k * ldk + R0 + r];
+      vb[q] = dg ? T(0) : p[k * ldk + c0 + r];
+      wv[q] = w[qc * TILE + k];
+    }
+  };
+  if (q0 < q1) ldg(q0);
+  int cur = 0;
+  for (int64_t qc = q0; qc < q1; ++qc) {
+    T* As = sm + cur * 2 * TILE * LDP;
+    T* Bs = As + TILE * LDP;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int k = kb + 8 * q;
+      As[r * LDP + k] = va[q] * wv[q];
+      Bs[r * LDP + k] = dg ? va[q] : vb[q];
+    }
+    __syncthreads();
+    if (qc + 1 < q1) ldg(qc + 1);
+    mma8<T>(As, Bs, acc);
+    cur ^= 1;
+  }
+  __syncthreads();
+}
+
 // STEP: the launch of a CAVI step (no identity rows, X_k and L not wanted in their real homes) with those three facts known at
 // compile time -- the general form carries the code and the registers of all of them through the chain.
-template <typename T, bool FUSED, bool BATCH = false, bool TRACE = false, bool STEP = false>
+template <typename T, bool FUSED, bool BATCH = false, bool TRACE = false, bool STEP = false, bool PRO = false>
 __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ldx,
                                                            int64_t lde, int64_t ne, int64_t nt,
                                                            int32_t* __restrict__ info, int64_t nvalid, int32_t* flags,
                                                            int32_t epoch, unsigned long long* trace, T* H, int64_t hstride,
-                                                           int64_t nx_, const T* __restrict__ erow, int opts, DagSync sync) {
+                                                           int64_t nx_, const T* __restrict__ erow, int opts, DagSync sync,
+                                                           ProArgs<T> pro = ProArgs<T>{}) {
+  static_assert(!PRO || (FUSED && STEP && !BATCH), "the prologue exists for the single-problem CAVI-step launch only");
   // opts bit 0: the chain also stores X_k to its real home (a single block column wanting its inverse: no identity rows run)
   //      bit 1: the factor L is wanted in its real home A as well (K's factor, the potrf entry points); the CAVI step only
   //             consumes the extension rows W, v and never reads L itself, so its launches skip those stores
@@ -1405,10 +1481,46 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   T* bufB = sm + TILE * LDP;
   const int tid = threadIdx.x;
   // column-major tile numbering: column c holds its diagonal tile, rows c+1..nt-1, then the ne extension blocks
+  // (PRO: the (nt - c)(ks[c] - 1) helper workgroups of a column come right before its tiles; refill workgroups after everything)
   int64_t b = bidx, c = 0;
-  while (b >= nt - c + ne + (nx ? c + 1 : 0)) {
-    b -= nt - c + ne + (nx ? c + 1 : 0);
-    ++c;
+  bool helper = false;
+  int64_t hbase = 0;  // PRO: helper slots of the columns before c
+  if (PRO) {
+    for (;;) {
+      if (c == nt) {  // trailing workgroups: the hand-over set the launch before this one used gets its sentinels back
+        const T sv = __builtin_bit_cast(T, Sent<T>::bits);
+        for (int64_t i = b * CHOL_THREADS + tid; i < pro.fill_n; i += (int64_t)pro.nfill * CHOL_THREADS) pro.fill[i] = sv;
+        return;
+      }
+      const int64_t nh = (nt - c) * (pro.ks[c] - 1), ntile = nt - c + ne;
+      if (b < nh) {
+        helper = true;
+        break;
+      }
+      b -= nh;
+      if (b < ntile) break;
+      b -= ntile;
+      hbase += nh;
+      ++c;
+    }
+  } else {
+    while (b >= nt - c + ne + (nx ? c + 1 : 0)) {
+      b -= nt - c + ne + (nx ? c + 1 : 0);
+      ++c;
+    }
+  }
+  if (PRO && helper) {  // one k-slice of S(R, c): no dependencies, one store of the partial tile, done
+    const int ksc = pro.ks[c];
+    const int64_t tb = b / (ksc - 1), sl = 1 + b % (ksc - 1), nq = pro.Kdim / TILE;
+    Acc8<T> S;
+    S.zero();
+    pro_slice<T>(pro.kap, pro.ldk, pro.w, (c + tb) * TILE, c * TILE, sl * nq / ksc, (sl + 1) * nq / ksc, sm, S);
+    T* hs = pro.HS + (hbase + b) * (TILE * TILE);
+    acc8_foreach<T>(S, [&](int r, int cc, T& val) {
+      __hip_atomic_store(hs + r * TILE + cc, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    });
+    dag_signal(pro.sflags + (hbase + b) * DAG_FS, epoch);
+    return;
   }
   const bool diag = b == 0, ext = b >= nt - c, idr = b >= nt - c + ne;  // idr: identity row i = b - (nt - c + ne) <= c
   const int64_t R = idr ? nt + ne + (b - (nt - c + ne)) : ext ? nt + (b - (nt - c)) : c + b;  // block row in [0, nt+ne+nx)
@@ -1424,18 +1536,122 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
 #define DAG_TRC(col, slot) \
   if (TRACE && tid == 0) trace[chain_slot(col, nt, ne, nx) * 8 + (slot)] = wall_clock64()
   DAG_TR(0);
-  if (STEP && !BATCH && sync.started && bidx == 0 && tid == 0)
+  const bool chain = FUSED && c == 0 && b == 0;  // (PRO: no longer workgroup 0 -- the helpers of column 0 come first)
+  if (STEP && !BATCH && sync.started && chain && tid == 0)
     __hip_atomic_store(sync.started, sync.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   Acc8<T> acc;
-  if (idr) {
+  if (PRO && !ext) {
+    // ---- prologue of a matrix tile: S(R, c) (own k-slice + the helpers' partial tiles), the eta2 step, A = -2 eta2 -> acc
+    const int ksc = pro.ks[c];
+    const int64_t nq = pro.Kdim / TILE;
+    acc.zero();
+    pro_slice<T>(pro.kap, pro.ldk, pro.w, R * TILE, c0, 0, nq / ksc, sm, acc);
+    // eta2 and K^-1 of the tile: in flight while the helpers' tiles are fetched
+    Acc8<T> e2v, kiv;
+    acc8_foreach<T>(e2v, [&](int r, int cc, T& val) { val = pro.eta2[(R * TILE + r) * pro.ldm + c0 + cc]; });
+    acc8_foreach<T>(kiv, [&](int r, int cc, T& val) { val = pro.Kinv[(R * TILE + r) * pro.ldm + c0 + cc]; });
+    if (ksc > 1) {
+      const int64_t h0 = hbase + b * (ksc - 1);
+      if (tid == 0) {  // helpers have lower workgroup indices and wait for nothing: they always arrive
+        long spins = 0;
+        for (int q = 0; q < ksc - 1; ++q)
+          while (__hip_atomic_load(pro.sflags + (h0 + q) * DAG_FS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1L << 28)) {  // minutes: the device is gone
+              atomicExch(info, -3);
+              break;
+            }
+          }
+      }
+      __syncthreads();
+      for (int q0 = 0; q0 < ksc - 1; q0 += 4) {
+        T pv[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q0 + q < ksc - 1) {
+            const T* hs = pro.HS + (h0 + q0 + q) * (TILE * TILE);
+            int e = 0;
+            acc8_foreach<T>(acc, [&](int r, int cc, T& val) {
+              (void)val;
+              pv[q][e++] = __hip_atomic_load(hs + r * TILE + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            });
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q0 + q < ksc - 1) {
+            const T* hs = pro.HS + (h0 + q0 + q) * (TILE * TILE);
+            int e = 0;
+            acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val += hv_settle<T>(hs + r * TILE + cc, pv[q][e++]); });
+          }
+        }
+      }
+    }
+    {
+      int e = 0;
+      const T lr = pro.lr;
+      acc8_foreach<T>(acc, [&](int r, int cc, T& val) {  // the step of the fused epilogue (k_syrk_tn<SY_ETA2>), same operations
+        const int mi = e >> 2, rr = e & 3;
+        ++e;
+        T e2 = e2v.a[mi][rr];
+        const T g = -(val + T(0.5) * kiv.a[mi][rr]) - e2;
+        e2 += lr * g;
+        val = e2;
+      });
+    }
+    if (diag) {  // the lower half is the truth, the upper half its mirror image (as the fused epilogue does it)
+      acc8_foreach<T>(acc, [&](int r, int cc, T& val) { bufA[r * LDP + cc] = val; });
+      __syncthreads();
+      acc8_foreach<T>(acc, [&](int r, int cc, T& val) {
+        if (cc > r) val = bufA[cc * LDP + r];
+        pro.eta2[(c0 + r) * pro.ldm + c0 + cc] = val;
+        val *= T(-2);
+      });
+      __syncthreads();
+    } else {
+      acc8_foreach<T>(acc, [&](int r, int cc, T& val) {
+        pro.eta2[(R * TILE + r) * pro.ldm + c0 + cc] = val;
+        pro.eta2[(c0 + cc) * pro.ldm + R * TILE + r] = val;
+        val *= T(-2);
+      });
+    }
+  } else if (idr) {
     const bool on_diag = (R - nt - ne) == c;
     acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = (on_diag && r == cc) ? T(1) : T(0); });
+  } else if (PRO && ext && R == nt + ne - 1) {
+    // ---- prologue of the [eta1' ; 0] tile: t = kappa[:, c0 ..]' r (eight row groups, fixed order), eta1 step, row 0 <- eta1
+    const int col = tid & 63, grp = tid >> 6;
+    T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
+    int64_t k = grp;
+    for (; k + 24 < pro.Kdim; k += 32) {
+      const T a0 = pro.kap[k * pro.ldk + c0 + col], a1 = pro.kap[(k + 8) * pro.ldk + c0 + col];
+      const T a2 = pro.kap[(k + 16) * pro.ldk + c0 + col], a3 = pro.kap[(k + 24) * pro.ldk + c0 + col];
+      s0 += a0 * pro.r[k];
+      s1 += a1 * pro.r[k + 8];
+      s2 += a2 * pro.r[k + 16];
+      s3 += a3 * pro.r[k + 24];
+    }
+    for (; k < pro.Kdim; k += 8) s0 += pro.kap[k * pro.ldk + c0 + col] * pro.r[k];
+    sc[grp * TILE + col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0) {
+      T t = T(0);
+#pragma unroll
+      for (int q = 0; q < CHOL_THREADS / 64; ++q) t += sc[q * TILE + col];
+      T e = pro.eta1[c0 + col];
+      e += pro.lr * (t + (pro.kinv_mu0 ? pro.kinv_mu0[c0 + col] : T(0)) - e);
+      pro.eta1[c0 + col] = e;
+      sc[CHOL_THREADS + col] = e;
+    }
+    __syncthreads();
+    acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = r == 0 ? sc[CHOL_THREADS + cc] : T(0); });
+    __syncthreads();
   } else if (erow && ext && R == nt + ne - 1) {
     acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = r == 0 ? erow[c0 + cc] : T(0); });
   } else {
     acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = rowp[r * ldr + c0 + cc]; });
   }
-  if (FUSED && bidx == 0) {
+  if (chain) {
     // ---- the chain: ONE workgroup carries the critical path through all columns, so that per column only the tile
     // factorisation and two 64^3 products are serial:  factor(c) -> L(c+1,c) = T X_c' -> S = D - L L' -> factor(c+1).
     // T = tile (c+1, c) and D = tile (c+1, c+1) arrive with all their other updates already applied by feeder workgroups.

@@ -214,6 +214,8 @@ static bool chol_use_dag(const agp_ctx* c, int64_t nt, int64_t ne = 0, int64_t n
 }
 
 __global__ void k_set_i32(int32_t* p, int32_t v) { *p = v; }
+// ... visible to a polling kernel of another stream (signal memory, system scope)
+__global__ void k_set_sig(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // grid-barrier words, retry counter and the CU count of the fallback (allocated on first use)
 template <typename T>
@@ -450,8 +452,9 @@ static void pro_ks_table(int64_t nt, int64_t nq, bool f64, unsigned char* ks) {
   for (int64_t c = 0; c < nt && c < 32; ++c) {
     int want;
     if (!env.empty()) want = env[std::min<size_t>((size_t)c, env.size() - 1)];
-    else if (c < 2) want = 8;
-    else want = (int)std::ceil((double)nq * tc / (tau * (double)c - 8.0));
+    else if (c == 0) want = 8;
+    else if (c == 1) want = f64 ? 4 : 8;
+    else want = (int)std::ceil((double)nq * (tc + 0.3) / (tau * (double)c - 12.0));
     want = std::max(1, std::min<int>(want, (int)std::min<int64_t>(8, nq)));
     ks[c] = (unsigned char)want;
   }
@@ -559,9 +562,33 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
         pa.nfill = 64;
         c->h_dirty[other].on = false;
       }
+      // development aids: AGP_PRO_TRACE=<file> dumps the prologue's wall-clock stamps of the 50th launch; AGP_PRO_LDS_PAD=<bytes>
+      // of dynamic LDS per workgroup (f32: two workgroups share a CU unless padded beyond 80 KB)
+      static const char* pro_trace_path = getenv("AGP_PRO_TRACE");
+      static const unsigned lds_pad = []() {
+        const char* e = getenv("AGP_PRO_LDS_PAD");
+        return e ? (unsigned)atoi(e) : 0u;
+      }();
+      static int pro_launches = 0;
+      unsigned long long* ptrace = nullptr;
+      if (pro_trace_path && ++pro_launches == 50) {
+        if (hipMalloc((void**)&ptrace, 2048 * 8) != hipSuccess) ptrace = nullptr;
+        if (ptrace) (void)hipMemsetAsync(ptrace, 0, 2048 * 8, c->stream);
+      }
       hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, true>), dim3((unsigned)(ntiles + nhelp + pa.nfill)),
-                         dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags,
-                         c->dag_epoch, trace, H, hstride, nx, erow, 0, ds, pa);
+                         dim3(CHOL_THREADS), lds_pad, c->stream, one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid,
+                         c->dag_flags, c->dag_epoch, ptrace, H, hstride, nx, erow, 0, ds, pa);
+      if (ptrace) {
+        std::vector<unsigned long long> hq(2048);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemcpy(hq.data(), ptrace, 2048 * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(ptrace);
+        if (FILE* f = fopen(pro_trace_path, "w")) {
+          for (size_t i = 0; i < hq.size(); ++i)
+            if (hq[i]) fprintf(f, "%zu %llu\n", i, hq[i]);
+          fclose(f);
+        }
+      }
       c->h_step_set = other;
     } else if (step_inst)  // the CAVI step's launch: specialised instantiation
       hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1,
@@ -1078,7 +1105,10 @@ struct Svgp : SvgpBase {
   // a step's kappa buffers -- what the NEXT look-ahead but one waits for -- is either an event recorded on the stream
   // (slot_kind 0) or, when the step after it starts with a task graph that stores its `started` number, that number (slot_kind
   // 1: nothing is enqueued on the stream).  Which one is only known when the next step is enqueued, hence rel_pending.
-  int32_t* sig[1] = {nullptr};
+  // sig[1] = "look-ahead done" (round 3): written by a one-thread kernel behind the look-ahead's GEMM, polled by a one-wave kernel
+  // at the head of the step that adopts the buffers -- the cross-stream event wait cost the step's queue ~6 us of idling
+  int32_t* sig[2] = {nullptr, nullptr};
+  int32_t pf_seq = 0;
   int sig_state = 0;  // 0 not tried, 1 usable, -1 not available / switched off (AGP_PF_INKERNEL=0)
   int32_t started_seq = 0;
   bool rel_pending = false;
@@ -1141,6 +1171,10 @@ struct Svgp : SvgpBase {
       return e && e[0] == '0';
     }();
     if (off || nl != 1 || mo || mo_sharded) return false;
+    // only where the launch is not bound by workgroup slots: at 32 block columns (C3) the task graph already queues 1584 tile
+    // workgroups through 256 slots, and the product's 27 ms of CU time inside it costs more than the kernel of its own (measured:
+    // 0.70 -> 0.86-0.96 ms per step with any k-split table)
+    if (mp / TILE > 16) return false;
     const int k = lp.kind;
     return k == AGP_LIK_GAUSSIAN || k == AGP_LIK_LOGISTIC || k == AGP_LIK_STUDENTT || k == AGP_LIK_LAPLACE ||
            k == AGP_LIK_BAYESIANSVM || k == AGP_LIK_NEGBINOMIAL || k == AGP_LIK_POISSON;
@@ -1725,7 +1759,15 @@ struct Svgp : SvgpBase {
       if (!use_pro) AGPCHK(flush());
     }
     if (prefetched) {  // kappa of this minibatch was produced on the prefetch stream: adopt those buffers
-      HIPCHK(ctx, hipStreamWaitEvent(st(), pf_done, 0));
+      static const bool pf_poll = []() {  // AGP_PF_POLL=0: wait for the look-ahead with an event (A/B measurements)
+        const char* e = getenv("AGP_PF_POLL");
+        return !(e && e[0] == '0');
+      }();
+      if (sig_state == 1 && pf_poll) {
+        hipLaunchKernelGGL(k_wait_ge_fast, dim3(1), dim3(64), 0, st(), (const int32_t*)sig[1], pf_seq, info_dev);
+        LAUNCHCHK(ctx);
+      } else
+        HIPCHK(ctx, hipStreamWaitEvent(st(), pf_done, 0));
       for (auto& g : lat) {
         std::swap(g.Knm, g.Knm_alt);
         std::swap(g.Wbuf, g.Wbuf_alt);
@@ -2519,6 +2561,11 @@ struct Svgp : SvgpBase {
     ctx->stream = keep_stream;
     AGPCHK(rc);
     HIPCHK(ctx, hipEventRecord(pf_done, pf_stream));
+    if (sig_state == 1) {
+      pf_seq += 1;
+      hipLaunchKernelGGL(k_set_sig, dim3(1), dim3(1), 0, pf_stream, sig[1], pf_seq);
+      LAUNCHCHK(ctx);
+    }
     pf_valid = true;
     pf_x = x;
     pf_idx = idx;

@@ -1261,6 +1261,20 @@ __global__ void k_wait_ge(const int32_t* __restrict__ p, int32_t want, int32_t* 
   }
 }
 
+// the step stream's side of the other direction (round 3): the look-ahead's "done" word instead of a cross-stream event wait.
+// Short naps: in the steady state the word is set long before this kernel runs, and when it is not, the step is waiting.
+__global__ void k_wait_ge_fast(const int32_t* __restrict__ p, int32_t want, int32_t* __restrict__ info) {
+  if (threadIdx.x != 0) return;
+  long spins = 0;
+  while ((int32_t)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+    __builtin_amdgcn_s_sleep(8);
+    if (++spins > (1L << 27)) {
+      atomicExch(info, -2);
+      break;
+    }
+  }
+}
+
 // every thread's hand-over stores acknowledged by the L2 -> barrier -> flag
 __device__ __forceinline__ void dag_signal(int32_t* flag, int32_t epoch) {
   // the flag is a hint (see "self-validating hand-over"): waiting for the L2's acknowledgement of the stores just makes it a
@@ -1373,6 +1387,35 @@ struct ChainPrefetch {
 // updated even when the factorisation behind them is aborted, so the in-stream fallback (k_chol_safe) finds its sources intact.
 // Partial tiles travel through sentinel-validated hand-over slots like every other tile; summation order is fixed (own slice,
 // then helpers 1, 2, ...), so results are bitwise reproducible.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte device-coherent load (the compiler has no such builtin: its agent-scope atomic loads stop at 8 bytes).  Every aligned
+// 4- / 8-byte part of the result is a single-copy-atomic read, which is all the sentinel validation needs.  The caller waits with
+// wait_vmcnt0() before touching the result (the compiler does not count these loads).
+__device__ __forceinline__ u32x4 load16_sc1(const void* p) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <typename T>
+__device__ __forceinline__ T vec16_elem(u32x4 v, int i);
+template <>
+__device__ __forceinline__ double vec16_elem<double>(u32x4 v, int i) {
+  const unsigned long long u = ((unsigned long long)v[2 * i + 1] << 32) | v[2 * i];
+  return __builtin_bit_cast(double, u);
+}
+template <>
+__device__ __forceinline__ float vec16_elem<float>(u32x4 v, int i) {
+  return __builtin_bit_cast(float, (unsigned int)v[i]);
+}
+// where thread `tid` keeps its e-th accumulator element (Acc8 order) inside a helper's slot: consecutive threads own consecutive
+// 16-byte groups, so both the helper's stores and the tile workgroup's 16-byte loads are contiguous across a wave
+template <typename T>
+__device__ __forceinline__ int pro_slot_off(int tid, int e) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  return (e / VEC) * (CHOL_THREADS * VEC) + tid * VEC + (e % VEC);
+}
+
 template <typename T>
 struct ProArgs {
   const T* kap = nullptr;  // kappa of the minibatch whose natural-gradient step is pending (Kdim x ldk)
@@ -1509,16 +1552,27 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
       ++c;
     }
   }
+  // development aid (AGP_PRO_TRACE): wall-clock stamps of the prologue -- chain [0..7], tiles (R, c) with R, c < 4 at
+  // 64 + 8 (4 R + c), end of factor(k) at 512 + k, the first helper of tile (0, 0) at 1024
+#define PRO_TS(i) \
+  if (PRO && trace && tid == 0) trace[i] = wall_clock64()
   if (PRO && helper) {  // one k-slice of S(R, c): no dependencies, one store of the partial tile, done
     const int ksc = pro.ks[c];
     const int64_t tb = b / (ksc - 1), sl = 1 + b % (ksc - 1), nq = pro.Kdim / TILE;
     Acc8<T> S;
     S.zero();
+    if (c == 0 && b == 0) PRO_TS(1024);
     pro_slice<T>(pro.kap, pro.ldk, pro.w, (c + tb) * TILE, c * TILE, sl * nq / ksc, (sl + 1) * nq / ksc, sm, S);
+    if (c == 0 && b == 0) PRO_TS(1025);
     T* hs = pro.HS + (hbase + b) * (TILE * TILE);
-    acc8_foreach<T>(S, [&](int r, int cc, T& val) {
-      __hip_atomic_store(hs + r * TILE + cc, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    });
+    {
+      int e = 0;
+      acc8_foreach<T>(S, [&](int r, int cc, T& val) {
+        (void)r;
+        (void)cc;
+        __hip_atomic_store(hs + pro_slot_off<T>(tid, e++), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      });
+    }
     dag_signal(pro.sflags + (hbase + b) * DAG_FS, epoch);
     return;
   }
@@ -1544,49 +1598,56 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
     // ---- prologue of a matrix tile: S(R, c) (own k-slice + the helpers' partial tiles), the eta2 step, A = -2 eta2 -> acc
     const int ksc = pro.ks[c];
     const int64_t nq = pro.Kdim / TILE;
+    const int tsb = chain ? 0 : (R < 4 && c < 4) ? 64 + 8 * (4 * (int)R + (int)c) : 2040;
+    PRO_TS(tsb);
     acc.zero();
     pro_slice<T>(pro.kap, pro.ldk, pro.w, R * TILE, c0, 0, nq / ksc, sm, acc);
+    PRO_TS(tsb + 1);
     // eta2 and K^-1 of the tile: in flight while the helpers' tiles are fetched
     Acc8<T> e2v, kiv;
     acc8_foreach<T>(e2v, [&](int r, int cc, T& val) { val = pro.eta2[(R * TILE + r) * pro.ldm + c0 + cc]; });
     acc8_foreach<T>(kiv, [&](int r, int cc, T& val) { val = pro.Kinv[(R * TILE + r) * pro.ldm + c0 + cc]; });
     if (ksc > 1) {
       const int64_t h0 = hbase + b * (ksc - 1);
-      if (tid == 0) {  // helpers have lower workgroup indices and wait for nothing: they always arrive
+      if (tid < ksc - 1) {  // one poller per helper; helpers have lower workgroup indices and wait for nothing: they always arrive
         long spins = 0;
-        for (int q = 0; q < ksc - 1; ++q)
-          while (__hip_atomic_load(pro.sflags + (h0 + q) * DAG_FS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1L << 28)) {  // minutes: the device is gone
-              atomicExch(info, -3);
-              break;
-            }
+        while (__hip_atomic_load(pro.sflags + (h0 + tid) * DAG_FS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1L << 28)) {  // minutes: the device is gone
+            atomicExch(info, -3);
+            break;
           }
+        }
       }
       __syncthreads();
-      for (int q0 = 0; q0 < ksc - 1; q0 += 4) {
-        T pv[4][8];
+      PRO_TS(tsb + 2);
+      // the helpers' tiles: thread-major slots (pro_slot_off), fetched with 16-byte coherent loads, all of them in flight at once
+      // (8-byte loads, four tiles at a time, took the chain 4.9 us for seven tiles), then added in helper order
+      constexpr int VEC = 16 / (int)sizeof(T), NV = 8 / VEC;
+      u32x4 pv[7][NV];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (q0 + q < ksc - 1) {
-            const T* hs = pro.HS + (h0 + q0 + q) * (TILE * TILE);
-            int e = 0;
-            acc8_foreach<T>(acc, [&](int r, int cc, T& val) {
-              (void)val;
-              pv[q][e++] = __hip_atomic_load(hs + r * TILE + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            });
-          }
-        }
+      for (int q = 0; q < 7; ++q)
+        if (q < ksc - 1) {
+          const T* hs = pro.HS + (h0 + q) * (TILE * TILE);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (q0 + q < ksc - 1) {
-            const T* hs = pro.HS + (h0 + q0 + q) * (TILE * TILE);
-            int e = 0;
-            acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val += hv_settle<T>(hs + r * TILE + cc, pv[q][e++]); });
-          }
+          for (int j = 0; j < NV; ++j) pv[q][j] = load16_sc1(hs + pro_slot_off<T>(tid, j * VEC));
         }
-      }
+      wait_vmcnt0();
+#pragma unroll
+      for (int q = 0; q < 7; ++q)
+        if (q < ksc - 1) {
+          const T* hs = pro.HS + (h0 + q) * (TILE * TILE);
+          int e = 0;
+          acc8_foreach<T>(acc, [&](int r, int cc, T& val) {
+            (void)r;
+            (void)cc;
+            const T got = vec16_elem<T>(pv[q][e / VEC], e % VEC);
+            val += hv_settle<T>(hs + pro_slot_off<T>(tid, e), got);
+            ++e;
+          });
+        }
     }
+    PRO_TS(tsb + 3);
     {
       int e = 0;
       const T lr = pro.lr;
@@ -1615,6 +1676,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
         val *= T(-2);
       });
     }
+    PRO_TS(tsb + 4);
   } else if (idr) {
     const bool on_diag = (R - nt - ne) == c;
     acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = (on_diag && r == cc) ? T(1) : T(0); });
@@ -1679,6 +1741,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
       if (tid == 0) pf_ok = pf_bad = 0;
       factor_diag_tile_2lvl<T, ChainPrefetch<T>>(bufA, bufB, sc, piv, info, k0, nvalid, pf);
       DAG_TRC(k, 2);
+      PRO_TS(512 + k);
       {  // X_k out (coherent): all LDS reads first, then the stores back to back (a read-store-read-store loop exposed the
          // LDS latency eight times: 0.6 us on the chain)
         T xv[TILE * TILE / CHOL_THREADS];
@@ -1795,6 +1858,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
       __hip_atomic_store(park + r * TILE + cc, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     });
     dag_signal((f1 ? pre1 + (c + 1) * DAG_FS : pre2 + c * DAG_FS), epoch);
+    if (R < 4 && c < 4) PRO_TS(64 + 8 * (4 * (int)R + (int)c) + 5);
     if (f2) {
       DAG_TR(6);
     } else {
@@ -1842,6 +1906,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   DAG_TR(3);
 #undef DAG_TR
 #undef DAG_TRC
+#undef PRO_TS
 }
 
 // fills the hand-over area with the sentinel (normally rider workgroups of the next k_syrk_tn launch do this; this kernel is the

@@ -1943,17 +1943,24 @@ struct Svgp : SvgpBase {
       const int nb = (int)((B + 255) / 256);
       hipLaunchKernelGGL((k_poisson_partial<T>), dim3(nb), dim3(256), 0, st(), B, (const T*)y, idx, (const T*)muf,
                          (const T*)varf, gh_n, (const double*)gh_dev, (const double*)(gh_dev + gh_n), lam_part);
-      hipLaunchKernelGGL((k_lambda_finish<T>), dim3(1), dim3(256), 0, st(), nb, 2, (const double*)lam_part, 0, (double)B,
-                         lam_dev);
+      if (lam_deferred)  // batch-sharded: the sums travel first (cavi_step_multi), lambda_finish_reduced() follows
+        hipLaunchKernelGGL(k_lambda_reduce, dim3(1), dim3(256), 0, st(), nb, 2, (const double*)lam_part, (double)B, scal_dev + 60);
+      else
+        hipLaunchKernelGGL((k_lambda_finish<T>), dim3(1), dim3(256), 0, st(), nb, 2, (const double*)lam_part, 0, (double)B,
+                           lam_dev);
       LAUNCHCHK(ctx);
     } else if (lp.kind == AGP_LIK_HETEROSCEDASTIC) {  // heteroscedastic.jl:71-129
       const int nb = (int)((B + 255) / 256);
       hipLaunchKernelGGL((k_hetero_local<T>), dim3(nb), dim3(256), 0, st(), B, Bp, (const T*)y, idx, (const T*)muf,
                          (const T*)varf, (const T*)lam_dev, cbuf, gamma, theta, lam_part);
-      hipLaunchKernelGGL((k_lambda_finish<T>), dim3(1), dim3(256), 0, st(), nb, 1, (const double*)lam_part, 1, (double)B,
-                         lam_dev);
-      hipLaunchKernelGGL((k_hetero_grads<T>), dim3(nb), dim3(256), 0, st(), B, Bp, (T)rho, (const T*)y, idx,
-                         (const T*)lam_dev, (const T*)gamma, theta, rbuf, wbuf);
+      if (lam_deferred) {
+        hipLaunchKernelGGL(k_lambda_reduce, dim3(1), dim3(256), 0, st(), nb, 1, (const double*)lam_part, (double)B, scal_dev + 60);
+      } else {
+        hipLaunchKernelGGL((k_lambda_finish<T>), dim3(1), dim3(256), 0, st(), nb, 1, (const double*)lam_part, 1, (double)B,
+                           lam_dev);
+        hipLaunchKernelGGL((k_hetero_grads<T>), dim3(nb), dim3(256), 0, st(), B, Bp, (T)rho, (const T*)y, idx,
+                           (const T*)lam_dev, (const T*)gamma, theta, rbuf, wbuf);
+      }
       LAUNCHCHK(ctx);
     }
     x_last = x;
@@ -2110,7 +2117,7 @@ struct Svgp : SvgpBase {
     hipLaunchKernelGGL((k_axpby<T>), grid1(mp), dim3(256), 0, st(), mp, T(1), (const T*)g.apred, T(-1),
                        (const T*)g.kinv_mu0, tmpv);
     hipLaunchKernelGGL((k_hyper_gK<T>), grid2(mp, mp), blk2, 0, st(), m, mp, (const T*)Tw, (const T*)g.Apred,
-                       (const T*)tmpv, Tw2);
+                       (const T*)tmpv, Tw2, (T)(1.0 / (double)bs_world));
     HIPCHK(ctx, hipMemsetAsync(hy_g, 0, sizeof(double) * (1 + D), st()));
     // backward through kernelmatrix(k, x, Z)  (gradient w.r.t. the second argument)
     {
@@ -2125,6 +2132,10 @@ struct Svgp : SvgpBase {
                          (const T*)hy_pZ, hy_dZ, T(1), 0);
     }
     const bool online_x = g.on && !g.on_first;
+    if (online_x && bs_world > 1) {
+      ctx->err = "hyper-gradient of a streaming (online) model on a batch-sharded handle is not wired";
+      return AGP_ERR_UNSUPPORTED;
+    }
     if (online_x) {
       // -extraKL (KLdivergences.jl:30-54) is part of the differentiated ELBO; its kernel matrices K_ab, kappa_a, K~_a are
       // recomputed with the candidate kernel / Z by compute_kappa(::OnlineVarLatent):
@@ -2323,8 +2334,14 @@ struct Svgp : SvgpBase {
 
   // update_hyperparameters!(m, state, x, y): ADAM ASCENT; positive kernel parameters are stepped in log space
   // (update_kernel!, autotuning_utils.jl:63-67), Z directly (update_Z!, :70-76).  K is refreshed before the next step.
+  bool hyper_multi_ok = false;
   agp_status hyper_step() override {
     if (!hy_k && !hy_z) return AGP_OK;
+    if (bs_world > 1 && !hyper_multi_ok) {
+      // every rank would step its kernel / Z with the gradient of its own shard and the replicas would drift apart
+      ctx->err = "batch-sharded handle: take the hyper step through agp_svgp_hyper_step_multi (the gradient is all-reduced)";
+      return AGP_ERR_INVALID;
+    }
     for (int l = 0; l < nl; ++l) {
       AGPCHK(hypergrad(l, nullptr, nullptr, nullptr));
       AGPCHK(hyper_apply_one(l, hy_last, (const T*)hy_dZ));
@@ -2601,6 +2618,18 @@ struct Svgp : SvgpBase {
     return AGP_OK;
   }
 
+  bool lam_deferred = false;  // set around step_local by the batch-sharded driver (see cavi_step_multi)
+  agp_status lambda_finish_reduced() {
+    const int mode = lp.kind == AGP_LIK_POISSON ? 0 : 1;
+    hipLaunchKernelGGL((k_lambda_finish_red<T>), dim3(1), dim3(64), 0, st(), (const double*)(scal_dev + 60), mode, lam_dev);
+    if (lp.kind == AGP_LIK_HETEROSCEDASTIC) {
+      const int nb = (int)((B_last + 255) / 256);
+      hipLaunchKernelGGL((k_hetero_grads<T>), dim3(nb), dim3(256), 0, st(), B_last, Bp, (T)rho_last, (const T*)y_last, idx_last,
+                         (const T*)lam_dev, (const T*)gamma, theta, rbuf, wbuf);
+    }
+    LAUNCHCHK(ctx);
+    return AGP_OK;
+  }
   double cur_lr() const {  // optimisers.jl:14-19 ; Descent(1.0) for AnalyticVI
     return desc.stochastic ? 1.0 / std::pow(desc.rm_tau + (double)n_opt, desc.rm_kappa) : 1.0;
   }
@@ -2923,9 +2952,21 @@ struct Svgp : SvgpBase {
   }
   double e_data = 0, kl_aug = 0, mo_e = 0, mo_kl = 0, kl_gauss_last = 0;
   bool shard_once = true;
+  // this handle sees shard bs_rank of bs_world of every minibatch (batch-parallel).  Set by agp_svgp_set_batch_shard and -- so that
+  // a host cannot forget it after a handle was re-created -- by every batch-mode *_multi call from its communicator.
+  int bs_rank = 0, bs_world = 1;
+  void adopt_batch_shard(const agp_comm* cm, int mode) {
+    if (mode == AGP_SHARD_BATCH && cm && cm->world > 1) {
+      bs_rank = cm->rank;
+      bs_world = cm->world;
+      shard_once = bs_rank == 0;
+    }
+  }
   agp_status set_batch_shard(int rank, int world) override {
     if (world < 1 || rank < 0 || rank >= world) return AGP_ERR_INVALID;
     shard_once = rank == 0;
+    bs_rank = rank;
+    bs_world = world;
     return AGP_OK;
   }
   agp_status elbo_terms(double* out3) override {
@@ -3346,12 +3387,20 @@ struct Svgp : SvgpBase {
       const char* e = getenv("AGP_FORCE_SPLIT");
       return e && e[0] == '1';
     }();
+    return comm_sum_typed(cm, buf, count, sizeof(T) == 8 ? AGP_F64 : AGP_F32, force);
+  }
+  agp_status comm_sum_typed(agp_comm* cm, void* buf, int64_t count, int dtype, bool force = false) {
+    if (!cm && mo_sharded && nl != qtot) {
+      // a handle that owns a slice of the latents cannot finish a mix, an ELBO or a prediction on its own
+      ctx->err = "latent-sharded multi-output handle: this call needs the communicator of the run (comm = NULL)";
+      return AGP_ERR_INVALID;
+    }
     if (!cm || (cm->world <= 1 && !force)) return AGP_OK;
     if (cm->ctx != ctx) {
       ctx->err = "agp_comm belongs to another ctx (its collectives would run on another stream)";
       return AGP_ERR_INVALID;
     }
-    return agp_comm_allreduce(cm, buf, count, sizeof(T) == 8 ? AGP_F64 : AGP_F32);
+    return agp_comm_allreduce(cm, buf, count, dtype);
   }
 
   agp_status cavi_step_multi(agp_comm* cm, int mode, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B,
@@ -3364,14 +3413,25 @@ struct Svgp : SvgpBase {
       return e && e[0] == '1';
     }();
     const bool multi = cm && (cm->world > 1 || (force_split && mode == AGP_SHARD_BATCH));
-    if (multi && (lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_HETEROSCEDASTIC)) {
-      // their lambda update (poisson.jl:78, heteroscedastic.jl:95) is a reduction over the whole minibatch that is not
-      // exchanged; the two heteroscedastic latents are coupled point-wise and stay on one handle
-      ctx->err = "Poisson / Heteroscedastic likelihoods are not wired for multi-GPU sharding";
+    adopt_batch_shard(cm, mode);
+    const bool lam_lik = lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_HETEROSCEDASTIC;
+    if (multi && lam_lik && mode == AGP_SHARD_LATENT) {
+      // a Poisson model has one latent, and the two heteroscedastic latents are coupled point-wise and stay on one handle:
+      // these models shard over the minibatch only
+      ctx->err = "Poisson / Heteroscedastic likelihoods shard over the minibatch (AGP_SHARD_BATCH), not over latents";
       return AGP_ERR_UNSUPPORTED;
     }
     if (mode == AGP_SHARD_BATCH && mo_sharded) return AGP_ERR_INVALID;
-    AGPCHK(step_local(x, ldx, y, idx, B, rho, false));
+    // batch-sharded Poisson / Heteroscedastic: lambda is re-estimated from sums over the WHOLE minibatch (poisson.jl:78,
+    // heteroscedastic.jl:94): the local update stops after its partial sums, three doubles are all-reduced, then it finishes
+    lam_deferred = multi && lam_lik;
+    const agp_status sl = step_local(x, ldx, y, idx, B, rho, false);
+    lam_deferred = false;
+    AGPCHK(sl);
+    if (multi && lam_lik) {
+      AGPCHK(comm_sum_typed(cm, scal_dev + 60, 3, AGP_F64, force_split));
+      AGPCHK(lambda_finish_reduced());
+    }
     const bool lsm = lp.kind == AGP_LIK_LOGISTICSOFTMAX;
     if (mode == AGP_SHARD_LATENT) {
       if (lsm) {
@@ -3405,6 +3465,7 @@ struct Svgp : SvgpBase {
 
   agp_status elbo_multi(agp_comm* cm, int mode, double* out) override {
     if (!out || !x_last || B_last <= 0) return AGP_ERR_INVALID;
+    adopt_batch_shard(cm, mode);
     if (mo_sharded) {
       AGPCHK(mo_refresh_f());
       AGPCHK(comm_sum(cm, fall, (int64_t)2 * qtot * Bp));
@@ -3418,7 +3479,7 @@ struct Svgp : SvgpBase {
     // scalars travel as doubles through a small device buffer (scal_dev[56..59])
     double h[2] = {mode == AGP_SHARD_LATENT ? mine : e_data, mode == AGP_SHARD_LATENT ? 0.0 : kl_aug};
     HIPCHK(ctx, hipMemcpyAsync(scal_dev + 56, h, sizeof(double) * 2, hipMemcpyHostToDevice, st()));
-    AGPCHK(agp_comm_allreduce(cm, scal_dev + 56, 2, AGP_F64));
+    AGPCHK(comm_sum_typed(cm, scal_dev + 56, 2, AGP_F64));
     HIPCHK(ctx, hipMemcpyAsync(h, scal_dev + 56, sizeof(double) * 2, hipMemcpyDeviceToHost, st()));
     HIPCHK(ctx, hipStreamSynchronize(st()));
     *out = mode == AGP_SHARD_LATENT ? h[0] : rho_last * h[0] - kl_gauss_last - rho_last * h[1];
@@ -3428,15 +3489,47 @@ struct Svgp : SvgpBase {
   double* hy_tied = nullptr;  // [1 + D + m*D] doubles: summed gradient of the tied-Z mode
   agp_status hyper_step_multi(agp_comm* cm, int tied) override {
     if (!hy_k && !hy_z) return AGP_OK;
-    if (!tied) {
-      if (mo_sharded) {  // the mixed data term of the gradient reads every latent's mean_f under the updated posterior
-        AGPCHK(mo_refresh_f());
-        AGPCHK(comm_sum(cm, fall, (int64_t)2 * qtot * Bp));
-      }
-      return hyper_step();
+    if (cm && cm->world > 1 && bs_world > 1 && bs_world != cm->world) {
+      ctx->err = "agp_svgp_hyper_step_multi: the handle's batch shard does not belong to this communicator";
+      return AGP_ERR_INVALID;
+    }
+    if (mo_sharded) {  // the mixed data term of the gradient reads every latent's mean_f under the updated posterior
+      AGPCHK(mo_refresh_f());
+      AGPCHK(comm_sum(cm, fall, (int64_t)2 * qtot * Bp));
     }
     const int64_t ng = 1 + D + m * D;
+    const bool batch_sharded = bs_world > 1;
+    if (!tied && !batch_sharded) {
+      hyper_multi_ok = true;
+      const agp_status hs_ = hyper_step();
+      hyper_multi_ok = false;
+      return hs_;
+    }
     if (!hy_tied) AGPCHK(dmalloc(ctx, &hy_tied, ng));
+    if (!tied) {
+      // batch-sharded handle, every latent its own kernel and Z: the data part of each latent's gradient is a sum over the ranks'
+      // shards (all-reduced, 1 + D + m D doubles per latent), its Gaussian-KL part is replicated and enters with weight
+      // 1 / world on every rank (k_hyper_gK) -- every rank then takes the identical ADAM step and the replicas stay together
+      if (!cm || cm->world != bs_world) {
+        ctx->err = "hyper step of a batch-sharded handle needs the communicator of the run";
+        return AGP_ERR_INVALID;
+      }
+      for (int l = 0; l < nl; ++l) {
+        AGPCHK(hypergrad(l, nullptr, nullptr, nullptr));
+        HIPCHK(ctx, hipMemsetAsync(hy_tied, 0, sizeof(double) * ng, st()));
+        HIPCHK(ctx, hipMemcpyAsync(hy_tied, hy_last.data(), sizeof(double) * (1 + D), hipMemcpyHostToDevice, st()));
+        hipLaunchKernelGGL((k_acc_to_double<T>), grid1(m * D), dim3(256), 0, st(), m * D, (const T*)hy_dZ, hy_tied + 1 + D);
+        LAUNCHCHK(ctx);
+        AGPCHK(comm_sum_typed(cm, hy_tied, ng, AGP_F64));
+        std::vector<double> hg(1 + D, 0.0);
+        HIPCHK(ctx, hipMemcpyAsync(hg.data(), hy_tied, sizeof(double) * (1 + D), hipMemcpyDeviceToHost, st()));
+        hipLaunchKernelGGL((k_double_to<T>), grid1(m * D), dim3(256), 0, st(), m * D, (const double*)(hy_tied + 1 + D), hy_dZ);
+        LAUNCHCHK(ctx);
+        HIPCHK(ctx, hipStreamSynchronize(st()));
+        AGPCHK(hyper_apply_one(l, hg, (const T*)hy_dZ));
+      }
+      return hyper_finish();
+    }
     HIPCHK(ctx, hipMemsetAsync(hy_tied, 0, sizeof(double) * ng, st()));
     std::vector<double> hs(1 + D, 0.0);
     for (int l = 0; l < nl; ++l) {
@@ -3446,7 +3539,7 @@ struct Svgp : SvgpBase {
       LAUNCHCHK(ctx);
     }
     HIPCHK(ctx, hipMemcpyAsync(hy_tied, hs.data(), sizeof(double) * (1 + D), hipMemcpyHostToDevice, st()));
-    if (cm && cm->world > 1) AGPCHK(agp_comm_allreduce(cm, hy_tied, ng, AGP_F64));
+    AGPCHK(comm_sum_typed(cm, hy_tied, ng, AGP_F64));
     HIPCHK(ctx, hipMemcpyAsync(hs.data(), hy_tied, sizeof(double) * (1 + D), hipMemcpyDeviceToHost, st()));
     hipLaunchKernelGGL((k_double_to<T>), grid1(m * D), dim3(256), 0, st(), m * D, (const double*)(hy_tied + 1 + D), hy_dZ);
     LAUNCHCHK(ctx);

@@ -597,6 +597,35 @@ __global__ void k_lambda_finish(int nparts, int stride, const double* __restrict
   }
 }
 
+// batch-sharded handles (round 3): the two sums and the batch size leave stage 1 as three doubles red3 = [S0, S1, B_local], are
+// all-reduced over the ranks, and stage 2 finishes from the reduced values -- poisson.jl:78 / heteroscedastic.jl:94 over the WHOLE
+// minibatch, not the shard
+__global__ void k_lambda_reduce(int nparts, int stride, const double* __restrict__ part, double Bn, double* __restrict__ red3) {
+  __shared__ double red[16];
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = threadIdx.x; b < nparts; b += blockDim.x) {
+    s0 += part[stride * b];
+    if (stride > 1) s1 += part[stride * b + 1];
+  }
+  s0 = block_sum<double>(s0, red);
+  s1 = block_sum<double>(s1, red);
+  if (threadIdx.x == 0) {
+    red3[0] = s0;
+    red3[1] = s1;
+    red3[2] = Bn;
+  }
+}
+template <typename T>
+__global__ void k_lambda_finish_red(const double* __restrict__ red3, int mode, T* __restrict__ lam) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (mode == 0) {
+    lam[0] = (T)(red3[0] / red3[1]);
+  } else {
+    const double cand = red3[2] / (2.0 * red3[0]), cur = (double)lam[0];
+    lam[0] = (T)(cand > cur ? cand : cur);
+  }
+}
+
 // Heteroscedastic Gaussian (heteroscedastic.jl:71-97): latent 0 = f, latent 1 = g ; arrays are [2][ldb]:
 //   c[0] = phi = E[(f-y)^2]/2 ; c[1] = c = sqrt(E[g^2]) ; gamma[1] = sigg ~ E[sigma(-g)] ; gamma[0] = gamma = lam phi sigg ;
 //   theta[1] = (1/2 + gamma) tanh(c/2)/(2c) ; part[b] = sum_block phi (1 - sigg)

@@ -80,15 +80,17 @@ __global__ void k_hyper_gknm(int64_t B, int64_t rows, int64_t cols, int64_t ld, 
 }
 
 // G_K = -1/2 (M1 + M1') - 1/2 Apred + 1/2 a a'   on the valid m x m block, zero in the padding
+// klw weighs the Gaussian-KL part (-1/2 Apred + 1/2 a a'): 1 normally, 1 / world on a batch-sharded handle, where that part is
+// replicated on every rank while the data part (M1) is a sum over the ranks' shards -- the all-reduced gradient then counts it once
 template <typename T>
 __global__ void k_hyper_gK(int64_t m, int64_t mp, const T* __restrict__ M1, const T* __restrict__ Apred,
-                           const T* __restrict__ a, T* __restrict__ out) {
+                           const T* __restrict__ a, T* __restrict__ out, T klw) {
   int64_t i = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
   int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= mp || j >= mp) return;
   T v = T(0);
   if (i < m && j < m)
-    v = T(-0.5) * (M1[i * mp + j] + M1[j * mp + i]) - T(0.5) * Apred[i * mp + j] + T(0.5) * a[i] * a[j];
+    v = T(-0.5) * (M1[i * mp + j] + M1[j * mp + i]) + klw * (T(-0.5) * Apred[i * mp + j] + T(0.5) * a[i] * a[j]);
   out[i * mp + j] = v;
 }
 

@@ -184,6 +184,9 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_syrk_tn(const T* __restrict__
                                                       const T* __restrict__ kinv_mu0 = nullptr, int64_t nrider = 0,
                                                       T* __restrict__ fillp = nullptr, int64_t fill_used = 0,
                                                       int64_t fill_stride = 0, int fill_nb = 0) {
+  // KG = 4 in f64 takes ALL of gfx950's 160 KB of LDS (4 x 40 KB staging areas): nothing else in this kernel may be __shared__,
+  // and the instantiation does not exist for smaller-LDS targets
+  static_assert((size_t)KG * SMEM_ELEMS * sizeof(T) <= 160 * 1024, "k_syrk_tn: staging areas exceed the 160 KB LDS of gfx950");
   __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
   syrk_tn_body<T, MODE, KG>(A, lda, Kdim, w, lower_a, out, ldo, eta2, Kinv, ldm, lr, ntri, rvec, eta1, kinv_mu0, nrider, fillp,
                             fill_used, fill_stride, fill_nb, smem);

@@ -333,6 +333,7 @@ class HipEngine:
         """this engine sees shard `rank` of `world` of every minibatch (batch-parallel): once-per-evaluation ELBO terms are
         then counted by rank 0 only"""
         self.model._chk(self.L.agp_svgp_set_batch_shard(self.h, rank, world))
+        self.model._batch_shard = (int(rank), int(world))  # re-applied whenever the model re-creates its handle
         return self
 
     def bind_data(self, X, y, obsdim: int = 1):
@@ -537,10 +538,13 @@ def train_parallel(model, X, y, iterations: int, idx_stream: Sequence, *, mode: 
     else:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
-    if world > 1 and type(model.likelihood).__name__ in ("PoissonLikelihood", "HeteroscedasticLikelihood"):
-        # their lambda update (poisson.jl:78, heteroscedastic.jl:95) is a reduction over the whole minibatch that the sharded
-        # drivers do not exchange; the two heteroscedastic latents are coupled point-wise and stay on one handle
-        raise NotImplementedError(f"{model.likelihood} is not wired for multi-GPU sharding")
+    if world > 1 and type(model.likelihood).__name__ in ("PoissonLikelihood", "HeteroscedasticLikelihood") and \
+            not (mode == "batch" and comm is not None):
+        # their lambda update (poisson.jl:78, heteroscedastic.jl:94) is a reduction over the whole minibatch: the library
+        # all-reduces the two sums inside agp_svgp_cavi_step_multi(AGP_SHARD_BATCH); the phase-level drivers below do not, and
+        # the two heteroscedastic latents are coupled point-wise (they stay on one handle: no latent sharding)
+        raise NotImplementedError(f"{model.likelihood} shards over the minibatch through a Comm only "
+                                  "(train_parallel(..., mode='batch', comm=Comm...))")
     N = np.asarray(X).shape[0] if obsdim == 1 else np.asarray(X).shape[1]
     B_total = len(idx_stream[0])
     B_local = B_total if mode == "latent" else B_total // world

@@ -146,12 +146,11 @@ class SVGP:
             if o is not None and not isinstance(o, ADAM):
                 raise NotImplementedError("only ADAM is wired as hyper-parameter optimiser")
         self.k_opt, self.z_opt = optimiser, Zoptimiser
-        if mean is not None and (optimiser is not None or Zoptimiser is not None):
-            # the reference would also step the prior mean here (autotuning.jl:104-106), but calls update!(mu0, grad, state)
-            # against the method update!(mu0, state, grad) (src/mean/constantmean.jl:31): it cannot run.  Not guessed at.
-            raise NotImplementedError("a non-zero prior mean together with hyper-parameter optimisation is not wired: the "
-                                      "reference's prior-mean update (autotuning.jl:104-106) is broken; pass optimiser=False, "
-                                      "Zoptimiser=False or mean=None")
+        # A non-zero prior mean together with hyper-parameter optimisation: the reference constructs such a model and runs until
+        # its first hyper step (n_iter >= 3, training.jl:65-69), where the prior-mean update calls update!(mu0, grad, state) against
+        # the method update!(mu0, state, grad) (src/mean/constantmean.jl:31 vs autotuning.jl:104-106) and cannot run.  Mirrored:
+        # construction, training up to that point, prediction and load_trained_model work; the first hyper step raises
+        # (train_, _hyper_step_guard).
         if mean is not None and not (np.isscalar(mean) or isinstance(mean, (list, np.ndarray))):
             raise TypeError("mean must be None (ZeroMean), a Real (ConstantMean) or a vector (EmpiricalMean)")
         self.likelihood = likelihood
@@ -300,6 +299,8 @@ class SVGP:
             nodes, weights = _gauss_hermite()
             self._chk(capi.lib().agp_svgp_set_quadrature(h, nodes.ctypes.data_as(C.POINTER(C.c_double)),
                                                          weights.ctypes.data_as(C.POINTER(C.c_double)), len(nodes)))
+        if getattr(self, "_batch_shard", None) is not None:  # a re-created handle keeps its place in a batch-parallel run
+            self._chk(capi.lib().agp_svgp_set_batch_shard(h, *self._batch_shard))
         o = self.k_opt or self.z_opt
         if o is not None:
             self._chk(capi.lib().agp_svgp_hyper_configure(
@@ -603,6 +604,7 @@ def train_(model: SVGP, X, y, iterations: int = 100, *, callback: Optional[Calla
             callback(model, State(model), inf.n_iter)
         # training.jl:65-69 (n_iter is the counter before this iteration's increment)
         if hyper_on and inf.n_iter % model.atfrequency == 0 and inf.n_iter >= 3 and local_iter != iterations:
+            _hyper_step_guard(model)
             model._chk(L.agp_svgp_hyper_step(h))
         if model.verbose > 2 or (model.verbose > 1 and local_iter % 10 == 0):
             print(f"iter {local_iter}  ELBO {objective(model, State(model), None):.6f}")
@@ -615,6 +617,14 @@ def train_(model: SVGP, X, y, iterations: int = 100, *, callback: Optional[Calla
     model._pull_hypers()
     model._pull_lik_state()
     return model, State(model)
+
+
+def _hyper_step_guard(model):
+    """update_hyperparameters! with a non-zero prior mean: the reference's prior-mean update cannot run (see SVGP.__init__)"""
+    if model.mean is not None:
+        raise NotImplementedError("a non-zero prior mean together with hyper-parameter optimisation is not wired: the "
+                                  "reference's prior-mean update (autotuning.jl:104-106) is broken; pass optimiser=False, "
+                                  "Zoptimiser=False or mean=None")
 
 
 def objective(model: SVGP, state: Optional[State] = None, y=None) -> float:

@@ -277,8 +277,13 @@ def test_hyper_step_is_structural(mods):
         else:
             assert k.transform.s != 2.5 and k.transform.s == pytest.approx(float(mr.latents[0].kernel.scale), rel=1e-9)
         assert _rel(ma.get_state(0)[3], mr.latents[0].eta2) < 1e-8
-    with pytest.raises(NotImplementedError):  # the reference's prior-mean update cannot run (constantmean.jl:31 vs its call)
-        AGP.SVGP(AGP.SqExponentialKernel(), AGP.GaussianLikelihood(0.05), AGP.AnalyticSVI(B), Z, mean=1.0)
+    # a non-zero prior mean with the (default) optimiser: like the reference, the model is built and trains until its first hyper
+    # step (n_iter >= 3, training.jl:65-69), where the reference's prior-mean update cannot run (constantmean.jl:31 vs its call)
+    mm = AGP.SVGP(AGP.SqExponentialKernel(), AGP.GaussianLikelihood(0.05), AGP.AnalyticSVI(B), Z, mean=1.0)
+    AGP.train_(mm, X, y, 3, idx_stream=idx)
+    assert np.all(np.isfinite(AGP.predict_f(mm, X[:10])))
+    with pytest.raises(NotImplementedError):
+        AGP.train_(mm, X, y, 3, idx_stream=idx, state=True)
 
 
 def test_train_without_state_restarts_the_state(mods):

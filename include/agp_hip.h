@@ -199,7 +199,13 @@ agp_status agp_svgp_get_opt_state(agp_svgp* h, int64_t* n_host);
  *   idx : int64[B] device, or NULL for rows 0..B-1 (full batch)
  *   rho : N / B   (training.jl:30)
  * Asynchronous; data-dependent failures (K~ <= 0, non-SPD -2*eta2) are latched and reported by
- * agp_svgp_check_status / the next synchronising call. */
+ * agp_svgp_check_status / the next synchronising call.
+ * Scheduling note (round 3, invisible through the ABI): for a single-latent handle in a training loop (look-ahead or full batch,
+ * up to 16 block columns of 64) the natural-gradient step of this minibatch (natural_gradient! + global_update!,
+ * analyticVI.jl:143-180, 229-246) is not enqueued by this call but rides as the PROLOGUE of the NEXT step's factorisation launch;
+ * every other entry point of the handle first takes a pending step with the stand-alone kernel, so eta, Sigma, the ELBO, the
+ * hyper-gradient and predictions always see the completed step (AGP_STEP_PROLOGUE=0 switches the scheduling off).  x, y, idx of a
+ * step are not read again after the call that follows it. */
 agp_status agp_svgp_cavi_step(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx,
                               int64_t B, double rho);
 /* The same step in phases, for multi-GPU runs:
@@ -271,8 +277,12 @@ agp_status agp_svgp_mo_predict_from_f(agp_svgp* h, int64_t n_t, int32_t mode, vo
                                       const double* gh_nodes_host, const double* gh_weights_host, int32_t n_nodes);
 /* Optional look-ahead: compute Knm / kappa of the NEXT minibatch (compute_kappa, latentgp.jl:209-215) on a second,
  * library-owned stream so it overlaps the current step's latency-bound factorisation.  The next cavi_step /
- * step_local called with the same (x, ldx, idx, B) adopts the result; any other call simply ignores it.  idx must stay
- * valid until that step. */
+ * step_local called with the same (x, ldx, idx, B) adopts the result; any other call simply ignores it.
+ * CONTRACT: the look-ahead is recognised by POINTER IDENTITY of (x, ldx, idx, B).  Between this call and the step that adopts it
+ * the index buffer must stay allocated AND unchanged (the step gathers nothing again: it takes the rows the look-ahead read), and so
+ * must the rows of x it names.  A host that refills one index buffer per iteration therefore either alternates between two
+ * buffers or calls agp_svgp_invalidate_data (which also drops a pending look-ahead) after refilling.  Kernel / Z / state changes
+ * (set_kernel, set_Z, hyper steps, refresh_K) drop it by themselves. */
 agp_status agp_svgp_prefetch(agp_svgp* h, const void* x, int64_t ldx, const int64_t* idx, int64_t B);
 agp_status agp_svgp_lsm_gamma(agp_svgp* h);
 agp_status agp_svgp_lsm_alpha(agp_svgp* h);
@@ -300,9 +310,13 @@ agp_status agp_svgp_elbo(agp_svgp* h, const void* x, int64_t ldx, const void* y,
  * (expec_loglikelihood), Gaussian KL (+ extraKL), unscaled augmented KL.  A batch-parallel driver sums terms 0 and 2 over the
  * minibatch shards and counts the (replicated) Gaussian KL once. */
 agp_status agp_svgp_elbo_terms(agp_svgp* h, double* terms_host);
-/* batch-parallel run: this handle sees shard `rank` of `world` of every minibatch.  Only changes the ELBO: the reference's
+/* batch-parallel run: this handle sees shard `rank` of `world` of every minibatch.  Changes the ELBO -- the reference's
  * once-per-evaluation terms (LogisticSoftMax `sum(log, first(beta))` logisticsoftmax.jl:138, the scalar-iteration terms of
- * the Laplace GIGEntropy in AGP_ELBO_REFERENCE mode) are then counted by rank 0 only. */
+ * the Laplace GIGEntropy in AGP_ELBO_REFERENCE mode) are then counted by rank 0 only -- and the hyper-gradient, whose replicated
+ * Gaussian-KL part enters with weight 1 / world so that the all-reduced gradient counts it once (agp_svgp_hyper_step_multi; the
+ * plain agp_svgp_hyper_step is refused on such a handle).  The batch-mode *_multi calls take rank and world from their
+ * communicator themselves, so this call is only needed by hosts that drive the phases (step_local / step_stats / ...) by hand;
+ * a handle that is re-created must be told again. */
 agp_status agp_svgp_set_batch_shard(agp_svgp* h, int32_t rank, int32_t world);
 
 /* state export / import : VarPosterior(mu, Sigma, eta1, eta2)  src/gpblocks/posterior.jl:21-27 ; any pointer
@@ -420,16 +434,23 @@ agp_status agp_comm_stats(agp_comm* comm, int64_t* n_calls_host, int64_t* bytes_
 
 /* update_parameters!(model, state, x, y) (src/training/training.jl:140-158) of a sharded model: agp_svgp_cavi_step with the
  * exchange points above carried out on `comm`.  comm == NULL or world == 1 degenerates to the single-GPU step through the
- * same phase sequence. */
+ * same phase sequence (a handle that owns only a slice of a multi-output model's latents refuses comm == NULL).
+ * Poisson / Heteroscedastic likelihoods (AGP_SHARD_BATCH only; the two heteroscedastic latents are coupled point-wise and share a
+ * handle): lambda is re-estimated from sums over the WHOLE minibatch (poisson.jl:78, heteroscedastic.jl:94) -- three doubles
+ * [S0, S1, B_local] are all-reduced between the local update's partial sums and its finish. */
 agp_status agp_svgp_cavi_step_multi(agp_svgp* h, agp_comm* comm, int32_t mode, const void* x, int64_t ldx, const void* y,
                                     const int64_t* idx, int64_t B, double rho);
 /* ELBO(model, state, y) of the last minibatch of a sharded run, identical on every rank (analyticVI.jl:255-297):
  * latent mode sums the ranks' shares (shared per-point terms are counted by the owner of latent 0); batch mode sums the data
- * and augmented-KL terms of the shards and counts the replicated Gaussian KL once (call agp_svgp_set_batch_shard first). */
+ * and augmented-KL terms of the shards and counts the replicated Gaussian KL once (rank and world of the shard are taken from
+ * the communicator). */
 agp_status agp_svgp_elbo_multi(agp_svgp* h, agp_comm* comm, int32_t mode, double* elbo_host);
-/* update_hyperparameters! (src/hyperparameter/autotuning.jl:86-140) of a latent-sharded model.
- *   tied = 0 : every latent optimises its own kernel and Z (the reference's deep copies, latentgp.jl:63-68): no collective,
- *              except that a sharded multi-output model first re-exchanges mean_f under the updated posterior.
+/* update_hyperparameters! (src/hyperparameter/autotuning.jl:86-140) of a sharded model.
+ *   tied = 0 : every latent optimises its own kernel and Z (the reference's deep copies, latentgp.jl:63-68).  Latent-sharded: no
+ *              collective, except that a sharded multi-output model first re-exchanges mean_f under the updated posterior.
+ *              Batch-sharded (the handle has seen a batch-mode call or agp_svgp_set_batch_shard): per latent, the gradient
+ *              (1 + D + m*D doubles; data part summed over the shards, Gaussian-KL part weighted 1 / world) is all-reduced and
+ *              every rank takes the identical ADAM step -- the replicas stay bit-identical.
  *   tied = 1 : ONE kernel and ONE Z shared by all latents (an opt-in extension; BASELINE.json config 4's "all-reduce on the
  *              Z hyper-grad"): the gradients of the local latents are summed, all-reduced (1 + D + m*D doubles), and the same
  *              ADAM step is applied to every latent on every rank. */

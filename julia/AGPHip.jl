@@ -6,13 +6,17 @@
 # stream / buffer handles (ROCArray, the stream pointer); there is no KernelAbstractions and no CUDA.jl compatibility layer:
 # every numeric operation is a `ccall` into hand-written HIP.
 #
-# Usage (the reference API, unchanged, on a wrapped model):
+# Usage -- the reference API, unchanged, on the reference's own model objects (section "drop-in methods" at the end):
 #
-#     m  = SVGP(kernel, LogisticLikelihood(), AnalyticSVI(1024), Z; optimiser=false)     # the reference constructor
-#     hm = AGPHip.HipModel(m)                                                              # device twin
-#     hm, state = train!(hm, X, y, 1000)                                                  # src/training/training.jl:13-111
-#     ŷ = predict_y(hm, X_test); p = proba_y(hm, X_test); μ, σ² = predict_f(hm, X_test; cov=true)
-#     ELBO(hm, X, y); objective(hm, state, y)
+#     using AugmentedGaussianProcesses, AGPHip                                              # loading the shim is the switch
+#     m = SVGP(kernel, LogisticLikelihood(), AnalyticSVI(1024), Z; optimiser=false)        # the reference constructor
+#     m, state = train!(m, X, y, 1000)                  # src/training/training.jl:13-111, now on the MI355X (backend=:cpu opts out)
+#     ŷ = predict_y(m, X_test); p = proba_y(m, X_test); μ, σ² = predict_f(m, X_test; cov=true); ELBO(m, X, y)
+#     Z = AGPHip.inducingpoints(KmeansAlg(1024), X)      # the device k-means (agp_kmeans) behind InducingPoints' interface
+#     om = OnlineSVGP(kernel, GaussianLikelihood(), AnalyticVI(), OIPS(0.9)); train!(om, Xbatch, ybatch; iterations=5)
+#
+# The explicit form (a wrapped model, for multi-GPU runs and for tests that keep both paths side by side) is still there:
+#     hm = AGPHip.HipModel(m); hm, state = train!(hm, X, y, 1000); predict_y(hm, X_test); ELBO(hm, X, y); objective(hm, state, y)
 #
 # Seams replaced (SURVEY.md section 8b):
 #   update_parameters!(model::SVGP / ::MOSVGP, state, x, y)   src/training/training.jl:140-158        -> agp_svgp_cavi_step[_multi]
@@ -29,7 +33,8 @@ using AMDGPU
 using AugmentedGaussianProcesses
 using KernelFunctions
 using LinearAlgebra
-using StatsBase: sample
+using StatsBase: sample, Weights
+using Random
 const AGP = AugmentedGaussianProcesses
 
 import AugmentedGaussianProcesses: train!, predict_f, predict_y, proba_y, ELBO, objective
@@ -153,6 +158,9 @@ mutable struct HipModel{T,M<:AGP.AbstractGPModel{T}}
     N::Int
     last_idx::Any                  # device indices of the last minibatch (kept alive: the step is asynchronous)
     stale_K::Bool
+    rank::Int32                    # place in a multi-GPU run (comm_init!): re-applied whenever the handle is re-created
+    world::Int32
+    keep::Vector{Any}              # index buffers a queued look-ahead / pending step may still read (two generations)
 end
 
 is_mo(hm::HipModel) = hm.model isa AGP.MOSVGP
@@ -169,7 +177,7 @@ function HipModel(model::M; reference_compat_stale_K::Bool=false,
     model isa Union{SVGP,AGP.MOSVGP} || error("only SVGP / MOSVGP run on the HIP path")
     AGP.inference(model) isa AnalyticVI || error("The inference object should be of type `AnalyticVI`")   # SVGP.jl:45-47
     return HipModel{T,M}(model, C_NULL, C_NULL, C_NULL, AGP_SHARD_LATENT, latent_range, 0, nothing, nothing, 0, nothing,
-                         reference_compat_stale_K)
+                         reference_compat_stale_K, Int32(0), Int32(1), Any[])
 end
 
 function ensure_ctx!(hm::HipModel)
@@ -218,9 +226,7 @@ function ensure_handle!(hm::HipModel{T}, maxbatch::Int) where {T}
         Zd = ROCArray{T}(reduce(hcat, AGP.Zview(gp)))       # D x m, point-major
         check(ctx, ccall((:agp_svgp_set_Z, libagp), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64), hm.h, i - 1, pointer(Zd), D))
         μ₀ = AGP.pr_mean(gp)
-        if !(μ₀ isa AGP.ZeroMean)
-            (AGP.opt(gp) === nothing && AGP.Zopt(gp) === nothing) ||
-                error("a non-zero prior mean with hyper-parameter optimisation is not wired (the reference's own update, autotuning.jl:104-106, cannot run)")
+        if !(μ₀ isa AGP.ZeroMean)   # (with an optimiser the FIRST HYPER STEP errors, like the reference's own broken update: update_hyperparameters!)
             v = ROCArray{T}(μ₀(AGP.Zview(gp)))
             check(ctx, ccall((:agp_svgp_set_prior_mean, libagp), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}), hm.h, i - 1, pointer(v)))
         end
@@ -255,6 +261,11 @@ function ensure_handle!(hm::HipModel{T}, maxbatch::Int) where {T}
     if old !== nothing
         push_posterior!(hm)
         check(ctx, ccall((:agp_svgp_set_opt_state, libagp), Int32, (Ptr{Cvoid}, Int64), hm.h, old))
+    end
+    # a handle created (or re-created for a larger batch) AFTER comm_init! must know its shard too: the once-per-evaluation ELBO
+    # terms and the Gaussian-KL weight of the hyper-gradient depend on it (the *_multi calls also take it from the communicator)
+    if hm.comm != C_NULL && hm.shard == AGP_SHARD_BATCH
+        check(ctx, ccall((:agp_svgp_set_batch_shard, libagp), Int32, (Ptr{Cvoid}, Int32, Int32), hm.h, hm.rank, hm.world))
     end
     return hm.h
 end
@@ -377,6 +388,9 @@ end
 
 # update_hyperparameters!(m, state, x, y) (autotuning.jl:86-140) on the minibatch of the last step
 function update_hyperparameters!(hm::HipModel; tied::Bool=false)
+    any(gp -> !(AGP.pr_mean(gp) isa AGP.ZeroMean), hm.model.f[hm.latent_range]) &&
+        error("a non-zero prior mean with hyper-parameter optimisation is not wired: the reference's own prior-mean update " *
+              "(autotuning.jl:104-106 vs src/mean/constantmean.jl:31) cannot run")
     st = hm.comm == C_NULL && !tied ? ccall((:agp_svgp_hyper_step, libagp), Int32, (Ptr{Cvoid},), hm.h) :
          ccall((:agp_svgp_hyper_step_multi, libagp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32), hm.h, hm.comm, tied ? 1 : 0)
     check(hm.ctx, st)
@@ -434,15 +448,21 @@ function train!(hm::HipModel{T}, X::AbstractArray, y, iterations::Int=100; callb
     while true
         update_parameters!(hm, idd, ρ)
         AGP.set_trained!(model, true)
+        # the next minibatch is drawn now and its look-ahead enqueued right behind the step (next to its factorisation) -- unless a
+        # hyper step follows: it moves the kernel / Z, a look-ahead against the old ones would be thrown away (agp_svgp_prefetch
+        # contract, include/agp_hip.h; the Python mirror skips it the same way, svgp.py train_)
+        hyper_now = hyper_on && (AGP.n_iter(model) % model.atfrequency == 0) && (AGP.n_iter(model) >= 3) && (local_iter != iterations)
+        nxt = local_iter < iterations ? draw(local_iter + 1) : nothing
+        # index buffers stay referenced for two iterations: the look-ahead reads `nxt`, and the step's natural-gradient part is
+        # taken by the NEXT launch (it reads device copies only, but the buffer identity is what the look-ahead is recognised by)
+        push!(hm.keep, idd); length(hm.keep) > 3 && popfirst!(hm.keep)
+        (nxt === nothing || hyper_now) || prefetch!(hm, nxt)
         callback === nothing || callback(hm, hm, AGP.n_iter(model))
-        if hyper_on && (AGP.n_iter(model) % model.atfrequency == 0) && (AGP.n_iter(model) >= 3) && (local_iter != iterations)
-            update_hyperparameters!(hm)
-        end
+        hyper_now && update_hyperparameters!(hm)
         local_iter += 1
         inf.n_iter += 1
         (local_iter <= iterations) || break
-        idd = draw(local_iter)
-        idd === nothing || prefetch!(hm, idd)
+        idd = nxt
     end
     check(hm.ctx, ccall((:agp_svgp_check_status, libagp), Int32, (Ptr{Cvoid},), hm.h))
     check(hm.ctx, ccall((:agp_svgp_refresh_K, libagp), Int32, (Ptr{Cvoid},), hm.h))            # compute_Ks, training.jl:107
@@ -473,7 +493,7 @@ end
 # update.  The reference keeps ρ = N/B of the last train! here (Appendix A Q13); pass ρ = 1 for the properly scaled value.
 function ELBO(hm::HipModel{T}, X::AbstractMatrix, y::AbstractArray; obsdim=1, ρ::Real=AGP.ρ(AGP.inference(hm.model))) where {T}
     twin = HipModel{T,typeof(hm.model)}(hm.model, hm.ctx, hm.h, C_NULL, hm.shard, hm.latent_range, hm.maxbatch, nothing, nothing,
-                                        0, nothing, hm.stale_K)                        # same handle, its own data buffers
+                                        0, nothing, hm.stale_K, hm.rank, hm.world, Any[])  # same handle, its own data buffers
     upload!(twin, X, y; obsdim)
     n = twin.N
     if n > hm.maxbatch
@@ -584,6 +604,7 @@ function comm_init!(hm::HipModel, rank::Integer, world::Integer, id::Vector{UInt
                                  hm.ctx, rank, world, id, c))
     hm.comm = c[]
     hm.shard = shard === :batch ? AGP_SHARD_BATCH : AGP_SHARD_LATENT
+    hm.rank, hm.world = Int32(rank), Int32(world)            # ensure_handle! re-applies them to every handle it creates later
     if shard === :batch && hm.h != C_NULL
         check(hm.ctx, ccall((:agp_svgp_set_batch_shard, libagp), Int32, (Ptr{Cvoid}, Int32, Int32), hm.h, rank, world))
     end
@@ -602,5 +623,212 @@ function latent_slice(n::Int, world::Int, rank::Int)
     lo = rank * base + min(rank, rem)
     return (lo + 1):(lo + base + (rank < rem ? 1 : 0))
 end
+
+# ---- inducing-point selection on the device (InducingPoints.jl's interface, agp_kmeans behind it) --------------------------------
+# `inducingpoints(KmeansAlg(m), X)` is how every example / test of the reference picks Z (test/testingtools.jl:66,
+# docs/examples/gpclassification.jl:47).  The random part (AFK-MC² seeding: first centre, proposals, Metropolis acceptances) needs
+# the caller's RNG and stays on the host, on a few thousand gathered candidates; the O(N m D) distance passes and the Lloyd
+# iterations run on the GPU (csrc/agp_kmeans.h).  Returns the same `Vector{Vector{T}}` the reference's constructors take.
+function inducingpoints(alg::AGP.KmeansAlg, X::AbstractMatrix{T}; obsdim::Int=1, rng=Random.default_rng(),
+                        nMarkov::Int=10, tol::Real=1e-3, maxiter::Int=100) where {T<:Union{Float32,Float64}}
+    Xd = ROCArray{T}(obsdim == 1 ? permutedims(X) : X)        # D x N == point-major
+    D, N = size(Xd); m = alg.m
+    m <= N || error("Input data not big enough given the desired number of inducing points")
+    ctx = Ref{Ptr{Cvoid}}()
+    st = ccall((:agp_ctx_create, libagp), Int32, (Int32, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), AMDGPU.device_id() - 1, AMDGPU.stream().stream, ctx)
+    st == 0 || throw(AGPError(st, "agp_ctx_create"))
+    dt = T == Float64 ? Int32(0) : Int32(1)
+    try
+        first = rand(rng, 1:N)
+        c1 = Xd[:, first:first]
+        d1 = ROCVector{T}(undef, N)
+        check(ctx[], ccall((:agp_nearest_center, libagp), Int32,
+                           (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Ptr{Int32}, Ptr{Cvoid}),
+                           ctx[], dt, pointer(Xd), N, D, D, pointer(c1), D, 1, C_NULL, pointer(d1)))
+        q = Float64.(Array(d1)); q = q ./ sum(q) ./ 2 .+ 1 / (2N); q ./= sum(q)
+        seeds = Matrix{Float64}(undef, D, m); seeds[:, 1] = Array(c1)
+        Xh = nothing
+        for i in 2:m                                           # one short Metropolis chain per further centre
+            prop = sample(rng, 1:N, Weights(q), nMarkov)
+            cand = Float64.(Array(Xd[:, prop]))
+            dmin(v) = minimum(sum(abs2, seeds[:, 1:(i - 1)] .- v; dims=1))
+            x = cand[:, 1]; dx = dmin(x)
+            for j in 2:nMarkov
+                yv = cand[:, j]; dy = dmin(yv)
+                if dy > rand(rng) * dx
+                    x, dx = yv, dy
+                end
+            end
+            seeds[:, i] = x
+        end
+        Cd = ROCArray{T}(seeds)
+        it, conv, obj = Ref{Int32}(), Ref{Int32}(), Ref{Float64}()
+        check(ctx[], ccall((:agp_kmeans, libagp), Int32,
+                           (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Int64, Int64, Int32, Float64, Ptr{Int32},
+                            Ptr{Int32}, Ref{Int32}, Ref{Float64}, Ref{Int32}),
+                           ctx[], dt, pointer(Xd), N, D, D, pointer(Cd), D, m, maxiter, tol, C_NULL, C_NULL, it, obj, conv))
+        Z = Array(Cd)
+        return [Z[:, j] for j in 1:m]
+    finally
+        ccall((:agp_ctx_destroy, libagp), Int32, (Ptr{Cvoid},), ctx[])
+    end
+end
+
+# ---- OnlineSVGP: streaming batches (src/models/OnlineSVGP.jl, src/training/onlinetraining.jl:17-218) ---------------------------
+# A streaming model is a CHAIN of device handles: every arriving batch may grow Z (the reference's own InducingPoints.updateZ /
+# remove_point run on the host, exactly where onlinetraining.jl:153-172 calls them), so a fresh handle is created for the new
+# inducing points and the previous posterior is installed as its prior:
+#   save_old_gp! (:170-180)          -> agp_svgp_online_snapshot  (invDₐ = Σₐ⁻¹ − Kₐ⁻¹, η₁ₐ, 𝓛ₐ read off the old handle)
+#   compute_kernel_matrices (:199-237) -> agp_svgp_set_online_prior (K_ab, κₐ, K̃ₐ formed at the next K refresh)
+#   first iteration (:78-104)        -> agp_svgp_online_first_step (local update under the OLD inducing points / posterior)
+#   later iterations                 -> agp_svgp_cavi_step (full batch, closed-form natural parameters, analyticVI.jl:183-203)
+# Only AnalyticVI() is accepted (the reference's stochastic branch uses an undefined name, onlinetraining.jl:52).  All latents of a
+# handle share m: latents whose OIPS runs end with fewer points are filled with neutral far-away points (every kernel value that
+# involves one is exactly 0), as the Python mirror does (augmentedgaussianprocesses.jl_amd/online.py, _pad_inducing).
+mutable struct HipOnlineModel{T}
+    model::AGP.OnlineSVGP{T}
+    cur::Union{Nothing,HipModel}     # device twin of the current inducing points (an SVGP view of model.f)
+    m_real::Vector{Int}
+end
+HipOnlineModel(m::AGP.OnlineSVGP{T}) where {T} = HipOnlineModel{T}(m, nothing, Int[])
+
+const FAR = 1.0e6
+function pad_inducing(Zs::Vector{<:AbstractVector})
+    mmax = maximum(length, Zs)
+    D = length(first(first(Zs)))
+    return [vcat(collect.(Z), [fill(FAR * j, D) for j in 1:(mmax - length(Z))]) for Z in Zs], length.(Zs)
+end
+
+function train!(ho::HipOnlineModel{T}, X::AbstractMatrix, y::AbstractArray, state=nothing; iterations::Int=20,
+                callback=nothing, obsdim::Int=1) where {T}
+    iterations > 0 || error("Number of iterations should be positive")
+    m = ho.model
+    AGP.is_stochastic(m) && error("OnlineSVGP streams full batches on this path (onlinetraining.jl:48-53 cannot run)")
+    Xv = KernelFunctions.vec_of_vecs(X; obsdim)
+    first_batch = AGP.n_iter(m) == 0
+    old = ho.cur
+    snaps = nothing
+    if first_batch
+        AGP.init_online_model(m, Xv)                                          # onlinetraining.jl:182-197 (OIPS on the host)
+    else
+        pull_hypers!(old)                                                     # kernels / Z as the last hyper steps left them
+        snaps = map(1:nlat(old)) do i                                         # save_old_gp!, :170-180
+            mo = old.maxbatch; mm = AGP.dim(old.model.f[i])
+            iD = ROCMatrix{T}(undef, mm, mm); e1 = ROCVector{T}(undef, mm); pl = Ref{Float64}()
+            check(old.ctx, ccall((:agp_svgp_online_snapshot, libagp), Int32,
+                                 (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ref{Float64}), old.h, i - 1, pointer(iD), mm, pointer(e1), pl))
+            (iD, e1, pl[], reduce(hcat, AGP.Zview(old.model.f[i])))
+        end
+        for gp in m.f                                                         # remove_point (:172) then updateZ (:153-160)
+            gp.Zₐ = deepcopy(gp.Z)
+            gp.Z = AGP.InducingPoints.remove_point(Random.GLOBAL_RNG, gp.Z, gp.Zalg,
+                                                   kernelmatrix(AGP.kernel(gp), gp.Z) + T(AGP.jitt) * I)
+            gp.Z = AGP.InducingPoints.updateZ(gp.Z, gp.Zalg, Xv; kernel=AGP.kernel(gp))
+            gp.post.dim = length(AGP.Zview(gp))
+        end
+    end
+    Zs, m_real = pad_inducing([AGP.Zview(gp) for gp in m.f])
+    # an SVGP view of the online latents (same kernels / optimisers, padded Z): what the device handle is created from
+    view = SVGP(AGP.kernel.(m.f) |> first, AGP.likelihood(m), AnalyticVI(), Zs[1]; optimiser=AGP.opt(first(m.f)),
+                Zoptimiser=AGP.Zopt(first(m.f)), atfrequency=m.atfrequency)
+    for (gp, k, Z) in zip(view.f, AGP.kernel.(m.f), Zs)
+        gp.prior.kernel = k; gp.Z = Z
+    end
+    new = HipModel(view)
+    data = upload!(new, X, y; obsdim)
+    B = new.N
+    ensure_handle!(new, max(B, old === nothing ? 0 : old.maxbatch))
+    mp = length(Zs[1])
+    for i in 1:length(m.f)
+        if first_batch                                                        # init_opt_state(::OnlineVarLatent), states.jl:85-97
+            E = Matrix{T}(I, mp, mp); E[(m_real[i] + 1):end, (m_real[i] + 1):end] .= 0
+            Ed = ROCArray(E); z = ROCArray(zeros(T, mp))
+            check(new.ctx, ccall((:agp_svgp_set_online_prior, libagp), Int32,
+                                 (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Float64),
+                                 new.h, i - 1, C_NULL, 0, mp, pointer(Ed), mp, pointer(z), 0.0))
+        else
+            iD, e1, pl, Za = snaps[i]
+            Zad = ROCArray{T}(Za)
+            check(new.ctx, ccall((:agp_svgp_set_online_prior, libagp), Int32,
+                                 (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Float64),
+                                 new.h, i - 1, pointer(Zad), size(Za, 1), size(Za, 2), pointer(iD), size(iD, 1), pointer(e1), pl))
+        end
+    end
+    start = 1
+    if !first_batch      # first iteration: local update under the old inducing points, natural gradient under the new (:78-104)
+        check(new.ctx, ccall((:agp_svgp_online_first_step, libagp), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64),
+                             new.h, old.h, pointer(new.X), size(new.X, 1), pointer(new.y), B))
+        start = 2
+    end
+    hyper_on = any(gp -> AGP.opt(gp) !== nothing || AGP.Zopt(gp) !== nothing, m.f)
+    for it in 1:iterations
+        it >= start && update_parameters!(new, nothing, 1.0)
+        callback === nothing || callback(ho, new, AGP.n_iter(m))
+        if hyper_on && AGP.n_iter(m) % m.atfrequency == 0 && AGP.n_iter(m) >= 3                     # :112-114
+            update_hyperparameters!(new)
+        end
+        AGP.inference(m).n_iter += 1
+    end
+    check(new.ctx, ccall((:agp_svgp_check_status, libagp), Int32, (Ptr{Cvoid},), new.h))
+    check(new.ctx, ccall((:agp_svgp_refresh_K, libagp), Int32, (Ptr{Cvoid},), new.h))
+    pull_posterior!(new); pull_hypers!(new)
+    for (gp, vgp, n) in zip(m.f, view.f, m_real)                              # back into the reference object, padding stripped
+        gp.post.μ = vgp.post.μ[1:n]; gp.post.Σ = Symmetric(Matrix(vgp.post.Σ)[1:n, 1:n])
+        gp.post.η₁ = vgp.post.η₁[1:n]; gp.post.η₂ = Symmetric(Matrix(vgp.post.η₂)[1:n, 1:n])
+        gp.Z = vgp.Z[1:n]
+    end
+    old === nothing || destroy!(old)
+    ho.cur, ho.m_real = new, m_real
+    AGP.set_trained!(m, true)
+    return ho, new
+end
+predict_f(ho::HipOnlineModel, Xt::AbstractMatrix, state=nothing; kw...) = predict_f(ho.cur, Xt; kw...)
+predict_y(ho::HipOnlineModel, Xt::AbstractMatrix, state=nothing; kw...) = predict_y(ho.cur, Xt; kw...)
+proba_y(ho::HipOnlineModel, Xt::AbstractMatrix, state=nothing; kw...) = proba_y(ho.cur, Xt; kw...)
+objective(ho::HipOnlineModel, state=nothing, y=nothing) = objective(ho.cur)   # incl. −extraKL (KLdivergences.jl:30-54)
+
+# ---- drop-in methods on the reference's own types ----------------------------------------------------------------------------------
+# With the shim loaded, `train!(model, X, y, n)` on an SVGP / MOSVGP / OnlineSVGP with AnalyticVI / AnalyticSVI runs on the device:
+# these methods are MORE SPECIFIC than the reference's `train!(model::AbstractGPModel, X::AbstractArray, y::AbstractArray, ...)`
+# (src/training/training.jl:13-22) and `update_parameters!` entry (:140-144), so dispatch selects them -- no wrapper call at the
+# user's site; `backend=:cpu` (or `AGPHip.default_backend!(:cpu)`) falls through to the reference's own method with `invoke`.
+# The device twin of a model lives in a WeakKeyDict keyed by the model object; predictions, ELBO and objective look it up and fall
+# back to the reference when the model was never trained on the device.  (As a package extension this section is
+# `ext/AGPHipExt.jl`, triggered by `using AMDGPU`.)
+const HipSVGP{T} = Union{SVGP{T,<:Any,<:AnalyticVI},AGP.MOSVGP{T,<:Any,<:AnalyticVI}}
+const BACKEND = Ref(:hip)
+default_backend!(b::Symbol) = (b in (:hip, :cpu) || throw(ArgumentError("backend is :hip or :cpu")); BACKEND[] = b)
+const TWINS = WeakKeyDict{Any,Any}()
+twin(model::HipSVGP; kw...) = get!(() -> HipModel(model; kw...), TWINS, model)
+twin(model::AGP.OnlineSVGP) = get!(() -> HipOnlineModel(model), TWINS, model)
+has_twin(model) = haskey(TWINS, model)
+
+function train!(model::HipSVGP, X::AbstractArray, y::AbstractArray, iterations::Int=100; backend::Symbol=BACKEND[],
+                reference_compat_stale_K::Bool=false, kwargs...)
+    backend === :cpu &&
+        return invoke(train!, Tuple{AGP.AbstractGPModel,AbstractArray,AbstractArray,Int}, model, X, y, iterations; kwargs...)
+    hm = twin(model; reference_compat_stale_K)
+    _, state = train!(hm, X, y, iterations; kwargs...)      # leaves the trained posterior / kernels / Z in `model` as well
+    return model, state
+end
+function train!(model::AGP.OnlineSVGP{T,<:Any,<:AnalyticVI}, X::AbstractMatrix, y::AbstractArray, state=nothing;
+                backend::Symbol=BACKEND[], kwargs...) where {T}
+    backend === :cpu &&
+        return invoke(train!, Tuple{AGP.OnlineSVGP,AbstractMatrix,AbstractArray,Any}, model, X, y, state; kwargs...)
+    _, st = train!(twin(model), X, y, state; kwargs...)
+    return model, st
+end
+for f in (:predict_f, :predict_y, :proba_y)
+    @eval function $f(model::Union{HipSVGP,AGP.OnlineSVGP}, X_test::AbstractMatrix, state=nothing; backend::Symbol=BACKEND[], kw...)
+        (backend === :cpu || !has_twin(model)) &&
+            return invoke($f, Tuple{AGP.AbstractGPModel,AbstractMatrix,Any}, model, X_test, state; kw...)
+        return $f(TWINS[model], X_test; kw...)
+    end
+end
+function ELBO(model::HipSVGP, X::AbstractMatrix, y::AbstractArray; backend::Symbol=BACKEND[], kw...)
+    (backend === :cpu || !has_twin(model)) && return invoke(ELBO, Tuple{AGP.AbstractGPModel,AbstractMatrix,AbstractArray}, model, X, y; kw...)
+    return ELBO(TWINS[model], X, y; kw...)
+end
+objective(model::HipSVGP, state::HipModel, y=nothing) = objective(state)    # the state train! returned IS the device twin
 
 end # module

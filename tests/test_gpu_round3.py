@@ -330,3 +330,35 @@ def test_latent_sharded_multioutput_handle_needs_its_communicator(mods):
     with pytest.raises(capi.AGPError) as ei:  # a slice of the latents cannot finish the mix alone
         eng.step_multi(rng.choice(len(X), 64, replace=False), len(X) / 64, capi.SHARD_LATENT, None)
     assert ei.value.status == 1 and "communicator" in str(ei.value)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the boundary without Python -- a C program (gcc) that includes include/agp_hip.h and owns its device buffers
+def test_c_host_drives_the_abi_on_a_golden_fixture(mods, tmp_path):
+    import struct
+    import subprocess
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "logistic_m64_svi.npz"))
+    X, Z, idx, Xt = g["X"], g["Z"], g["idx"], g["Xt"]
+    y = np.where(g["y"] > 0, 1.0, -1.0)  # treat_labels! (classification.jl:29-39) is host logic: the ABI takes +-1
+    N, D = X.shape
+    m, B, iters, nt = len(Z), int(g["B"]), len(idx), len(Xt)
+    case = tmp_path / "case.bin"
+    with open(case, "wb") as f:
+        f.write(struct.pack("<6q", N, D, m, B, iters, nt))
+        f.write(struct.pack("<2d", float(g["scale"]), float(g["variance"])))
+        for a in (X, y, Z):
+            f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
+        f.write(np.ascontiguousarray(idx, dtype="<i8").tobytes())
+        for a in (g["eta1_it10_l0"], g["eta2_it10_l0"], g["mu_it10_l0"], g["Sigma_it10_l0"], g["elbo"][-1:], Xt, g["pred_mu"][0],
+                  g["pred_var"][0]):
+            f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
+    pkg = os.path.join(ROOT, "augmentedgaussianprocesses.jl_amd")
+    exe = tmp_path / "abi_smoke"
+    cc = ["gcc", "-std=c11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+          os.path.join(ROOT, "tests", "c_host", "abi_smoke.c"), "-o", str(exe), "-L", pkg, "-lagp_hip", "-L", "/opt/rocm/lib",
+          "-lamdhip64", "-lm", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cc, check=True)
+    r = subprocess.run([str(exe), str(case)], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "ABI_SMOKE_OK" in r.stdout, (r.returncode, r.stdout, r.stderr)

@@ -221,3 +221,18 @@ int main(int argc, char** argv) {
                                               env.get("LD_LIBRARY_PATH", "")])
     out = subprocess.run([str(exe), capi.LIB_PATH], check=True, capture_output=True, text=True, env=env).stdout.split()
     assert int(out[0]) >= 100 and int(out[1]) == C.sizeof(capi.SvgpDesc) and int(out[2]) == C.sizeof(capi.KernelDesc)
+
+
+def test_c_client_compiles_and_links_against_the_header_and_library(built, tmp_path):
+    """tests/c_host/abi_smoke.c is a plain-C client of include/agp_hip.h (gcc -std=c11): it must compile without the C++ front end
+    and every entry point it calls must resolve in libagp_hip.so (it is RUN by the GPU suite, tests/test_gpu_round3.py)."""
+    import subprocess
+
+    pkg = os.path.join(ROOT, "augmentedgaussianprocesses.jl_amd")
+    exe = tmp_path / "abi_smoke"
+    cc = ["gcc", "-std=c11", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+          os.path.join(ROOT, "tests", "c_host", "abi_smoke.c"), "-o", str(exe), "-L", pkg, "-lagp_hip", "-L", "/opt/rocm/lib",
+          "-lamdhip64", "-lm", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cc, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.getsize(exe) > 0

@@ -1137,7 +1137,10 @@ struct Svgp : SvgpBase {
   int64_t pred_chunk = 0, pred_nt_cap = 0;
   double* gh_dev = nullptr;
   int gh_cap = 0, gh_n = 0;  // Gauss-Hermite nodes | weights (agp_svgp_set_quadrature / proba_y)
-  T* lam_dev = nullptr;       // Poisson / heteroscedastic lambda (state re-estimated by every local update)
+  T* lam_dev = nullptr;       // Poisson / heteroscedastic lambda (state re-estimated by every local update); Gaussian noise sigma2
+                              // when it is optimised (LikParams::noise_dev)
+  double* noise_adam = nullptr;
+  double noise_eta = 0.0;
   double* lam_part = nullptr; // per-workgroup partial sums of the lambda update
   double* frob_part = nullptr;  // row partial sums of frob_dot
   int64_t frob_cap = 0;
@@ -1240,6 +1243,10 @@ struct Svgp : SvgpBase {
       return AGP_ERR_UNSUPPORTED;
     }
     if (lp.kind == AGP_LIK_GAUSSIAN && !(desc.lik.p0 > 0)) return AGP_ERR_INVALID;
+    if (lp.kind == AGP_LIK_GAUSSIAN && desc.lik.p1 > 0) {  // GaussianLikelihood(sigma2; opt_noise = ADAM(p1)), gaussian.jl:18-23
+      lp.noise_dev = 1;
+      noise_eta = desc.lik.p1;
+    }
     if (lp.kind == AGP_LIK_STUDENTT && !(desc.lik.p0 > 0.5)) {
       ctx->err = "nu should be greater than 0.5";  // studentt.jl:28
       return AGP_ERR_INVALID;
@@ -1308,6 +1315,8 @@ struct Svgp : SvgpBase {
     AGPCHK(dmalloc(ctx, &scal_dev, 64));
     AGPCHK(dmalloc(ctx, &lam_dev, 1));
     AGPCHK(dmalloc(ctx, &lam_part, 2 * (Bp / 256 + 1)));
+    AGPCHK(dmalloc(ctx, &noise_adam, 6));  // ADAM state [m, v, t] of the noise optimiser, + a scratch state for fresh evaluations
+    HIPCHK(ctx, hipMemsetAsync(noise_adam, 0, sizeof(double) * 6, st()));
     hipLaunchKernelGGL((k_fill<T>), dim3(1), dim3(64), 0, st(), lam_dev, (int64_t)1, (T)(desc.lik.p0 > 0 ? desc.lik.p0 : 1.0));
     HIPCHK(ctx, hipMemsetAsync(info_dev, 0, sizeof(int32_t), st()));
     HIPCHK(ctx, hipMemsetAsync(infoK_dev, 0, sizeof(int32_t), st()));
@@ -1372,6 +1381,7 @@ struct Svgp : SvgpBase {
     if (gh_dev) dfree(gh_dev);
     if (lam_dev) dfree(lam_dev);
     if (lam_part) dfree(lam_part);
+    if (noise_adam) dfree(noise_adam);
     if (frob_part) dfree(frob_part);
   }
 
@@ -1935,7 +1945,24 @@ struct Svgp : SvgpBase {
                          rbuf + l0 * Bp, wbuf + l0 * Bp, Bp, flags_dev, (const T*)lam_dev, gamma + l0 * Bp);
       LAUNCHCHK(ctx);
     }
-    if (lp.kind == AGP_LIK_POISSON) {  // lambda <- sum(y) / sum E[logistic(f)]   poisson.jl:78
+    if (lp.kind == AGP_LIK_GAUSSIAN && lp.noise_dev) {  // sigma2 step, then theta / gradients with the new sigma2  gaussian.jl:56-72
+      const int nb = (int)((B + 255) / 256);
+      // a fresh evaluation (external ELBO: new local variables, ELBO.jl:32-47) steps sigma2 from a NEW optimiser state and throws
+      // that state away, as the reference does; the training state is left alone
+      double* ad = fresh ? noise_adam + 3 : noise_adam;
+      if (fresh) HIPCHK(ctx, hipMemsetAsync(ad, 0, sizeof(double) * 3, st()));
+      hipLaunchKernelGGL((k_noise_partial<T>), dim3(nb), dim3(256), 0, st(), B, (const T*)y, idx, (const T*)muf, (const T*)varf,
+                         lam_part);
+      if (lam_deferred) {
+        hipLaunchKernelGGL(k_lambda_reduce, dim3(1), dim3(256), 0, st(), nb, 1, (const double*)lam_part, (double)B, scal_dev + 60);
+      } else {
+        hipLaunchKernelGGL((k_noise_finish<T>), dim3(1), dim3(256), 0, st(), nb, (const double*)lam_part, (double)B,
+                           (const double*)nullptr, noise_eta, 0.9, 0.999, 1e-8, ad, lam_dev);
+        hipLaunchKernelGGL((k_gauss_grads<T>), dim3(nb), dim3(256), 0, st(), B, (T)rho, (const T*)y, idx, (const T*)lam_dev, theta,
+                           cbuf, rbuf, wbuf);
+      }
+      LAUNCHCHK(ctx);
+    } else if (lp.kind == AGP_LIK_POISSON) {  // lambda <- sum(y) / sum E[logistic(f)]   poisson.jl:78
       if (gh_n <= 0) {
         ctx->err = "PoissonLikelihood: install the Gauss-Hermite rule first (agp_svgp_set_quadrature)";
         return AGP_ERR_INVALID;
@@ -2380,6 +2407,10 @@ struct Svgp : SvgpBase {
         ctx->err = "multi-output tasks support the Gaussian / Logistic / StudentT likelihoods on this path";
         return AGP_ERR_UNSUPPORTED;
       }
+      if (tk == AGP_LIK_GAUSSIAN && liks[t].p1 > 0) {
+        ctx->err = "GaussianLikelihood(...; opt_noise) is not wired as a multi-output task likelihood";
+        return AGP_ERR_UNSUPPORTED;
+      }
       mocfg.kind[t] = liks[t].kind;
       mocfg.p0[t] = (T)liks[t].p0;
       mocfg.p1[t] = (T)liks[t].p1;
@@ -2620,6 +2651,15 @@ struct Svgp : SvgpBase {
 
   bool lam_deferred = false;  // set around step_local by the batch-sharded driver (see cavi_step_multi)
   agp_status lambda_finish_reduced() {
+    if (lp.kind == AGP_LIK_GAUSSIAN) {  // the reduced sum and batch size: the same ADAM step on every rank
+      const int nb = (int)((B_last + 255) / 256);
+      hipLaunchKernelGGL((k_noise_finish<T>), dim3(1), dim3(256), 0, st(), 1, (const double*)(scal_dev + 60), 0.0,
+                         (const double*)(scal_dev + 62), noise_eta, 0.9, 0.999, 1e-8, noise_adam, lam_dev);
+      hipLaunchKernelGGL((k_gauss_grads<T>), dim3(nb), dim3(256), 0, st(), B_last, (T)rho_last, (const T*)y_last, idx_last,
+                         (const T*)lam_dev, theta, cbuf, rbuf, wbuf);
+      LAUNCHCHK(ctx);
+      return AGP_OK;
+    }
     const int mode = lp.kind == AGP_LIK_POISSON ? 0 : 1;
     hipLaunchKernelGGL((k_lambda_finish_red<T>), dim3(1), dim3(64), 0, st(), (const double*)(scal_dev + 60), mode, lam_dev);
     if (lp.kind == AGP_LIK_HETEROSCEDASTIC) {
@@ -3011,6 +3051,7 @@ struct Svgp : SvgpBase {
   // optimisers.jl:12) and new hyper-optimiser states.  The posterior (eta1, eta2) belongs to the model, not the state: kept.
   agp_status init_state() override {
     n_opt = 1;
+    if (noise_adam) HIPCHK(ctx, hipMemsetAsync(noise_adam, 0, sizeof(double) * 6, st()));  // init_local_vars: new state_sigma2
     const T kk = (T)(lp.kind == AGP_LIK_LOGISTICSOFTMAX ? desc.lik.n_class : 1);
     hipLaunchKernelGGL((k_fill<T>), grid1(Bp), dim3(256), 0, st(), alpha, Bp, kk);
     LAUNCHCHK(ctx);
@@ -3253,7 +3294,7 @@ struct Svgp : SvgpBase {
   }
   agp_status get_lik_param(double* out) override {
     if (!out) return AGP_ERR_INVALID;
-    if (lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_HETEROSCEDASTIC) {
+    if (lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_HETEROSCEDASTIC || (lp.kind == AGP_LIK_GAUSSIAN && lp.noise_dev)) {
       T v;
       HIPCHK(ctx, hipMemcpyAsync(&v, lam_dev, sizeof(T), hipMemcpyDeviceToHost, st()));
       HIPCHK(ctx, hipStreamSynchronize(st()));
@@ -3264,7 +3305,9 @@ struct Svgp : SvgpBase {
     return AGP_OK;
   }
   agp_status set_lik_param(double v) override {
-    if (!(v > 0) || !(lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_HETEROSCEDASTIC)) return AGP_ERR_INVALID;
+    if (!(v > 0) || !(lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_HETEROSCEDASTIC ||
+                      (lp.kind == AGP_LIK_GAUSSIAN && lp.noise_dev)))
+      return AGP_ERR_INVALID;
     hipLaunchKernelGGL((k_fill<T>), dim3(1), dim3(64), 0, st(), lam_dev, (int64_t)1, (T)v);
     LAUNCHCHK(ctx);
     return AGP_OK;
@@ -3341,11 +3384,14 @@ struct Svgp : SvgpBase {
   //   cov = K** + jitt I - K*m (K^-1 - K^-1 Sigma K^-1) Km*      (K*m materialised: meant for small n_t)
   agp_status predict_f_cov(const void* xt, int64_t ldx, int64_t nt, void* mu_out, void* cov_out) override {
     if (!xt || nt <= 0 || nt > 8192 || ldx < D || !mu_out || !cov_out) return AGP_ERR_INVALID;
-    if (mo) {
-      ctx->err = "full predictive covariance is per latent: not defined for the mixed outputs of a multi-output model here";
+    if (mo_sharded) {
+      ctx->err = "full predictive covariance of a latent-sharded multi-output model is not wired (partial mixes would have to be "
+                 "all-reduced)";
       return AGP_ERR_UNSUPPORTED;
     }
-    AGPCHK(predict_f_latent(xt, ldx, nt, mu_out, nullptr));
+    // multi-output (predictions.jl:52-92): mu_out T[n_task][n_t] = sum_q A[t][q] mu_q, cov_out T[n_task][n_t][n_t] = sum_q A[t][q]^2 Cov_q
+    if (mo) AGPCHK(predict_f(xt, ldx, nt, mu_out, nullptr));
+    else AGPCHK(predict_f_latent(xt, ldx, nt, mu_out, nullptr));
     const int64_t nq = rup64(nt);
     T *Ks = nullptr, *T1 = nullptr, *Kss = nullptr, *Cq = nullptr;
     AGPCHK(dmalloc(ctx, &Ks, nq * mp));
@@ -3369,8 +3415,11 @@ struct Svgp : SvgpBase {
       if (rc != AGP_OK) break;
       rc = gemm_nt<T, EPI_EMINUS>(ctx, T1, mp, Ks, mp, nq, nq, mp, 0, Cq, nq, Kss, nq, nullptr, nullptr, nullptr, 0);
       if (rc != AGP_OK) break;
-      if (hipMemcpy2DAsync((T*)cov_out + (int64_t)l * nt * nt, sizeof(T) * nt, Cq, sizeof(T) * nq, sizeof(T) * nt, nt,
-                           hipMemcpyDeviceToDevice, st()) != hipSuccess)
+      if (mo) {
+        hipLaunchKernelGGL((k_mo_cov_acc<T>), grid2(nt, nt), blk2, 0, st(), nt, nT, (const T*)(A_dev + l), (int64_t)Qa(),
+                           (const T*)Cq, nq, (T*)cov_out, l == 0 ? 1 : 0);
+      } else if (hipMemcpy2DAsync((T*)cov_out + (int64_t)l * nt * nt, sizeof(T) * nt, Cq, sizeof(T) * nq, sizeof(T) * nt, nt,
+                                  hipMemcpyDeviceToDevice, st()) != hipSuccess)
         rc = AGP_ERR_HIP;
     }
     (void)hipStreamSynchronize(st());
@@ -3414,7 +3463,8 @@ struct Svgp : SvgpBase {
     }();
     const bool multi = cm && (cm->world > 1 || (force_split && mode == AGP_SHARD_BATCH));
     adopt_batch_shard(cm, mode);
-    const bool lam_lik = lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_HETEROSCEDASTIC;
+    const bool lam_lik = lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_HETEROSCEDASTIC ||
+                         (lp.kind == AGP_LIK_GAUSSIAN && lp.noise_dev);  // likelihood state re-estimated from whole-minibatch sums
     if (multi && lam_lik && mode == AGP_SHARD_LATENT) {
       // a Poisson model has one latent, and the two heteroscedastic latents are coupled point-wise and stay on one handle:
       // these models shard over the minibatch only
@@ -3569,8 +3619,14 @@ struct Svgp : SvgpBase {
     AGPCHK(predict_f(xt, ldx, nt, pmu, pvar));
     if (lp.kind == AGP_LIK_GAUSSIAN) {
       if (!o1) return AGP_ERR_INVALID;
-      hipLaunchKernelGGL((k_proba_regression<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)pmu, (const T*)pvar,
-                         lp.p0, 0, (T*)o0, (T*)o1);
+      T s2 = lp.p0;
+      if (lp.noise_dev) {  // the optimised noise lives on the device (compute_proba adds noise(l), gaussian.jl:41-45)
+        double v = 0.0;
+        AGPCHK(get_lik_param(&v));
+        s2 = (T)v;
+      }
+      hipLaunchKernelGGL((k_proba_regression<T>), grid1(nt), dim3(256), 0, st(), nt, (const T*)pmu, (const T*)pvar, s2, 0, (T*)o0,
+                         (T*)o1);
     } else if (lp.kind == AGP_LIK_STUDENTT) {
       if (!o1) return AGP_ERR_INVALID;
       const double nu = desc.lik.p0, sg = desc.lik.p1;

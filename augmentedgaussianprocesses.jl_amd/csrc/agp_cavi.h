@@ -407,6 +407,8 @@ struct LikParams {
   int kind;
   T p0;  // gaussian sigma2 / studentt nu / laplace beta / negbinomial r
   T p1;  // studentt sigma
+  int noise_dev = 0;  // GaussianLikelihood(...; opt_noise=ADAM(eta)): sigma2 is STATE, stepped by every local update and read from the
+                      // handle's likelihood-parameter word (lam[0], like the lambda of Poisson / Heteroscedastic) instead of p0
 };
 
 // Point-wise local update + expectation gradients of the single-latent likelihoods whose q(omega) needs no other state:
@@ -521,6 +523,7 @@ __device__ __forceinline__ void rowstats_row(int64_t i, int lane, int q, int64_t
     return;
   }
   if (lp.kind == LIK_MO || lp.kind == LIK_HETERO) return;  // mixing / two-latent coupling follow in k_mo_local, k_hetero_*
+  if (lp.kind == LIK_GAUSSIAN && lp.noise_dev) return;     // the noise step comes first (k_noise_*), then theta / gradients
   T yi = y[idx ? idx[i] : i];
   T th, cc, g1;
   if (lp.kind == LIK_POISSON) {  // poisson.jl:64-80,94-103 (lambda itself is re-estimated afterwards by k_poisson_*)
@@ -595,6 +598,57 @@ __global__ void k_lambda_finish(int nparts, int stride, const double* __restrict
       lam[0] = (T)(cand > cur ? cand : cur);
     }
   }
+}
+
+// GaussianLikelihood(sigma2; opt_noise = ADAM(eta))  (gaussian.jl:18-23, 56-72): before theta = 1 / sigma2 is refreshed, every
+// local update takes one ADAM ascent step on log sigma2 with
+//     grad = ((sum_i (y_i - mu_i)^2 + sum_i var_f,i) / sigma2 - B) / 2          (= d E_q[log p(y|f)] / d log sigma2)
+//     sigma2 <- exp(log sigma2 + ADAM(grad))
+// stage 1: per-block partial sums of (y - mu)^2 + var_f ; stage 2 (one workgroup): the sum in block order, the ADAM step on the
+// state adam = [m, v, t] (doubles) and the new sigma2 ; then theta, r = rho y / sigma2, w = rho theta / 2 with the NEW sigma2.
+template <typename T>
+__global__ void k_noise_partial(int64_t B, const T* __restrict__ y, const int64_t* __restrict__ idx, const T* __restrict__ muf,
+                                const T* __restrict__ varf, double* __restrict__ part) {
+  __shared__ double red[16];
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  double s = 0.0;
+  if (i < B) {
+    const double d = (double)y[idx ? idx[i] : i] - (double)muf[i];
+    s = d * d + (double)varf[i];
+  }
+  s = block_sum<double>(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// S = sum of part[0 .. nparts) ; Bn_ptr (nullable): the batch size as a device double (after an all-reduce over the shards)
+template <typename T>
+__global__ void k_noise_finish(int nparts, const double* __restrict__ part, double Bn, const double* __restrict__ Bn_ptr, double eta,
+                               double b1, double b2, double eps, double* __restrict__ adam, T* __restrict__ sigma2) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nparts; b += blockDim.x) s += part[b];
+  s = block_sum<double>(s, red);
+  if (threadIdx.x != 0) return;
+  const double s2 = (double)sigma2[0], n = Bn_ptr ? Bn_ptr[0] : Bn;
+  const double g = (s / s2 - n) / 2.0;
+  const double t = adam[2] + 1.0;
+  const double m = b1 * adam[0] + (1.0 - b1) * g, v = b2 * adam[1] + (1.0 - b2) * g * g;
+  adam[0] = m;
+  adam[1] = v;
+  adam[2] = t;
+  const double mh = m / (1.0 - pow(b1, t)), vh = v / (1.0 - pow(b2, t));
+  sigma2[0] = (T)exp(log(s2) + eta * mh / (sqrt(vh) + eps));
+}
+template <typename T>
+__global__ void k_gauss_grads(int64_t B, T rho, const T* __restrict__ y, const int64_t* __restrict__ idx,
+                              const T* __restrict__ sigma2, T* __restrict__ theta, T* __restrict__ c, T* __restrict__ r,
+                              T* __restrict__ w) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const T th = T(1) / sigma2[0];
+  theta[i] = th;
+  c[i] = T(0);
+  r[i] = rho * y[idx ? idx[i] : i] * th;
+  w[i] = rho * th / T(2);
 }
 
 // batch-sharded handles (round 3): the two sums and the batch size leave stage 1 as three doubles red3 = [S0, S1, B_local], are
@@ -989,6 +1043,22 @@ __global__ void k_axpy2d(int64_t rows, int64_t cols, int64_t ld, T alpha, const 
   if (r < rows && c < cols) A[r * ld + c] += alpha * Bm[r * ld + c];
 }
 
+// multi-output full predictive covariance (predictions.jl:82-90): cov_t (+)= A[t][q]^2 C_q for every task t ; C is n x n with
+// leading dimension ldc, out is T[n_task][n][n] ; first = 1 initialises
+template <typename T>
+__global__ void k_mo_cov_acc(int64_t n, int nT, const T* __restrict__ Aq, int64_t lda, const T* __restrict__ Cq, int64_t ldc,
+                             T* __restrict__ out, int first) {
+  int64_t r = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= n || c >= n) return;
+  const T v = Cq[r * ldc + c];
+  for (int t = 0; t < nT; ++t) {
+    const T a = Aq[t * lda];
+    T* o = out + ((int64_t)t * n + r) * n + c;
+    *o = (first ? T(0) : *o) + a * a * v;
+  }
+}
+
 // A -= (M + M')/2 on the n x n block
 template <typename T>
 __global__ void k_sub_sym(T* __restrict__ A, const T* __restrict__ M, int64_t ld, int64_t n) {
@@ -1085,7 +1155,7 @@ __global__ void k_elbo_terms(int64_t B, int nl, int64_t ldb, LikParams<T> lp, in
       double yi = (double)y[(idx ? idx[i] : i) * ystr];
       double mu = (double)muf[i], s = (double)varf[i];
       if (lp.kind == LIK_GAUSSIAN) {
-        double s2 = (double)lp.p0;
+        double s2 = lp.noise_dev ? (double)lam[0] : (double)lp.p0;
         e += -0.5 * (LOG2PI + log(s2) + ((yi - mu) * (yi - mu) + s) / s2);
       } else if (lp.kind == LIK_LOGISTIC) {
         double th = (double)theta[i], cc = (double)c[i];

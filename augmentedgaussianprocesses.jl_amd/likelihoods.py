@@ -21,19 +21,36 @@ class AbstractLikelihood:
 
 
 class GaussianLikelihood(AbstractLikelihood):
-    """GaussianLikelihood(σ²=1e-3)  src/likelihood/gaussian.jl:10-24 (opt_noise is not on this path)."""
+    """GaussianLikelihood(σ²=1e-3; opt_noise=false)  src/likelihood/gaussian.jl:10-24.  opt_noise: True -> ADAM(0.05) (:18-21), an
+    ADAM object, or False.  With it σ² is state: every local update takes one ADAM ascent step on log σ² before θ = 1/σ² is
+    refreshed (:56-72); the value is mirrored back into `sigma2` when training ends."""
 
     kind = capi.LIK_GAUSSIAN
 
     def __init__(self, sigma2: float = 1e-3, opt_noise=False):
-        if opt_noise:
-            raise NotImplementedError("opt_noise uses a removed Optimisers API in the reference (gaussian.jl:63-69)")
         if not sigma2 > 0:
             raise ValueError("σ² must be positive")
         self.sigma2 = float(sigma2)
+        if isinstance(opt_noise, bool):
+            self.noise_eta = 0.05 if opt_noise else 0.0
+        else:
+            eta = getattr(opt_noise, "eta", None)
+            if eta is None or tuple(getattr(opt_noise, "beta", (0.9, 0.999))) != (0.9, 0.999):
+                raise NotImplementedError("opt_noise takes ADAM(eta) with the default moments")
+            self.noise_eta = float(eta)
+
+    @property
+    def lam(self):  # the handle's likelihood-state word (what Poisson / Heteroscedastic call lambda)
+        if not self.noise_eta:
+            raise AttributeError("lam")
+        return self.sigma2
+
+    @lam.setter
+    def lam(self, v):
+        self.sigma2 = float(v)
 
     def lik_desc(self):
-        return capi.LikDesc(self.kind, 1, self.sigma2, 0.0)
+        return capi.LikDesc(self.kind, 1, self.sigma2, self.noise_eta)
 
     def __repr__(self):
         return f"Gaussian likelihood (σ² = {self.sigma2})"

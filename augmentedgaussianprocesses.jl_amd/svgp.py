@@ -313,7 +313,8 @@ class SVGP:
 
     def _pull_lik_state(self):
         """λ of PoissonLikelihood / HeteroscedasticLikelihood lives on the device while training; mirror it back"""
-        if self._h is not None and isinstance(self.likelihood, (PoissonLikelihood, HeteroscedasticLikelihood)):
+        if self._h is not None and (isinstance(self.likelihood, (PoissonLikelihood, HeteroscedasticLikelihood)) or
+                                    getattr(self.likelihood, "noise_eta", 0.0)):
             v = C.c_double()
             self._chk(capi.lib().agp_svgp_get_lik_param(self._h, C.byref(v)))
             self.likelihood.lam = v.value
@@ -676,19 +677,18 @@ def _predict_f_fullcov(model: SVGP, X_test, obsdim: int = 1):
     latent (K*m is materialised on the device: small n_t only)."""
     torch = _torch()
     L = capi.lib()
-    if isinstance(model, MOSVGP):
-        raise NotImplementedError("full predictive covariance of the mixed outputs is not wired")
     Xd = model._upload(X_test, obsdim)
     nt = Xd.shape[0]
     h = model._ensure_handle(max(model._max_batch, 1))
     dev = model._dev()
-    mu = torch.empty(model.n_latent, nt, dtype=model.tdtype, device=dev)
-    cov = torch.empty(model.n_latent, nt, nt, dtype=model.tdtype, device=dev)
+    nout = model.n_out  # latents, or tasks of a multi-output model (mixed: sum_q A[t][q]^2 cov_q, predictions.jl:82-90)
+    mu = torch.empty(nout, nt, dtype=model.tdtype, device=dev)
+    cov = torch.empty(nout, nt, nt, dtype=model.tdtype, device=dev)
     model._chk(L.agp_svgp_predict_f_cov(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), nt, C.c_void_p(mu.data_ptr()),
                                         C.c_void_p(cov.data_ptr())))
     model._chk(L.agp_ctx_sync(model._ctx))
     mu_np, cov_np = mu.cpu().numpy(), cov.cpu().numpy()
-    if model.n_latent > 1:
+    if nout > 1 or isinstance(model, MOSVGP):
         return tuple(mu_np), tuple(cov_np)
     return mu_np[0], cov_np[0]
 

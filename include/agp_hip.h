@@ -112,7 +112,9 @@ typedef struct {
   int32_t kind;    /* AGP_LIK_* */
   int32_t n_class; /* LogisticSoftMax: K (= number of latent GPs); else 1 */
   double p0;       /* Gaussian: sigma2 ; StudentT: nu ; Laplace: beta ; NegBinomial: r ; Poisson / Heteroscedastic: lambda_0 */
-  double p1;       /* StudentT: sigma */
+  double p1;       /* StudentT: sigma ; Gaussian: learning rate of the optional noise optimiser -- GaussianLikelihood(sigma2;
+                      opt_noise = ADAM(p1)), gaussian.jl:18-23,56-72; 0 = noise fixed.  With it sigma2 is STATE (stepped by every
+                      local update in log space, read / set with agp_svgp_get/set_lik_param) */
 } agp_lik_desc;
 
 typedef struct {
@@ -345,7 +347,9 @@ agp_status agp_svgp_init_state(agp_svgp* h);
 agp_status agp_svgp_predict_f(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* mu_out, void* var_out);
 /* predict_f(model, X_test; cov=true, diag=false)  predictions.jl:45-49 : full posterior covariance
  *   cov = K** + jitt I - K*m (K^-1 - K^-1 Sigma K^-1) Km*   per latent, cov_out : T[n_latent][n_t][n_t] row-major (mu_out as
- * predict_f).  K*m IS materialised here (n_t x m), so n_t <= 8192 (AGP_ERR_INVALID beyond). */
+ * predict_f).  A multi-output handle returns the MIXED outputs (predictions.jl:52-92): mu_out T[n_task][n_t] = sum_q A[t][q] mu_q,
+ * cov_out T[n_task][n_t][n_t] = sum_q A[t][q]^2 cov_q.  K*m IS materialised here (n_t x m), so n_t <= 8192 (AGP_ERR_INVALID
+ * beyond). */
 agp_status agp_svgp_predict_f_cov(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_t, void* mu_out, void* cov_out);
 /* predict_y  predictions.jl:178-198 : regression (Gaussian, StudentT, Laplace, Heteroscedastic) -> T[n_t] mean ;
  * logistic / BayesianSVM -> int32[n_t] (mu_f > 0) ; Poisson / NegBinomial -> T[n_t] expected count (predictions.jl:211) ;

@@ -129,7 +129,8 @@ function pull_kernel!(k::Kernel, σ²::Float64, scales::Vector{Float64})
     return nothing
 end
 
-lik_desc(l::GaussianLikelihood) = LikDesc(0, 1, AGP.noise(l), 0.0)
+# opt_noise (gaussian.jl:18-23): p1 carries the ADAM learning rate, σ² is then device state (pull_hypers! mirrors it back)
+lik_desc(l::GaussianLikelihood) = LikDesc(0, 1, AGP.noise(l), l.opt_noise === nothing ? 0.0 : Float64(l.opt_noise.eta))
 lik_desc(::AGP.BernoulliLikelihood{<:AGP.LogisticLink}) = LikDesc(1, 1, 0.0, 0.0)
 lik_desc(l::StudentTLikelihood) = LikDesc(2, 1, l.ν, l.σ)
 lik_desc(l::AGP.MultiClassLikelihood{<:AGP.LogisticSoftMaxLink}) = LikDesc(3, AGP.n_class(l), 0.0, 0.0)
@@ -318,6 +319,11 @@ function pull_hypers!(hm::HipModel{T}) where {T}
         v = Ref{Float64}()
         check(hm.ctx, ccall((:agp_svgp_get_lik_param, libagp), Int32, (Ptr{Cvoid}, Ref{Float64}), hm.h, v))
         l.invlink.λ .= v[]                                   # poisson.jl:78, heteroscedastic.jl:95 mutate it in place
+    end
+    if l isa GaussianLikelihood && l.opt_noise !== nothing   # gaussian.jl:69 mutates l.σ² in place
+        v = Ref{Float64}()
+        check(hm.ctx, ccall((:agp_svgp_get_lik_param, libagp), Int32, (Ptr{Cvoid}, Ref{Float64}), hm.h, v))
+        l.σ² .= v[]
     end
     if is_mo(hm)
         liks = AGP.likelihood(hm.model); Q = length(hm.model.f)

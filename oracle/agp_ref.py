@@ -220,11 +220,13 @@ class Kernel:
 # --------------------------------------------------------------------------------------------
 @dataclass
 class GaussianLikelihood:
-    """src/likelihood/gaussian.jl (opt_noise is OOS)."""
+    """src/likelihood/gaussian.jl.  opt_noise: an Adam (defined below) or None -- gaussian.jl:18-23; the step itself is in
+    local_updates (gaussian.jl:56-72; `Optimisers.apply!` there is the removed in-place form of the `apply` this port states)."""
 
     sigma2: float = 1e-3
     n_latent: int = 1
     name: str = "gaussian"
+    opt_noise: object = None
 
 
 @dataclass
@@ -375,7 +377,10 @@ def init_local_vars(lik, B, rng=None):
     local update before being read, except the LogisticSoftMax alpha (= K) which is state."""
     rng = rng or np.random.default_rng(0)
     if lik.name == "gaussian":
-        return {"theta": np.full(B, 1.0 / lik.sigma2)}
+        lv = {"theta": np.full(B, 1.0 / lik.sigma2)}
+        if lik.opt_noise is not None:  # gaussian.jl:49-52
+            lv["state_sigma2"] = lik.opt_noise.init(np.zeros(1))
+        return lv
     if lik.name in ("logistic", "studentt", "bayesiansvm", "negbinomial"):
         return {"c": rng.random(B), "theta": np.zeros(B)}
     if lik.name == "laplace":  # laplace.jl:56-58
@@ -400,6 +405,10 @@ def local_updates(lv, lik, y, mu_f, var_f):
     """local_updates! : gaussian.jl:56-72, logistic.jl:39-51, studentt.jl:68-82,
     logisticsoftmax.jl:55-79.  mu_f/var_f are tuples (one entry per latent)."""
     if lik.name == "gaussian":
+        if lik.opt_noise is not None:  # gaussian.jl:63-69: one optimiser step on log sigma2, ascent
+            grad = ((np.sum(np.abs(y - mu_f[0]) ** 2) + np.sum(var_f[0])) / lik.sigma2 - len(y)) / 2.0
+            lv["state_sigma2"], gradlog = lik.opt_noise.apply(lv["state_sigma2"], np.array([grad]))
+            lik.sigma2 = float(np.exp(np.log(lik.sigma2) + gradlog[0]))
         lv["theta"] = np.full(len(y), 1.0 / lik.sigma2)
         return lv
     if lik.name == "logistic":
@@ -1297,12 +1306,13 @@ class MOSVGP:
                          for t, l in enumerate(self.likelihoods))
         return float(tot)
 
-    def predict_f(self, Xt, cov=False):
-        """predictions.jl:52-92: latent predictions mixed by A (means by A, variances by A^2)."""
+    def predict_f(self, Xt, cov=False, diag=True):
+        """predictions.jl:52-92: latent predictions mixed by A (means by A, variances / full covariances (diag=False, :82-90) by
+        A^2)."""
         helper = SVGP.__new__(SVGP)
         helper.latents, helper.jitter = self.latents, self.jitter
         if cov:
-            mq, vq = SVGP.predict_f(helper, Xt, cov=True)
+            mq, vq = SVGP.predict_f(helper, Xt, cov=True, diag=diag)
         else:
             mq, vq = SVGP.predict_f(helper, Xt, cov=False), None
         mu_t = [sum(self.A[t, q] * mq[q] for q in range(self.Q)) for t in range(self.n_task)]

@@ -362,3 +362,108 @@ def test_c_host_drives_the_abi_on_a_golden_fixture(mods, tmp_path):
     r = subprocess.run([str(exe), str(case)], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "ABI_SMOKE_OK" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# GaussianLikelihood(sigma2; opt_noise) -- one ADAM ascent step on log sigma2 per local update (gaussian.jl:56-72)
+@pytest.mark.parametrize("stochastic", [True, False])
+def test_gaussian_opt_noise_matches_oracle(mods, stochastic):
+    AGP, R, capi, torch = mods
+    rng = np.random.default_rng(31)
+    X, f, Z = _toy(rng, N=300, m=20)
+    y = f + 0.3 * rng.standard_normal(len(f))
+    B, iters = 64, 12
+    idx = [rng.choice(len(X), B, replace=False) for _ in range(iters)]
+    ka = 1.5 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0))
+    la, lr = AGP.GaussianLikelihood(0.5, opt_noise=True), R.GaussianLikelihood(0.5, opt_noise=R.Adam(0.05))
+    ma = AGP.SVGP(ka, la, AGP.AnalyticSVI(B) if stochastic else AGP.AnalyticVI(), Z, optimiser=False)
+    mr = R.SVGP(R.Kernel("sqexponential", 2.0, 1.5), lr, Z, stochastic=stochastic, batchsize=B)
+    ea, er, sa, sr = [], [], [], []
+
+    def cb(mdl, s, i):
+        ea.append(AGP.objective(mdl, s))
+        mdl._pull_lik_state()
+        sa.append(la.sigma2)
+
+    AGP.train_(ma, X, y, iters, idx_stream=idx, callback=cb)
+    mr.train(X, y, iters, idx_stream=idx, callback=lambda M, it, xb, yb: (er.append(M.elbo(yb)), sr.append(lr.sigma2)))
+    assert np.allclose(sa, sr, rtol=1e-10) and abs(sa[-1] - 0.5) > 0.05  # the noise moved, identically
+    assert la.sigma2 == pytest.approx(lr.sigma2, rel=1e-10)
+    g = mr.latents[0]
+    mu, Sig, e1, e2 = ma.get_state(0)
+    assert _rel(e1, g.eta1) < 1e-9 and _rel(e2, g.eta2) < 1e-9 and _rel(mu, g.mu) < 1e-8 and _rel(Sig, g.Sigma) < 1e-8
+    assert np.allclose(ea, er, rtol=1e-8)
+    Xt = rng.random((77, X.shape[1]))
+    pa, pr = AGP.proba_y(ma, Xt), mr.proba_y(Xt)
+    assert _rel(pa[0], pr[0]) < 1e-8 and _rel(pa[1], pr[1]) < 1e-8  # predictive variance includes the LEARNED noise
+    # a second train! with the state continues the optimiser; without it the optimiser state restarts (init_local_vars)
+    AGP.train_(ma, X, y, 3, idx_stream=idx[:3], state=True)
+    yt = R.treat_labels(y, lr)
+    mr.train(X, yt, 3, idx_stream=idx[:3], labels_treated=True, fresh_state=False)
+    assert la.sigma2 == pytest.approx(lr.sigma2, rel=1e-10)
+    # external ELBO: fresh local variables -> one noise step from a NEW optimiser state (reference side effect, ELBO.jl:32-47)
+    ea2, er2 = AGP.ELBO(ma, X, y, rho=1.0), mr.elbo_fresh(X, yt, 1.0)
+    assert ea2 == pytest.approx(er2, rel=1e-8)
+    ma._pull_lik_state()
+    assert la.sigma2 == pytest.approx(lr.sigma2, rel=1e-10)
+
+
+def test_gaussian_opt_noise_batch_sharded_and_refused_as_task(mods):
+    AGP, R, capi, torch = mods
+    from agp_amd import parallel as P
+    from test_gpu_comm import _thread_ranks
+
+    rng = np.random.default_rng(32)
+    X, f, Z = _toy(rng)
+    y = f + 0.3 * rng.standard_normal(len(f))
+    B, iters = 128, 6
+    idx = [rng.choice(len(X), B, replace=False) for _ in range(iters)]
+    make = lambda: AGP.SVGP(1.5 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0)), AGP.GaussianLikelihood(0.4, opt_noise=True),
+                            AGP.AnalyticSVI(B), Z, optimiser=False)
+    ref = make()
+    AGP.train_(ref, X, y, iters, idx_stream=idx)
+
+    def body(rank, group):
+        m = make()
+        P.train_parallel(m, X, y, iters, idx, mode="batch", comm=P.Comm.from_group(m, group, rank, 2))
+        m._pull_lik_state()
+        return m.get_state(0), m.likelihood.sigma2
+
+    res = _thread_ranks(2, body)
+    assert res[0][1] == res[1][1] == pytest.approx(ref.likelihood.sigma2, rel=1e-10)
+    assert _rel(res[0][0][3], ref.get_state(0)[3]) < 1e-9
+    with pytest.raises(capi.AGPError):  # not wired as a multi-output task likelihood
+        mo = AGP.MOSVGP(AGP.SqExponentialKernel(), [AGP.GaussianLikelihood(0.1, opt_noise=True), AGP.LogisticLikelihood()],
+                        AGP.AnalyticVI(), [Z, Z], optimiser=False)
+        AGP.train_(mo, X, [y, np.sign(f)], 1)
+
+
+def test_multioutput_full_predictive_covariance(mods):
+    """predict_f(model::MOSVGP, X; cov=true, diag=false) (predictions.jl:52-92): the mixed outputs' full covariance
+    sum_q A[t][q]^2 Cov_q against the oracle, its diagonal against the streamed variances."""
+    AGP, R, capi, torch = mods
+    rng = np.random.default_rng(41)
+    X, f, Z = _toy(rng, N=300, m=40)
+    ys = [f + 0.1 * rng.standard_normal(len(f)), np.sign(f + 0.1 * rng.standard_normal(len(f)))]
+    Q = 3
+    A = rng.standard_normal((2, Q))
+    A /= np.linalg.norm(A, axis=1, keepdims=True)
+    Zs = [X[rng.permutation(len(X))[:40]].copy() for _ in range(Q)]
+    B, iters = 64, 4
+    idx = [rng.choice(len(X), B, replace=False) for _ in range(iters)]
+    ka = 1.3 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.5))
+    ma = AGP.MOSVGP(ka, [AGP.GaussianLikelihood(0.05), AGP.LogisticLikelihood()], AGP.AnalyticSVI(B), Zs, A=A.copy(),
+                    Aoptimiser=False, optimiser=False)
+    mr = R.MOSVGP(R.Kernel("sqexponential", 2.5, 1.3), [R.GaussianLikelihood(0.05), R.LogisticLikelihood()], Zs, A.copy(),
+                  stochastic=True, batchsize=B, A_opt=None)
+    AGP.train_(ma, X, ys, iters, idx_stream=idx)
+    mr.train(X, ys, iters, idx_stream=idx)
+    Xt = rng.random((50, X.shape[1]))
+    mu, cov = AGP.predict_f(ma, Xt, cov=True, diag=False)
+    mur, covr = mr.predict_f(Xt, cov=True, diag=False)
+    _, var = AGP.predict_f(ma, Xt, cov=True)
+    for t in range(2):
+        assert cov[t].shape == (50, 50)
+        assert _rel(mu[t], mur[t]) < 1e-8 and _rel(cov[t], covr[t]) < 1e-7
+        assert _rel(np.diag(cov[t]), var[t]) < 1e-8
+        assert np.max(np.abs(cov[t] - cov[t].T)) < 1e-12

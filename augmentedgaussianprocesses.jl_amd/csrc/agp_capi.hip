@@ -955,6 +955,8 @@ struct SvgpBase {
   virtual agp_status get_lik_param(double* out) = 0;
   virtual agp_status set_lik_param(double v) = 0;
   int64_t n_opt = 1;  // RobbinsMonro counter (optimisers.jl:12)
+  int64_t n_prologue = 0;  // CAVI steps whose natural-gradient part rode on the next step's task-graph launch (agp_svgp_step_counters)
+  int64_t n_steps = 0;     // agp_svgp_cavi_step calls
   // HIP-event timing of the dominant kernel sequence (agp_svgp_timing_*)
   bool timing = false;
   int timing_every = 1, timing_ctr = 0;  // every n-th sequence is bracketed (the two event records cost the step ~16 us at C2)
@@ -1894,6 +1896,7 @@ struct Svgp : SvgpBase {
             ph.kinv_mu0 = pend.kinv_mu0;
             ph.lr = pend.lr;
             pend.on = false;
+            n_prologue += 1;
           }
           AGPCHK(potrf_fused<T>(ctx, bt.A[0], mp, mp, bt.X[0], mp, bt.Dg[0], bt.E[0], mp, nel, 0, info_dev, m,
                                 (const T*)lat[todo[l0]].eta1, false, &src, &defer, sync_step ? &ssync : nullptr,
@@ -4246,7 +4249,14 @@ agp_status agp_svgp_cavi_step(agp_svgp* h, const void* x, int64_t ldx, const voi
       AGPCHK(s->lsm_alpha());
     }
   }
+  s->n_steps += 1;
   return s->step_finish();
+}
+agp_status agp_svgp_step_counters(agp_svgp* h, int64_t* n_steps_host, int64_t* n_prologue_host) {
+  HCHK(h);
+  if (n_steps_host) *n_steps_host = h->impl->n_steps;
+  if (n_prologue_host) *n_prologue_host = h->impl->n_prologue;
+  return AGP_OK;
 }
 
 agp_status agp_svgp_step_local(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B,

@@ -85,6 +85,8 @@ def parse():
     p.add_argument("--no-elbo-tol", action="store_true")
     p.add_argument("--no-extras", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
+    p.add_argument("--cpu-elbo-seconds", type=float, default=90.0,
+                   help="budget for running the CPU oracle through the smoothed time-to-ELBO rule (0: only extrapolate)")
     p.add_argument("--collective", default="rccl", choices=["rccl", "torch"],
                    help="N > 1: who issues the all-reduces: libagp_hip.so through its own RCCL communicator (default) or a "
                         "callback into torch.distributed (diagnostic)")
@@ -313,7 +315,9 @@ def main():
 
     for i in range(warm):
         step(i)
-    model._chk(L.agp_svgp_check_status(h))
+    model._chk(L.agp_svgp_check_status(h))  # (also takes the natural-gradient step the last warm-up iteration left pending)
+    cnt0 = (C.c_int64(), C.c_int64())
+    model._chk(L.agp_svgp_step_counters(h, C.byref(cnt0[0]), C.byref(cnt0[1])))
     # HIP events around the dominant kernel sequence of every 4th step (every step at c5): bracketing every step costs the C2
     # step 16 us (0.375 -> 0.391 ms), every 4th 4 us
     t_every = 1 if a.config == "c5" or steps < 12 else 4
@@ -327,6 +331,10 @@ def main():
     for i in range(warm, total):
         step(i)
     t_enq = time.perf_counter()  # host side done enqueueing (diagnostic: a host-bound loop shows up as t_enq ~ t1)
+    # the natural-gradient step of a single-latent CAVI step rides on the NEXT step's factorisation launch (include/agp_hip.h):
+    # the last timed step's is still pending here.  check_status takes it (stand-alone kernel) and synchronises, INSIDE the timed
+    # region -- all `steps` natural-gradient steps are paid for between t0 and t1, none is left outside
+    model._chk(L.agp_svgp_check_status(h))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -336,7 +344,9 @@ def main():
     nl, kms = C.c_int64(), C.c_double()
     model._chk(L.agp_svgp_timing_read(h, C.byref(nl), C.byref(kms)))
     model._chk(L.agp_svgp_timing_enable(h, 0))
-    model._chk(L.agp_svgp_check_status(h))
+    cnt1 = (C.c_int64(), C.c_int64())
+    model._chk(L.agp_svgp_step_counters(h, C.byref(cnt1[0]), C.byref(cnt1[1])))
+    n_pro = cnt1[1].value - cnt0[1].value  # timed steps whose natural-gradient part was the prologue of the next launch
     coll_stats = comm.stats() if comm is not None else (0, 0, 0.0)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
@@ -354,6 +364,13 @@ def main():
     n_lat_local = model.n_latent
     # algorithmic flops of one augmented factorisation: potrf m^3/3 + panel solves of the (B + 64) extension rows m^2 each
     flops_fact = mp ** 3 / 3.0 + (Bq + 64) * mp ** 2
+    # with the prologue the same launch also takes the natural-gradient step of the minibatch before (kappa' diag(w) kappa + the
+    # eta steps, analyticVI.jl:143-180): credited 2 B m^2 like SURVEY 8d's F_iter credits it (B m^2 executed: one triangle)
+    prologue = n_pro >= steps - 1 and steps > 1
+    flops_pro_credit, flops_pro_exec = 2.0 * Bq * mp ** 2, 1.0 * Bq * mp ** 2
+    if prologue:
+        flops_fact_exec = flops_fact + flops_pro_exec
+        flops_fact += flops_pro_credit
     launches_per_step = nl.value / max(-(-steps // t_every), 1)  # launches of the bracketed sequences / number of them
     avg_launch_s = (kms.value * 1e-3) / max(nl.value, 1)
     flops_per_launch = flops_fact * n_lat_local / max(launches_per_step, 1e-9)
@@ -361,7 +378,8 @@ def main():
     dag = launches_per_step <= n_lat_local + 0.5
     per_fact = launches_per_step / max(1, -(-n_lat_local // 16))  # latents share launches in chunks of up to 16
     blocked = (not dag) and abs(per_fact - mp // 64) > 0.5
-    kernel_name = (f"k_chol_dag<{tname}, true, {'true' if n_lat_local > 1 else 'false'}>" if dag else
+    kernel_name = (f"k_chol_dag<{tname}, true, false, false, true, true>" if dag and prologue else
+                   f"k_chol_dag<{tname}, true, {'true' if n_lat_local > 1 else 'false'}>" if dag else
                    f"blocked factorisation: k_chol_step + k_chol_panel + k_chol_trail <{tname}>" if blocked else
                    f"k_chol_step<{tname}>")
     # beyond the task graph the live number above is taken while the next minibatch's kappa GEMM runs on the prefetch stream
@@ -398,6 +416,12 @@ def main():
         "timed_steps": f"every {t_every}th step of the timed region ({-(-steps // t_every)} of {steps})" if t_every > 1 else "every step",
         "algorithmic_flops_per_launch": flops_per_launch,
     }
+    if prologue:
+        roofline["contents"] = ("one launch = the augmented Cholesky of -2 eta2 with the [kappa; eta1'] extension rows (m^3/3 + (B+64) m^2) "
+                                "AND, as its prologue, the natural-gradient step of the minibatch before (kappa' diag(w) kappa, credited "
+                                "2 B m^2 as in SURVEY 8d; B m^2 executed) -- until round 2 a kernel of its own between two factorisations")
+        roofline["executed_frac"] = round(flops_fact_exec * n_lat_local / max(launches_per_step, 1e-9) / avg_launch_s / 1e12 / peak, 4)
+        roofline["factorisation_only_frac"] = round((mp ** 3 / 3.0 + (Bq + 64) * mp ** 2) / avg_launch_s / 1e12 / peak, 4)
     if isolated:
         roofline["isolated"] = isolated
     # whole-iteration algorithmic rate (F_iter = 6 B m^2 + m^3 + B m (3D + 12) per latent)
@@ -461,7 +485,8 @@ def main():
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE as
     # MI355X_MICROARCH.md prescribes for gfx950); rocprofv3 cannot wrap bench.py from inside, so this is not live
     if a.config in ("c2", "c3") and world == 1 and comm is None:
-        for pf in (("r02_pmc_hbm_bytes.json", "r01h_pmc_hbm_bytes.json") if a.config == "c2" else ("r02_c3_pmc_hbm_bytes.json",)):
+        for pf in (("r03_pmc_hbm_bytes.json", "r02_pmc_hbm_bytes.json", "r01h_pmc_hbm_bytes.json") if a.config == "c2" else
+                   ("r03_c3_pmc_hbm_bytes.json", "r02_c3_pmc_hbm_bytes.json")):
             try:
                 with open(os.path.join(ROOT, "profiles", pf)) as fh:
                     pm = json.load(fh)
@@ -469,6 +494,8 @@ def main():
                 # ... and take the CAVI step's own instantiation (last template argument STEP = true) when the file has it: the
                 # other launches of the same kernel in that run (K_ZZ, factorisations with the inverse) have no extension rows
                 keys = [k for k in pm["kernels"] if k.startswith(roofline["kernel"][:-1])]
+                if not keys:
+                    continue
                 key = ([k for k in keys if k.endswith(", true>")] or keys)[0]
                 roofline["traffic"] = pm["kernels"][key]["hbm_bytes_per_launch_corrected"]
                 roofline["traffic_source"] = f"profiles/{pf} (rocprofv3 --pmc, separate passes, same command)"
@@ -480,7 +507,9 @@ def main():
         # measured MFMA ceiling (issue-rate microbenchmark inside the library)
         pk = C.c_double()
         if L.agp_mfma_peak(model._ctx, capi.F32 if f32 else capi.F64, C.byref(pk)) == 0:
-            out["roofline"]["measured_mfma_ceiling"] = round(pk.value, 1)
+            # (a sustained issue-rate figure under the chip's power limit, NOT a ceiling: the production GEMMs reach 1.03-1.05 of it
+            #  in short launches; every fraction in this line is against the datasheet peak)
+            out["roofline"]["mfma_issue_ubench_tflops"] = round(pk.value, 1)
 
     single_latent = cfg["lik"] in ("logistic", "studentt")
     # ---- extras (rank 0, single GPU, single-latent configs): hyper-parameter step and streaming prediction ----
@@ -529,15 +558,19 @@ def main():
         rho_e = N / EVAL
         e = C.c_double()
         hist, it = [], 0
-        max_it = 6000
+        # the contracted rule needs consecutive checks within 1e-4: with RobbinsMonro's (1 + t)^-0.51 step the minibatch noise of
+        # the logistic model falls below that only after tens of thousands of iterations (C2: ~3e-4 at t = 6000), so the loop runs
+        # up to 60 000 iterations or AGP_BENCH_ELBO_SECONDS (default 40 s), whichever comes first
+        max_it = 60000
+        t_cap = float(os.environ.get("AGP_BENCH_ELBO_SECONDS", "40"))
         rng2 = np.random.default_rng(99)
-        chunk = torch.as_tensor(np.stack([rng2.choice(N, B, replace=False) for _ in range(max_it // 10)]).astype(np.int64),
-                                device=dev)  # 600 distinct minibatches, cycled
+        chunk_np = np.stack([rng2.choice(N, B, replace=False) for _ in range(600)]).astype(np.int64)
+        chunk = torch.as_tensor(chunk_np, device=dev)  # 600 distinct minibatches, cycled
         hit = {"raw": None, "smoothed": None}
         consec = 0
         torch.cuda.synchronize()
         ts = time.perf_counter()
-        while it < max_it and (hit["raw"] is None or hit["smoothed"] is None):
+        while it < max_it and (hit["raw"] is None or hit["smoothed"] is None) and (time.perf_counter() - ts) < t_cap:
             for _ in range(10):
                 st = L.agp_svgp_cavi_step(h2, xp, ld, yp, C.c_void_p(chunk[it % chunk.shape[0]].data_ptr()), B, rho)
                 if st != 0:
@@ -563,7 +596,12 @@ def main():
         out["elbo_at_tol"] = hit["raw"][2] if hit["raw"] else None
         out["elbo_tol_rule"] = ("SURVEY 8d: ELBO (corrected, fresh local variables) on a fixed 8192-point batch every 10 iterations; stop "
                                 "when |ELBO_t - ELBO_{t-10}| / |ELBO_t| < 1e-4 for 3 consecutive checks; wall-clock includes the "
-                                f"ELBO evaluations; null = not reached within {max_it} iterations")
+                                f"ELBO evaluations; null = not reached within {it} iterations / {t_cap:.0f} s")
+        if len(hist) > 20:  # what the rule is up against: the spread of consecutive checks at the end of the run
+            d = np.abs(np.diff(hist[-101:])) / np.abs(np.asarray(hist[-100:] if len(hist) > 100 else hist[1:]))
+            out["elbo_check_noise_floor"] = {"median_rel_change_of_consecutive_checks": float(np.median(d)),
+                                             "max": float(np.max(d)), "over_last_checks": int(len(d)), "at_iteration": it}
+        out["_elbo_ctx"] = {"chunk": chunk_np, "eval_idx": eval_idx.cpu().numpy(), "EVAL": EVAL}
         out["time_to_elbo_tol_smoothed"] = {
             "seconds": round(hit["smoothed"][0], 4) if hit["smoothed"] else None,
             "iters": hit["smoothed"][1] if hit["smoothed"] else None,
@@ -586,6 +624,7 @@ def main():
     if dist is not None:
         dist.barrier()
     flush_c_stdio()
+    out.pop("_elbo_ctx", None)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if comm is not None:
@@ -685,12 +724,48 @@ def cpu_baseline(a, cfg, ell, Z, X, yh, idx_np, out):
                   f"(GEMM-form distances, best of {{8,16,32,64,all}} BLAS threads; host has {avail} cores), {tcpu:.1f} s of CPU "
                   f"work" + (f"; {min(cfg['K'], cfg['c5_latents'])} of the 16 latents, like the GPU line" if lik == "mo" else ""),
     }
-    # the same rule on the same index stream needs the same number of iterations: extrapolated, not run (it would take minutes)
+    # the same rule on the same index stream needs the same number of iterations: extrapolated where running it would take many
+    # minutes (the contracted rule at C2: tens of thousands of iterations at ~17 it/s) ...
     if out.get("iters_to_elbo_tol"):
         res["time_to_elbo_tol_s_extrapolated"] = round(out["iters_to_elbo_tol"] / rate, 1)
     sm = (out.get("time_to_elbo_tol_smoothed") or {}).get("iters")
     if sm:
         res["time_to_elbo_tol_smoothed_s_extrapolated"] = round(sm / rate, 1)
+    # ... and RUN where it is affordable: the smoothed rule with the oracle on the host cores, same minibatch stream, same
+    # evaluation batch, same rule, wall-clock including the ELBO evaluations (budget --cpu-elbo-seconds; 0 skips it)
+    ctx = out.get("_elbo_ctx")
+    budget = float(getattr(a, "cpu_elbo_seconds", 0.0))
+    if ctx is not None and sm and lik in ("logistic", "studentt") and budget > 0 and sm / rate < budget:
+        Xall = X.cpu().numpy().astype(np.float64)
+        yall = np.asarray(yh, dtype=np.float64)
+        with threadpool_limits(limits=best_thr):
+            r = fresh_ref()
+            yall_t = R.treat_labels(yall, r.likelihood)
+            ev = ctx["eval_idx"]
+            Xe, ye = Xall[ev], yall_t[ev]
+            hist, it, hit_s, hit_r, consec = [], 0, None, None, 0
+            ts = time.perf_counter()
+            while (time.perf_counter() - ts) < budget and hit_s is None:
+                for _ in range(10):
+                    ib = ctx["chunk"][it % len(ctx["chunk"])]
+                    r.update_parameters(Xall[ib], yall_t[ib])
+                    it += 1
+                hist.append(r.elbo_fresh(Xe, ye, N / ctx["EVAL"]))
+                now = time.perf_counter() - ts
+                if len(hist) >= 2:
+                    consec = consec + 1 if abs(hist[-1] - hist[-2]) / abs(hist[-1]) < 1e-4 else 0
+                    if hit_r is None and consec >= 3:
+                        hit_r = (now, it)
+                if len(hist) >= 20:
+                    m1, m0 = sum(hist[-10:]) / 10.0, sum(hist[-20:-10]) / 10.0
+                    if abs(m1 - m0) / abs(m1) < 1e-3:
+                        hit_s = (now, it, hist[-1])
+        res["time_to_elbo_tol_smoothed_measured"] = {
+            "seconds": round(hit_s[0], 1) if hit_s else None, "iters": hit_s[1] if hit_s else None,
+            "elbo": hit_s[2] if hit_s else None,
+            "note": "the oracle RUN through the same rule on the same minibatch stream and evaluation batch (not extrapolated)"}
+        if hit_r:
+            res["time_to_elbo_tol_measured"] = {"seconds": round(hit_r[0], 1), "iters": hit_r[1]}
     return res
 
 

@@ -210,6 +210,10 @@ agp_status agp_svgp_get_opt_state(agp_svgp* h, int64_t* n_host);
  * step are not read again after the call that follows it. */
 agp_status agp_svgp_cavi_step(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx,
                               int64_t B, double rho);
+/* Diagnostics of the scheduling described above: number of agp_svgp_cavi_step calls on this handle, and how many of them had their
+ * natural-gradient part taken as the prologue of the following step's factorisation launch (the rest took it with the stand-alone
+ * kernel).  bench.py reads them to decide what the dominant launch contained.  Host counters, no synchronisation. */
+agp_status agp_svgp_step_counters(agp_svgp* h, int64_t* n_steps_host, int64_t* n_prologue_host);
 /* The same step in phases, for multi-GPU runs:
  *   step_local  : compute_kappa + mean_f/var_f (+ c_k for LogisticSoftMax)   latentgp.jl:209-215,171-189
  *   lsm_*       : LogisticSoftMax cross-latent fixed point, logisticsoftmax.jl:65-72:

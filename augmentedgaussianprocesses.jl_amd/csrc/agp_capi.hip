@@ -608,7 +608,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       const char* e = getenv("AGP_DAG_TEST_ABORT");
       return e && e[0] == '1';
     }();
-    if (safe && !do_x) {
+    if (safe && (!do_x || safe->want_x)) {
       if (test_abort) hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, c->stream, info_dev, -1);
       if (can_defer) *defer_safe = true;
       else AGPCHK(launch_chol_safe<T>(c, one, *safe, 1, ld, ldx, lde, ne, nt, info_dev, nvalid));
@@ -1045,13 +1045,16 @@ struct Svgp : SvgpBase {
     bool keep_last = false;  // this step reuses kappa / K~ of the previous full-batch step
     bool via_inverse = false;  // this step gets W, v from the available inverse factor instead of a new factorisation
     // hyper-parameter optimiser state (ADAM): kernel parameters on the host, Z on the device
-    std::vector<double> k_m, k_v;
+    std::vector<double> k_m, k_v;  // (host staging of the moments for agp_svgp_hyper_opt_state; the live ones are kadam)
     int k_step = 0, z_step = 0;
+    double* kadam = nullptr;       // device: ADAM moments of the kernel parameters [m (1 + D) | v (1 + D)]
+    bool host_params_stale = false;  // the device parameter array moved (device ADAM): k.variance / k.scales lag behind
     double *z_am = nullptr, *z_av = nullptr;
     // La holds: 0 = -2*eta2 (unfactored), 1 = its Cholesky factor ; xa_valid: Xa = La^-1 is current
     int la_state = 0;
     bool xa_valid = false;
     double half_logdetK = 0.0;
+    bool logdet_pending = false;  // half_logdetK still sits in logdetK_dev (asynchronous K refresh)
     // AGP_FLAG_STALE_K: the step-side copies of (inv(K), L^-1, K\mu0, logdet K) frozen at the first hyper step of a train! --
     // what the reference keeps using until train! ends (training.jl:187-208); the members above are always the fresh ones
     T *sKinv = nullptr, *sXk = nullptr, *skinv_mu0 = nullptr;
@@ -1271,7 +1274,7 @@ struct Svgp : SvgpBase {
     const int64_t mm = mp * mp;
     for (auto& g : lat) {
       g.k.scales.assign(D, 1.0);
-      AGPCHK(dmalloc(ctx, &g.scales, D));
+      AGPCHK(dmalloc(ctx, &g.scales, D + 1));  // [scale_0 .. scale_{D-1} | variance]: the kernel's device parameter array
       AGPCHK(dmalloc(ctx, &g.Z, m * D));
       AGPCHK(dmalloc(ctx, &g.L, mm));
       AGPCHK(dmalloc(ctx, &g.Xk, mm));
@@ -1367,6 +1370,7 @@ struct Svgp : SvgpBase {
       T* sp[] = {g.sKinv, g.sXk, g.skinv_mu0};
       for (T* q : sp)
         if (q) dfree(q);
+      if (g.kadam) dfree(g.kadam);
       if (g.z_am) dfree(g.z_am);
       if (g.z_av) dfree(g.z_av);
     }
@@ -1385,15 +1389,35 @@ struct Svgp : SvgpBase {
     if (lam_part) dfree(lam_part);
     if (noise_adam) dfree(noise_adam);
     if (frob_part) dfree(frob_part);
+    if (logdetK_dev) dfree(logdetK_dev);
   }
 
+  // host copy of the kernel parameters -> device array [scales | variance] (set_kernel; the training loop never comes here: the
+  // hyper step's ADAM runs on the device, k_adam_kernel_params)
   agp_status upload_scales(Latent& g) {
-    std::vector<T> h(D);
+    std::vector<T> h(D + 1);
     for (int64_t d = 0; d < D; ++d) h[d] = (T)g.k.scales[d];
-    HIPCHK(ctx, hipMemcpyAsync(g.scales, h.data(), sizeof(T) * D, hipMemcpyHostToDevice, st()));
+    h[D] = (T)g.k.variance;
+    HIPCHK(ctx, hipMemcpyAsync(g.scales, h.data(), sizeof(T) * (D + 1), hipMemcpyHostToDevice, st()));
     HIPCHK(ctx, hipStreamSynchronize(st()));  // h goes out of scope
+    g.host_params_stale = false;
     return AGP_OK;
   }
+  // device -> host copy, only where host logic needs the values (get_kernel, prediction set-up, the online model's hand-over):
+  // synchronises
+  agp_status params_to_host(Latent& g) {
+    if (!g.host_params_stale) return AGP_OK;
+    std::vector<T> h(D + 1);
+    HIPCHK(ctx, hipMemcpyAsync(h.data(), g.scales, sizeof(T) * (D + 1), hipMemcpyDeviceToHost, st()));
+    HIPCHK(ctx, hipStreamSynchronize(st()));
+    for (int64_t d = 0; d < D; ++d) g.k.scales[d] = (double)h[d];
+    g.k.variance = (double)h[D];
+    g.host_params_stale = false;
+    return AGP_OK;
+  }
+  // the variance argument of the kernels that take (scales, variance): the host value, or -1 = "read element D of the device
+  // parameter array" while the host copy is stale (between a device-side ADAM step and the next params_to_host)
+  T kvar(const Latent& g) const { return g.host_params_stale ? T(-1) : (T)g.k.variance; }
 
   // VarPosterior{T}(dim): mu = 0, Sigma = I, eta1 = 0, eta2 = -I/2   (posterior.jl:29-37)
   agp_status reset_posterior(Latent& g) {
@@ -1481,40 +1505,48 @@ struct Svgp : SvgpBase {
       any = true;
       // the factorisations of K_ZZ latch their failures in a word of their own (infoK_dev): what an earlier asynchronous step
       // latched (K~ <= 0, a non-SPD -2*eta2) stays in info_dev / flags_dev and is reported as what it is by check_status
-      for (int attempt = 0; attempt < 2; ++attempt) {
+      {
         AGPCHK(ensure_zsc(g));
         (void)launch_kernelmatrix<T>(ctx, st(), (const T*)g.Z, D, (const int64_t*)nullptr, m, (const T*)g.Z, D, m, D,
-                                     (const T*)g.scales, g.k.kind, (T)g.k.variance, g.L, mp, mp, mp, 1, (T)jitter,
+                                     (const T*)g.scales, g.k.kind, kvar(g), g.L, mp, mp, mp, 1, (T)jitter,
                                      (const T*)nullptr, (T*)nullptr, (int64_t)0, 0, (const T*)g.Zsc, (const T*)g.zn);
         LAUNCHCHK(ctx);
-        AGPCHK(potrf_fused<T>(ctx, g.L, mp, mp, g.Xk, mp, g.DgK, (T*)nullptr, 0, 0, 1, infoK_dev, m));
+        // the task graph's in-stream fallback recomputes K from the inducing points (the factor overwrote it) and forms L^-1 itself
+        SafeSrc<T> src{};
+        src.want_x = 1;
+        src.kz = g.Z;
+        src.ldz = D;
+        src.mz = m;
+        src.Dz = D;
+        src.kscales = g.scales;
+        src.kkind = g.k.kind;
+        src.kvariance = kvar(g);
+        src.kjitter = (T)jitter;
+        AGPCHK(potrf_fused<T>(ctx, g.L, mp, mp, g.Xk, mp, g.DgK, (T*)nullptr, 0, 0, 1, infoK_dev, m, (const T*)nullptr, true, &src));
         AGPCHK(xtx_padded<T>(ctx, g.Xk, mp, mp, g.Kinv, mp));
-        hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.DgK, m, scal_dev);
+        if (!logdetK_dev) AGPCHK(dmalloc(ctx, &logdetK_dev, nl));
+        const int li = (int)(&g - lat.data());
+        hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.DgK, m, logdetK_dev + li);
         LAUNCHCHK(ctx);
-        double hl = 0;
-        int32_t info = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&hl, scal_dev, sizeof(double), hipMemcpyDeviceToHost, st()));
-        HIPCHK(ctx, hipMemcpyAsync(&info, infoK_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st()));
-        HIPCHK(ctx, hipStreamSynchronize(st()));  // one synchronisation per refreshed latent: log det K and the status together
-        if (info != 0) HIPCHK(ctx, hipMemsetAsync(infoK_dev, 0, sizeof(int32_t), st()));
-        if (info == -1 && attempt == 0) {  // the task graph lost a dependency: recompute K and factor with per-column launches
-          if (!ctx->dag_off)
-            fprintf(stderr, "[agp_hip] warning: a task-graph factorisation lost a tile dependency (is another process using this "
-                            "GPU?); re-running it with plain launches, which this context uses for the next %lld steps\n",
-                    (long long)ctx->dag_backoff);
-          dag_pause(ctx);
-          continue;
+        g.logdet_pending = true;
+        if (!refresh_lazy) {
+          // log det K and the status, read now: one synchronisation per refreshed latent.  (refresh_lazy: a refresh issued from
+          // inside the training loop -- the hyper step moved the kernel -- leaves both on the device: log det K is fetched when an
+          // ELBO asks for it, a non-SPD K_ZZ stays latched in infoK_dev and is reported by agp_svgp_check_status)
+          int32_t info = 0;
+          HIPCHK(ctx, hipMemcpyAsync(&info, infoK_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st()));
+          AGPCHK(resolve_logdet(g));  // synchronises
+          if (info != 0) {
+            HIPCHK(ctx, hipMemsetAsync(infoK_dev, 0, sizeof(int32_t), st()));
+            for (auto& q : lat) q.K_stale = true;
+            // a failure an earlier asynchronous step latched (K~ <= 0 makes everything after it NaN, kernel parameters included)
+            // is the root cause and is what the reference would have thrown first
+            AGPCHK(check_status());
+            ctx->err = info < 0 ? std::string("task-graph factorisation of K_ZZ aborted: a tile dependency never arrived")
+                                : "PosDefException: K_ZZ + jitter*I is not positive definite; leading minor " + std::to_string(info);
+            return info < 0 ? AGP_ERR_HIP : AGP_ERR_NOT_POSDEF;
+          }
         }
-        if (info != 0) {
-          for (auto& q : lat) q.K_stale = true;
-          // a failure an earlier asynchronous step latched (K~ <= 0 makes everything after it NaN, kernel parameters included)
-          // is the root cause and is what the reference would have thrown first
-          AGPCHK(check_status());
-          ctx->err = "PosDefException: K_ZZ + jitter*I is not positive definite; leading minor " + std::to_string(info);
-          return AGP_ERR_NOT_POSDEF;
-        }
-        g.half_logdetK = hl;
-        break;
       }
       if (g.mu0) {
         hipLaunchKernelGGL((k_symv<T>), grid1(mp * 64), dim3(256), 0, st(), (const T*)g.Kinv, mp, mp, (const T*)g.mu0,
@@ -1594,14 +1626,14 @@ struct Svgp : SvgpBase {
     } else {
       dim3 gk((unsigned)(mp / TILE), (unsigned)(map / TILE));
       (void)launch_kernelmatrix<T>(ctx, st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
-                         (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Kab, mp, map, mp, 0, T(0),
+                         (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, kvar(g), g.Kab, mp, map, mp, 0, T(0),
                          (const T*)nullptr, (T*)nullptr, (int64_t)0, 0, (const T*)g.Zsc, (const T*)g.zn);
       LAUNCHCHK(ctx);
       AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.Kab, mp, g.Kinv, mp, map, mp, mp, 0, g.kappa_a, mp, nullptr, 0, nullptr, nullptr,
                                     nullptr, 0)));
       dim3 ga((unsigned)(map / TILE), (unsigned)(map / TILE));
       (void)launch_kernelmatrix<T>(ctx, st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
-                         (const T*)g.Za, D, ma, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Kta, map, map, map, 0,
+                         (const T*)g.Za, D, ma, D, (const T*)g.scales, g.k.kind, kvar(g), g.Kta, map, map, map, 0,
                          T(0), (const T*)nullptr, (T*)nullptr, (int64_t)0);
       hipLaunchKernelGGL((k_add_diag<T>), grid1(ma), dim3(256), 0, st(), g.Kta, map, ma, (T)jitter);
       LAUNCHCHK(ctx);
@@ -1650,6 +1682,7 @@ struct Svgp : SvgpBase {
     HIPCHK(ctx, hipMemcpyAsync(h, scal_dev + 2, sizeof(double) * 2, hipMemcpyDeviceToHost, st()));
     HIPCHK(ctx, hipStreamSynchronize(st()));
     // (-logdet Sigma + logdet K - mu'eta1)/2 with logdet Sigma = -2 sum log diag chol(-2 eta2)
+    AGPCHK(resolve_logdet(g));
     *prevLa_host = 0.5 * (2.0 * h[0] + 2.0 * g.half_logdetK - h[1]);
     return AGP_OK;
   }
@@ -1738,7 +1771,10 @@ struct Svgp : SvgpBase {
     AGPCHK(check_batch(B));
     if (!x || !y || ldx < D) return AGP_ERR_INVALID;
     dag_tick(ctx);
-    AGPCHK(refresh_K());
+    refresh_lazy = !fresh;  // a refresh issued from inside the training loop (the hyper step moved the kernel) does not synchronise
+    const agp_status rks = refresh_K();
+    refresh_lazy = false;
+    AGPCHK(rks);
     const int64_t Bq = rup64(B);
     const int ns = (int)(2 * mp / TILE);
     const bool reuse = !desc.stochastic && !fresh && x == x_last && idx == idx_last && B == B_last && ldx == ldx_last;
@@ -1806,7 +1842,7 @@ struct Svgp : SvgpBase {
         AGPCHK(ensure_zsc(g));
         dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
         (void)launch_kernelmatrix<T>(ctx, st(), (const T*)x, ldx, idx, B, (const T*)g.Z,
-                           D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Knm, mp, Bq, mp, 0, T(0),
+                           D, m, D, (const T*)g.scales, g.k.kind, kvar(g), g.Knm, mp, Bq, mp, 0, T(0),
                            (const T*)nullptr, (T*)nullptr, (int64_t)0, 0, (const T*)g.Zsc, (const T*)g.zn);
         LAUNCHCHK(ctx);
         AGPCHK((gemm_nt<T, EPI_KAPPA>(ctx, g.Knm, mp, kinv_kappa(g), mp, Bq, mp, mp, 0, g.kappa, mp, g.Knm, mp, nullptr,
@@ -1928,7 +1964,8 @@ struct Svgp : SvgpBase {
         rb.pk[q] = g.pk;
         rb.W[q] = g.Wbuf;
         rb.v[q] = g.Wbuf + Bq * mp;
-        rb.kdiag[q] = (T)g.k.variance;
+        rb.kdiag[q] = kvar(g);
+        rb.kd_ptr[q] = g.scales + D;
         rb.use_kt[q] = g.keep_last ? 1 : 0;
       }
       if (merged_safe) {  // nl == 1
@@ -2070,7 +2107,7 @@ struct Svgp : SvgpBase {
       if (!hyKnm && dmalloc(ctx, &hyKnm, Bp * mp) != AGP_OK) return nullptr;
       dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
       (void)launch_kernelmatrix<T>(ctx, st(), (const T*)x_last, ldx_last, idx_last, B,
-                         (const T*)q.Z, D, m, D, (const T*)q.scales, q.k.kind, (T)q.k.variance, hyKnm, mp, Bq, mp, 0, T(0),
+                         (const T*)q.Z, D, m, D, (const T*)q.scales, q.k.kind, kvar(q), hyKnm, mp, Bq, mp, 0, T(0),
                          (const T*)nullptr, (T*)nullptr, (int64_t)0, 0, (const T*)q.Zsc, (const T*)q.zn);
       return hyKnm;
     };
@@ -2154,7 +2191,7 @@ struct Svgp : SvgpBase {
       dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
       const int64_t tiles = (int64_t)gk.x * gk.y;
       hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)x_last, ldx_last, idx_last, B,
-                         (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, (const T*)hyH3, mp,
+                         (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, kvar(g), (const T*)hyH3, mp,
                          hy_pvar, hy_pscale, hy_pZ, mp);
       hipLaunchKernelGGL((k_hyper_reduce_scalar<T>), dim3((unsigned)(D + 1)), dim3(256), 0, st(), tiles, D, (const double*)hy_pvar,
                          (const double*)hy_pscale, hy_g, 1.0);
@@ -2205,7 +2242,7 @@ struct Svgp : SvgpBase {
       dim3 gk((unsigned)(mp / TILE), (unsigned)(mp / TILE));
       const int64_t tiles = (int64_t)gk.x * gk.y;
       hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)g.Z, D, (const int64_t*)nullptr,
-                         m, (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, (const T*)Tw2, mp,
+                         m, (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, kvar(g), (const T*)Tw2, mp,
                          hy_pvar, hy_pscale, hy_pZ, mp);
       hipLaunchKernelGGL((k_hyper_reduce_scalar<T>), dim3((unsigned)(D + 1)), dim3(256), 0, st(), tiles, D, (const double*)hy_pvar,
                          (const double*)hy_pscale, hy_g, 1.0);
@@ -2217,7 +2254,7 @@ struct Svgp : SvgpBase {
       const int64_t map = g.map, ma = g.ma;
       dim3 gk((unsigned)(mp / TILE), (unsigned)(map / TILE));
       hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
-                         (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, (const T*)g.oh1, mp, hy_pvar,
+                         (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, kvar(g), (const T*)g.oh1, mp, hy_pvar,
                          hy_pscale, hy_pZ, mp);
       hipLaunchKernelGGL((k_hyper_reduce_scalar<T>), dim3((unsigned)(D + 1)), dim3(256), 0, st(), (int64_t)gk.x * gk.y, D,
                          (const double*)hy_pvar, (const double*)hy_pscale, hy_g, 1.0);
@@ -2225,7 +2262,7 @@ struct Svgp : SvgpBase {
                          hy_dZ, T(1), 1);
       dim3 ga((unsigned)(map / TILE), (unsigned)(map / TILE));
       hipLaunchKernelGGL((k_kernel_backward<T>), ga, dim3(NTHREADS), 0, st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
-                         (const T*)g.Za, D, ma, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, (const T*)g.invDa, map,
+                         (const T*)g.Za, D, ma, D, (const T*)g.scales, g.k.kind, kvar(g), (const T*)g.invDa, map,
                          hy_pvar, hy_pscale, hy_pZ, map);
       hipLaunchKernelGGL((k_hyper_reduce_scalar<T>), dim3((unsigned)(D + 1)), dim3(256), 0, st(), (int64_t)ga.x * ga.y, D,
                          (const double*)hy_pvar, (const double*)hy_pscale, hy_g, 0.5);
@@ -2233,9 +2270,10 @@ struct Svgp : SvgpBase {
     }
     hipLaunchKernelGGL((k_hyper_sum<T>), dim3(1), dim3(1024), 0, st(), B, (const T*)hy_gs, (double)rho, hy_g);
     LAUNCHCHK(ctx);
+    if (dZ_out) HIPCHK(ctx, hipMemcpyAsync(dZ_out, hy_dZ, sizeof(T) * m * D, hipMemcpyDeviceToDevice, st()));
+    if (hy_grad_on_device_only) return AGP_OK;  // the training loop: the gradient stays in hy_g / hy_dZ for the device-side ADAM
     std::vector<double> hg(1 + D);
     HIPCHK(ctx, hipMemcpyAsync(hg.data(), hy_g, sizeof(double) * (1 + D), hipMemcpyDeviceToHost, st()));
-    if (dZ_out) HIPCHK(ctx, hipMemcpyAsync(dZ_out, hy_dZ, sizeof(T) * m * D, hipMemcpyDeviceToDevice, st()));
     HIPCHK(ctx, hipStreamSynchronize(st()));
     if (dvar) *dvar = hg[0];
     if (dscale)
@@ -2244,79 +2282,64 @@ struct Svgp : SvgpBase {
     return AGP_OK;
   }
   std::vector<double> hy_last;
+  bool hy_grad_on_device_only = false;  // set around hypergrad() by hyper_step(): no download, no synchronisation
 
-  static void adam_host(std::vector<double>& am, std::vector<double>& av, int step, const std::vector<double>& g, double eta,
-                        double b1, double b2, double eps, std::vector<double>& delta) {
-    delta.resize(g.size());
-    for (size_t i = 0; i < g.size(); ++i) {
-      am[i] = b1 * am[i] + (1 - b1) * g[i];
-      av[i] = b2 * av[i] + (1 - b2) * g[i] * g[i];
-      double mh = am[i] / (1 - std::pow(b1, step)), vh = av[i] / (1 - std::pow(b2, step));
-      delta[i] = eta * mh / (std::sqrt(vh) + eps);
+  // ADAM moments of the kernel-parameter optimiser (1 + D entries: variance, scales; a ScaleTransform uses entry 1 only).  They
+  // live on the device (Latent::kadam); this call copies them out / in (handle re-creation, the online model's chain of handles,
+  // checkpoints) and synchronises.
+  agp_status ensure_kadam(Latent& g) {
+    if (!g.kadam) {
+      AGPCHK(dmalloc(ctx, &g.kadam, 2 * (1 + D)));
+      HIPCHK(ctx, hipMemsetAsync(g.kadam, 0, sizeof(double) * 2 * (1 + D), st()));
+      g.k_step = 0;
     }
+    return AGP_OK;
   }
-
-  // update_hyperparameters!(m, state, x, y): ADAM ASCENT; positive kernel parameters are stepped in log space
-  // (update_kernel!, autotuning_utils.jl:63-67), Z directly (update_Z!, :70-76).  K is refreshed before the next step.
-  // ADAM moments of the kernel-parameter optimiser (1 + D entries: variance, scales; a ScaleTransform uses entry 1 only)
   agp_status hyper_state(int l, int set, double* k_m, double* k_v, int32_t* k_step) override {
     if (l < 0 || l >= nl || !k_m || !k_v || !k_step) return AGP_ERR_INVALID;
     Latent& g = lat[l];
     const size_t np = 1 + (g.k.ard ? (size_t)D : 1);
+    AGPCHK(ensure_kadam(g));
+    std::vector<double> h(2 * (1 + D), 0.0);
     if (set) {
-      g.k_m.assign(k_m, k_m + np);
-      g.k_v.assign(k_v, k_v + np);
+      for (size_t i = 0; i < np; ++i) {
+        h[i] = k_m[i];
+        h[1 + D + i] = k_v[i];
+      }
+      HIPCHK(ctx, hipMemcpyAsync(g.kadam, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, st()));
+      HIPCHK(ctx, hipStreamSynchronize(st()));
       g.k_step = *k_step;
     } else {
+      HIPCHK(ctx, hipMemcpyAsync(h.data(), g.kadam, sizeof(double) * h.size(), hipMemcpyDeviceToHost, st()));
+      HIPCHK(ctx, hipStreamSynchronize(st()));
       for (size_t i = 0; i < np; ++i) {
-        k_m[i] = i < g.k_m.size() ? g.k_m[i] : 0.0;
-        k_v[i] = i < g.k_v.size() ? g.k_v[i] : 0.0;
+        k_m[i] = h[i];
+        k_v[i] = h[1 + D + i];
       }
-      *k_step = g.k_m.size() == np ? g.k_step : 0;
+      *k_step = g.k_step;
     }
     return AGP_OK;
   }
 
-  // ADAM ascent on latent l with the gradient hg = [dvariance, dscale_0..D-1] (w.r.t. the parameters themselves; positive
-  // parameters are stepped in log space, update_kernel! autotuning_utils.jl:63-67) and dZ (device, m x D; update_Z! :70-76)
-  agp_status hyper_apply_one(int l, const std::vector<double>& hg, const T* dZ_dev) {
+  // ADAM ascent on latent l (update_kernel!, autotuning_utils.jl:47-67; update_Z!, :70-76) -- ON THE DEVICE, from the gradient in
+  // hy_g = [dvariance, dscale_0..D-1] (doubles, w.r.t. the parameters themselves) and dZ_dev (m x D).  hg_host != nullptr: a
+  // caller-supplied gradient (tied / all-reduced) is uploaded into hy_g first.  Nothing synchronises; the host copy of the kernel
+  // parameters goes stale until somebody asks for it (params_to_host).
+  agp_status hyper_apply_one(int l, const std::vector<double>* hg_host, const T* dZ_dev) {
     Latent& g = lat[l];
     if (hy_k) {
-      const size_t np = 1 + (g.k.ard ? (size_t)D : 1);
-      if (g.k_m.size() != np) {
-        g.k_m.assign(np, 0.0);
-        g.k_v.assign(np, 0.0);
-        g.k_step = 0;
-      }
-      std::vector<double> p(np), gl(np), delta;
-      p[0] = g.k.variance;
-      gl[0] = p[0] * hg[0];
-      if (g.k.ard) {
-        for (int64_t d = 0; d < D; ++d) {
-          p[1 + d] = g.k.scales[d];
-          gl[1 + d] = p[1 + d] * hg[1 + d];
-        }
-      } else {
-        double s = 0;
-        for (int64_t d = 0; d < D; ++d) s += hg[1 + d];
-        p[1] = g.k.scales[0];
-        gl[1] = p[1] * s;
+      AGPCHK(hyper_alloc());
+      AGPCHK(ensure_kadam(g));
+      if (hg_host) {
+        hy_up = *hg_host;  // staging that outlives the asynchronous copy
+        HIPCHK(ctx, hipMemcpyAsync(hy_g, hy_up.data(), sizeof(double) * (1 + D), hipMemcpyHostToDevice, st()));
       }
       g.k_step += 1;
-      // variance and scale(s) are separate parameter arrays in the reference: separate ADAM states, same step count
-      // the reference's gradient is structural (a Zygote NamedTuple over the kernel object, autotuning.jl:99-118): a
-      // parameter that does not exist in the object -- the variance of a kernel that is not `sigma2 * k`, the scale of one
-      // without a transform -- has no gradient entry, no optimiser state, and is never stepped
-      if (!g.k.has_variance) gl[0] = 0.0;
-      if (!g.k.has_transform)
-        for (size_t j = 1; j < np; ++j) gl[j] = 0.0;
-      adam_host(g.k_m, g.k_v, g.k_step, gl, hy_keta, hy_b1, hy_b2, hy_eps, delta);
-      if (g.k.has_variance) g.k.variance = std::exp(std::log(p[0]) + delta[0]);
-      else g.k_m[0] = g.k_v[0] = 0.0;
-      for (int64_t d = 0; d < D && g.k.has_transform; ++d) {
-        const size_t j = g.k.ard ? 1 + (size_t)d : 1;
-        g.k.scales[d] = std::exp(std::log(p[j]) + delta[j]);
-      }
+      hipLaunchKernelGGL((k_adam_kernel_params<T>), dim3(1), dim3(256), 0, st(), (int)D, g.k.ard ? 1 : 0, g.k.has_variance ? 1 : 0,
+                         g.k.has_transform ? 1 : 0, (const double*)hy_g, g.scales, g.kadam, g.kadam + (1 + D), g.k_step, hy_keta,
+                         hy_b1, hy_b2, hy_eps);
+      LAUNCHCHK(ctx);
+      g.host_params_stale = true;
     }
     if (hy_z && dZ_dev) {
       if (!g.z_am) {
@@ -2332,6 +2355,7 @@ struct Svgp : SvgpBase {
     }
     return AGP_OK;
   }
+  std::vector<double> hy_up;
 
   agp_status hyper_finish() {
     for (auto& g : lat) {
@@ -2348,11 +2372,11 @@ struct Svgp : SvgpBase {
           if (!g.skinv_mu0) AGPCHK(dmalloc(ctx, &g.skinv_mu0, mp));
           HIPCHK(ctx, hipMemcpyAsync(g.skinv_mu0, g.kinv_mu0, sizeof(T) * mp, hipMemcpyDeviceToDevice, st()));
         }
+        AGPCHK(resolve_logdet(g));
         g.s_half_logdetK = g.half_logdetK;
         g.stale_on = true;
       }
-      if (hy_k) AGPCHK(upload_scales(g));
-      g.K_stale = true;
+      g.K_stale = true;  // (the kernel parameters were stepped in place on the device: nothing to upload)
       g.zsc_valid = false;
       // (the reference's full-batch path keeps its kernel matrices across a hyper step, training.jl:196-204)
       if (!(g.stale_on && !desc.stochastic)) g.kappa_valid = false;
@@ -2373,8 +2397,11 @@ struct Svgp : SvgpBase {
       return AGP_ERR_INVALID;
     }
     for (int l = 0; l < nl; ++l) {
-      AGPCHK(hypergrad(l, nullptr, nullptr, nullptr));
-      AGPCHK(hyper_apply_one(l, hy_last, (const T*)hy_dZ));
+      hy_grad_on_device_only = true;
+      const agp_status hs = hypergrad(l, nullptr, nullptr, nullptr);
+      hy_grad_on_device_only = false;
+      AGPCHK(hs);
+      AGPCHK(hyper_apply_one(l, nullptr, (const T*)hy_dZ));
     }
     return hyper_finish();
   }
@@ -2386,12 +2413,13 @@ struct Svgp : SvgpBase {
     std::vector<double> hg(1 + D);
     hg[0] = *dvar;
     for (int64_t d = 0; d < D; ++d) hg[1 + d] = dscale[d];
-    AGPCHK(hyper_apply_one(l, hg, (const T*)dZ));
+    AGPCHK(hyper_apply_one(l, &hg, (const T*)dZ));
     return hyper_finish();
   }
 
   agp_status get_kernel(int l, double* var, double* scales) override {
     if (l < 0 || l >= nl) return AGP_ERR_INVALID;
+    AGPCHK(params_to_host(lat[l]));
     if (var) *var = lat[l].k.variance;
     if (scales)
       for (int64_t d = 0; d < D; ++d) scales[d] = lat[l].k.scales[d];
@@ -2603,7 +2631,7 @@ struct Svgp : SvgpBase {
     for (auto& g : lat) {
       dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
       (void)launch_kernelmatrix<T>(ctx, pf_stream, (const T*)x, ldx, idx, B, (const T*)g.Z,
-                         D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, g.Knm_alt, mp, Bq, mp, 0, T(0),
+                         D, m, D, (const T*)g.scales, g.k.kind, kvar(g), g.Knm_alt, mp, Bq, mp, 0, T(0),
                          (const T*)nullptr, (T*)nullptr, (int64_t)0, 0, (const T*)g.Zsc, (const T*)g.zn);
       rc = gemm_nt<T, EPI_KAPPA>(ctx, g.Knm_alt, mp, kinv_kappa(g), mp, Bq, mp, mp, 0, g.kappa_alt, mp, g.Knm_alt, mp, nullptr,
                                  g.pk_alt, g.Wbuf_alt, ldp);
@@ -2652,6 +2680,17 @@ struct Svgp : SvgpBase {
     return AGP_OK;
   }
 
+  double* logdetK_dev = nullptr;  // [nl] log det of chol(K) diagonals (half log det K), fetched lazily (resolve_logdet)
+  bool refresh_lazy = false;      // set around refresh_K() by the training loop's step_local
+  agp_status resolve_logdet(Latent& g) {
+    if (!g.logdet_pending) return AGP_OK;
+    double hl = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&hl, logdetK_dev + (&g - lat.data()), sizeof(double), hipMemcpyDeviceToHost, st()));
+    HIPCHK(ctx, hipStreamSynchronize(st()));
+    g.half_logdetK = hl;
+    g.logdet_pending = false;
+    return AGP_OK;
+  }
   bool lam_deferred = false;  // set around step_local by the batch-sharded driver (see cavi_step_multi)
   agp_status lambda_finish_reduced() {
     if (lp.kind == AGP_LIK_GAUSSIAN) {  // the reduced sum and batch size: the same ADAM step on every rank
@@ -2756,21 +2795,12 @@ struct Svgp : SvgpBase {
     src.kappa[0] = g.kappa;  // every caller copies kappa into Wbuf first (or passes Bq = 0)
     src.eta1[0] = g.eta1;
     src.eta2[0] = g.eta2;
-    const bool dag = chol_use_dag(ctx, mp / TILE, Bq / TILE + 1);
+    // with_x: the inverse rides along (identity block rows of the task graph); its fallback forms X = L^-1 in the stream as well
+    // (SafeSrc::want_x), so that no host check -- no stream synchronisation -- sits behind the launch (round 3: the hyper-parameter
+    // iteration used to wait here once per step)
+    src.want_x = with_x ? 1 : 0;
     AGPCHK(potrf_fused<T>(ctx, g.La, mp, mp, g.Xa, mp, g.DgA, g.Wbuf, mp, Bq / TILE + 1, with_x, info_dev, m,
                           (const T*)g.eta1, false, &src));
-    if (dag && with_x) {  // the inverse rides along: no in-stream fallback, checked here (these callers synchronise soon anyway)
-      bool lost = false;
-      AGPCHK(dag_lost_dependency(ctx, info_dev, &lost));
-      if (lost) {
-        hipLaunchKernelGGL((k_copy2d<T>), grid2(mp, mp), blk2, 0, st(), (const T*)g.eta2, mp, mp, mp, g.La, mp, mp, mp, T(1),
-                           T(-2));
-        if (Bq > 0) HIPCHK(ctx, hipMemcpyAsync(g.Wbuf, g.kappa, sizeof(T) * Bq * mp, hipMemcpyDeviceToDevice, st()));
-        LAUNCHCHK(ctx);
-        AGPCHK(potrf_fused<T>(ctx, g.La, mp, mp, g.Xa, mp, g.DgA, g.Wbuf, mp, Bq / TILE + 1, with_x, info_dev, m,
-                              (const T*)g.eta1, false));
-      }
-    }
     AGPCHK(timing_end(chol_use_dag(ctx, mp / TILE, Bq / TILE + 1) ? 1 : chol_launch_count(mp / TILE, Bq / TILE + 1)));
     g.la_state = 1;
     g.xa_valid = with_x != 0;
@@ -2831,14 +2861,17 @@ struct Svgp : SvgpBase {
   agp_status check_status() override {
     int32_t info = 0;
     int flags = 0;
+    int32_t infoK = 0;
     HIPCHK(ctx, hipMemcpyAsync(&info, info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st()));
     HIPCHK(ctx, hipMemcpyAsync(&flags, flags_dev, sizeof(int), hipMemcpyDeviceToHost, st()));
+    HIPCHK(ctx, hipMemcpyAsync(&infoK, infoK_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st()));
     HIPCHK(ctx, hipStreamSynchronize(st()));
     dag_retry_check(ctx);  // steps the in-stream fallback had to re-run: warn once, stop using the task graph
     if (info != 0 || flags != 0) {
       HIPCHK(ctx, hipMemsetAsync(info_dev, 0, sizeof(int32_t), st()));
       HIPCHK(ctx, hipMemsetAsync(flags_dev, 0, sizeof(int), st()));
     }
+    if (infoK != 0) HIPCHK(ctx, hipMemsetAsync(infoK_dev, 0, sizeof(int32_t), st()));
     if (flags & FLAG_NEG_KTILDE) {
       ctx->err = "K~ has negative values";  // latentgp.jl:213
       return AGP_ERR_NEG_KTILDE;
@@ -2858,6 +2891,15 @@ struct Svgp : SvgpBase {
     if (info != 0) {
       ctx->err = "PosDefException: -2*eta2 is not positive definite; leading minor " + std::to_string(info);
       return AGP_ERR_NOT_POSDEF;
+    }
+    if (infoK > 0) {  // latched by a kernel refresh inside the training loop (the hyper step moved the kernel / Z)
+      for (auto& q : lat) q.K_stale = true;
+      ctx->err = "PosDefException: K_ZZ + jitter*I is not positive definite; leading minor " + std::to_string(infoK);
+      return AGP_ERR_NOT_POSDEF;
+    }
+    if (infoK < 0) {
+      ctx->err = "task-graph factorisation of K_ZZ aborted: a tile dependency never arrived (spin limit)";
+      return AGP_ERR_HIP;
     }
     return AGP_OK;
   }
@@ -2978,6 +3020,7 @@ struct Svgp : SvgpBase {
         e_data = mo ? mo_e : h[0];
         kl_aug = mo ? mo_kl : h[1];
       }
+      AGPCHK(resolve_logdet(g));
       const double logdetK = 2.0 * (use_stale ? g.s_half_logdetK : g.half_logdetK), logdetS = -2.0 * h[2];
       kl_gauss += 0.5 * (logdetK - logdetS + h[3] + h[4] - (double)m);
       if (g.on) {
@@ -3063,6 +3106,7 @@ struct Svgp : SvgpBase {
       g.k_v.clear();
       g.k_step = 0;
       g.z_step = 0;
+      if (g.kadam) HIPCHK(ctx, hipMemsetAsync(g.kadam, 0, sizeof(double) * 2 * (1 + D), st()));
       if (g.z_am) {
         HIPCHK(ctx, hipMemsetAsync(g.z_am, 0, sizeof(double) * m * D, st()));
         HIPCHK(ctx, hipMemsetAsync(g.z_av, 0, sizeof(double) * m * D, st()));
@@ -3206,6 +3250,7 @@ struct Svgp : SvgpBase {
 
   agp_status predict_f_latent(const void* xt, int64_t ldx, int64_t nt, void* mu_out, void* var_out) {
     if (!xt || nt <= 0 || ldx < D || !mu_out) return AGP_ERR_INVALID;
+    for (auto& g : lat) AGPCHK(params_to_host(g));  // k_predict_finish takes the variance by value
     const bool need_var = var_out != nullptr;
     AGPCHK(ensure_pred_ws(0, need_var));
     for (auto& g : lat) {
@@ -3219,7 +3264,7 @@ struct Svgp : SvgpBase {
         // means only: ONE launch over all test points, every workgroup carries its 64 rows through all inducing-point tiles with
         // the row-dot against K^-1 mu in registers -- K*m and per-tile partial sums never reach memory (predictions.jl:33-34)
         const int slices = launch_kernelmatrix<T>(ctx, st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt, (const T*)g.Z, D, m, D,
-                                                  (const T*)g.scales, g.k.kind, (T)g.k.variance, (T*)nullptr, mp, nt, mp, 0, T(0),
+                                                  (const T*)g.scales, g.k.kind, kvar(g), (T*)nullptr, mp, nt, mp, 0, T(0),
                                                   (const T*)g.apred, (T*)mu_out + (int64_t)l * nt, nt, 1, (const T*)g.Zsc,
                                                   (const T*)g.zn);
         LAUNCHCHK(ctx);
@@ -3231,7 +3276,7 @@ struct Svgp : SvgpBase {
         const int64_t nq = rup64(nc);
         const T* xs = (const T*)xt + s * ldx;
         const int slices = launch_kernelmatrix<T>(ctx, st(), xs, ldx, (const int64_t*)nullptr, nc, (const T*)g.Z, D, m, D,
-                                                  (const T*)g.scales, g.k.kind, (T)g.k.variance, need_var ? Kstar : (T*)nullptr, mp,
+                                                  (const T*)g.scales, g.k.kind, kvar(g), need_var ? Kstar : (T*)nullptr, mp,
                                                   nq, mp, 0, T(0), (const T*)g.apred, ppm, CH, 0, (const T*)g.Zsc, (const T*)g.zn);
         LAUNCHCHK(ctx);
         if (need_var)
@@ -3408,11 +3453,11 @@ struct Svgp : SvgpBase {
       if (rc != AGP_OK) break;
       dim3 gk((unsigned)(mp / TILE), (unsigned)(nq / TILE));
       (void)launch_kernelmatrix<T>(ctx, st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt,
-                         (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, Ks, mp, nq, mp, 0, T(0),
+                         (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, kvar(g), Ks, mp, nq, mp, 0, T(0),
                          (const T*)nullptr, (T*)nullptr, (int64_t)0, 0, (const T*)g.Zsc, (const T*)g.zn);
       dim3 gs((unsigned)(nq / TILE), (unsigned)(nq / TILE));
       (void)launch_kernelmatrix<T>(ctx, st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt,
-                         (const T*)xt, ldx, nt, D, (const T*)g.scales, g.k.kind, (T)g.k.variance, Kss, nq, nq, nq, 1,
+                         (const T*)xt, ldx, nt, D, (const T*)g.scales, g.k.kind, kvar(g), Kss, nq, nq, nq, 1,
                          (T)jitter, (const T*)nullptr, (T*)nullptr, (int64_t)0);
       rc = gemm_nt<T, EPI_STORE>(ctx, Ks, mp, g.Apred, mp, nq, mp, mp, 0, T1, mp, nullptr, 0, nullptr, nullptr, nullptr, 0);
       if (rc != AGP_OK) break;
@@ -3579,7 +3624,7 @@ struct Svgp : SvgpBase {
         hipLaunchKernelGGL((k_double_to<T>), grid1(m * D), dim3(256), 0, st(), m * D, (const double*)(hy_tied + 1 + D), hy_dZ);
         LAUNCHCHK(ctx);
         HIPCHK(ctx, hipStreamSynchronize(st()));
-        AGPCHK(hyper_apply_one(l, hg, (const T*)hy_dZ));
+        AGPCHK(hyper_apply_one(l, &hg, (const T*)hy_dZ));
       }
       return hyper_finish();
     }
@@ -3597,7 +3642,7 @@ struct Svgp : SvgpBase {
     hipLaunchKernelGGL((k_double_to<T>), grid1(m * D), dim3(256), 0, st(), m * D, (const double*)(hy_tied + 1 + D), hy_dZ);
     LAUNCHCHK(ctx);
     HIPCHK(ctx, hipStreamSynchronize(st()));
-    for (int l = 0; l < nl; ++l) AGPCHK(hyper_apply_one(l, hs, (const T*)hy_dZ));
+    for (int l = 0; l < nl; ++l) AGPCHK(hyper_apply_one(l, &hs, (const T*)hy_dZ));
     return hyper_finish();
   }
 

@@ -59,6 +59,9 @@ __global__ __launch_bounds__(NTHREADS) void k_kernelmatrix(const T* __restrict__
                                                            int64_t p_out, int sym, T diag_add,
                                                            const T* __restrict__ alpha, T* __restrict__ part,
                                                            int64_t ldp) {
+  // variance < 0: the kernel parameters are device-resident state (they are stepped by a device-side ADAM during training) and
+  // the variance is element D of the scales array
+  if (variance < T(0)) variance = scales[D];
   __shared__ T xs[TILE][KM_DC + 1];
   __shared__ T ys[TILE][KM_DC + 1];
   const int tid = threadIdx.x;
@@ -179,6 +182,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_kernelmatrix_mma(const T* __res
                                                                int64_t n_out, int64_t p_out, int sym_, T diag_add,
                                                                const T* __restrict__ alpha_, T* __restrict__ part,
                                                                int64_t ldp, int64_t ctiles) {
+  if (variance < T(0)) variance = scales[D];  // device-resident kernel parameters (see k_kernelmatrix)
   T* __restrict__ out = SPEC == 1 ? nullptr : out_;
   const int sym = SPEC != 0 ? 0 : sym_;
   const T* __restrict__ alpha = SPEC == 2 ? nullptr : alpha_;
@@ -454,7 +458,8 @@ struct RowstatsBatch {
   const T* pk[ROWSTATS_MAXB];  // K~ partial slices
   const T* W[ROWSTATS_MAXB];   // kappa L_A^-T
   const T* v[ROWSTATS_MAXB];   // L_A^-1 eta1
-  T kdiag[ROWSTATS_MAXB];      // kernel variance (diagonal of the kernel matrix)
+  T kdiag[ROWSTATS_MAXB];      // kernel variance (diagonal of the kernel matrix); < 0: read it from kd_ptr (device-resident)
+  const T* kd_ptr[ROWSTATS_MAXB];
   int use_kt[ROWSTATS_MAXB];   // K~ kept from the previous full-batch step
 };
 // one wave's work on row i of latent q (shared by k_rowstats_local and the kernel that also carries the task graph's fallback)
@@ -468,7 +473,7 @@ __device__ __forceinline__ void rowstats_row(int64_t i, int lane, int q, int64_t
   const T* __restrict__ pk = rb.pk[q];
   const T* __restrict__ W = rb.W[q];
   const T* __restrict__ v = rb.v[q];
-  const T kdiag = rb.kdiag[q];
+  const T kdiag = rb.kdiag[q] < T(0) ? rb.kd_ptr[q][0] : rb.kdiag[q];
   const int use_kt = rb.use_kt[q];
   Kt += q * ostride;
   muf += q * ostride;

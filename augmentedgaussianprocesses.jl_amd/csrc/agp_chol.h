@@ -1024,7 +1024,34 @@ struct SafeSrc {
   const T* eta1[CHOL_MAXB];   // first row of the last extension block (the others are zero)
   const T* eta2[CHOL_MAXB];   // A = -2 eta2
   int64_t Bq;
+  // round 3: launches that also deliver X = L^-1 (the factor of the updated -2 eta2 for Sigma / mu, K_ZZ's at a kernel refresh)
+  // have an in-stream fallback too, so that no host check (= stream synchronisation) sits behind them:
+  int want_x = 0;             // after the factorisation, X = L^-1 by forward substitution, one thread per column (slow, rare)
+  // kz: A is not -2 eta2 but the kernel matrix of the inducing points, recomputed from its inputs (the factor overwrote it):
+  //   A[i][j] = variance * base(|| s .* (z_i - z_j) ||^2) + jitter [i == j], identity in the padding (i, j >= mz)
+  const T* kz = nullptr;      // Z (mz x D, leading dimension ldz); nullptr: A = -2 eta2
+  const T* kscales = nullptr; // [scale_0 .. scale_{D-1} | variance]
+  int64_t mz = 0, ldz = 0, Dz = 0;
+  int kkind = 0;
+  T kvariance = T(1), kjitter = T(0);  // kvariance < 0: read kscales[Dz]
 };
+
+// the kernel functions of agp_cavi.h restated for the fallback (agp_chol.h is included first): base(d2), d2 = squared scaled distance
+template <typename T>
+__device__ __forceinline__ T safe_kernel_base(int kind, T d2) {
+  d2 = d2 > T(0) ? d2 : T(0);
+  if (kind == 0) return exp(T(-0.5) * d2);  // SqExponential
+  const T r = sqrt(d2);
+  if (kind == 1) {  // Matern 5/2
+    const T s5 = T(2.23606797749978969641);
+    return (T(1) + s5 * r + T(5) / T(3) * d2) * exp(-s5 * r);
+  }
+  if (kind == 2) {  // Matern 3/2
+    const T s3 = T(1.73205080756887729353);
+    return (T(1) + s3 * r) * exp(-s3 * r);
+  }
+  return exp(-r);  // Exponential
+}
 
 __device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
   __syncthreads();
@@ -1051,10 +1078,29 @@ __device__ __forceinline__ bool chol_safe_body(const CholBatch<T>& bt, const Saf
   for (int q = 0; q < nb; ++q) {  // inputs back from their sources (the aborted launch left E half overwritten)
     T* A = bt.A[q];
     T* E = bt.E[q];
-    for (int64_t e = g0; e < n * n; e += gsz) A[(e / n) * ld + (e % n)] = T(-2) * src.eta2[q][(e / n) * ld + (e % n)];
-    for (int64_t e = g0; e < src.Bq * n; e += gsz) E[(e / n) * lde + (e % n)] = src.kappa[q][(e / n) * lde + (e % n)];
-    for (int64_t e = g0; e < TILE * n; e += gsz)
-      E[(src.Bq + e / n) * lde + (e % n)] = (e / n) == 0 ? src.eta1[q][e % n] : T(0);
+    if (src.kz) {  // K_ZZ + jitter I from the inducing points (q == 0 only: one latent per launch)
+      const T var = src.kvariance < T(0) ? src.kscales[src.Dz] : src.kvariance;
+      for (int64_t e = g0; e < n * n; e += gsz) {
+        const int64_t i = e / n, j = e % n;
+        T v = i == j ? T(1) : T(0);
+        if (i < src.mz && j < src.mz) {
+          T d2 = T(0);
+          for (int64_t d = 0; d < src.Dz; ++d) {
+            const T t = (src.kscales ? src.kscales[d] : T(1)) * (src.kz[i * src.ldz + d] - src.kz[j * src.ldz + d]);
+            d2 += t * t;
+          }
+          v = var * safe_kernel_base<T>(src.kkind, d2) + (i == j ? src.kjitter : T(0));
+        }
+        A[i * ld + j] = v;
+      }
+    } else {
+      for (int64_t e = g0; e < n * n; e += gsz) A[(e / n) * ld + (e % n)] = T(-2) * src.eta2[q][(e / n) * ld + (e % n)];
+    }
+    if (ne > 0) {
+      for (int64_t e = g0; e < src.Bq * n; e += gsz) E[(e / n) * lde + (e % n)] = src.kappa[q][(e / n) * lde + (e % n)];
+      for (int64_t e = g0; e < TILE * n; e += gsz)
+        E[(src.Bq + e / n) * lde + (e % n)] = (e / n) == 0 ? src.eta1[q][e % n] : T(0);
+    }
   }
   grid_barrier(bar, ++phase * nwg);
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // every workgroup has seen the -1 by now: the latch goes back to "no failure",
@@ -1069,6 +1115,30 @@ __device__ __forceinline__ bool chol_safe_body(const CholBatch<T>& bt, const Saf
       const int q = (int)(v % nb);
       chol_step_body<T>(bt.A[q], bt.X[q], bt.Dg[q], bt.E[q], v / nb, ld, ldx, lde, ne, 0, k, nt, info, nvalid, sm, sc, piv);
       __syncthreads();  // the next share reuses the LDS tiles
+    }
+    grid_barrier(bar, ++phase * nwg);
+  }
+  if (src.want_x) {
+    // X = L^-1 (lower triangular) column by column: thread j solves L x = e_j by forward substitution.  L's strictly-lower tiles sit
+    // in A, its diagonal tiles in Dg.  O(n^2) dependent steps per thread: milliseconds -- this is the path of a lost dependency,
+    // which the bounded spin in front of it has already made ~0.1 s long.
+    for (int q = 0; q < nb; ++q) {
+      const T* A = bt.A[q];
+      const T* Dg = bt.Dg[q];
+      T* X = bt.X[q];
+      auto Lel = [&](int64_t i, int64_t k) -> T {
+        return (i / TILE) == (k / TILE) ? Dg[(i / TILE) * TILE * TILE + (i % TILE) * TILE + (k % TILE)] : A[i * ld + k];
+      };
+      for (int64_t j = g0; j < n; j += gsz) {
+        const int64_t t0 = (j / TILE) * TILE;
+        for (int64_t i = t0; i < j; ++i) X[i * ldx + j] = T(0);  // above the diagonal inside the diagonal tile
+        X[j * ldx + j] = T(1) / Lel(j, j);
+        for (int64_t i = j + 1; i < n; ++i) {
+          T sacc = T(0);
+          for (int64_t k = j; k < i; ++k) sacc += Lel(i, k) * X[k * ldx + j];
+          X[i * ldx + j] = -sacc / Lel(i, i);
+        }
+      }
     }
     grid_barrier(bar, ++phase * nwg);
   }

@@ -94,6 +94,46 @@ __global__ void k_hyper_gK(int64_t m, int64_t mp, const T* __restrict__ M1, cons
   out[i * mp + j] = v;
 }
 
+// update_kernel! (autotuning_utils.jl:47-67) on the device: ADAM ASCENT on [variance | scale(s)] in log space,
+//   x <- exp(log x + ADAM(x .* g)) ,
+// from the gradient g = [dvariance, dscale_0 .. dscale_{D-1}] (doubles, w.r.t. the parameters themselves) left by the backward pass.
+// params = the kernel's device parameter array [scale_0 .. scale_{D-1} | variance]; am / av: ADAM moments [1 + (ard ? D : 1)];
+// a ScaleTransform has ONE scale (its gradient is the sum over dimensions, all D entries carry the same value).  Structural like
+// the reference's Zygote gradient (autotuning.jl:99-118): a parameter that does not exist in the kernel object (has_variance /
+// has_transform = 0) is never stepped and keeps zero moments.  One workgroup; thread j steps parameter j.
+template <typename T>
+__global__ void k_adam_kernel_params(int D, int ard, int has_variance, int has_transform, const double* __restrict__ g,
+                                     T* __restrict__ params, double* __restrict__ am, double* __restrict__ av, int step, double eta,
+                                     double b1, double b2, double eps) {
+  const int np = 1 + (ard ? D : 1);
+  const int j = threadIdx.x;
+  if (j >= np) return;
+  const double p = j == 0 ? (double)params[D] : (double)params[ard ? j - 1 : 0];
+  double gl;
+  if (j == 0) {
+    gl = has_variance ? p * g[0] : 0.0;
+  } else if (ard) {
+    gl = has_transform ? p * g[j] : 0.0;
+  } else {
+    double sgm = 0.0;
+    for (int d = 0; d < D; ++d) sgm += g[1 + d];
+    gl = has_transform ? p * sgm : 0.0;
+  }
+  const double m = b1 * am[j] + (1.0 - b1) * gl, v = b2 * av[j] + (1.0 - b2) * gl * gl;
+  am[j] = m;
+  av[j] = v;
+  const double mh = m / (1.0 - pow(b1, (double)step)), vh = v / (1.0 - pow(b2, (double)step));
+  const double np_ = exp(log(p) + eta * mh / (sqrt(vh) + eps));
+  if (j == 0) {
+    if (has_variance) params[D] = (T)np_;
+    else am[0] = av[0] = 0.0;
+  } else if (has_transform) {
+    if (ard) params[j - 1] = (T)np_;
+    else
+      for (int d = 0; d < D; ++d) params[d] = (T)np_;
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ T kernel_dbase(int kind, T d2) {
   d2 = d2 > T(0) ? d2 : T(0);
@@ -125,6 +165,7 @@ __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restric
                                                               const T* __restrict__ G, int64_t ldg,
                                                               double* __restrict__ pvar, double* __restrict__ pscale,
                                                               T* __restrict__ pZ, int64_t p_pad) {
+  if (variance < T(0)) variance = scales[D];  // device-resident kernel parameters (see k_kernelmatrix)
   __shared__ T xs[TILE][KM_DC + 1];
   __shared__ T ys[TILE][KM_DC + 1];
   __shared__ T zred[4][TILE][KM_DC];  // per wave: column sums for the chunk

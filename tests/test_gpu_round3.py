@@ -467,3 +467,64 @@ def test_multioutput_full_predictive_covariance(mods):
         assert _rel(mu[t], mur[t]) < 1e-8 and _rel(cov[t], covr[t]) < 1e-7
         assert _rel(np.diag(cov[t]), var[t]) < 1e-8
         assert np.max(np.abs(cov[t] - cov[t].T)) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# round 3: the task-graph launches that also deliver X = L^-1 (factor of the updated -2 eta2 for Sigma / mu, K_ZZ at a kernel
+# refresh) have an in-stream fallback too (no host check behind them: the hyper-parameter iteration no longer synchronises)
+def _fallback_x_child(q):
+    try:
+        import sys
+
+        sys.path.insert(0, ROOT)
+        import ctypes as C
+
+        import agp_amd as AGP
+        from agp_amd import capi
+
+        rng = np.random.default_rng(51)
+        N, D, m, B, iters = 3000, 4, 200, 256, 7
+        X = rng.random((N, D))
+        f = np.sin(4 * X[:, 0]) + X[:, 1]
+        y = (f > f.mean()).astype(int)
+        Z = X[rng.permutation(N)[:m]].copy()
+        idx = [rng.choice(N, B, replace=False) for _ in range(iters)]
+        ma = AGP.SVGP(1.5 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0)), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z,
+                      optimiser=AGP.ADAM(0.01), Zoptimiser=AGP.ADAM(0.001))
+        AGP.train_(ma, X, y, iters, idx_stream=idx)
+        n = C.c_int64()
+        f_ = capi.lib().agp_dev_dag_retries
+        f_.restype, f_.argtypes = C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)]
+        assert f_(ma._ctx, C.byref(n)) == 0
+        mu, Sig, e1, e2 = ma.get_state(0)
+        q.put((int(n.value), e2, Sig, (ma.kernels[0].variance, ma.kernels[0].transform.s), ma.Zs[0], X, y, Z, idx))
+    except BaseException as e:  # noqa: BLE001
+        q.put(repr(e))
+
+
+def test_fallback_of_launches_with_the_inverse_matches_oracle(mods):
+    """AGP_DAG_TEST_ABORT=1 makes EVERY task-graph launch with a fallback look aborted -- now including the ones that deliver L^-1:
+    the fallback rebuilds -2 eta2 (or K_ZZ from the inducing points), factors with grid barriers and forms L^-1 by forward
+    substitution.  A training run with hyper steps (K refreshed and Sigma materialised every iteration) must land on the oracle."""
+    import multiprocessing as mp
+
+    AGP, R, capi, torch = mods
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    os.environ["AGP_DAG_TEST_ABORT"] = "1"
+    try:
+        p = ctx.Process(target=_fallback_x_child, args=(q,))
+        p.start()
+        got = q.get(timeout=900)
+        p.join(timeout=60)
+    finally:
+        del os.environ["AGP_DAG_TEST_ABORT"]
+    assert not isinstance(got, str), got
+    retries, eta2, Sig, (var, sc), Zf, X, y, Z, idx = got
+    assert retries >= 10  # steps, materialisations and kernel refreshes all went through their fallbacks
+    mr = R.SVGP(R.Kernel("sqexponential", 2.0, 1.5), R.LogisticLikelihood(), Z, stochastic=True, batchsize=256, k_opt=R.Adam(0.01),
+                z_opt=R.Adam(0.001))
+    mr.train(X, y, len(idx), idx_stream=idx)
+    g = mr.latents[0]
+    assert var == pytest.approx(g.kernel.sigma2, rel=1e-8) and sc == pytest.approx(float(g.kernel.scale), rel=1e-8)
+    assert _rel(Zf, g.Z) < 1e-8 and _rel(eta2, g.eta2) < 1e-7 and _rel(Sig, g.Sigma) < 1e-6

@@ -733,7 +733,9 @@ static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_
   T* fillp = nullptr;
   int64_t fused_used = 0, fstride = 0, nfill = 0;
   int fnb = 0;
-  if ((MODE == SY_ETA2 || MODE == SY_PACK) && rvec && c->h_dirty[0].on && c->htype == (int)sizeof(T)) {
+  // (round 3: any symmetric-product launch refills a dirty set, e.g. X'X behind a factorisation with its inverse: the inline refill
+  //  in front of the NEXT task graph was a 6 us launch of its own on the hyper-parameter iteration's path)
+  if (c->h_dirty[0].on && c->htype == (int)sizeof(T) && out != nullptr) {
     fillp = (T*)c->hset[0];
     fused_used = c->h_dirty[0].used;
     fstride = c->h_dirty[0].stride;
@@ -2181,22 +2183,19 @@ struct Svgp : SvgpBase {
       else
         hipLaunchKernelGGL((k_gemm_tn<T, 1>), gt, dim3(NTHREADS), 0, st(), kap, mp, (const T*)hyH2, mp, Bq, Tw, mp);
     }
-    hipLaunchKernelGGL((k_axpby<T>), grid1(mp), dim3(256), 0, st(), mp, T(1), (const T*)g.apred, T(-1),
-                       (const T*)g.kinv_mu0, tmpv);
     hipLaunchKernelGGL((k_hyper_gK<T>), grid2(mp, mp), blk2, 0, st(), m, mp, (const T*)Tw, (const T*)g.Apred,
-                       (const T*)tmpv, Tw2, (T)(1.0 / (double)bs_world));
-    HIPCHK(ctx, hipMemsetAsync(hy_g, 0, sizeof(double) * (1 + D), st()));
-    // backward through kernelmatrix(k, x, Z)  (gradient w.r.t. the second argument)
+                       (const T*)g.apred, Tw2, (T)(1.0 / (double)bs_world), (const T*)g.kinv_mu0);
+    // backward through kernelmatrix(k, x, Z)  (gradient w.r.t. the second argument); its reduction initialises the gradient and
+    // adds the kdiag term of the variance (rho sum_i g_sigma,i), which used to be a memset in front and a kernel behind
     {
       dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
       const int64_t tiles = (int64_t)gk.x * gk.y;
       hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)x_last, ldx_last, idx_last, B,
                          (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, kvar(g), (const T*)hyH3, mp,
                          hy_pvar, hy_pscale, hy_pZ, mp);
-      hipLaunchKernelGGL((k_hyper_reduce_scalar<T>), dim3((unsigned)(D + 1)), dim3(256), 0, st(), tiles, D, (const double*)hy_pvar,
-                         (const double*)hy_pscale, hy_g, 1.0);
-      hipLaunchKernelGGL((k_hyper_reduce_Z<T>), grid1(m * D), dim3(256), 0, st(), (int64_t)gk.y, m, mp, D,
-                         (const T*)hy_pZ, hy_dZ, T(1), 0);
+      hipLaunchKernelGGL((k_hyper_reduce<T>), dim3((unsigned)(D + 1 + (m * D + 255) / 256)), dim3(256), 0, st(), tiles, D,
+                         (const double*)hy_pvar, (const double*)hy_pscale, hy_g, 1.0, 1, (int64_t)gk.y, m, mp, (const T*)hy_pZ, hy_dZ,
+                         T(1), (const T*)hy_gs, B, (double)rho);
     }
     const bool online_x = g.on && !g.on_first;
     if (online_x && bs_world > 1) {
@@ -2244,10 +2243,9 @@ struct Svgp : SvgpBase {
       hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)g.Z, D, (const int64_t*)nullptr,
                          m, (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, kvar(g), (const T*)Tw2, mp,
                          hy_pvar, hy_pscale, hy_pZ, mp);
-      hipLaunchKernelGGL((k_hyper_reduce_scalar<T>), dim3((unsigned)(D + 1)), dim3(256), 0, st(), tiles, D, (const double*)hy_pvar,
-                         (const double*)hy_pscale, hy_g, 1.0);
-      hipLaunchKernelGGL((k_hyper_reduce_Z<T>), grid1(m * D), dim3(256), 0, st(), (int64_t)gk.y, m, mp, D,
-                         (const T*)hy_pZ, hy_dZ, T(2), 1);
+      hipLaunchKernelGGL((k_hyper_reduce<T>), dim3((unsigned)(D + 1 + (m * D + 255) / 256)), dim3(256), 0, st(), tiles, D,
+                         (const double*)hy_pvar, (const double*)hy_pscale, hy_g, 1.0, 0, (int64_t)gk.y, m, mp, (const T*)hy_pZ, hy_dZ,
+                         T(2), (const T*)nullptr, (int64_t)0, 0.0);
     }
     if (online_x) {
       // K_ab = k(Z_a, Z): gradient w.r.t. the kernel parameters and the second argument ; K_a = k(Z_a, Z_a): parameters only
@@ -2268,7 +2266,6 @@ struct Svgp : SvgpBase {
                          (const double*)hy_pvar, (const double*)hy_pscale, hy_g, 0.5);
       LAUNCHCHK(ctx);
     }
-    hipLaunchKernelGGL((k_hyper_sum<T>), dim3(1), dim3(1024), 0, st(), B, (const T*)hy_gs, (double)rho, hy_g);
     LAUNCHCHK(ctx);
     if (dZ_out) HIPCHK(ctx, hipMemcpyAsync(dZ_out, hy_dZ, sizeof(T) * m * D, hipMemcpyDeviceToDevice, st()));
     if (hy_grad_on_device_only) return AGP_OK;  // the training loop: the gradient stays in hy_g / hy_dZ for the device-side ADAM

@@ -82,15 +82,18 @@ __global__ void k_hyper_gknm(int64_t B, int64_t rows, int64_t cols, int64_t ld, 
 // G_K = -1/2 (M1 + M1') - 1/2 Apred + 1/2 a a'   on the valid m x m block, zero in the padding
 // klw weighs the Gaussian-KL part (-1/2 Apred + 1/2 a a'): 1 normally, 1 / world on a batch-sharded handle, where that part is
 // replicated on every rank while the data part (M1) is a sum over the ranks' shards -- the all-reduced gradient then counts it once
+// (a = a1 - a2 when a2 is given: K^-1 mu - K^-1 mu0 without a kernel of its own in front)
 template <typename T>
 __global__ void k_hyper_gK(int64_t m, int64_t mp, const T* __restrict__ M1, const T* __restrict__ Apred,
-                           const T* __restrict__ a, T* __restrict__ out, T klw) {
+                           const T* __restrict__ a, T* __restrict__ out, T klw, const T* __restrict__ a2 = nullptr) {
   int64_t i = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
   int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= mp || j >= mp) return;
   T v = T(0);
-  if (i < m && j < m)
-    v = T(-0.5) * (M1[i * mp + j] + M1[j * mp + i]) + klw * (T(-0.5) * Apred[i * mp + j] + T(0.5) * a[i] * a[j]);
+  if (i < m && j < m) {
+    const T ai = a[i] - (a2 ? a2[i] : T(0)), aj = a[j] - (a2 ? a2[j] : T(0));
+    v = T(-0.5) * (M1[i * mp + j] + M1[j * mp + i]) + klw * (T(-0.5) * Apred[i * mp + j] + T(0.5) * ai * aj);
+  }
   out[i * mp + j] = v;
 }
 
@@ -314,6 +317,39 @@ __global__ void k_hyper_sum(int64_t B, const T* __restrict__ x, double wgt, doub
   for (int64_t i = threadIdx.x; i < B; i += blockDim.x) s += (double)x[i];
   s = block_sum<double>(s, red);
   if (threadIdx.x == 0) out[0] += wgt * s;
+}
+
+// the two reductions behind one backward pass in ONE launch (they were two, plus a memset in front of the first pass): workgroups
+// 0 .. D take the scalar outputs (k_hyper_reduce_scalar), the rest the inducing-point gradient (k_hyper_reduce_Z).  init: this is
+// the first pass of a gradient evaluation -- the scalars start from zero (+ the kdiag term  wgt_kd * sum_{i < Bkd} xkd[i]  on the
+// variance, k_hyper_sum's job) and dZ is overwritten.
+template <typename T>
+__global__ void k_hyper_reduce(int64_t ntiles, int64_t D, const double* __restrict__ pvar, const double* __restrict__ pscale,
+                               double* __restrict__ out, double wgt, int init, int64_t nrowtiles, int64_t p, int64_t p_pad,
+                               const T* __restrict__ pZ, T* __restrict__ dZ, T wgtZ, const T* __restrict__ xkd, int64_t Bkd,
+                               double wgt_kd) {
+  if ((int64_t)blockIdx.x <= D) {
+    __shared__ double red[16];
+    const int d = blockIdx.x;  // 0: variance, 1..D: scales
+    double s = 0.0;
+    for (int64_t t = threadIdx.x; t < ntiles; t += blockDim.x) s += (d == 0) ? pvar[t] : pscale[t * D + d - 1];
+    s = block_sum<double>(s, red);
+    double extra = 0.0;
+    if (d == 0 && xkd) {
+      double q = 0.0;
+      for (int64_t i = threadIdx.x; i < Bkd; i += blockDim.x) q += (double)xkd[i];
+      extra = wgt_kd * block_sum<double>(q, red);
+    }
+    if (threadIdx.x == 0) out[d] = (init ? 0.0 : out[d]) + wgt * s + extra;
+    return;
+  }
+  if (!dZ) return;
+  const int64_t e = ((int64_t)blockIdx.x - (D + 1)) * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= p * D) return;
+  const int64_t j = e / D, d = e % D;
+  T s = T(0);
+  for (int64_t b = 0; b < nrowtiles; ++b) s += pZ[(b * p_pad + j) * D + d];
+  dZ[e] = (init ? T(0) : dZ[e]) + wgtZ * s;
 }
 
 // tied-Z mode: gradients of several latents are summed (and all-reduced across ranks) in double

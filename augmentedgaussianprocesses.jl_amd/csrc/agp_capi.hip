@@ -259,16 +259,33 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_safe_rowstats(CholBatch<T> bt,
                                                                 T* __restrict__ Kt, T* __restrict__ muf, T* __restrict__ varf,
                                                                 T* __restrict__ cb, T* __restrict__ theta, T* __restrict__ r,
                                                                 T* __restrict__ w, int* __restrict__ flags,
-                                                                const T* __restrict__ lam, T* __restrict__ gamma) {
+                                                                const T* __restrict__ lam, T* __restrict__ gamma,
+                                                                int rows_done = 0, const int32_t* __restrict__ pf_word = nullptr,
+                                                                int32_t pf_want = 0) {
   __shared__ __attribute__((aligned(16))) T sm[3 * TILE * LDP];
   __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
   __shared__ T piv[TILE];
-  (void)chol_safe_body<T>(bt, src, 1, ld, ldx, lde, ne, nt, info, nvalid, bar, retries, sm, sc, piv);
+  const bool ran = chol_safe_body<T>(bt, src, 1, ld, ldx, lde, ne, nt, info, nvalid, bar, retries, sm, sc, piv);
   // (after a fallback the last grid barrier of the column loop has made every workgroup's tiles visible)
-  const int64_t wpb = CHOL_THREADS / 64, nwave = (int64_t)gridDim.x * wpb;
-  for (int64_t i = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); i < B; i += nwave)
-    rowstats_row<T>(i, threadIdx.x & 63, 0, B, nslices, rb, ldp, ldw, cols, jitter, rho, lp, y, idx, Kt, muf, varf, cb, theta, r, w,
-                    (int64_t)0, flags, lam, gamma);
+  // rows_done (round 3): the task-graph launch finished its rows itself (EpiArgs, agp_chol.h) -- unless it was aborted and re-run here
+  if (ran || !rows_done) {
+    const int64_t wpb = CHOL_THREADS / 64, nwave = (int64_t)gridDim.x * wpb;
+    for (int64_t i = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); i < B; i += nwave)
+      rowstats_row<T>(i, threadIdx.x & 63, 0, B, nslices, rb, ldp, ldw, cols, jitter, rho, lp, y, idx, Kt, muf, varf, cb, theta, r,
+                      w, (int64_t)0, flags, lam, gamma);
+  }
+  // pf_word (round 3): this launch was deferred to the head of the NEXT step and also carries that step's wait for its look-ahead
+  // (one wave polls the look-ahead's "done" word; in the steady state it is set long before)
+  if (pf_word && blockIdx.x == 0 && threadIdx.x == 0) {
+    long spins = 0;
+    while ((int32_t)(__hip_atomic_load(pf_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - pf_want) < 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1L << 27)) {
+        atomicExch(info, -2);
+        break;
+      }
+    }
+  }
 }
 
 // Factorisation by plain launches (matrices beyond the task graph, and the task graph's fallback).  From 8 block columns on it is
@@ -475,7 +492,7 @@ template <typename T>
 static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int64_t ldx, T* Dg, T* E, int64_t lde,
                               int64_t ne, int do_x, int32_t* info_dev, int64_t nvalid, const T* erow = nullptr,
                               bool want_l = true, const SafeSrc<T>* safe = nullptr, bool* defer_safe = nullptr,
-                              StepSync* ssync = nullptr, const ProHost<T>* pro = nullptr) {
+                              StepSync* ssync = nullptr, const ProHost<T>* pro = nullptr, const EpiArgs<T>* epi = nullptr) {
   // ssync (CAVI step next to a look-ahead stream): the step's task-graph instantiation stores its `started` number (`used` is set)
   // defer_safe (in: the caller can run the fallback itself, k_safe_rowstats; out: whether it has to -- the task graph was used)
   const bool can_defer = defer_safe && *defer_safe;
@@ -577,7 +594,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       }
       hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, true>), dim3((unsigned)(ntiles + nhelp + pa.nfill)),
                          dim3(CHOL_THREADS), lds_pad, c->stream, one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid,
-                         c->dag_flags, c->dag_epoch, ptrace, H, hstride, nx, erow, 0, ds, pa);
+                         c->dag_flags, c->dag_epoch, ptrace, H, hstride, nx, erow, 0, ds, pa, epi ? *epi : EpiArgs<T>{});
       if (ptrace) {
         std::vector<unsigned long long> hq(2048);
         (void)hipStreamSynchronize(c->stream);
@@ -957,6 +974,7 @@ struct SvgpBase {
   virtual agp_status get_lik_param(double* out) = 0;
   virtual agp_status set_lik_param(double v) = 0;
   int64_t n_opt = 1;  // RobbinsMonro counter (optimisers.jl:12)
+  bool in_cavi_step = false;  // step_local is running as the first half of agp_svgp_cavi_step (its tail may then be deferred)
   int64_t n_prologue = 0;  // CAVI steps whose natural-gradient part rode on the next step's task-graph launch (agp_svgp_step_counters)
   int64_t n_steps = 0;     // agp_svgp_cavi_step calls
   // HIP-event timing of the dominant kernel sequence (agp_svgp_timing_*)
@@ -1174,7 +1192,48 @@ struct Svgp : SvgpBase {
     T lr = T(0);
     const T* kap = nullptr;
     const T *Kinv = nullptr, *kinv_mu0 = nullptr;
+    const T *r = nullptr, *w = nullptr;  // rho grad_E_mu / rho grad_E_Sigma of that minibatch (the r / w pair current at the time)
   } pend;
+  // Second (r, w) pair: a task-graph launch with the row-statistics EPILOGUE (EpiArgs) writes this step's r, w while late workgroups
+  // of its own prologue may still read the previous step's -- the two pairs alternate.
+  T *rbuf2 = nullptr, *wbuf2 = nullptr;
+  // The launch behind such a task graph -- its in-stream fallback (k_chol_safe), which also redoes the rows if it has to run -- is
+  // DEFERRED to the head of the next step, where it also carries that step's wait for its look-ahead: one tiny kernel between two
+  // task graphs instead of two (k_safe_rowstats + k_wait_ge_fast; every kernel costs the in-order queue ~5 us).  Anything else that
+  // needs the step's results runs it first (flush()).
+  struct SafeDeferred {
+    bool on = false;
+    CholBatch<T> bt{};
+    SafeSrc<T> src{};
+    RowstatsBatch<T> rb{};
+    int64_t ne = 0, nt = 0, B = 0;
+    int ns = 0;
+    T rho = T(0);
+    const T* y = nullptr;
+    const int64_t* idx = nullptr;
+    T *r = nullptr, *w = nullptr;
+    unsigned grid = 1;
+  } sdef;
+  agp_status run_deferred_safe(const int32_t* pf_word = nullptr, int32_t pf_want = 0) {
+    if (!sdef.on) return AGP_OK;
+    sdef.on = false;
+    hipLaunchKernelGGL((k_safe_rowstats<T>), dim3(sdef.grid), dim3(CHOL_THREADS), 0, st(), sdef.bt, sdef.src, mp, mp, mp, sdef.ne,
+                       sdef.nt, info_dev, m, ctx->safe_bar, ctx->safe_retries, sdef.B, sdef.ns, sdef.rb, ldp, mp, mp, (T)jitter,
+                       sdef.rho, lp, sdef.y, sdef.idx, Kt, muf, varf, cbuf, theta, sdef.r, sdef.w, flags_dev, (const T*)lam_dev,
+                       gamma, 1, pf_word, pf_want);
+    LAUNCHCHK(ctx);
+    return AGP_OK;
+  }
+  bool epi_allowed() const {
+    static const bool off = []() {
+      const char* e = getenv("AGP_STEP_EPILOGUE");
+      return e && e[0] == '0';
+    }();
+    if (off) return false;
+    const int k = lp.kind;  // likelihoods whose local update is complete in rowstats_finish (no further kernel reads mean_f / var_f)
+    return (k == AGP_LIK_GAUSSIAN && !lp.noise_dev) || k == AGP_LIK_LOGISTIC || k == AGP_LIK_STUDENTT || k == AGP_LIK_LAPLACE ||
+           k == AGP_LIK_BAYESIANSVM || k == AGP_LIK_NEGBINOMIAL;
+  }
   bool pro_allowed() const {
     static const bool off = []() {
       const char* e = getenv("AGP_STEP_PROLOGUE");
@@ -1190,10 +1249,11 @@ struct Svgp : SvgpBase {
            k == AGP_LIK_BAYESIANSVM || k == AGP_LIK_NEGBINOMIAL || k == AGP_LIK_POISSON;
   }
   agp_status flush() override {
+    AGPCHK(run_deferred_safe());
     if (!pend.on) return AGP_OK;
     Latent& g = lat[0];
     pend.on = false;
-    AGPCHK((syrk_tn<T, SY_ETA2>(ctx, pend.kap, mp, mp, pend.Bq, wbuf, 0, g.La, mp, g.eta2, pend.Kinv, mp, pend.lr, (const T*)rbuf,
+    AGPCHK((syrk_tn<T, SY_ETA2>(ctx, pend.kap, mp, mp, pend.Bq, pend.w, 0, g.La, mp, g.eta2, pend.Kinv, mp, pend.lr, pend.r,
                                 g.eta1, pend.kinv_mu0)));
     LAUNCHCHK(ctx);
     g.la_state = 0;  // the epilogue left La = -2 eta2
@@ -1210,6 +1270,8 @@ struct Svgp : SvgpBase {
       pend.kap = g.kappa;
       pend.Kinv = kinv_step(g);
       pend.kinv_mu0 = kinv_mu0_step(g);
+      pend.r = rbuf;
+      pend.w = wbuf;
       // the bookkeeping of step_global: the posterior changes (as soon as the step is taken)
       g.la_state = 1;  // La does not hold -2 eta2: whoever wants it rebuilds it from eta2 (after flush())
       g.xa_valid = false;
@@ -1218,6 +1280,7 @@ struct Svgp : SvgpBase {
       n_opt += 1;
       return kappa_released();
     }
+    AGPCHK(run_deferred_safe());
     AGPCHK(step_stats(true));
     return step_global(true);
   }
@@ -1307,6 +1370,10 @@ struct Svgp : SvgpBase {
       AGPCHK(dmalloc(ctx, p, nl * Bp));
       HIPCHK(ctx, hipMemsetAsync(*p, 0, sizeof(T) * nl * Bp, st()));
     }
+    AGPCHK(dmalloc(ctx, &rbuf2, nl * Bp));
+    AGPCHK(dmalloc(ctx, &wbuf2, nl * Bp));
+    HIPCHK(ctx, hipMemsetAsync(rbuf2, 0, sizeof(T) * nl * Bp, st()));
+    HIPCHK(ctx, hipMemsetAsync(wbuf2, 0, sizeof(T) * nl * Bp, st()));
     AGPCHK(dmalloc(ctx, &alpha, Bp));
     AGPCHK(dmalloc(ctx, &beta, Bp));
     AGPCHK(dmalloc(ctx, &gsum, Bp));
@@ -1357,7 +1424,7 @@ struct Svgp : SvgpBase {
     if (pf_done) dcheck(hipEventDestroy(pf_done), __LINE__);
     for (auto e : step_done)
       if (e) dcheck(hipEventDestroy(e), __LINE__);
-    T* ps[] = {pw0, pw1, Kt, muf, varf, cbuf, theta, gamma, rbuf, wbuf, alpha, beta, gsum, alpha_save, emuf,
+    T* ps[] = {rbuf2, wbuf2, pw0, pw1, Kt, muf, varf, cbuf, theta, gamma, rbuf, wbuf, alpha, beta, gsum, alpha_save, emuf,
                evarf, stats, Tw, Tw2, tmpv, lr_dev, Kstar, ppm, ppv, pmu, pvar};
     for (T* p : ps)
       if (p) dfree(p);
@@ -1808,16 +1875,24 @@ struct Svgp : SvgpBase {
                 mp / TILE <= 32 && dag_fused_on() && !dag_trace_on() && pend.Bq >= TILE;
       if (!use_pro) AGPCHK(flush());
     }
+    // the row statistics of this step as the epilogue of its task-graph launch, the launch's fallback deferred to the next step
+    const bool use_epi = use_pro && in_cavi_step && epi_allowed();
     if (prefetched) {  // kappa of this minibatch was produced on the prefetch stream: adopt those buffers
       static const bool pf_poll = []() {  // AGP_PF_POLL=0: wait for the look-ahead with an event (A/B measurements)
         const char* e = getenv("AGP_PF_POLL");
         return !(e && e[0] == '0');
       }();
       if (sig_state == 1 && pf_poll) {
-        hipLaunchKernelGGL(k_wait_ge_fast, dim3(1), dim3(64), 0, st(), (const int32_t*)sig[1], pf_seq, info_dev);
-        LAUNCHCHK(ctx);
-      } else
+        if (sdef.on) {  // the previous step's deferred fallback launch carries this step's wait for its look-ahead
+          AGPCHK(run_deferred_safe((const int32_t*)sig[1], pf_seq));
+        } else {
+          hipLaunchKernelGGL(k_wait_ge_fast, dim3(1), dim3(64), 0, st(), (const int32_t*)sig[1], pf_seq, info_dev);
+          LAUNCHCHK(ctx);
+        }
+      } else {
+        AGPCHK(run_deferred_safe());
         HIPCHK(ctx, hipStreamWaitEvent(st(), pf_done, 0));
+      }
       for (auto& g : lat) {
         std::swap(g.Knm, g.Knm_alt);
         std::swap(g.Wbuf, g.Wbuf_alt);
@@ -1831,6 +1906,7 @@ struct Svgp : SvgpBase {
       }
       pf_valid = false;
     }
+    AGPCHK(run_deferred_safe());  // (full-batch steps: no look-ahead to wait for)
     CholBatch<T> merged_bt{};  // single latent on the task graph: fallback + row statistics share a launch (k_safe_rowstats)
     SafeSrc<T> merged_src{};
     bool merged_safe = false;
@@ -1925,8 +2001,8 @@ struct Svgp : SvgpBase {
             ph.kap = pend.kap;
             ph.ldk = mp;
             ph.Kdim = pend.Bq;
-            ph.w = wbuf;
-            ph.r = rbuf;
+            ph.w = pend.w;
+            ph.r = pend.r;
             ph.eta2 = g0.eta2;
             ph.Kinv = pend.Kinv;
             ph.ldm = mp;
@@ -1936,9 +2012,39 @@ struct Svgp : SvgpBase {
             pend.on = false;
             n_prologue += 1;
           }
+          EpiArgs<T> ea{};
+          if (use_epi) {
+            Latent& g0 = lat[0];
+            // this launch writes r, w of THIS minibatch while its prologue reads the pending step's pair: alternate
+            std::swap(rbuf, rbuf2);
+            std::swap(wbuf, wbuf2);
+            ea.on = 1;
+            ea.B = B;
+            ea.nslices = ns;
+            ea.pk = g0.pk;
+            ea.ldp = ldp;
+            ea.kdiag = kvar(g0);
+            ea.kd_ptr = g0.scales + D;
+            ea.use_kt = g0.keep_last ? 1 : 0;
+            ea.jitter = (T)jitter;
+            ea.rho = (T)rho;
+            ea.lp = lp;
+            ea.y = (const T*)y;
+            ea.idx = idx;
+            ea.Kt = Kt;
+            ea.muf = muf;
+            ea.varf = varf;
+            ea.cb = cbuf;
+            ea.theta = theta;
+            ea.r = rbuf;
+            ea.w = wbuf;
+            ea.flags = flags_dev;
+            ea.lam = lam_dev;
+            ea.gamma = gamma;
+          }
           AGPCHK(potrf_fused<T>(ctx, bt.A[0], mp, mp, bt.X[0], mp, bt.Dg[0], bt.E[0], mp, nel, 0, info_dev, m,
                                 (const T*)lat[todo[l0]].eta1, false, &src, &defer, sync_step ? &ssync : nullptr,
-                                use_pro ? &ph : nullptr));
+                                use_pro ? &ph : nullptr, use_epi ? &ea : nullptr));
           merged_safe = defer;
           launches += dag_nb > 0 ? 1 : chol_launch_count(ntl, nel);
         } else if (dag_nb > 0) {
@@ -1975,6 +2081,23 @@ struct Svgp : SvgpBase {
         const int64_t nt_ = mp / TILE, ne_ = Bq / TILE + 1;
         const int64_t most = std::max<int64_t>(nt_ + ne_ + nt_ * (nt_ + 1) / 2 + ne_ * nt_, (B + 7) / 8);
         const unsigned g1 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ctx->n_cu, most));
+        if (use_epi) {  // the rows are done inside the task graph: the fallback launch waits for the head of the next step
+          sdef.on = true;
+          sdef.bt = merged_bt;
+          sdef.src = merged_src;
+          sdef.rb = rb;
+          sdef.ne = ne_;
+          sdef.nt = nt_;
+          sdef.B = B;
+          sdef.ns = ns;
+          sdef.rho = (T)rho;
+          sdef.y = (const T*)y;
+          sdef.idx = idx;
+          sdef.r = rbuf;
+          sdef.w = wbuf;
+          sdef.grid = g1;
+          continue;
+        }
         hipLaunchKernelGGL((k_safe_rowstats<T>), dim3(g1), dim3(CHOL_THREADS), 0, st(), merged_bt, merged_src, mp, mp, mp, ne_, nt_,
                            info_dev, m, ctx->safe_bar, ctx->safe_retries, B, ns, rb, ldp, mp, mp, (T)jitter, (T)rho, lp, (const T*)y,
                            idx, Kt, muf, varf, cbuf, theta, rbuf, wbuf, flags_dev, (const T*)lam_dev, gamma);
@@ -4284,7 +4407,10 @@ agp_status agp_svgp_cavi_step(agp_svgp* h, const void* x, int64_t ldx, const voi
                               double rho) {
   HCHK(h);
   SvgpBase* s = h->impl;
-  AGPCHK(s->step_local(x, ldx, y, idx, B, rho, false));
+  s->in_cavi_step = true;
+  const agp_status sl_ = s->step_local(x, ldx, y, idx, B, rho, false);
+  s->in_cavi_step = false;
+  AGPCHK(sl_);
   if (s->desc.lik.kind == AGP_LIK_LOGISTICSOFTMAX) {
     for (int it = 0; it < 2; ++it) {  // logisticsoftmax.jl:65
       AGPCHK(s->lsm_gamma());

@@ -462,6 +462,47 @@ struct RowstatsBatch {
   const T* kd_ptr[ROWSTATS_MAXB];
   int use_kt[ROWSTATS_MAXB];   // K~ kept from the previous full-batch step
 };
+// what one thread does for row i once the three row sums are known (s0 = sum_j W_ij^2, s1 = sum_j W_ij v_j, sk = sum of the K~
+// slices): K~ / mean_f / var_f and the likelihood's local update + expectation gradients.  Shared by the row-statistics kernels and
+// by the epilogue of the CAVI step's task-graph launch (agp_chol.h, round 3).  The output pointers are those of the row's latent.
+template <typename T>
+__device__ __forceinline__ void rowstats_finish(int64_t i, T s0, T s1, T sk, T kdiag, int use_kt, T jitter, T rho,
+                                                const LikParams<T>& lp, const T* __restrict__ y,
+                                                const int64_t* __restrict__ idx, T* __restrict__ Kt, T* __restrict__ muf,
+                                                T* __restrict__ varf, T* __restrict__ c, T* __restrict__ theta, T* __restrict__ r,
+                                                T* __restrict__ w, int* __restrict__ flags, const T* __restrict__ lam,
+                                                T* __restrict__ gamma, const T* yi_pre = nullptr) {
+  // (yi_pre: the row's target, already fetched by the caller)
+  // use_kt: kappa (hence K~) was kept from the previous full-batch step (training.jl:199-205)
+  T kt = use_kt ? Kt[i] : kdiag + jitter - sk;
+  if (!(kt > T(0))) atomicOr(flags, FLAG_NEG_KTILDE);
+  T var = s0 + kt, mu = s1;
+  Kt[i] = kt;
+  muf[i] = mu;
+  varf[i] = var;
+  if (lp.kind == LIK_LSM) {
+    c[i] = sqrt(mu * mu + var);  // logisticsoftmax.jl:62-64
+    return;
+  }
+  if (lp.kind == LIK_MO || lp.kind == LIK_HETERO) return;  // mixing / two-latent coupling follow in k_mo_local, k_hetero_*
+  if (lp.kind == LIK_GAUSSIAN && lp.noise_dev) return;     // the noise step comes first (k_noise_*), then theta / gradients
+  T yi = yi_pre ? *yi_pre : y[idx ? idx[i] : i];
+  T th, cc, g1;
+  if (lp.kind == LIK_POISSON) {  // poisson.jl:64-80,94-103 (lambda itself is re-estimated afterwards by k_poisson_*)
+    cc = sqrt(mu * mu + var);
+    T gam = (T)((double)lam[0] * safe_expcosh_d(-0.5 * (double)mu, 0.5 * (double)cc) / 2.0);
+    th = (yi + gam) * T(2) * theta_pg<T>(cc);
+    g1 = (yi - gam) / T(2);
+    gamma[i] = gam;
+  } else {
+    lik_point<T>(lp.kind, lp.p0, lp.p1, mu, var, yi, th, cc, g1);
+  }
+  c[i] = cc;
+  theta[i] = th;
+  r[i] = rho * g1;
+  w[i] = rho * th / T(2);
+}
+
 // one wave's work on row i of latent q (shared by k_rowstats_local and the kernel that also carries the task graph's fallback)
 template <typename T>
 __device__ __forceinline__ void rowstats_row(int64_t i, int lane, int q, int64_t B, int nslices, const RowstatsBatch<T>& rb,
@@ -516,34 +557,7 @@ __device__ __forceinline__ void rowstats_row(int64_t i, int lane, int q, int64_t
     sk += __shfl_down(sk, o);
   }
   if (lane != 0) return;
-  // use_kt: kappa (hence K~) was kept from the previous full-batch step (training.jl:199-205)
-  T kt = use_kt ? Kt[i] : kdiag + jitter - sk;
-  if (!(kt > T(0))) atomicOr(flags, FLAG_NEG_KTILDE);
-  T var = s0 + kt, mu = s1;
-  Kt[i] = kt;
-  muf[i] = mu;
-  varf[i] = var;
-  if (lp.kind == LIK_LSM) {
-    c[i] = sqrt(mu * mu + var);  // logisticsoftmax.jl:62-64
-    return;
-  }
-  if (lp.kind == LIK_MO || lp.kind == LIK_HETERO) return;  // mixing / two-latent coupling follow in k_mo_local, k_hetero_*
-  if (lp.kind == LIK_GAUSSIAN && lp.noise_dev) return;     // the noise step comes first (k_noise_*), then theta / gradients
-  T yi = y[idx ? idx[i] : i];
-  T th, cc, g1;
-  if (lp.kind == LIK_POISSON) {  // poisson.jl:64-80,94-103 (lambda itself is re-estimated afterwards by k_poisson_*)
-    cc = sqrt(mu * mu + var);
-    T gam = (T)((double)lam[0] * safe_expcosh_d(-0.5 * (double)mu, 0.5 * (double)cc) / 2.0);
-    th = (yi + gam) * T(2) * theta_pg<T>(cc);
-    g1 = (yi - gam) / T(2);
-    gamma[i] = gam;
-  } else {
-    lik_point<T>(lp.kind, lp.p0, lp.p1, mu, var, yi, th, cc, g1);
-  }
-  c[i] = cc;
-  theta[i] = th;
-  r[i] = rho * g1;
-  w[i] = rho * th / T(2);
+  rowstats_finish<T>(i, s0, s1, sk, kdiag, use_kt, jitter, rho, lp, y, idx, Kt, muf, varf, c, theta, r, w, flags, lam, gamma);
 }
 
 template <typename T>

@@ -20,6 +20,7 @@
 //     applies the rank-4 update to its cyclic 4x4 sub-blocks of A and of M; triangular skipping is compile-time per
 //     16-column group.
 #pragma once
+#include "agp_cavi.h"  // LikParams, rowstats_finish: the CAVI step's task-graph launch finishes its rows itself (EpiArgs)
 #include "agp_device.h"
 
 namespace agp {
@@ -1486,6 +1487,33 @@ __device__ __forceinline__ int pro_slot_off(int tid, int e) {
   return (e / VEC) * (CHOL_THREADS * VEC) + tid * VEC + (e % VEC);
 }
 
+// ---- EPI: the row statistics + local update of the step as the EPILOGUE of its task-graph launch (round 3) -------------------------
+// mean_f = W v and var_f = rowsum(W .* W) + K~ (latentgp.jl:179,189) need a whole row of W = kappa L^-T, i.e. the tiles (R, 0 ..
+// nt-1) of an extension block row R and the matching pieces of v = L^-1 eta1.  The workgroup of the LAST tile of the row, (R, nt-1),
+// has fetched every W(R, j), j < nt-1, anyway (for its own rank-64 updates): it accumulates the two row sums on the way, adds its own
+// tile when that is solved, and finishes its 64 rows -- K~, mean_f, var_f, the likelihood's local update and the expectation
+// gradients r = rho grad_E_mu, w = rho grad_E_Sigma (rowstats_finish, agp_cavi.h) -- so that no row-statistics kernel follows the
+// launch.  r and w are written to the buffers the NEXT launch's prologue reads (this launch's prologue reads the previous pair).
+template <typename T>
+struct EpiArgs {
+  int on = 0;
+  int64_t B = 0;
+  int nslices = 0;
+  const T* pk = nullptr;  // K~ partial slices [nslices][ldp]
+  int64_t ldp = 0;
+  T kdiag = T(0);
+  const T* kd_ptr = nullptr;  // kdiag < 0: device-resident kernel variance
+  int use_kt = 0;
+  T jitter = T(0), rho = T(0);
+  LikParams<T> lp{};
+  const T* y = nullptr;
+  const int64_t* idx = nullptr;
+  T *Kt = nullptr, *muf = nullptr, *varf = nullptr, *cb = nullptr, *theta = nullptr, *r = nullptr, *w = nullptr;
+  int* flags = nullptr;
+  const T* lam = nullptr;
+  T* gamma = nullptr;
+};
+
 template <typename T>
 struct ProArgs {
   const T* kap = nullptr;  // kappa of the minibatch whose natural-gradient step is pending (Kdim x ldk)
@@ -1553,7 +1581,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
                                                            int32_t* __restrict__ info, int64_t nvalid, int32_t* flags,
                                                            int32_t epoch, unsigned long long* trace, T* H, int64_t hstride,
                                                            int64_t nx_, const T* __restrict__ erow, int opts, DagSync sync,
-                                                           ProArgs<T> pro = ProArgs<T>{}) {
+                                                           ProArgs<T> pro = ProArgs<T>{}, EpiArgs<T> epi = EpiArgs<T>{}) {
   static_assert(!PRO || (FUSED && STEP && !BATCH), "the prologue exists for the single-problem CAVI-step launch only");
   // opts bit 0: the chain also stores X_k to its real home (a single block column wanting its inverse: no identity rows run)
   //      bit 1: the factor L is wanted in its real home A as well (K's factor, the potrf entry points); the CAVI step only
@@ -1910,6 +1938,26 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   const bool f1 = FUSED && b == 1 && !ext;  // tile (c+1, c): feeds the chain instead of waiting for X_c itself
   const bool f2 = FUSED && diag;            // diagonal tile (c, c), c >= 1: the chain applies the last update itself
   const int64_t jend = f2 ? c - 1 : c;
+  // EPI: the last tile of a kappa block row gathers the row's statistics while it fetches the tiles left of it
+  const bool epi_row = PRO && epi.on && ext && c == nt - 1 && R < nt + ne - 1;
+  T epi_ss = T(0), epi_dt = T(0), epi_sk = T(0), epi_y = T(0);
+  const int er = tid >> 3, es = (tid & 7) * 8;  // thread -> row er, columns es .. es + 7 of a 64 x 64 tile
+  if (epi_row) {  // what the rows need besides W and v is fetched now, far from the launch's tail: the K~ slices of row er
+    const int64_t i = (R - nt) * TILE + er;
+    if (!epi.use_kt && i < epi.B)
+      for (int q = (tid & 7); q < epi.nslices; q += 8) epi_sk += epi.pk[q * epi.ldp + i];
+    if ((tid & 7) == 0 && i < epi.B) epi_y = epi.y[epi.idx ? epi.idx[i] : i];  // ... and its target
+  }
+  auto epi_acc = [&](const T* Wt /* LDS [r][k] */, const T* vslot /* hand-over slot of the v tile of this block column */) {
+    if (tid < TILE) piv[tid] = hv_settle<T>(vslot + tid, __hip_atomic_load(vslot + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const T a = Wt[er * LDP + es + q];
+      epi_ss += a * a;
+      epi_dt += a * piv[es + q];
+    }
+  };
   for (int64_t j = idr ? R - nt - ne : 0; j < jend; ++j) {  // row i of the identity is zero left of block column i
     if (!dag_wait(ready + (R * nt + j) * DAG_FS, diag ? nullptr : ready + (c * nt + j) * DAG_FS, epoch, abortf, info, &wait_ok))
       return;
@@ -1918,6 +1966,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
     else load_tiles_lds_hv2<T>(HL + (R * nt + j) * SLOT, bufA, HL + (c * nt + j) * SLOT, bufB);
     __syncthreads();
     if (j == c - 1) DAG_TR(5);
+    if (epi_row) epi_acc(bufA, HL + ((nt + ne - 1) * nt + j) * SLOT);  // (ends behind a barrier of its own: piv is stable below)
     mma8_sub<T>(bufA, diag ? bufA : bufB, acc);
     __syncthreads();
   }
@@ -1974,6 +2023,27 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   DAG_TR(7);
   dag_signal(ready + (R * nt + c) * DAG_FS, epoch);
   DAG_TR(3);
+  if (epi_row) {
+    // own tile W(R, nt-1) (still in the accumulators) through LDS, the last piece of v from the tile of the [eta1' ; 0] row in
+    // this block column (solved by its own workgroup at about the same time: its slot validates itself), then the 64 rows
+    __syncthreads();
+    acc8_foreach<T>(out, [&](int r, int cc, T& val) { bufA[r * LDP + cc] = val; });
+    __syncthreads();
+    epi_acc(bufA, HL + ((nt + ne - 1) * nt + c) * SLOT);
+    const int64_t i = (R - nt) * TILE + er;
+    T sk = epi_sk;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      epi_ss += __shfl_xor(epi_ss, o);
+      epi_dt += __shfl_xor(epi_dt, o);
+      sk += __shfl_xor(sk, o);
+    }
+    if ((tid & 7) == 0 && i < epi.B) {
+      const T kd = epi.kdiag < T(0) ? epi.kd_ptr[0] : epi.kdiag;
+      rowstats_finish<T>(i, epi_ss, epi_dt, sk, kd, epi.use_kt, epi.jitter, epi.rho, epi.lp, epi.y, epi.idx, epi.Kt, epi.muf,
+                         epi.varf, epi.cb, epi.theta, epi.r, epi.w, epi.flags, epi.lam, epi.gamma, &epi_y);
+    }
+  }
 #undef DAG_TR
 #undef DAG_TRC
 #undef PRO_TS

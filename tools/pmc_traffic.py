@@ -19,7 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = sys.argv[2] if len(sys.argv) > 2 else "c2"
-TAG = sys.argv[3] if len(sys.argv) > 3 else f"r02_{CFG}"
+TAG = sys.argv[3] if len(sys.argv) > 3 else f"r03_{CFG}"
 OUT = os.path.join(ROOT, "gpurun_out", f"pmc_{TAG}")
 CMD = ["python", os.path.join(ROOT, "bench.py"), "--config", CFG, "--no-cpu-baseline", "--no-elbo-tol", "--steps",
        "10" if CFG == "c5" else "40", "--warmup", "4" if CFG == "c5" else "10"]

@@ -504,7 +504,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
   // path needs it in E first)
   const int64_t nt = n / TILE;
   const bool use_dag = chol_use_dag(c, nt, ne);
-  if (pro && !(use_dag && X && dag_fused_on() && !dag_trace_on() && !do_x && !want_l && nt <= 32)) {
+  if (pro && !(use_dag && X && dag_fused_on() && !dag_trace_on() && !want_l && nt <= 32)) {
     c->err = "potrf_fused: a pending natural-gradient step can only ride on the CAVI step's task-graph launch";
     return AGP_ERR_INVALID;
   }
@@ -558,7 +558,8 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       hipLaunchKernelGGL((k_chol_dag<T, true, false, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1,
                          (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
                          (int)(do_x && nx == 0) | (want_l ? 2 : 0), DagSync{});
-    else if (step_inst && pro) {  // ... with the pending natural-gradient step as its prologue
+    else if (fused && !trace && pro) {  // ... with the pending natural-gradient step as its prologue (the CAVI step's launch, or --
+                                        // hyper-parameter iteration -- the factorisation of the updated -2 eta2 with its inverse)
       pa.kap = pro->kap;
       pa.ldk = pro->ldk;
       pa.Kdim = pro->Kdim;
@@ -570,8 +571,8 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       pa.eta1 = pro->eta1;
       pa.kinv_mu0 = pro->kinv_mu0;
       pa.lr = pro->lr;
-      pa.HS = H + (3 * nt + (nt + ne) * nt) * TILE * TILE;
-      pa.sflags = c->dag_flags + ((nt + ne) * nt + 3 * nt + 1) * DAG_FS;
+      pa.HS = H + (3 * nt + (nt + ne + nx) * nt) * TILE * TILE;
+      pa.sflags = c->dag_flags + ((nt + ne + nx) * nt + 3 * nt + 1) * DAG_FS;
       const int other = hs ^ 1;
       if (c->hset[other] && c->h_dirty[other].on && c->h_dirty[other].nb == 1 && c->htype == (int)sizeof(T)) {
         pa.fill = (T*)c->hset[other];  // the set the launch before this one used: refilled in this launch's shadow
@@ -592,9 +593,15 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
         if (hipMalloc((void**)&ptrace, 2048 * 8) != hipSuccess) ptrace = nullptr;
         if (ptrace) (void)hipMemsetAsync(ptrace, 0, 2048 * 8, c->stream);
       }
-      hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, true>), dim3((unsigned)(ntiles + nhelp + pa.nfill)),
-                         dim3(CHOL_THREADS), lds_pad, c->stream, one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid,
-                         c->dag_flags, c->dag_epoch, ptrace, H, hstride, nx, erow, 0, ds, pa, epi ? *epi : EpiArgs<T>{});
+      if (step_inst)
+        hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, true>), dim3((unsigned)(ntiles + nhelp + pa.nfill)),
+                           dim3(CHOL_THREADS), lds_pad, c->stream, one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid,
+                           c->dag_flags, c->dag_epoch, ptrace, H, hstride, nx, erow, 0, ds, pa, epi ? *epi : EpiArgs<T>{});
+      else
+        hipLaunchKernelGGL((k_chol_dag<T, true, false, false, false, true>), dim3((unsigned)(ntiles + nhelp + pa.nfill)),
+                           dim3(CHOL_THREADS), lds_pad, c->stream, one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid,
+                           c->dag_flags, c->dag_epoch, ptrace, H, hstride, nx, erow, (int)(do_x && nx == 0) | (want_l ? 2 : 0),
+                           DagSync{}, pa, EpiArgs<T>{});
       if (ptrace) {
         std::vector<unsigned long long> hq(2048);
         (void)hipStreamSynchronize(c->stream);
@@ -2904,7 +2911,31 @@ struct Svgp : SvgpBase {
   //   Wbuf <- [kappa L^-T ; (L^-1 eta1)']   i.e. W and v of mean_f = W v, var_f = rowsum(W^2) + K~.
   // with_x additionally forms Xa = L^-1 (needed only for Sigma / mu export, ELBO and prediction).
   agp_status aug_factor(Latent& g, int64_t Bq, int with_x) {
-    if (g.la_state != 0) {  // La holds a factor: rebuild -2*eta2
+    // a pending natural-gradient step (only the hyper step's wrapper leaves one: every other entry point has flushed) rides on this
+    // launch as its prologue -- the hyper-parameter iteration's "eta step, then factor the new -2 eta2 with its inverse" in ONE launch
+    AGPCHK(run_deferred_safe());
+    ProHost<T> ph{};
+    bool use_pro = false;
+    if (pend.on) {
+      use_pro = nl == 1 && pro_allowed() && chol_use_dag(ctx, mp / TILE, Bq / TILE + 1) && dag_fused_on() && !dag_trace_on() &&
+                pend.Bq >= TILE && mp / TILE > 1;
+      if (!use_pro) AGPCHK(flush());
+    }
+    if (use_pro) {
+      ph.kap = pend.kap;
+      ph.ldk = mp;
+      ph.Kdim = pend.Bq;
+      ph.w = pend.w;
+      ph.r = pend.r;
+      ph.eta2 = g.eta2;
+      ph.Kinv = pend.Kinv;
+      ph.ldm = mp;
+      ph.eta1 = g.eta1;
+      ph.kinv_mu0 = pend.kinv_mu0;
+      ph.lr = pend.lr;
+      pend.on = false;
+      n_prologue += 1;
+    } else if (g.la_state != 0) {  // La holds a factor: rebuild -2*eta2
       hipLaunchKernelGGL((k_copy2d<T>), grid2(mp, mp), blk2, 0, st(), (const T*)g.eta2, mp, mp, mp, g.La, mp, mp, mp,
                          T(1), T(-2));
       LAUNCHCHK(ctx);
@@ -2920,7 +2951,7 @@ struct Svgp : SvgpBase {
     // iteration used to wait here once per step)
     src.want_x = with_x ? 1 : 0;
     AGPCHK(potrf_fused<T>(ctx, g.La, mp, mp, g.Xa, mp, g.DgA, g.Wbuf, mp, Bq / TILE + 1, with_x, info_dev, m,
-                          (const T*)g.eta1, false, &src));
+                          (const T*)g.eta1, false, &src, nullptr, nullptr, use_pro ? &ph : nullptr));
     AGPCHK(timing_end(chol_use_dag(ctx, mp / TILE, Bq / TILE + 1) ? 1 : chol_launch_count(mp / TILE, Bq / TILE + 1)));
     g.la_state = 1;
     g.xa_valid = with_x != 0;
@@ -4490,7 +4521,7 @@ agp_status agp_svgp_hypergrad(agp_svgp* h, int32_t latent, double* dvariance_hos
   return h->impl->hypergrad(latent, dvariance_host, dscale_host, dZ);
 }
 agp_status agp_svgp_hyper_step(agp_svgp* h) {
-  HCHKF(h);
+  HCHK(h);  // (no flush: a pending natural-gradient step becomes the prologue of the factorisation the gradient needs, aug_factor)
   return h->impl->hyper_step();
 }
 agp_status agp_svgp_get_kernel(agp_svgp* h, int32_t latent, double* variance_host, double* scales_host) {

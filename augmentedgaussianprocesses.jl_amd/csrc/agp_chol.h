@@ -1582,7 +1582,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
                                                            int32_t epoch, unsigned long long* trace, T* H, int64_t hstride,
                                                            int64_t nx_, const T* __restrict__ erow, int opts, DagSync sync,
                                                            ProArgs<T> pro = ProArgs<T>{}, EpiArgs<T> epi = EpiArgs<T>{}) {
-  static_assert(!PRO || (FUSED && STEP && !BATCH), "the prologue exists for the single-problem CAVI-step launch only");
+  static_assert(!PRO || (FUSED && !BATCH), "the prologue exists for single-problem launches with a chain workgroup only");
   // opts bit 0: the chain also stores X_k to its real home (a single block column wanting its inverse: no identity rows run)
   //      bit 1: the factor L is wanted in its real home A as well (K's factor, the potrf entry points); the CAVI step only
   //             consumes the extension rows W, v and never reads L itself, so its launches skip those stores
@@ -1633,7 +1633,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
         for (int64_t i = b * CHOL_THREADS + tid; i < pro.fill_n; i += (int64_t)pro.nfill * CHOL_THREADS) pro.fill[i] = sv;
         return;
       }
-      const int64_t nh = (nt - c) * (pro.ks[c] - 1), ntile = nt - c + ne;
+      const int64_t nh = (nt - c) * (pro.ks[c] - 1), ntile = nt - c + ne + (nx ? c + 1 : 0);
       if (b < nh) {
         helper = true;
         break;
@@ -1939,7 +1939,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   const bool f2 = FUSED && diag;            // diagonal tile (c, c), c >= 1: the chain applies the last update itself
   const int64_t jend = f2 ? c - 1 : c;
   // EPI: the last tile of a kappa block row gathers the row's statistics while it fetches the tiles left of it
-  const bool epi_row = PRO && epi.on && ext && c == nt - 1 && R < nt + ne - 1;
+  const bool epi_row = PRO && epi.on && ext && !idr && c == nt - 1 && R < nt + ne - 1;
   T epi_ss = T(0), epi_dt = T(0), epi_sk = T(0), epi_y = T(0);
   const int er = tid >> 3, es = (tid & 7) * 8;  // thread -> row er, columns es .. es + 7 of a 64 x 64 tile
   if (epi_row) {  // what the rows need besides W and v is fetched now, far from the launch's tail: the K~ slices of row er

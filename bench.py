@@ -536,6 +536,28 @@ def main():
             mh._chk(L.agp_svgp_hyper_step(hh))
         torch.cuda.synchronize()
         out["ms_per_step_with_hyper_update"] = round((time.perf_counter() - th) / nh * 1e3, 4)
+        # the reference's default training mode (SVGP(...; optimiser=ADAM(0.01)), SVGP.jl:39): its dominant kernel is the task-graph
+        # factorisation WITH the inverse (twice per iteration: the updated -2 eta2 for Sigma / mu -- with the pending natural-gradient
+        # step as its prologue --, and K_ZZ); a few more iterations with HIP events around the first of the two
+        mh._chk(L.agp_svgp_timing_enable(hh, 1))
+        for i in range(6):
+            mh._chk(L.agp_svgp_cavi_step(hh, xp, ld, yp, C.c_void_p(idx_all[3 + nh + i].data_ptr()), B, rho))
+            mh._chk(L.agp_svgp_hyper_step(hh))
+        nlh, kmsh = C.c_int64(), C.c_double()
+        mh._chk(L.agp_svgp_timing_read(hh, C.byref(nlh), C.byref(kmsh)))
+        mh._chk(L.agp_svgp_timing_enable(hh, 0))
+        if nlh.value:
+            mpad = (m + 63) // 64 * 64
+            us = kmsh.value * 1e3 / nlh.value
+            fl = 2.0 * mpad ** 3 / 3.0 + 64 * mpad ** 2 + 2.0 * ((B + 63) // 64 * 64) * mpad ** 2  # potrf + inverse + eta1 row + product
+            out["hyper_roofline"] = {
+                "kernel": f"k_chol_dag<{'float' if f32 else 'double'}, true, false, false, false, true>",
+                "what": "factorisation of the updated -2 eta2 with L^-1 (identity block rows) and the natural-gradient step as prologue; "
+                        "the iteration runs a second task graph of the same shape for K_ZZ",
+                "bound": "mfma", "avg_launch_us": round(us, 2), "launches_per_iteration": 2,
+                "algorithmic_flops_per_launch": fl, "achieved": round(fl / us / 1e6, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(fl / us / 1e6 / peak, 4),
+                "iteration": "41 kernels back to back, no host synchronisation (profiles/r03_c2_hyper_timeline.txt)"}
         del mh, cfg_h
         # streaming predict_f (means) over all N points: K_*m is never materialised
         mu_out = torch.empty(1, N, dtype=model.tdtype, device=dev)

@@ -199,17 +199,26 @@ static agp_status dag_handover_release(agp_ctx* c, int64_t used, int64_t stride,
 // m = 1024 f64 0.39 vs 0.52 ms, m = 2048 f32 0.80 vs 1.05 ms, m = 4096 f64 11.6 vs 8.3 ms -- the task graph removes launch
 // gaps and re-reads from the latency-bound chain, but its tiles stream their operands past the L2s (coherent loads), which
 // costs more than it saves once the trailing updates dominate.  AGP_CHOL_DAG=0 / 1 forces one or the other.
-// Residency bound (never overridden): the chain of a task graph waits for feeder tiles with HIGHER workgroup indices; they are
-// guaranteed to be resident only while the unretired workgroups before them -- one block column of every problem, nb * (nt + ne
-// [+ 1 with the inverse rows]) tiles, an eighth of them per XCD -- fit into an XCD's 32 workgroup slots with room to spare.
-constexpr int64_t DAG_MAX_NT = 32, DAG_MAX_COLUMN_TILES = 208;
+// Column bound: the chain of a task graph waits for feeder tiles with HIGHER workgroup indices -- tile (k+1, k) in block column k
+// and tile (k+1, k+1), the first workgroup of column k + 1.  Progress does not depend on them being resident early: the chain
+// publishes X_k before it blocks on them (k_chol_dag, "late_feed"), so every resident workgroup -- all of them belong to block
+// columns <= k of their problem -- can finish on what the chains have published, retires, and the in-order dispatch reaches the
+// feeders.  (Rounds 1-2 published X_k after that wait and therefore needed a whole block column of every problem resident,
+// nb * (nt + ne + 1) <= 208; 8 problems of 34 tiles stalled.)  What remains is a performance matter: a feeder that gets its slot only
+// when the column before it retires applies its k pending updates on the chain's critical path.  Up to 288 tiles per column of all
+// problems the launch is still well ahead of per-column launches (8 x 34: 0.62 ms against 2 x 0.40 ms for 4 + 4).
+constexpr int64_t DAG_MAX_NT = 32, DAG_MAX_COLUMN_TILES = 288;
 static bool chol_use_dag(const agp_ctx* c, int64_t nt, int64_t ne = 0, int64_t nb = 1) {
   static const int v = []() {
     const char* e = getenv("AGP_CHOL_DAG");
     return e ? (e[0] == '0' ? 0 : 1) : -1;
   }();
   if (c->dag_off) return false;  // a lost dependency was seen on this context (two processes sharing the device): stay safe
-  if (nb * (nt + ne + 1) > DAG_MAX_COLUMN_TILES) return false;
+  static const int64_t col_tiles = []() {
+    const char* e = getenv("AGP_DAG_MAX_COLUMN_TILES");
+    return e ? (int64_t)atoll(e) : DAG_MAX_COLUMN_TILES;
+  }();
+  if (nb * (nt + ne + 1) > col_tiles) return false;
   return v < 0 ? nt <= DAG_MAX_NT : v == 1;
 }
 
@@ -686,8 +695,8 @@ static agp_status dag_lost_dependency(agp_ctx* c, int32_t* info_dev, bool* lost)
 }
 
 // nb <= DAG_MAX_NB independent problems of identical shape as ONE interleaved task-graph launch (see k_chol_dag): their chains
-// run side by side on nb CUs.  The bound keeps every chain's next feeder tile among the workgroups an XCD can hold.
-constexpr int DAG_MAX_NB = 6;
+// run side by side on nb CUs (workgroup index = tile * nb + problem: with 8 problems each one lives on its own XCD).
+constexpr int DAG_MAX_NB = 8;
 template <typename T>
 static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, int64_t ld, int64_t n, int64_t ldx, int64_t lde,
                                   int64_t ne, int32_t* info_dev, int64_t nvalid, const SafeSrc<T>* safe = nullptr) {
@@ -937,6 +946,7 @@ struct SvgpBase {
   virtual agp_status get_kernel(int l, double* var, double* scales) = 0;
   virtual agp_status lsm_gamma() = 0;
   virtual agp_status lsm_alpha() = 0;
+  virtual agp_status lsm_local_all() = 0;  // both rounds and the final theta, r, w of a handle holding every latent
   virtual agp_status lsm_gsum_ptr(void** p, int64_t* n) = 0;
   virtual agp_status step_stats(bool fused) = 0;
   virtual agp_status stats_ptr(void** p, int64_t* n) = 0;
@@ -1846,6 +1856,7 @@ struct Svgp : SvgpBase {
                         bool fresh) override {
     AGPCHK(check_batch(B));
     if (!x || !y || ldx < D) return AGP_ERR_INVALID;
+    lsm_finished = false;
     dag_tick(ctx);
     refresh_lazy = !fresh;  // a refresh issued from inside the training loop (the hyper step moved the kernel) does not synchronise
     const agp_status rks = refresh_K();
@@ -1857,7 +1868,11 @@ struct Svgp : SvgpBase {
     const bool prefetched = pf_valid && !fresh && x == pf_x && idx == pf_idx && B == pf_B && ldx == pf_ldx;
     // how many problems one task-graph launch may take (0: none fits, plain launches)
     int dag_nb = 0;
-    for (int q = DAG_MAX_NB; q >= 1 && !dag_nb; --q)
+    static const int max_nb = []() {
+      const char* e = getenv("AGP_DAG_MAX_NB");
+      return e ? std::max(1, std::min(atoi(e), (int)CHOL_MAXB)) : DAG_MAX_NB;
+    }();
+    for (int q = max_nb; q >= 1 && !dag_nb; --q)
       if (chol_use_dag(ctx, mp / TILE, Bq / TILE + 1, q)) dag_nb = q;
     // single latent on the task graph: the launch itself tells the look-ahead stream that the step
     // before has released its kappa buffers (DagSync) -- no event record on this stream
@@ -2697,10 +2712,15 @@ struct Svgp : SvgpBase {
       if (g.K_stale) return AGP_OK;  // nothing sensible to prefetch against
     if (!pf_stream) {
       {
-        // lowest priority: the look-ahead GEMM must not take CUs from the latency-bound factorisation chain
+        // one latent: lowest priority -- the look-ahead GEMM must not take CUs from the latency-bound factorisation chain (C2 0.309
+        // -> 0.336 ms with the highest).  Several latents: highest -- the batched task graph holds every CU with mostly waiting
+        // workgroups for 0.6 ms and nl look-ahead pairs have to get through next to it; a starved look-ahead is what the main stream
+        // then waits for (C4, 8 latents: 1.34 -> 1.21 ms).  AGP_PF_PRIORITY=l|n|h overrides.
         int lo = 0, hi = 0;
         HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHK(ctx, hipStreamCreateWithPriority(&pf_stream, hipStreamNonBlocking, lo));
+        int pr = nl > 1 ? hi : lo;
+        if (const char* e = getenv("AGP_PF_PRIORITY")) pr = e[0] == 'h' ? hi : e[0] == 'n' ? (lo + hi) / 2 : lo;
+        HIPCHK(ctx, hipStreamCreateWithPriority(&pf_stream, hipStreamNonBlocking, pr));
       }
       HIPCHK(ctx, hipEventCreateWithFlags(&pf_done, hipEventDisableTiming));
       for (auto& e : step_done) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2798,8 +2818,34 @@ struct Svgp : SvgpBase {
     *n = B_last;
     return AGP_OK;
   }
+  bool lsm_finished = false;  // k_lsm_fused has written theta, r, w of this step already
+  agp_status lsm_local_all() override {
+    if (lp.kind != AGP_LIK_LOGISTICSOFTMAX) return AGP_OK;
+    static const bool fuse = []() {
+      const char* e = getenv("AGP_LSM_FUSED");
+      return !(e && e[0] == '0');
+    }();
+    if (!fuse || nl > LSM_FUSED_MAXL) {
+      for (int it = 0; it < 2; ++it) {  // logisticsoftmax.jl:65
+        AGPCHK(lsm_gamma());
+        AGPCHK(lsm_alpha());
+      }
+      return AGP_OK;
+    }
+    // 64 threads per workgroup: a 1024-point minibatch spreads over 16 CUs instead of 4 (the kernel is latency, not bandwidth)
+    hipLaunchKernelGGL((k_lsm_fused<T>), dim3((unsigned)((B_last + 63) / 64)), dim3(64), 0, st(), B_last, nl, Bp,
+                       desc.latent_offset, (T)rho_last, (const int32_t*)y_last, idx_last, (const T*)muf, (const T*)cbuf, alpha,
+                       (const T*)beta, gamma, gsum, theta, rbuf, wbuf, (int)desc.lik.n_class, flags_dev);
+    LAUNCHCHK(ctx);
+    lsm_finished = true;
+    return AGP_OK;
+  }
   agp_status lsm_finish() {
     if (lp.kind != AGP_LIK_LOGISTICSOFTMAX) return AGP_OK;
+    if (lsm_finished) {
+      lsm_finished = false;
+      return AGP_OK;
+    }
     hipLaunchKernelGGL((k_lsm_finish<T>), grid1(B_last), dim3(256), 0, st(), B_last, nl, Bp, desc.latent_offset,
                        (T)rho_last, (const int32_t*)y_last, idx_last, (const T*)cbuf, (const T*)gamma, theta, rbuf,
                        wbuf, (int)desc.lik.n_class, flags_dev);
@@ -3703,12 +3749,7 @@ struct Svgp : SvgpBase {
       AGPCHK(step_stats(true));  // each latent is whole on its rank: the fused natural-gradient step applies
       return step_global(true);
     }
-    if (lsm) {
-      for (int it = 0; it < 2; ++it) {  // all latents are local: the fixed point is per point, nothing to exchange
-        AGPCHK(lsm_gamma());
-        AGPCHK(lsm_alpha());
-      }
-    }
+    if (lsm) AGPCHK(lsm_local_all());  // all latents are local: the fixed point is per point, nothing to exchange
     if (!multi) {
       AGPCHK(step_stats(true));
       return step_global(true);
@@ -4448,12 +4489,7 @@ agp_status agp_svgp_cavi_step(agp_svgp* h, const void* x, int64_t ldx, const voi
   const agp_status sl_ = s->step_local(x, ldx, y, idx, B, rho, false);
   s->in_cavi_step = false;
   AGPCHK(sl_);
-  if (s->desc.lik.kind == AGP_LIK_LOGISTICSOFTMAX) {
-    for (int it = 0; it < 2; ++it) {  // logisticsoftmax.jl:65
-      AGPCHK(s->lsm_gamma());
-      AGPCHK(s->lsm_alpha());
-    }
-  }
+  AGPCHK(s->lsm_local_all());
   s->n_steps += 1;
   return s->step_finish();
 }

@@ -1591,8 +1591,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   const bool store_l = STEP ? false : (opts & 2) != 0;
   // nb > 1: nb independent problems of the same shape (the latents of a small multi-class model) in ONE launch, their
   // workgroups interleaved (linear index = tile * nb + problem) so that the chains of all problems start at once and the
-  // per-XCD dispatch order stays a topological order of every graph.  Each problem has its own flags (fstride apart).  Safe
-  // while the unretired workgroups below a chain's next feeder fit into an XCD's share of the slots: nb <= 6.
+  // per-XCD dispatch order stays a topological order of every graph.  Each problem has its own flags (fstride apart).  The
+  // chains publish X_k before they block on a feeder of a later index (late_feed below), so no residency bound is needed.
   // (BATCH is a template parameter so that the single-problem instantiation keeps constant kernel-argument offsets)
   const int prob = BATCH ? (int)(blockIdx.x % (unsigned)nb) : 0;
   const int64_t bidx = BATCH ? (int64_t)(blockIdx.x / (unsigned)nb) : (int64_t)blockIdx.x;
@@ -1864,7 +1864,14 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
         DAG_TRC(k, 3);
         return;
       }
-      if (!pf_ok || pf_bad) {  // the feeders were not done (or not yet visible) when the side job looked: fetch now
+      const bool late_feed = !pf_ok || pf_bad;
+      if (late_feed) {  // the feeders were not done (or not yet visible) when the side job looked: fetch now
+        // X_k is published BEFORE this wait: the second feeder, tile (k+1, k+1), is the first workgroup of block column k + 1, and
+        // it may not have a slot yet while all of column k's workgroups sit waiting for X_k (a launch whose block column does not
+        // fit into the resident window: 8 problems of 34 tiles each).  With it, every resident workgroup can finish on what the
+        // chains have already published, so the dispatch order alone guarantees progress -- no residency bound is needed.
+        dag_signal(xready + k * DAG_FS, epoch);
+        DAG_TRC(k, 3);
         if (!dag_wait(pf.f1, pf.f2, epoch, abortf, info, &wait_ok)) return;
         load_tiles_lds_hv2<T>(HP + 2 * (k + 1) * SLOT, bufC, HP + (2 * (k + 1) + 1) * SLOT, bufD);
         __syncthreads();
@@ -1886,8 +1893,12 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
         ob = mma_tile16<T>(bufC + 16 * ri * LDP, bufB + 16 * cB * LDP, 16 * (cB + 1), ob, false, lane);
         // X_k went out before the product: its stores are acknowledged by now, so publishing it here costs the chain one
         // barrier instead of a store round trip (the column's other tiles see X_k ~2 us later; they have ~10 us of slack)
-        dag_signal(xready + k * DAG_FS, epoch);
-        DAG_TRC(k, 3);
+        if (!late_feed) {
+          dag_signal(xready + k * DAG_FS, epoch);
+          DAG_TRC(k, 3);
+        } else {
+          __syncthreads();  // (every wave has read T before it is overwritten in place)
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * ri + Mfma<T>::row(lane, r);

@@ -1,8 +1,7 @@
 export TMPDIR=/tmp
 R=$PWD
-T=r03
-c=c5; st=20; wu=5
-python bench.py --config $c --steps $st --warmup $wu --cpu-elbo-seconds 0 > gpurun_out/${T}_${c}_bench_line.json 2> gpurun_out/${T}_${c}_line.err
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${T}_$c -o p -- python $R/bench.py --config $c --steps $st --warmup $wu --no-cpu-baseline --no-elbo-tol --no-extras > /dev/null 2>&1)
-cp gpurun_out/prof_${T}_$c/p_kernel_stats.csv gpurun_out/${T}_${c}_kernel_stats.csv
-python tools/summarize_prof.py gpurun_out/${T}_${c}_kernel_stats.csv 8; tail -c 900 gpurun_out/${T}_${c}_bench_line.json; tail -3 gpurun_out/${T}_${c}_line.err
+B="python $R/bench.py --config c4 --steps 60 --warmup 10 --no-cpu-baseline --no-elbo-tol --no-extras"
+for f in 1 0; do echo "== c4 lsm_fused=$f"; AGP_LSM_FUSED=$f timeout 300 $B 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['avg_launch_us'], d['roofline']['launches_per_step'])"; done
+timeout 900 python tools/soak_multilatent.py 8 3000 2 2>&1 | tail -4
+timeout 900 python tools/soak_multilatent.py 5 2000 2 2>&1 | tail -3
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -5

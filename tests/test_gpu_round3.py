@@ -114,6 +114,39 @@ def test_c3_shape_fp64_steps_match_oracle(mods):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
+# C4 path
+def test_c4_path_eight_latents_in_one_launch_match_oracle(mods):
+    """C4's kernel path at its own size: 8-class LogisticSoftMax = 8 latent GPs, m = B = 1024, fp64 -- all 8 augmented Cholesky
+    factorisations in ONE interleaved task-graph launch (`k_chol_dag<double, true, true, ...>`, 8 x 34 tiles per block column: more
+    than the 256 workgroup slots, the case that needs the chain to publish X_k before it blocks on a late feeder), the fused
+    (gamma, alpha) fixed point (`k_lsm_fused`, logisticsoftmax.jl:55-79) and the batched eta step.  Every latent <= 1e-8."""
+    AGP, R, capi, torch = mods
+    rng = np.random.default_rng(404)
+    N, D, m, B, K, iters = 4096, 32, 1024, 1024, 8, 3
+    X = rng.random((N, D))
+    ell = np.sqrt(D) / 4
+    f = _rff_targets(rng, X, ell)
+    y = 1 + np.digitize(f, np.quantile(f, np.linspace(0, 1, K + 1)[1:-1]))
+    Z = X[rng.permutation(N)[:m]].copy()
+    idx = [rng.choice(N, B, replace=False) for _ in range(iters)]
+    ma = AGP.SVGP(AGP.with_lengthscale(AGP.SqExponentialKernel(), ell), AGP.LogisticSoftMaxLikelihood(K), AGP.AnalyticSVI(B), Z,
+                  optimiser=False)
+    mr = R.SVGP(R.Kernel("sqexponential", 1.0 / ell, 1.0), R.LogisticSoftMaxLikelihood(K), Z, stochastic=True, batchsize=B)
+    ea, er = [], []
+    AGP.train_(ma, X, y, iters, idx_stream=idx, callback=lambda mdl, s, i: ea.append(AGP.objective(mdl, s)))
+    mr.train(X, y, iters, idx_stream=idx, callback=lambda M, it, xb, yb: er.append(M.elbo(yb)))
+    for l in range(K):
+        g = mr.latents[l]
+        mu, Sig, e1, e2 = ma.get_state(l)
+        assert _rel(e1, g.eta1) < 1e-9 and _rel(e2, g.eta2) < 1e-9, l
+        assert _rel(mu, g.mu) < 1e-8 and _rel(np.diag(Sig), np.diag(g.Sigma)) < 1e-8, l
+    assert np.allclose(ea, er, rtol=1e-8)
+    Xt = rng.random((200, D))
+    pa, pr = AGP.proba_y(ma, Xt), mr.proba_y(Xt)
+    assert np.max(np.abs(np.stack([pa[k] for k in range(1, K + 1)], axis=1) - pr)) < 1e-8
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
 # C5 path
 def _c5_inputs():
     rng = np.random.default_rng(505)

@@ -630,3 +630,45 @@ def test_pending_step_is_invisible_through_the_abi(mods, likname, T):
     g = mr.latents[0]
     mu, Sig, e1, e2 = ma.get_state(0)
     assert _rel(e1, g.eta1) < tol and _rel(e2, g.eta2) < tol and _rel(mu, g.mu) < 10 * tol
+
+
+def test_ragged_and_changing_minibatch_sizes_with_a_pending_step(mods):
+    """A host may hand `agp_svgp_cavi_step` any B <= the handle's capacity, step after step: not a multiple of 64, below one tile
+    (no prologue: the pending step is flushed), a single point, back to full size -- each with the next minibatch prefetched.  The
+    pending natural-gradient step belongs to the minibatch that produced it (its kappa rows, r, w and rho g-vectors), whatever the
+    next launch's size is.  Against the oracle (rho fixed at N / batchsize like training.jl:51-53 keeps it), <= 1e-8."""
+    AGP, R, capi, torch = mods
+    rng = np.random.default_rng(77)
+    N, D, m, Bcap = 3000, 4, 200, 256
+    Bs = [256, 200, 256, 130, 64, 63, 256, 1, 256, 192, 255, 256]
+    X = rng.random((N, D))
+    f = np.sin(4 * X[:, 0]) + X[:, 1] - 1.0
+    y = np.sign(f + 0.3 * rng.standard_normal(N))
+    y[y == 0] = 1.0
+    Z = X[rng.permutation(N)[:m]].copy()
+    idx = [rng.choice(N, b, replace=False) for b in Bs]
+    ma = AGP.SVGP(1.5 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0)), AGP.LogisticLikelihood(), AGP.AnalyticSVI(Bcap), Z,
+                  optimiser=False)
+    mr = R.SVGP(R.Kernel("sqexponential", 2.0, 1.5), R.LogisticLikelihood(), Z, stochastic=True, batchsize=Bcap)
+    # one ordinary iteration creates the handle (capacity Bcap), uploads X / y and initialises the state on both sides
+    first = rng.choice(N, Bcap, replace=False)
+    AGP.train_(ma, X, y, 1, idx_stream=[first])
+    mr.train(X, y, 1, idx_stream=[first])
+    L, h = capi.lib(), ma._h
+    Xd, yd, _ = ma._data
+    rho = N / Bcap
+    dev = [torch.as_tensor(np.asarray(i, dtype=np.int64), device="cuda") for i in idx]
+    xp, yp = C.c_void_p(Xd.data_ptr()), C.c_void_p(yd.data_ptr())
+    for it, b in enumerate(Bs):
+        assert L.agp_svgp_cavi_step(h, xp, Xd.stride(0), yp, C.c_void_p(dev[it].data_ptr()), b, rho) == 0
+        if it + 1 < len(Bs):
+            assert L.agp_svgp_prefetch(h, xp, Xd.stride(0), C.c_void_p(dev[it + 1].data_ptr()), Bs[it + 1]) == 0
+    assert L.agp_svgp_check_status(h) == 0
+    n, npro = C.c_int64(), C.c_int64()
+    assert L.agp_svgp_step_counters(h, C.byref(n), C.byref(npro)) == 0
+    assert npro.value >= 6  # the steps that follow a minibatch of at least one tile took it as their prologue
+    mr.train(X, y, len(Bs), idx_stream=idx, fresh_state=False)
+    g = mr.latents[0]
+    mu, Sig, e1, e2 = ma.get_state(0)
+    assert _rel(e1, g.eta1) < 1e-8 and _rel(e2, g.eta2) < 1e-8
+    assert _rel(mu, g.mu) < 1e-8 and _rel(np.diag(Sig), np.diag(g.Sigma)) < 1e-8

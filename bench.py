@@ -499,7 +499,10 @@ def main():
                 keys = [k for k in pm["kernels"] if k.startswith(roofline["kernel"][:-1])]
                 if not keys:
                     continue
-                key = ([k for k in keys if k.endswith(", true>")] or keys)[0]
+                def _is_step(k):  # template arguments <T, FUSED, BATCH, TRACE, STEP, PRO>
+                    ta = k[k.index("<") + 1:k.rindex(">")].split(", ")
+                    return len(ta) >= 5 and ta[4] == "true"
+                key = ([k for k in keys if _is_step(k)] or keys)[0]
                 roofline["traffic"] = pm["kernels"][key]["hbm_bytes_per_launch_corrected"]
                 roofline["traffic_source"] = f"profiles/{pf} (rocprofv3 --pmc, separate passes, same command)"
                 break
@@ -549,15 +552,20 @@ def main():
         if nlh.value:
             mpad = (m + 63) // 64 * 64
             us = kmsh.value * 1e3 / nlh.value
-            fl = 2.0 * mpad ** 3 / 3.0 + 64 * mpad ** 2 + 2.0 * ((B + 63) // 64 * 64) * mpad ** 2  # potrf + inverse + eta1 row + product
+            pro_h = mpad // 64 <= 16  # the pending natural-gradient step rides on this launch up to 16 block columns (pro_allowed)
+            fl = 2.0 * mpad ** 3 / 3.0 + 64 * mpad ** 2  # potrf + inverse (identity block rows) + the eta1 row
+            if pro_h:
+                fl += 2.0 * ((B + 63) // 64 * 64) * mpad ** 2  # + the product kappa' diag(w) kappa, credited as in SURVEY 8d
             out["hyper_roofline"] = {
-                "kernel": f"k_chol_dag<{'float' if f32 else 'double'}, true, false, false, false, true>",
-                "what": "factorisation of the updated -2 eta2 with L^-1 (identity block rows) and the natural-gradient step as prologue; "
-                        "the iteration runs a second task graph of the same shape for K_ZZ",
+                "kernel": f"k_chol_dag<{'float' if f32 else 'double'}, true, false, false, false, {'true' if pro_h else 'false'}>",
+                "what": "factorisation of the updated -2 eta2 with L^-1 (identity block rows)"
+                        + (" and the natural-gradient step as prologue" if pro_h else "")
+                        + "; the iteration runs a second task graph of the same shape (without prologue) for K_ZZ",
                 "bound": "mfma", "avg_launch_us": round(us, 2), "launches_per_iteration": 2,
                 "algorithmic_flops_per_launch": fl, "achieved": round(fl / us / 1e6, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(fl / us / 1e6 / peak, 4),
-                "iteration": "41 kernels back to back, no host synchronisation (profiles/r03_c2_hyper_timeline.txt)"}
+                "iteration": "no host synchronisation inside the iteration"
+                             + (" (33 kernels back to back, profiles/r03_c2_hyper_timeline.txt)" if a.config == "c2" else "")}
         del mh, cfg_h
         # streaming predict_f (means) over all N points: K_*m is never materialised
         mu_out = torch.empty(1, N, dtype=model.tdtype, device=dev)
@@ -760,7 +768,9 @@ def cpu_baseline(a, cfg, ell, Z, X, yh, idx_np, out):
     # evaluation batch, same rule, wall-clock including the ELBO evaluations (budget --cpu-elbo-seconds; 0 skips it)
     ctx = out.get("_elbo_ctx")
     budget = float(getattr(a, "cpu_elbo_seconds", 0.0))
-    if ctx is not None and sm and lik in ("logistic", "studentt") and budget > 0 and sm / rate < budget:
+    want_r = bool(out.get("iters_to_elbo_tol"))  # the contracted rule was met on the device: run the oracle through it as well
+    need_it = max(sm or 0, out.get("iters_to_elbo_tol") or 0)
+    if ctx is not None and sm and lik in ("logistic", "studentt") and budget > 0 and need_it / rate < budget:
         Xall = X.cpu().numpy().astype(np.float64)
         yall = np.asarray(yh, dtype=np.float64)
         with threadpool_limits(limits=best_thr):
@@ -770,7 +780,7 @@ def cpu_baseline(a, cfg, ell, Z, X, yh, idx_np, out):
             Xe, ye = Xall[ev], yall_t[ev]
             hist, it, hit_s, hit_r, consec = [], 0, None, None, 0
             ts = time.perf_counter()
-            while (time.perf_counter() - ts) < budget and hit_s is None:
+            while (time.perf_counter() - ts) < budget and (hit_s is None or (want_r and hit_r is None)):
                 for _ in range(10):
                     ib = ctx["chunk"][it % len(ctx["chunk"])]
                     r.update_parameters(Xall[ib], yall_t[ib])
@@ -781,7 +791,7 @@ def cpu_baseline(a, cfg, ell, Z, X, yh, idx_np, out):
                     consec = consec + 1 if abs(hist[-1] - hist[-2]) / abs(hist[-1]) < 1e-4 else 0
                     if hit_r is None and consec >= 3:
                         hit_r = (now, it)
-                if len(hist) >= 20:
+                if len(hist) >= 20 and hit_s is None:
                     m1, m0 = sum(hist[-10:]) / 10.0, sum(hist[-20:-10]) / 10.0
                     if abs(m1 - m0) / abs(m1) < 1e-3:
                         hit_s = (now, it, hist[-1])
@@ -790,7 +800,8 @@ def cpu_baseline(a, cfg, ell, Z, X, yh, idx_np, out):
             "elbo": hit_s[2] if hit_s else None,
             "note": "the oracle RUN through the same rule on the same minibatch stream and evaluation batch (not extrapolated)"}
         if hit_r:
-            res["time_to_elbo_tol_measured"] = {"seconds": round(hit_r[0], 1), "iters": hit_r[1]}
+            res["time_to_elbo_tol_measured"] = {"seconds": round(hit_r[0], 1), "iters": hit_r[1],
+                                                "note": "the contracted rule (SURVEY 8d), oracle RUN on the host cores"}
     return res
 
 

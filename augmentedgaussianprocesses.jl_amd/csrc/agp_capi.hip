@@ -457,6 +457,7 @@ struct ProHost {
   T* eta1 = nullptr;
   const T* kinv_mu0 = nullptr;
   T lr = T(0);
+  const T *packed = nullptr, *tred = nullptr;  // batch-parallel step: reduced statistics instead of (kap, w, r)  (ProArgs)
 };
 // k-slices per block column of the prologue's product: a tile of block column c has to be there when the chain reaches the
 // column (about tau * c after the start, tau = 17.8 us f64 / 14 us f32 per block column), a 64-row chunk of the product costs a
@@ -523,7 +524,10 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     ProArgs<T> pa{};
     int64_t nhelp = 0;
     if (pro) {
-      pro_ks_table(nt, pro->Kdim / TILE, sizeof(T) == 8, pa.ks);
+      if (pro->packed)
+        for (int64_t cc = 0; cc < nt; ++cc) pa.ks[cc] = 1;  // nothing to compute: no helpers
+      else
+        pro_ks_table(nt, pro->Kdim / TILE, sizeof(T) == 8, pa.ks);
       for (int64_t cc = 0; cc < nt; ++cc) nhelp += (nt - cc) * (pa.ks[cc] - 1);
     }
     const int64_t nf = ((nt + ne + nx) * nt + 3 * nt + 1 + nhelp) * DAG_FS;
@@ -580,6 +584,8 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       pa.eta1 = pro->eta1;
       pa.kinv_mu0 = pro->kinv_mu0;
       pa.lr = pro->lr;
+      pa.packed = pro->packed;
+      pa.tred = pro->tred;
       pa.HS = H + (3 * nt + (nt + ne + nx) * nt) * TILE * TILE;
       pa.sflags = c->dag_flags + ((nt + ne + nx) * nt + 3 * nt + 1) * DAG_FS;
       const int other = hs ^ 1;
@@ -1211,6 +1217,13 @@ struct Svgp : SvgpBase {
     const T *Kinv = nullptr, *kinv_mu0 = nullptr;
     const T *r = nullptr, *w = nullptr;  // rho grad_E_mu / rho grad_E_Sigma of that minibatch (the r / w pair current at the time)
   } pend;
+  // ... and the batch-parallel form of it (agp_svgp_cavi_step_multi, AGP_SHARD_BATCH over several ranks): the statistics have been
+  // all-reduced into `stats` = [t | packed lower tiles]; the eta step from them rides on the next launch as well
+  struct PendingPacked {
+    bool on = false;
+    T lr = T(0);
+    const T *Kinv = nullptr, *kinv_mu0 = nullptr;
+  } pendp;
   // Second (r, w) pair: a task-graph launch with the row-statistics EPILOGUE (EpiArgs) writes this step's r, w while late workgroups
   // of its own prologue may still read the previous step's -- the two pairs alternate.
   T *rbuf2 = nullptr, *wbuf2 = nullptr;
@@ -1267,11 +1280,18 @@ struct Svgp : SvgpBase {
   }
   agp_status flush() override {
     AGPCHK(run_deferred_safe());
-    if (!pend.on) return AGP_OK;
+    if (!pend.on && !pendp.on) return AGP_OK;
     Latent& g = lat[0];
-    pend.on = false;
-    AGPCHK((syrk_tn<T, SY_ETA2>(ctx, pend.kap, mp, mp, pend.Bq, pend.w, 0, g.La, mp, g.eta2, pend.Kinv, mp, pend.lr, pend.r,
-                                g.eta1, pend.kinv_mu0)));
+    if (pend.on) {
+      pend.on = false;
+      AGPCHK((syrk_tn<T, SY_ETA2>(ctx, pend.kap, mp, mp, pend.Bq, pend.w, 0, g.La, mp, g.eta2, pend.Kinv, mp, pend.lr, pend.r,
+                                  g.eta1, pend.kinv_mu0)));
+    } else {
+      pendp.on = false;
+      const int64_t ntri = (mp / TILE) * (mp / TILE + 1) / 2;
+      hipLaunchKernelGGL((k_eta2_from_packed<T>), dim3((unsigned)(4 * ntri + (mp + 255) / 256)), dim3(256), 0, st(), stats + mp, mp,
+                         g.eta2, pendp.Kinv, g.La, pendp.lr, ntri, (const T*)stats, pendp.kinv_mu0, g.eta1, mp);
+    }
     LAUNCHCHK(ctx);
     g.la_state = 0;  // the epilogue left La = -2 eta2
     g.xa_valid = false;
@@ -1892,9 +1912,9 @@ struct Svgp : SvgpBase {
     // a pending natural-gradient step rides on this step's task-graph launch when this is the steady state of a training loop
     // (kappa of the minibatch already there -- look-ahead or kept --, one latent on the task graph); otherwise it is taken now
     bool use_pro = false;
-    if (pend.on) {
+    if (pend.on || pendp.on) {
       use_pro = !fresh && nl == 1 && dag_nb > 0 && (prefetched || (reuse && lat[0].kappa_valid)) && pro_allowed() &&
-                mp / TILE <= 32 && dag_fused_on() && !dag_trace_on() && pend.Bq >= TILE;
+                mp / TILE <= 32 && dag_fused_on() && !dag_trace_on() && (pendp.on || pend.Bq >= TILE);
       if (!use_pro) AGPCHK(flush());
     }
     // the row statistics of this step as the epilogue of its task-graph launch, the launch's fallback deferred to the next step
@@ -2020,18 +2040,28 @@ struct Svgp : SvgpBase {
           ProHost<T> ph{};
           if (use_pro) {
             Latent& g0 = lat[0];
-            ph.kap = pend.kap;
             ph.ldk = mp;
-            ph.Kdim = pend.Bq;
-            ph.w = pend.w;
-            ph.r = pend.r;
             ph.eta2 = g0.eta2;
-            ph.Kinv = pend.Kinv;
             ph.ldm = mp;
             ph.eta1 = g0.eta1;
-            ph.kinv_mu0 = pend.kinv_mu0;
-            ph.lr = pend.lr;
-            pend.on = false;
+            if (pendp.on) {  // reduced statistics of a batch-parallel step
+              ph.packed = stats + mp;
+              ph.tred = stats;
+              ph.Kdim = 0;
+              ph.Kinv = pendp.Kinv;
+              ph.kinv_mu0 = pendp.kinv_mu0;
+              ph.lr = pendp.lr;
+              pendp.on = false;
+            } else {
+              ph.kap = pend.kap;
+              ph.Kdim = pend.Bq;
+              ph.w = pend.w;
+              ph.r = pend.r;
+              ph.Kinv = pend.Kinv;
+              ph.kinv_mu0 = pend.kinv_mu0;
+              ph.lr = pend.lr;
+              pend.on = false;
+            }
             n_prologue += 1;
           }
           EpiArgs<T> ea{};
@@ -2960,6 +2990,7 @@ struct Svgp : SvgpBase {
     // a pending natural-gradient step (only the hyper step's wrapper leaves one: every other entry point has flushed) rides on this
     // launch as its prologue -- the hyper-parameter iteration's "eta step, then factor the new -2 eta2 with its inverse" in ONE launch
     AGPCHK(run_deferred_safe());
+    if (pendp.on) AGPCHK(flush());
     ProHost<T> ph{};
     bool use_pro = false;
     if (pend.on) {
@@ -3726,9 +3757,22 @@ struct Svgp : SvgpBase {
     // batch-sharded Poisson / Heteroscedastic: lambda is re-estimated from sums over the WHOLE minibatch (poisson.jl:78,
     // heteroscedastic.jl:94): the local update stops after its partial sums, three doubles are all-reduced, then it finishes
     lam_deferred = multi && lam_lik;
+    // batch-parallel over several ranks, one latent: the step rides on the task-graph launches like the one-GPU step does (round 3)
+    // -- row statistics as the epilogue of this launch, the eta step from the REDUCED statistics as the prologue of the next one
+    // (PendingPacked) -- so that between two factorisations only the packed product, the all-reduce and one 5 us kernel remain.
+    // AGP_SPLIT_MERGED=0 keeps the separate kernels (k_safe_rowstats, k_eta2_from_packed).
+    static const bool split_merged = []() {
+      const char* e = getenv("AGP_SPLIT_MERGED");
+      return !(e && e[0] == '0');
+    }();
+    const bool merge = split_merged && multi && mode == AGP_SHARD_BATCH && !lam_lik && nl == 1 && pro_allowed() &&
+                       chol_use_dag(ctx, mp / TILE, rup64(B) / TILE + 1, 1) && dag_fused_on() && !dag_trace_on();
+    in_cavi_step = merge;
     const agp_status sl = step_local(x, ldx, y, idx, B, rho, false);
+    in_cavi_step = false;
     lam_deferred = false;
     AGPCHK(sl);
+    AGPCHK(run_deferred_safe());  // (the launch's fallback: the packed product below needs this step's r, w now)
     if (multi && lam_lik) {
       AGPCHK(comm_sum_typed(cm, scal_dev + 60, 3, AGP_F64, force_split));
       AGPCHK(lambda_finish_reduced());
@@ -3756,6 +3800,19 @@ struct Svgp : SvgpBase {
     }
     AGPCHK(step_stats(false));
     AGPCHK(comm_sum(cm, stats, (int64_t)nl * stats_stride()));
+    if (merge) {
+      Latent& g = lat[0];
+      pendp.on = true;
+      pendp.lr = (T)cur_lr();
+      pendp.Kinv = kinv_step(g);
+      pendp.kinv_mu0 = kinv_mu0_step(g);
+      g.la_state = 1;  // La does not hold -2 eta2: whoever wants it rebuilds it from eta2 (after flush())
+      g.xa_valid = false;
+      g.post_valid = false;
+      g.pred_valid = g.predvar_valid = false;
+      n_opt += 1;
+      return AGP_OK;
+    }
     return step_global(false);
   }
 
@@ -4868,7 +4925,8 @@ agp_status agp_comm_stats(agp_comm* cm, int64_t* n_calls_host, int64_t* bytes_ho
 
 agp_status agp_svgp_cavi_step_multi(agp_svgp* h, agp_comm* comm, int32_t mode, const void* x, int64_t ldx, const void* y,
                                     const int64_t* idx, int64_t B, double rho) {
-  HCHKF(h);
+  HCHK(h);  // (no flush: like agp_svgp_cavi_step, the step takes a pending natural-gradient step itself -- as its prologue)
+  h->impl->n_steps += 1;
   return h->impl->cavi_step_multi(comm, mode, x, ldx, y, idx, B, rho);
 }
 agp_status agp_svgp_elbo_multi(agp_svgp* h, agp_comm* comm, int32_t mode, double* elbo_host) {

@@ -1531,6 +1531,10 @@ struct ProArgs {
   T* fill = nullptr;         // hand-over set used by the PREVIOUS launch: refilled with the sentinel by the trailing workgroups
   int64_t fill_n = 0;
   int32_t nfill = 0;
+  // batch-parallel step: the statistics arrive REDUCED over the ranks (all-reduced packed lower tiles, SY_PACK layout, and the
+  // vector t = kappa' r); the prologue then only takes the eta step from them (Kdim = 0: no product, no helpers)
+  const T* packed = nullptr;
+  const T* tred = nullptr;
   unsigned char ks[32] = {};  // k-slices per block column (1: the tile workgroup forms the whole product itself)
 };
 
@@ -1700,6 +1704,10 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
     PRO_TS(tsb);
     acc.zero();
     pro_slice<T>(pro.kap, pro.ldk, pro.w, R * TILE, c0, 0, nq / ksc, sm, acc);
+    if (pro.packed) {  // the reduced statistic of this tile (what k_eta2_from_packed reads)
+      const T* __restrict__ tp = pro.packed + (R * (R + 1) / 2 + c) * (TILE * TILE);
+      acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = tp[r * TILE + cc]; });
+    }
     PRO_TS(tsb + 1);
     // eta2 and K^-1 of the tile: in flight while the helpers' tiles are fetched
     Acc8<T> e2v, kiv;
@@ -1798,6 +1806,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
       T t = T(0);
 #pragma unroll
       for (int q = 0; q < CHOL_THREADS / 64; ++q) t += sc[q * TILE + col];
+      if (pro.tred) t = pro.tred[c0 + col];
       T e = pro.eta1[c0 + col];
       e += pro.lr * (t + (pro.kinv_mu0 ? pro.kinv_mu0[c0 + col] : T(0)) - e);
       pro.eta1[c0 + col] = e;

@@ -491,6 +491,25 @@ class HipEngine:
                                              float(rho))
         self._mchk(st, comm)
 
+    def prefetch(self, idx):
+        """agp_svgp_prefetch: announce the NEXT minibatch (this rank's share) so that its K_nm / kappa are formed on the look-ahead
+        stream while the current step factors.  Returns the device index tensor: hand exactly that object to the next
+        step_multi / step_local (the look-ahead is recognised by pointer identity, include/agp_hip.h)."""
+        import torch
+
+        idx_t = idx if isinstance(idx, torch.Tensor) else torch.as_tensor(np.asarray(idx, dtype=np.int64),
+                                                                          device=self.model._dev())
+        self._keep_next = idx_t
+        self.model._chk(self.L.agp_svgp_prefetch(self.h, C.c_void_p(self._X.data_ptr()), self._X.stride(0),
+                                                 C.c_void_p(idx_t.data_ptr()), idx_t.numel()))
+        return idx_t
+
+    def step_counters(self):
+        """(steps, steps whose natural-gradient part rode on the following task-graph launch)  -- agp_svgp_step_counters"""
+        n, npro = C.c_int64(), C.c_int64()
+        self.model._chk(self.L.agp_svgp_step_counters(self.h, C.byref(n), C.byref(npro)))
+        return n.value, npro.value
+
     def elbo_multi(self, mode: int, comm: Optional["Comm"] = None) -> float:
         out = C.c_double()
         self._mchk(self.L.agp_svgp_elbo_multi(self.h, comm.h if comm is not None else None, mode, C.byref(out)), comm)

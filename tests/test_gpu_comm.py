@@ -164,6 +164,50 @@ def test_batch_parallel_two_ranks_match_single_handle(built, likname):
     assert res[0][1] == res[1][1]  # identical on every rank
 
 
+def test_batch_parallel_step_rides_on_the_task_graph_launches(built):
+    """Round 3: with the next minibatch announced (agp_svgp_prefetch) and nobody looking in between, a batch-parallel step over two
+    ranks leaves its eta step PENDING on the reduced statistics; the next step's task-graph launch takes it as its prologue (no
+    k_eta2_from_packed) and does the row statistics as its epilogue.  Same trajectory as the single handle, ranks identical, and the
+    step counters say the scheduling really was in use.  4 block columns, 128 points per rank (two kappa block rows)."""
+    import agp_amd as AGP
+    from agp_amd import capi
+    from agp_amd import parallel as P
+
+    rng = np.random.default_rng(9)
+    N, D, m, B, iters = 3000, 4, 200, 256, 12
+    X = rng.random((N, D))
+    f = np.sin(4 * X[:, 0]) + X[:, 1] - 1.0
+    y = np.sign(f + 0.3 * rng.standard_normal(N))
+    y[y == 0] = 1.0
+    Z = X[rng.permutation(N)[:m]].copy()
+    idx = [rng.choice(N, B, replace=False) for _ in range(iters)]
+    kern = lambda: 1.5 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0))
+    ref = AGP.SVGP(kern(), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z, optimiser=False)
+    AGP.train_(ref, X, y, iters, idx_stream=idx)
+
+    def body(rank, group):
+        mdl = AGP.SVGP(kern(), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z, optimiser=False)
+        comm = P.Comm.from_group(mdl, group, rank, 2)
+        eng = P.HipEngine(mdl, B // 2).bind_data(X, y).set_batch_shard(rank, 2)
+        nxt = P.shard_batch(idx[0], 2, rank)
+        for it in range(iters):
+            cur = nxt
+            eng.step_multi(cur, N / B, capi.SHARD_BATCH, comm)
+            if it + 1 < iters:
+                nxt = eng.prefetch(P.shard_batch(idx[it + 1], 2, rank))
+        eng.check()
+        counters = eng.step_counters()
+        return mdl.get_state(0), counters
+
+    res = _thread_ranks(2, body)
+    r = ref.get_state(0)
+    for st, (n, npro) in res:
+        assert npro >= iters - 2, (n, npro)  # every step after the first rode on its successor's launch
+        assert _rel(st[3], r[3]) < 1e-9 and _rel(st[2], r[2]) < 1e-9 and _rel(st[0], r[0]) < 1e-8
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)  # the replicas stay bitwise together
+
+
 def test_latent_parallel_lsm_and_tied_hyper_two_ranks(built):
     """C4's sharding: 4-class LogisticSoftMax, two latents per rank, sum_k gamma_k all-reduced twice per step; then the
     tied-Z hyper step (gradient summed over latents and ranks, one all-reduce of 1 + D + m D doubles)."""

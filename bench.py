@@ -748,10 +748,22 @@ def cpu_baseline(a, cfg, ell, Z, X, yh, idx_np, out):
             if (time.perf_counter() - t_start) > a.cpu_seconds and n_cpu >= 2:
                 break
     rate = n_cpu / tcpu
+    # ... and a single-thread run next to it, a few iterations only
+    one_thr = None
+    if lik in ("logistic", "studentt"):
+        with threadpool_limits(limits=1):
+            r1 = fresh_ref()
+            one(r1, 0)
+            t1, n1 = time.perf_counter(), 0
+            while n1 < 3 and (time.perf_counter() - t1) < 10.0:
+                one(r1, 1 + n1)
+                n1 += 1
+            one_thr = round(n1 / (time.perf_counter() - t1), 3)
     res = {
         "value": round(rate, 3),
         "unit": "iter/s",
         "cores": best_thr,
+        "single_thread_value": one_thr,
         "kind": "port",
         "sample": f"{n_cpu} iterations of the same workload ({out['config']['workload']}) with the NumPy/SciPy(OpenBLAS) oracle "
                   f"(GEMM-form distances, best of {{8,16,32,64,all}} BLAS threads; host has {avail} cores), {tcpu:.1f} s of CPU "

@@ -445,7 +445,10 @@ agp_status agp_comm_stats(agp_comm* comm, int64_t* n_calls_host, int64_t* bytes_
  * same phase sequence (a handle that owns only a slice of a multi-output model's latents refuses comm == NULL).
  * Poisson / Heteroscedastic likelihoods (AGP_SHARD_BATCH only; the two heteroscedastic latents are coupled point-wise and share a
  * handle): lambda is re-estimated from sums over the WHOLE minibatch (poisson.jl:78, heteroscedastic.jl:94) -- three doubles
- * [S0, S1, B_local] are all-reduced between the local update's partial sums and its finish. */
+ * [S0, S1, B_local] are all-reduced between the local update's partial sums and its finish.
+ * Scheduling note (round 3, invisible through the ABI, like agp_svgp_cavi_step's): a single-latent AGP_SHARD_BATCH step over several
+ * ranks in a training loop (next minibatch announced with agp_svgp_prefetch) leaves its eta step PENDING on the all-reduced
+ * statistics; the next step's factorisation launch takes it as its prologue.  Every other entry point completes it first. */
 agp_status agp_svgp_cavi_step_multi(agp_svgp* h, agp_comm* comm, int32_t mode, const void* x, int64_t ldx, const void* y,
                                     const int64_t* idx, int64_t B, double rho);
 /* ELBO(model, state, y) of the last minibatch of a sharded run, identical on every rank (analyticVI.jl:255-297):

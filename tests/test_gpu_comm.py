@@ -208,6 +208,20 @@ def test_batch_parallel_step_rides_on_the_task_graph_launches(built):
         assert np.array_equal(a, b)  # the replicas stay bitwise together
 
 
+def test_batch_parallel_merged_step_survives_aborted_launches(built):
+    """The same two-rank run in a fresh process with AGP_DAG_TEST_ABORT=1 (read once per process): every task-graph launch is treated
+    as having lost a dependency, so every step goes through the in-stream fallback -- which must find eta already stepped by the
+    prologue (from the reduced statistics) and redo the rows the epilogue wrote.  Same assertions as above."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, AGP_DAG_TEST_ABORT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                        "test_batch_parallel_step_rides_on_the_task_graph_launches"], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_latent_parallel_lsm_and_tied_hyper_two_ranks(built):
     """C4's sharding: 4-class LogisticSoftMax, two latents per rank, sum_k gamma_k all-reduced twice per step; then the
     tied-Z hyper step (gradient summed over latents and ranks, one all-reduce of 1 + D + m D doubles)."""

@@ -370,8 +370,12 @@ def main():
     # with the prologue the same launch also takes the natural-gradient step of the minibatch before (kappa' diag(w) kappa + the
     # eta steps, analyticVI.jl:143-180): credited 2 B m^2 like SURVEY 8d's F_iter credits it (B m^2 executed: one triangle)
     prologue = n_pro >= steps - 1 and steps > 1
+    # batch-parallel over a communicator: the prologue only takes the eta step from the all-reduced statistics -- the product is the
+    # packed launch in front of the collective, not part of this launch
+    pro_product = prologue and comm is None
     flops_pro_credit, flops_pro_exec = 2.0 * Bq * mp ** 2, 1.0 * Bq * mp ** 2
-    if prologue:
+    flops_fact_exec = flops_fact
+    if pro_product:
         flops_fact_exec = flops_fact + flops_pro_exec
         flops_fact += flops_pro_credit
     launches_per_step = nl.value / max(-(-steps // t_every), 1)  # launches of the bracketed sequences / number of them
@@ -419,7 +423,12 @@ def main():
         "timed_steps": f"every {t_every}th step of the timed region ({-(-steps // t_every)} of {steps})" if t_every > 1 else "every step",
         "algorithmic_flops_per_launch": flops_per_launch,
     }
-    if prologue:
+    if prologue and not pro_product:
+        roofline["contents"] = ("one launch = the augmented Cholesky of -2 eta2 with the [kappa; eta1'] extension rows (m^3/3 + (B+64) m^2), "
+                                "the eta step from the all-reduced statistics of the minibatch before as its prologue and the row "
+                                "statistics as its epilogue; the product kappa' diag(w) kappa is the packed launch in front of the "
+                                "all-reduce")
+    elif prologue:
         roofline["contents"] = ("one launch = the augmented Cholesky of -2 eta2 with the [kappa; eta1'] extension rows (m^3/3 + (B+64) m^2) "
                                 "AND, as its prologue, the natural-gradient step of the minibatch before (kappa' diag(w) kappa, credited "
                                 "2 B m^2 as in SURVEY 8d; B m^2 executed) -- until round 2 a kernel of its own between two factorisations")

@@ -463,7 +463,7 @@ struct ProHost {
 // column (about tau * c after the start, tau = 17.8 us f64 / 14 us f32 per block column), a 64-row chunk of the product costs a
 // workgroup about tc = 2.7 / 1.6 us; columns 0 and 1 feed the chain at once and are split as far as it pays (8).
 // AGP_PRO_KS="8,8,4,2,1" overrides (the last entry repeats).
-static void pro_ks_table(int64_t nt, int64_t nq, bool f64, unsigned char* ks) {
+static void pro_ks_table(int64_t nt, int64_t nq, bool f64, unsigned char* ks, unsigned char* kf) {
   static const std::vector<int> env = []() {
     std::vector<int> v;
     if (const char* e = getenv("AGP_PRO_KS")) {
@@ -484,6 +484,23 @@ static void pro_ks_table(int64_t nt, int64_t nq, bool f64, unsigned char* ks) {
     else want = (int)std::ceil((double)nq * (tc + 0.3) / (tau * (double)c - 12.0));
     want = std::max(1, std::min<int>(want, (int)std::min<int64_t>(8, nq)));
     ks[c] = (unsigned char)want;
+  }
+  // the tiles next to the diagonal (ProArgs::kf): the same split as their column unless AGP_PRO_KF says otherwise
+  static const std::vector<int> envf = []() {
+    std::vector<int> v;
+    if (const char* e = getenv("AGP_PRO_KF")) {
+      for (const char* p = e; *p;) {
+        v.push_back(atoi(p));
+        while (*p && *p != ',') ++p;
+        if (*p == ',') ++p;
+      }
+    }
+    return v;
+  }();
+  for (int64_t c = 0; c < nt && c < 32; ++c) {
+    int want = envf.empty() ? (int)ks[c] : envf[std::min<size_t>((size_t)c, envf.size() - 1)];
+    want = std::max<int>(want, (int)ks[c]);
+    kf[c] = (unsigned char)std::max(1, std::min<int>(want, (int)std::min<int64_t>(8, nq)));
   }
 }
 static bool dag_trace_on() {
@@ -525,10 +542,10 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     int64_t nhelp = 0;
     if (pro) {
       if (pro->packed)
-        for (int64_t cc = 0; cc < nt; ++cc) pa.ks[cc] = 1;  // nothing to compute: no helpers
+        for (int64_t cc = 0; cc < nt; ++cc) pa.ks[cc] = pa.kf[cc] = 1;  // nothing to compute: no helpers
       else
-        pro_ks_table(nt, pro->Kdim / TILE, sizeof(T) == 8, pa.ks);
-      for (int64_t cc = 0; cc < nt; ++cc) nhelp += (nt - cc) * (pa.ks[cc] - 1);
+        pro_ks_table(nt, pro->Kdim / TILE, sizeof(T) == 8, pa.ks, pa.kf);
+      for (int64_t cc = 0; cc < nt; ++cc) nhelp += pro_nhelp(nt, cc, pa.ks[cc], pa.kf[cc]);
     }
     const int64_t nf = ((nt + ne + nx) * nt + 3 * nt + 1 + nhelp) * DAG_FS;
     if (c->dag_cap < nf) {
@@ -1273,7 +1290,11 @@ struct Svgp : SvgpBase {
     // only where the launch is not bound by workgroup slots: at 32 block columns (C3) the task graph already queues 1584 tile
     // workgroups through 256 slots, and the product's 27 ms of CU time inside it costs more than the kernel of its own (measured:
     // 0.70 -> 0.86-0.96 ms per step with any k-split table)
-    if (mp / TILE > 16) return false;
+    static const int64_t max_nt = []() {
+      const char* e = getenv("AGP_PRO_MAX_NT");
+      return e ? (int64_t)atoll(e) : (int64_t)16;
+    }();
+    if (mp / TILE > max_nt) return false;
     const int k = lp.kind;
     return k == AGP_LIK_GAUSSIAN || k == AGP_LIK_LOGISTIC || k == AGP_LIK_STUDENTT || k == AGP_LIK_LAPLACE ||
            k == AGP_LIK_BAYESIANSVM || k == AGP_LIK_NEGBINOMIAL || k == AGP_LIK_POISSON;

@@ -1535,12 +1535,21 @@ struct ProArgs {
   // vector t = kappa' r); the prologue then only takes the eta step from them (Kdim = 0: no product, no helpers)
   const T* packed = nullptr;
   const T* tred = nullptr;
-  unsigned char ks[32] = {};  // k-slices per block column (1: the tile workgroup forms the whole product itself)
+  unsigned char ks[32] = {};
+  // k-split of the PRO_NEAR tiles next to the diagonal of block column c (the chain's two feeders and the two tiles the NEXT
+  // feeders wait for): their product has to be done while the chain is at most a column or two away, whatever the column
+  unsigned char kf[32] = {};  // k-slices per block column (1: the tile workgroup forms the whole product itself)
 };
 
 // acc += sum over the 64-row chunks [q0, q1) of kappa of  (w .* kappa[:, R0 + .])' kappa[:, c0 + .]  -- 64-deep chunks staged in
 // LDS as [r][k] tiles (the layout mma8 reads), two buffer pairs alternating, the next chunk's global loads in flight during the
 // product.  sm: 4 * TILE * LDP elements.  All 512 threads; ends with a barrier (sm is free again).
+constexpr int PRO_NEAR = 4;
+// helpers of block column c (nn = its near-diagonal tiles): [near tiles: kf - 1 each][the others: ks - 1 each]
+__host__ __device__ __forceinline__ int64_t pro_nhelp(int64_t nt, int64_t c, int ks, int kf) {
+  const int64_t ntc = nt - c, nn = ntc < PRO_NEAR ? ntc : PRO_NEAR;
+  return nn * (kf - 1) + (ntc - nn) * (ks - 1);
+}
 template <typename T>
 __device__ __forceinline__ void pro_slice(const T* __restrict__ kap, int64_t ldk, const T* __restrict__ w, int64_t R0, int64_t c0,
                                           int64_t q0, int64_t q1, T* sm, Acc8<T>& acc) {
@@ -1637,7 +1646,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
         for (int64_t i = b * CHOL_THREADS + tid; i < pro.fill_n; i += (int64_t)pro.nfill * CHOL_THREADS) pro.fill[i] = sv;
         return;
       }
-      const int64_t nh = (nt - c) * (pro.ks[c] - 1), ntile = nt - c + ne + (nx ? c + 1 : 0);
+      const int64_t nh = pro_nhelp(nt, c, pro.ks[c], pro.kf[c]), ntile = nt - c + ne + (nx ? c + 1 : 0);
       if (b < nh) {
         helper = true;
         break;
@@ -1659,8 +1668,12 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
 #define PRO_TS(i) \
   if (PRO && trace && tid == 0) trace[i] = wall_clock64()
   if (PRO && helper) {  // one k-slice of S(R, c): no dependencies, one store of the partial tile, done
-    const int ksc = pro.ks[c];
-    const int64_t tb = b / (ksc - 1), sl = 1 + b % (ksc - 1), nq = pro.Kdim / TILE;
+    const int64_t ntc = nt - c, nn = ntc < PRO_NEAR ? ntc : PRO_NEAR;
+    const int kfc = pro.kf[c], kso = pro.ks[c];
+    const bool near = b < nn * (kfc - 1);
+    const int ksc = near ? kfc : kso;
+    const int64_t bo = near ? b : b - nn * (kfc - 1);
+    const int64_t tb = (near ? 0 : nn) + bo / (ksc - 1), sl = 1 + bo % (ksc - 1), nq = pro.Kdim / TILE;
     Acc8<T> S;
     S.zero();
     if (c == 0 && b == 0) PRO_TS(1024);
@@ -1698,7 +1711,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   Acc8<T> acc;
   if (PRO && !ext) {
     // ---- prologue of a matrix tile: S(R, c) (own k-slice + the helpers' partial tiles), the eta2 step, A = -2 eta2 -> acc
-    const int ksc = pro.ks[c];
+    const int64_t ntc_ = nt - c, nn_ = ntc_ < PRO_NEAR ? ntc_ : PRO_NEAR;
+    const int ksc = b < nn_ ? pro.kf[c] : pro.ks[c];
     const int64_t nq = pro.Kdim / TILE;
     const int tsb = chain ? 0 : (R < 4 && c < 4) ? 64 + 8 * (4 * (int)R + (int)c) : 2040;
     PRO_TS(tsb);
@@ -1714,7 +1728,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
     acc8_foreach<T>(e2v, [&](int r, int cc, T& val) { val = pro.eta2[(R * TILE + r) * pro.ldm + c0 + cc]; });
     acc8_foreach<T>(kiv, [&](int r, int cc, T& val) { val = pro.Kinv[(R * TILE + r) * pro.ldm + c0 + cc]; });
     if (ksc > 1) {
-      const int64_t h0 = hbase + b * (ksc - 1);
+      const int64_t h0 = hbase + (b < nn_ ? b * (pro.kf[c] - 1) : nn_ * (pro.kf[c] - 1) + (b - nn_) * (pro.ks[c] - 1));
       if (tid < ksc - 1) {  // one poller per helper; helpers have lower workgroup indices and wait for nothing: they always arrive
         long spins = 0;
         while (__hip_atomic_load(pro.sflags + (h0 + tid) * DAG_FS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {

@@ -538,13 +538,13 @@ def main():
         hh = mh._ensure_handle(B)
         mh._chk(L.agp_svgp_refresh_K(hh))
         for i in range(3):
-            mh._chk(L.agp_svgp_cavi_step(hh, xp, ld, yp, C.c_void_p(idx_all[i].data_ptr()), B, rho))
+            mh._chk(L.agp_svgp_cavi_step(hh, xp, ld, yp, C.c_void_p(idx_all[i % total].data_ptr()), B, rho))
             mh._chk(L.agp_svgp_hyper_step(hh))
         torch.cuda.synchronize()
         th = time.perf_counter()
         nh = 20
         for i in range(nh):
-            mh._chk(L.agp_svgp_cavi_step(hh, xp, ld, yp, C.c_void_p(idx_all[3 + i].data_ptr()), B, rho))
+            mh._chk(L.agp_svgp_cavi_step(hh, xp, ld, yp, C.c_void_p(idx_all[(3 + i) % total].data_ptr()), B, rho))
             mh._chk(L.agp_svgp_hyper_step(hh))
         torch.cuda.synchronize()
         out["ms_per_step_with_hyper_update"] = round((time.perf_counter() - th) / nh * 1e3, 4)
@@ -553,7 +553,7 @@ def main():
         # step as its prologue --, and K_ZZ); a few more iterations with HIP events around the first of the two
         mh._chk(L.agp_svgp_timing_enable(hh, 1))
         for i in range(6):
-            mh._chk(L.agp_svgp_cavi_step(hh, xp, ld, yp, C.c_void_p(idx_all[3 + nh + i].data_ptr()), B, rho))
+            mh._chk(L.agp_svgp_cavi_step(hh, xp, ld, yp, C.c_void_p(idx_all[(3 + nh + i) % total].data_ptr()), B, rho))
             mh._chk(L.agp_svgp_hyper_step(hh))
         nlh, kmsh = C.c_int64(), C.c_double()
         mh._chk(L.agp_svgp_timing_read(hh, C.byref(nlh), C.byref(kmsh)))

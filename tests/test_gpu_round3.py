@@ -672,3 +672,30 @@ def test_ragged_and_changing_minibatch_sizes_with_a_pending_step(mods):
     mu, Sig, e1, e2 = ma.get_state(0)
     assert _rel(e1, g.eta1) < 1e-8 and _rel(e2, g.eta2) < 1e-8
     assert _rel(mu, g.mu) < 1e-8 and _rel(np.diag(Sig), np.diag(g.Sigma)) < 1e-8
+
+
+def test_many_classes_beyond_the_batched_launch_limits(mods):
+    """18-class LogisticSoftMax = 18 latents on one handle: more than the 16 a row-statistics / eta-step launch batches
+    (ROWSTATS_MAXB, SYRK_MAXB), more than the fused local update holds in registers (LSM_FUSED_MAXL -> the five-launch sequence),
+    three task-graph launches of 6 problems (m = 130: 3 block columns).  Every latent against the oracle (logisticsoftmax.jl:55-79)."""
+    AGP, R, capi, torch = mods
+    rng = np.random.default_rng(18)
+    N, D, m, B, K, iters = 1500, 3, 130, 192, 18, 4
+    X = rng.random((N, D))
+    f = np.sin(5 * X[:, 0]) + X[:, 1] * X[:, 2]
+    y = 1 + np.digitize(f, np.quantile(f, np.linspace(0, 1, K + 1)[1:-1]))
+    Z = X[rng.permutation(N)[:m]].copy()
+    idx = [rng.choice(N, B, replace=False) for _ in range(iters)]
+    ma = AGP.SVGP(1.5 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(3.0)), AGP.LogisticSoftMaxLikelihood(K), AGP.AnalyticSVI(B), Z,
+                  optimiser=False)
+    mr = R.SVGP(R.Kernel("sqexponential", 3.0, 1.5), R.LogisticSoftMaxLikelihood(K), Z, stochastic=True, batchsize=B)
+    ea, er = [], []
+    AGP.train_(ma, X, y, iters, idx_stream=idx, callback=lambda mdl, s, i: ea.append(AGP.objective(mdl, s)))
+    mr.train(X, y, iters, idx_stream=idx, callback=lambda M, it, xb, yb: er.append(M.elbo(yb)))
+    for l in range(K):
+        g = mr.latents[l]
+        mu, Sig, e1, e2 = ma.get_state(l)
+        assert _rel(e1, g.eta1) < 1e-9 and _rel(e2, g.eta2) < 1e-9, l
+        assert _rel(mu, g.mu) < 1e-8 and _rel(np.diag(Sig), np.diag(g.Sigma)) < 1e-8, l
+    assert np.allclose(ea, er, rtol=1e-8)
+    assert _rel(ma.get_matrix(capi.VEC_ALPHA, 0, B), mr.local_vars["alpha"]) < 1e-9

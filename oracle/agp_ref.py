@@ -16,7 +16,10 @@ What pins this restatement instead:
     full-batch Gaussian step, exact-GP limit Z = X, utils identities of test/functions/utils.jl,
     one-hot answers of test/likelihood/multiclass.jl, mpmath tables, ELBO monotonicity,
     finite-difference check of the hyper-gradient),
-  * the reference's behavioural thresholds (test/testingtools.jl:223-253) on its own toy set-ups.
+  * the reference's behavioural thresholds (test/testingtools.jl:223-253) on its own toy set-ups,
+  * an independent third-party implementation where one is installed (tests/test_oracle_sklearn.py:
+    kernel definitions against scikit-learn's RBF / Matern, the Gaussian path with Z = X against
+    GaussianProcessRegressor -- predictions, proba_y, ELBO = exact log marginal likelihood).
 
 Third-party arithmetic that is NOT under /root/reference and is restated from the published
 definitions: KernelFunctions.jl (compat 0.8-0.10; SqExponential / Matern / ScaleTransform /

@@ -17,7 +17,7 @@ What pins this restatement instead:
     one-hot answers of test/likelihood/multiclass.jl, mpmath tables, ELBO monotonicity,
     finite-difference check of the hyper-gradient),
   * the reference's behavioural thresholds (test/testingtools.jl:223-253) on its own toy set-ups,
-  * an independent third-party implementation where one is installed (tests/test_oracle_sklearn.py:
+  * an independent third-party implementation where one is installed (tests/test_oracle_third_party.py:
     kernel definitions against scikit-learn's RBF / Matern, the Gaussian path with Z = X against
     GaussianProcessRegressor -- predictions, proba_y, ELBO = exact log marginal likelihood).
 

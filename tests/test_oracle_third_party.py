@@ -63,3 +63,51 @@ def test_gaussian_svgp_with_Z_equal_X_is_sklearn_gp_regression(kind):
     # ELBO(q*) = log N(y | 0, K + sigma^2 I)
     elbo = m.elbo(R.treat_labels(y, m.likelihood))
     assert abs(elbo - gpr.log_marginal_likelihood_value_) < 1e-5 * abs(gpr.log_marginal_likelihood_value_)
+
+
+# ---- the KL divergences of the ELBO (src/functions/KLdivergences.jl) against torch.distributions' closed forms -------------------
+def test_gaussian_kl_matches_torch_distributions():
+    torch = pytest.importorskip("torch")
+    from torch.distributions import MultivariateNormal, kl_divergence
+
+    rng = np.random.default_rng(3)
+    m = 12
+    A, B = rng.standard_normal((m, m)), rng.standard_normal((m, m))
+    Sigma, K = A @ A.T + 0.5 * np.eye(m), B @ B.T + 0.5 * np.eye(m)
+    mu, mu0 = rng.standard_normal(m), rng.standard_normal(m)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64)
+    ref = kl_divergence(MultivariateNormal(t(mu), covariance_matrix=t(Sigma)), MultivariateNormal(t(mu0), covariance_matrix=t(K))).item()
+    assert R.gaussian_kl(mu, mu0, Sigma, np.linalg.cholesky(K)) == pytest.approx(ref, rel=1e-11)  # KLdivergences.jl:11-18
+
+
+def test_gamma_and_poisson_kl_match_torch_distributions():
+    torch = pytest.importorskip("torch")
+    from torch.distributions import Gamma, Poisson, kl_divergence
+
+    rng = np.random.default_rng(4)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64)
+    # KLdivergences.jl:62-67 (the StudentT likelihood's inverse-gamma local variables: scalar shape, vector rate; a KL is invariant
+    # under the reparametrisation omega -> 1 / omega, so the gamma closed form applies)
+    alpha, alpha_p, beta_p = 2.5, 1.5, 0.7
+    beta = rng.uniform(0.3, 3.0, 20)
+    ref = kl_divergence(Gamma(t(alpha), t(beta)), Gamma(t(alpha_p), t(beta_p))).sum().item()
+    assert R.gamma_kl(alpha, beta, alpha_p, beta_p) == pytest.approx(ref, rel=1e-11)
+    # KLdivergences.jl:83-89 with psi = log(lambda0): the plain Poisson KL (the likelihoods pass E[log lambda0] for psi)
+    lam, lam0 = rng.uniform(0.1, 5.0, 30), rng.uniform(0.1, 5.0, 30)
+    ref = kl_divergence(Poisson(t(lam)), Poisson(t(lam0))).sum().item()
+    assert R.poisson_kl(lam, lam0, np.log(lam0)) == pytest.approx(ref, rel=1e-11)
+
+
+def test_polya_gamma_kl_against_the_series_of_its_laplace_transform():
+    """KLdivergences.jl:96-98: KL(PG(b, c) || PG(b, 0)) = b log cosh(c / 2) - c^2 / 2 E[omega], E[omega] = b tanh(c / 2) / (2 c)
+    (Polson, Scott & Windle 2013: the PG(b, c) density is the PG(b, 0) density tilted by exp(-c^2 omega / 2) cosh^b(c / 2)).
+    Independent check of E[omega] from the defining series omega = (1 / 2 pi^2) sum_k g_k / ((k - 1/2)^2 + c^2 / 4 pi^2),
+    g_k ~ Gamma(b, 1): E[omega] = (b / 2 pi^2) sum_k 1 / ((k - 1/2)^2 + c^2 / (4 pi^2))."""
+    b = np.array([1.0, 1.0, 2.0, 3.5])
+    c = np.array([0.3, 2.0, 1.1, 4.0])
+    k = np.arange(1, 2_000_001, dtype=np.float64)[None, :]
+    series = (b / (2 * np.pi ** 2)) * np.sum(1.0 / ((k - 0.5) ** 2 + (c[:, None] ** 2) / (4 * np.pi ** 2)), axis=1)
+    theta = b * np.tanh(c / 2) / (2 * c)
+    assert np.allclose(series, theta, rtol=1e-6)  # (the tail of the series beyond 2e6 terms is ~ b / (4 pi^2 1e6))
+    expect = float(np.sum(b * np.log(np.cosh(c / 2)) - c * c / 2 * theta))
+    assert R.polya_gamma_kl(b, c, theta) == pytest.approx(expect, rel=1e-12)

@@ -124,13 +124,16 @@ class SVGP:
     def __init__(self, kernel, likelihood, inference, Z, *, verbose: int = 0, optimiser=None, atfrequency: int = 1,
                  mean=None, Zoptimiser=False, T=np.float64, device: Optional[int] = None, seed: Optional[int] = None,
                  elbo_mode: str = "corrected", latent_slice: Optional[tuple] = None,
-                 reference_compat_stale_K: bool = False):
+                 reference_compat_stale_K: bool = False, jitter: Optional[float] = None):
         if not isinstance(inference, AnalyticVI):
             raise TypeError("The inference object should be of type `VariationalInference` : either `AnalyticVI` or "
                             "`NumericalVI`")  # SVGP.jl:45-47 (only AnalyticVI exists on this path)
         # inside one train! the reference keeps the Cholesky of K_ZZ of the first iteration even after
         # hyper-parameter steps (training.jl:187-208).  False (default): K is refreshed; True: mirror the reference.
         self.reference_compat_stale_K = bool(reference_compat_stale_K)
+        # jitt of the reference is a constant per float type (src/functions/utils.jl:8-9: 1e-4 for Float64, 1e-3 for Float32): None
+        # keeps it; a value overrides it for this model (agp_svgp_desc.jitter) -- used by tests that compare with exact GP regression
+        self.jitter = None if jitter is None else float(jitter)
         if not isinstance(likelihood, (GaussianLikelihood, LogisticLikelihood, StudentTLikelihood,
                                        LogisticSoftMaxLikelihood, _MultiOutputLikelihood, LaplaceLikelihood,
                                        BayesianSVM, PoissonLikelihood, NegBinomialLikelihood,
@@ -260,7 +263,7 @@ class SVGP:
         d.stochastic = 1 if self.inference.stoch else 0
         d.m, d.D, d.max_batch = self.m, self.D, int(max_batch)
         d.lik = self.likelihood.lik_desc()
-        d.jitter = 0.0
+        d.jitter = 0.0 if getattr(self, "jitter", None) is None else self.jitter
         opt = self.inference.optimiser or RobbinsMonro()
         d.rm_kappa, d.rm_tau = opt.kappa, opt.tau
         d.elbo_mode = capi.ELBO_REFERENCE if self.elbo_mode == "reference" else capi.ELBO_CORRECTED

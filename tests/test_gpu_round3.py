@@ -699,3 +699,40 @@ def test_many_classes_beyond_the_batched_launch_limits(mods):
         assert _rel(mu, g.mu) < 1e-8 and _rel(np.diag(Sig), np.diag(g.Sigma)) < 1e-8, l
     assert np.allclose(ea, er, rtol=1e-8)
     assert _rel(ma.get_matrix(capi.VEC_ALPHA, 0, B), mr.local_vars["alpha"]) < 1e-9
+
+
+@pytest.mark.parametrize("kind", ["sqexponential", "matern52"])
+def test_device_gaussian_path_against_sklearn_gp_regression(mods, kind):
+    """The HIP path against an independent third-party implementation (not via the oracle): Gaussian likelihood, inducing points =
+    the data (Z = X, m = N = 150: three block columns), full-batch AnalyticVI.  One CAVI step is the optimal q(u) and the model is
+    exact GP regression: predictive mean / variance, proba_y and ELBO = log marginal likelihood of scikit-learn's
+    GaussianProcessRegressor (Cholesky of K + sigma^2 I).  jitter 1e-6 instead of the reference's 1e-4: with Z = X the step's
+    K~ = kdiag + jitter - rowsum(kappa .* Knm) is jitter-sized, and the jitter has to stay above cond(K) eps (the reference throws
+    "K~ has negative values" below that, latentgp.jl:213, and so does the device); what it adds to the exact answers is ~ jitter /
+    sigma^2 = 2e-5 relative."""
+    AGP, R, capi, torch = mods
+    sk = pytest.importorskip("sklearn.gaussian_process")
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern
+
+    rng = np.random.default_rng(12)
+    N, D, noise, ell, var = 150, 2, 0.05, 0.4, 1.5
+    X = rng.random((N, D))
+    y = np.sin(4 * X[:, 0]) + X[:, 1] ** 2 + np.sqrt(noise) * rng.standard_normal(N)
+    Xt = rng.random((40, D))
+    base = AGP.SqExponentialKernel() if kind == "sqexponential" else AGP.Matern52Kernel()
+    ma = AGP.SVGP(var * AGP.with_lengthscale(base, ell), AGP.GaussianLikelihood(noise), AGP.AnalyticVI(), X.copy(), optimiser=False,
+                  jitter=1e-6)
+    AGP.train_(ma, X, y, 2)
+    skb = RBF(length_scale=ell) if kind == "sqexponential" else Matern(length_scale=ell, nu=2.5)
+    gpr = sk.GaussianProcessRegressor(kernel=ConstantKernel(var, constant_value_bounds="fixed") * skb, alpha=noise,
+                                      optimizer=None).fit(X, y)
+    mu_sk, sd_sk = gpr.predict(Xt, return_std=True)
+    mu, v = AGP.predict_f(ma, Xt, cov=True)
+    assert np.max(np.abs(np.asarray(mu) - mu_sk)) < 1e-4 * max(1.0, np.max(np.abs(mu_sk)))
+    assert np.max(np.abs(np.asarray(v) - sd_sk ** 2)) < 1e-4
+    pm, pv = AGP.proba_y(ma, Xt)
+    assert np.max(np.abs(np.asarray(pm) - mu_sk)) < 1e-4 * max(1.0, np.max(np.abs(mu_sk)))
+    assert np.max(np.abs(np.asarray(pv) - (sd_sk ** 2 + noise))) < 1e-4
+    # ELBO = log marginal likelihood minus the jitter's share of the trace term, sum_i K~_i / (2 sigma^2) ~ N jitter / (2 sigma^2)
+    lml = gpr.log_marginal_likelihood_value_
+    assert abs(AGP.ELBO(ma, X, y, rho=1.0) - lml) < 2.0 * N * 1e-6 / (2.0 * noise) + 1e-6 * abs(lml)

@@ -1441,9 +1441,9 @@ struct Svgp : SvgpBase {
     AGPCHK(dmalloc(ctx, &Tw2, mm));
     AGPCHK(dmalloc(ctx, &tmpv, mp));
     AGPCHK(dmalloc(ctx, &lr_dev, 1));
-    AGPCHK(dmalloc(ctx, &info_dev, 1));
-    AGPCHK(dmalloc(ctx, &infoK_dev, 1));
-    AGPCHK(dmalloc(ctx, &flags_dev, 1));
+    AGPCHK(dmalloc(ctx, &info_dev, 4));  // [info | infoK | flags | -]: one block, so that check_status fetches them with one copy
+    infoK_dev = info_dev + 1;
+    flags_dev = (int*)(info_dev + 2);
     AGPCHK(dmalloc(ctx, &scal_dev, 64));
     AGPCHK(dmalloc(ctx, &lam_dev, 1));
     AGPCHK(dmalloc(ctx, &lam_part, 2 * (Bp / 256 + 1)));
@@ -1507,9 +1507,7 @@ struct Svgp : SvgpBase {
     double* dps[] = {gradA_dev, am_dev, av_dev};
     for (double* p : dps)
       if (p) dfree(p);
-    if (info_dev) dfree(info_dev);
-    if (infoK_dev) dfree(infoK_dev);
-    if (flags_dev) dfree(flags_dev);
+    if (info_dev) dfree(info_dev);  // (infoK_dev, flags_dev point into the same block)
     if (scal_dev) dfree(scal_dev);
     if (gh_dev) dfree(gh_dev);
     if (lam_dev) dfree(lam_dev);
@@ -3108,13 +3106,11 @@ struct Svgp : SvgpBase {
   }
 
   agp_status check_status() override {
-    int32_t info = 0;
-    int flags = 0;
-    int32_t infoK = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&info, info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st()));
-    HIPCHK(ctx, hipMemcpyAsync(&flags, flags_dev, sizeof(int), hipMemcpyDeviceToHost, st()));
-    HIPCHK(ctx, hipMemcpyAsync(&infoK, infoK_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st()));
+    int32_t words[3] = {0, 0, 0};  // info | infoK | flags
+    HIPCHK(ctx, hipMemcpyAsync(words, info_dev, sizeof(words), hipMemcpyDeviceToHost, st()));
     HIPCHK(ctx, hipStreamSynchronize(st()));
+    const int32_t info = words[0], infoK = words[1];
+    const int flags = (int)words[2];
     dag_retry_check(ctx);  // steps the in-stream fallback had to re-run: warn once, stop using the task graph
     if (info != 0 || flags != 0) {
       HIPCHK(ctx, hipMemsetAsync(info_dev, 0, sizeof(int32_t), st()));

@@ -31,6 +31,8 @@ from .likelihoods import (  # noqa: F401
 )
 from .svgp import (  # noqa: F401
     ADAM,
+    Descent,
+    Momentum,
     ELBO,
     MOSVGP,
     SVGP,

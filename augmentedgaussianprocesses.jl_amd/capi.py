@@ -27,6 +27,7 @@ F64, F32 = 0, 1
 K_SQEXP, K_MATERN52, K_MATERN32, K_EXPONENTIAL = 0, 1, 2, 3
 LIK_GAUSSIAN, LIK_LOGISTIC, LIK_STUDENTT, LIK_LOGISTICSOFTMAX, LIK_MULTIOUTPUT = 0, 1, 2, 3, 4
 LIK_LAPLACE, LIK_BAYESIANSVM, LIK_POISSON, LIK_NEGBINOMIAL, LIK_HETEROSCEDASTIC = 5, 6, 7, 8, 9
+OPT_ADAM, OPT_DESCENT, OPT_MOMENTUM = 0, 1, 2  # agp_svgp_hyper_rule
 ELBO_CORRECTED, ELBO_REFERENCE = 0, 1
 FLAG_STALE_K = 1  # reference_compat_stale_K
 SHARD_LATENT, SHARD_BATCH = 0, 1
@@ -98,6 +99,7 @@ SYMBOLS = {
     "agp_svgp_step_counters": (_I32, [_VP, _PI64, _PI64]),
     "agp_svgp_step_local": (_I32, [_VP, _VP, _I64, _VP, _VP, _I64, _DBL]),
     "agp_svgp_hyper_configure": (_I32, [_VP, _I32, _DBL, _I32, _DBL, _DBL, _DBL, _DBL]),
+    "agp_svgp_hyper_rule": (_I32, [_VP, _I32, _DBL, _I32, _DBL]),
     "agp_svgp_hypergrad": (_I32, [_VP, _I32, _PDBL, _PDBL, _VP]),
     "agp_svgp_hyper_step": (_I32, [_VP]),
     "agp_svgp_get_kernel": (_I32, [_VP, _I32, _PDBL, _PDBL]),

@@ -58,6 +58,13 @@ struct agp_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   void* chol_li = nullptr;
   size_t chol_li_bytes = 0;
+  // split task-graph launches (k_chol_dag ROLE 1 / 2): the chain kernels' own high-priority stream, the word the tile kernel
+  // releases them with (signal memory) and the event this context's stream waits on behind every split launch
+  hipStream_t chain_stream = nullptr;
+  int32_t* chain_go = nullptr;
+  hipEvent_t chain_done = nullptr;
+  int chain_state = 0;  // 0 not tried, 1 usable, -1 not available (the two streams do not run kernels side by side) / switched off
+  int32_t chain_seq = 0;
 };
 
 #define HIPCHK(ctx, expr)                                                                       \
@@ -439,6 +446,62 @@ static void dag_retry_check(agp_ctx* c) {
   }
 }
 
+// Split task-graph launches: worth it when the launch queues far more tiles than the chip has workgroup slots (C3: 1584, C4: 3264);
+// the small launches (C2: 408 tiles, and its merged step with the prologue) stay one kernel.  AGP_CHAIN_SPLIT=0 / 1 forces.
+static bool chain_split_wanted(int64_t tiles) {
+  static const int v = []() {
+    const char* e = getenv("AGP_CHAIN_SPLIT");
+    return e ? (e[0] == '0' ? 0 : 1) : -1;
+  }();
+  static const int64_t min_tiles = []() {
+    const char* e = getenv("AGP_CHAIN_SPLIT_MIN_TILES");
+    return e ? (int64_t)atoll(e) : (int64_t)600;
+  }();
+  return v < 0 ? tiles >= min_tiles : v == 1;
+}
+// the chain stream, its release word and the proof that kernels of the two streams run at the same time (k_handshake: where
+// dispatches are serialised -- rocprofv3 --pmc, AMD_SERIALIZE_KERNEL -- a chain kernel polling for the tile kernel behind it in
+// the device's single queue would never be released; such a context keeps the merged kernel)
+static bool chain_split_ready(agp_ctx* c) {
+  if (c->chain_state != 0) return c->chain_state == 1;
+  c->chain_state = -1;
+  int lo = 0, hi = 0;
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return false;
+  if (hipStreamCreateWithPriority(&c->chain_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+    c->chain_stream = nullptr;
+    (void)hipGetLastError();
+    return false;
+  }
+  bool ok = hipExtMallocWithFlags((void**)&c->chain_go, 8, hipMallocSignalMemory) == hipSuccess && hipMemset(c->chain_go, 0, 8) == hipSuccess &&
+            hipEventCreateWithFlags(&c->chain_done, hipEventDisableTiming) == hipSuccess;
+  int32_t* hs = nullptr;
+  ok = ok && hipMalloc((void**)&hs, 4 * sizeof(int32_t)) == hipSuccess && hipMemset(hs, 0, 4 * sizeof(int32_t)) == hipSuccess;
+  if (ok) {
+    (void)hipStreamSynchronize(c->stream);
+    hipLaunchKernelGGL(k_handshake, dim3(1), dim3(64), 0, c->chain_stream, hs, (const int32_t*)(hs + 1), hs + 2);
+    hipLaunchKernelGGL(k_handshake, dim3(1), dim3(64), 0, c->stream, hs + 1, (const int32_t*)hs, hs + 3);
+    int32_t res[4] = {0, 0, 0, 0};
+    ok = hipStreamSynchronize(c->chain_stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess &&
+         hipMemcpy(res, hs, sizeof(res), hipMemcpyDeviceToHost) == hipSuccess && res[2] == 1 && res[3] == 1;
+  }
+  if (hs) (void)hipFree(hs);
+  (void)hipGetLastError();
+  if (ok) c->chain_state = 1;
+  return ok;
+}
+// behind a split launch: this context's stream continues only when the chain kernel has ended too (it ends microseconds after
+// the last tile, but a host synchronisation of the stream must cover it, and so must whatever reads the diagonal factors next)
+static agp_status chain_split_join(agp_ctx* c) {
+  static const bool off = []() {  // AGP_CHAIN_JOIN=0: A/B measurements of what the join costs the stream (not for use)
+    const char* e = getenv("AGP_CHAIN_JOIN");
+    return e && e[0] == '0';
+  }();
+  if (off) return AGP_OK;
+  HIPCHK(c, hipEventRecord(c->chain_done, c->chain_stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->chain_done, 0));
+  return AGP_OK;
+}
+
 // what a CAVI step hands to its factorisation about the look-ahead stream (see DagSync, agp_chol.h)
 struct StepSync {
   DagSync ds{};
@@ -625,7 +688,18 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
         if (hipMalloc((void**)&ptrace, 2048 * 8) != hipSuccess) ptrace = nullptr;
         if (ptrace) (void)hipMemsetAsync(ptrace, 0, 2048 * 8, c->stream);
       }
-      if (step_inst)
+      if (step_inst && chain_split_wanted(ntiles + nhelp) && chain_split_ready(c)) {  // chain kernel + tile kernel (k_chol_dag, ROLE)
+        ds.go = c->chain_go;
+        ds.go_val = ++c->chain_seq;
+        hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, true, 1>), dim3(1), dim3(CHOL_THREADS), 0, c->chain_stream, one, 1,
+                           (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, ptrace, H, hstride, nx, erow, 0,
+                           ds, pa, epi ? *epi : EpiArgs<T>{});
+        hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, true, 2>), dim3((unsigned)(ntiles + nhelp + pa.nfill)),
+                           dim3(CHOL_THREADS), lds_pad, c->stream, one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid,
+                           c->dag_flags, c->dag_epoch, ptrace, H, hstride, nx, erow, 0, ds, pa, epi ? *epi : EpiArgs<T>{});
+        LAUNCHCHK(c);
+        AGPCHK(chain_split_join(c));
+      } else if (step_inst)
         hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, true>), dim3((unsigned)(ntiles + nhelp + pa.nfill)),
                            dim3(CHOL_THREADS), lds_pad, c->stream, one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid,
                            c->dag_flags, c->dag_epoch, ptrace, H, hstride, nx, erow, 0, ds, pa, epi ? *epi : EpiArgs<T>{});
@@ -646,6 +720,18 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
         }
       }
       c->h_step_set = other;
+    } else if (step_inst && chain_split_wanted(ntiles) && chain_split_ready(c)) {
+      // ... as two kernels: the chain workgroup on its own stream (enqueued first), every other tile on this one
+      ds.go = c->chain_go;
+      ds.go_val = ++c->chain_seq;
+      hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, false, 1>), dim3(1), dim3(CHOL_THREADS), 0, c->chain_stream, one, 1,
+                         (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
+                         0, ds);
+      hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, false, 2>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream,
+                         one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx,
+                         erow, 0, ds);
+      LAUNCHCHK(c);
+      AGPCHK(chain_split_join(c));
     } else if (step_inst)  // the CAVI step's launch: specialised instantiation
       hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1,
                          (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
@@ -740,9 +826,22 @@ static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, in
   T* H = nullptr;
   const int hs = 0;
   AGPCHK(dag_handover_acquire<T>(c, hstride * nb, hs, &H));
-  hipLaunchKernelGGL((k_chol_dag<T, true, true, false, true>), dim3((unsigned)(ntiles * nb)), dim3(CHOL_THREADS), 0, c->stream, bt, nb, fstride, ld,
-                     ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, (unsigned long long*)nullptr, H, hstride,
-                     (int64_t)0, (const T*)nullptr, 0, DagSync{});
+  if (chain_split_wanted(ntiles * nb) && chain_split_ready(c)) {  // the nb chains as one kernel, all other tiles as another
+    DagSync ds{};
+    ds.go = c->chain_go;
+    ds.go_val = ++c->chain_seq;
+    hipLaunchKernelGGL((k_chol_dag<T, true, true, false, true, false, 1>), dim3((unsigned)nb), dim3(CHOL_THREADS), 0, c->chain_stream, bt,
+                       nb, fstride, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, (unsigned long long*)nullptr, H,
+                       hstride, (int64_t)0, (const T*)nullptr, 0, ds);
+    hipLaunchKernelGGL((k_chol_dag<T, true, true, false, true, false, 2>), dim3((unsigned)(ntiles * nb)), dim3(CHOL_THREADS), 0,
+                       c->stream, bt, nb, fstride, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch,
+                       (unsigned long long*)nullptr, H, hstride, (int64_t)0, (const T*)nullptr, 0, ds);
+    LAUNCHCHK(c);
+    AGPCHK(chain_split_join(c));
+  } else
+    hipLaunchKernelGGL((k_chol_dag<T, true, true, false, true>), dim3((unsigned)(ntiles * nb)), dim3(CHOL_THREADS), 0, c->stream, bt, nb, fstride, ld,
+                       ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, (unsigned long long*)nullptr, H, hstride,
+                       (int64_t)0, (const T*)nullptr, 0, DagSync{});
   LAUNCHCHK(c);
   AGPCHK(dag_handover_release<T>(c, (3 * nt + (nt + ne) * nt) * TILE * TILE, hstride, nb, hs));
   if (safe) {
@@ -962,6 +1061,7 @@ struct SvgpBase {
   virtual agp_status mo_refresh_f() = 0;
   virtual agp_status mo_predict_from_f(int64_t nt, int mode, void* o0, void* o1, const double* nodes,
                                        const double* weights, int nn) = 0;
+  virtual agp_status hyper_rule(int k_rule, double k_rho, int z_rule, double z_rho) = 0;
   virtual agp_status hyper_configure(int opt_k, double k_eta, int opt_z, double z_eta, double b1, double b2,
                                      double eps) = 0;
   virtual agp_status hypergrad(int l, double* dvar, double* dscale, void* dZ) = 0;
@@ -1139,6 +1239,8 @@ struct Svgp : SvgpBase {
   // hyper-parameter step (update_hyperparameters!, autotuning.jl:86-140)
   bool hy_k = false, hy_z = false;
   double hy_keta = 0.01, hy_zeta = 0.001, hy_b1 = 0.9, hy_b2 = 0.999, hy_eps = 1e-8;
+  int hy_krule = AGP_OPT_ADAM, hy_zrule = AGP_OPT_ADAM;  // agp_svgp_hyper_rule: ADAM / Descent / Momentum (opt_rule_delta)
+  double hy_krho = 0.0, hy_zrho = 0.0;
   T *hyKap = nullptr, *hyKnm = nullptr;  // kappa (Knm) under the fresh inv(K) (kernel) for the hyper-gradient, AGP_FLAG_STALE_K
   T *hyH1 = nullptr, *hyH2 = nullptr, *hyH3 = nullptr, *hy_gmu = nullptr, *hy_gs = nullptr, *hy_muf = nullptr,
     *hy_pZ = nullptr, *hy_dZ = nullptr;
@@ -1923,7 +2025,9 @@ struct Svgp : SvgpBase {
       ssync.ds.seq = started_seq + 1;
     } else if (rel_pending) {
       // the release of the previous step's kappa buffers becomes an event here, before anything of this step is enqueued (the
-      // look-ahead waiting for it is meant to run next to this step's factorisation)
+      // look-ahead waiting for it is meant to run next to this step's factorisation).  The previous step's deferred fallback goes
+      // first: if it really re-runs it rewrites that step's Wbuf and reads its pk -- the buffers this event releases
+      AGPCHK(run_deferred_safe());
       slot_kind[rel_slot] = 0;
       HIPCHK(ctx, hipEventRecord(step_done[rel_slot], st()));
       rel_pending = false;
@@ -2070,7 +2174,6 @@ struct Svgp : SvgpBase {
               ph.Kinv = pendp.Kinv;
               ph.kinv_mu0 = pendp.kinv_mu0;
               ph.lr = pendp.lr;
-              pendp.on = false;
             } else {
               ph.kap = pend.kap;
               ph.Kdim = pend.Bq;
@@ -2079,9 +2182,7 @@ struct Svgp : SvgpBase {
               ph.Kinv = pend.Kinv;
               ph.kinv_mu0 = pend.kinv_mu0;
               ph.lr = pend.lr;
-              pend.on = false;
             }
-            n_prologue += 1;
           }
           EpiArgs<T> ea{};
           if (use_epi) {
@@ -2116,6 +2217,10 @@ struct Svgp : SvgpBase {
           AGPCHK(potrf_fused<T>(ctx, bt.A[0], mp, mp, bt.X[0], mp, bt.Dg[0], bt.E[0], mp, nel, 0, info_dev, m,
                                 (const T*)lat[todo[l0]].eta1, false, &src, &defer, sync_step ? &ssync : nullptr,
                                 use_pro ? &ph : nullptr, use_epi ? &ea : nullptr));
+          if (use_pro) {  // the launch has taken the pending step (had it been refused, the step would still be pending for flush())
+            pend.on = pendp.on = false;
+            n_prologue += 1;
+          }
           merged_safe = defer;
           launches += dag_nb > 0 ? 1 : chol_launch_count(ntl, nel);
         } else if (dag_nb > 0) {
@@ -2244,6 +2349,18 @@ struct Svgp : SvgpBase {
   }
 
   // ---- hyper-parameter / inducing-point gradient (see agp_hyper.h) ------------------------------------------------
+  agp_status hyper_rule(int k_rule, double k_rho, int z_rule, double z_rho) override {
+    for (int r : {k_rule, z_rule})
+      if (r != AGP_OPT_ADAM && r != AGP_OPT_DESCENT && r != AGP_OPT_MOMENTUM) {
+        ctx->err = "agp_svgp_hyper_rule: unknown optimiser rule";
+        return AGP_ERR_INVALID;
+      }
+    hy_krule = k_rule;
+    hy_krho = k_rho;
+    hy_zrule = z_rule;
+    hy_zrho = z_rho;
+    return AGP_OK;
+  }
   agp_status hyper_configure(int opt_k, double k_eta, int opt_z, double z_eta, double b1, double b2,
                              double eps) override {
     hy_k = opt_k != 0;
@@ -2528,7 +2645,7 @@ struct Svgp : SvgpBase {
       g.k_step += 1;
       hipLaunchKernelGGL((k_adam_kernel_params<T>), dim3(1), dim3(256), 0, st(), (int)D, g.k.ard ? 1 : 0, g.k.has_variance ? 1 : 0,
                          g.k.has_transform ? 1 : 0, (const double*)hy_g, g.scales, g.kadam, g.kadam + (1 + D), g.k_step, hy_keta,
-                         hy_b1, hy_b2, hy_eps);
+                         hy_b1, hy_b2, hy_eps, hy_krule, hy_krho);
       LAUNCHCHK(ctx);
       g.host_params_stale = true;
     }
@@ -2541,7 +2658,7 @@ struct Svgp : SvgpBase {
       }
       g.z_step += 1;
       hipLaunchKernelGGL((k_adam_ascent<T>), grid1(m * D), dim3(256), 0, st(), m * D, g.Z, dZ_dev, g.z_am, g.z_av, g.z_step,
-                         hy_zeta, hy_b1, hy_b2, hy_eps);
+                         hy_zeta, hy_b1, hy_b2, hy_eps, hy_zrule, hy_zrho);
       LAUNCHCHK(ctx);
     }
     return AGP_OK;
@@ -3029,8 +3146,6 @@ struct Svgp : SvgpBase {
       ph.eta1 = g.eta1;
       ph.kinv_mu0 = pend.kinv_mu0;
       ph.lr = pend.lr;
-      pend.on = false;
-      n_prologue += 1;
     } else if (g.la_state != 0) {  // La holds a factor: rebuild -2*eta2
       hipLaunchKernelGGL((k_copy2d<T>), grid2(mp, mp), blk2, 0, st(), (const T*)g.eta2, mp, mp, mp, g.La, mp, mp, mp,
                          T(1), T(-2));
@@ -3048,6 +3163,10 @@ struct Svgp : SvgpBase {
     src.want_x = with_x ? 1 : 0;
     AGPCHK(potrf_fused<T>(ctx, g.La, mp, mp, g.Xa, mp, g.DgA, g.Wbuf, mp, Bq / TILE + 1, with_x, info_dev, m,
                           (const T*)g.eta1, false, &src, nullptr, nullptr, use_pro ? &ph : nullptr));
+    if (use_pro) {  // taken by the launch (a refused launch leaves it pending for flush())
+      pend.on = false;
+      n_prologue += 1;
+    }
     AGPCHK(timing_end(chol_use_dag(ctx, mp / TILE, Bq / TILE + 1) ? 1 : chol_launch_count(mp / TILE, Bq / TILE + 1)));
     g.la_state = 1;
     g.xa_valid = with_x != 0;
@@ -3117,6 +3236,13 @@ struct Svgp : SvgpBase {
       HIPCHK(ctx, hipMemsetAsync(flags_dev, 0, sizeof(int), st()));
     }
     if (infoK != 0) HIPCHK(ctx, hipMemsetAsync(infoK_dev, 0, sizeof(int32_t), st()));
+    // a non-SPD K_ZZ latched by a refresh inside the training loop is the ROOT cause of whatever followed it on a garbage inverse
+    // (negative K~, NaNs, a non-SPD -2 eta2): it is reported first, like the PosDefException the reference raises at that refresh
+    if (infoK > 0) {
+      for (auto& q : lat) q.K_stale = true;
+      ctx->err = "PosDefException: K_ZZ + jitter*I is not positive definite; leading minor " + std::to_string(infoK);
+      return AGP_ERR_NOT_POSDEF;
+    }
     if (flags & FLAG_NEG_KTILDE) {
       ctx->err = "K~ has negative values";  // latentgp.jl:213
       return AGP_ERR_NEG_KTILDE;
@@ -3135,11 +3261,6 @@ struct Svgp : SvgpBase {
     }
     if (info != 0) {
       ctx->err = "PosDefException: -2*eta2 is not positive definite; leading minor " + std::to_string(info);
-      return AGP_ERR_NOT_POSDEF;
-    }
-    if (infoK > 0) {  // latched by a kernel refresh inside the training loop (the hyper step moved the kernel / Z)
-      for (auto& q : lat) q.K_stale = true;
-      ctx->err = "PosDefException: K_ZZ + jitter*I is not positive definite; leading minor " + std::to_string(infoK);
       return AGP_ERR_NOT_POSDEF;
     }
     if (infoK < 0) {
@@ -3900,6 +4021,10 @@ struct Svgp : SvgpBase {
       }
       return hyper_finish();
     }
+    if (batch_sharded && (!cm || cm->world != bs_world)) {  // (the Gaussian-KL part enters with weight 1 / world: without the
+      ctx->err = "tied hyper step of a batch-sharded handle needs the communicator of the run";  // all-reduce the step is wrong)
+      return AGP_ERR_INVALID;
+    }
     HIPCHK(ctx, hipMemsetAsync(hy_tied, 0, sizeof(double) * ng, st()));
     std::vector<double> hs(1 + D, 0.0);
     for (int l = 0; l < nl; ++l) {
@@ -4015,6 +4140,12 @@ agp_status agp_ctx_destroy(agp_ctx* ctx) {
     if (ctx->tri_scratch) (void)hipFree(ctx->tri_scratch);
   }
   if (ctx->kmm_scratch) (void)hipFree(ctx->kmm_scratch);
+  if (ctx->chain_stream) {
+    (void)hipStreamSynchronize(ctx->chain_stream);
+    (void)hipStreamDestroy(ctx->chain_stream);
+  }
+  if (ctx->chain_go) (void)hipFree(ctx->chain_go);
+  if (ctx->chain_done) (void)hipEventDestroy(ctx->chain_done);
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -4621,6 +4752,11 @@ agp_status agp_svgp_mo_predict_from_f(agp_svgp* h, int64_t n_t, int32_t mode, vo
   HCHKF(h);
   return h->impl->mo_predict_from_f(n_t, mode, out0, out1, gh_nodes_host, gh_weights_host, n_nodes);
 }
+agp_status agp_svgp_hyper_rule(agp_svgp* h, int32_t kernel_rule, double kernel_rho, int32_t z_rule, double z_rho) {
+  HCHK(h);
+  return h->impl->hyper_rule(kernel_rule, kernel_rho, z_rule, z_rho);
+}
+
 agp_status agp_svgp_hyper_configure(agp_svgp* h, int32_t opt_kernel, double kernel_eta, int32_t opt_Z, double z_eta,
                                     double adam_b1, double adam_b2, double adam_eps) {
   HCHKF(h);

@@ -1302,6 +1302,10 @@ __device__ __forceinline__ bool dag_wait(const int32_t* f0, const int32_t* f1, i
 struct DagSync {
   int32_t* started = nullptr;
   int32_t seq = 0;
+  // split launch (ROLE 1 / 2 of k_chol_dag): the chain kernel sits on its own stream and may be dispatched before the kernels that
+  // precede the tile kernel on the step's stream are done; it waits for `go` == go_val, which the tile kernel stores when it starts
+  int32_t* go = nullptr;
+  int32_t go_val = 0;
 };
 
 // Self-test for the hand-over below, run once per handle on the two streams at the same time: each side raises its own word
@@ -1396,6 +1400,7 @@ struct ChainPrefetch {
   const T* lsrc;   // LDS: L(k, k-1), still to be stored to its real home in A (nullptr: none)
   T* gL;           // A + (k * TILE) * ld + (k - 1) * TILE
   int ld_i;
+  bool coh = false;  // the chain runs as a kernel of its own: its plain stores would only become visible when THAT kernel ends
   T v[TILE * TILE / 256];
   __device__ __forceinline__ void operator()(int round) {
     const int t = (int)threadIdx.x - 256;
@@ -1405,7 +1410,8 @@ struct ChainPrefetch {
 #pragma unroll
         for (int q = 0; q < TILE * TILE / 512; ++q) {
           const int e = t + (2 * q + round) * 256;
-          gDg[e] = dgsrc[(e >> 6) * LDP + (e & 63)];
+          if (coh) __hip_atomic_store(gDg + e, dgsrc[(e >> 6) * LDP + (e & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else gDg[e] = dgsrc[(e >> 6) * LDP + (e & 63)];
         }
       }
       return;
@@ -1588,14 +1594,34 @@ __device__ __forceinline__ void pro_slice(const T* __restrict__ kap, int64_t ldk
 
 // STEP: the launch of a CAVI step (no identity rows, X_k and L not wanted in their real homes) with those three facts known at
 // compile time -- the general form carries the code and the registers of all of them through the chain.
-template <typename T, bool FUSED, bool BATCH = false, bool TRACE = false, bool STEP = false, bool PRO = false>
-__global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ldx,
+// ROLE (round 4): 0 = the whole task graph in one kernel.  1 / 2 = the same graph as TWO kernels -- the chain workgroup(s) alone
+// (ROLE 1, one workgroup per problem, on a high-priority stream of its own) and every other tile (ROLE 2, on the step's stream) --
+// with the same flags, sentinels and epochs.  The chain's tile elimination needs 176-255 VGPRs, which held the merged kernel to one
+// 512-thread workgroup per CU; the tile kernel alone compiles to <= 128 (f64) / <= 80 (f32) and runs 2 - 3 workgroups per CU, which
+// is what a launch of 1500+ tiles (C3, C4) is short of.  The chain kernel may start before the work in front of the tile kernel
+// has finished: it polls DagSync::go (stored by the tile kernel's first workgroup) and then drops its caches.
+#ifndef AGP_TILES_WAVES_F64
+#define AGP_TILES_WAVES_F64 4
+#endif
+#ifndef AGP_TILES_WAVES_F32
+#define AGP_TILES_WAVES_F32 6
+#endif
+// (with the prologue a tile workgroup stages four LDS tiles: 135 KB in f64 = one workgroup per CU whatever the registers,
+//  68 KB in f32 = two)
+template <typename T, int ROLE, bool PRO>
+constexpr int dag_min_waves() {
+  return ROLE != 2 ? 1 : PRO ? (sizeof(T) == 8 ? 2 : 4) : (sizeof(T) == 8 ? AGP_TILES_WAVES_F64 : AGP_TILES_WAVES_F32);
+}
+template <typename T, bool FUSED, bool BATCH = false, bool TRACE = false, bool STEP = false, bool PRO = false, int ROLE = 0>
+__global__ __launch_bounds__(CHOL_THREADS, (dag_min_waves<T, ROLE, PRO>()))
+void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ldx,
                                                            int64_t lde, int64_t ne, int64_t nt,
                                                            int32_t* __restrict__ info, int64_t nvalid, int32_t* flags,
                                                            int32_t epoch, unsigned long long* trace, T* H, int64_t hstride,
                                                            int64_t nx_, const T* __restrict__ erow, int opts, DagSync sync,
                                                            ProArgs<T> pro = ProArgs<T>{}, EpiArgs<T> epi = EpiArgs<T>{}) {
   static_assert(!PRO || (FUSED && !BATCH), "the prologue exists for single-problem launches with a chain workgroup only");
+  static_assert(ROLE == 0 || (FUSED && STEP && !TRACE), "the split launch exists for the CAVI step's launches");
   // opts bit 0: the chain also stores X_k to its real home (a single block column wanting its inverse: no identity rows run)
   //      bit 1: the factor L is wanted in its real home A as well (K's factor, the potrf entry points); the CAVI step only
   //             consumes the extension rows W, v and never reads L itself, so its launches skip those stores
@@ -1627,10 +1653,24 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   // nx = nt: also X = L^-1 in full.  L^-T = I L^-T, so nt more extension block rows holding the identity give X' column by
   // column with the same task graph and off the critical path (row i: tiles (i, c), c >= i; the others stay zero and have
   // no workgroup).  They recurse through their hand-over slots (rows nt + ne + i) and are stored transposed into X.
-  __shared__ __attribute__((aligned(16))) T sm[(FUSED ? 4 : 2) * TILE * LDP];
-  __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
+  __shared__ __attribute__((aligned(16))) T sm[((FUSED && ROLE != 2) || PRO ? 4 : 2) * TILE * LDP];
+  __shared__ __attribute__((aligned(16))) T sc[(ROLE == 2 && !PRO) ? TILE : SC_ELEMS];
   __shared__ T piv[TILE];
   __shared__ int wait_ok, pf_ok, pf_bad;
+  if (ROLE == 1) {  // the chain as a kernel of its own: wait until the tile kernel runs (= everything before it on its stream is done)
+    if (threadIdx.x == 0 && sync.go) {
+      long spins = 0;
+      while (__hip_atomic_load(sync.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != sync.go_val) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1L << 26)) {  // about a minute: the tile kernel never started
+          atomicExch(info, -2);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this kernel's caches may predate what those kernels wrote
+  }
   T* bufA = sm;
   T* bufB = sm + TILE * LDP;
   const int tid = threadIdx.x;
@@ -1639,7 +1679,9 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   int64_t b = bidx, c = 0;
   bool helper = false;
   int64_t hbase = 0;  // PRO: helper slots of the columns before c
-  if (PRO) {
+  if (PRO && ROLE == 1) {
+    // the chain kernel: tile (0, 0), whose place in the tile kernel comes right after the helpers of block column 0 (hbase = 0)
+  } else if (PRO) {
     for (;;) {
       if (c == nt) {  // trailing workgroups: the hand-over set the launch before this one used gets its sentinels back
         const T sv = __builtin_bit_cast(T, Sent<T>::bits);
@@ -1706,8 +1748,13 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   if (TRACE && tid == 0) trace[chain_slot(col, nt, ne, nx) * 8 + (slot)] = wall_clock64()
   DAG_TR(0);
   const bool chain = FUSED && c == 0 && b == 0;  // (PRO: no longer workgroup 0 -- the helpers of column 0 come first)
-  if (STEP && !BATCH && sync.started && chain && tid == 0)
+  if (STEP && !BATCH && sync.started && chain && tid == 0 && ROLE != 1)
     __hip_atomic_store(sync.started, sync.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (ROLE == 2 && chain) {  // the chain's place in the tile kernel: it is the first workgroup to run, so it releases the chain kernel
+    if (tid == 0 && sync.go) __hip_atomic_store(sync.go, sync.go_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  if (ROLE == 1 && !chain) return;
   Acc8<T> acc;
   if (PRO && !ext) {
     // ---- prologue of a matrix tile: S(R, c) (own k-slice + the helpers' partial tiles), the eta2 step, A = -2 eta2 -> acc
@@ -1834,7 +1881,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
   } else {
     acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = rowp[r * ldr + c0 + cc]; });
   }
-  if (chain) {
+  if (ROLE != 2 && chain) {
     // ---- the chain: ONE workgroup carries the critical path through all columns, so that per column only the tile
     // factorisation and two 64^3 products are serial:  factor(c) -> L(c+1,c) = T X_c' -> S = D - L L' -> factor(c+1).
     // T = tile (c+1, c) and D = tile (c+1, c+1) arrive with all their other updates already applied by feeder workgroups.
@@ -1859,6 +1906,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
       pf.lsrc = (k >= 1 && store_l) ? bufC : nullptr;  // L(k, k-1) stays in bufC until the prefetch of round 5 overwrites it
       pf.gL = A + k0 * ld + (k0 - TILE);
       pf.ld_i = (int)ld;
+      pf.coh = ROLE == 1;
       if (tid == 0) pf_ok = pf_bad = 0;
       factor_diag_tile_2lvl<T, ChainPrefetch<T>>(bufA, bufB, sc, piv, info, k0, nvalid, pf);
       DAG_TRC(k, 2);
@@ -1882,7 +1930,10 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
         // (the real X block is only read when the full inverse was requested, and then the identity-row tile (k, k) writes it)
       }
       if (k + 1 == nt) {
-        for (int e = tid; e < TILE * TILE; e += CHOL_THREADS) Dg[k * TILE * TILE + e] = bufA[(e >> 6) * LDP + (e & 63)];
+        for (int e = tid; e < TILE * TILE; e += CHOL_THREADS) {
+          if (ROLE == 1) __hip_atomic_store(Dg + k * TILE * TILE + e, bufA[(e >> 6) * LDP + (e & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else Dg[k * TILE * TILE + e] = bufA[(e >> 6) * LDP + (e & 63)];
+        }
         dag_signal(xready + k * DAG_FS, epoch);
         DAG_TRC(k, 3);
         return;
@@ -1969,6 +2020,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
     }
     return;
   }
+  if (ROLE == 1) return;
   const bool f1 = FUSED && b == 1 && !ext;  // tile (c+1, c): feeds the chain instead of waiting for X_c itself
   const bool f2 = FUSED && diag;            // diagonal tile (c, c), c >= 1: the chain applies the last update itself
   const int64_t jend = f2 ? c - 1 : c;
@@ -2020,7 +2072,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_chol_dag(CholBatch<T> bt, int 
     return;
   }
   acc8_foreach<T>(acc, [&](int r, int cc, T& val) { bufA[r * LDP + cc] = val; });
-  if (diag) {
+  if (!FUSED && diag) {  // (FUSED: the chain factors every diagonal tile; tile (c, c) left above as its feeder)
     __syncthreads();
     factor_diag_tile_2lvl<T>(bufA, bufB, sc, piv, info, c0, nvalid);
     DAG_TR(2);

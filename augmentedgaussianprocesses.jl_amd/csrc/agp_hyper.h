@@ -97,6 +97,26 @@ __global__ void k_hyper_gK(int64_t m, int64_t mp, const T* __restrict__ M1, cons
   out[i * mp + j] = v;
 }
 
+// The optimiser rules the reference may be handed for its hyper-parameters (any Optimisers.jl rule, autotuning_utils.jl:47-82;
+// unvendored, restated from the package's documented update rules): dx' = apply(rule, state, dx), which the reference ADDS
+//   rule 0  ADAM(eta, (b1, b2), eps)   m = b1 m + (1 - b1) dx ; v = b2 v + (1 - b2) dx^2 ; dx' = eta mhat / (sqrt(vhat) + eps)
+//   rule 1  Descent(eta)               dx' = eta dx
+//   rule 2  Momentum(eta, rho)         vel = rho vel + eta dx ; dx' = vel          (the velocity lives in the first-moment slot)
+__device__ __forceinline__ double opt_rule_delta(int rule, double g, double* am, double* av, int step, double eta, double b1,
+                                                 double b2, double eps, double rho) {
+  if (rule == 1) return eta * g;
+  if (rule == 2) {
+    const double vel = rho * am[0] + eta * g;
+    am[0] = vel;
+    return vel;
+  }
+  const double m = b1 * am[0] + (1.0 - b1) * g, v = b2 * av[0] + (1.0 - b2) * g * g;
+  am[0] = m;
+  av[0] = v;
+  const double mh = m / (1.0 - pow(b1, (double)step)), vh = v / (1.0 - pow(b2, (double)step));
+  return eta * mh / (sqrt(vh) + eps);
+}
+
 // update_kernel! (autotuning_utils.jl:47-67) on the device: ADAM ASCENT on [variance | scale(s)] in log space,
 //   x <- exp(log x + ADAM(x .* g)) ,
 // from the gradient g = [dvariance, dscale_0 .. dscale_{D-1}] (doubles, w.r.t. the parameters themselves) left by the backward pass.
@@ -107,7 +127,7 @@ __global__ void k_hyper_gK(int64_t m, int64_t mp, const T* __restrict__ M1, cons
 template <typename T>
 __global__ void k_adam_kernel_params(int D, int ard, int has_variance, int has_transform, const double* __restrict__ g,
                                      T* __restrict__ params, double* __restrict__ am, double* __restrict__ av, int step, double eta,
-                                     double b1, double b2, double eps) {
+                                     double b1, double b2, double eps, int rule = 0, double rho = 0.0) {
   const int np = 1 + (ard ? D : 1);
   const int j = threadIdx.x;
   if (j >= np) return;
@@ -122,11 +142,7 @@ __global__ void k_adam_kernel_params(int D, int ard, int has_variance, int has_t
     for (int d = 0; d < D; ++d) sgm += g[1 + d];
     gl = has_transform ? p * sgm : 0.0;
   }
-  const double m = b1 * am[j] + (1.0 - b1) * gl, v = b2 * av[j] + (1.0 - b2) * gl * gl;
-  am[j] = m;
-  av[j] = v;
-  const double mh = m / (1.0 - pow(b1, (double)step)), vh = v / (1.0 - pow(b2, (double)step));
-  const double np_ = exp(log(p) + eta * mh / (sqrt(vh) + eps));
+  const double np_ = exp(log(p) + opt_rule_delta(rule, gl, am + j, av + j, step, eta, b1, b2, eps, rho));
   if (j == 0) {
     if (has_variance) params[D] = (T)np_;
     else am[0] = av[0] = 0.0;
@@ -367,15 +383,11 @@ __global__ void k_double_to(int64_t n, const double* __restrict__ a, T* __restri
 // ADAM ascent on Z (update_Z!, autotuning_utils.jl:70-76): z += eta * mhat / (sqrt(vhat) + eps)
 template <typename T>
 __global__ void k_adam_ascent(int64_t n, T* __restrict__ z, const T* __restrict__ g, double* __restrict__ am,
-                              double* __restrict__ av, int step, double eta, double b1, double b2, double eps) {
+                              double* __restrict__ av, int step, double eta, double b1, double b2, double eps, int rule = 0,
+                              double rho = 0.0) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
-  double gi = (double)g[i];
-  double m = b1 * am[i] + (1.0 - b1) * gi, v = b2 * av[i] + (1.0 - b2) * gi * gi;
-  am[i] = m;
-  av[i] = v;
-  double mh = m / (1.0 - pow(b1, (double)step)), vh = v / (1.0 - pow(b2, (double)step));
-  z[i] = (T)((double)z[i] + eta * mh / (sqrt(vh) + eps));
+  z[i] = (T)((double)z[i] + opt_rule_delta(rule, (double)g[i], am + i, av + i, step, eta, b1, b2, eps, rho));
 }
 
 // C(M x N) = A(K x M)^T B(K x N)  (both operands row-contiguous; general, non-symmetric).  grid = (N/64, M/64)

@@ -35,8 +35,10 @@ class GaussianLikelihood(AbstractLikelihood):
             self.noise_eta = 0.05 if opt_noise else 0.0
         else:
             eta = getattr(opt_noise, "eta", None)
-            if eta is None or tuple(getattr(opt_noise, "beta", (0.9, 0.999))) != (0.9, 0.999):
-                raise NotImplementedError("opt_noise takes ADAM(eta) with the default moments")
+            if (eta is None or tuple(getattr(opt_noise, "beta", (0.9, 0.999))) != (0.9, 0.999)
+                    or float(getattr(opt_noise, "eps", 1e-8)) != 1e-8):
+                # (the device kernel k_noise_finish carries Optimisers.ADAM's default moments and epsilon as constants)
+                raise NotImplementedError("opt_noise takes ADAM(eta) with the default moments and epsilon")
             self.noise_eta = float(eta)
 
     @property

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import kernels as K
 from . import likelihoods as LK
-from .svgp import ADAM, MOSVGP, SVGP, AnalyticSVI, AnalyticVI, RobbinsMonro
+from .svgp import ADAM, MOSVGP, SVGP, AnalyticSVI, AnalyticVI, Descent, Momentum, RobbinsMonro
 
 _KERNELS = {"SqExponentialKernel": K.SqExponentialKernel, "Matern52Kernel": K.Matern52Kernel,
             "Matern32Kernel": K.Matern32Kernel, "ExponentialKernel": K.ExponentialKernel}
@@ -35,9 +35,31 @@ def _kernel_from(spec):
     return spec["variance"] * k if spec.get("has_variance", True) else k
 
 
+def _opt_spec(o):
+    if o is None:
+        return None
+    d = {"rule": type(o).__name__, "eta": o.eta}
+    for a in ("rho", "beta", "eps"):
+        if hasattr(o, a):
+            d[a] = getattr(o, a)
+    return d
+
+
+def _opt_from(d):
+    if not d:
+        return False
+    if not isinstance(d, dict):  # files written before the rule was stored: ADAM(eta)
+        return ADAM(d)
+    if d["rule"] == "Descent":
+        return Descent(d["eta"])
+    if d["rule"] == "Momentum":
+        return Momentum(d["eta"], d["rho"])
+    return ADAM(d["eta"], tuple(d.get("beta", (0.9, 0.999))), d.get("eps", 1e-8))
+
+
 def _lik_spec(l):
     d = {"type": type(l).__name__}
-    for a in ("sigma2", "nu", "sigma", "beta", "lam", "r", "n_class", "class_mapping"):
+    for a in ("sigma2", "noise_eta", "nu", "sigma", "beta", "lam", "r", "n_class", "class_mapping"):
         if hasattr(l, a):
             v = getattr(l, a)
             d[a] = v if not isinstance(v, np.generic) else v.item()
@@ -47,7 +69,8 @@ def _lik_spec(l):
 def _lik_from(d):
     t = d["type"]
     if t == "GaussianLikelihood":
-        return LK.GaussianLikelihood(d["sigma2"])
+        eta = d.get("noise_eta", 0.0)  # opt_noise: the model keeps optimising its noise after a reload (ADAM moments restart)
+        return LK.GaussianLikelihood(d["sigma2"], opt_noise=ADAM(eta) if eta else False)
     if t == "LogisticLikelihood":
         return LK.LogisticLikelihood()
     if t == "StudentTLikelihood":
@@ -82,8 +105,9 @@ def save_trained_model(filename: str, model: SVGP) -> None:
         "likelihood": [_lik_spec(l) for l in model.likelihood.likelihoods] if mo else _lik_spec(model.likelihood),
         "stochastic": bool(inf.stoch), "batchsize": int(inf.batchsize), "n_iter": int(inf.n_iter),
         "rm": [opt.kappa, opt.tau], "T": str(model.T), "elbo_mode": model.elbo_mode,
-        "k_opt": model.k_opt.eta if model.k_opt else None, "z_opt": model.z_opt.eta if model.z_opt else None,
+        "k_opt": _opt_spec(model.k_opt), "z_opt": _opt_spec(model.z_opt),
         "atfrequency": model.atfrequency, "mean": model.mean if np.isscalar(model.mean) or model.mean is None else None,
+        "jitter": getattr(model, "jitter", None), "stale_K": bool(getattr(model, "reference_compat_stale_K", False)),
     }
     import ctypes as C
 
@@ -119,9 +143,11 @@ def load_trained_model(filename: str, *, device=None):
     inf = AnalyticSVI(meta["batchsize"], optimiser=RobbinsMonro(*meta["rm"])) if meta["stochastic"] else AnalyticVI()
     T = np.float64 if "64" in meta["T"] else np.float32
     mean = g["mean_vec"] if "mean_vec" in g.files else meta.get("mean")
-    kw = dict(optimiser=ADAM(meta["k_opt"]) if meta["k_opt"] else False, Zoptimiser=ADAM(meta["z_opt"]) if meta["z_opt"] else False,
-              atfrequency=meta["atfrequency"], mean=mean, T=T, device=device, elbo_mode=meta["elbo_mode"])
+    kw = dict(optimiser=_opt_from(meta["k_opt"]), Zoptimiser=_opt_from(meta["z_opt"]),
+              atfrequency=meta["atfrequency"], mean=mean, T=T, device=device, elbo_mode=meta["elbo_mode"],
+              jitter=meta.get("jitter"), reference_compat_stale_K=meta.get("stale_K", False))
     if meta["class"] == "MOSVGP":
+        kw.pop("jitter"), kw.pop("reference_compat_stale_K")  # (not constructor arguments of the multi-output model)
         model = MOSVGP(kernels, [_lik_from(d) for d in meta["likelihood"]], inf, Zs, A=g["A"], Aoptimiser=False, **kw)
     else:
         model = SVGP(kernels, _lik_from(meta["likelihood"]), inf, Zs, **kw)

@@ -61,6 +61,29 @@ class ADAM:
         self.eta, self.beta, self.eps = float(eta), (float(beta[0]), float(beta[1])), float(eps)
 
 
+class Descent:
+    """Descent(η=0.1) of Optimisers.jl: dx' = η dx (the reference adds it: ascent on the ELBO, autotuning_utils.jl:63-76)."""
+
+    def __init__(self, eta: float = 0.1):
+        self.eta = float(eta)
+
+
+class Momentum:
+    """Momentum(η=0.01, ρ=0.9) of Optimisers.jl: vel = ρ vel + η dx ; dx' = vel."""
+
+    def __init__(self, eta: float = 0.01, rho: float = 0.9):
+        self.eta, self.rho = float(eta), float(rho)
+
+
+def _opt_rule(o):
+    """(rule, rho) of agp_svgp_hyper_rule for an optimiser object"""
+    if isinstance(o, Descent):
+        return capi.OPT_DESCENT, 0.0
+    if isinstance(o, Momentum):
+        return capi.OPT_MOMENTUM, o.rho
+    return capi.OPT_ADAM, 0.0
+
+
 class _MultiOutputLikelihood(AbstractLikelihood):
     """Tuple of task likelihoods of a MOSVGP (nf_per_task = 1 on this path)."""
 
@@ -146,8 +169,12 @@ class SVGP:
         if isinstance(Zoptimiser, bool):
             Zoptimiser = ADAM(0.001) if Zoptimiser else None  # SVGP.jl:61-65
         for o in (optimiser, Zoptimiser):
-            if o is not None and not isinstance(o, ADAM):
-                raise NotImplementedError("only ADAM is wired as hyper-parameter optimiser")
+            if o is not None and not isinstance(o, (ADAM, Descent, Momentum)):
+                # the reference hands any Optimisers.jl rule to Optimisers.apply (autotuning_utils.jl:47-82); the device carries these
+                raise NotImplementedError("hyper-parameter optimisers on the device: ADAM, Descent, Momentum")
+        adams = [o for o in (optimiser, Zoptimiser) if isinstance(o, ADAM)]
+        if len(adams) == 2 and (adams[0].beta != adams[1].beta or adams[0].eps != adams[1].eps):
+            raise NotImplementedError("optimiser and Zoptimiser share one pair of ADAM moments / epsilon on the device")
         self.k_opt, self.z_opt = optimiser, Zoptimiser
         # A non-zero prior mean together with hyper-parameter optimisation: the reference constructs such a model and runs until
         # its first hyper step (n_iter >= 3, training.jl:65-69), where the prior-mean update calls update!(mu0, grad, state) against
@@ -304,11 +331,13 @@ class SVGP:
                                                          weights.ctypes.data_as(C.POINTER(C.c_double)), len(nodes)))
         if getattr(self, "_batch_shard", None) is not None:  # a re-created handle keeps its place in a batch-parallel run
             self._chk(capi.lib().agp_svgp_set_batch_shard(h, *self._batch_shard))
-        o = self.k_opt or self.z_opt
-        if o is not None:
+        if self.k_opt is not None or self.z_opt is not None:
+            o = next((q for q in (self.k_opt, self.z_opt) if isinstance(q, ADAM)), ADAM())
             self._chk(capi.lib().agp_svgp_hyper_configure(
                 h, 1 if self.k_opt else 0, self.k_opt.eta if self.k_opt else 0.0, 1 if self.z_opt else 0,
                 self.z_opt.eta if self.z_opt else 0.0, o.beta[0], o.beta[1], o.eps))
+            (kr, krho), (zr, zrho) = _opt_rule(self.k_opt), _opt_rule(self.z_opt)
+            self._chk(capi.lib().agp_svgp_hyper_rule(h, kr, krho, zr, zrho))
 
     def _pre_destroy(self):
         self._pull_hypers()
@@ -587,35 +616,52 @@ def train_(model: SVGP, X, y, iterations: int = 100, *, callback: Optional[Calla
 
     nxt = draw(1) if inf.stoch else None
     while True:
-        if inf.stoch:
-            idx = nxt
-            idx_ptr = C.c_void_p(idx.data_ptr())
-            model._keep = [idx]
-        else:
-            idx_ptr = None
-        model._chk(L.agp_svgp_cavi_step(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(yd.data_ptr()),
-                                        idx_ptr, B, inf.rho))
-        model.trained = True
-        model._last_idx = idx_ptr
-        hyper_on = model.k_opt is not None or model.z_opt is not None
-        if inf.stoch and local_iter < iterations:
-            nxt = draw(local_iter + 1)
-            model._keep.append(nxt)
-            if not hyper_on:  # look-ahead: next minibatch's kappa on the second stream (pointless if K is about to change)
-                model._chk(L.agp_svgp_prefetch(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0),
-                                               C.c_void_p(nxt.data_ptr()), B))
-        if callback is not None:
-            callback(model, State(model), inf.n_iter)
-        # training.jl:65-69 (n_iter is the counter before this iteration's increment)
-        if hyper_on and inf.n_iter % model.atfrequency == 0 and inf.n_iter >= 3 and local_iter != iterations:
-            _hyper_step_guard(model)
-            model._chk(L.agp_svgp_hyper_step(h))
-        if model.verbose > 2 or (model.verbose > 1 and local_iter % 10 == 0):
-            print(f"iter {local_iter}  ELBO {objective(model, State(model), None):.6f}")
-        local_iter += 1
-        inf.n_iter += 1
-        if local_iter > iterations:
+        stepped = False  # this iteration's variational update has been enqueued (the device's own counters have moved on)
+        try:
+            if inf.stoch:
+                idx = nxt
+                idx_ptr = C.c_void_p(idx.data_ptr())
+                model._keep = [idx]
+            else:
+                idx_ptr = None
+            model._chk(L.agp_svgp_cavi_step(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(yd.data_ptr()),
+                                            idx_ptr, B, inf.rho))
+            stepped = True
+            model.trained = True
+            model._last_idx = idx_ptr
+            hyper_on = model.k_opt is not None or model.z_opt is not None
+            if inf.stoch and local_iter < iterations:
+                nxt = draw(local_iter + 1)
+                model._keep.append(nxt)
+                if not hyper_on:  # look-ahead: next minibatch's kappa on the second stream (pointless if K is about to change)
+                    model._chk(L.agp_svgp_prefetch(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0),
+                                                   C.c_void_p(nxt.data_ptr()), B))
+            if callback is not None:
+                callback(model, State(model), inf.n_iter)
+            # training.jl:65-69 (n_iter is the counter before this iteration's increment)
+            if hyper_on and inf.n_iter % model.atfrequency == 0 and inf.n_iter >= 3 and local_iter != iterations:
+                _hyper_step_guard(model)
+                model._chk(L.agp_svgp_hyper_step(h))
+            if model.verbose > 2 or (model.verbose > 1 and local_iter % 10 == 0):
+                # (the reference drives a ProgressMeter with the same two values, training.jl:71-90)
+                print(f"iter {local_iter}  ELBO {objective(model, State(model), None):.6f}")
+            local_iter += 1
+            inf.n_iter += 1
+            if local_iter > iterations:
+                break
+        except KeyboardInterrupt:
+            # training.jl:95-101: InterruptException -> warn, leave the loop, still finish with compute_Ks.  The work enqueued so far
+            # stays valid: a variational update that was already issued counts as done (its Robbins-Monro step has been taken on the
+            # device), the pending natural-gradient step is taken by check_status below, and `state=` continues from there.
+            import warnings
+
+            warnings.warn(f"Training interrupted by user at iteration {local_iter}")
+            if stepped:
+                local_iter += 1
+                inf.n_iter += 1
             break
+    if model.verbose > 0:  # training.jl:103-105
+        print(f"Training ended after {local_iter - 1} iterations. Total number of iterations {inf.n_iter}")
     model._chk(L.agp_svgp_check_status(h))
     model._chk(L.agp_svgp_refresh_K(h))  # compute_Ks(model), training.jl:107: final kernel matrices for predictions
     model._pull_hypers()

@@ -239,6 +239,12 @@ agp_status agp_svgp_step_local(agp_svgp* h, const void* x, int64_t ldx, const vo
  *   get_kernel      : current variance and per-dimension scales */
 agp_status agp_svgp_hyper_configure(agp_svgp* h, int32_t opt_kernel, double kernel_eta, int32_t opt_Z, double z_eta,
                                     double adam_b1, double adam_b2, double adam_eps);
+/*   hyper_rule      : which Optimisers.jl rule `optimiser` / `Zoptimiser` are (the reference hands whatever rule it is given to
+ *                     Optimisers.apply, src/hyperparameter/autotuning_utils.jl:47-82): ADAM (default; eta and the moments from
+ *                     hyper_configure), Descent(eta): dx' = eta dx, Momentum(eta, rho): vel = rho vel + eta dx, dx' = vel.
+ *                     The optimiser state exported by agp_svgp_hyper_opt_state holds the velocity in the first-moment slot. */
+enum { AGP_OPT_ADAM = 0, AGP_OPT_DESCENT = 1, AGP_OPT_MOMENTUM = 2 };
+agp_status agp_svgp_hyper_rule(agp_svgp* h, int32_t kernel_rule, double kernel_rho, int32_t z_rule, double z_rho);
 agp_status agp_svgp_hypergrad(agp_svgp* h, int32_t latent, double* dvariance_host, double* dscale_host, void* dZ);
 agp_status agp_svgp_hyper_step(agp_svgp* h);
 /* the optimiser half of hyper_step with a caller-supplied gradient in the layout of agp_svgp_hypergrad (dZ: device m x D,

@@ -35,6 +35,7 @@ using KernelFunctions
 using LinearAlgebra
 using StatsBase: sample, Weights
 using Random
+using Optimisers
 const AGP = AugmentedGaussianProcesses
 
 import AugmentedGaussianProcesses: train!, predict_f, predict_y, proba_y, ELBO, objective
@@ -253,11 +254,18 @@ function ensure_handle!(hm::HipModel{T}, maxbatch::Int) where {T}
     # hyper-parameter optimisers: SVGP(...; optimiser, Zoptimiser) (SVGP.jl:39-42, default ADAM(0.01) / nothing)
     ko, zo = AGP.opt(gp1), AGP.Zopt(gp1)
     if ko !== nothing || zo !== nothing
-        o = ko === nothing ? zo : ko
+        # the reference hands whatever Optimisers.jl rule it is given to Optimisers.apply (autotuning_utils.jl:47-82); the device
+        # carries ADAM, Descent and Momentum (agp_svgp_hyper_rule), anything else is refused here rather than silently replaced
+        rule(o) = o === nothing || o isa Optimisers.ADAM ? (0, 0.0) : o isa Optimisers.Descent ? (1, 0.0) :
+                  o isa Optimisers.Momentum ? (2, Float64(o.rho)) :
+                  error("hyper-parameter optimiser $(typeof(o)) is not available on the device (ADAM, Descent, Momentum are)")
+        (kr, kρ), (zr, zρ) = rule(ko), rule(zo)
+        adam = ko isa Optimisers.ADAM ? ko : zo isa Optimisers.ADAM ? zo : Optimisers.ADAM()
         check(ctx, ccall((:agp_svgp_hyper_configure, libagp), Int32,
                          (Ptr{Cvoid}, Int32, Float64, Int32, Float64, Float64, Float64, Float64),
                          hm.h, ko === nothing ? 0 : 1, ko === nothing ? 0.0 : ko.eta, zo === nothing ? 0 : 1,
-                         zo === nothing ? 0.0 : zo.eta, o.beta[1], o.beta[2], 1e-8))
+                         zo === nothing ? 0.0 : zo.eta, adam.beta[1], adam.beta[2], 1e-8))
+        check(ctx, ccall((:agp_svgp_hyper_rule, libagp), Int32, (Ptr{Cvoid}, Int32, Float64, Int32, Float64), hm.h, kr, kρ, zr, zρ))
     end
     if old !== nothing
         push_posterior!(hm)
@@ -452,7 +460,10 @@ function train!(hm::HipModel{T}, X::AbstractArray, y, iterations::Int=100; callb
     local_iter = 1
     idd = draw(1)
     while true
+        stepped = false   # this iteration's variational update has been enqueued (the device's own counters have moved on)
+        try
         update_parameters!(hm, idd, ρ)
+        stepped = true
         AGP.set_trained!(model, true)
         # the next minibatch is drawn now and its look-ahead enqueued right behind the step (next to its factorisation) -- unless a
         # hyper step follows: it moves the kernel / Z, a look-ahead against the old ones would be thrown away (agp_svgp_prefetch
@@ -469,6 +480,24 @@ function train!(hm::HipModel{T}, X::AbstractArray, y, iterations::Int=100; callb
         inf.n_iter += 1
         (local_iter <= iterations) || break
         idd = nxt
+        catch e
+            # training.jl:95-101: an InterruptException ends the loop with a warning, everything else is rethrown.  A variational
+            # update that was already enqueued counts (its Robbins-Monro step has been taken on the device); the pending natural-
+            # gradient step is taken by agp_svgp_check_status below, and `state=` continues from there.
+            if isa(e, InterruptException)
+                @warn "Training interrupted by user at iteration $local_iter"
+                if stepped
+                    local_iter += 1
+                    inf.n_iter += 1
+                end
+                break
+            else
+                rethrow(e)
+            end
+        end
+    end
+    if AGP.verbose(model) > 0   # training.jl:103-105
+        @info "Training ended after $(local_iter - 1) iterations. Total number of iterations $(AGP.n_iter(model))"
     end
     check(hm.ctx, ccall((:agp_svgp_check_status, libagp), Int32, (Ptr{Cvoid},), hm.h))
     check(hm.ctx, ccall((:agp_svgp_refresh_K, libagp), Int32, (Ptr{Cvoid},), hm.h))            # compute_Ks, training.jl:107

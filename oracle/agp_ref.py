@@ -1107,6 +1107,33 @@ class Adam:
         return st, self.eta * mh / (np.sqrt(vh) + self.eps)
 
 
+@dataclass
+class Descent:
+    """Optimisers.jl Descent(eta): dx' = eta dx [unvendored; the package's documented rule].  The reference hands whatever rule
+    it is given to Optimisers.apply and ADDS dx' (src/hyperparameter/autotuning_utils.jl:63-76)."""
+    eta: float = 0.1
+
+    def init(self, x):
+        return {}
+
+    def apply(self, st, g):
+        return st, self.eta * g
+
+
+@dataclass
+class Momentum:
+    """Optimisers.jl Momentum(eta, rho): vel = rho vel + eta dx ; dx' = vel [unvendored; the package's documented rule]."""
+    eta: float = 0.01
+    rho: float = 0.9
+
+    def init(self, x):
+        return {"vel": np.zeros_like(x)}
+
+    def apply(self, st, g):
+        st["vel"] = self.rho * st["vel"] + self.eta * g
+        return st, st["vel"].copy()
+
+
 def init_local_vars_single(lik, B):
     """theta / c as the positional buffers of init_local_vars (classification.jl:10-12 etc.), with the `rand` entries that
     are always overwritten before use set to zero."""

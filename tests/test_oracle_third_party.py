@@ -111,3 +111,159 @@ def test_polya_gamma_kl_against_the_series_of_its_laplace_transform():
     assert np.allclose(series, theta, rtol=1e-6)  # (the tail of the series beyond 2e6 terms is ~ b / (4 pi^2 1e6))
     expect = float(np.sum(b * np.log(np.cosh(c / 2)) - c * c / 2 * theta))
     assert R.polya_gamma_kl(b, c, theta) == pytest.approx(expect, rel=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Independent pins for the NON-Gaussian path (round 4).  The augmented-variable CAVI of the reference is coordinate ascent on a
+# bound whose optimum over the local variables is known in closed form from the original papers -- none of the formulas below is
+# taken from the reference or from the oracle: the collapsed bound is written down from the literature, maximised directly over
+# q(u) = N(mu, Sigma) with a generic optimiser (scipy L-BFGS on a torch-autograd objective), and the maximiser is compared with the
+# fixed point the oracle's update equations (analyticVI.jl:143-246 + the likelihood's local_updates!) converge to.
+#   * logistic  (src/likelihood/logistic.jl:39-92): Polya-Gamma augmentation == the Jaakkola-Jordan bound
+#         log sigma(y f) >= log sigma(xi) + (y f - xi) / 2 - lambda(xi) (f^2 - xi^2),  lambda(xi) = tanh(xi / 2) / (4 xi),
+#     tight in xi at xi^2 = E f^2, where it collapses to  log sigma(c) + (y E f - c) / 2,  c = sqrt(E f^2)   (Jaakkola & Jordan 2000;
+#     Wenzel et al. 2019, eq. 9)
+#   * Student-t (src/likelihood/studentt.jl:68-127): scale mixture y | f, w ~ N(f, w), w ~ IG(nu / 2, nu sigma^2 / 2); integrating
+#     the optimal q(w) out of the ELBO leaves  -alpha log c_i + const,  alpha = (nu + 1) / 2,  c_i = (E (y_i - f_i)^2 + nu sigma^2) / 2
+#     (the EM bound of the scale-mixture model)
+#   * logistic-softmax (src/likelihood/logisticsoftmax.jl:55-140): no closed-form collapsed bound; pinned by two properties that tie
+#     the restated UPDATE equations to the separately restated ELBO terms -- every full-batch CAVI sweep increases the ELBO, and at
+#     the fixed point no perturbation of q(u) (local variables re-converged) increases it.
+def _sparse_pieces(kern, X, Z, jitter):
+    m = len(Z)
+    K = kern.matrix(Z) + jitter * np.eye(m)            # latentgp.jl:205-207
+    Knm = kern.matrix(X, Z)
+    kappa = np.linalg.solve(K, Knm.T).T                # latentgp.jl:209-211
+    Kt = kern.diag(X) + jitter - np.sum(kappa * Knm, axis=1)  # :212
+    return K, kappa, Kt
+
+
+def _maximise_collapsed_bound(point_term, K, kappa, Kt, y, mu0, L0):
+    """argmax over (mu, Sigma = L L') of  sum_i point_term(E f_i, Var f_i, y_i) - KL(N(mu, Sigma) || N(0, K))  by L-BFGS"""
+    import torch
+    from scipy.optimize import minimize
+
+    m = len(K)
+    Kt_, kap_, K_, y_ = (torch.tensor(a, dtype=torch.float64) for a in (Kt, kappa, K, y))
+    Kinv = torch.linalg.inv(K_)
+    logdetK = torch.logdet(K_)
+    tril = np.tril_indices(m)
+
+    def unpack(p):
+        mu = p[:m]
+        L = torch.zeros((m, m), dtype=torch.float64)
+        L[tril[0], tril[1]] = p[m:]
+        d = torch.diagonal(L)
+        L = L - torch.diag(d) + torch.diag(torch.exp(d))  # positive diagonal
+        return mu, L
+
+    def neg(p_np):
+        p = torch.tensor(p_np, dtype=torch.float64, requires_grad=True)
+        mu, L = unpack(p)
+        Sig = L @ L.T
+        mf = kap_ @ mu
+        vf = Kt_ + torch.sum((kap_ @ L) ** 2, dim=1)
+        kl = 0.5 * (torch.trace(Kinv @ Sig) + mu @ Kinv @ mu - m + logdetK - 2.0 * torch.sum(torch.log(torch.diagonal(L))))
+        val = -(torch.sum(point_term(mf, vf, y_)) - kl)
+        val.backward()
+        return float(val.detach()), p.grad.numpy().copy()
+
+    p0 = np.concatenate([mu0, np.where(np.eye(m, dtype=bool), np.log(np.abs(L0) + 1e-300), L0)[tril]])
+    res = minimize(neg, p0, jac=True, method="L-BFGS-B", options=dict(maxiter=20000, ftol=1e-16, gtol=1e-10, maxcor=50))
+    with torch.no_grad():
+        mu, L = unpack(torch.tensor(res.x, dtype=torch.float64))
+        return mu.numpy(), (L @ L.T).numpy(), -res.fun
+
+
+def _toy_sparse(rng, N=60, D=2, m=7):
+    X = rng.random((N, D))
+    f = 2.0 * np.sin(4 * X[:, 0]) + 1.5 * X[:, 1] - 1.0
+    Z = X[rng.permutation(N)[:m]].copy()
+    return X, f, Z
+
+
+def test_logistic_cavi_fixed_point_maximises_the_jaakkola_jordan_bound():
+    import torch
+
+    rng = np.random.default_rng(31)
+    X, f, Z = _toy_sparse(rng)
+    y = np.where(f + 0.3 * rng.standard_normal(len(f)) > 0, 1.0, -1.0)
+    kern = R.Kernel("sqexponential", 2.0, 1.5)
+    mdl = R.SVGP(kern, R.LogisticLikelihood(), Z, stochastic=False)
+    mdl.train(X, y, 400, labels_treated=True)
+    g = mdl.latents[0]
+    K, kappa, Kt = _sparse_pieces(kern, X, Z, mdl.jitter)
+
+    def jj(mf, vf, yy):  # the Jaakkola-Jordan bound at its optimal xi^2 = E f^2
+        c = torch.sqrt(mf ** 2 + vf)
+        return torch.nn.functional.logsigmoid(c) + 0.5 * (yy * mf - c)
+
+    mu, Sig, val = _maximise_collapsed_bound(jj, K, kappa, Kt, y, 0.9 * g.mu, np.linalg.cholesky(1.1 * g.Sigma))
+    assert np.max(np.abs(mu - g.mu)) < 2e-6 * np.max(np.abs(g.mu))
+    assert np.max(np.abs(Sig - g.Sigma)) < 2e-6 * np.max(np.abs(g.Sigma))
+    # ... and the oracle's ELBO at its fixed point IS that bound (the augmented terms cancel at the optimal local variables; corrected
+    # mode, analyticVI.jl:255-274 with logistic.jl:70-92) -- up to a constant: the reference writes -N log(2) / 2 (logistic.jl:78)
+    # where the Polya-Gamma identity sigma(z) = exp(z / 2) / (2 cosh(z / 2)) gives -N log 2.  Mirrored by the oracle and the device
+    # (it moves no optimum and no hyper-gradient); recorded here so that the offset is a known quantity, not a surprise.
+    assert mdl.elbo(y) - len(y) * np.log(2.0) / 2 == pytest.approx(val, rel=1e-8)
+
+
+def test_studentt_cavi_fixed_point_maximises_the_scale_mixture_em_bound():
+    import torch
+    from scipy.special import gammaln
+
+    rng = np.random.default_rng(32)
+    X, f, Z = _toy_sparse(rng)
+    nu, sig = 4.0, 0.7
+    y = f + sig * rng.standard_t(nu, len(f))
+    kern = R.Kernel("matern52", 1.5, 2.0)
+    mdl = R.SVGP(kern, R.StudentTLikelihood(nu, sig), Z, stochastic=False)
+    mdl.train(X, y, 600)
+    g = mdl.latents[0]
+    K, kappa, Kt = _sparse_pieces(kern, X, Z, mdl.jitter)
+    alpha = (nu + 1) / 2
+
+    def em(mf, vf, yy):  # log int N(y | f-moments, w) IG(w; nu/2, nu sig^2/2) dw with q(w) optimal = -alpha log c + const
+        c = 0.5 * ((yy - mf) ** 2 + vf + nu * sig ** 2)
+        const = 0.5 * nu * np.log(0.5 * nu * sig ** 2) - gammaln(0.5 * nu) - 0.5 * np.log(2 * np.pi) + gammaln(alpha)
+        return -alpha * torch.log(c) + const
+
+    mu, Sig, val = _maximise_collapsed_bound(em, K, kappa, Kt, y, 0.9 * g.mu, np.linalg.cholesky(1.1 * g.Sigma))
+    assert np.max(np.abs(mu - g.mu)) < 2e-6 * np.max(np.abs(g.mu))
+    assert np.max(np.abs(Sig - g.Sigma)) < 2e-6 * np.max(np.abs(g.Sigma))
+
+
+def test_logisticsoftmax_updates_and_elbo_agree():
+    rng = np.random.default_rng(33)
+    X, f, Z = _toy_sparse(rng, N=90, m=8)
+    y = 1 + np.digitize(f + 0.2 * rng.standard_normal(len(f)), np.quantile(f, [0.33, 0.66]))
+    kern = R.Kernel("sqexponential", 2.0, 1.0)
+    mdl = R.SVGP(kern, R.LogisticSoftMaxLikelihood(3), Z, stochastic=False)
+    yt = R.treat_labels(y, mdl.likelihood)
+    elbos = []
+    mdl.train(X, yt, 150, labels_treated=True, callback=lambda M, it, xb, yb: elbos.append(M.elbo(yb)))
+    e = np.array(elbos)
+    assert np.all(np.diff(e) > -1e-9 * np.abs(e[1:])), "a full-batch CAVI sweep decreased the ELBO"
+    assert abs(e[-1] - e[-2]) < 1e-7 * abs(e[-1])  # converged
+    # local maximum in q(u): perturb (mu, Sigma) of every latent, let the local variables re-converge at the perturbed q(u)
+    # (they have a unique fixed point given q(u)), compare the ELBO
+    import copy
+
+    for trial in range(6):
+        p = copy.deepcopy(mdl)
+        for gp in p.latents:
+            d = 1e-2 * rng.standard_normal(len(gp.mu))
+            S = gp.Sigma + 1e-2 * np.outer(d, d) * np.trace(gp.Sigma)
+            mu = gp.mu + d * np.max(np.abs(gp.mu))
+            gp.eta2 = -0.5 * np.linalg.inv(S)
+            gp.eta1 = -2.0 * gp.eta2 @ mu
+            gp.mu, gp.Sigma = mu, S
+        for _ in range(300):  # one call = one (gamma, alpha) round of logisticsoftmax.jl:55-79
+            p.local_vars = R.local_updates(p.local_vars, p.likelihood, yt, p.mean_f(), p.var_f())
+        assert p.elbo(yt) <= e[-1] + 1e-9 * abs(e[-1])
+    # proba_y of the multi-class likelihoods is the link at the posterior MEAN (multiclass.jl:96-118 ignores the variance)
+    Xt = rng.random((20, X.shape[1]))
+    pr = np.asarray(mdl.proba_y(Xt))                    # (n_test, n_class)
+    mus = np.stack(mdl.predict_f(Xt, cov=False), axis=1)
+    s = 1.0 / (1.0 + np.exp(-mus))
+    assert np.allclose(pr, s / s.sum(axis=1, keepdims=True), atol=1e-12) and np.allclose(pr.sum(axis=1), 1.0)

@@ -85,7 +85,7 @@ def parse():
     p.add_argument("--no-elbo-tol", action="store_true")
     p.add_argument("--no-extras", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
-    p.add_argument("--cpu-elbo-seconds", type=float, default=90.0,
+    p.add_argument("--cpu-elbo-seconds", type=float, default=170.0,
                    help="budget for running the CPU oracle through the smoothed time-to-ELBO rule (0: only extrapolate)")
     p.add_argument("--collective", default="rccl", choices=["rccl", "torch"],
                    help="N > 1: who issues the all-reduces: libagp_hip.so through its own RCCL communicator (default) or a "
@@ -526,6 +526,50 @@ def main():
             #  in short launches; every fraction in this line is against the datasheet peak)
             out["roofline"]["mfma_issue_ubench_tflops"] = round(pk.value, 1)
 
+        # ... with the engine clock and socket power sampled at >= 10 Hz while it runs (tools/clock_sampler.py; outside the timed
+        # region): what "sustained" means on this box.  The clock the rate itself implies (every SIMD issuing back to back:
+        # 256 CUs x 4 SIMDs x 2048 flop per 64-cycle v_mfma_f64_16x16x4, half the cycles in fp32) is printed next to it.
+        if not a.no_extras:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from clock_sampler import ClockSampler
+
+                idle = ClockSampler(local_rank, 20.0).start()
+                time.sleep(0.5)
+                idle_s = idle.stop()
+                smp = ClockSampler(local_rank, 20.0).start()
+                vals, t0s = [], time.perf_counter()
+                while time.perf_counter() - t0s < 3.0:
+                    if L.agp_mfma_peak(model._ctx, capi.F32 if f32 else capi.F64, C.byref(pk)) != 0:
+                        break
+                    vals.append(pk.value)
+                sus = smp.stop()
+                if vals:
+                    tf = float(np.median(vals))
+                    flop_per_cycle = 256 * 4 * 2048 / (32.0 if f32 else 64.0)
+                    out["mfma_sustained"] = {"tflops": round(tf, 1), "calls": len(vals), "seconds": 3.0,
+                                             "implied_clock_mhz": round(tf * 1e12 / flop_per_cycle / 1e6, 0),
+                                             "idle": {k: idle_s[k] for k in ("sclk_mhz", "power_w")}, **sus}
+                # the same readings while the workload's own steps run (2 s)
+                smp = ClockSampler(local_rank, 20.0).start()
+                t0s, j = time.perf_counter(), 0
+                while time.perf_counter() - t0s < 2.0:
+                    for _ in range(50):
+                        if use_multi:
+                            st = L.agp_svgp_cavi_step_multi(h, None, smode, xp, ld, yp, C.c_void_p(idx_all[j % total].data_ptr()), B, rho)
+                        else:
+                            st = L.agp_svgp_cavi_step(h, xp, ld, yp, C.c_void_p(idx_all[j % total].data_ptr()), B, rho)
+                        if st != 0:
+                            capi.check(model._ctx, st)
+                        j += 1
+                        if use_prefetch:
+                            L.agp_svgp_prefetch(h, xp, ld, C.c_void_p(idx_all[j % total].data_ptr()), B)
+                    torch.cuda.synchronize()
+                out["step_clock"] = {"steps": j, **smp.stop()}
+                model._chk(L.agp_svgp_check_status(h))
+            except Exception as ex:  # a missing SMI library must not cost the line
+                out["mfma_sustained"] = {"error": repr(ex)}
+
     single_latent = cfg["lik"] in ("logistic", "studentt")
     # ---- extras (rank 0, single GPU, single-latent configs): hyper-parameter step and streaming prediction ----
     if rank == 0 and world == 1 and single_latent and not a.no_extras:
@@ -608,11 +652,13 @@ def main():
         rng2 = np.random.default_rng(99)
         chunk_np = np.stack([rng2.choice(N, B, replace=False) for _ in range(600)]).astype(np.int64)
         chunk = torch.as_tensor(chunk_np, device=dev)  # 600 distinct minibatches, cycled
-        hit = {"raw": None, "smoothed": None}
-        consec = 0
+        hit = {"raw": None, "smoothed": None, "reach": None}
+        consec = consec_r = 0
+        TOL_R = 1e-3  # the "reachable" consecutive-check rule: 4 x the measured noise floor of consecutive checks at C2 (2.5e-4)
         torch.cuda.synchronize()
         ts = time.perf_counter()
-        while it < max_it and (hit["raw"] is None or hit["smoothed"] is None) and (time.perf_counter() - ts) < t_cap:
+        while it < max_it and (hit["raw"] is None or hit["smoothed"] is None or hit["reach"] is None) and \
+                (time.perf_counter() - ts) < t_cap:
             for _ in range(10):
                 st = L.agp_svgp_cavi_step(h2, xp, ld, yp, C.c_void_p(chunk[it % chunk.shape[0]].data_ptr()), B, rho)
                 if st != 0:
@@ -627,6 +673,9 @@ def main():
                 consec = consec + 1 if abs(hist[-1] - hist[-2]) / abs(hist[-1]) < 1e-4 else 0
                 if hit["raw"] is None and consec >= 3:
                     hit["raw"] = (now, it, hist[-1])
+                consec_r = consec_r + 1 if abs(hist[-1] - hist[-2]) / abs(hist[-1]) < TOL_R else 0
+                if hit["reach"] is None and consec_r >= 3:
+                    hit["reach"] = (now, it, hist[-1])
             if hit["smoothed"] is None and len(hist) >= 20:
                 m1, m0 = sum(hist[-10:]) / 10.0, sum(hist[-20:-10]) / 10.0
                 if abs(m1 - m0) / abs(m1) < 1e-3:
@@ -643,7 +692,16 @@ def main():
             d = np.abs(np.diff(hist[-101:])) / np.abs(np.asarray(hist[-100:] if len(hist) > 100 else hist[1:]))
             out["elbo_check_noise_floor"] = {"median_rel_change_of_consecutive_checks": float(np.median(d)),
                                              "max": float(np.max(d)), "over_last_checks": int(len(d)), "at_iteration": it}
-        out["_elbo_ctx"] = {"chunk": chunk_np, "eval_idx": eval_idx.cpu().numpy(), "EVAL": EVAL}
+        # the same three-consecutive-checks rule at a tolerance both sides can meet: 1e-3 = 4 x the noise floor
+        out["time_to_elbo_tol_reachable"] = {
+            "seconds": round(hit["reach"][0], 4) if hit["reach"] else None,
+            "iters": hit["reach"][1] if hit["reach"] else None,
+            "elbo": hit["reach"][2] if hit["reach"] else None,
+            "rule": f"the contracted rule's three consecutive checks (10 iterations apart, same 8192-point evaluation batch) at "
+                    f"|dELBO| / |ELBO| < {TOL_R:g} = 4 x the measured noise floor of consecutive checks (2.5e-4 at C2); device AND "
+                    "CPU oracle are RUN through it (cpu_baseline.time_to_elbo_tol_reachable_measured)",
+        }
+        out["_elbo_ctx"] = {"chunk": chunk_np, "eval_idx": eval_idx.cpu().numpy(), "EVAL": EVAL, "tol_reachable": TOL_R}
         out["time_to_elbo_tol_smoothed"] = {
             "seconds": round(hit["smoothed"][0], 4) if hit["smoothed"] else None,
             "iters": hit["smoothed"][1] if hit["smoothed"] else None,
@@ -790,7 +848,10 @@ def cpu_baseline(a, cfg, ell, Z, X, yh, idx_np, out):
     ctx = out.get("_elbo_ctx")
     budget = float(getattr(a, "cpu_elbo_seconds", 0.0))
     want_r = bool(out.get("iters_to_elbo_tol"))  # the contracted rule was met on the device: run the oracle through it as well
-    need_it = max(sm or 0, out.get("iters_to_elbo_tol") or 0)
+    rc_it = (out.get("time_to_elbo_tol_reachable") or {}).get("iters")
+    if rc_it:
+        res["time_to_elbo_tol_reachable_s_extrapolated"] = round(rc_it / rate, 1)
+    need_it = sm or 0  # the run starts when at least the smoothed rule fits the budget; the other rules are met if the budget lasts
     if ctx is not None and sm and lik in ("logistic", "studentt") and budget > 0 and need_it / rate < budget:
         Xall = X.cpu().numpy().astype(np.float64)
         yall = np.asarray(yh, dtype=np.float64)
@@ -800,8 +861,9 @@ def cpu_baseline(a, cfg, ell, Z, X, yh, idx_np, out):
             ev = ctx["eval_idx"]
             Xe, ye = Xall[ev], yall_t[ev]
             hist, it, hit_s, hit_r, consec = [], 0, None, None, 0
+            hit_q, consec_q, tol_q = None, 0, ctx.get("tol_reachable", 1e-3)
             ts = time.perf_counter()
-            while (time.perf_counter() - ts) < budget and (hit_s is None or (want_r and hit_r is None)):
+            while (time.perf_counter() - ts) < budget and (hit_s is None or (want_r and hit_r is None) or (rc_it and hit_q is None)):
                 for _ in range(10):
                     ib = ctx["chunk"][it % len(ctx["chunk"])]
                     r.update_parameters(Xall[ib], yall_t[ib])
@@ -812,6 +874,9 @@ def cpu_baseline(a, cfg, ell, Z, X, yh, idx_np, out):
                     consec = consec + 1 if abs(hist[-1] - hist[-2]) / abs(hist[-1]) < 1e-4 else 0
                     if hit_r is None and consec >= 3:
                         hit_r = (now, it)
+                    consec_q = consec_q + 1 if abs(hist[-1] - hist[-2]) / abs(hist[-1]) < tol_q else 0
+                    if hit_q is None and consec_q >= 3:
+                        hit_q = (now, it, hist[-1])
                 if len(hist) >= 20 and hit_s is None:
                     m1, m0 = sum(hist[-10:]) / 10.0, sum(hist[-20:-10]) / 10.0
                     if abs(m1 - m0) / abs(m1) < 1e-3:
@@ -820,6 +885,10 @@ def cpu_baseline(a, cfg, ell, Z, X, yh, idx_np, out):
             "seconds": round(hit_s[0], 1) if hit_s else None, "iters": hit_s[1] if hit_s else None,
             "elbo": hit_s[2] if hit_s else None,
             "note": "the oracle RUN through the same rule on the same minibatch stream and evaluation batch (not extrapolated)"}
+        res["time_to_elbo_tol_reachable_measured"] = {
+            "seconds": round(hit_q[0], 1) if hit_q else None, "iters": hit_q[1] if hit_q else None,
+            "elbo": hit_q[2] if hit_q else None,
+            "note": f"three consecutive checks within {tol_q:g}: the oracle RUN on the host cores, same minibatch stream and evaluation batch"}
         if hit_r:
             res["time_to_elbo_tol_measured"] = {"seconds": round(hit_r[0], 1), "iters": hit_r[1],
                                                 "note": "the contracted rule (SURVEY 8d), oracle RUN on the host cores"}

@@ -1265,6 +1265,9 @@ struct Svgp : SvgpBase {
   int Qa() const { return mo_sharded ? qtot : nl; }
   // prefetch of the next minibatch's Knm / kappa on a second stream (overlaps the latency-bound factorisation)
   hipStream_t pf_stream = nullptr;
+  static constexpr int PF_SIDE = 3;  // further look-ahead streams of a handle with several latents (prefetch())
+  hipStream_t pf_side[PF_SIDE] = {nullptr, nullptr, nullptr};
+  hipEvent_t pf_fork = nullptr, pf_join[PF_SIDE] = {nullptr, nullptr, nullptr};
   hipEvent_t pf_done = nullptr, step_done[2] = {nullptr, nullptr};
   int step_parity = 0;
   bool pf_valid = false;
@@ -1555,6 +1558,7 @@ struct Svgp : SvgpBase {
     HIPCHK(ctx, hipMemsetAsync(info_dev, 0, sizeof(int32_t), st()));
     HIPCHK(ctx, hipMemsetAsync(infoK_dev, 0, sizeof(int32_t), st()));
     HIPCHK(ctx, hipMemsetAsync(flags_dev, 0, sizeof(int), st()));
+    HIPCHK(ctx, hipMemsetAsync(info_dev + 3, 0, sizeof(int32_t), st()));  // orderK (k_logdiag_sum)
     // LogisticSoftMax state: alpha = beta = K (total classes)  logisticsoftmax.jl:43-53
     const T kk = (T)(lp.kind == AGP_LIK_LOGISTICSOFTMAX ? desc.lik.n_class : 1);
     hipLaunchKernelGGL((k_fill<T>), grid1(Bp), dim3(256), 0, st(), alpha, Bp, kk);
@@ -1578,6 +1582,14 @@ struct Svgp : SvgpBase {
       (void)hipMemcpy(sig[0], &started_seq, sizeof(int32_t), hipMemcpyHostToDevice);
       (void)hipStreamSynchronize(pf_stream);
     }
+    for (int q = 0; q < PF_SIDE; ++q) {
+      if (pf_side[q]) {
+        (void)hipStreamSynchronize(pf_side[q]);
+        dcheck(hipStreamDestroy(pf_side[q]), __LINE__);
+      }
+      if (pf_join[q]) dcheck(hipEventDestroy(pf_join[q]), __LINE__);
+    }
+    if (pf_fork) dcheck(hipEventDestroy(pf_fork), __LINE__);
     if (pf_stream) dcheck(hipStreamDestroy(pf_stream), __LINE__);
     for (auto q : sig)
       if (q) dcheck(hipFree(q), __LINE__);
@@ -1753,7 +1765,7 @@ struct Svgp : SvgpBase {
         AGPCHK(xtx_padded<T>(ctx, g.Xk, mp, mp, g.Kinv, mp));
         if (!logdetK_dev) AGPCHK(dmalloc(ctx, &logdetK_dev, nl));
         const int li = (int)(&g - lat.data());
-        hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.DgK, m, logdetK_dev + li);
+        hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.DgK, m, logdetK_dev + li, info_dev);
         LAUNCHCHK(ctx);
         g.logdet_pending = true;
         if (!refresh_lazy) {
@@ -2939,11 +2951,38 @@ struct Svgp : SvgpBase {
       HIPCHK(ctx, hipStreamWaitEvent(pf_stream, step_done[step_parity], 0));
     const int64_t Bq = rup64(B);
     hipStream_t keep_stream = ctx->stream;
-    ctx->stream = pf_stream;  // reuse the launch helpers on the prefetch stream
     agp_status rc = AGP_OK;
-    for (auto& g : lat) {
+    // several latents (round 4): their (K_nm, kappa) pairs are independent, and one in-order stream runs them as 2 nl kernels of
+    // exactly one workgroup per CU each, next to a task graph that holds most CUs -- every kernel boundary drains.  They are spread
+    // over two streams (fork / join by events on the look-ahead's own streams, none on the step's); more streams take too much of
+    // the chip from the task graph.  AGP_PF_STREAMS=1..4 overrides.
+    static const int pf_ways = []() {
+      const char* e = getenv("AGP_PF_STREAMS");
+      return e ? std::max(1, std::min(atoi(e), PF_SIDE + 1)) : 2;  // measured at C4 (8 latents): 1 stream 1.186, 2: 1.088, 3: 1.41, 4: 1.34 ms
+    }();
+    // (only next to the batched task graph: at C5 -- blocked factorisation, GEMMs of 4096 tiles -- two streams cost 13.5 -> 14.5 ms)
+    const int ways = (nl > 1 && chol_use_dag(ctx, mp / TILE, Bq / TILE + 1, 2)) ? std::min<int>(pf_ways, nl) : 1;
+    if (ways > 1) {
+      if (!pf_side[0]) {
+        int lo = 0, hi = 0;
+        HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        int pr = hi;
+        if (const char* e = getenv("AGP_PF_PRIORITY")) pr = e[0] == 'h' ? hi : e[0] == 'n' ? (lo + hi) / 2 : lo;
+        for (int q = 0; q < PF_SIDE; ++q) {
+          HIPCHK(ctx, hipStreamCreateWithPriority(&pf_side[q], hipStreamNonBlocking, pr));
+          HIPCHK(ctx, hipEventCreateWithFlags(&pf_join[q], hipEventDisableTiming));
+        }
+        HIPCHK(ctx, hipEventCreateWithFlags(&pf_fork, hipEventDisableTiming));
+      }
+      HIPCHK(ctx, hipEventRecord(pf_fork, pf_stream));
+      for (int q = 0; q < ways - 1; ++q) HIPCHK(ctx, hipStreamWaitEvent(pf_side[q], pf_fork, 0));
+    }
+    for (int l = 0; l < nl; ++l) {
+      Latent& g = lat[l];
+      hipStream_t sl = (ways > 1 && l % ways) ? pf_side[l % ways - 1] : pf_stream;
+      ctx->stream = sl;  // reuse the launch helpers on the look-ahead streams
       dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
-      (void)launch_kernelmatrix<T>(ctx, pf_stream, (const T*)x, ldx, idx, B, (const T*)g.Z,
+      (void)launch_kernelmatrix<T>(ctx, sl, (const T*)x, ldx, idx, B, (const T*)g.Z,
                          D, m, D, (const T*)g.scales, g.k.kind, kvar(g), g.Knm_alt, mp, Bq, mp, 0, T(0),
                          (const T*)nullptr, (T*)nullptr, (int64_t)0, 0, (const T*)g.Zsc, (const T*)g.zn);
       rc = gemm_nt<T, EPI_KAPPA>(ctx, g.Knm_alt, mp, kinv_kappa(g), mp, Bq, mp, mp, 0, g.kappa_alt, mp, g.Knm_alt, mp, nullptr,
@@ -2952,6 +2991,10 @@ struct Svgp : SvgpBase {
     }
     ctx->stream = keep_stream;
     AGPCHK(rc);
+    for (int q = 0; q < ways - 1; ++q) {
+      HIPCHK(ctx, hipEventRecord(pf_join[q], pf_side[q]));
+      HIPCHK(ctx, hipStreamWaitEvent(pf_stream, pf_join[q], 0));
+    }
     HIPCHK(ctx, hipEventRecord(pf_done, pf_stream));
     if (sig_state == 1) {
       pf_seq += 1;
@@ -3225,10 +3268,10 @@ struct Svgp : SvgpBase {
   }
 
   agp_status check_status() override {
-    int32_t words[3] = {0, 0, 0};  // info | infoK | flags
+    int32_t words[4] = {0, 0, 0, 0};  // info | infoK | flags | orderK (k_logdiag_sum: did K_ZZ fail before or after the others?)
     HIPCHK(ctx, hipMemcpyAsync(words, info_dev, sizeof(words), hipMemcpyDeviceToHost, st()));
     HIPCHK(ctx, hipStreamSynchronize(st()));
-    const int32_t info = words[0], infoK = words[1];
+    const int32_t info = words[0], infoK = words[1], orderK = words[3];
     const int flags = (int)words[2];
     dag_retry_check(ctx);  // steps the in-stream fallback had to re-run: warn once, stop using the task graph
     if (info != 0 || flags != 0) {
@@ -3236,9 +3279,12 @@ struct Svgp : SvgpBase {
       HIPCHK(ctx, hipMemsetAsync(flags_dev, 0, sizeof(int), st()));
     }
     if (infoK != 0) HIPCHK(ctx, hipMemsetAsync(infoK_dev, 0, sizeof(int32_t), st()));
+    if (orderK != 0) HIPCHK(ctx, hipMemsetAsync(info_dev + 3, 0, sizeof(int32_t), st()));
     // a non-SPD K_ZZ latched by a refresh inside the training loop is the ROOT cause of whatever followed it on a garbage inverse
-    // (negative K~, NaNs, a non-SPD -2 eta2): it is reported first, like the PosDefException the reference raises at that refresh
-    if (infoK > 0) {
+    // (negative K~, NaNs, a non-SPD -2 eta2): it is reported first, like the PosDefException the reference raises at that refresh --
+    // unless an earlier step had ALREADY latched a failure of its own when K_ZZ failed (orderK == 2: e.g. the stale-K quirk drives
+    // K~ negative, the NaNs that follow reach the kernel parameters, and K_ZZ is the consequence), which then comes first below
+    if (infoK > 0 && orderK != 2) {
       for (auto& q : lat) q.K_stale = true;
       ctx->err = "PosDefException: K_ZZ + jitter*I is not positive definite; leading minor " + std::to_string(infoK);
       return AGP_ERR_NOT_POSDEF;
@@ -3261,6 +3307,11 @@ struct Svgp : SvgpBase {
     }
     if (info != 0) {
       ctx->err = "PosDefException: -2*eta2 is not positive definite; leading minor " + std::to_string(info);
+      return AGP_ERR_NOT_POSDEF;
+    }
+    if (infoK > 0) {
+      for (auto& q : lat) q.K_stale = true;
+      ctx->err = "PosDefException: K_ZZ + jitter*I is not positive definite; leading minor " + std::to_string(infoK);
       return AGP_ERR_NOT_POSDEF;
     }
     if (infoK < 0) {
@@ -3565,8 +3616,19 @@ struct Svgp : SvgpBase {
       // A = K \ (I - Sigma / K) = Kinv - Kinv Sigma Kinv :  T2 = Kinv Sigma (NT, both symmetric) ; A = Kinv - Kinv T2'
       AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.Kinv, mp, g.Sigma, mp, mp, mp, mp, 0, Tw2, mp, nullptr, 0, nullptr, nullptr,
                                     nullptr, 0)));
-      AGPCHK((gemm_nt<T, EPI_EMINUS>(ctx, g.Kinv, mp, Tw2, mp, mp, mp, mp, 0, g.Apred, mp, g.Kinv, mp, nullptr,
-                                     nullptr, nullptr, 0)));
+      {  // (symmetric result: lower tiles only, mirrored -- half the flops of the full EPI_EMINUS product)
+        const int64_t ntm = mp / TILE, tiles = ntm * (ntm + 1) / 2;
+        if (tiles <= 160 && mp >= 8 * BK)  // fewer tiles than CUs: four k-groups per workgroup, like the symmetric product (syrk_tn)
+          hipLaunchKernelGGL((k_gemm_nt_eminus_sym<T, 4>), dim3((unsigned)tiles), dim3(4 * NTHREADS), 0, st(), (const T*)g.Kinv, mp,
+                             (const T*)Tw2, mp, mp, g.Apred, mp, (const T*)g.Kinv, mp);
+        else if (tiles <= kg2_limit() && mp >= 4 * BK)
+          hipLaunchKernelGGL((k_gemm_nt_eminus_sym<T, 2>), dim3((unsigned)tiles), dim3(2 * NTHREADS), 0, st(), (const T*)g.Kinv, mp,
+                             (const T*)Tw2, mp, mp, g.Apred, mp, (const T*)g.Kinv, mp);
+        else
+          hipLaunchKernelGGL((k_gemm_nt_eminus_sym<T, 1>), dim3((unsigned)tiles), dim3(NTHREADS), 0, st(), (const T*)g.Kinv, mp,
+                             (const T*)Tw2, mp, mp, g.Apred, mp, (const T*)g.Kinv, mp);
+        LAUNCHCHK(ctx);
+      }
       g.predvar_valid = true;
     }
     return AGP_OK;

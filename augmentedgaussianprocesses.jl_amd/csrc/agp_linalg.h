@@ -79,6 +79,31 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_gemm_nt(const T* __restrict__
   }
 }
 
+// C = E - A B^T for a result known to be SYMMETRIC (A = K^-1 - K^-1 (Sigma K^-1): predictions.jl:38 and the hyper-gradient's G_K):
+// only the nt (nt + 1) / 2 lower tiles are formed -- half the flops of k_gemm_nt<EPI_EMINUS> -- and mirrored on the way out
+// (diagonal tiles: the lower half is the truth).  grid = nt (nt + 1) / 2, row-major triangle order.
+template <typename T, int KG = 1>
+__global__ __launch_bounds__(NTHREADS * KG) void k_gemm_nt_eminus_sym(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+                                                                       int64_t ldb, int64_t K, T* __restrict__ C, int64_t ldc,
+                                                                       const T* __restrict__ E, int64_t lde) {
+  __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
+  int64_t ta, tb;
+  tri_index(blockIdx.x, ta, tb);
+  const int64_t r0 = ta * TILE, c0 = tb * TILE;
+  Acc<T> acc;
+  acc.zero();
+  gemm_tile<T, KC, KC, KG>(A + r0 * lda, lda, B + c0 * ldb, ldb, 0, K, nullptr, acc, smem);
+  if (KG > 1 && threadIdx.x >= NTHREADS) return;
+  acc_foreach<T>(acc, [&](int r, int c, T val) {
+    const int64_t gr = r0 + r, gc = c0 + c;
+    if (ta != tb || gc <= gr) {
+      const T v = E[gr * lde + gc] - val;
+      C[gr * ldc + gc] = v;
+      C[gc * ldc + gr] = v;
+    }
+  });
+}
+
 // ---------------------------------------------------------------------------------------------------
 // S(n x n) = A(Kdim x n)^T diag(w) A(Kdim x n)  ("TN", operands row-contiguous), lower tiles only, mirrored.
 // grid = nt*(nt+1)/2 linear over lower-triangular tiles.
@@ -366,14 +391,21 @@ __global__ void k_symv(const T* __restrict__ M, int64_t ld, int64_t n, const T* 
 }
 
 // sum of log(diag) over the first nvalid entries (logdet from a Cholesky factor) -> out[0] (double)
+// status (optional; the refresh of K_ZZ inside a training loop): [info | infoK | flags | orderK].  When this refresh has latched a
+// failure in infoK, orderK records ONCE whether an earlier step had already latched one of its own (2) or not (1): the host reports
+// the failure that came FIRST as the root cause -- a non-SPD K_ZZ makes K~ negative afterwards, a negative K~ turns the kernel
+// parameters into NaNs and K_ZZ non-SPD afterwards (agp_svgp_check_status).
 template <typename T>
-__global__ void k_logdiag_sum(const T* __restrict__ Dg, int64_t nvalid, double* __restrict__ out) {
+__global__ void k_logdiag_sum(const T* __restrict__ Dg, int64_t nvalid, double* __restrict__ out, int32_t* __restrict__ status = nullptr) {
   __shared__ double red[16];
   double s = 0.0;
   for (int64_t i = threadIdx.x; i < nvalid; i += blockDim.x)
     s += log((double)Dg[(i / TILE) * TILE * TILE + (i % TILE) * (TILE + 1)]);
   s = block_sum<double>(s, red);
-  if (threadIdx.x == 0) out[0] = s;
+  if (threadIdx.x == 0) {
+    out[0] = s;
+    if (status && status[1] != 0 && status[3] == 0) status[3] = (status[0] != 0 || status[2] != 0) ? 2 : 1;
+  }
 }
 
 // MFMA issue-rate microbenchmark (roofline ceiling): each wave runs `iters` x 8 independent-accumulator MFMAs

@@ -322,3 +322,25 @@ def test_device_fixed_points_maximise_the_independent_bounds(mods, likname):
     K, kappa, Kt = _sparse_pieces(kern, X, Z, 1e-4)
     mu, Sig, val = _maximise_collapsed_bound(term, K, kappa, Kt, y, 0.9 * mu_d, np.linalg.cholesky(1.1 * Sig_d))
     assert _rel(mu_d, mu) < 2e-6 and _rel(Sig_d, Sig) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the failure that came first is the one reported
+def test_non_spd_K_inside_the_loop_is_reported_as_the_root_cause(mods):
+    """A hyper step that destroys K_ZZ (here: a Descent step of infinite length on the inducing points, which sends them to infinity, where
+    every distance is NaN) is only latched on the device -- the refresh inside the training loop does not synchronise -- and
+    everything after it runs on a garbage inverse (NaN / negative K~, a non-SPD -2 eta2).  agp_svgp_check_status reports the K_ZZ
+    failure, like the PosDefException the reference raises at that refresh, not its consequences.  (The opposite order -- the
+    stale-K quirk drives K~ negative first and the NaNs reach the kernel afterwards -- keeps reporting K~:
+    tests/test_gpu_round2.py::test_stale_K_runs_into_negative_ktilde_like_the_reference.)"""
+    AGP, R, capi, torch = mods
+    rng = np.random.default_rng(3)
+    X, f, Z = _toy(rng, N=200, m=12)
+    y = (f > 0).astype(int)
+    B = 50
+    idx = [rng.choice(len(X), B, replace=False) for _ in range(8)]
+    m = AGP.SVGP(1.1 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0)), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z,
+                 optimiser=False, Zoptimiser=AGP.Descent(float("inf")))
+    with pytest.raises(capi.AGPError) as ei:
+        AGP.train_(m, X, y, 8, idx_stream=idx)
+    assert ei.value.status == 2 and "K_ZZ" in str(ei.value), str(ei.value)  # AGP_ERR_NOT_POSDEF, not AGP_ERR_NEG_KTILDE

@@ -3,7 +3,7 @@
 # profiles/.   usage: bash tools/collect_profiles.sh [tag]   (default r03)
 export TMPDIR=/tmp
 R=$PWD
-T=${1:-r03}
+T=${1:-r04}
 python bench.py > gpurun_out/${T}_c2_bench_line.json 2> gpurun_out/${T}_c2_line.err
 for c in c3 c4 c5; do
   st=100; wu=20; [ $c = c5 ] && st=20 && wu=5; [ $c = c4 ] && st=60 && wu=10

@@ -448,11 +448,14 @@ static void dag_retry_check(agp_ctx* c) {
 
 // Split task-graph launches: worth it when the launch queues far more tiles than the chip has workgroup slots (C3: 1584, C4: 3264);
 // the small launches (C2: 408 tiles, and its merged step with the prologue) stay one kernel.  AGP_CHAIN_SPLIT=0 / 1 forces.
-static bool chain_split_wanted(int64_t tiles) {
+static bool chain_split_wanted(int64_t tiles, bool with_prologue = false) {
   static const int v = []() {
     const char* e = getenv("AGP_CHAIN_SPLIT");
     return e ? (e[0] == '0' ? 0 : 1) : -1;
   }();
+  // launches with the prologue stay merged unless forced: their tile workgroups stage four LDS tiles (one workgroup per CU in f64
+  // whatever the registers), and the one measured case lost (C2: 0.3167 ms split, 0.3103 ms merged)
+  if (with_prologue && v < 0) return false;
   static const int64_t min_tiles = []() {
     const char* e = getenv("AGP_CHAIN_SPLIT_MIN_TILES");
     return e ? (int64_t)atoll(e) : (int64_t)600;
@@ -688,7 +691,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
         if (hipMalloc((void**)&ptrace, 2048 * 8) != hipSuccess) ptrace = nullptr;
         if (ptrace) (void)hipMemsetAsync(ptrace, 0, 2048 * 8, c->stream);
       }
-      if (step_inst && chain_split_wanted(ntiles + nhelp) && chain_split_ready(c)) {  // chain kernel + tile kernel (k_chol_dag, ROLE)
+      if (step_inst && chain_split_wanted(ntiles + nhelp, true) && chain_split_ready(c)) {  // chain kernel + tile kernel (k_chol_dag, ROLE)
         ds.go = c->chain_go;
         ds.go_val = ++c->chain_seq;
         hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, true, 1>), dim3(1), dim3(CHOL_THREADS), 0, c->chain_stream, one, 1,

@@ -85,7 +85,7 @@ def parse():
     p.add_argument("--no-elbo-tol", action="store_true")
     p.add_argument("--no-extras", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
-    p.add_argument("--cpu-elbo-seconds", type=float, default=170.0,
+    p.add_argument("--cpu-elbo-seconds", type=float, default=200.0,
                    help="budget for running the CPU oracle through the smoothed time-to-ELBO rule (0: only extrapolate)")
     p.add_argument("--collective", default="rccl", choices=["rccl", "torch"],
                    help="N > 1: who issues the all-reduces: libagp_hip.so through its own RCCL communicator (default) or a "
@@ -434,6 +434,16 @@ def main():
                                 "2 B m^2 as in SURVEY 8d; B m^2 executed) -- until round 2 a kernel of its own between two factorisations")
         roofline["executed_frac"] = round(flops_fact_exec * n_lat_local / max(launches_per_step, 1e-9) / avg_launch_s / 1e12 / peak, 4)
         roofline["factorisation_only_frac"] = round((mp ** 3 / 3.0 + (Bq + 64) * mp ** 2) / avg_launch_s / 1e12 / peak, 4)
+    # round 4: from 600 tiles per launch the task graph runs as TWO kernels (k_chol_dag<..., ROLE 1> = the chain workgroup(s) on a
+    # stream of their own, <..., ROLE 2> = every other tile on the step's stream) -- the HIP events bracket the tile
+    # kernel and the join with the chain kernel, i.e. the whole factorisation, as before
+    ne_t, nt_t = Bq // 64 + 1, mp // 64
+    tiles_per_launch = (nt_t * (nt_t + 1) // 2 + ne_t * nt_t) * (min(n_lat_local, 8) if n_lat_local > 1 else 1)
+    if dag and not prologue and tiles_per_launch >= 600 and os.environ.get("AGP_CHAIN_SPLIT", "") != "0":
+        roofline["kernel"] = kernel_name[:-1] + ", ..., ROLE 1 + ROLE 2> (chain kernel + tile kernel)"
+        roofline["split_launch"] = {"tiles_per_launch": tiles_per_launch,
+                                    "note": "chain workgroup(s) as a kernel of their own so that the tile kernel compiles to <= 100 "
+                                            "(f64) / 71 (f32) VGPRs and runs 2-3 workgroups per CU (DESIGN.md 5b)"}
     if isolated:
         roofline["isolated"] = isolated
     # whole-iteration algorithmic rate (F_iter = 6 B m^2 + m^3 + B m (3D + 12) per latent)
@@ -497,8 +507,8 @@ def main():
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE as
     # MI355X_MICROARCH.md prescribes for gfx950); rocprofv3 cannot wrap bench.py from inside, so this is not live
     if a.config in ("c2", "c3") and world == 1 and comm is None:
-        for pf in (("r03_pmc_hbm_bytes.json", "r02_pmc_hbm_bytes.json", "r01h_pmc_hbm_bytes.json") if a.config == "c2" else
-                   ("r03_c3_pmc_hbm_bytes.json", "r02_c3_pmc_hbm_bytes.json")):
+        for pf in (("r04_pmc_hbm_bytes.json", "r03_pmc_hbm_bytes.json", "r02_pmc_hbm_bytes.json", "r01h_pmc_hbm_bytes.json")
+                   if a.config == "c2" else ("r04_c3_pmc_hbm_bytes.json", "r03_c3_pmc_hbm_bytes.json", "r02_c3_pmc_hbm_bytes.json")):
             try:
                 with open(os.path.join(ROOT, "profiles", pf)) as fh:
                     pm = json.load(fh)

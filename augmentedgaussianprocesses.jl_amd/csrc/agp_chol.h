@@ -2156,7 +2156,7 @@ template <typename T>
 __global__ __launch_bounds__(NTHREADS) void k_trtri_level(const T* __restrict__ A, int64_t ld, T* __restrict__ X, int64_t ldx,
                                                           T* __restrict__ S, int64_t lds, int64_t nt, int64_t bs,
                                                           int phase) {
-  __shared__ __attribute__((aligned(16))) T smem[SMEM_ELEMS];
+  __shared__ __attribute__((aligned(16))) T smem[smem_elems<T>()];
   const int64_t base = (int64_t)blockIdx.z * 2 * bs, r0 = base + bs, c0 = base;
   if (r0 >= nt) return;
   const int64_t nr = (nt - r0) < bs ? (nt - r0) : bs;

@@ -41,24 +41,49 @@ struct Mfma<float> {
 };
 
 constexpr int TILE = 64;       // block tile edge (rows and cols of C per workgroup)
-constexpr int BK = 16;         // k-depth staged per LDS buffer
+constexpr int BK = 16;         // k-depth staged per LDS buffer (f64; and the unit host-side k ranges are checked against)
 constexpr int NTHREADS = 256;  // 4 waves as 2 (M) x 2 (N), each wave owns a 32x32 sub-tile = 2x2 MFMA tiles
-constexpr int LDK = BK + 2;    // KC layout row stride: 16 rows x {k,k+1} hit 32 distinct 8-byte bank slots
 constexpr int LDR = TILE + 16; // RC layout row stride: rows k,k+1 land on disjoint bank halves
-constexpr int OPER_ELEMS = (TILE * LDK > BK * LDR) ? TILE * LDK : BK * LDR;  // 1280
-constexpr int SMEM_ELEMS = 2 * 2 * OPER_ELEMS;  // double-buffered A and B tiles
+// The staged k-depth is a compile-time property of the element type (round 4 experiment).  An fp32 v_mfma_16x16x4 takes half the
+// cycles of the fp64 one, so at the same depth the fp32 kernels spend twice the share of their time between barriers
+// (k_syrk_tn<float> runs at 0.46 of the sustained fp32 MFMA rate, the fp64 instantiations at 0.95).  Measured with 32 k per fp32 slab
+// (-DAGP_BK_F32=32: as many MFMA cycles and as many LDS bytes per slab as fp64 at 16): C3's symmetric product 138 -> 166 us, step
+// 0.672 -> 0.719 ms -- the 80 KB of a two-k-group workgroup allow two workgroups per CU instead of three, which costs more than the
+// longer slabs return.  The default stays 16 for both types.
+#ifndef AGP_BK_F32
+#define AGP_BK_F32 16
+#endif
+template <typename T>
+struct BkOf {
+  static constexpr int v = sizeof(T) == 4 ? AGP_BK_F32 : BK;
+};
+template <int BKK>
+struct Slab {
+  static constexpr int LDK = BKK + 2;  // KC layout row stride: 16 rows x {k,k+1} hit distinct bank slots
+  static constexpr int OPER = (TILE * LDK > BKK * LDR) ? TILE * LDK : BKK * LDR;  // 1280 at BKK = 16, 2560 at 32
+  static constexpr int SMEM = 2 * 2 * OPER;  // double-buffered A and B tiles
+};
+constexpr int LDK = Slab<BK>::LDK;
+constexpr int OPER_ELEMS = Slab<BK>::OPER;
+constexpr int SMEM_ELEMS = Slab<BK>::SMEM;
+// elements of the staging area of one k-group for element type T
+template <typename T>
+constexpr int smem_elems() {
+  return Slab<BkOf<T>::v>::SMEM;
+}
 
 // Operand memory layouts.  "row" is the operand's C-side index (i for A, j for B).
 struct KC {};  // element (row, k) at P[row*ld + k]   (k contiguous)   e.g. A[i][k], B^T given as B[j][k]
 struct RC {};  // element (row, k) at P[k*ld + row]   (row contiguous) e.g. A^T given as A[k][i], B[k][j]
 
-template <typename T, typename L>
+template <typename T, typename L, int BKK = BkOf<T>::v>
 struct TileIO;
 
-template <typename T>
-struct TileIO<T, KC> {
+template <typename T, int BKK>
+struct TileIO<T, KC, BKK> {
   static constexpr int VEC = Mfma<T>::VEC;
-  static constexpr int NV = BK / VEC;                   // vectors per row
+  static constexpr int LDK = Slab<BKK>::LDK;
+  static constexpr int NV = BKK / VEC;                  // vectors per row
   static constexpr int VPT = TILE * NV / NTHREADS;      // vectors per thread (2 f64, 1 f32)
   typedef typename Mfma<T>::vec_t vec_t;
   struct Regs {
@@ -89,11 +114,11 @@ struct TileIO<T, KC> {
   }
 };
 
-template <typename T>
-struct TileIO<T, RC> {
+template <typename T, int BKK>
+struct TileIO<T, RC, BKK> {
   static constexpr int VEC = Mfma<T>::VEC;
   static constexpr int NV = TILE / VEC;                 // vectors per k-row
-  static constexpr int VPT = BK * NV / NTHREADS;        // 2 f64, 1 f32
+  static constexpr int VPT = BKK * NV / NTHREADS;       // 2 f64, 1 f32 (2 at BKK = 32)
   typedef typename Mfma<T>::vec_t vec_t;
   struct Regs {
     vec_t v[VPT];
@@ -140,8 +165,9 @@ struct Acc {
 // MFMA over one staged BK slab
 template <typename T, typename LA, typename LB>
 __device__ __forceinline__ void mma_slab(const T* As, const T* Bs, Acc<T>& acc, int wm, int wn, int lane) {
+  constexpr int BKK = BkOf<T>::v;
 #pragma unroll
-  for (int kk = 0; kk < BK / 4; ++kk) {
+  for (int kk = 0; kk < BKK / 4; ++kk) {
     T a0 = TileIO<T, LA>::frag(As, wm * 32, kk, lane);
     T a1 = TileIO<T, LA>::frag(As, wm * 32 + 16, kk, lane);
     T b0 = TileIO<T, LB>::frag(Bs, wn * 32, kk, lane);
@@ -163,6 +189,8 @@ template <typename T, typename LA, typename LB, int KG = 1>
 __device__ __forceinline__ void gemm_tile(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
                                           int64_t kBegin, int64_t kEnd, const T* __restrict__ wscaleA, Acc<T>& acc,
                                           T* smem_all) {
+  constexpr int BK = BkOf<T>::v;  // (shadows the f64 constant: everything below is in units of this type's slab depth)
+  constexpr int OPER_ELEMS = Slab<BK>::OPER, SMEM_ELEMS = Slab<BK>::SMEM;
   const int tid = threadIdx.x & (NTHREADS - 1);
   const int grp = (KG > 1) ? (threadIdx.x >> 8) : 0;
   const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;

@@ -395,7 +395,7 @@ template <typename T, int KG>
 __global__ __launch_bounds__(NTHREADS * KG) void k_gemm_tn(const T* __restrict__ A, int64_t lda,
                                                            const T* __restrict__ B, int64_t ldb, int64_t K,
                                                            T* __restrict__ C, int64_t ldc) {
-  __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
+  __shared__ __attribute__((aligned(16))) T smem[KG * smem_elems<T>()];
   const int64_t r0 = blockIdx.y * (int64_t)TILE, c0 = blockIdx.x * (int64_t)TILE;
   Acc<T> acc;
   acc.zero();

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_gemm_nt(const T* __restrict__
                                                       int64_t ldc, const T* __restrict__ E, int64_t lde,
                                                       const T* __restrict__ v, T* __restrict__ part0,
                                                       T* __restrict__ part1, int64_t ldp) {
-  __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
+  __shared__ __attribute__((aligned(16))) T smem[KG * smem_elems<T>()];
   int64_t bn, bm;  // XCD-aware: every XCD works on a compact block of C tiles (agp_chol.h, xcd_contiguous)
 #ifndef AGP_GEMM_XCD
 #define AGP_GEMM_XCD 1
@@ -86,7 +86,7 @@ template <typename T, int KG = 1>
 __global__ __launch_bounds__(NTHREADS * KG) void k_gemm_nt_eminus_sym(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
                                                                        int64_t ldb, int64_t K, T* __restrict__ C, int64_t ldc,
                                                                        const T* __restrict__ E, int64_t lde) {
-  __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
+  __shared__ __attribute__((aligned(16))) T smem[KG * smem_elems<T>()];
   int64_t ta, tb;
   tri_index(blockIdx.x, ta, tb);
   const int64_t r0 = ta * TILE, c0 = tb * TILE;
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_syrk_tn(const T* __restrict__
                                                       int64_t fill_stride = 0, int fill_nb = 0) {
   // KG = 4 in f64 takes ALL of gfx950's 160 KB of LDS (4 x 40 KB staging areas): nothing else in this kernel may be __shared__,
   // and the instantiation does not exist for smaller-LDS targets
-  static_assert((size_t)KG * SMEM_ELEMS * sizeof(T) <= 160 * 1024, "k_syrk_tn: staging areas exceed the 160 KB LDS of gfx950");
-  __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
+  static_assert((size_t)KG * smem_elems<T>() * sizeof(T) <= 160 * 1024, "k_syrk_tn: staging areas exceed the 160 KB LDS of gfx950");
+  __shared__ __attribute__((aligned(16))) T smem[KG * smem_elems<T>()];
   syrk_tn_body<T, MODE, KG>(A, lda, Kdim, w, lower_a, out, ldo, eta2, Kinv, ldm, lr, ntri, rvec, eta1, kinv_mu0, nrider, fillp,
                             fill_used, fill_stride, fill_nb, smem);
 }
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_syrk_eta_batch(SyrkBatch<T> b
                                                              int64_t ldm, T lr, int64_t ntri, int64_t nrider,
                                                              T* __restrict__ fillp, int64_t fill_used,
                                                              int64_t fill_stride, int fill_nb) {
-  __shared__ __attribute__((aligned(16))) T smem[KG * SMEM_ELEMS];
+  __shared__ __attribute__((aligned(16))) T smem[KG * smem_elems<T>()];
   const int q = blockIdx.y;
   // the hand-over refill riders exist once (in the slice of latent 0)
   if (q != 0 && (int64_t)blockIdx.x >= ntri + nrider) return;

@@ -92,7 +92,8 @@ def test_c3_path_fp32_steps_match_oracle(mods):
     Xt = X[:1500]
     pm, pv = AGP.predict_f(ma, Xt, cov=True)
     rm, rv = mr.predict_f(Xt, cov=True)
-    assert _rel(pm, rm[0]) < 5e-3 and _rel(pv, rv[0]) < 2e-2
+    # (measured: mu_f 1.1e-5, sigma2_f 7.3e-5; the fp32 GATE itself -- mu_f <= 1e-3 -- is tests/test_gpu_round4.py::test_fp32_gate_at_the_c3_shape)
+    assert _rel(pm, rm[0]) < 2e-4 and _rel(pv, rv[0]) < 1e-3
 
 
 def test_c3_shape_fp64_steps_match_oracle(mods):

@@ -1658,17 +1658,20 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
   __shared__ T piv[TILE];
   __shared__ int wait_ok, pf_ok, pf_bad;
   if (ROLE == 1) {  // the chain as a kernel of its own: wait until the tile kernel runs (= everything before it on its stream is done)
-    if (threadIdx.x == 0 && sync.go) {
+    if (threadIdx.x == 0) {
+      wait_ok = 1;
       long spins = 0;
-      while (__hip_atomic_load(sync.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != sync.go_val) {
+      while (sync.go && __hip_atomic_load(sync.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != sync.go_val) {
         __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1L << 26)) {  // about a minute: the tile kernel never started
-          atomicExch(info, -2);
+        if (++spins > (1L << 26)) {  // about a minute: the tile kernel never started.  Treated like a lost dependency: the latch
+          atomicExch(info, -1);      // sends the launch to the in-stream fallback (the tiles, should they still come, give up on
+          wait_ok = 0;               // their own bounded waits for the chain)
           break;
         }
       }
     }
     __syncthreads();
+    if (!wait_ok) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this kernel's caches may predate what those kernels wrote
   }
   T* bufA = sm;

@@ -62,7 +62,9 @@ struct agp_ctx {
   // releases them with (signal memory) and the event this context's stream waits on behind every split launch
   hipStream_t chain_stream = nullptr;
   int32_t* chain_go = nullptr;
-  hipEvent_t chain_done = nullptr;
+  hipEvent_t chain_done = nullptr;   // (only with AGP_CHAIN_JOIN=1: an event join behind every split launch, for A/B measurements)
+  int32_t* chain_ctr = nullptr;      // device word: chain workgroups that have exited (DagSync::done); chain_exits = what it will reach
+  int32_t chain_exits = 0;
   int chain_state = 0;  // 0 not tried, 1 usable, -1 not available (the two streams do not run kernels side by side) / switched off
   int32_t chain_seq = 0;
 };
@@ -448,14 +450,15 @@ static void dag_retry_check(agp_ctx* c) {
 
 // Split task-graph launches: worth it when the launch queues far more tiles than the chip has workgroup slots (C3: 1584, C4: 3264);
 // the small launches (C2: 408 tiles, and its merged step with the prologue) stay one kernel.  AGP_CHAIN_SPLIT=0 / 1 forces.
-static bool chain_split_wanted(int64_t tiles, bool with_prologue = false) {
+static bool chain_split_wanted(int64_t tiles, bool with_prologue = false, bool f64 = true) {
   static const int v = []() {
     const char* e = getenv("AGP_CHAIN_SPLIT");
     return e ? (e[0] == '0' ? 0 : 1) : -1;
   }();
-  // launches with the prologue stay merged unless forced: their tile workgroups stage four LDS tiles (one workgroup per CU in f64
-  // whatever the registers), and the one measured case lost (C2: 0.3167 ms split, 0.3103 ms merged)
-  if (with_prologue && v < 0) return false;
+  // fp64 launches with the prologue stay merged unless forced: their tile workgroups stage four LDS tiles (135 KB: one workgroup
+  // per CU whatever the registers), and the measured case lost (C2: 0.3167 ms split, 0.3103 ms merged).  In fp32 the same tile
+  // kernel fits two workgroups per CU (68 KB, 128 VGPRs) and wins: m = 1024, B = 2048 fp32 0.325 -> 0.270 ms per step.
+  if (with_prologue && f64 && v < 0) return false;
   static const int64_t min_tiles = []() {
     const char* e = getenv("AGP_CHAIN_SPLIT_MIN_TILES");
     return e ? (int64_t)atoll(e) : (int64_t)600;
@@ -476,7 +479,8 @@ static bool chain_split_ready(agp_ctx* c) {
     return false;
   }
   bool ok = hipExtMallocWithFlags((void**)&c->chain_go, 8, hipMallocSignalMemory) == hipSuccess && hipMemset(c->chain_go, 0, 8) == hipSuccess &&
-            hipEventCreateWithFlags(&c->chain_done, hipEventDisableTiming) == hipSuccess;
+            hipEventCreateWithFlags(&c->chain_done, hipEventDisableTiming) == hipSuccess &&
+            hipMalloc((void**)&c->chain_ctr, sizeof(int32_t)) == hipSuccess && hipMemset(c->chain_ctr, 0, sizeof(int32_t)) == hipSuccess;
   int32_t* hs = nullptr;
   ok = ok && hipMalloc((void**)&hs, 4 * sizeof(int32_t)) == hipSuccess && hipMemset(hs, 0, 4 * sizeof(int32_t)) == hipSuccess;
   if (ok) {
@@ -492,17 +496,30 @@ static bool chain_split_ready(agp_ctx* c) {
   if (ok) c->chain_state = 1;
   return ok;
 }
-// behind a split launch: this context's stream continues only when the chain kernel has ended too (it ends microseconds after
-// the last tile, but a host synchronisation of the stream must cover it, and so must whatever reads the diagonal factors next)
+// Behind a split launch NO event joins the two streams: the tile kernel cannot end before the chain's last publish, after which the
+// chain writes nothing (its diagonal factors are write-through stores issued before that publish), so whatever follows on this
+// context's stream -- and a host synchronisation of it -- sees a finished factorisation.  The one exception, an aborted launch whose
+// chain is still inside a tile factorisation, is handled where it matters: the fallback waits for the chain workgroups' exit count
+// (DagSync::done, SafeSrc::chain_done).  An event join (record on the chain stream, wait on this one) was the first version and
+// DEADLOCKED with the host several steps ahead, the look-ahead on and the prologue inside the split launch (fp32, m = 1024,
+// B = 2048; not with the host synchronising every step, not without the look-ahead, not with a ring of distinct events either):
+// AGP_CHAIN_JOIN=1 brings it back for A/B measurements only.
 static agp_status chain_split_join(agp_ctx* c) {
-  static const bool off = []() {  // AGP_CHAIN_JOIN=0: A/B measurements of what the join costs the stream (not for use)
+  static const bool on = []() {
     const char* e = getenv("AGP_CHAIN_JOIN");
-    return e && e[0] == '0';
+    return e && e[0] == '1';
   }();
-  if (off) return AGP_OK;
+  if (!on) return AGP_OK;
   HIPCHK(c, hipEventRecord(c->chain_done, c->chain_stream));
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->chain_done, 0));
   return AGP_OK;
+}
+// what a split launch hands its kernels / its fallback about the chain kernel (nb chain workgroups)
+static void chain_split_arm(agp_ctx* c, DagSync& ds, int nb) {
+  ds.go = c->chain_go;
+  ds.go_val = ++c->chain_seq;
+  ds.done = c->chain_ctr;
+  c->chain_exits += nb;
 }
 
 // what a CAVI step hands to its factorisation about the look-ahead stream (see DagSync, agp_chol.h)
@@ -584,7 +601,7 @@ static bool dag_fused_on() {
 template <typename T>
 static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int64_t ldx, T* Dg, T* E, int64_t lde,
                               int64_t ne, int do_x, int32_t* info_dev, int64_t nvalid, const T* erow = nullptr,
-                              bool want_l = true, const SafeSrc<T>* safe = nullptr, bool* defer_safe = nullptr,
+                              bool want_l = true, SafeSrc<T>* safe = nullptr, bool* defer_safe = nullptr,
                               StepSync* ssync = nullptr, const ProHost<T>* pro = nullptr, const EpiArgs<T>* epi = nullptr) {
   // ssync (CAVI step next to a look-ahead stream): the step's task-graph instantiation stores its `started` number (`used` is set)
   // defer_safe (in: the caller can run the fallback itself, k_safe_rowstats; out: whether it has to -- the task graph was used)
@@ -597,6 +614,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
   // path needs it in E first)
   const int64_t nt = n / TILE;
   const bool use_dag = chol_use_dag(c, nt, ne);
+  bool split_used = false;  // the launch went out as chain kernel + tile kernel: its fallback waits for the chain's exit count
   if (pro && !(use_dag && X && dag_fused_on() && !dag_trace_on() && !want_l && nt <= 32)) {
     c->err = "potrf_fused: a pending natural-gradient step can only ride on the CAVI step's task-graph launch";
     return AGP_ERR_INVALID;
@@ -691,9 +709,9 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
         if (hipMalloc((void**)&ptrace, 2048 * 8) != hipSuccess) ptrace = nullptr;
         if (ptrace) (void)hipMemsetAsync(ptrace, 0, 2048 * 8, c->stream);
       }
-      if (step_inst && chain_split_wanted(ntiles + nhelp, true) && chain_split_ready(c)) {  // chain kernel + tile kernel (k_chol_dag, ROLE)
-        ds.go = c->chain_go;
-        ds.go_val = ++c->chain_seq;
+      if (step_inst && chain_split_wanted(ntiles + nhelp, true, sizeof(T) == 8) && chain_split_ready(c)) {  // chain kernel + tile kernel (k_chol_dag, ROLE)
+        chain_split_arm(c, ds, 1);
+        split_used = true;
         hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, true, 1>), dim3(1), dim3(CHOL_THREADS), 0, c->chain_stream, one, 1,
                            (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, ptrace, H, hstride, nx, erow, 0,
                            ds, pa, epi ? *epi : EpiArgs<T>{});
@@ -725,8 +743,8 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       c->h_step_set = other;
     } else if (step_inst && chain_split_wanted(ntiles) && chain_split_ready(c)) {
       // ... as two kernels: the chain workgroup on its own stream (enqueued first), every other tile on this one
-      ds.go = c->chain_go;
-      ds.go_val = ++c->chain_seq;
+      chain_split_arm(c, ds, 1);
+      split_used = true;
       hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, false, 1>), dim3(1), dim3(CHOL_THREADS), 0, c->chain_stream, one, 1,
                          (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
                          0, ds);
@@ -753,6 +771,10 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       const char* e = getenv("AGP_DAG_TEST_ABORT");
       return e && e[0] == '1';
     }();
+    if (safe) {
+      safe->chain_done = split_used ? c->chain_ctr : nullptr;
+      safe->chain_want = c->chain_exits;
+    }
     if (safe && (!do_x || safe->want_x)) {
       if (test_abort) hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, c->stream, info_dev, -1);
       if (can_defer) *defer_safe = true;
@@ -811,8 +833,9 @@ static agp_status dag_lost_dependency(agp_ctx* c, int32_t* info_dev, bool* lost)
 constexpr int DAG_MAX_NB = 8;
 template <typename T>
 static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, int64_t ld, int64_t n, int64_t ldx, int64_t lde,
-                                  int64_t ne, int32_t* info_dev, int64_t nvalid, const SafeSrc<T>* safe = nullptr) {
+                                  int64_t ne, int32_t* info_dev, int64_t nvalid, SafeSrc<T>* safe = nullptr) {
   const int64_t nt = n / TILE;
+  bool split_used = false;
   const int64_t fstride = ((nt + ne) * nt + 3 * nt + 1) * DAG_FS, nf = fstride * nb;
   if (c->dag_cap < nf) {
     if (c->dag_flags) (void)hipFree(c->dag_flags);
@@ -831,8 +854,8 @@ static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, in
   AGPCHK(dag_handover_acquire<T>(c, hstride * nb, hs, &H));
   if (chain_split_wanted(ntiles * nb) && chain_split_ready(c)) {  // the nb chains as one kernel, all other tiles as another
     DagSync ds{};
-    ds.go = c->chain_go;
-    ds.go_val = ++c->chain_seq;
+    chain_split_arm(c, ds, nb);
+    split_used = true;
     hipLaunchKernelGGL((k_chol_dag<T, true, true, false, true, false, 1>), dim3((unsigned)nb), dim3(CHOL_THREADS), 0, c->chain_stream, bt,
                        nb, fstride, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, (unsigned long long*)nullptr, H,
                        hstride, (int64_t)0, (const T*)nullptr, 0, ds);
@@ -848,6 +871,8 @@ static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, in
   LAUNCHCHK(c);
   AGPCHK(dag_handover_release<T>(c, (3 * nt + (nt + ne) * nt) * TILE * TILE, hstride, nb, hs));
   if (safe) {
+    safe->chain_done = split_used ? c->chain_ctr : nullptr;
+    safe->chain_want = c->chain_exits;
     static const bool test_abort = []() {
       const char* e = getenv("AGP_DAG_TEST_ABORT");
       return e && e[0] == '1';
@@ -4210,6 +4235,7 @@ agp_status agp_ctx_destroy(agp_ctx* ctx) {
     (void)hipStreamDestroy(ctx->chain_stream);
   }
   if (ctx->chain_go) (void)hipFree(ctx->chain_go);
+  if (ctx->chain_ctr) (void)hipFree(ctx->chain_ctr);
   if (ctx->chain_done) (void)hipEventDestroy(ctx->chain_done);
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);

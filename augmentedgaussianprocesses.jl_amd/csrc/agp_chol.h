@@ -1035,6 +1035,9 @@ struct SafeSrc {
   int64_t mz = 0, ldz = 0, Dz = 0;
   int kkind = 0;
   T kvariance = T(1), kjitter = T(0);  // kvariance < 0: read kscales[Dz]
+  // split launch (k_chol_dag ROLE 1 / 2): the chain kernel(s) of the launch have counted themselves out when *chain_done >= chain_want
+  const int32_t* chain_done = nullptr;
+  int32_t chain_want = 0;
 };
 
 // the kernel functions of agp_cavi.h restated for the fallback (agp_chol.h is included first): base(d2), d2 = squared scaled distance
@@ -1073,6 +1076,15 @@ __device__ __forceinline__ bool chol_safe_body(const CholBatch<T>& bt, const Saf
                                                int64_t lde, int64_t ne, int64_t nt, int32_t* __restrict__ info, int64_t nvalid,
                                                unsigned* __restrict__ bar, int32_t* __restrict__ retries, T* sm, T* sc, T* piv) {
   if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != -1) return false;
+  if (src.chain_done) {  // a split launch: its chain kernel may still be writing diagonal factors for a few microseconds (DagSync::done)
+    if (threadIdx.x == 0) {
+      long spins = 0;
+      while ((int32_t)(__hip_atomic_load(src.chain_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - src.chain_want) < 0 &&
+             ++spins < (1L << 24))
+        __builtin_amdgcn_s_sleep(16);
+    }
+    __syncthreads();
+  }
   const unsigned nwg = gridDim.x;
   const int64_t n = nt * TILE, gsz = (int64_t)nwg * CHOL_THREADS, g0 = (int64_t)blockIdx.x * CHOL_THREADS + threadIdx.x;
   unsigned phase = 0;
@@ -1306,7 +1318,19 @@ struct DagSync {
   // precede the tile kernel on the step's stream are done; it waits for `go` == go_val, which the tile kernel stores when it starts
   int32_t* go = nullptr;
   int32_t go_val = 0;
+  // ... and counts itself out on `done` (one per chain workgroup, at every exit): the in-stream fallback of an ABORTED launch waits
+  // for that count before it rebuilds the inputs -- the only place where the tile kernel can end before the chain kernel has stopped
+  // writing (a chain that is in the middle of a tile factorisation notices the abort at its next wait, up to ~17 us later).  No
+  // event joins the two streams: the tile kernel cannot end before the chain's last publish, after which the chain writes nothing.
+  int32_t* done = nullptr;
 };
+// (ROLE 1) every thread's stores acknowledged, then one count
+__device__ __forceinline__ void chain_count_out(const DagSync& sync) {
+  if (!sync.done) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(sync.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Self-test for the hand-over below, run once per handle on the two streams at the same time: each side raises its own word
 // and waits (bounded, ~2 ms) for the other's.  Both succeed only if kernels of the two streams really are in flight together;
@@ -1671,7 +1695,10 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
       }
     }
     __syncthreads();
-    if (!wait_ok) return;
+    if (!wait_ok) {
+      chain_count_out(sync);
+      return;
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this kernel's caches may predate what those kernels wrote
   }
   T* bufA = sm;
@@ -1939,6 +1966,7 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
         }
         dag_signal(xready + k * DAG_FS, epoch);
         DAG_TRC(k, 3);
+        if (ROLE == 1) chain_count_out(sync);
         return;
       }
       const bool late_feed = !pf_ok || pf_bad;
@@ -1949,7 +1977,10 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
         // chains have already published, so the dispatch order alone guarantees progress -- no residency bound is needed.
         dag_signal(xready + k * DAG_FS, epoch);
         DAG_TRC(k, 3);
-        if (!dag_wait(pf.f1, pf.f2, epoch, abortf, info, &wait_ok)) return;
+        if (!dag_wait(pf.f1, pf.f2, epoch, abortf, info, &wait_ok)) {
+          if (ROLE == 1) chain_count_out(sync);
+          return;
+        }
         load_tiles_lds_hv2<T>(HP + 2 * (k + 1) * SLOT, bufC, HP + (2 * (k + 1) + 1) * SLOT, bufD);
         __syncthreads();
       }
@@ -2021,6 +2052,7 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
       }
       DAG_TRC(k + 1, 1);
     }
+    if (ROLE == 1) chain_count_out(sync);
     return;
   }
   if (ROLE == 1) return;

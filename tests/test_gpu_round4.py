@@ -219,7 +219,7 @@ def test_fp32_gate_at_the_c3_shape(mods):
 # split task-graph launch
 def _run_child(env_extra, code):
     env = dict(os.environ, **env_extra)
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout
 
@@ -344,3 +344,40 @@ def test_non_spd_K_inside_the_loop_is_reported_as_the_root_cause(mods):
     with pytest.raises(capi.AGPError) as ei:
         AGP.train_(m, X, y, 8, idx_stream=idx)
     assert ei.value.status == 2 and "K_ZZ" in str(ei.value), str(ei.value)  # AGP_ERR_NOT_POSDEF, not AGP_ERR_NEG_KTILDE
+
+
+def test_split_launch_with_prologue_lookahead_and_the_host_far_ahead(mods):
+    """Regression for a deadlock of the first version of the split launch (an event joined the chain kernel's stream with the step's
+    behind every launch): fp32, m = 1024, B = 2048 -- the prologue rides in the split launch --, look-ahead on, 200 steps enqueued
+    without a single synchronisation.  Now no event sits between the streams; the run must simply finish, and it
+    must land where the merged launch lands."""
+    code = r"""
+import sys, ctypes as C, hashlib
+sys.path.insert(0, '.')
+import numpy as np, torch
+import __graft_entry__ as g; g.build()
+import agp_amd as AGP
+from agp_amd import capi
+m, B, D, N, steps = 1024, 2048, 16, 50000, 200
+rng = np.random.default_rng(0)
+X = rng.random((N, D)); y = np.sin(X @ rng.standard_normal(D)) + 0.1 * rng.standard_normal(N)
+Z = X[rng.permutation(N)[:m]].copy()
+idx = np.stack([rng.choice(N, B, replace=False) for _ in range(32)])
+model = AGP.SVGP(AGP.with_lengthscale(AGP.Matern52Kernel(), 1.0), AGP.StudentTLikelihood(3.0), AGP.AnalyticSVI(B), Z, optimiser=False, T=np.float32)
+AGP.train_(model, X, y, 1, idx_stream=idx[:1])
+L, h = capi.lib(), model._h
+Xd, yd, _ = model._data
+ia = torch.as_tensor(idx, device="cuda")
+for i in range(steps):
+    j = i % 32
+    assert L.agp_svgp_cavi_step(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(yd.data_ptr()), C.c_void_p(ia[j].data_ptr()), B, N / B) == 0
+    L.agp_svgp_prefetch(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(ia[(j + 1) % 32].data_ptr()), B)
+torch.cuda.synchronize()
+mu, Sig, e1, e2 = model.get_state(0)
+assert np.all(np.isfinite(e2))
+print('HASH', hashlib.sha256(np.ascontiguousarray(e2).tobytes()).hexdigest())
+"""
+    get = lambda s: [l for l in s.splitlines() if l.startswith("HASH")][0]
+    h_split = get(_run_child({"AGP_CHAIN_SPLIT": "1"}, code))
+    h_merged = get(_run_child({"AGP_CHAIN_SPLIT": "0"}, code))
+    assert h_split == h_merged

@@ -40,6 +40,8 @@ from .svgp import (  # noqa: F401
     AnalyticVI,
     RobbinsMonro,
     objective,
+    objective_enqueue,
+    objective_fetch,
     predict_f,
     predict_y,
     proba_y,

@@ -123,6 +123,8 @@ SYMBOLS = {
     "agp_svgp_timing_read": (_I32, [_VP, _PI64, _PDBL]),
     "agp_svgp_check_status": (_I32, [_VP]),
     "agp_svgp_elbo": (_I32, [_VP, _VP, _I64, _VP, _VP, _I64, _DBL, _I32, _PDBL]),
+    "agp_svgp_elbo_enqueue": (_I32, [_VP, _VP, _I64, _VP, _VP, _I64, _DBL, _I32, _PI32]),
+    "agp_svgp_elbo_fetch": (_I32, [_VP, _I32, _I32, _PDBL, _PI32]),
     "agp_svgp_get_state": (_I32, [_VP, _I32, _VP, _VP, _VP, _VP]),
     "agp_svgp_set_state": (_I32, [_VP, _I32, _VP, _VP]),
     "agp_svgp_get_matrix": (_I32, [_VP, _I32, _I32, _VP, _I64, _I64]),

@@ -1111,6 +1111,9 @@ struct SvgpBase {
   virtual agp_status elbo(const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B, double rho,
                           int fresh, double* out) = 0;
   virtual agp_status elbo_terms(double* out3) = 0;
+  virtual agp_status elbo_enqueue(const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B, double rho, int fresh,
+                                  int32_t* ticket) = 0;
+  virtual agp_status elbo_fetch(int32_t ticket, int wait, double* out, int32_t* ready) = 0;
   virtual agp_status set_batch_shard(int rank, int world) = 0;
   virtual agp_status get_state(int l, void* mu, void* sigma, void* eta1, void* eta2) = 0;
   virtual agp_status set_state(int l, const void* eta1, const void* eta2) = 0;
@@ -1188,6 +1191,15 @@ struct SvgpBase {
     return AGP_OK;
   }
 };
+
+// the last line of the ELBO on the device (agp_svgp_elbo_enqueue): rho E_data - KL(q(u) || p(u)) - rho KL_aug from the five partial
+// results of the evaluation and log det K, written to mapped host memory -- no stream synchronisation on the host's side
+__global__ void k_elbo_combine(const double* __restrict__ sc, const double* __restrict__ half_logdetK, double m, double rho,
+                               double* __restrict__ out) {
+  const double kl = 0.5 * (2.0 * half_logdetK[0] + 2.0 * sc[2] + sc[3] + sc[4] - m);  // log det Sigma = -2 sc[2]
+  *out = rho * sc[0] - kl - rho * sc[1];
+  __threadfence_system();
+}
 
 struct agp_svgp {
   SvgpBase* impl;
@@ -1618,6 +1630,11 @@ struct Svgp : SvgpBase {
       if (pf_join[q]) dcheck(hipEventDestroy(pf_join[q]), __LINE__);
     }
     if (pf_fork) dcheck(hipEventDestroy(pf_fork), __LINE__);
+    if (elbo_pin) {
+      dcheck(hipHostFree(elbo_pin), __LINE__);
+      for (auto& e : elbo_ev)
+        if (e) dcheck(hipEventDestroy(e), __LINE__);
+    }
     if (pf_stream) dcheck(hipStreamDestroy(pf_stream), __LINE__);
     for (auto q : sig)
       if (q) dcheck(hipFree(q), __LINE__);
@@ -3458,6 +3475,16 @@ struct Svgp : SvgpBase {
                          (const T*)tmpv, pw0);
       hipLaunchKernelGGL((k_sumsq<T>), dim3(1), dim3(1024), 0, st(), (const T*)pw0, mp, scal_dev + 4);
       LAUNCHCHK(ctx);
+      if (elbo_async >= 0 && nl == 1 && !mo && !g.on && !use_stale && logdetK_dev) {
+        // agp_svgp_elbo_enqueue: the scalar is put together on the device and lands in mapped host memory behind an event
+        hipLaunchKernelGGL(k_elbo_combine, dim3(1), dim3(1), 0, st(), (const double*)scal_dev, (const double*)logdetK_dev, (double)m,
+                           rho, elbo_pin + elbo_async);
+        LAUNCHCHK(ctx);
+        HIPCHK(ctx, hipEventRecord(elbo_ev[elbo_async], st()));
+        elbo_async_used = true;
+        *out = 0.0;
+        return AGP_OK;
+      }
       double h[5];
       HIPCHK(ctx, hipMemcpyAsync(h, scal_dev, sizeof(double) * 5, hipMemcpyDeviceToHost, st()));
       HIPCHK(ctx, hipStreamSynchronize(st()));
@@ -3483,6 +3510,78 @@ struct Svgp : SvgpBase {
   }
   double e_data = 0, kl_aug = 0, mo_e = 0, mo_kl = 0, kl_gauss_last = 0;
   bool shard_once = true;
+
+  // ---- ELBO without a host round trip (round 4): agp_svgp_elbo_enqueue / agp_svgp_elbo_fetch --------------------------------------
+  // Convergence monitoring evaluates the ELBO every few iterations; the synchronous call costs a stream synchronisation and a
+  // read-back each time (C2: ~1 ms of idle GPU per check, a fifth of the time to the ELBO plateau).  enqueue() puts the same
+  // evaluation into the stream and returns a ticket; the value arrives in mapped host memory behind an event, and fetch() reads it
+  // when the caller wants it (wait = 0: only if it is there).  Models whose ELBO needs host-side pieces (several latents,
+  // multi-output, streaming prior, the frozen matrices of AGP_FLAG_STALE_K) are evaluated synchronously inside enqueue().
+  static constexpr int ELBO_RING = 8;
+  double* elbo_pin = nullptr;
+  hipEvent_t elbo_ev[ELBO_RING] = {};
+  bool elbo_ready[ELBO_RING] = {};   // the value was computed synchronously (elbo_val)
+  bool elbo_open[ELBO_RING] = {};
+  double elbo_val[ELBO_RING] = {};
+  int elbo_next = 0, elbo_async = -1;
+  bool elbo_async_used = false;
+  agp_status elbo_enqueue(const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B, double rho, int fresh,
+                          int32_t* ticket) override {
+    if (!ticket) return AGP_ERR_INVALID;
+    if (!elbo_pin) {
+      HIPCHK(ctx, hipHostMalloc((void**)&elbo_pin, sizeof(double) * ELBO_RING, hipHostMallocMapped));
+      for (auto& e : elbo_ev) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const int slot = elbo_next;
+    if (elbo_open[slot]) {
+      ctx->err = "agp_svgp_elbo_enqueue: more than 8 evaluations in flight (fetch the older tickets first)";
+      return AGP_ERR_INVALID;
+    }
+    elbo_async = slot;
+    elbo_async_used = false;
+    double v = 0.0;
+    const agp_status st_ = elbo(x, ldx, y, idx, B, rho, fresh, &v);
+    elbo_async = -1;
+    AGPCHK(st_);
+    if (elbo_async_used && fresh && pf_stream) {
+      // The evaluation's local step ran on the CURRENT kernel-matrix buffers (Knm, Wbuf, K~ slices) after its step_local had
+      // released them to the look-ahead (a fresh step between two CAVI steps releases the previous step's buffers where it starts).
+      // With the synchronous call the host waits for the evaluation before it enqueues anything else; here the look-ahead after
+      // next could overwrite them while the evaluation still reads them (seen as ELBO values off by tens of per cent): the release
+      // it will wait for is recorded again, behind the evaluation.
+      const int sl = step_parity ^ 1;
+      slot_kind[sl] = 0;
+      HIPCHK(ctx, hipEventRecord(step_done[sl], st()));
+    }
+    elbo_ready[slot] = !elbo_async_used;
+    elbo_val[slot] = v;
+    elbo_open[slot] = true;
+    elbo_next = (slot + 1) % ELBO_RING;
+    *ticket = slot;
+    return AGP_OK;
+  }
+  agp_status elbo_fetch(int32_t ticket, int wait, double* out, int32_t* ready) override {
+    if (ticket < 0 || ticket >= ELBO_RING || !elbo_open[ticket] || !out) return AGP_ERR_INVALID;
+    if (!elbo_ready[ticket]) {
+      if (wait) {
+        HIPCHK(ctx, hipEventSynchronize(elbo_ev[ticket]));
+      } else {
+        const hipError_t q = hipEventQuery(elbo_ev[ticket]);
+        if (q == hipErrorNotReady) {
+          (void)hipGetLastError();
+          if (ready) *ready = 0;
+          return AGP_OK;
+        }
+        HIPCHK(ctx, q);
+      }
+      elbo_val[ticket] = elbo_pin[ticket];
+      elbo_ready[ticket] = true;
+    }
+    *out = elbo_val[ticket];
+    elbo_open[ticket] = false;
+    if (ready) *ready = 1;
+    return AGP_OK;
+  }
   // this handle sees shard bs_rank of bs_world of every minibatch (batch-parallel).  Set by agp_svgp_set_batch_shard and -- so that
   // a host cannot forget it after a handle was re-created -- by every batch-mode *_multi call from its communicator.
   int bs_rank = 0, bs_world = 1;
@@ -4843,6 +4942,16 @@ agp_status agp_svgp_mo_predict_from_f(agp_svgp* h, int64_t n_t, int32_t mode, vo
   HCHKF(h);
   return h->impl->mo_predict_from_f(n_t, mode, out0, out1, gh_nodes_host, gh_weights_host, n_nodes);
 }
+agp_status agp_svgp_elbo_enqueue(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B, double rho,
+                                 int32_t fresh_local, int32_t* ticket) {
+  HCHKF(h);
+  return h->impl->elbo_enqueue(x, ldx, y, idx, B, rho, fresh_local, ticket);
+}
+agp_status agp_svgp_elbo_fetch(agp_svgp* h, int32_t ticket, int32_t wait, double* out_host, int32_t* ready) {
+  HCHK(h);
+  return h->impl->elbo_fetch(ticket, wait, out_host, ready);
+}
+
 agp_status agp_svgp_hyper_rule(agp_svgp* h, int32_t kernel_rule, double kernel_rho, int32_t z_rule, double z_rho) {
   HCHK(h);
   return h->impl->hyper_rule(kernel_rule, kernel_rho, z_rule, z_rho);

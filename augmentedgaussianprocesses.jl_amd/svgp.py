@@ -688,6 +688,26 @@ def objective(model: SVGP, state: Optional[State] = None, y=None) -> float:
     return out.value
 
 
+def objective_enqueue(model: SVGP) -> int:
+    """`objective(model, state, y)` put into the stream without waiting for it (agp_svgp_elbo_enqueue): returns a ticket for
+    `objective_fetch`.  For convergence monitoring inside a training loop: the next iterations are enqueued while the value is
+    on its way (up to 8 tickets in flight)."""
+    L = capi.lib()
+    Xd, yd, N = model._data
+    t = C.c_int32()
+    idx_ptr = getattr(model, "_last_idx", None)
+    model._chk(L.agp_svgp_elbo_enqueue(model._h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(yd.data_ptr()), idx_ptr,
+                                       model.inference.batchsize, model.inference.rho, 0, C.byref(t)))
+    return t.value
+
+
+def objective_fetch(model: SVGP, ticket: int, wait: bool = True):
+    """the value of an `objective_enqueue` ticket; with wait=False: None while it has not arrived yet"""
+    out, ready = C.c_double(), C.c_int32()
+    model._chk(capi.lib().agp_svgp_elbo_fetch(model._h, int(ticket), 1 if wait else 0, C.byref(out), C.byref(ready)))
+    return out.value if ready.value else None
+
+
 def ELBO(model: SVGP, X, y, *, obsdim: int = 1, rho: Optional[float] = None) -> float:
     """External ELBO(model, X, y) (src/functions/ELBO.jl:28-47): fresh local variables on (X, y), one local update.
     rho defaults to the reference's behaviour (the ρ left by the last train!, Appendix A Q13); pass rho=1 for the

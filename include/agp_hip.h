@@ -318,6 +318,15 @@ agp_status agp_svgp_check_status(agp_svgp* h);
  *                     batch, re-initialise local variables, one local update, then the ELBO; rho explicit. */
 agp_status agp_svgp_elbo(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B,
                          double rho, int32_t fresh_local, double* elbo_host);
+/* The same evaluation WITHOUT a host round trip (convergence monitoring: `objective(model, state, y)` every few iterations of
+ * train!, training.jl:71-90, evaluated while the next iterations are already enqueued).  enqueue puts the evaluation into the
+ * stream and returns a ticket (up to 8 in flight); the value lands in mapped host memory behind an event.  fetch returns it:
+ * wait = 1 blocks until it is there; wait = 0 only reports (*ready = 0 / 1).  A fetched ticket is closed.  Models whose ELBO has
+ * host-side pieces (several latents, multi-output, streaming prior, AGP_FLAG_STALE_K) are evaluated synchronously inside enqueue.
+ * agp_svgp_elbo_terms keeps referring to the last SYNCHRONOUS evaluation. */
+agp_status agp_svgp_elbo_enqueue(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B,
+                                 double rho, int32_t fresh_local, int32_t* ticket);
+agp_status agp_svgp_elbo_fetch(agp_svgp* h, int32_t ticket, int32_t wait, double* elbo_host, int32_t* ready);
 /* the three terms of the last agp_svgp_elbo call, ELBO = rho * terms[0] - terms[1] - rho * terms[2]: unscaled data term
  * (expec_loglikelihood), Gaussian KL (+ extraKL), unscaled augmented KL.  A batch-parallel driver sums terms 0 and 2 over the
  * minibatch shards and counts the (replicated) Gaussian KL once. */

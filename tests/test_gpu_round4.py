@@ -381,3 +381,88 @@ print('HASH', hashlib.sha256(np.ascontiguousarray(e2).tobytes()).hexdigest())
     h_split = get(_run_child({"AGP_CHAIN_SPLIT": "1"}, code))
     h_merged = get(_run_child({"AGP_CHAIN_SPLIT": "0"}, code))
     assert h_split == h_merged
+
+
+def test_enqueued_elbo_equals_the_synchronous_one(mods):
+    """agp_svgp_elbo_enqueue / agp_svgp_elbo_fetch: the ELBO evaluated in the stream without a host round trip (device-side
+    combination of the five partial results, value in mapped host memory behind an event) equals `objective(model, state, y)` of the
+    synchronous call; several tickets in flight while training continues; models with host-side pieces fall back to the
+    synchronous evaluation inside enqueue."""
+    AGP, R, capi, torch = mods
+    rng = np.random.default_rng(17)
+    X, f, Z = _toy(rng, N=500, m=32)
+    y = (f + 0.2 * rng.standard_normal(len(f)) > 0).astype(int)
+    B = 100
+    idx = [rng.choice(len(X), B, replace=False) for _ in range(12)]
+    sync_vals, async_vals, tickets = [], [], []
+    ma = AGP.SVGP(1.3 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0)), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z, optimiser=False)
+    AGP.train_(ma, X, y, 12, idx_stream=idx, callback=lambda mdl, s, i: sync_vals.append(AGP.objective(mdl, s)))
+    mb = AGP.SVGP(1.3 * (AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0)), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z, optimiser=False)
+
+    def cb(mdl, s, i):
+        tickets.append(AGP.objective_enqueue(mdl))
+        if len(tickets) > 3:  # keep a few in flight, fetch the oldest
+            async_vals.append(AGP.objective_fetch(mdl, tickets.pop(0)))
+
+    AGP.train_(mb, X, y, 12, idx_stream=idx, callback=cb)
+    async_vals += [AGP.objective_fetch(mb, t) for t in tickets]
+    assert len(async_vals) == 12 and np.allclose(async_vals, sync_vals, rtol=1e-12, atol=0)
+    # a multi-class model: several latents -> evaluated synchronously inside enqueue, same interface
+    yc = 1 + np.digitize(f, np.quantile(f, [0.33, 0.66]))
+    mc = AGP.SVGP(AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0), AGP.LogisticSoftMaxLikelihood(3), AGP.AnalyticSVI(B), Z, optimiser=False)
+    AGP.train_(mc, X, yc, 3, idx_stream=idx[:3])
+    t = AGP.objective_enqueue(mc)
+    assert AGP.objective_fetch(mc, t) == pytest.approx(AGP.objective(mc), rel=1e-12)
+
+
+def test_enqueued_fresh_elbo_with_training_and_look_ahead_continuing(mods):
+    """The setting of bench.py's time-to-ELBO loop: external ELBO (fresh local variables on an evaluation batch) enqueued every ten
+    iterations and fetched one check later, the training steps and the look-ahead of the next minibatches running on behind it.
+    The first version let the look-ahead after next overwrite the kernel-matrix buffers the evaluation was still reading (values
+    off by tens of per cent); the release of those buffers is now recorded behind the evaluation.  Same values as the synchronous
+    calls, bit for bit up to the last-place difference of the device-side combination."""
+    import ctypes as C
+
+    AGP, R, capi, torch = mods
+    L = capi.lib()
+    m, B, D, N, EVAL = 256, 256, 8, 20000, 2048
+    rng = np.random.default_rng(0)
+    X = rng.random((N, D))
+    y = np.sign(np.sin(X @ rng.standard_normal(D)) + 0.1 * rng.standard_normal(N))
+    Z = X[rng.permutation(N)[:m]].copy()
+    idx = np.stack([rng.choice(N, B, replace=False) for _ in range(32)])
+    ev_np = rng.choice(N, EVAL, replace=False).astype(np.int64)
+    seqs = {}
+    for mode in ("sync", "late"):
+        model = AGP.SVGP(AGP.with_lengthscale(AGP.SqExponentialKernel(), 0.7), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z, optimiser=False)
+        model.inference.rho = N / B
+        Xd = model._upload(X, 1)
+        yd = model._upload_y(model._treat(y))
+        model._data = (Xd, yd, N)
+        h = model._ensure_handle(EVAL)
+        model._chk(L.agp_svgp_refresh_K(h))
+        ia = torch.as_tensor(idx, device="cuda")
+        ev = torch.as_tensor(ev_np, device="cuda")
+        xp, yp, ld = C.c_void_p(Xd.data_ptr()), C.c_void_p(yd.data_ptr()), Xd.stride(0)
+        e, tk, rdy = C.c_double(), C.c_int32(), C.c_int32()
+        vals, it, prev = [], 0, None
+        for chk in range(8):
+            for _ in range(10):
+                model._chk(L.agp_svgp_cavi_step(h, xp, ld, yp, C.c_void_p(ia[it % 32].data_ptr()), B, N / B))
+                it += 1
+                model._chk(L.agp_svgp_prefetch(h, xp, ld, C.c_void_p(ia[it % 32].data_ptr()), B))
+            if mode == "sync":
+                model._chk(L.agp_svgp_elbo(h, xp, ld, yp, C.c_void_p(ev.data_ptr()), EVAL, N / EVAL, 1, C.byref(e)))
+                vals.append(e.value)
+            else:
+                model._chk(L.agp_svgp_elbo_enqueue(h, xp, ld, yp, C.c_void_p(ev.data_ptr()), EVAL, N / EVAL, 1, C.byref(tk)))
+                if prev is not None:
+                    model._chk(L.agp_svgp_elbo_fetch(h, prev, 1, C.byref(e), C.byref(rdy)))
+                    vals.append(e.value)
+                prev = tk.value
+        if mode == "late":
+            model._chk(L.agp_svgp_elbo_fetch(h, prev, 1, C.byref(e), C.byref(rdy)))
+            vals.append(e.value)
+        seqs[mode] = vals
+    assert len(seqs["late"]) == len(seqs["sync"]) == 8
+    assert np.allclose(seqs["late"], seqs["sync"], rtol=1e-13, atol=0), (seqs["late"], seqs["sync"])

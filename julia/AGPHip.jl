@@ -524,6 +524,26 @@ function objective(hm::HipModel, state=nothing, y=nothing)
     return out[]
 end
 
+# the same evaluation put into the stream without waiting for it (agp_svgp_elbo_enqueue / agp_svgp_elbo_fetch): a callback that
+# monitors convergence enqueues `t = objective_enqueue(hm)` and reads `objective_fetch(hm, t)` an iteration or ten later, so the
+# training loop never synchronises with the device (up to 8 tickets in flight)
+function objective_enqueue(hm::HipModel)
+    B = hm.last_idx === nothing ? hm.N : length(hm.last_idx)
+    ρ = AGP.is_stochastic(hm.model) ? hm.N / B : 1.0
+    idp = hm.last_idx === nothing ? Ptr{Int64}(C_NULL) : pointer(hm.last_idx)
+    t = Ref{Int32}()
+    check(hm.ctx, ccall((:agp_svgp_elbo_enqueue, libagp), Int32,
+                        (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int64, Float64, Int32, Ref{Int32}),
+                        hm.h, pointer(hm.X), size(hm.X, 1), pointer(hm.y), idp, B, ρ, 0, t))
+    return t[]
+end
+function objective_fetch(hm::HipModel, ticket::Integer; wait::Bool=true)
+    out, ready = Ref{Float64}(), Ref{Int32}()
+    check(hm.ctx, ccall((:agp_svgp_elbo_fetch, libagp), Int32, (Ptr{Cvoid}, Int32, Int32, Ref{Float64}, Ref{Int32}),
+                        hm.h, ticket, wait ? 1 : 0, out, ready))
+    return ready[] == 1 ? out[] : nothing
+end
+
 # external ELBO(model, X, y) (src/functions/ELBO.jl:28-47): kernel matrices recomputed on (X, y), fresh local variables, one local
 # update.  The reference keeps ρ = N/B of the last train! here (Appendix A Q13); pass ρ = 1 for the properly scaled value.
 function ELBO(hm::HipModel{T}, X::AbstractMatrix, y::AbstractArray; obsdim=1, ρ::Real=AGP.ρ(AGP.inference(hm.model))) where {T}

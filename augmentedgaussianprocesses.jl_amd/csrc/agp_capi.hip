@@ -250,6 +250,11 @@ static agp_status ensure_safe_words(agp_ctx* c) {
   return AGP_OK;
 }
 
+// Workgroups the grid-barrier fallback may count on being resident together.  One per CU -- minus the CUs a chain kernel of the
+// NEXT split launch may be sitting on: with the host ahead, that kernel is already in flight on its own stream, polls for a tile
+// kernel that is enqueued BEHIND the fallback, and holds most of its CU's LDS while it does (a fallback workgroup cannot share the
+// CU).  A fallback grid of n_cu workgroups would then wait at its first barrier for a workgroup that can never be placed.
+static int64_t safe_grid_cap(const agp_ctx* c) { return std::max<int64_t>(1, (int64_t)c->n_cu - (c->chain_state == 1 ? CHOL_MAXB : 0)); }
 // the fallback behind a task-graph launch (see k_chol_safe): one launch that returns at once unless the latch reads -1
 template <typename T>
 static agp_status launch_chol_safe(agp_ctx* c, const CholBatch<T>& bt, const SafeSrc<T>& src, int nb, int64_t ld, int64_t ldx,
@@ -257,7 +262,7 @@ static agp_status launch_chol_safe(agp_ctx* c, const CholBatch<T>& bt, const Saf
   AGPCHK(ensure_safe_words<T>(c));
   // one workgroup per CU at most (each needs ~110 KB of LDS, so one fits per CU): all of them become resident, whatever else runs
   const int64_t most = (nt + ne + nt * (nt + 1) / 2 + ne * nt) * nb;
-  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(c->n_cu, most));
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(safe_grid_cap(c), most));
   hipLaunchKernelGGL((k_chol_safe<T>), dim3(grid), dim3(CHOL_THREADS), 0, c->stream, bt, src, nb, ld, ldx, lde, ne, nt, info_dev,
                      nvalid, c->safe_bar, c->safe_retries);
   LAUNCHCHK(c);
@@ -2313,7 +2318,7 @@ struct Svgp : SvgpBase {
         AGPCHK(ensure_safe_words<T>(ctx));
         const int64_t nt_ = mp / TILE, ne_ = Bq / TILE + 1;
         const int64_t most = std::max<int64_t>(nt_ + ne_ + nt_ * (nt_ + 1) / 2 + ne_ * nt_, (B + 7) / 8);
-        const unsigned g1 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ctx->n_cu, most));
+        const unsigned g1 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(safe_grid_cap(ctx), most));
         if (use_epi) {  // the rows are done inside the task graph: the fallback launch waits for the head of the next step
           sdef.on = true;
           sdef.bt = merged_bt;

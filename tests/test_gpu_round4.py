@@ -466,3 +466,37 @@ def test_enqueued_fresh_elbo_with_training_and_look_ahead_continuing(mods):
         seqs[mode] = vals
     assert len(seqs["late"]) == len(seqs["sync"]) == 8
     assert np.allclose(seqs["late"], seqs["sync"], rtol=1e-13, atol=0), (seqs["late"], seqs["sync"])
+
+
+def test_split_launch_fallback_with_a_full_grid_and_the_host_ahead(mods):
+    """The grid-barrier fallback behind an aborted SPLIT launch at a size where it wants one workgroup on every CU (m = B = 1024:
+    441 shares), with the host several steps ahead: the chain kernel of the next launch is then already in flight and sits on a CU
+    the fallback cannot use -- its grid leaves those CUs out (safe_grid_cap), otherwise its first barrier would never complete.
+    Every launch is made to abort (AGP_DAG_TEST_ABORT=1); the trajectory must equal the undisturbed one to rounding."""
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, '.')
+import __graft_entry__ as g; g.build()
+import agp_amd as AGP
+rng = np.random.default_rng(6)
+N, D, m, B, iters = 6000, 6, 1024, 1024, 6
+X = rng.random((N, D)); f = np.sin(4 * X[:, 0]) + X[:, 1] - 0.8
+y = np.sign(f + 0.3 * rng.standard_normal(N))
+Z = X[rng.permutation(N)[:m]].copy()
+idx = [rng.choice(N, B, replace=False) for _ in range(iters)]
+ma = AGP.SVGP(AGP.SqExponentialKernel() @ AGP.ScaleTransform(3.0), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z, optimiser=False)
+AGP.train_(ma, X, y, iters, idx_stream=idx)
+mu, Sig, e1, e2 = ma.get_state(0)
+np.save(sys.argv[1], e2)
+print('OK')
+"""
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        pa, pb = os.path.join(td, "a.npy"), os.path.join(td, "b.npy")
+        for env, path in (({"AGP_CHAIN_SPLIT": "1", "AGP_DAG_TEST_ABORT": "1"}, pa), ({"AGP_CHAIN_SPLIT": "0"}, pb)):
+            r = subprocess.run([sys.executable, "-c", code, path], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True,
+                               timeout=300)
+            assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+        a, b = np.load(pa), np.load(pb)
+        assert _rel(a, b) < 1e-9

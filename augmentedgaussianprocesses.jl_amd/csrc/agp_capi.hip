@@ -234,6 +234,12 @@ static bool chol_use_dag(const agp_ctx* c, int64_t nt, int64_t ne = 0, int64_t n
 __global__ void k_set_i32(int32_t* p, int32_t v) { *p = v; }
 // ... visible to a polling kernel of another stream (signal memory, system scope)
 __global__ void k_set_sig(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// ... and the arrival word of a column group of the all-reduced statistics (comm_allreduce_groups): the collective's kernel before
+// this one on the same stream has ended, i.e. its writes are in memory
+__global__ void k_set_arrive(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+static agp_status comm_allreduce_groups(agp_comm* cm, void* base, int esz, const int64_t* off, const int64_t* cnt, int ng,
+                                        int32_t dtype, int32_t* arrive, int32_t epoch);  // (defined with agp_comm_allreduce)
 
 // grid-barrier words, retry counter and the CU count of the fallback (allocated on first use)
 template <typename T>
@@ -546,6 +552,9 @@ struct ProHost {
   const T* kinv_mu0 = nullptr;
   T lr = T(0);
   const T *packed = nullptr, *tred = nullptr;  // batch-parallel step: reduced statistics instead of (kap, w, r)  (ProArgs)
+  const int32_t* arrive = nullptr;             // ... arriving in block-column groups (AGP_SPLIT_OVERLAP)
+  int32_t arrive_want = 0;
+  unsigned char grp[32] = {};
 };
 // k-slices per block column of the prologue's product: a tile of block column c has to be there when the chain reaches the
 // column (about tau * c after the start, tau = 17.8 us f64 / 14 us f32 per block column), a 64-row chunk of the product costs a
@@ -692,6 +701,9 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       pa.lr = pro->lr;
       pa.packed = pro->packed;
       pa.tred = pro->tred;
+      pa.arrive = pro->arrive;
+      pa.arrive_want = pro->arrive_want;
+      memcpy(pa.grp, pro->grp, sizeof(pa.grp));
       pa.HS = H + (3 * nt + (nt + ne + nx) * nt) * TILE * TILE;
       pa.sflags = c->dag_flags + ((nt + ne + nx) * nt + 3 * nt + 1) * DAG_FS;
       const int other = hs ^ 1;
@@ -1390,7 +1402,18 @@ struct Svgp : SvgpBase {
     bool on = false;
     T lr = T(0);
     const T *Kinv = nullptr, *kinv_mu0 = nullptr;
+    // AGP_SPLIT_OVERLAP: the statistics are still arriving, group by group, on the communicator's stream (arrive words at `epoch`)
+    bool overlap = false;
+    int32_t epoch = 0;
+    agp_comm* cm = nullptr;
   } pendp;
+  // arrival words of the block-column groups (device memory, ARRIVE_STRIDE apart), the step counter they carry, the groups
+  int32_t* arrive_dev = nullptr;
+  int32_t arrive_epoch = 0;
+  int ov_ng = 0;
+  int64_t ov_nt = 0;
+  int64_t ov_off[8] = {}, ov_cnt[8] = {};
+  unsigned char ov_grp[32] = {};
   // Second (r, w) pair: a task-graph launch with the row-statistics EPILOGUE (EpiArgs) writes this step's r, w while late workgroups
   // of its own prologue may still read the previous step's -- the two pairs alternate.
   T *rbuf2 = nullptr, *wbuf2 = nullptr;
@@ -1459,6 +1482,10 @@ struct Svgp : SvgpBase {
                                   g.eta1, pend.kinv_mu0)));
     } else {
       pendp.on = false;
+      if (pendp.overlap) {  // the stand-alone step reads the whole statistic: join the collective's stream
+        pendp.overlap = false;
+        HIPCHK(ctx, hipStreamWaitEvent(st(), pendp.cm->ev_out, 0));
+      }
       const int64_t ntri = (mp / TILE) * (mp / TILE + 1) / 2;
       hipLaunchKernelGGL((k_eta2_from_packed<T>), dim3((unsigned)(4 * ntri + (mp + 255) / 256)), dim3(256), 0, st(), stats + mp, mp,
                          g.eta2, pendp.Kinv, g.La, pendp.lr, ntri, (const T*)stats, pendp.kinv_mu0, g.eta1, mp);
@@ -1643,6 +1670,7 @@ struct Svgp : SvgpBase {
     if (pf_stream) dcheck(hipStreamDestroy(pf_stream), __LINE__);
     for (auto q : sig)
       if (q) dcheck(hipFree(q), __LINE__);
+    if (arrive_dev) dcheck(hipFree(arrive_dev), __LINE__);
     if (pf_done) dcheck(hipEventDestroy(pf_done), __LINE__);
     for (auto e : step_done)
       if (e) dcheck(hipEventDestroy(e), __LINE__);
@@ -2232,6 +2260,11 @@ struct Svgp : SvgpBase {
             if (pendp.on) {  // reduced statistics of a batch-parallel step
               ph.packed = stats + mp;
               ph.tred = stats;
+              if (pendp.overlap) {
+                ph.arrive = arrive_dev;
+                ph.arrive_want = pendp.epoch;
+                memcpy(ph.grp, ov_grp, sizeof(ph.grp));
+              }
               ph.Kdim = 0;
               ph.Kinv = pendp.Kinv;
               ph.kinv_mu0 = pendp.kinv_mu0;
@@ -2280,7 +2313,7 @@ struct Svgp : SvgpBase {
                                 (const T*)lat[todo[l0]].eta1, false, &src, &defer, sync_step ? &ssync : nullptr,
                                 use_pro ? &ph : nullptr, use_epi ? &ea : nullptr));
           if (use_pro) {  // the launch has taken the pending step (had it been refused, the step would still be pending for flush())
-            pend.on = pendp.on = false;
+            pend.on = pendp.on = pendp.overlap = false;
             n_prologue += 1;
           }
           merged_safe = defer;
@@ -3351,6 +3384,10 @@ struct Svgp : SvgpBase {
       ctx->err = "the look-ahead stream waited about a minute for a CAVI step that never started (k_wait_ge)";
       return AGP_ERR_HIP;
     }
+    if (info == -4) {
+      ctx->err = "AGP_SPLIT_OVERLAP: a column group of the all-reduced statistics did not arrive within the gate's limit";
+      return AGP_ERR_HIP;
+    }
     if (info < 0) {
       ctx->err = "task-graph factorisation aborted: a tile dependency never arrived (spin limit)";
       return AGP_ERR_HIP;
@@ -4066,6 +4103,39 @@ struct Svgp : SvgpBase {
     return agp_comm_allreduce(cm, buf, count, dtype);
   }
 
+  // block-column groups of the packed statistics for AGP_SPLIT_OVERLAP: AGP_SPLIT_OVERLAP_GROUPS (default 4, at most 8) groups of
+  // about equal tile count; group 0 also carries t (it sits in front of block column 0 in `stats`)
+  agp_status overlap_groups() {
+    const int64_t nt = mp / TILE;
+    int want = 4;
+    if (const char* e = getenv("AGP_SPLIT_OVERLAP_GROUPS")) want = atoi(e);
+    want = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, 8), nt));
+    if (!arrive_dev) {
+      HIPCHK(ctx, hipMalloc((void**)&arrive_dev, 8 * ARRIVE_STRIDE * sizeof(int32_t)));
+      HIPCHK(ctx, hipMemsetAsync(arrive_dev, 0, 8 * ARRIVE_STRIDE * sizeof(int32_t), st()));
+    }
+    if (ov_nt == nt && ov_ng == want) return AGP_OK;
+    auto cum = [&](int64_t c) { return c * nt - c * (c - 1) / 2; };  // tiles of block columns [0, c)
+    const int64_t total = cum(nt);
+    int64_t bnd[9];
+    bnd[0] = 0;
+    for (int g = 1; g < want; ++g) {
+      const double tgt = (double)total * g / want;
+      int64_t c = bnd[g - 1] + 1;
+      while (c < nt - (want - g) && std::fabs((double)cum(c + 1) - tgt) < std::fabs((double)cum(c) - tgt)) ++c;
+      bnd[g] = c;
+    }
+    bnd[want] = nt;
+    for (int g = 0; g < want; ++g) {
+      ov_off[g] = g == 0 ? 0 : mp + cum(bnd[g]) * TILE * TILE;
+      ov_cnt[g] = (g == 0 ? mp : 0) + (cum(bnd[g + 1]) - cum(bnd[g])) * TILE * TILE;
+      for (int64_t c = bnd[g]; c < bnd[g + 1]; ++c) ov_grp[c] = (unsigned char)g;
+    }
+    ov_ng = want;
+    ov_nt = nt;
+    return AGP_OK;
+  }
+
   agp_status cavi_step_multi(agp_comm* cm, int mode, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B,
                              double rho) override {
     if (mode != AGP_SHARD_LATENT && mode != AGP_SHARD_BATCH) return AGP_ERR_INVALID;
@@ -4131,10 +4201,31 @@ struct Svgp : SvgpBase {
       return step_global(true);
     }
     AGPCHK(step_stats(false));
-    AGPCHK(comm_sum(cm, stats, (int64_t)nl * stats_stride()));
+    // AGP_SPLIT_OVERLAP=1 (default off; read at every call so that bench.py can A/B it in one process): the statistics travel in
+    // block-column groups on the communicator's own stream and the next task-graph launch starts on the first group
+    // (comm_allreduce_groups).  Only where the step rides on the task-graph launches (`merge`).
+    bool overlap = false;
+    if (merge) {
+      const char* e = getenv("AGP_SPLIT_OVERLAP");
+      overlap = e && e[0] == '1';
+    }
+    if (overlap) {
+      if (cm->ctx != ctx) {
+        ctx->err = "agp_comm belongs to another ctx (its collectives would run on another stream)";
+        return AGP_ERR_INVALID;
+      }
+      AGPCHK(overlap_groups());
+      arrive_epoch += 1;
+      AGPCHK(comm_allreduce_groups(cm, stats, (int)sizeof(T), ov_off, ov_cnt, ov_ng, sizeof(T) == 8 ? AGP_F64 : AGP_F32, arrive_dev,
+                                   arrive_epoch));
+    } else
+      AGPCHK(comm_sum(cm, stats, (int64_t)nl * stats_stride()));
     if (merge) {
       Latent& g = lat[0];
       pendp.on = true;
+      pendp.overlap = overlap;
+      pendp.epoch = arrive_epoch;
+      pendp.cm = cm;
       pendp.lr = (T)cur_lr();
       pendp.Kinv = kinv_step(g);
       pendp.kinv_mu0 = kinv_mu0_step(g);
@@ -5192,6 +5283,12 @@ agp_status agp_comm_destroy(agp_comm* cm) {
   DevGuard guard(cm->ctx->device);
   (void)hipStreamSynchronize(cm->ctx->stream);
   for (auto e : cm->ev) (void)hipEventDestroy(e);
+  if (cm->side) {
+    (void)hipStreamSynchronize(cm->side);
+    (void)hipStreamDestroy(cm->side);
+  }
+  if (cm->ev_in) (void)hipEventDestroy(cm->ev_in);
+  if (cm->ev_out) (void)hipEventDestroy(cm->ev_out);
   if (cm->kind == 0 && cm->nccl) {
     std::string why;
     RcclApi* api = rccl_api(why);
@@ -5209,12 +5306,31 @@ agp_status agp_comm_info(agp_comm* cm, int32_t* rank_host, int32_t* world_host, 
   return AGP_OK;
 }
 
-agp_status agp_comm_allreduce(agp_comm* cm, void* buf, int64_t count, int32_t dtype) {
-  if (!cm || !buf || count <= 0 || (dtype != AGP_F64 && dtype != AGP_F32)) return AGP_ERR_INVALID;
+}  // extern "C"
+
+// one in-place sum on `stream` through whichever transport the communicator has
+static agp_status comm_issue(agp_comm* cm, void* buf, int64_t count, int32_t dtype, hipStream_t stream) {
   agp_ctx* ctx = cm->ctx;
-  DevGuard guard(ctx->device);
-  cm->n_calls += 1;
-  cm->bytes += count * (dtype == AGP_F64 ? 8 : 4);
+  if (cm->kind == 0) {
+    std::string why;
+    RcclApi* api = rccl_api(why);
+    if (!api) return AGP_ERR_UNSUPPORTED;
+    ncclResult_t r = api->AllReduce(buf, buf, (size_t)count, dtype == AGP_F64 ? ncclFloat64 : ncclFloat32, ncclSum, cm->nccl, stream);
+    if (r != ncclSuccess) {
+      ctx->err = std::string("ncclAllReduce : ") + api->GetErrorString(r);
+      return AGP_ERR_HIP;
+    }
+  } else {
+    const int32_t r = cm->fn(cm->user, buf, count, dtype, (void*)stream);
+    if (r != 0) {
+      ctx->err = "agp_comm: the host all-reduce callback failed with code " + std::to_string(r);
+      return AGP_ERR_HIP;
+    }
+  }
+  return AGP_OK;
+}
+static agp_status comm_timing_begin(agp_comm* cm, hipStream_t stream) {
+  agp_ctx* ctx = cm->ctx;
   cm->timing_now = cm->timing && ((cm->n_calls - 1) % cm->timing_every == 0);
   if (cm->timing_now) {
     if (cm->ev_used + 2 > cm->ev.size())
@@ -5223,31 +5339,63 @@ agp_status agp_comm_allreduce(agp_comm* cm, void* buf, int64_t count, int32_t dt
         HIPCHK(ctx, hipEventCreate(&e));
         cm->ev.push_back(e);
       }
-    HIPCHK(ctx, hipEventRecord(cm->ev[cm->ev_used], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(cm->ev[cm->ev_used], stream));
   }
-  if (cm->kind == 0) {
-    std::string why;
-    RcclApi* api = rccl_api(why);
-    if (!api) return AGP_ERR_UNSUPPORTED;
-    ncclResult_t r = api->AllReduce(buf, buf, (size_t)count, dtype == AGP_F64 ? ncclFloat64 : ncclFloat32, ncclSum, cm->nccl,
-                                    ctx->stream);
-    if (r != ncclSuccess) {
-      ctx->err = std::string("ncclAllReduce : ") + api->GetErrorString(r);
-      return AGP_ERR_HIP;
-    }
-  } else {
-    const int32_t r = cm->fn(cm->user, buf, count, dtype, (void*)ctx->stream);
-    if (r != 0) {
-      ctx->err = "agp_comm: the host all-reduce callback failed with code " + std::to_string(r);
-      return AGP_ERR_HIP;
-    }
-  }
+  return AGP_OK;
+}
+static agp_status comm_timing_end(agp_comm* cm, hipStream_t stream) {
+  agp_ctx* ctx = cm->ctx;
   if (cm->timing_now) {
-    HIPCHK(ctx, hipEventRecord(cm->ev[cm->ev_used + 1], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(cm->ev[cm->ev_used + 1], stream));
     cm->ev_used += 2;
     cm->n_timed += 1;
   }
   return AGP_OK;
+}
+
+// AGP_SPLIT_OVERLAP: the batch-parallel statistics as a train of `ng` ranges (block-column groups, agp_chol.h pack_index) on the
+// communicator's OWN stream, ordered after what the ctx's stream holds now; after range g a one-thread kernel stores `epoch` into
+// arrive[g * ARRIVE_STRIDE], which the tile workgroups of the NEXT task-graph launch poll (pro_arrival_gate) -- that launch is
+// enqueued on the ctx's stream right away and starts on group 0 while the others are still travelling.  Nothing on the ctx's stream
+// waits for the train (cm->ev_out is there for a flush that wants the whole statistic).  Counted as ONE collective call of the sum
+// of the ranges for agp_comm_stats; with timing on, the events bracket the whole train on the side stream.
+static agp_status comm_allreduce_groups(agp_comm* cm, void* base, int esz, const int64_t* off, const int64_t* cnt, int ng,
+                                        int32_t dtype, int32_t* arrive, int32_t epoch) {
+  agp_ctx* ctx = cm->ctx;
+  DevGuard guard(ctx->device);
+  if (!cm->side) {
+    int lo = 0, hi = 0;
+    HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(ctx, hipStreamCreateWithPriority(&cm->side, hipStreamNonBlocking, hi));
+    HIPCHK(ctx, hipEventCreateWithFlags(&cm->ev_in, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&cm->ev_out, hipEventDisableTiming));
+  }
+  HIPCHK(ctx, hipEventRecord(cm->ev_in, ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(cm->side, cm->ev_in, 0));
+  cm->n_calls += 1;
+  AGPCHK(comm_timing_begin(cm, cm->side));
+  for (int g = 0; g < ng; ++g) {
+    cm->bytes += cnt[g] * esz;
+    AGPCHK(comm_issue(cm, (char*)base + off[g] * esz, cnt[g], dtype, cm->side));
+    hipLaunchKernelGGL(k_set_arrive, dim3(1), dim3(1), 0, cm->side, arrive + g * ARRIVE_STRIDE, epoch);
+    LAUNCHCHK(ctx);
+  }
+  AGPCHK(comm_timing_end(cm, cm->side));
+  HIPCHK(ctx, hipEventRecord(cm->ev_out, cm->side));
+  return AGP_OK;
+}
+
+extern "C" {
+
+agp_status agp_comm_allreduce(agp_comm* cm, void* buf, int64_t count, int32_t dtype) {
+  if (!cm || !buf || count <= 0 || (dtype != AGP_F64 && dtype != AGP_F32)) return AGP_ERR_INVALID;
+  agp_ctx* ctx = cm->ctx;
+  DevGuard guard(ctx->device);
+  cm->n_calls += 1;
+  cm->bytes += count * (dtype == AGP_F64 ? 8 : 4);
+  AGPCHK(comm_timing_begin(cm, ctx->stream));
+  AGPCHK(comm_issue(cm, buf, count, dtype, ctx->stream));
+  return comm_timing_end(cm, ctx->stream);
 }
 
 agp_status agp_comm_timing(agp_comm* cm, int32_t on) {
@@ -5266,6 +5414,7 @@ agp_status agp_comm_stats(agp_comm* cm, int64_t* n_calls_host, int64_t* bytes_ho
   double ms = 0.0;
   if (cm->ev_used) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (cm->side) HIPCHK(ctx, hipStreamSynchronize(cm->side));
     for (size_t i = 0; i + 1 < cm->ev_used; i += 2) {
       float t = 0;
       HIPCHK(ctx, hipEventElapsedTime(&t, cm->ev[i], cm->ev[i + 1]));

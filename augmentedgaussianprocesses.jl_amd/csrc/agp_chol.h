@@ -759,6 +759,13 @@ __device__ __forceinline__ void tri_index(int64_t idx, int64_t& ti, int64_t& tj)
   tj = idx - t * (t + 1) / 2;
 }
 
+// Packed lower tiles of the batch-parallel statistics (SY_PACK): block column by block column -- tile (ta, tb <= ta) of an nt x nt
+// grid at index tb nt - tb (tb - 1) / 2 + (ta - tb) -- so that a range of block columns is one contiguous range of the buffer: the
+// all-reduce can travel, and arrive, in column groups (AGP_SPLIT_OVERLAP), and block column 0 is what the factorisation needs first.
+__host__ __device__ __forceinline__ int64_t pack_index(int64_t ta, int64_t tb, int64_t nt) {
+  return tb * nt - tb * (tb - 1) / 2 + (ta - tb);
+}
+
 // ---- XCD-aware workgroup -> tile maps (speed only: the dispatcher is observed to place workgroup b on XCD b % 8, and each XCD
 // has its own 4 MiB L2; nothing depends on it for correctness).  With the launch order as tile order every XCD ends up reading
 // ALL operand panels (C2's kappa GEMM: 72 MB through the fabric for a 16 MB operand set); giving each XCD a contiguous range of
@@ -1565,11 +1572,36 @@ struct ProArgs {
   // vector t = kappa' r); the prologue then only takes the eta step from them (Kdim = 0: no product, no helpers)
   const T* packed = nullptr;
   const T* tred = nullptr;
+  // AGP_SPLIT_OVERLAP: those statistics arrive in groups of block columns, all-reduced one after the other on the communicator's
+  // own stream; arrive[g * ARRIVE_STRIDE] holds the number of the last step whose group g is complete (t travels with group 0).
+  // A workgroup waits for the group of its block column before it reads its tile (pro_arrival_gate).
+  const int32_t* arrive = nullptr;
+  int32_t arrive_want = 0;
+  unsigned char grp[32] = {};
   unsigned char ks[32] = {};
   // k-split of the PRO_NEAR tiles next to the diagonal of block column c (the chain's two feeders and the two tiles the NEXT
   // feeders wait for): their product has to be done while the chain is at most a column or two away, whatever the column
   unsigned char kf[32] = {};  // k-slices per block column (1: the tile workgroup forms the whole product itself)
 };
+
+// The gate of AGP_SPLIT_OVERLAP.  It is NOT one of the task graph's abortable waits: what it waits for was enqueued before this
+// launch and depends on nothing in it, and a workgroup that gave up here would leave its tile of eta2 un-stepped for the in-stream
+// fallback (which relies on every prologue having completed).  Its limit (seconds) is a hang guard: info = -4.
+constexpr int ARRIVE_STRIDE = 16;  // one word per 64 bytes
+__device__ __forceinline__ void pro_arrival_gate(const int32_t* arrive, int g, int32_t want, int32_t* info) {
+  if (threadIdx.x == 0) {
+    long spins = 0;
+    while ((int32_t)(__hip_atomic_load(arrive + g * ARRIVE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1L << 23)) {
+        atomicExch(info, -4);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the collective's kernel wrote the tile after this launch started
+}
 
 // acc += sum over the 64-row chunks [q0, q1) of kappa of  (w .* kappa[:, R0 + .])' kappa[:, c0 + .]  -- 64-deep chunks staged in
 // LDS as [r][k] tiles (the layout mma8 reads), two buffer pairs alternating, the next chunk's global loads in flight during the
@@ -1796,7 +1828,8 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
     acc.zero();
     pro_slice<T>(pro.kap, pro.ldk, pro.w, R * TILE, c0, 0, nq / ksc, sm, acc);
     if (pro.packed) {  // the reduced statistic of this tile (what k_eta2_from_packed reads)
-      const T* __restrict__ tp = pro.packed + (R * (R + 1) / 2 + c) * (TILE * TILE);
+      if (pro.arrive) pro_arrival_gate(pro.arrive, pro.grp[c], pro.arrive_want, info);
+      const T* __restrict__ tp = pro.packed + pack_index(R, c, nt) * (TILE * TILE);
       acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = tp[r * TILE + cc]; });
     }
     PRO_TS(tsb + 1);
@@ -1879,6 +1912,7 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
     acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = (on_diag && r == cc) ? T(1) : T(0); });
   } else if (PRO && ext && R == nt + ne - 1) {
     // ---- prologue of the [eta1' ; 0] tile: t = kappa[:, c0 ..]' r (eight row groups, fixed order), eta1 step, row 0 <- eta1
+    if (pro.tred && pro.arrive) pro_arrival_gate(pro.arrive, 0, pro.arrive_want, info);
     const int col = tid & 63, grp = tid >> 6;
     T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
     int64_t k = grp;
@@ -1897,7 +1931,7 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
       T t = T(0);
 #pragma unroll
       for (int q = 0; q < CHOL_THREADS / 64; ++q) t += sc[q * TILE + col];
-      if (pro.tred) t = pro.tred[c0 + col];
+      if (pro.tred) t = pro.tred[c0 + col];  // (pro.arrive: group 0 was waited for above)
       T e = pro.eta1[c0 + col];
       e += pro.lr * (t + (pro.kinv_mu0 ? pro.kinv_mu0[c0 + col] : T(0)) - e);
       pro.eta1[c0 + col] = e;

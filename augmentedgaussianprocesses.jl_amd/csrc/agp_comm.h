@@ -94,4 +94,8 @@ struct agp_comm {
   bool timing_now = false;
   std::vector<hipEvent_t> ev;
   size_t ev_used = 0;
+  // AGP_SPLIT_OVERLAP: the collective's own stream (highest priority) and the two events that tie it to the ctx's stream --
+  // `ev_in`: what the collective reduces is complete; `ev_out`: its last group is done (only waited for by a flush)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
 };

@@ -115,8 +115,9 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_gemm_nt_eminus_sym(const T* _
 //                g = -(S + Kinv/2) - eta2 ; eta2 += lr*g ; out(=Amat) = -2*eta2     (both triangles)
 //              lr = RobbinsMonro step (or 1 for AnalyticVI), passed by value.
 // ---------------------------------------------------------------------------------------------------
-//   SY_PACK  : S -> out as packed lower tiles: tile (ta, tb <= ta) at out + (ta(ta+1)/2 + tb) * 64*64, row-major inside the
-//              tile (the batch-parallel statistics buffer: one triangle travels over xGMI)
+//   SY_PACK  : S -> out as packed lower tiles, block column by block column: tile (ta, tb <= ta) at out + pack_index(ta, tb, nt)
+//              * 64*64 (agp_chol.h), row-major inside the tile (the batch-parallel statistics buffer: one triangle travels over
+//              xGMI; nt = ldo / 64)
 enum { SY_STORE = 0, SY_ETA2 = 1, SY_PACK = 2 };
 
 template <typename T, int MODE, int KG = 1>
@@ -171,7 +172,7 @@ __device__ __forceinline__ void syrk_tn_body(const T* __restrict__ A, int64_t ld
   gemm_tile<T, RC, RC, KG>(A + a0, lda, A + b0, lda, kBegin, Kdim, w, acc, smem);
   if (KG > 1 && threadIdx.x >= NTHREADS) return;
   if (MODE == SY_PACK) {
-    T* tp = out + (ta * (ta + 1) / 2 + tb) * (TILE * TILE);
+    T* tp = out + pack_index(ta, tb, ldo / TILE) * (TILE * TILE);  // (ldo = the statistic's order: nt = ldo / 64)
     acc_foreach<T>(acc, [&](int r, int c, T val) { tp[r * TILE + c] = val; });
   } else if (MODE == SY_STORE) {
     acc_foreach<T>(acc, [&](int r, int c, T val) {
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void k_eta2_from_packed(const T* __restrict__ 
   const int sub = blockIdx.x & 3;
   int64_t ta, tb;
   tri_index(q, ta, tb);
-  const T* tp = Sp + q * (TILE * TILE);
+  const T* tp = Sp + pack_index(ta, tb, mp / TILE) * (TILE * TILE);
   for (int e = sub * 1024 + threadIdx.x; e < (sub + 1) * 1024; e += 256) {
     const int r = e >> 6, c = e & 63;
     if (ta == tb && c > r) continue;

@@ -35,6 +35,23 @@ import numpy as np
 from . import capi
 
 
+_EXT_STREAMS = {}
+
+
+def on_stream(stream):
+    """torch context for the raw hipStream_t an all-reduce callback is handed (None / 0: the default stream torch is on anyway)"""
+    import contextlib
+
+    if not stream:
+        return contextlib.nullcontext()
+    import torch
+
+    key = int(stream)
+    if key not in _EXT_STREAMS:
+        _EXT_STREAMS[key] = torch.cuda.ExternalStream(key)
+    return torch.cuda.stream(_EXT_STREAMS[key])
+
+
 class Comm:
     """An `agp_comm` (include/agp_hip.h): sum all-reduce across the ranks of a run, enqueued on the model's HIP stream."""
 
@@ -103,7 +120,8 @@ class Comm:
 
         if group is not None and hasattr(group, "all_reduce_sum"):
             def fn(ptr, count, dtype, stream):
-                group.all_reduce_sum(view(ptr, count, dtype))
+                with on_stream(stream):
+                    group.all_reduce_sum(view(ptr, count, dtype))
             return cls.from_callback(model, rank, world, fn)
         import torch.distributed as dist
 
@@ -111,13 +129,15 @@ class Comm:
         gloo = dist.get_backend(group) == "gloo"
 
         def fn(ptr, count, dtype, stream):
-            t = view(ptr, count, dtype)
-            if gloo:  # host-staged: gloo reduces host memory
-                hbuf = t.cpu()
-                dist.all_reduce(hbuf, op=dist.ReduceOp.SUM, group=group)
-                t.copy_(hbuf)
-            else:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            # the library names the stream the sum has to be ordered on: the ctx's, or -- AGP_SPLIT_OVERLAP -- the communicator's own
+            with on_stream(stream):
+                t = view(ptr, count, dtype)
+                if gloo:  # host-staged: gloo reduces host memory
+                    hbuf = t.cpu()
+                    dist.all_reduce(hbuf, op=dist.ReduceOp.SUM, group=group)
+                    t.copy_(hbuf)
+                else:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         return cls.from_callback(model, r, w, fn)
 
     @property

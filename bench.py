@@ -265,11 +265,18 @@ def main():
         fake_us = float(os.environ.get("AGP_BENCH_FAKE_ALLREDUCE_US", "0"))
         if fake_us > 0:
             # stand-in for the xGMI all-reduce on a one-GPU box: a kernel that just occupies the stream for about that long
-            cyc = int(fake_us * 1700)  # torch.cuda._sleep: ~0.59 ns per count on MI355X (the JSON line carries the measured us per call)
+            # (torch.cuda._sleep: ~0.59 ns per count on MI355X; the JSON line carries the measured us per call.)  A call on PART of
+            # the statistics (AGP_SPLIT_OVERLAP's column groups) is charged its share of the bytes, but never less than a latency
+            # floor (AGP_BENCH_FAKE_ALLREDUCE_LAT_US, default 15: a small xGMI all-reduce is latency-bound)
+            lat_us = float(os.environ.get("AGP_BENCH_FAKE_ALLREDUCE_LAT_US", "15"))
+            mp_ = (m + 63) // 64 * 64
+            full_count = mp_ + (mp_ // 64) * (mp_ // 64 + 1) // 2 * 4096
             exts = {}
 
             def _fake(ptr, count, dtype, stream):
                 try:
+                    us = fake_us if count >= full_count else max(lat_us, fake_us * count / full_count)
+                    cyc = int(us * 1700)
                     if stream is None:  # the ctx runs on the default stream, which is torch's current one here
                         torch.cuda._sleep(cyc)
                     else:
@@ -355,6 +362,46 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- A/B of the batch-parallel step's collective (outside the timed region above): the same loop once more with
+    # AGP_SPLIT_OVERLAP flipped -- the statistics travelling in block-column groups on the communicator's own stream, the next
+    # task-graph launch starting on the first group.  The library reads the variable at every step.
+    overlap_ab = None
+    if comm is not None and mode == "batch" and os.environ.get("AGP_BENCH_NO_OVERLAP_AB") != "1":
+        keep = os.environ.get("AGP_SPLIT_OVERLAP")
+        flipped = "0" if keep == "1" else "1"
+        os.environ["AGP_SPLIT_OVERLAP"] = flipped
+        try:
+            for i in range(warm):
+                step(i)
+            model._chk(L.agp_svgp_check_status(h))
+            comm.stats()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for i in range(warm, total):
+                step(i)
+            model._chk(L.agp_svgp_check_status(h))
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            dt_ab = time.perf_counter() - ta
+            nc_ab, nb_ab, ms_ab = comm.stats()
+            if dist is not None:
+                t = torch.tensor([dt_ab], dtype=torch.float64, device="cpu" if share else dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_ab = float(t.item())
+            overlap_ab = {"AGP_SPLIT_OVERLAP": int(flipped), "ms_per_step": round(dt_ab * 1e3 / max(steps, 1), 4),
+                          "collective_us_per_call": round(ms_ab * 1e3 / max(nc_ab, 1), 2),
+                          "bytes_allreduced_per_step_per_rank": int(nb_ab / max(steps, 1)),
+                          "note": "same loop, same index stream, variable flipped; the headline line above ran with AGP_SPLIT_OVERLAP="
+                                  + (keep or "0") + "; with the flag on, one call is the train of column groups on the communicator's stream"}
+        finally:
+            if keep is None:
+                os.environ.pop("AGP_SPLIT_OVERLAP", None)
+            else:
+                os.environ["AGP_SPLIT_OVERLAP"] = keep
 
     # ---- roofline of the dominant kernel: the augmented Cholesky factorisation of -2*eta2 with the [kappa; eta1'] extension
     # rows: ONE launch of the tile task graph k_chol_dag per factorisation up to m = 2048 (several latents of one GPU share
@@ -503,6 +550,8 @@ def main():
         }
         if tied:
             out["collective"]["tied_Z_hyper_step_every"] = cfg["hyper_every"]
+        if overlap_ab is not None:
+            out["collective"]["split_overlap_ab"] = overlap_ab
 
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE as
     # MI355X_MICROARCH.md prescribes for gfx950); rocprofv3 cannot wrap bench.py from inside, so this is not live

@@ -221,8 +221,9 @@ agp_status agp_svgp_step_counters(agp_svgp* h, int64_t* n_steps_host, int64_t* n
  *                 the caller all-reduces gsum across latent-parallel ranks; lsm_alpha sets alpha = 1 + gsum.
  *                 (called twice, as the reference loops twice)
  *   step_stats  : theta, grad_E_mu, grad_E_Sigma and the batch statistics
- *                 stats = [ kappa'(rho g1) (mp) | rho kappa' diag(g2) kappa, lower 64x64 tiles packed row by row of tiles:
- *                 tile (i, j <= i) at offset mp + (i(i+1)/2 + j) * 4096, row-major inside the tile ] per latent
+ *                 stats = [ kappa'(rho g1) (mp) | rho kappa' diag(g2) kappa, lower 64x64 tiles packed block column by block
+ *                 column: tile (i, j <= i) of the nt x nt grid (nt = mp / 64) at offset mp + (j nt - j(j-1)/2 + i - j) * 4096,
+ *                 row-major inside the tile ] per latent
  *                 -- the buffer a batch-parallel run all-reduces (analyticVI.jl:168,179)
  *   step_global : natural-gradient step + (mu, Sigma) refresh      analyticVI.jl:229-246, inference.jl:25-28 */
 agp_status agp_svgp_step_local(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx,

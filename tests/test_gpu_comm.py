@@ -33,11 +33,17 @@ class ThreadGroup:
         self.tl = threading.local()
 
     def all_reduce_sum(self, t):
+        import torch
+
+        # (the ranks may sit on different streams -- AGP_SPLIT_OVERLAP hands the communicator's own -- so the host waits for its
+        # rank's input, and for its reads of the others', before the barriers let anybody go on)
+        torch.cuda.current_stream().synchronize()
         self.slots[self.tl.rank] = t
         self.bar.wait()
         s = self.slots[0].clone()
         for o in self.slots[1:]:
             s += o
+        torch.cuda.current_stream().synchronize()
         self.bar.wait()
         t.copy_(s)
         self.bar.wait()
@@ -164,8 +170,11 @@ def test_batch_parallel_two_ranks_match_single_handle(built, likname):
     assert res[0][1] == res[1][1]  # identical on every rank
 
 
-def test_batch_parallel_step_rides_on_the_task_graph_launches(built):
-    """Round 3: with the next minibatch announced (agp_svgp_prefetch) and nobody looking in between, a batch-parallel step over two
+@pytest.mark.parametrize("overlap", [False, True])
+def test_batch_parallel_step_rides_on_the_task_graph_launches(built, overlap, monkeypatch):
+    """(overlap: AGP_SPLIT_OVERLAP=1 -- the statistics travel in block-column groups on the communicator's own stream and the tile
+    workgroups of the next launch wait for their column's group; same assertions.)
+    Round 3: with the next minibatch announced (agp_svgp_prefetch) and nobody looking in between, a batch-parallel step over two
     ranks leaves its eta step PENDING on the reduced statistics; the next step's task-graph launch takes it as its prologue (no
     k_eta2_from_packed) and does the row statistics as its epilogue.  Same trajectory as the single handle, ranks identical, and the
     step counters say the scheduling really was in use.  4 block columns, 128 points per rank (two kappa block rows)."""
@@ -173,6 +182,8 @@ def test_batch_parallel_step_rides_on_the_task_graph_launches(built):
     from agp_amd import capi
     from agp_amd import parallel as P
 
+    if overlap:
+        monkeypatch.setenv("AGP_SPLIT_OVERLAP", "1")
     rng = np.random.default_rng(9)
     N, D, m, B, iters = 3000, 4, 200, 256, 12
     X = rng.random((N, D))
@@ -219,7 +230,7 @@ def test_batch_parallel_merged_step_survives_aborted_launches(built):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k",
                         "test_batch_parallel_step_rides_on_the_task_graph_launches"], env=env, capture_output=True, text=True,
                        timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
 def test_latent_parallel_lsm_and_tied_hyper_two_ranks(built):
@@ -286,7 +297,8 @@ def _proc_rank(rank, world, shm_name, nbytes, bar, q, mode):
         shm = shared_memory.SharedMemory(name=shm_name)
         slots = np.ndarray((world, nbytes // 8), dtype=np.float64, buffer=shm.buf)
         rng = np.random.default_rng(6)
-        big = mode.endswith("-big")
+        big = "-big" in mode
+        overlap = mode.endswith("-overlap")  # AGP_SPLIT_OVERLAP=1 (set by the parent) + the look-ahead: the step rides on the launches
         mode = mode.split("-")[0]
         K = 1 if mode == "batch" else 3
         X, y, Z = _data(rng, K=K, **(BIG if big else {}))
@@ -295,27 +307,39 @@ def _proc_rank(rank, world, shm_name, nbytes, bar, q, mode):
         lik = AGP.LogisticLikelihood() if K == 1 else AGP.LogisticSoftMaxLikelihood(3)
         sl = None if mode == "batch" else P.latent_slice(3, world, rank)
         m = AGP.SVGP(_kernel(AGP), lik, AGP.AnalyticSVI(B), Z, optimiser=False, latent_slice=sl)
+        seen = []
 
         def allreduce(ptr, count, dtype, stream):
             assert dtype == capi.F64 and count * 8 <= nbytes
-            t = torch.as_tensor(P._DevBuf(ptr, count, "<f8"), device="cuda")
-            slots[rank, :count] = t.cpu().numpy()  # orders after the work already enqueued on the stream
-            bar.wait()
-            s = slots[:, :count].sum(axis=0)
-            bar.wait()
-            t.copy_(torch.from_numpy(s))
+            seen.append((count, bool(stream)))
+            with P.on_stream(stream):  # the stream the library names: the ctx's, or the communicator's own (column groups)
+                t = torch.as_tensor(P._DevBuf(ptr, count, "<f8"), device="cuda")
+                slots[rank, :count] = t.cpu().numpy()  # orders after the work already enqueued on that stream
+                bar.wait()
+                s = slots[:, :count].sum(axis=0)
+                bar.wait()
+                t.copy_(torch.from_numpy(s))
 
         comm = P.Comm.from_callback(m, rank, world, allreduce)
         assert not comm.is_rccl
         eng = P.HipEngine(m, B // world if mode == "batch" else B).bind_data(X, y)
         if mode == "batch":
             eng.set_batch_shard(rank, world)
+        nxt = P.shard_batch(idx[0], world, rank) if mode == "batch" else None
         for it in range(iters):
             if mode == "batch":
-                eng.step_multi(P.shard_batch(idx[it], world, rank), len(X) / B, capi.SHARD_BATCH, comm)
+                eng.step_multi(nxt, len(X) / B, capi.SHARD_BATCH, comm)
+                if it + 1 < iters:
+                    nxt = P.shard_batch(idx[it + 1], world, rank)
+                    if overlap:
+                        nxt = eng.prefetch(nxt)
             else:
                 eng.step_multi(idx[it], len(X) / B, capi.SHARD_LATENT, comm)
         eng.check()
+        if overlap:  # the statistics really travelled as several ranges on a stream of the communicator's own
+            per_step = len(seen) // iters
+            assert per_step >= 2 and all(on_side for _, on_side in seen), (per_step, seen[:8])
+            assert eng.step_counters()[1] >= iters - 2
         q.put((rank, [m.get_state(k)[3] for k in range(m.n_latent)]))
     except BaseException as e:
         q.put((rank, repr(e)))
@@ -325,8 +349,8 @@ def _proc_rank(rank, world, shm_name, nbytes, bar, q, mode):
             pass
 
 
-@pytest.mark.parametrize("mode", ["batch", "latent", "batch-big"])
-def test_two_processes_share_one_gpu_without_torch_distributed(built, mode):
+@pytest.mark.parametrize("mode", ["batch", "latent", "batch-big", "batch-big-overlap", "batch-big-abort-overlap"])
+def test_two_processes_share_one_gpu_without_torch_distributed(built, mode, monkeypatch):
     """Two host processes, each with its own ctx / handle on GPU 0, drive a sharded run through the C ABI only; the
     all-reduce is a host callback over POSIX shared memory.  Doubles as the "second process on the same GPU" check: both
     processes factor with the one-launch task graph at the same time.  At the C2 size ("batch-big") the two 408-workgroup task
@@ -337,7 +361,11 @@ def test_two_processes_share_one_gpu_without_torch_distributed(built, mode):
 
     import agp_amd as AGP
 
-    big = mode.endswith("-big")
+    big = "-big" in mode
+    if mode.endswith("-overlap"):  # the children inherit the environment (spawn)
+        monkeypatch.setenv("AGP_SPLIT_OVERLAP", "1")
+    if "-abort" in mode:  # ... and every task-graph launch is made to lose a dependency: fallback behind gated prologues
+        monkeypatch.setenv("AGP_DAG_TEST_ABORT", "1")
     world, nbytes = 2, 8 * ((1 << 20) if big else (1 << 16))
     ctx = mp.get_context("spawn")
     shm = shared_memory.SharedMemory(create=True, size=world * nbytes)
@@ -366,6 +394,7 @@ def test_two_processes_share_one_gpu_without_torch_distributed(built, mode):
     if mode == "batch":
         for r in range(world):
             assert _rel(got[r][0], ref.get_state(0)[3]) < 1e-9
+        assert np.array_equal(got[0][0], got[1][0])  # the replicas stay bitwise together
     else:
         from agp_amd import parallel as P
 

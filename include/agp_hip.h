@@ -437,6 +437,12 @@ agp_status agp_svgp_proba_y(agp_svgp* h, const void* xt, int64_t ldx, int64_t n_
  * agp_comm_init      : ncclCommInitRank on ctx's device; collectives are enqueued on ctx's stream (RCCL over xGMI).
  * agp_comm_init_callback : the host supplies the all-reduce instead (must sum `count` elements of `dtype` in place at the
  *                      DEVICE pointer `buf`, ordered after the work already enqueued on `hip_stream`; return 0 on success).
+ *                      `hip_stream` is the ctx's stream, or -- AGP_SPLIT_OVERLAP=1 -- a stream of the communicator's own.
+ * AGP_SPLIT_OVERLAP=1 (environment, default off, read at every step; batch-parallel single-latent steps that ride on the task-graph
+ *                      launches): the statistics are all-reduced as AGP_SPLIT_OVERLAP_GROUPS (default 4) contiguous ranges -- groups
+ *                      of block columns -- one after the other on the communicator's own stream, and the next step's factorisation
+ *                      starts on the first group while the others travel (its tile workgroups wait for their column's group).
+ *                      Same results bit for bit; every rank must use the same setting (the call sequence differs).
  * All ranks must issue the same sequence of *_multi calls. */
 typedef struct agp_comm agp_comm;
 enum { AGP_COMM_ID_BYTES = 128 };

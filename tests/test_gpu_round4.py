@@ -500,3 +500,21 @@ print('OK')
             assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
         a, b = np.load(pa), np.load(pb)
         assert _rel(a, b) < 1e-9
+
+
+def test_split_overlap_gates_really_wait_and_change_nothing(mods):
+    """AGP_SPLIT_OVERLAP=1 on one GPU with a one-rank callback communicator whose "all-reduce" is an ASYNCHRONOUS sleep kernel on the
+    stream it is handed (AGP_FORCE_SPLIT=1; tools/dbg_overlap.py): the host runs ahead, so the tile workgroups of the next task-graph
+    launch do wait at their arrival gates while the later column groups are still "travelling".  One rank: the sum is the input, so
+    the final state must be bit-identical with and without the flag, the statistics must have gone out as 4 ranges per step, and
+    every step after the first must have ridden on its successor's launch."""
+    outs = []
+    for ov in ("0", "1"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg_overlap.py"), "80", "60"], cwd=ROOT, capture_output=True, text=True,
+                           env=dict(os.environ, AGP_FORCE_SPLIT="1", AGP_SPLIT_OVERLAP=ov), timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("overlap=")]
+        assert r.returncode == 0 and line, r.stdout[-1500:] + r.stderr[-1500:]
+        outs.append(dict(kv.split("=") for kv in line[-1].replace("prologue steps", "prologue_steps").replace("ms/step", "ms_step").split()))
+    assert outs[0]["calls/step"] == "1.0" and outs[1]["calls/step"] == "4.0"
+    assert int(outs[0]["prologue_steps"]) >= 58 and int(outs[1]["prologue_steps"]) >= 58
+    assert outs[0]["state"] == outs[1]["state"]

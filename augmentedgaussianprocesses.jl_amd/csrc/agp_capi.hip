@@ -921,6 +921,13 @@ static int64_t kg2_limit() {
   }();
   return v;
 }
+static int64_t syrk_kg2_limit() {  // (AGP_SYRK_KG2_LIMIT: the symmetric products alone, for A/B measurements)
+  static const int64_t v = []() {
+    const char* e = getenv("AGP_SYRK_KG2_LIMIT");
+    return e ? (int64_t)atoll(e) : kg2_limit();
+  }();
+  return v;
+}
 // S = A' diag(w) A (lower tiles mirrored), two k-groups per workgroup when the tile count underfills the chip
 template <typename T, int MODE>
 static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_t Kdim, const T* w, int lower_a, T* out,
@@ -954,7 +961,7 @@ static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_
     hipLaunchKernelGGL((k_syrk_tn<T, MODE, 4>), dim3((unsigned)grid), dim3(4 * NTHREADS), 0, c->stream, A, lda, Kdim, w,
                        lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0, nrider, fillp, fused_used, fstride,
                        fnb);
-  else if (tiles <= kg2_limit() && Kdim >= 4 * BK)
+  else if (tiles <= syrk_kg2_limit() && Kdim >= 4 * BK)
     hipLaunchKernelGGL((k_syrk_tn<T, MODE, 2>), dim3((unsigned)grid), dim3(2 * NTHREADS), 0, c->stream, A, lda, Kdim, w,
                        lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0, nrider, fillp, fused_used, fstride,
                        fnb);

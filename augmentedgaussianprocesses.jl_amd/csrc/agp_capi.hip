@@ -44,6 +44,10 @@ struct agp_ctx {
   // been seen by the host (any synchronising call) the task graph is not used again on this context
   void* kmm_scratch = nullptr;  // scaled copy + squared norms of the Y side of a kernel matrix whose Y is not a cached Z
   size_t kmm_bytes = 0;
+  void* bal_ws = nullptr;       // partial tiles / arrival counters of the balanced triangular product (k_xtx_bal)
+  size_t bal_bytes = 0;
+  int32_t* bal_cnt = nullptr;
+  int64_t bal_cnt_n = 0;
   unsigned* safe_bar = nullptr;
   int32_t* safe_retries = nullptr;
   int n_cu = 0;
@@ -555,6 +559,7 @@ struct ProHost {
   const int32_t* arrive = nullptr;             // ... arriving in block-column groups (AGP_SPLIT_OVERLAP)
   int32_t arrive_want = 0;
   unsigned char grp[32] = {};
+  T* Cout = nullptr;                           // ProArgs::Cout
 };
 // k-slices per block column of the prologue's product: a tile of block column c has to be there when the chain reaches the
 // column (about tau * c after the start, tau = 17.8 us f64 / 14 us f32 per block column), a 64-row chunk of the product costs a
@@ -700,6 +705,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       pa.kinv_mu0 = pro->kinv_mu0;
       pa.lr = pro->lr;
       pa.packed = pro->packed;
+      pa.Cout = pro->Cout;
       pa.tred = pro->tred;
       pa.arrive = pro->arrive;
       pa.arrive_want = pro->arrive_want;
@@ -975,9 +981,60 @@ static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_
 
 // out = X' X for lower-triangular X  (A^-1 from its inverse Cholesky factor): the symmetric product with the k range of every
 // tile starting at its first row, k-groups chosen like everywhere else (it ran with one k-group on 136 tiles: 60 us at m = 1024)
+// Round 4: from 8 block rows on, the balanced form (k_xtx_bal: units of at most ch k-blocks, partial tiles added by the last arriver
+// in unit order): 42 -> ~15 us at m = 1024.  AGP_XTX_BALANCED=0 keeps the one-workgroup-per-tile product; AGP_XTX_CH sets ch.
 template <typename T>
 static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* out, int64_t ldo) {
-  return syrk_tn<T, SY_STORE>(c, X, ld, n, n, (const T*)nullptr, 1, out, ldo, (T*)nullptr, (const T*)nullptr, (int64_t)0, T(0));
+  static const int bal_env = [] {
+    const char* e = getenv("AGP_XTX_BALANCED");
+    return e ? atoi(e) : 1;
+  }();
+  static const int ch_env = [] {
+    const char* e = getenv("AGP_XTX_CH");
+    return e ? std::max(1, atoi(e)) : 0;
+  }();
+  const int64_t nt = n / TILE;
+  if (!bal_env || nt < 8)
+    return syrk_tn<T, SY_STORE>(c, X, ld, n, n, (const T*)nullptr, 1, out, ldo, (T*)nullptr, (const T*)nullptr, (int64_t)0, T(0));
+  const int ch = ch_env ? ch_env : (int)std::max<int64_t>(2, nt / 8);
+  const int64_t nunits = xtx_bal_units(nt, ch), ntri = nt * (nt + 1) / 2;
+  const size_t need = sizeof(T) * (size_t)nunits * TILE * TILE;
+  if (c->bal_bytes < need) {
+    if (c->bal_ws) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      (void)hipFree(c->bal_ws);
+    }
+    c->bal_ws = nullptr;
+    c->bal_bytes = 0;
+    HIPCHK(c, hipMalloc(&c->bal_ws, need));
+    c->bal_bytes = need;
+  }
+  if (c->bal_cnt_n < ntri) {
+    if (c->bal_cnt) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      (void)hipFree(c->bal_cnt);
+    }
+    c->bal_cnt = nullptr;
+    c->bal_cnt_n = 0;
+    HIPCHK(c, hipMalloc((void**)&c->bal_cnt, sizeof(int32_t) * (size_t)ntri));
+    HIPCHK(c, hipMemsetAsync(c->bal_cnt, 0, sizeof(int32_t) * (size_t)ntri, c->stream));
+    c->bal_cnt_n = ntri;
+  }
+  T* fillp = nullptr;
+  int64_t fused_used = 0, fstride = 0, nfill = 0;
+  int fnb = 0;
+  if (c->h_dirty[0].on && c->htype == (int)sizeof(T)) {  // hand-over refill riders, as in syrk_tn()
+    fillp = (T*)c->hset[0];
+    fused_used = c->h_dirty[0].used;
+    fstride = c->h_dirty[0].stride;
+    fnb = c->h_dirty[0].nb;
+    nfill = 96;
+    c->h_dirty[0].on = false;
+  }
+  hipLaunchKernelGGL((k_xtx_bal<T>), dim3((unsigned)(nunits + nfill)), dim3(NTHREADS), 0, c->stream, X, ld, n, out, ldo,
+                     (T*)c->bal_ws, c->bal_cnt, ch, nunits, fillp, fused_used, fstride, fnb);
+  LAUNCHCHK(c);
+  return AGP_OK;
 }
 
 template <typename T, int EPI>
@@ -1059,6 +1116,8 @@ static int launch_kernelmatrix(agp_ctx* c, hipStream_t stream, const T* X, int64
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);                                       \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kernelmatrix_mma<T, KIND, 2>),                             \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);                                       \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kernelmatrix_mma<T, KIND, 3>),                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);                                       \
         asked = sh;                                                                                                           \
       }                                                                                                                       \
     }                                                                                                                         \
@@ -1067,6 +1126,9 @@ static int launch_kernelmatrix(agp_ctx* c, hipStream_t stream, const T* X, int64
                          Dp, scales, variance, out, ldo, n_out, p_out, sym, diag_add, alpha, part, ldp, ctiles);              \
     else if (out != nullptr && !sym && alpha == nullptr)                                                                      \
       hipLaunchKernelGGL((k_kernelmatrix_mma<T, KIND, 2>), grid, dim3(NTHREADS), sh, stream, X, ldx, idx, n, ysc, ysn, p, D, \
+                         Dp, scales, variance, out, ldo, n_out, p_out, sym, diag_add, alpha, part, ldp, ctiles);              \
+    else if (out != nullptr && sym && alpha == nullptr)                                                                       \
+      hipLaunchKernelGGL((k_kernelmatrix_mma<T, KIND, 3>), grid, dim3(NTHREADS), sh, stream, X, ldx, idx, n, ysc, ysn, p, D, \
                          Dp, scales, variance, out, ldo, n_out, p_out, sym, diag_add, alpha, part, ldp, ctiles);              \
     else                                                                                                                      \
       hipLaunchKernelGGL((k_kernelmatrix_mma<T, KIND>), grid, dim3(NTHREADS), sh, stream, X, ldx, idx, n, ysc, ysn, p, D,    \
@@ -1264,6 +1326,11 @@ struct Svgp : SvgpBase {
     T* DgK = nullptr;     // diagonal 64x64 factors of chol(K)      (mp x 64)
     T* DgA = nullptr;     // diagonal 64x64 factors of chol(-2 eta2)
     T* Apred = nullptr;   // K^-1 - K^-1 Sigma K^-1
+    // hyper-parameter iteration: C = kappa' diag(w) kappa + K^-1 / 4 of the natural-gradient step that the factorisation launch took
+    // as its prologue (ProArgs::Cout); valid until the next local step / natural-gradient step (hypergrad, k_hyper_gK_fused)
+    T* Cmat = nullptr;
+    bool C_valid = false;
+    const T* C_kap = nullptr;  // the kappa buffer it was formed from
     T* apred = nullptr;   // K^-1 mu
     bool K_stale = true, post_valid = false, pred_valid = false, predvar_valid = false, kappa_valid = false;
     bool keep_last = false;  // this step reuses kappa / K~ of the previous full-batch step
@@ -1306,6 +1373,7 @@ struct Svgp : SvgpBase {
   int hy_krule = AGP_OPT_ADAM, hy_zrule = AGP_OPT_ADAM;  // agp_svgp_hyper_rule: ADAM / Descent / Momentum (opt_rule_delta)
   double hy_krho = 0.0, hy_zrho = 0.0;
   T *hyKap = nullptr, *hyKnm = nullptr;  // kappa (Knm) under the fresh inv(K) (kernel) for the hyper-gradient, AGP_FLAG_STALE_K
+  T* hy_upart = nullptr;                 // per tile row: partial column sums of kappa' g_mu (k_hyper_hk_tile -> k_hyper_gK_fused)
   T *hyH1 = nullptr, *hyH2 = nullptr, *hyH3 = nullptr, *hy_gmu = nullptr, *hy_gs = nullptr, *hy_muf = nullptr,
     *hy_pZ = nullptr, *hy_dZ = nullptr;
   double *hy_pvar = nullptr, *hy_pscale = nullptr, *hy_g = nullptr;
@@ -1360,6 +1428,7 @@ struct Svgp : SvgpBase {
   int64_t stats_stride() const { return mp + (mp / TILE) * (mp / TILE + 1) / 2 * TILE * TILE; }
   T* Tw = nullptr;                                 // mp x mp scratch
   T* Tw2 = nullptr;                                // mp x mp scratch (predict)
+  int tw2_kis_of = -1;                             // latent whose K^-1 Sigma the scratch holds, -1: something else
   T* tmpv = nullptr;                               // mp
   T* lr_dev = nullptr;
   int32_t* info_dev = nullptr;   // failure latch of the factorisations of -2*eta2 (asynchronous steps)
@@ -1483,6 +1552,7 @@ struct Svgp : SvgpBase {
     AGPCHK(run_deferred_safe());
     if (!pend.on && !pendp.on) return AGP_OK;
     Latent& g = lat[0];
+    g.C_valid = false;
     if (pend.on) {
       pend.on = false;
       AGPCHK((syrk_tn<T, SY_ETA2>(ctx, pend.kap, mp, mp, pend.Bq, pend.w, 0, g.La, mp, g.eta2, pend.Kinv, mp, pend.lr, pend.r,
@@ -1506,6 +1576,7 @@ struct Svgp : SvgpBase {
     if (pro_allowed() && chol_use_dag(ctx, mp / TILE, rup64(B_last) / TILE + 1, 1) && mp / TILE <= 32 && dag_fused_on() &&
         !dag_trace_on()) {
       Latent& g = lat[0];
+      g.C_valid = false;
       pend.on = true;
       pend.Bq = rup64(B_last);
       pend.lr = (T)cur_lr();
@@ -1685,7 +1756,7 @@ struct Svgp : SvgpBase {
                evarf, stats, Tw, Tw2, tmpv, lr_dev, Kstar, ppm, ppv, pmu, pvar};
     for (T* p : ps)
       if (p) dfree(p);
-    T* hps[] = {hyH1, hyH2, hyH3, hy_gmu, hy_gs, hy_muf, hy_pZ, hy_dZ, hyKap, hyKnm};
+    T* hps[] = {hyH1, hyH2, hyH3, hy_gmu, hy_gs, hy_muf, hy_pZ, hy_dZ, hyKap, hyKnm, hy_upart};
     for (T* p : hps)
       if (p) dfree(p);
     double* hds[] = {hy_pvar, hy_pscale, hy_g, hy_tied};
@@ -1693,7 +1764,7 @@ struct Svgp : SvgpBase {
       if (p) dfree(p);
     for (auto& g : lat) {
       free_online(g);
-      T* sp[] = {g.sKinv, g.sXk, g.skinv_mu0};
+      T* sp[] = {g.sKinv, g.sXk, g.skinv_mu0, g.Cmat};
       for (T* q : sp)
         if (q) dfree(q);
       if (g.kadam) dfree(g.kadam);
@@ -2095,6 +2166,7 @@ struct Svgp : SvgpBase {
     AGPCHK(check_batch(B));
     if (!x || !y || ldx < D) return AGP_ERR_INVALID;
     lsm_finished = false;
+    for (auto& g : lat) g.C_valid = false;  // the local variables (theta, w) and kappa it belongs to are about to change
     dag_tick(ctx);
     refresh_lazy = !fresh;  // a refresh issued from inside the training loop (the hyper step moved the kernel) does not synchronise
     const agp_status rks = refresh_K();
@@ -2508,7 +2580,20 @@ struct Svgp : SvgpBase {
     AGPCHK(hyper_alloc());
     const int64_t B = B_last, Bq = rup64(B);
     const T rho = (T)rho_last;
-    AGPCHK(ensure_pred(g, true));  // Sigma, mu, K^-1 mu, Apred = K^-1 - K^-1 Sigma K^-1
+    // round 4: H = G_kappa K^-1 comes from ONE product, kappa (Sigma K^-1), with the K^-1 Sigma that is formed on the way to Apred
+    // (k_hyper_hk) -- not kappa Sigma followed by (.) K^-1.  The heteroscedastic model needs kappa Sigma itself (var_f under the
+    // current posterior) and keeps the two products; AGP_HYPER_TWO_PRODUCTS=1 forces them (A/B).
+    static const bool two_products_env = [] {
+      const char* e = getenv("AGP_HYPER_TWO_PRODUCTS");
+      return e && atoi(e) != 0;
+    }();
+    const bool one_product = lp.kind != AGP_LIK_HETEROSCEDASTIC && !two_products_env;
+    // ... and G_K from ONE more, C (Sigma K^-1), when the factorisation launch inside materialize() took the pending natural-gradient
+    // step as its prologue and left C = kappa' diag(w) kappa + K^-1 / 4 behind (aug_factor, k_hyper_gK_fused): no kappa' H, no Apred
+    AGPCHK(refresh_K());
+    AGPCHK(materialize(g));
+    const bool gk_fused = one_product && g.C_valid && g.C_kap == g.kappa && !g.stale_on && !(g.on && !g.on_first);
+    AGPCHK(ensure_pred(g, !gk_fused));  // Sigma, mu, K^-1 mu (, Apred = K^-1 - K^-1 Sigma K^-1)
     // AGP_FLAG_STALE_K: the step's kappa mixes the new Knm with the frozen inv(K); the differentiated ELBO recomputes the
     // kernel matrices (ELBO.jl:15-21), so the gradient takes kappa = Knm K^-1 with the FRESH inverse
     if (g.stale_on && lp.kind == AGP_LIK_HETEROSCEDASTIC) {
@@ -2539,9 +2624,11 @@ struct Svgp : SvgpBase {
     const T* kap = kappa_for_grad(g);
     if (!kap) return AGP_ERR_NOMEM;
     // mean_f with the current posterior, then g_mu / g_sigma from the step's local variables
-    hipLaunchKernelGGL((k_gemv_rows<T>), grid1(B * 64), dim3(256), 0, st(), kap, mp, B, mp, (const T*)g.mu, hy_muf);
-    AGPCHK((gemm_nt<T, EPI_STORE>(ctx, kap, mp, g.Sigma, mp, Bq, mp, mp, 0, hyH1, mp, nullptr, 0, nullptr, nullptr,
-                                  nullptr, 0)));
+    if (!one_product || mo)
+      hipLaunchKernelGGL((k_gemv_rows<T>), grid1(B * 64), dim3(256), 0, st(), kap, mp, B, mp, (const T*)g.mu, hy_muf);
+    if (!one_product)
+      AGPCHK((gemm_nt<T, EPI_STORE>(ctx, kap, mp, g.Sigma, mp, Bq, mp, mp, 0, hyH1, mp, nullptr, 0, nullptr, nullptr,
+                                    nullptr, 0)));
     if (mo) {
       // mixed means under the current posterior need every latent's mean_f on this batch
       if (mo_sharded && fall_state != 2) {
@@ -2575,29 +2662,61 @@ struct Svgp : SvgpBase {
         hipLaunchKernelGGL((k_hyper_varf<T>), grid1(B * 64), dim3(256), 0, st(), B, mp, mp, (const T*)hyH1,
                            kap, (const T*)(Kt + l * Bp), pw0);
       }
-      hipLaunchKernelGGL((k_hyper_gvec<T>), grid1(B), dim3(256), 0, st(), B, rho, gmode, (const T*)(rbuf + l * Bp),
-                         (const T*)(theta + l * Bp), (const T*)hy_muf, (const T*)y_last, idx_last, (const T*)pw0,
-                         (const T*)gamma, (const T*)lam_dev, hy_gmu, hy_gs);
+      if (one_product)
+        hipLaunchKernelGGL((k_hyper_muf_gvec<T>), grid1(B * 64), dim3(256), 0, st(), B, mp, mp, rho, gmode, kap,
+                           (const T*)g.mu, (const T*)(rbuf + l * Bp), (const T*)(theta + l * Bp), (const T*)y_last, idx_last,
+                           hy_muf, hy_gmu, hy_gs);
+      else
+        hipLaunchKernelGGL((k_hyper_gvec<T>), grid1(B), dim3(256), 0, st(), B, rho, gmode, (const T*)(rbuf + l * Bp),
+                           (const T*)(theta + l * Bp), (const T*)hy_muf, (const T*)y_last, idx_last, (const T*)pw0,
+                           (const T*)gamma, (const T*)lam_dev, hy_gmu, hy_gs);
       LAUNCHCHK(ctx);
     }
     const T* knm = knm_for_grad(g);  // (the scratch is per handle: recomputed after the loop over the other latents)
     if (!knm) return AGP_ERR_NOMEM;
-    hipLaunchKernelGGL((k_hyper_gkappa<T>), grid2(Bq, mp), blk2, 0, st(), B, Bq, mp, mp, rho, (const T*)hy_gmu,
-                       (const T*)hy_gs, (const T*)g.mu, knm, hyH1);
-    LAUNCHCHK(ctx);
-    AGPCHK((gemm_nt<T, EPI_STORE>(ctx, hyH1, mp, g.Kinv, mp, Bq, mp, mp, 0, hyH2, mp, nullptr, 0, nullptr, nullptr,
-                                  nullptr, 0)));
-    hipLaunchKernelGGL((k_hyper_gknm<T>), grid2(Bq, mp), blk2, 0, st(), B, Bq, mp, mp, rho, (const T*)hy_gs,
-                       (const T*)hyH2, kap, hyH3);
-    {
+    if (one_product) {
+      if (tw2_kis_of != l) {  // Apred was still valid (a prediction since the last step): K^-1 Sigma is not in the scratch
+        AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.Kinv, mp, g.Sigma, mp, mp, mp, mp, 0, Tw2, mp, nullptr, 0, nullptr, nullptr,
+                                      nullptr, 0)));
+        tw2_kis_of = l;
+      }
+      AGPCHK((gemm_nt<T, EPI_STORE>(ctx, kap, mp, Tw2, mp, Bq, mp, mp, 0, hyH1, mp, nullptr, 0, nullptr, nullptr, nullptr,
+                                    0)));  // kappa (K^-1 Sigma)' = kappa Sigma K^-1
+      if (gk_fused) {
+        if (!hy_upart) AGPCHK(dmalloc(ctx, &hy_upart, (Bp / TILE) * mp));
+        hipLaunchKernelGGL((k_hyper_hk_tile<T>), dim3((unsigned)(mp / TILE), (unsigned)(Bq / TILE)), dim3(256), 0, st(), B, mp, rho,
+                           (const T*)hy_gmu, (const T*)hy_gs, (const T*)g.apred, (const T*)hyH1, kap, (T*)nullptr, hyH3, hy_upart,
+                           mp);
+      } else {
+        hipLaunchKernelGGL((k_hyper_hk<T>), grid2(Bq, mp), blk2, 0, st(), B, Bq, mp, mp, rho, (const T*)hy_gmu,
+                           (const T*)hy_gs, (const T*)g.apred, (const T*)hyH1, kap, hyH2, hyH3);
+      }
+      LAUNCHCHK(ctx);
+    } else {
+      hipLaunchKernelGGL((k_hyper_gkappa<T>), grid2(Bq, mp), blk2, 0, st(), B, Bq, mp, mp, rho, (const T*)hy_gmu,
+                         (const T*)hy_gs, (const T*)g.mu, knm, hyH1);
+      LAUNCHCHK(ctx);
+      AGPCHK((gemm_nt<T, EPI_STORE>(ctx, hyH1, mp, g.Kinv, mp, Bq, mp, mp, 0, hyH2, mp, nullptr, 0, nullptr, nullptr,
+                                    nullptr, 0)));
+      hipLaunchKernelGGL((k_hyper_gknm<T>), grid2(Bq, mp), blk2, 0, st(), B, Bq, mp, mp, rho, (const T*)hy_gs,
+                         (const T*)hyH2, kap, hyH3);
+    }
+    if (gk_fused) {
+      AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.Cmat, mp, Tw2, mp, mp, mp, mp, 0, Tw, mp, nullptr, 0, nullptr, nullptr, nullptr,
+                                    0)));  // C (K^-1 Sigma)' = C Sigma K^-1
+      hipLaunchKernelGGL((k_hyper_gK_fused<T>), grid2(mp, mp), blk2, 0, st(), m, mp, (const T*)Tw, (const T*)g.Cmat,
+                         (const T*)g.Kinv, (const T*)g.apred, (const T*)g.kinv_mu0, (const T*)hy_upart, (int)(Bq / TILE), mp, rho,
+                         Tw2);
+    } else {
       dim3 gt((unsigned)(mp / TILE), (unsigned)(mp / TILE));
       if ((mp / TILE) * (mp / TILE) <= 320)
         hipLaunchKernelGGL((k_gemm_tn<T, 2>), gt, dim3(2 * NTHREADS), 0, st(), kap, mp, (const T*)hyH2, mp, Bq, Tw, mp);
       else
         hipLaunchKernelGGL((k_gemm_tn<T, 1>), gt, dim3(NTHREADS), 0, st(), kap, mp, (const T*)hyH2, mp, Bq, Tw, mp);
+      hipLaunchKernelGGL((k_hyper_gK<T>), grid2(mp, mp), blk2, 0, st(), m, mp, (const T*)Tw, (const T*)g.Apred,
+                         (const T*)g.apred, Tw2, (T)(1.0 / (double)bs_world), (const T*)g.kinv_mu0);
     }
-    hipLaunchKernelGGL((k_hyper_gK<T>), grid2(mp, mp), blk2, 0, st(), m, mp, (const T*)Tw, (const T*)g.Apred,
-                       (const T*)g.apred, Tw2, (T)(1.0 / (double)bs_world), (const T*)g.kinv_mu0);
+    tw2_kis_of = -1;
     // backward through kernelmatrix(k, x, Z)  (gradient w.r.t. the second argument); its reduction initialises the gradient and
     // adds the kdiag term of the variance (rho sum_i g_sigma,i), which used to be a memset in front and a kernel behind
     {
@@ -3252,6 +3371,14 @@ struct Svgp : SvgpBase {
     return AGP_OK;
   }
 
+  // AGP_HYPER_GK_FUSED=0: the hyper-gradient forms G_K from kappa' H and Apred as before round 4 (A/B, tests)
+  static bool gk_fused_on() {
+    static const bool on = [] {
+      const char* e = getenv("AGP_HYPER_GK_FUSED");
+      return !(e && e[0] == '0');
+    }();
+    return on;
+  }
   // Augmented Cholesky of -2*eta2 with the extension rows [kappa (Bq rows, already in Wbuf) ; eta1'] :
   //   Wbuf <- [kappa L^-T ; (L^-1 eta1)']   i.e. W and v of mean_f = W v, var_f = rowsum(W^2) + K~.
   // with_x additionally forms Xa = L^-1 (needed only for Sigma / mu export, ELBO and prediction).
@@ -3260,6 +3387,7 @@ struct Svgp : SvgpBase {
     // launch as its prologue -- the hyper-parameter iteration's "eta step, then factor the new -2 eta2 with its inverse" in ONE launch
     AGPCHK(run_deferred_safe());
     if (pendp.on) AGPCHK(flush());
+    g.C_valid = false;
     ProHost<T> ph{};
     bool use_pro = false;
     if (pend.on) {
@@ -3279,6 +3407,12 @@ struct Svgp : SvgpBase {
       ph.eta1 = g.eta1;
       ph.kinv_mu0 = pend.kinv_mu0;
       ph.lr = pend.lr;
+      // the hyper-parameter iteration's launch (the inverse rides along): leave C = S + K^-1 / 4 for the gradient's G_K (hypergrad)
+      if (with_x && (hy_k || hy_z) && gk_fused_on() && !g.stale_on && !g.on && bs_world == 1 && !mo &&
+          lp.kind != AGP_LIK_HETEROSCEDASTIC) {
+        if (!g.Cmat) AGPCHK(dmalloc(ctx, &g.Cmat, mp * mp));
+        ph.Cout = g.Cmat;
+      }
     } else if (g.la_state != 0) {  // La holds a factor: rebuild -2*eta2
       hipLaunchKernelGGL((k_copy2d<T>), grid2(mp, mp), blk2, 0, st(), (const T*)g.eta2, mp, mp, mp, g.La, mp, mp, mp,
                          T(1), T(-2));
@@ -3299,6 +3433,10 @@ struct Svgp : SvgpBase {
     if (use_pro) {  // taken by the launch (a refused launch leaves it pending for flush())
       pend.on = false;
       n_prologue += 1;
+      if (ph.Cout) {
+        g.C_valid = true;
+        g.C_kap = ph.kap;
+      }
     }
     AGPCHK(timing_end(chol_use_dag(ctx, mp / TILE, Bq / TILE + 1) ? 1 : chol_launch_count(mp / TILE, Bq / TILE + 1)));
     g.la_state = 1;
@@ -3312,7 +3450,6 @@ struct Svgp : SvgpBase {
     g.post_valid = false;
     g.pred_valid = g.predvar_valid = false;
     AGPCHK(aug_factor(g, 0, 1));
-    HIPCHK(ctx, hipMemcpyAsync(g.v, g.Wbuf, sizeof(T) * mp, hipMemcpyDeviceToDevice, st()));
     return AGP_OK;
   }
 
@@ -3329,6 +3466,7 @@ struct Svgp : SvgpBase {
       }
       g.la_state = 0;  // La now holds the new -2*eta2 (unfactored); it is factored inside the next local phase
       g.xa_valid = false;
+      g.C_valid = false;
       g.post_valid = false;
       g.pred_valid = g.predvar_valid = false;
     }
@@ -3418,12 +3556,11 @@ struct Svgp : SvgpBase {
   // Sigma = Xa' Xa ; mu = Xa' v   with Xa = chol(-2 eta2)^-1, v = Xa eta1     (inference.jl:25-28)
   agp_status materialize(Latent& g) {
     if (g.post_valid) return AGP_OK;
-    if (!(g.la_state == 1 && g.xa_valid)) {
-      AGPCHK(aug_factor(g, 0, 1));
-      HIPCHK(ctx, hipMemcpyAsync(g.v, g.Wbuf, sizeof(T) * mp, hipMemcpyDeviceToDevice, st()));
-    }
+    if (!(g.la_state == 1 && g.xa_valid)) AGPCHK(aug_factor(g, 0, 1));
     AGPCHK(xtx_padded<T>(ctx, g.Xa, mp, mp, g.Sigma, mp));
-    hipLaunchKernelGGL((k_trmv_lower_t<T>), dim3((unsigned)(mp / 64)), dim3(1024), 0, st(), (const T*)g.Xa, mp, mp, (const T*)g.v, g.mu);
+    // mu = Sigma eta1 as the reference writes it (global_update!, analyticVI.jl:229-246).  Until round 4 this was Xa' (Xa eta1) from
+    // the factorisation's [eta1'] row: a copy and a 16-workgroup triangular mat-vec (4.8 + 15.6 us at m = 1024 against 7.0)
+    hipLaunchKernelGGL((k_symv<T>), grid1(mp * 64), dim3(256), 0, st(), (const T*)g.Sigma, mp, mp, (const T*)g.eta1, g.mu);
     LAUNCHCHK(ctx);
     g.post_valid = true;
     return AGP_OK;
@@ -3792,6 +3929,7 @@ struct Svgp : SvgpBase {
       // A = K \ (I - Sigma / K) = Kinv - Kinv Sigma Kinv :  T2 = Kinv Sigma (NT, both symmetric) ; A = Kinv - Kinv T2'
       AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.Kinv, mp, g.Sigma, mp, mp, mp, mp, 0, Tw2, mp, nullptr, 0, nullptr, nullptr,
                                     nullptr, 0)));
+      tw2_kis_of = (int)(&g - lat.data());  // the hyper-gradient reuses K^-1 Sigma (hypergrad, one_product)
       {  // (symmetric result: lower tiles only, mirrored -- half the flops of the full EPI_EMINUS product)
         const int64_t ntm = mp / TILE, tiles = ntm * (ntm + 1) / 2;
         if (tiles <= 160 && mp >= 8 * BK)  // fewer tiles than CUs: four k-groups per workgroup, like the symmetric product (syrk_tn)
@@ -4432,6 +4570,11 @@ agp_status agp_ctx_destroy(agp_ctx* ctx) {
     if (ctx->tri_scratch) (void)hipFree(ctx->tri_scratch);
   }
   if (ctx->kmm_scratch) (void)hipFree(ctx->kmm_scratch);
+  if (ctx->bal_ws || ctx->bal_cnt) {
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->bal_ws) (void)hipFree(ctx->bal_ws);
+    if (ctx->bal_cnt) (void)hipFree(ctx->bal_cnt);
+  }
   if (ctx->chain_stream) {
     (void)hipStreamSynchronize(ctx->chain_stream);
     (void)hipStreamDestroy(ctx->chain_stream);

@@ -184,8 +184,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_kernelmatrix_mma(const T* __res
                                                                int64_t ldp, int64_t ctiles) {
   if (variance < T(0)) variance = scales[D];  // device-resident kernel parameters (see k_kernelmatrix)
   T* __restrict__ out = SPEC == 1 ? nullptr : out_;
-  const int sym = SPEC != 0 ? 0 : sym_;
-  const T* __restrict__ alpha = SPEC == 2 ? nullptr : alpha_;
+  const int sym = SPEC == 3 ? 1 : SPEC != 0 ? 0 : sym_;  // SPEC 3 (round 4): K_ZZ of a refresh -- store only, symmetric, no row-dot
+  const T* __restrict__ alpha = (SPEC == 2 || SPEC == 3) ? nullptr : alpha_;
   extern __shared__ __attribute__((aligned(16))) unsigned char kmm_smem[];
   const int LDX = Dp + 2;  // 16 rows x {k, k+1} land on distinct banks (same stride rule as LDK in agp_device.h)
   T* Xs = reinterpret_cast<T*>(kmm_smem);  // [64][LDX]

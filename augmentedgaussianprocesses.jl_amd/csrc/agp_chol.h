@@ -1582,6 +1582,9 @@ struct ProArgs {
   // k-split of the PRO_NEAR tiles next to the diagonal of block column c (the chain's two feeders and the two tiles the NEXT
   // feeders wait for): their product has to be done while the chain is at most a column or two away, whatever the column
   unsigned char kf[32] = {};  // k-slices per block column (1: the tile workgroup forms the whole product itself)
+  // hyper-parameter iteration (round 4): C = S + K^-1 / 4 of the step, S = kappa' diag(w) kappa, both triangles (ld = ldm).  The
+  // hyper-gradient's G_K then needs ONE m^3 product, C (Sigma K^-1), where it took kappa' H and K^-1 Sigma K^-1 (hypergrad)
+  T* Cout = nullptr;
 };
 
 // The gate of AGP_SPLIT_OVERLAP.  It is NOT one of the task graph's abortable waits: what it waits for was enqueued before this
@@ -1878,6 +1881,15 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
         }
     }
     PRO_TS(tsb + 3);
+    if (pro.Cout) {
+      int e = 0;
+      acc8_foreach<T>(acc, [&](int r, int cc, T& val) {
+        const T cv = val + T(0.25) * kiv.a[e >> 2][e & 3];
+        ++e;
+        pro.Cout[(R * TILE + r) * pro.ldm + c0 + cc] = cv;
+        if (!diag) pro.Cout[(c0 + cc) * pro.ldm + R * TILE + r] = cv;
+      });
+    }
     {
       int e = 0;
       const T lr = pro.lr;

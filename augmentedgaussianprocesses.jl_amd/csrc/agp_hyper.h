@@ -79,6 +79,124 @@ __global__ void k_hyper_gknm(int64_t B, int64_t rows, int64_t cols, int64_t ld, 
   out[i * ld + j] = (i < B) ? H[i * ld + j] - rho * gs[i] * kappa[i * ld + j] : T(0);
 }
 
+// Round 4 (one GEMM and two element-wise launches fewer): with T1 = kappa (Sigma K^-1) -- ONE product, the intermediate
+// K^-1 Sigma of Apred is reused -- and a = K^-1 mu,
+//   H     = G_kappa K^-1 = rho ( g_mu a' + g_s (2 T1 - kappa) )        (Knm K^-1 IS kappa)
+//   G_Knm = H - rho g_s kappa
+// rows >= B are zero.
+template <typename T>
+__global__ void k_hyper_hk(int64_t B, int64_t rows, int64_t cols, int64_t ld, T rho, const T* __restrict__ gmu,
+                           const T* __restrict__ gs, const T* __restrict__ a, const T* __restrict__ T1,
+                           const T* __restrict__ kappa, T* __restrict__ H, T* __restrict__ Gknm) {
+  int64_t i = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
+  int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= rows || j >= cols) return;
+  T h = T(0), g = T(0);
+  if (i < B) {
+    const T k = kappa[i * ld + j], s = rho * gs[i];
+    h = rho * gmu[i] * a[j] + s * (T(2) * T1[i * ld + j] - k);
+    g = h - s * k;
+  }
+  H[i * ld + j] = h;
+  Gknm[i * ld + j] = g;
+}
+
+// The same on 64 x 64 tiles (grid = (cols / 64, rows / 64), 256 threads) with the column sums  u = kappa' g_mu  on the way:
+// upart[tile row][col] = sum over the tile's rows of g_mu_i kappa_ij (fixed order; the consumer, k_hyper_gK_fused, adds the tile
+// rows).  H is optional (the fused G_K does not need it).
+template <typename T>
+__global__ __launch_bounds__(256) void k_hyper_hk_tile(int64_t B, int64_t ld, T rho, const T* __restrict__ gmu,
+                                                       const T* __restrict__ gs, const T* __restrict__ a,
+                                                       const T* __restrict__ T1, const T* __restrict__ kappa,
+                                                       T* __restrict__ H, T* __restrict__ Gknm, T* __restrict__ upart,
+                                                       int64_t ldu) {
+  __shared__ T red[4][64];
+  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int64_t j = blockIdx.x * (int64_t)64 + col, i0 = blockIdx.y * (int64_t)64 + rg * 16;
+  const T aj = a[j];
+  T u = T(0);
+#pragma unroll 4
+  for (int q = 0; q < 16; ++q) {
+    const int64_t i = i0 + q;
+    T h = T(0), g = T(0);
+    if (i < B) {
+      const T k = kappa[i * ld + j], s = rho * gs[i], gm = gmu[i];
+      h = rho * gm * aj + s * (T(2) * T1[i * ld + j] - k);
+      g = h - s * k;
+      u += gm * k;
+    }
+    if (H) H[i * ld + j] = h;
+    Gknm[i * ld + j] = g;
+  }
+  red[rg][col] = u;
+  __syncthreads();
+  if (rg == 0) upart[blockIdx.y * ldu + j] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+}
+
+// G_K from ONE m^3 product (round 4).  With S = kappa' diag(w) kappa of the step (w = rho grad_E_Sigma = -rho g_s), C = S + K^-1/4
+// (left by the prologue of the factorisation launch, ProArgs::Cout), M = Sigma K^-1, a = K^-1 mu, at = a - K^-1 mu0, u = kappa' g_mu:
+//   kappa' H = rho u a' - 2 S M + S         K^-1 - K^-1 Sigma K^-1 = K^-1 - K^-1 M
+//   G_K = -1/2 sym2(kappa' H) - 1/2 (K^-1 - K^-1 M) + 1/2 at at'
+//       = TM + TM' - C - K^-1/4 - rho/2 (u a' + a u') + 1/2 at at' ,   TM = C M
+// instead of the two products kappa' H (2 B m^2) and K^-1 (Sigma K^-1).  Valid m x m block; zero in the padding.
+template <typename T>
+__global__ void k_hyper_gK_fused(int64_t m, int64_t mp, const T* __restrict__ TM, const T* __restrict__ C,
+                                 const T* __restrict__ Kinv, const T* __restrict__ a, const T* __restrict__ a2,
+                                 const T* __restrict__ upart, int nchunk, int64_t ldu, T rho, T* __restrict__ out) {
+  __shared__ T ui[16], uj[16], up[8][32];
+  const int64_t i = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
+  const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int t = threadIdx.y * 16 + threadIdx.x;
+  {  // u of the block's 16 rows and 16 columns: eight threads per entry fetch the tile-row partials side by side (a single thread
+     // walking all of them was 10 us of dependent loads), added in a fixed order
+    const int el = t & 31, cg = t >> 5;
+    const int64_t e = el < 16 ? blockIdx.y * (int64_t)16 + el : blockIdx.x * (int64_t)16 + (el - 16);
+    T s = T(0);
+    if (e < mp)
+      for (int c = cg; c < nchunk; c += 8) s += upart[c * ldu + e];
+    up[cg][el] = s;
+  }
+  __syncthreads();
+  if (t < 32) {
+    const T s = ((up[0][t] + up[1][t]) + (up[2][t] + up[3][t])) + ((up[4][t] + up[5][t]) + (up[6][t] + up[7][t]));
+    (t < 16 ? ui[t] : uj[t - 16]) = s;
+  }
+  __syncthreads();
+  if (i >= mp || j >= mp) return;
+  T v = T(0);
+  if (i < m && j < m) {
+    const T ai = a[i], aj = a[j];
+    const T ati = ai - (a2 ? a2[i] : T(0)), atj = aj - (a2 ? a2[j] : T(0));
+    v = TM[i * mp + j] + TM[j * mp + i] - C[i * mp + j] - T(0.25) * Kinv[i * mp + j] -
+        T(0.5) * rho * (ui[threadIdx.y] * aj + ai * uj[threadIdx.x]) + T(0.5) * ati * atj;
+  }
+  out[i * mp + j] = v;
+}
+
+// mean_f = kappa mu (one wave per row) and, in the same launch, k_hyper_gvec's modes 0 - 2 from it
+template <typename T>
+__global__ void k_hyper_muf_gvec(int64_t B, int64_t cols, int64_t ld, T rho, int mode, const T* __restrict__ kappa,
+                                 const T* __restrict__ mu, const T* __restrict__ r, const T* __restrict__ theta,
+                                 const T* __restrict__ y, const int64_t* __restrict__ idx, T* __restrict__ muf,
+                                 T* __restrict__ gmu, T* __restrict__ gs) {
+  const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= B) return;
+  T s = T(0);
+  for (int64_t k = lane; k < cols; k += 64) s += kappa[i * ld + k] * mu[k];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if (lane != 0) return;
+  muf[i] = s;
+  const T th = theta[i];
+  if (mode == 2) {
+    const T yi = y[idx ? idx[i] : i];
+    gmu[i] = yi - T(2) * th * (T(1) - yi * s) * yi;
+  } else {
+    gmu[i] = r[i] / rho - (mode == 1 ? th / T(2) : th * s);
+  }
+  gs[i] = -th / T(2);
+}
+
 // G_K = -1/2 (M1 + M1') - 1/2 Apred + 1/2 a a'   on the valid m x m block, zero in the padding
 // klw weighs the Gaussian-KL part (-1/2 Apred + 1/2 a a'): 1 normally, 1 / world on a batch-sharded handle, where that part is
 // replicated on every rank while the data part (M1) is a sum over the ranks' shards -- the all-reduced gradient then counts it once
@@ -166,6 +284,20 @@ __device__ __forceinline__ T kernel_dbase(int kind, T d2) {
   return T(-1.5) * exp(-s3 * r);
 }
 
+// phi and phi' of one squared distance with ONE exponential (the backward pass evaluated kernel_base and kernel_dbase separately:
+// two software exp per value in fp64).  Same expressions as kernel_base (agp_cavi.h) / kernel_dbase.
+template <typename T>
+__device__ __forceinline__ void kernel_base_dbase(int kind, T d2, T& base, T& dbase) {
+  if (kind == K_SQEXP) {
+    const T e = exp(T(-0.5) * (d2 > T(0) ? d2 : T(0)));
+    base = e;
+    dbase = T(-0.5) * e;
+    return;
+  }
+  base = kernel_base<T>(kind, d2);
+  dbase = kernel_dbase<T>(kind, d2);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Backward of k_kernelmatrix for one 64x64 tile: given G = dL/dk(x_i, z_j),
 //   dvar   += sum_ij G_ij phi_ij
@@ -187,8 +319,8 @@ __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restric
   if (variance < T(0)) variance = scales[D];  // device-resident kernel parameters (see k_kernelmatrix)
   __shared__ T xs[TILE][KM_DC + 1];
   __shared__ T ys[TILE][KM_DC + 1];
-  __shared__ T zred[4][TILE][KM_DC];  // per wave: column sums for the chunk
-  __shared__ double sred[4][KM_DC];
+  __shared__ T Cs[TILE][TILE + 1];  // c_ij of the tile (pass 2 contracts it against the staged coordinates)
+  __shared__ T rows[TILE];
   __shared__ double red[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ty = tid >> 4, tx = tid & 15;
@@ -199,19 +331,33 @@ __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restric
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = T(0);
+  // a thread stages one dimension of NST rows; the row indices are resolved once (the gather's index loads used to sit in front of
+  // every coordinate load: at one wave per SIMD the two dependent round trips per element were most of the kernel's time)
+  constexpr int NST = TILE * KM_DC / NTHREADS;
+  static_assert(NTHREADS % KM_DC == 0 && TILE * KM_DC % NTHREADS == 0, "k_kernel_backward: staging layout");
+  const int sd = tid % KM_DC, sr0 = tid / KM_DC;
+  int64_t xrow[NST];
+#pragma unroll
+  for (int q = 0; q < NST; ++q) {
+    const int64_t gi = i0 + sr0 + q * (NTHREADS / KM_DC);
+    xrow[q] = gi < n ? (idx ? idx[gi] : gi) : (int64_t)-1;
+  }
   auto stage = [&](int64_t d0) {
-    for (int e = tid; e < TILE * KM_DC; e += NTHREADS) {
-      int r = e / KM_DC, d = e % KM_DC;
-      int64_t gd = d0 + d;
-      T sc = (scales && gd < D) ? scales[gd] : T(1);
-      int64_t gi = i0 + r, gj = j0 + r;
-      T xv = T(0), yv = T(0);
-      if (gd < D) {
-        if (gi < n) xv = X[(idx ? idx[gi] : gi) * ldx + gd] * sc;
-        if (gj < p) yv = Y[gj * ldy + gd] * sc;
-      }
-      xs[r][d] = xv;
-      ys[r][d] = yv;
+    const int64_t gd = d0 + sd;
+    const bool dok = gd < D;
+    const T sc = (scales && dok) ? scales[gd] : T(1);
+    T xv[NST], yv[NST];
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {
+      const int64_t gj = j0 + sr0 + q * (NTHREADS / KM_DC);
+      xv[q] = (dok && xrow[q] >= 0) ? X[xrow[q] * ldx + gd] : T(0);
+      yv[q] = (dok && gj < p) ? Y[gj * ldy + gd] : T(0);
+    }
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {
+      const int r = sr0 + q * (NTHREADS / KM_DC);
+      xs[r][sd] = xv[q] * sc;
+      ys[r][sd] = yv[q] * sc;
     }
   };
   // pass 1: squared distances
@@ -243,60 +389,58 @@ __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restric
     for (int b = 0; b < 4; ++b) {
       int64_t gi = i0 + ty + 16 * a, gj = j0 + tx + 16 * b;
       T g = (gi < n && gj < p) ? G[gi * ldg + gj] : T(0);
-      dv += (double)(g * kernel_base<T>(kind, acc[a][b]));
-      acc[a][b] = g * variance * kernel_dbase<T>(kind, acc[a][b]);
+      T kb, kd;
+      kernel_base_dbase<T>(kind, acc[a][b], kb, kd);
+      dv += (double)(g * kb);
+      acc[a][b] = g * variance * kd;
     }
   dv = block_sum<double>(dv, red);
   if (tid == 0) pvar[tile] = dv;
-  // pass 2: per-dimension reductions
+  // pass 2: per-dimension reductions in product form (round 4: the per-dimension shuffle reductions of the first version cost
+  // 45 us per pass at m = B = 1024; this one ~ 10).  With t_ijd = xs_id - ys_jd:
+  //   sum_i c_ij t_ijd        = (C'xs)_jd - colsum_j ys_jd
+  //   sum_ij c_ij t_ijd^2     = sum_i rowsum_i xs_id^2 - 2 sum_j ys_jd (C'xs)_jd + sum_j colsum_j ys_jd^2   (combined in double)
+  // thread (j = lane, dg = wave) owns (C'xs)_{j, 8 dg .. 8 dg + 7} of the staged chunk.
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) Cs[ty + 16 * a][tx + 16 * b] = acc[a][b];
+  __syncthreads();
+  if (tid < TILE) {
+    T s = T(0);
+    for (int j = 0; j < TILE; ++j) s += Cs[tid][j];
+    rows[tid] = s;
+  }
+  T cols = T(0);
+  for (int i = 0; i < TILE; ++i) cols += Cs[i][lane];
+  constexpr int DPT = KM_DC / 4;  // dimensions per thread
   for (int64_t d0 = 0; d0 < D; d0 += KM_DC) {
-    __syncthreads();
-    stage(d0);
-    __syncthreads();
-    for (int d = 0; d < KM_DC; ++d) {
-      T xv[4], yv[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) xv[a] = xs[ty + 16 * a][d];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) yv[b] = ys[tx + 16 * b][d];
-      T ssum = T(0), zc[4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        zc[b] = T(0);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          T t = xv[a] - yv[b];
-          T ct = acc[a][b] * t;
-          zc[b] += ct;
-          ssum += ct * t;
-        }
-      }
-      // column sums over the 4 ty of this wave (lanes tx, tx+16, tx+32, tx+48), then all 64 lanes for the scale sum
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        zc[b] += __shfl_xor(zc[b], 16);
-        zc[b] += __shfl_xor(zc[b], 32);
-      }
-      for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o);
-      if (lane < 16) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) zred[wave][tx + 16 * b][d] = zc[b];
-      }
-      if (lane == 0) sred[wave][d] = (double)ssum;
+    if (D > KM_DC) {  // (one chunk: pass 1 left it staged)
+      __syncthreads();
+      stage(d0);
     }
     __syncthreads();
-    for (int e = tid; e < TILE * KM_DC; e += NTHREADS) {
-      int c = e / KM_DC, d = e % KM_DC;
-      int64_t gd = d0 + d, gj = j0 + c;
-      if (gd < D && gj < p_pad) {
-        T sc = scales ? scales[gd] : T(1);
-        T z = zred[0][c][d] + zred[1][c][d] + zred[2][c][d] + zred[3][c][d];
-        pZ[(blockIdx.y * p_pad + gj) * D + gd] = T(-2) * sc * z;
-      }
+    T zs[DPT];
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) zs[q] = T(0);
+    for (int i = 0; i < TILE; ++i) {
+      const T c = Cs[i][lane];
+#pragma unroll
+      for (int q = 0; q < DPT; ++q) zs[q] += c * xs[i][wave * DPT + q];
     }
-    if (tid < KM_DC && d0 + tid < D) {
-      T sc = scales ? scales[d0 + tid] : T(1);
-      pscale[tile * D + d0 + tid] = 2.0 / (double)sc * (sred[0][tid] + sred[1][tid] + sred[2][tid] + sred[3][tid]);
+    const T rw = rows[lane];
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) {
+      const int d = wave * DPT + q;
+      const int64_t gd = d0 + d, gj = j0 + lane;
+      const T sc = (scales && gd < D) ? scales[gd] : T(1);
+      const double xv = (double)xs[lane][d], yv = (double)ys[lane][d];
+      double ss = (double)rw * xv * xv - 2.0 * yv * (double)zs[q] + (double)cols * yv * yv;
+      for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+      if (gd < D) {
+        if (gj < p_pad) pZ[(blockIdx.y * p_pad + gj) * D + gd] = T(-2) * sc * (zs[q] - cols * ys[lane][d]);
+        if (lane == 0) pscale[tile * D + gd] = 2.0 / (double)sc * ss;
+      }
     }
   }
 }

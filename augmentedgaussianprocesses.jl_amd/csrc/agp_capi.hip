@@ -44,10 +44,8 @@ struct agp_ctx {
   // been seen by the host (any synchronising call) the task graph is not used again on this context
   void* kmm_scratch = nullptr;  // scaled copy + squared norms of the Y side of a kernel matrix whose Y is not a cached Z
   size_t kmm_bytes = 0;
-  void* bal_ws = nullptr;       // partial tiles / arrival counters of the balanced triangular product (k_xtx_bal)
+  void* bal_ws = nullptr;       // partial tiles of the balanced triangular product (k_xtx_bal)
   size_t bal_bytes = 0;
-  int32_t* bal_cnt = nullptr;
-  int64_t bal_cnt_n = 0;
   unsigned* safe_bar = nullptr;
   int32_t* safe_retries = nullptr;
   int n_cu = 0;
@@ -996,7 +994,7 @@ static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* o
   const int64_t nt = n / TILE;
   if (!bal_env || nt < 8)
     return syrk_tn<T, SY_STORE>(c, X, ld, n, n, (const T*)nullptr, 1, out, ldo, (T*)nullptr, (const T*)nullptr, (int64_t)0, T(0));
-  const int ch = ch_env ? ch_env : (int)std::max<int64_t>(2, nt / 8);
+  const int ch = (int)std::max<int64_t>(ch_env ? ch_env : 2, (nt + XTX_MAXU - 1) / XTX_MAXU);  // at most XTX_MAXU units per tile
   const int64_t nunits = xtx_bal_units(nt, ch), ntri = nt * (nt + 1) / 2;
   const size_t need = sizeof(T) * (size_t)nunits * TILE * TILE;
   if (c->bal_bytes < need) {
@@ -1009,17 +1007,6 @@ static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* o
     HIPCHK(c, hipMalloc(&c->bal_ws, need));
     c->bal_bytes = need;
   }
-  if (c->bal_cnt_n < ntri) {
-    if (c->bal_cnt) {
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      (void)hipFree(c->bal_cnt);
-    }
-    c->bal_cnt = nullptr;
-    c->bal_cnt_n = 0;
-    HIPCHK(c, hipMalloc((void**)&c->bal_cnt, sizeof(int32_t) * (size_t)ntri));
-    HIPCHK(c, hipMemsetAsync(c->bal_cnt, 0, sizeof(int32_t) * (size_t)ntri, c->stream));
-    c->bal_cnt_n = ntri;
-  }
   T* fillp = nullptr;
   int64_t fused_used = 0, fstride = 0, nfill = 0;
   int fnb = 0;
@@ -1031,8 +1018,18 @@ static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* o
     nfill = 96;
     c->h_dirty[0].on = false;
   }
-  hipLaunchKernelGGL((k_xtx_bal<T>), dim3((unsigned)(nunits + nfill)), dim3(NTHREADS), 0, c->stream, X, ld, n, out, ldo,
-                     (T*)c->bal_ws, c->bal_cnt, ch, nunits, fillp, fused_used, fstride, fnb);
+  static const int kg_env = [] {
+    const char* e = getenv("AGP_XTX_KG");
+    return e ? atoi(e) : 1;
+  }();
+  if (kg_env == 2)
+    hipLaunchKernelGGL((k_xtx_bal<T, 2>), dim3((unsigned)(nunits + nfill)), dim3(2 * NTHREADS), 0, c->stream, X, ld, n, out, ldo,
+                       (T*)c->bal_ws, ch, nunits, fillp, fused_used, fstride, fnb);
+  else
+    hipLaunchKernelGGL((k_xtx_bal<T, 1>), dim3((unsigned)(nunits + nfill)), dim3(NTHREADS), 0, c->stream, X, ld, n, out, ldo,
+                       (T*)c->bal_ws, ch, nunits, fillp, fused_used, fstride, fnb);
+  hipLaunchKernelGGL((k_xtx_bal_reduce<T>), dim3((unsigned)ntri), dim3(NTHREADS), 0, c->stream, n, out, ldo, (const T*)c->bal_ws,
+                     ch);
   LAUNCHCHK(c);
   return AGP_OK;
 }
@@ -2856,6 +2853,30 @@ struct Svgp : SvgpBase {
   // parameters goes stale until somebody asks for it (params_to_host).
   agp_status hyper_apply_one(int l, const std::vector<double>* hg_host, const T* dZ_dev) {
     Latent& g = lat[l];
+    if (hy_k && hy_z && dZ_dev && D + 1 <= 256) {  // both steps in one launch (k_adam_z_and_params)
+      AGPCHK(hyper_alloc());
+      AGPCHK(ensure_kadam(g));
+      if (hg_host) {
+        hy_up = *hg_host;  // staging that outlives the asynchronous copy
+        HIPCHK(ctx, hipMemcpyAsync(hy_g, hy_up.data(), sizeof(double) * (1 + D), hipMemcpyHostToDevice, st()));
+      }
+      if (!g.z_am) {
+        AGPCHK(dmalloc(ctx, &g.z_am, m * D));
+        AGPCHK(dmalloc(ctx, &g.z_av, m * D));
+        HIPCHK(ctx, hipMemsetAsync(g.z_am, 0, sizeof(double) * m * D, st()));
+        HIPCHK(ctx, hipMemsetAsync(g.z_av, 0, sizeof(double) * m * D, st()));
+      }
+      g.k_step += 1;
+      g.z_step += 1;
+      const int64_t nzb = (m * D + 255) / 256;
+      hipLaunchKernelGGL((k_adam_z_and_params<T>), dim3((unsigned)(nzb + 1)), dim3(256), 0, st(), m * D, nzb, g.Z, dZ_dev, g.z_am,
+                         g.z_av, g.z_step, hy_zeta, hy_zrule, hy_zrho, (int)D, g.k.ard ? 1 : 0, g.k.has_variance ? 1 : 0,
+                         g.k.has_transform ? 1 : 0, (const double*)hy_g, g.scales, g.kadam, g.kadam + (1 + D), g.k_step, hy_keta,
+                         hy_krule, hy_krho, hy_b1, hy_b2, hy_eps);
+      LAUNCHCHK(ctx);
+      g.host_params_stale = true;
+      return AGP_OK;
+    }
     if (hy_k) {
       AGPCHK(hyper_alloc());
       AGPCHK(ensure_kadam(g));
@@ -4570,10 +4591,9 @@ agp_status agp_ctx_destroy(agp_ctx* ctx) {
     if (ctx->tri_scratch) (void)hipFree(ctx->tri_scratch);
   }
   if (ctx->kmm_scratch) (void)hipFree(ctx->kmm_scratch);
-  if (ctx->bal_ws || ctx->bal_cnt) {
+  if (ctx->bal_ws) {
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->bal_ws) (void)hipFree(ctx->bal_ws);
-    if (ctx->bal_cnt) (void)hipFree(ctx->bal_cnt);
+    (void)hipFree(ctx->bal_ws);
   }
   if (ctx->chain_stream) {
     (void)hipStreamSynchronize(ctx->chain_stream);

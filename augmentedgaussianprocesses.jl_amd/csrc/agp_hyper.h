@@ -534,6 +534,45 @@ __global__ void k_adam_ascent(int64_t n, T* __restrict__ z, const T* __restrict_
   z[i] = (T)((double)z[i] + opt_rule_delta(rule, (double)g[i], am + i, av + i, step, eta, b1, b2, eps, rho));
 }
 
+// both optimiser steps of a latent in ONE launch (round 4): workgroups 0 .. nzb - 1 are k_adam_ascent on Z, the last one is
+// k_adam_kernel_params (one thread per kernel parameter) -- they touch disjoint state
+template <typename T>
+__global__ void k_adam_z_and_params(int64_t nz, int64_t nzb, T* __restrict__ z, const T* __restrict__ gz, double* __restrict__ zm,
+                                    double* __restrict__ zv, int zstep, double zeta, int zrule, double zrho, int D, int ard,
+                                    int has_variance, int has_transform, const double* __restrict__ g, T* __restrict__ params,
+                                    double* __restrict__ am, double* __restrict__ av, int kstep, double keta, int krule,
+                                    double krho, double b1, double b2, double eps) {
+  if ((int64_t)blockIdx.x < nzb) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= nz) return;
+    z[i] = (T)((double)z[i] + opt_rule_delta(zrule, (double)gz[i], zm + i, zv + i, zstep, zeta, b1, b2, eps, zrho));
+    return;
+  }
+  const int np = 1 + (ard ? D : 1);
+  const int j = threadIdx.x;
+  if (j >= np) return;
+  const double p = j == 0 ? (double)params[D] : (double)params[ard ? j - 1 : 0];
+  double gl;
+  if (j == 0) {
+    gl = has_variance ? p * g[0] : 0.0;
+  } else if (ard) {
+    gl = has_transform ? p * g[j] : 0.0;
+  } else {
+    double sgm = 0.0;
+    for (int d = 0; d < D; ++d) sgm += g[1 + d];
+    gl = has_transform ? p * sgm : 0.0;
+  }
+  const double np_ = exp(log(p) + opt_rule_delta(krule, gl, am + j, av + j, kstep, keta, b1, b2, eps, krho));
+  if (j == 0) {
+    if (has_variance) params[D] = (T)np_;
+    else am[0] = av[0] = 0.0;
+  } else if (has_transform) {
+    if (ard) params[j - 1] = (T)np_;
+    else
+      for (int d = 0; d < D; ++d) params[d] = (T)np_;
+  }
+}
+
 // C(M x N) = A(K x M)^T B(K x N)  (both operands row-contiguous; general, non-symmetric).  grid = (N/64, M/64)
 template <typename T, int KG>
 __global__ __launch_bounds__(NTHREADS * KG) void k_gemm_tn(const T* __restrict__ A, int64_t lda,

@@ -223,25 +223,37 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_syrk_tn(const T* __restrict__
 // k_syrk_tn<SY_STORE> with lower_a gives every lower tile (ta, tb) to one workgroup: tile (0, 0) carries nt 64-deep k-blocks, tile
 // (nt-1, .) one -- the launch lasts as long as its longest tile (a CU forms one k-block in ~2.7 us of its fp64 MFMA pipes: 16 of
 // them = the 42 us measured at m = 1024), although the whole product is only nt (nt + 1)(nt + 2) / 6 k-blocks (816: 8.6 us of the
-// chip).  Here a workgroup takes a UNIT = at most `ch` consecutive k-blocks of one tile; a tile of several units collects their
-// partial tiles in a workspace, and the unit that arrives last (device-scope counter) adds them in unit order -- the sum does not
-// depend on who that is -- and stores the tile, mirrored.  Units are numbered row of tiles by row of tiles:
+// chip).  Here a workgroup takes a UNIT = at most `ch` consecutive k-blocks of one tile.  A tile of one unit is stored at once
+// (mirrored); a tile of several units leaves their partial tiles in a workspace and a SECOND launch (k_xtx_bal_reduce) adds them in
+// unit order.  (A single launch in which the last unit to arrive -- device-scope counter -- adds the partial tiles was built first:
+// every unit then needs a device-scope release, an L2 write-back on this chip, and 444 of them serialise: 121 us.)  Units are
+// numbered row of tiles by row of tiles:
 //   row ta: (ta + 1) tiles x nu(ta) = ceil((nt - ta) / ch) units, unit index = [rows before] + tb * nu + u.
-// ws: nunits x 64 x 64 elements (thread-major partial tiles); cnt: one word per lower tile, zero between launches (the last
-// arriver puts it back).  Further workgroups (blockIdx.x >= nunits) refill a dirty hand-over set like the riders of k_syrk_tn.
+// ws: nunits x 64 x 64 elements (thread-major partial tiles).  Further workgroups of the first launch (blockIdx.x >= nunits) refill a
+// dirty hand-over set like the riders of k_syrk_tn.
 // ---------------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ int64_t xtx_bal_units(int64_t nt, int ch) {
   int64_t s = 0;
   for (int64_t ta = 0; ta < nt; ++ta) s += (ta + 1) * ((nt - ta + ch - 1) / ch);
   return s;
 }
-template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_xtx_bal(const T* __restrict__ X, int64_t ld, int64_t n, T* __restrict__ out,
-                                                      int64_t ldo, T* __restrict__ ws, int32_t* __restrict__ cnt, int ch,
-                                                      int64_t nunits, T* __restrict__ fillp, int64_t fill_used,
-                                                      int64_t fill_stride, int fill_nb) {
-  __shared__ __attribute__((aligned(16))) T smem[smem_elems<T>()];
-  __shared__ int is_last;
+template <typename T, typename F>
+__device__ __forceinline__ void xtx_store_mirrored(Acc<T>& acc, int64_t ta, int64_t tb, T* __restrict__ out, int64_t ldo, F) {
+  const int64_t a0 = ta * TILE, b0 = tb * TILE;
+  acc_foreach<T>(acc, [&](int rr, int c, T val) {
+    const int64_t gr = a0 + rr, gc = b0 + c;
+    if (ta != tb || gc <= gr) {  // diagonal tile: the lower half is the truth, mirrored
+      out[gr * ldo + gc] = val;
+      out[gc * ldo + gr] = val;
+    }
+  });
+}
+template <typename T, int KG>
+__global__ __launch_bounds__(NTHREADS * KG) void k_xtx_bal(const T* __restrict__ X, int64_t ld, int64_t n, T* __restrict__ out,
+                                                           int64_t ldo, T* __restrict__ ws, int ch, int64_t nunits,
+                                                           T* __restrict__ fillp, int64_t fill_used, int64_t fill_stride,
+                                                           int fill_nb) {
+  __shared__ __attribute__((aligned(16))) T smem[KG * smem_elems<T>()];
   if ((int64_t)blockIdx.x >= nunits) {
     const int64_t nfb = (int64_t)gridDim.x - nunits, fb = (int64_t)blockIdx.x - nunits;
     const T sv = __builtin_bit_cast(T, Sent<T>::bits);
@@ -260,12 +272,11 @@ __global__ __launch_bounds__(NTHREADS) void k_xtx_bal(const T* __restrict__ X, i
     r -= inrow;
   }
   const int64_t tb = r / nu, u = r % nu;
-  const int64_t a0 = ta * TILE, b0 = tb * TILE;
   const int64_t k0 = (ta + u * ch) * TILE, k1 = (k0 + (int64_t)ch * TILE) < n ? (k0 + (int64_t)ch * TILE) : n;
   Acc<T> acc;
   acc.zero();
-  gemm_tile<T, RC, RC, 1>(X + a0, ld, X + b0, ld, k0, k1, nullptr, acc, smem);
-  const int tid = threadIdx.x;
+  gemm_tile<T, RC, RC, KG>(X + ta * TILE, ld, X + tb * TILE, ld, k0, k1, nullptr, acc, smem);
+  if (KG > 1 && threadIdx.x >= NTHREADS) return;
   if (nu > 1) {
     T* wp = ws + (int64_t)blockIdx.x * (TILE * TILE);
 #pragma unroll
@@ -273,38 +284,43 @@ __global__ __launch_bounds__(NTHREADS) void k_xtx_bal(const T* __restrict__ X, i
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wp[((mi * 2 + ni) * 4 + q) * NTHREADS + tid] = acc.a[mi][ni][q];
-    __threadfence();  // the partial tile is visible device-wide before the arrival is counted
-    __syncthreads();
-    if (tid == 0) {
-      int32_t* cw = cnt + (ta * (ta + 1) / 2 + tb);
-      const int old = atomicAdd(cw, 1);
-      is_last = old == (int)nu - 1;
-      if (is_last) atomicExch(cw, 0);  // every unit of the tile has arrived: the word is free for the next launch
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();  // (acquire: the other units' tiles were written by other CUs / XCDs)
-    const T* w0 = ws + ((int64_t)blockIdx.x - u) * (TILE * TILE);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int e = (mi * 2 + ni) * 4 + q;
-          T v = T(0);
-          for (int64_t k = 0; k < nu; ++k) v += __builtin_nontemporal_load(w0 + k * (TILE * TILE) + e * NTHREADS + tid);
-          acc.a[mi][ni][q] = v;
-        }
+        for (int q = 0; q < 4; ++q) wp[((mi * 2 + ni) * 4 + q) * NTHREADS + threadIdx.x] = acc.a[mi][ni][q];
+    return;
   }
-  acc_foreach<T>(acc, [&](int rr, int c, T val) {
-    const int64_t gr = a0 + rr, gc = b0 + c;
-    if (ta != tb || gc <= gr) {  // diagonal tile: the lower half is the truth, mirrored
-      out[gr * ldo + gc] = val;
-      out[gc * ldo + gr] = val;
+  xtx_store_mirrored<T>(acc, ta, tb, out, ldo, 0);
+}
+// second launch: one workgroup per lower tile (row-major triangle order); tiles of one unit are done already.  All partial values
+// of an element are fetched side by side (a loop of dependent loads per element made this launch slower than the product)
+constexpr int XTX_MAXU = 8;  // units per tile the reduction is written for (the host picks ch so that nt / ch <= 8)
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_xtx_bal_reduce(int64_t n, T* __restrict__ out, int64_t ldo,
+                                                             const T* __restrict__ ws, int ch) {
+  const int64_t nt = n / TILE;
+  int64_t ta, tb;
+  tri_index(blockIdx.x, ta, tb);
+  const int nu = (int)((nt - ta + ch - 1) / ch);
+  if (nu <= 1) return;
+  int64_t base = 0;
+  for (int64_t a = 0; a < ta; ++a) base += (a + 1) * ((nt - a + ch - 1) / ch);
+  const T* w0 = ws + (base + tb * nu) * (TILE * TILE) + threadIdx.x;
+  Acc<T> acc;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {  // two halves of the thread's 16 values: 8 x XTX_MAXU loads in flight
+    T p[8][XTX_MAXU];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int k = 0; k < XTX_MAXU; ++k) p[q][k] = k < nu ? w0[(int64_t)k * (TILE * TILE) + (h * 8 + q) * NTHREADS] : T(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      T v = p[q][0];
+#pragma unroll
+      for (int k = 1; k < XTX_MAXU; ++k) v += p[q][k];  // unit order (the zeros of absent units change nothing)
+      const int e = h * 8 + q;
+      acc.a[e >> 3][(e >> 2) & 1][e & 3] = v;
     }
-  });
+  }
+  xtx_store_mirrored<T>(acc, ta, tb, out, ldo, 0);
 }
 
 // The fused natural-gradient step of SEVERAL latents (multi-class, multi-output, heteroscedastic models on one GPU) as one

@@ -1601,7 +1601,33 @@ struct Svgp : SvgpBase {
   int64_t B_last = 0, ldx_last = 0;
   double rho_last = 1.0;
 
-  hipStream_t st() { return ctx->stream; }
+  // (st_over: the hyper-gradient puts its small launches on a side stream next to the main stream's products, hypergrad)
+  hipStream_t st_over = nullptr;
+  hipStream_t st() { return st_over ? st_over : ctx->stream; }
+  struct StreamOver {  // scope guard: st() returns `s` until the guard goes
+    hipStream_t& slot;
+    StreamOver(hipStream_t& sl, hipStream_t s) : slot(sl) { slot = s; }
+    ~StreamOver() { slot = nullptr; }
+  };
+  // side stream of the hyper-gradient (round 4) and its fork / join events.  OFF unless AGP_HYPER_SIDE=1: measured at C2, the two
+  // fork / join pairs hide 46 us of small launches behind the products and still lengthen the iteration (1063 -> 1077 us) -- every
+  // cross-stream event costs the waiting stream 7 - 12 us here, and the kernels that share the chip slow one another down
+  // (the backward pass 24 -> 54 us next to a product)
+  hipStream_t hy_side = nullptr;
+  hipEvent_t hy_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int hy_side_state = 0;  // 0 not tried, 1 usable, -1 off
+  bool hy_side_ready() {
+    if (hy_side_state == 0) {
+      hy_side_state = -1;
+      const char* e = getenv("AGP_HYPER_SIDE");
+      if (e && e[0] == '1' && hipStreamCreateWithFlags(&hy_side, hipStreamNonBlocking) == hipSuccess) {
+        bool ok = true;
+        for (auto& ev : hy_ev) ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        if (ok) hy_side_state = 1;
+      }
+    }
+    return hy_side_state == 1;
+  }
 
   agp_status init() override {
     m = desc.m;
@@ -1737,6 +1763,12 @@ struct Svgp : SvgpBase {
       if (pf_join[q]) dcheck(hipEventDestroy(pf_join[q]), __LINE__);
     }
     if (pf_fork) dcheck(hipEventDestroy(pf_fork), __LINE__);
+    if (hy_side) {
+      (void)hipStreamSynchronize(hy_side);
+      dcheck(hipStreamDestroy(hy_side), __LINE__);
+    }
+    for (auto& ev : hy_ev)
+      if (ev) dcheck(hipEventDestroy(ev), __LINE__);
     if (elbo_pin) {
       dcheck(hipHostFree(elbo_pin), __LINE__);
       for (auto& e : elbo_ev)
@@ -2590,7 +2622,19 @@ struct Svgp : SvgpBase {
     AGPCHK(refresh_K());
     AGPCHK(materialize(g));
     const bool gk_fused = one_product && g.C_valid && g.C_kap == g.kappa && !g.stale_on && !(g.on && !g.on_first);
-    AGPCHK(ensure_pred(g, !gk_fused));  // Sigma, mu, K^-1 mu (, Apred = K^-1 - K^-1 Sigma K^-1)
+    // ... and with the small launches next to the products instead of between them: K^-1 mu, mean_f / g_mu / g_sigma run on a side
+    // stream while the main stream forms K^-1 Sigma and kappa (Sigma K^-1); the backward pass through K_nm and its reduction run
+    // there while the main stream forms C (Sigma K^-1) and G_K.  Two fork / join pairs of events; everything the side stream does
+    // is joined before this function returns.
+    const bool side = gk_fused && !mo && hy_side_ready();
+    if (side) {
+      HIPCHK(ctx, hipEventRecord(hy_ev[0], ctx->stream));
+      HIPCHK(ctx, hipStreamWaitEvent(hy_side, hy_ev[0], 0));
+    }
+    {
+      StreamOver so(st_over, side ? hy_side : (hipStream_t) nullptr);
+      AGPCHK(ensure_pred(g, !gk_fused));  // Sigma, mu, K^-1 mu (, Apred = K^-1 - K^-1 Sigma K^-1)
+    }
     // AGP_FLAG_STALE_K: the step's kappa mixes the new Knm with the frozen inv(K); the differentiated ELBO recomputes the
     // kernel matrices (ELBO.jl:15-21), so the gradient takes kappa = Knm K^-1 with the FRESH inverse
     if (g.stale_on && lp.kind == AGP_LIK_HETEROSCEDASTIC) {
@@ -2659,11 +2703,12 @@ struct Svgp : SvgpBase {
         hipLaunchKernelGGL((k_hyper_varf<T>), grid1(B * 64), dim3(256), 0, st(), B, mp, mp, (const T*)hyH1,
                            kap, (const T*)(Kt + l * Bp), pw0);
       }
-      if (one_product)
+      if (one_product) {
+        StreamOver so(st_over, side ? hy_side : (hipStream_t) nullptr);
         hipLaunchKernelGGL((k_hyper_muf_gvec<T>), grid1(B * 64), dim3(256), 0, st(), B, mp, mp, rho, gmode, kap,
                            (const T*)g.mu, (const T*)(rbuf + l * Bp), (const T*)(theta + l * Bp), (const T*)y_last, idx_last,
                            hy_muf, hy_gmu, hy_gs);
-      else
+      } else
         hipLaunchKernelGGL((k_hyper_gvec<T>), grid1(B), dim3(256), 0, st(), B, rho, gmode, (const T*)(rbuf + l * Bp),
                            (const T*)(theta + l * Bp), (const T*)hy_muf, (const T*)y_last, idx_last, (const T*)pw0,
                            (const T*)gamma, (const T*)lam_dev, hy_gmu, hy_gs);
@@ -2679,6 +2724,10 @@ struct Svgp : SvgpBase {
       }
       AGPCHK((gemm_nt<T, EPI_STORE>(ctx, kap, mp, Tw2, mp, Bq, mp, mp, 0, hyH1, mp, nullptr, 0, nullptr, nullptr, nullptr,
                                     0)));  // kappa (K^-1 Sigma)' = kappa Sigma K^-1
+      if (side) {  // join: K^-1 mu, g_mu, g_sigma
+        HIPCHK(ctx, hipEventRecord(hy_ev[1], hy_side));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, hy_ev[1], 0));
+      }
       if (gk_fused) {
         if (!hy_upart) AGPCHK(dmalloc(ctx, &hy_upart, (Bp / TILE) * mp));
         hipLaunchKernelGGL((k_hyper_hk_tile<T>), dim3((unsigned)(mp / TILE), (unsigned)(Bq / TILE)), dim3(256), 0, st(), B, mp, rho,
@@ -2689,6 +2738,10 @@ struct Svgp : SvgpBase {
                            (const T*)hy_gs, (const T*)g.apred, (const T*)hyH1, kap, hyH2, hyH3);
       }
       LAUNCHCHK(ctx);
+      if (side) {  // fork: the backward pass through K_nm needs G_Knm only
+        HIPCHK(ctx, hipEventRecord(hy_ev[2], ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(hy_side, hy_ev[2], 0));
+      }
     } else {
       hipLaunchKernelGGL((k_hyper_gkappa<T>), grid2(Bq, mp), blk2, 0, st(), B, Bq, mp, mp, rho, (const T*)hy_gmu,
                          (const T*)hy_gs, (const T*)g.mu, knm, hyH1);
@@ -2717,6 +2770,7 @@ struct Svgp : SvgpBase {
     // backward through kernelmatrix(k, x, Z)  (gradient w.r.t. the second argument); its reduction initialises the gradient and
     // adds the kdiag term of the variance (rho sum_i g_sigma,i), which used to be a memset in front and a kernel behind
     {
+      StreamOver so(st_over, side ? hy_side : (hipStream_t) nullptr);
       dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
       const int64_t tiles = (int64_t)gk.x * gk.y;
       hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)x_last, ldx_last, idx_last, B,
@@ -2725,6 +2779,10 @@ struct Svgp : SvgpBase {
       hipLaunchKernelGGL((k_hyper_reduce<T>), dim3((unsigned)(D + 1 + (m * D + 255) / 256)), dim3(256), 0, st(), tiles, D,
                          (const double*)hy_pvar, (const double*)hy_pscale, hy_g, 1.0, 1, (int64_t)gk.y, m, mp, (const T*)hy_pZ, hy_dZ,
                          T(1), (const T*)hy_gs, B, (double)rho);
+    }
+    if (side) {  // join: the second backward pass reuses the partial-sum buffers and accumulates into the gradient
+      HIPCHK(ctx, hipEventRecord(hy_ev[3], hy_side));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, hy_ev[3], 0));
     }
     const bool online_x = g.on && !g.on_first;
     if (online_x && bs_world > 1) {

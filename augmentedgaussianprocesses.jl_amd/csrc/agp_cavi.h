@@ -173,8 +173,10 @@ __global__ void k_scale_rows(const T* __restrict__ Y, int64_t ldy, int64_t p, in
 // exp for non-positive arguments was also tried: no different from the library's).
 // SPEC 1: row-dot only (streaming prediction: no matrix output, not symmetric); SPEC 2: store only (Knm of the step: not
 // symmetric, no row-dot); SPEC 0: everything at run time.  The specialised forms drop the unused code and its registers.
+// (SPEC 3 keeps the symmetric / diagonal logic and spilled 14 registers under the 128-VGPR cap; a K_ZZ launch is one workgroup per CU
+//  anyway, so it is compiled for two)
 template <typename T, int KIND, int SPEC = 0>
-__global__ __launch_bounds__(NTHREADS, 4) void k_kernelmatrix_mma(const T* __restrict__ X, int64_t ldx,
+__global__ __launch_bounds__(NTHREADS, (SPEC == 3 ? 2 : 4)) void k_kernelmatrix_mma(const T* __restrict__ X, int64_t ldx,
                                                                const int64_t* __restrict__ idx, int64_t n,
                                                                const T* __restrict__ Ysc, const T* __restrict__ yng,
                                                                int64_t p, int64_t D, int Dp, const T* __restrict__ scales,

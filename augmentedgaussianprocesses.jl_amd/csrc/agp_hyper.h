@@ -408,10 +408,12 @@ __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restric
   __syncthreads();
   if (tid < TILE) {
     T s = T(0);
+#pragma unroll 8
     for (int j = 0; j < TILE; ++j) s += Cs[tid][j];
     rows[tid] = s;
   }
   T cols = T(0);
+#pragma unroll 8
   for (int i = 0; i < TILE; ++i) cols += Cs[i][lane];
   constexpr int DPT = KM_DC / 4;  // dimensions per thread
   for (int64_t d0 = 0; d0 < D; d0 += KM_DC) {
@@ -423,6 +425,7 @@ __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restric
     T zs[DPT];
 #pragma unroll
     for (int q = 0; q < DPT; ++q) zs[q] = T(0);
+#pragma unroll 4
     for (int i = 0; i < TILE; ++i) {
       const T c = Cs[i][lane];
 #pragma unroll

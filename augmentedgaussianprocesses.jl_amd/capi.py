@@ -97,6 +97,7 @@ SYMBOLS = {
     "agp_svgp_get_opt_state": (_I32, [_VP, _PI64]),
     "agp_svgp_cavi_step": (_I32, [_VP, _VP, _I64, _VP, _VP, _I64, _DBL]),
     "agp_svgp_step_counters": (_I32, [_VP, _PI64, _PI64]),
+    "agp_svgp_hyper_counters": (_I32, [_VP, _PI64, _PI64]),
     "agp_svgp_step_local": (_I32, [_VP, _VP, _I64, _VP, _VP, _I64, _DBL]),
     "agp_svgp_hyper_configure": (_I32, [_VP, _I32, _DBL, _I32, _DBL, _DBL, _DBL, _DBL]),
     "agp_svgp_hyper_rule": (_I32, [_VP, _I32, _DBL, _I32, _DBL]),

@@ -1231,6 +1231,7 @@ struct SvgpBase {
   bool in_cavi_step = false;  // step_local is running as the first half of agp_svgp_cavi_step (its tail may then be deferred)
   int64_t n_prologue = 0;  // CAVI steps whose natural-gradient part rode on the next step's task-graph launch (agp_svgp_step_counters)
   int64_t n_steps = 0;     // agp_svgp_cavi_step calls
+  int64_t n_hgrad = 0, n_gk_fused = 0;  // hyper-gradient evaluations / those with the one-product G_K (agp_svgp_hyper_counters)
   // HIP-event timing of the dominant kernel sequence (agp_svgp_timing_*)
   bool timing = false;
   int timing_every = 1, timing_ctr = 0;  // every n-th sequence is bracketed (the two event records cost the step ~16 us at C2)
@@ -2626,6 +2627,8 @@ struct Svgp : SvgpBase {
     // stream while the main stream forms K^-1 Sigma and kappa (Sigma K^-1); the backward pass through K_nm and its reduction run
     // there while the main stream forms C (Sigma K^-1) and G_K.  Two fork / join pairs of events; everything the side stream does
     // is joined before this function returns.
+    n_hgrad += 1;
+    n_gk_fused += gk_fused ? 1 : 0;
     const bool side = gk_fused && !mo && hy_side_ready();
     if (side) {
       HIPCHK(ctx, hipEventRecord(hy_ev[0], ctx->stream));
@@ -5216,6 +5219,13 @@ agp_status agp_svgp_step_counters(agp_svgp* h, int64_t* n_steps_host, int64_t* n
   HCHK(h);
   if (n_steps_host) *n_steps_host = h->impl->n_steps;
   if (n_prologue_host) *n_prologue_host = h->impl->n_prologue;
+  return AGP_OK;
+}
+
+agp_status agp_svgp_hyper_counters(agp_svgp* h, int64_t* n_grad_host, int64_t* n_gk_fused_host) {
+  HCHK(h);
+  if (n_grad_host) *n_grad_host = h->impl->n_hgrad;
+  if (n_gk_fused_host) *n_gk_fused_host = h->impl->n_gk_fused;
   return AGP_OK;
 }
 

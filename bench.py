@@ -179,6 +179,26 @@ def build_model(AGP, cfg, ell, Z, B_local, rank, world, dev_index, mode):
     raise ValueError(lik)
 
 
+def _hyper_products(m, B):
+    """The seven GEMM-shaped launches of one hyper-on iteration: executed vs dense-count flops."""
+    rows = [
+        ("kappa = Knm K^-1", 2.0 * B * m * m, 2.0 * B * m * m),
+        ("W = kappa Xa' (Xa lower triangular: k range of a column tile stops at its last column)", 1.0 * B * m * m * (1 + 64.0 / m),
+         2.0 * B * m * m),
+        ("Sigma = Xa' Xa (lower tiles, triangular k ranges, balanced units: k_xtx_bal)", m ** 3 / 3.0, 2.0 * m ** 3),
+        ("K^-1 Sigma", 2.0 * m ** 3, 2.0 * m ** 3),
+        ("kappa (Sigma K^-1)  [H = G_kappa K^-1 from one product]", 2.0 * B * m * m, 2.0 * B * m * m),
+        ("C (Sigma K^-1)  [G_K from one product; C = kappa' diag(w) kappa + K^-1/4 comes from the factorisation launch's prologue]",
+         2.0 * m ** 3, 2.0 * m ** 3),
+        ("K^-1 = X' X after the K_ZZ refresh (k_xtx_bal)", m ** 3 / 3.0, 2.0 * m ** 3),
+    ]
+    return {"launches": len(rows), "executed_gflop": round(sum(r[1] for r in rows) / 1e9, 3),
+            "dense_count_gflop": round(sum(r[2] for r in rows) / 1e9, 3),
+            "round3": "nine 2 n^3-shaped launches + the half-flop Apred product (kappa Sigma, (.) K^-1, kappa' H, K^-1 Sigma, Apred "
+                      "in addition to kappa, W, Sigma, K^-1)",
+            "list": [r[0] for r in rows]}
+
+
 def main():
     # c5 on one GPU times the share of ONE rank of the 8-GPU run (a latent slice without its communicator): the library refuses
     # that by default (the mixes are partial), the benchmark asks for it explicitly
@@ -633,7 +653,14 @@ def main():
                 "algorithmic_flops_per_launch": fl, "achieved": round(fl / us / 1e6, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(fl / us / 1e6 / peak, 4),
                 "iteration": "no host synchronisation inside the iteration"
-                             + (" (33 kernels back to back, profiles/r03_c2_hyper_timeline.txt)" if a.config == "c2" else "")}
+                             + (" (29 kernels back to back, profiles/r04_c2_hyper_timeline.txt)" if a.config == "c2" else ""),
+                # the GEMM-shaped launches of one iteration (round 4: seven, round 3: nine + the symmetric Apred product) with the
+                # flops they execute against what a dense 2 n^3-style count credits them (triangular operands, symmetric results)
+                "products": _hyper_products(mpad, (B + 63) // 64 * 64)}
+            ngr, ngf = C.c_int64(), C.c_int64()
+            if hasattr(L, "agp_svgp_hyper_counters"):
+                mh._chk(L.agp_svgp_hyper_counters(hh, C.byref(ngr), C.byref(ngf)))
+                out["hyper_roofline"]["gradients_with_one_product_G_K"] = f"{ngf.value} of {ngr.value}"
         del mh, cfg_h
         # streaming predict_f (means) over all N points: K_*m is never materialised
         mu_out = torch.empty(1, N, dtype=model.tdtype, device=dev)

@@ -214,6 +214,10 @@ agp_status agp_svgp_cavi_step(agp_svgp* h, const void* x, int64_t ldx, const voi
  * natural-gradient part taken as the prologue of the following step's factorisation launch (the rest took it with the stand-alone
  * kernel).  bench.py reads them to decide what the dominant launch contained.  Host counters, no synchronisation. */
 agp_status agp_svgp_step_counters(agp_svgp* h, int64_t* n_steps_host, int64_t* n_prologue_host);
+/* ... and of the hyper-parameter iteration (round 4): number of hyper-gradient evaluations on this handle, and how many of them
+ * formed G_K from ONE m^3 product -- C (Sigma K^-1) with C = kappa' diag(w) kappa + K^-1 / 4 left behind by the prologue of the
+ * factorisation launch -- instead of kappa' H and K^-1 Sigma K^-1 (update_hyperparameters!, autotuning.jl:86-140).  Host counters. */
+agp_status agp_svgp_hyper_counters(agp_svgp* h, int64_t* n_grad_host, int64_t* n_gk_fused_host);
 /* The same step in phases, for multi-GPU runs:
  *   step_local  : compute_kappa + mean_f/var_f (+ c_k for LogisticSoftMax)   latentgp.jl:209-215,171-189
  *   lsm_*       : LogisticSoftMax cross-latent fixed point, logisticsoftmax.jl:65-72:

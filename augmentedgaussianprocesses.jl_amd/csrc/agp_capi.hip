@@ -932,6 +932,68 @@ static int64_t syrk_kg2_limit() {  // (AGP_SYRK_KG2_LIMIT: the symmetric product
   }();
   return v;
 }
+// Tail split of a symmetric-product launch (syrk_tn_body, agp_linalg.h): `tiles` tile workgroups (all latents together) on
+// S = occupancy x CUs slots.  When the launch needs more than one round and the last round would be at most half full, the last
+// `rsplit` tiles (per latent: rsplit / nl) are cut into P k-slices each so that the pieces fill the tail.
+// OFF unless AGP_SYRK_SPLIT=1 (2: also print the plan).  Measured in round 4 and not adopted: at C3 (528 tiles, fp32) the occupancy
+// is 3 x 256 = 768 slots -- one round, the launch's 0.40 of peak is the fp32 tile product itself, not a tail --; at C4 (8 x 136
+// tiles on 512 slots: 64 tiles cut into 8 slices) k_syrk_eta_batch went 380 -> 373 us and the step did not move (1.107 vs 1.140 ms,
+// within the run-to-run spread): next to two look-ahead streams the launch is bound by the chip's MFMA throughput, not by rounds.
+struct SyrkSplit {
+  int64_t per_latent = 0;  // tiles of every latent that are split
+  int P = 1;
+};
+static int ctx_cus(agp_ctx* c) {
+  if (c->n_cu <= 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || v <= 0) v = 64;
+    c->n_cu = v;
+  }
+  return c->n_cu;
+}
+static SyrkSplit syrk_split_plan(agp_ctx* c, const void* kernel, int threads, int64_t tiles_per_latent, int nl, int64_t nslab) {
+  static const bool on = [] {
+    const char* e = getenv("AGP_SYRK_SPLIT");
+    return e && (e[0] == '1' || e[0] == '2');
+  }();
+  SyrkSplit sp;
+  if (!on) return sp;
+  int occ = 0;
+  const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, 0);
+  static const bool verbose = [] {
+    const char* e = getenv("AGP_SYRK_SPLIT");
+    return e && e[0] == '2';
+  }();
+  if (verbose) fprintf(stderr, "[agp] syrk_split_plan: occupancy query %d -> %d per CU, %d CUs, %lld tiles x %d\n", (int)oe, occ,
+                       ctx_cus(c), (long long)tiles_per_latent, nl);
+  if (oe != hipSuccess || occ <= 0) return sp;
+  const int64_t S = (int64_t)occ * ctx_cus(c), T = tiles_per_latent * nl;
+  if (T <= S) return sp;
+  const int64_t R = T % S;
+  if (R == 0 || 2 * R > S) return sp;
+  const int64_t per = (R + nl - 1) / nl;  // per latent (rounded up: a few more pieces than slots)
+  if (per >= tiles_per_latent) return sp;
+  int64_t P = S / (per * nl);
+  P = std::min<int64_t>(P, std::min<int64_t>(32, nslab / 2));  // at least two slabs per piece
+  if (P < 2) return sp;
+  sp.per_latent = per;
+  sp.P = (int)P;
+  return sp;
+}
+static agp_status ensure_bal_ws(agp_ctx* c, size_t need) {
+  if (c->bal_bytes < need) {
+    if (c->bal_ws) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      (void)hipFree(c->bal_ws);
+    }
+    c->bal_ws = nullptr;
+    c->bal_bytes = 0;
+    HIPCHK(c, hipMalloc(&c->bal_ws, need));
+    c->bal_bytes = need;
+  }
+  return AGP_OK;
+}
+
 // S = A' diag(w) A (lower tiles mirrored), two k-groups per workgroup when the tile count underfills the chip
 template <typename T, int MODE>
 static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_t Kdim, const T* w, int lower_a, T* out,
@@ -954,25 +1016,42 @@ static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_
     nfill = 96;
     c->h_dirty[0].on = false;
   }
-  const int64_t grid = tiles + nrider + nfill;
   // up to 160 tiles (C2: 136 on 256 CUs, one workgroup per CU) four k-groups: 16 waves per CU instead of 8 -- 58 -> 52 us at C2
   // (step 0.379 -> 0.3735 ms); AGP_SYRK_KG4=0 switches it off
   static const bool kg4 = []() {
     const char* e = getenv("AGP_SYRK_KG4");
     return !(e && e[0] == '0');
   }();
-  if (kg4 && tiles <= 160 && Kdim >= 8 * BK)
+  const int kg = (kg4 && tiles <= 160 && Kdim >= 8 * BK) ? 4 : (tiles <= syrk_kg2_limit() && Kdim >= 4 * BK) ? 2 : 1;
+  // tail split (syrk_tn_body): the remainder tiles of the last round as k-slices behind the full tiles, finished by a second launch
+  SyrkSplit sp;
+  if (!lower_a && out != nullptr && kg != 4)
+    sp = syrk_split_plan(c, kg == 2 ? (const void*)&k_syrk_tn<T, MODE, 2> : (const void*)&k_syrk_tn<T, MODE, 1>, kg * NTHREADS, tiles,
+                         1, Kdim / BkOf<T>::v);
+  const int64_t nfull = tiles - sp.per_latent, npiece = sp.per_latent * sp.P;
+  if (npiece) AGPCHK(ensure_bal_ws(c, sizeof(T) * (size_t)npiece * TILE * TILE));
+  T* ws = npiece ? (T*)c->bal_ws : (T*)nullptr;
+  const int64_t grid = nfull + npiece + nrider + nfill;
+  if (kg == 4)
     hipLaunchKernelGGL((k_syrk_tn<T, MODE, 4>), dim3((unsigned)grid), dim3(4 * NTHREADS), 0, c->stream, A, lda, Kdim, w,
                        lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0, nrider, fillp, fused_used, fstride,
-                       fnb);
-  else if (tiles <= syrk_kg2_limit() && Kdim >= 4 * BK)
+                       fnb, nfull, sp.P, ws);
+  else if (kg == 2)
     hipLaunchKernelGGL((k_syrk_tn<T, MODE, 2>), dim3((unsigned)grid), dim3(2 * NTHREADS), 0, c->stream, A, lda, Kdim, w,
                        lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0, nrider, fillp, fused_used, fstride,
-                       fnb);
+                       fnb, nfull, sp.P, ws);
   else
     hipLaunchKernelGGL((k_syrk_tn<T, MODE, 1>), dim3((unsigned)grid), dim3(NTHREADS), 0, c->stream, A, lda, Kdim, w,
                        lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0, nrider, fillp, fused_used, fstride,
-                       fnb);
+                       fnb, nfull, sp.P, ws);
+  if (npiece) {
+    SyrkBatch<T> b{};
+    b.out[0] = out;
+    b.eta2[0] = eta2;
+    b.Kinv[0] = Kinv;
+    hipLaunchKernelGGL((k_syrk_split_finish<T, MODE>), dim3((unsigned)sp.per_latent, 1), dim3(NTHREADS), 0, c->stream, b, ldo, ldm,
+                       lr, tiles, nfull, sp.P, (const T*)ws);
+  }
   LAUNCHCHK(c);
   return AGP_OK;
 }
@@ -996,17 +1075,7 @@ static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* o
     return syrk_tn<T, SY_STORE>(c, X, ld, n, n, (const T*)nullptr, 1, out, ldo, (T*)nullptr, (const T*)nullptr, (int64_t)0, T(0));
   const int ch = (int)std::max<int64_t>(ch_env ? ch_env : 2, (nt + XTX_MAXU - 1) / XTX_MAXU);  // at most XTX_MAXU units per tile
   const int64_t nunits = xtx_bal_units(nt, ch), ntri = nt * (nt + 1) / 2;
-  const size_t need = sizeof(T) * (size_t)nunits * TILE * TILE;
-  if (c->bal_bytes < need) {
-    if (c->bal_ws) {
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      (void)hipFree(c->bal_ws);
-    }
-    c->bal_ws = nullptr;
-    c->bal_bytes = 0;
-    HIPCHK(c, hipMalloc(&c->bal_ws, need));
-    c->bal_bytes = need;
-  }
+  AGPCHK(ensure_bal_ws(c, sizeof(T) * (size_t)nunits * TILE * TILE));
   T* fillp = nullptr;
   int64_t fused_used = 0, fstride = 0, nfill = 0;
   int fnb = 0;
@@ -3420,13 +3489,23 @@ struct Svgp : SvgpBase {
         nfill = 96;
         ctx->h_dirty[0].on = false;
       }
-      dim3 grid((unsigned)(tiles + nrider + nfill), (unsigned)nl);
-      if (tiles * nl <= kg2_limit() && Bq >= 4 * BK)
+      const bool kg2 = tiles * nl <= kg2_limit() && Bq >= 4 * BK;
+      // tail split over all latents' tiles (syrk_tn_body): every latent cuts its last tiles into k-slices, one more launch finishes
+      const SyrkSplit sp = syrk_split_plan(ctx, kg2 ? (const void*)&k_syrk_eta_batch<T, 2> : (const void*)&k_syrk_eta_batch<T, 1>,
+                                           (kg2 ? 2 : 1) * NTHREADS, tiles, nl, Bq / BkOf<T>::v);
+      const int64_t nfull = tiles - sp.per_latent, npiece = sp.per_latent * sp.P;
+      if (npiece) AGPCHK(ensure_bal_ws(ctx, sizeof(T) * (size_t)npiece * nl * TILE * TILE));
+      T* ws = npiece ? (T*)ctx->bal_ws : (T*)nullptr;
+      dim3 grid((unsigned)(nfull + npiece + nrider + nfill), (unsigned)nl);
+      if (kg2)
         hipLaunchKernelGGL((k_syrk_eta_batch<T, 2>), grid, dim3(2 * NTHREADS), 0, st(), b, mp, Bq, mp, mp, lr, tiles, nrider, fillp,
-                           fused_used, fstride, fnb);
+                           fused_used, fstride, fnb, nfull, sp.P, ws);
       else
         hipLaunchKernelGGL((k_syrk_eta_batch<T, 1>), grid, dim3(NTHREADS), 0, st(), b, mp, Bq, mp, mp, lr, tiles, nrider, fillp,
-                           fused_used, fstride, fnb);
+                           fused_used, fstride, fnb, nfull, sp.P, ws);
+      if (npiece)
+        hipLaunchKernelGGL((k_syrk_split_finish<T, SY_ETA2>), dim3((unsigned)sp.per_latent, (unsigned)nl), dim3(NTHREADS), 0, st(), b,
+                           mp, mp, lr, tiles, nfull, sp.P, (const T*)ws);
       LAUNCHCHK(ctx);
       return AGP_OK;
     }

@@ -154,3 +154,42 @@ def test_balanced_xtx_through_spd_inverse(mods, n, dtype):
         assert abs(ld.value - np.linalg.slogdet(A)[1]) < (1e-9 if dtype == 0 else 1e-3) * max(1.0, abs(ld.value))
     finally:
         L.agp_ctx_destroy(ctx)
+
+
+_SPLIT_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import agp_amd as AGP
+rng = np.random.default_rng(9)
+N, D, m, B, K, iters = 6000, 4, 1024, 1024, 8, 3
+X = rng.random((N, D)); f = np.sin(4 * X[:, 0]) + X[:, 1] - 0.8 * X[:, 2] + 0.5 * X[:, 3]
+y = 1 + np.digitize(f, np.quantile(f, np.linspace(0, 1, K + 1)[1:-1]))
+Z = X[rng.permutation(N)[:m]].copy()
+idx = [rng.choice(N, B, replace=False) for _ in range(iters)]
+k = AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0)
+ma = AGP.SVGP(k, AGP.LogisticSoftMaxLikelihood(K), AGP.AnalyticSVI(B), Z, optimiser=False)
+AGP.train_(ma, X, y, iters, idx_stream=idx)
+out = {{}}
+for q in range(K):
+    mu, Sig, e1, e2 = ma.get_state(q)
+    out[f"e1_{{q}}"] = e1; out[f"e2_{{q}}"] = e2
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_syrk_tail_split_switch_keeps_the_trajectory(mods, tmp_path):
+    """AGP_SYRK_SPLIT=1 (measured, not adopted: DESIGN.md section 12) cuts the remainder tiles of a multi-round symmetric-product
+    launch into k-slices behind the full tiles and finishes them with k_syrk_split_finish.  The C4 shape (8 latents x 136 tiles
+    on 512 slots: 64 tiles in 8 slices) with and without it: eta1, eta2 of every latent agree to rounding."""
+    script = tmp_path / "split.py"
+    script.write_text(_SPLIT_SCRIPT.format(root=ROOT))
+    outs = {}
+    for name, env in [("off", {}), ("on", {"AGP_SYRK_SPLIT": "1"})]:
+        out = tmp_path / f"{name}.npz"
+        r = subprocess.run([sys.executable, str(script), str(out)], env={**os.environ, **env}, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(out)
+    for key in outs["off"].files:
+        assert _rel(outs["on"][key], outs["off"][key]) < 1e-10, key
+    assert any(not np.array_equal(outs["on"][k], outs["off"][k]) for k in outs["off"].files)  # the switch did something

@@ -932,13 +932,14 @@ static int64_t syrk_kg2_limit() {  // (AGP_SYRK_KG2_LIMIT: the symmetric product
   }();
   return v;
 }
-// Tail split of a symmetric-product launch (syrk_tn_body, agp_linalg.h): `tiles` tile workgroups (all latents together) on
-// S = occupancy x CUs slots.  When the launch needs more than one round and the last round would be at most half full, the last
-// `rsplit` tiles (per latent: rsplit / nl) are cut into P k-slices each so that the pieces fill the tail.
-// OFF unless AGP_SYRK_SPLIT=1 (2: also print the plan).  Measured in round 4 and not adopted: at C3 (528 tiles, fp32) the occupancy
-// is 3 x 256 = 768 slots -- one round, the launch's 0.40 of peak is the fp32 tile product itself, not a tail --; at C4 (8 x 136
-// tiles on 512 slots: 64 tiles cut into 8 slices) k_syrk_eta_batch went 380 -> 373 us and the step did not move (1.107 vs 1.140 ms,
-// within the run-to-run spread): next to two look-ahead streams the launch is bound by the chip's MFMA throughput, not by rounds.
+// Tail split of a symmetric-product launch (syrk_tn_body, agp_linalg.h): T tile workgroups (all latents together) on n CUs.
+// Co-resident workgroups share their CU's MFMA pipes, so by the arithmetic a launch is as long as the CU with the most tiles: the
+// remainder R = T mod n of T / n whole rounds is cut into n / R k-slices per tile, one piece per CU, dispatched behind the full tiles.
+// OFF unless AGP_SYRK_SPLIT=1 (2: also print the plan).  Measured in round 4 and NOT adopted: C3 (528 fp32 tiles = 2 rounds + 16
+// tiles in 16 slices) k_syrk_tn<float> 141 -> 144 us plus the finishing launch, step 0.668 -> 0.707 ms; C4 (8 x 136 tiles = 4
+// rounds + 64 tiles in 4 slices) step 1.108 -> 1.131 ms.  Neither launch is bound by its tail: the fp32 product moves 16 flop per
+// operand byte through the L2 (267 MB of fabric traffic at C3) and the C4 launch shares the chip with two look-ahead streams.
+// (A first version counted rounds of occupancy x CUs slots instead of CUs: the same result.)
 struct SyrkSplit {
   int64_t per_latent = 0;  // tiles of every latent that are split
   int P = 1;
@@ -967,13 +968,16 @@ static SyrkSplit syrk_split_plan(agp_ctx* c, const void* kernel, int threads, in
   if (verbose) fprintf(stderr, "[agp] syrk_split_plan: occupancy query %d -> %d per CU, %d CUs, %lld tiles x %d\n", (int)oe, occ,
                        ctx_cus(c), (long long)tiles_per_latent, nl);
   if (oe != hipSuccess || occ <= 0) return sp;
-  const int64_t S = (int64_t)occ * ctx_cus(c), T = tiles_per_latent * nl;
-  if (T <= S) return sp;
-  const int64_t R = T % S;
-  if (R == 0 || 2 * R > S) return sp;
-  const int64_t per = (R + nl - 1) / nl;  // per latent (rounded up: a few more pieces than slots)
+  // The unit that matters is the CU, not the slot: co-resident workgroups share their CU's MFMA pipes, so a launch is as long as the
+  // CU with the most tiles.  T tiles on n CUs: T / n whole rounds of one tile per CU, and the remainder R = T mod n as n / R slices
+  // each -- one piece per CU, dispatched behind the full tiles.  (Slots only matter when a round does not fit into them.)
+  const int64_t ncu = ctx_cus(c), T = tiles_per_latent * nl;
+  if (T <= ncu || T / ncu > (int64_t)occ * 4) return sp;
+  const int64_t R = T % ncu;
+  if (R == 0 || 2 * R > ncu) return sp;
+  const int64_t per = (R + nl - 1) / nl;  // per latent (rounded up: a few more pieces than CUs)
   if (per >= tiles_per_latent) return sp;
-  int64_t P = S / (per * nl);
+  int64_t P = ncu / (per * nl);
   P = std::min<int64_t>(P, std::min<int64_t>(32, nslab / 2));  // at least two slabs per piece
   if (P < 2) return sp;
   sp.per_latent = per;

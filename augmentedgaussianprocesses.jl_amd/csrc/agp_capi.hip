@@ -1064,8 +1064,11 @@ static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_
 // tile starting at its first row, k-groups chosen like everywhere else (it ran with one k-group on 136 tiles: 60 us at m = 1024)
 // Round 4: from 8 block rows on, the balanced form (k_xtx_bal: units of at most ch k-blocks, partial tiles added by the last arriver
 // in unit order): 42 -> ~15 us at m = 1024.  AGP_XTX_BALANCED=0 keeps the one-workgroup-per-tile product; AGP_XTX_CH sets ch.
+// (Dg ...: log det from the diagonal factors rides on the reduction launch; *rider_done says whether it did)
 template <typename T>
-static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* out, int64_t ldo) {
+static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* out, int64_t ldo, const T* Dg = nullptr,
+                             int64_t nvalid = 0, double* ld_out = nullptr, int32_t* status = nullptr, bool* rider_done = nullptr) {
+  if (rider_done) *rider_done = false;
   static const int bal_env = [] {
     const char* e = getenv("AGP_XTX_BALANCED");
     return e ? atoi(e) : 1;
@@ -1101,9 +1104,11 @@ static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* o
   else
     hipLaunchKernelGGL((k_xtx_bal<T, 1>), dim3((unsigned)(nunits + nfill)), dim3(NTHREADS), 0, c->stream, X, ld, n, out, ldo,
                        (T*)c->bal_ws, ch, nunits, fillp, fused_used, fstride, fnb);
-  hipLaunchKernelGGL((k_xtx_bal_reduce<T>), dim3((unsigned)ntri), dim3(NTHREADS), 0, c->stream, n, out, ldo, (const T*)c->bal_ws,
-                     ch);
+  const bool rider = Dg != nullptr && ld_out != nullptr;
+  hipLaunchKernelGGL((k_xtx_bal_reduce<T>), dim3((unsigned)(ntri + (rider ? 1 : 0))), dim3(NTHREADS), 0, c->stream, n, out, ldo,
+                     (const T*)c->bal_ws, ch, Dg, nvalid, ld_out, status);
   LAUNCHCHK(c);
+  if (rider && rider_done) *rider_done = true;
   return AGP_OK;
 }
 
@@ -1444,6 +1449,8 @@ struct Svgp : SvgpBase {
   int hy_krule = AGP_OPT_ADAM, hy_zrule = AGP_OPT_ADAM;  // agp_svgp_hyper_rule: ADAM / Descent / Momentum (opt_rule_delta)
   double hy_krho = 0.0, hy_zrho = 0.0;
   T *hyKap = nullptr, *hyKnm = nullptr;  // kappa (Knm) under the fresh inv(K) (kernel) for the hyper-gradient, AGP_FLAG_STALE_K
+  T* hy_pZ2 = nullptr;
+  double *hy_pvar2 = nullptr, *hy_pscale2 = nullptr;
   T* hy_upart = nullptr;                 // per tile row: partial column sums of kappa' g_mu (k_hyper_hk_tile -> k_hyper_gK_fused)
   T *hyH1 = nullptr, *hyH2 = nullptr, *hyH3 = nullptr, *hy_gmu = nullptr, *hy_gs = nullptr, *hy_muf = nullptr,
     *hy_pZ = nullptr, *hy_dZ = nullptr;
@@ -1859,10 +1866,10 @@ struct Svgp : SvgpBase {
                evarf, stats, Tw, Tw2, tmpv, lr_dev, Kstar, ppm, ppv, pmu, pvar};
     for (T* p : ps)
       if (p) dfree(p);
-    T* hps[] = {hyH1, hyH2, hyH3, hy_gmu, hy_gs, hy_muf, hy_pZ, hy_dZ, hyKap, hyKnm, hy_upart};
+    T* hps[] = {hyH1, hyH2, hyH3, hy_gmu, hy_gs, hy_muf, hy_pZ, hy_dZ, hyKap, hyKnm, hy_upart, hy_pZ2};
     for (T* p : hps)
       if (p) dfree(p);
-    double* hds[] = {hy_pvar, hy_pscale, hy_g, hy_tied};
+    double* hds[] = {hy_pvar, hy_pscale, hy_g, hy_tied, hy_pvar2, hy_pscale2};
     for (double* p : hds)
       if (p) dfree(p);
     for (auto& g : lat) {
@@ -2021,10 +2028,12 @@ struct Svgp : SvgpBase {
         src.kvariance = kvar(g);
         src.kjitter = (T)jitter;
         AGPCHK(potrf_fused<T>(ctx, g.L, mp, mp, g.Xk, mp, g.DgK, (T*)nullptr, 0, 0, 1, infoK_dev, m, (const T*)nullptr, true, &src));
-        AGPCHK(xtx_padded<T>(ctx, g.Xk, mp, mp, g.Kinv, mp));
         if (!logdetK_dev) AGPCHK(dmalloc(ctx, &logdetK_dev, nl));
         const int li = (int)(&g - lat.data());
-        hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.DgK, m, logdetK_dev + li, info_dev);
+        bool ld_done = false;
+        AGPCHK(xtx_padded<T>(ctx, g.Xk, mp, mp, g.Kinv, mp, (const T*)g.DgK, m, logdetK_dev + li, info_dev, &ld_done));
+        if (!ld_done)
+          hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.DgK, m, logdetK_dev + li, info_dev);
         LAUNCHCHK(ctx);
         g.logdet_pending = true;
         if (!refresh_lazy) {
@@ -2669,6 +2678,10 @@ struct Svgp : SvgpBase {
     AGPCHK(dmalloc(ctx, &hy_pvar, tiles));
     AGPCHK(dmalloc(ctx, &hy_pscale, tiles * D));
     AGPCHK(dmalloc(ctx, &hy_g, 1 + D));
+    // second set of partial sums: both backward passes are reduced by ONE launch (k_hyper_reduce2)
+    AGPCHK(dmalloc(ctx, &hy_pZ2, rowt * mp * D));
+    AGPCHK(dmalloc(ctx, &hy_pvar2, tiles));
+    AGPCHK(dmalloc(ctx, &hy_pscale2, tiles * D));
     return AGP_OK;
   }
 
@@ -2702,6 +2715,19 @@ struct Svgp : SvgpBase {
     // is joined before this function returns.
     n_hgrad += 1;
     n_gk_fused += gk_fused ? 1 : 0;
+    // K^-1 mu rides on the mean_f / g_mu / g_sigma launch (k_hyper_muf_gvec) when that launch exists and nothing else needs it first
+    const bool fuse_a = one_product && !mo && !g.pred_valid;
+    struct PredGuard {  // an error return between here and the fused launch must not leave K^-1 mu marked valid
+      bool* flag = nullptr;
+      ~PredGuard() {
+        if (flag) *flag = false;
+      }
+    } pred_guard;
+    if (fuse_a) {
+      if (!g.apred) AGPCHK(dmalloc(ctx, &g.apred, mp));
+      g.pred_valid = true;  // (ensure_pred below then skips its own launch)
+      pred_guard.flag = &g.pred_valid;
+    }
     const bool side = gk_fused && !mo && hy_side_ready();
     if (side) {
       HIPCHK(ctx, hipEventRecord(hy_ev[0], ctx->stream));
@@ -2781,9 +2807,10 @@ struct Svgp : SvgpBase {
       }
       if (one_product) {
         StreamOver so(st_over, side ? hy_side : (hipStream_t) nullptr);
-        hipLaunchKernelGGL((k_hyper_muf_gvec<T>), grid1(B * 64), dim3(256), 0, st(), B, mp, mp, rho, gmode, kap,
-                           (const T*)g.mu, (const T*)(rbuf + l * Bp), (const T*)(theta + l * Bp), (const T*)y_last, idx_last,
-                           hy_muf, hy_gmu, hy_gs);
+        hipLaunchKernelGGL((k_hyper_muf_gvec<T>), grid1((B + (fuse_a ? mp : 0)) * 64), dim3(256), 0, st(), B, mp, mp, rho, gmode,
+                           kap, (const T*)g.mu, (const T*)(rbuf + l * Bp), (const T*)(theta + l * Bp), (const T*)y_last, idx_last,
+                           hy_muf, hy_gmu, hy_gs, fuse_a ? (const T*)g.Kinv : (const T*)nullptr, g.apred);
+        pred_guard.flag = nullptr;  // K^-1 mu is enqueued
       } else
         hipLaunchKernelGGL((k_hyper_gvec<T>), grid1(B), dim3(256), 0, st(), B, rho, gmode, (const T*)(rbuf + l * Bp),
                            (const T*)(theta + l * Bp), (const T*)hy_muf, (const T*)y_last, idx_last, (const T*)pw0,
@@ -2844,7 +2871,11 @@ struct Svgp : SvgpBase {
     }
     tw2_kis_of = -1;
     // backward through kernelmatrix(k, x, Z)  (gradient w.r.t. the second argument); its reduction initialises the gradient and
-    // adds the kdiag term of the variance (rho sum_i g_sigma,i), which used to be a memset in front and a kernel behind
+    // adds the kdiag term of the variance (rho sum_i g_sigma,i), which used to be a memset in front and a kernel behind.  Unless the
+    // streaming model's extra passes follow, the reductions of both backward passes are ONE launch behind the second pass
+    // (k_hyper_reduce2, second set of partial sums).
+    const bool online_x = g.on && !g.on_first;
+    const bool one_reduce = !online_x;
     {
       StreamOver so(st_over, side ? hy_side : (hipStream_t) nullptr);
       dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
@@ -2852,15 +2883,15 @@ struct Svgp : SvgpBase {
       hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)x_last, ldx_last, idx_last, B,
                          (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, kvar(g), (const T*)hyH3, mp,
                          hy_pvar, hy_pscale, hy_pZ, mp);
-      hipLaunchKernelGGL((k_hyper_reduce<T>), dim3((unsigned)(D + 1 + (m * D + 255) / 256)), dim3(256), 0, st(), tiles, D,
-                         (const double*)hy_pvar, (const double*)hy_pscale, hy_g, 1.0, 1, (int64_t)gk.y, m, mp, (const T*)hy_pZ, hy_dZ,
-                         T(1), (const T*)hy_gs, B, (double)rho);
+      if (!one_reduce)
+        hipLaunchKernelGGL((k_hyper_reduce<T>), dim3((unsigned)(D + 1 + (m * D + 255) / 256)), dim3(256), 0, st(), tiles, D,
+                           (const double*)hy_pvar, (const double*)hy_pscale, hy_g, 1.0, 1, (int64_t)gk.y, m, mp, (const T*)hy_pZ,
+                           hy_dZ, T(1), (const T*)hy_gs, B, (double)rho);
     }
     if (side) {  // join: the second backward pass reuses the partial-sum buffers and accumulates into the gradient
       HIPCHK(ctx, hipEventRecord(hy_ev[3], hy_side));
       HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, hy_ev[3], 0));
     }
-    const bool online_x = g.on && !g.on_first;
     if (online_x && bs_world > 1) {
       ctx->err = "hyper-gradient of a streaming (online) model on a batch-sharded handle is not wired";
       return AGP_ERR_UNSUPPORTED;
@@ -2905,10 +2936,16 @@ struct Svgp : SvgpBase {
       const int64_t tiles = (int64_t)gk.x * gk.y;
       hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)g.Z, D, (const int64_t*)nullptr,
                          m, (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, kvar(g), (const T*)Tw2, mp,
-                         hy_pvar, hy_pscale, hy_pZ, mp);
-      hipLaunchKernelGGL((k_hyper_reduce<T>), dim3((unsigned)(D + 1 + (m * D + 255) / 256)), dim3(256), 0, st(), tiles, D,
-                         (const double*)hy_pvar, (const double*)hy_pscale, hy_g, 1.0, 0, (int64_t)gk.y, m, mp, (const T*)hy_pZ, hy_dZ,
-                         T(2), (const T*)nullptr, (int64_t)0, 0.0);
+                         one_reduce ? hy_pvar2 : hy_pvar, one_reduce ? hy_pscale2 : hy_pscale, one_reduce ? hy_pZ2 : hy_pZ, mp);
+      if (one_reduce)
+        hipLaunchKernelGGL((k_hyper_reduce2<T>), dim3((unsigned)(D + 1 + (m * D + 255) / 256)), dim3(256), 0, st(), D, hy_g, m, mp,
+                           hy_dZ, (int64_t)(mp / TILE) * (Bq / TILE), (const double*)hy_pvar, (const double*)hy_pscale,
+                           (int64_t)(Bq / TILE), (const T*)hy_pZ, tiles, (const double*)hy_pvar2, (const double*)hy_pscale2,
+                           (int64_t)gk.y, (const T*)hy_pZ2, (const T*)hy_gs, B, (double)rho);
+      else
+        hipLaunchKernelGGL((k_hyper_reduce<T>), dim3((unsigned)(D + 1 + (m * D + 255) / 256)), dim3(256), 0, st(), tiles, D,
+                           (const double*)hy_pvar, (const double*)hy_pscale, hy_g, 1.0, 0, (int64_t)gk.y, m, mp, (const T*)hy_pZ,
+                           hy_dZ, T(2), (const T*)nullptr, (int64_t)0, 0.0);
     }
     if (online_x) {
       // K_ab = k(Z_a, Z): gradient w.r.t. the kernel parameters and the second argument ; K_a = k(Z_a, Z_a): parameters only

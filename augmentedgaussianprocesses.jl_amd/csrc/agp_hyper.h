@@ -174,14 +174,24 @@ __global__ void k_hyper_gK_fused(int64_t m, int64_t mp, const T* __restrict__ TM
 }
 
 // mean_f = kappa mu (one wave per row) and, in the same launch, k_hyper_gvec's modes 0 - 2 from it
+// (Kinv != nullptr: waves B .. B + cols - 1 also form a = K^-1 mu, the symmetric mat-vec that was a launch of its own in front)
 template <typename T>
 __global__ void k_hyper_muf_gvec(int64_t B, int64_t cols, int64_t ld, T rho, int mode, const T* __restrict__ kappa,
                                  const T* __restrict__ mu, const T* __restrict__ r, const T* __restrict__ theta,
                                  const T* __restrict__ y, const int64_t* __restrict__ idx, T* __restrict__ muf,
-                                 T* __restrict__ gmu, T* __restrict__ gs) {
+                                 T* __restrict__ gmu, T* __restrict__ gs, const T* __restrict__ Kinv = nullptr,
+                                 T* __restrict__ a_out = nullptr) {
   const int64_t i = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (i >= B) return;
+  if (i >= B) {
+    const int64_t q = i - B;
+    if (!Kinv || q >= cols) return;
+    T s = T(0);
+    for (int64_t k = lane; k < cols; k += 64) s += Kinv[q * ld + k] * mu[k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0) a_out[q] = s;
+    return;
+  }
   T s = T(0);
   for (int64_t k = lane; k < cols; k += 64) s += kappa[i * ld + k] * mu[k];
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
@@ -513,6 +523,42 @@ __global__ void k_hyper_reduce(int64_t ntiles, int64_t D, const double* __restri
   T s = T(0);
   for (int64_t b = 0; b < nrowtiles; ++b) s += pZ[(b * p_pad + j) * D + d];
   dZ[e] = (init ? T(0) : dZ[e]) + wgtZ * s;
+}
+
+// The reductions behind BOTH backward passes of a gradient evaluation in one launch (round 4): set 1 = the pass through K_nm (weight
+// 1 on the scalars and on Z, + the kdiag term of the variance), set 2 = the pass through K_ZZ (weight 1 on the scalars, 2 on Z: both
+// arguments are Z and G_K is symmetric).  Same per-set summation order as two k_hyper_reduce launches (init = 1, then init = 0).
+template <typename T>
+__global__ void k_hyper_reduce2(int64_t D, double* __restrict__ out, int64_t p, int64_t p_pad, T* __restrict__ dZ, int64_t ntiles1,
+                                const double* __restrict__ pvar1, const double* __restrict__ pscale1, int64_t nrow1,
+                                const T* __restrict__ pZ1, int64_t ntiles2, const double* __restrict__ pvar2,
+                                const double* __restrict__ pscale2, int64_t nrow2, const T* __restrict__ pZ2,
+                                const T* __restrict__ xkd, int64_t Bkd, double wgt_kd) {
+  if ((int64_t)blockIdx.x <= D) {
+    __shared__ double red[16];
+    const int d = blockIdx.x;  // 0: variance, 1..D: scales
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t t = threadIdx.x; t < ntiles1; t += blockDim.x) s1 += (d == 0) ? pvar1[t] : pscale1[t * D + d - 1];
+    s1 = block_sum<double>(s1, red);
+    for (int64_t t = threadIdx.x; t < ntiles2; t += blockDim.x) s2 += (d == 0) ? pvar2[t] : pscale2[t * D + d - 1];
+    s2 = block_sum<double>(s2, red);
+    double extra = 0.0;
+    if (d == 0 && xkd) {
+      double q = 0.0;
+      for (int64_t i = threadIdx.x; i < Bkd; i += blockDim.x) q += (double)xkd[i];
+      extra = wgt_kd * block_sum<double>(q, red);
+    }
+    if (threadIdx.x == 0) out[d] = ((0.0 + 1.0 * s1 + extra)) + 1.0 * s2;
+    return;
+  }
+  if (!dZ) return;
+  const int64_t e = ((int64_t)blockIdx.x - (D + 1)) * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= p * D) return;
+  const int64_t j = e / D, d = e % D;
+  T a = T(0), b = T(0);
+  for (int64_t r = 0; r < nrow1; ++r) a += pZ1[(r * p_pad + j) * D + d];
+  for (int64_t r = 0; r < nrow2; ++r) b += pZ2[(r * p_pad + j) * D + d];
+  dZ[e] = (T(0) + T(1) * a) + T(2) * b;
 }
 
 // tied-Z mode: gradients of several latents are summed (and all-reduced across ranks) in double

@@ -329,10 +329,27 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_xtx_bal(const T* __restrict__
 // second launch: one workgroup per lower tile (row-major triangle order); tiles of one unit are done already.  All partial values
 // of an element are fetched side by side (a loop of dependent loads per element made this launch slower than the product)
 constexpr int XTX_MAXU = 8;  // units per tile the reduction is written for (the host picks ch so that nt / ch <= 8)
+// (Dg != nullptr: one more workgroup, blockIdx.x = nt (nt + 1) / 2, is k_logdiag_sum -- log det from the diagonal factors, with the
+//  failure-order word of the K_ZZ refresh --, a launch of its own behind the refresh until round 4)
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void k_xtx_bal_reduce(int64_t n, T* __restrict__ out, int64_t ldo,
-                                                             const T* __restrict__ ws, int ch) {
+                                                             const T* __restrict__ ws, int ch, const T* __restrict__ Dg = nullptr,
+                                                             int64_t nvalid = 0, double* __restrict__ ld_out = nullptr,
+                                                             int32_t* __restrict__ status = nullptr) {
   const int64_t nt = n / TILE;
+  if ((int64_t)blockIdx.x >= nt * (nt + 1) / 2) {
+    __shared__ double red[16];
+    double s = 0.0;
+    if (Dg)
+      for (int64_t i = threadIdx.x; i < nvalid; i += blockDim.x)
+        s += log((double)Dg[(i / TILE) * TILE * TILE + (i % TILE) * (TILE + 1)]);
+    s = block_sum<double>(s, red);
+    if (Dg && threadIdx.x == 0) {
+      ld_out[0] = s;
+      if (status && status[1] != 0 && status[3] == 0) status[3] = (status[0] != 0 || status[2] != 0) ? 2 : 1;
+    }
+    return;
+  }
   int64_t ta, tb;
   tri_index(blockIdx.x, ta, tb);
   const int nu = (int)((nt - ta + ch - 1) / ch);

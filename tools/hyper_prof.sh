@@ -6,4 +6,6 @@ rm -rf /tmp/ph_$T
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ph_$T -o p -- python $R/tools/prof_hyper.py > /dev/null 2>&1)
 f=$(find /tmp/ph_$T -name "*kernel_trace.csv" | head -1)
 python $R/tools/hyper_timeline.py $f > $R/gpurun_out/hyper_tl_$T.txt 2>&1
+python $R/tools/hyper_seq_check.py $f >> $R/gpurun_out/hyper_tl_$T.txt 2>&1
+cp $(find /tmp/ph_$T -name "*kernel_stats.csv" | head -1) $R/gpurun_out/hyper_stats_$T.csv
 cat $R/gpurun_out/hyper_tl_$T.txt

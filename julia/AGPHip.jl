@@ -411,6 +411,18 @@ function update_hyperparameters!(hm::HipModel; tied::Bool=false)
 end
 
 """
+    hyper_counters(hm) -> (gradients, gradients_with_one_product_G_K)
+
+Diagnostics of the hyper-parameter iteration (`agp_svgp_hyper_counters`, round 4): how many hyper-gradients this handle has
+evaluated, and how many of them formed `G_K` from one m^3 product (DESIGN.md section 6) instead of `kappa' H` and `K^-1 Sigma K^-1`.
+"""
+function hyper_counters(hm::HipModel)
+    ng = Ref{Int64}(0); nf = Ref{Int64}(0)
+    check(hm.ctx, ccall((:agp_svgp_hyper_counters, libagp), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), hm.h, ng, nf))
+    return ng[], nf[]
+end
+
+"""
     train!(hm::HipModel, X, y, iterations=100; callback=nothing, state=nothing, obsdim=1, idx_stream=nothing)
 
 `train!` of the reference (src/training/training.jl:13-111) with the step on the device: same checks, same ρ = N/B, same

@@ -1420,6 +1420,10 @@ struct Svgp : SvgpBase {
     // La holds: 0 = -2*eta2 (unfactored), 1 = its Cholesky factor ; xa_valid: Xa = La^-1 is current
     int la_state = 0;
     bool xa_valid = false;
+    // v = Xa eta1 formed by materialize() next to mu belongs to the inverse with this number (aug_factor counts them): a step that
+    // takes W, v from the inverse uses it instead of launching the triangular mat-vec itself
+    int64_t xa_epoch = 0, v_epoch = -1;
+    bool v_ready = false;
     double half_logdetK = 0.0;
     bool logdet_pending = false;  // half_logdetK still sits in logdetK_dev (asynchronous K refresh)
     // AGP_FLAG_STALE_K: the step-side copies of (inv(K), L^-1, K\mu0, logdet K) frozen at the first hyper step of a train! --
@@ -2382,11 +2386,14 @@ struct Svgp : SvgpBase {
       if (g.via_inverse) {
         AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.kappa, mp, g.Xa, mp, Bq, mp, mp, 1, g.Wbuf, mp, nullptr, 0, nullptr, nullptr,
                                       nullptr, 0)));
-        hipLaunchKernelGGL((k_trmv_lower<T>), grid1(mp * 64), dim3(256), 0, st(), (const T*)g.Xa, mp, mp, (const T*)g.eta1,
-                           g.Wbuf + Bq * mp);
+        g.v_ready = g.v_epoch == g.xa_epoch;  // materialize() left v = Xa eta1 of this very inverse in g.v
+        if (!g.v_ready)
+          hipLaunchKernelGGL((k_trmv_lower<T>), grid1(mp * 64), dim3(256), 0, st(), (const T*)g.Xa, mp, mp, (const T*)g.eta1,
+                             g.Wbuf + Bq * mp);
         LAUNCHCHK(ctx);
         continue;
       }
+      g.v_ready = false;
       // pre-factorisation part of aug_factor: -2*eta2 back into La if it holds a factor, extension rows [eta1' ; 0]
       if (g.la_state != 0 && !use_pro) {  // (with the prologue, -2 eta2 is formed inside the launch and never stored)
         hipLaunchKernelGGL((k_copy2d<T>), grid2(mp, mp), blk2, 0, st(), (const T*)g.eta2, mp, mp, mp, g.La, mp, mp, mp,
@@ -2533,7 +2540,7 @@ struct Svgp : SvgpBase {
         Latent& g = lat[l0 + q];
         rb.pk[q] = g.pk;
         rb.W[q] = g.Wbuf;
-        rb.v[q] = g.Wbuf + Bq * mp;
+        rb.v[q] = (g.via_inverse && g.v_ready) ? g.v : g.Wbuf + Bq * mp;
         rb.kdiag[q] = kvar(g);
         rb.kd_ptr[q] = g.scales + D;
         rb.use_kt[q] = g.keep_last ? 1 : 0;
@@ -2665,8 +2672,9 @@ struct Svgp : SvgpBase {
       ctx->err = "hyper-gradient: input dimension above HB_MAXD";
       return AGP_ERR_UNSUPPORTED;
     }
-    const int64_t tiles = std::max((Bp / TILE) * (mp / TILE), (mp / TILE) * (mp / TILE));
-    const int64_t rowt = std::max(Bp / TILE, mp / TILE);
+    // (partial sums per RT x 64 tile of a backward pass: k_kernel_backward, HB_RT rows per workgroup)
+    const int64_t tiles = std::max((Bp / HB_RT) * (mp / TILE), (mp / HB_RT) * (mp / TILE));
+    const int64_t rowt = std::max(Bp / HB_RT, mp / HB_RT);
     AGPCHK(dmalloc(ctx, &hyH1, Bp * mp));
     AGPCHK(dmalloc(ctx, &hyH2, Bp * mp));
     AGPCHK(dmalloc(ctx, &hyH3, Bp * mp));
@@ -2878,7 +2886,7 @@ struct Svgp : SvgpBase {
     const bool one_reduce = !online_x;
     {
       StreamOver so(st_over, side ? hy_side : (hipStream_t) nullptr);
-      dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / TILE));
+      dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / HB_RT));
       const int64_t tiles = (int64_t)gk.x * gk.y;
       hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)x_last, ldx_last, idx_last, B,
                          (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, kvar(g), (const T*)hyH3, mp,
@@ -2932,15 +2940,15 @@ struct Svgp : SvgpBase {
     }
     // backward through kernelmatrix(k, Z) : both arguments are Z and G_K is symmetric -> twice the second-argument part
     {
-      dim3 gk((unsigned)(mp / TILE), (unsigned)(mp / TILE));
+      dim3 gk((unsigned)(mp / TILE), (unsigned)(mp / HB_RT));
       const int64_t tiles = (int64_t)gk.x * gk.y;
       hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)g.Z, D, (const int64_t*)nullptr,
                          m, (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, kvar(g), (const T*)Tw2, mp,
                          one_reduce ? hy_pvar2 : hy_pvar, one_reduce ? hy_pscale2 : hy_pscale, one_reduce ? hy_pZ2 : hy_pZ, mp);
       if (one_reduce)
         hipLaunchKernelGGL((k_hyper_reduce2<T>), dim3((unsigned)(D + 1 + (m * D + 255) / 256)), dim3(256), 0, st(), D, hy_g, m, mp,
-                           hy_dZ, (int64_t)(mp / TILE) * (Bq / TILE), (const double*)hy_pvar, (const double*)hy_pscale,
-                           (int64_t)(Bq / TILE), (const T*)hy_pZ, tiles, (const double*)hy_pvar2, (const double*)hy_pscale2,
+                           hy_dZ, (int64_t)(mp / TILE) * (Bq / HB_RT), (const double*)hy_pvar, (const double*)hy_pscale,
+                           (int64_t)(Bq / HB_RT), (const T*)hy_pZ, tiles, (const double*)hy_pvar2, (const double*)hy_pscale2,
                            (int64_t)gk.y, (const T*)hy_pZ2, (const T*)hy_gs, B, (double)rho);
       else
         hipLaunchKernelGGL((k_hyper_reduce<T>), dim3((unsigned)(D + 1 + (m * D + 255) / 256)), dim3(256), 0, st(), tiles, D,
@@ -2950,7 +2958,7 @@ struct Svgp : SvgpBase {
     if (online_x) {
       // K_ab = k(Z_a, Z): gradient w.r.t. the kernel parameters and the second argument ; K_a = k(Z_a, Z_a): parameters only
       const int64_t map = g.map, ma = g.ma;
-      dim3 gk((unsigned)(mp / TILE), (unsigned)(map / TILE));
+      dim3 gk((unsigned)(mp / TILE), (unsigned)(map / HB_RT));
       hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
                          (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, kvar(g), (const T*)g.oh1, mp, hy_pvar,
                          hy_pscale, hy_pZ, mp);
@@ -2958,7 +2966,7 @@ struct Svgp : SvgpBase {
                          (const double*)hy_pvar, (const double*)hy_pscale, hy_g, 1.0);
       hipLaunchKernelGGL((k_hyper_reduce_Z<T>), grid1(m * D), dim3(256), 0, st(), (int64_t)gk.y, m, mp, D, (const T*)hy_pZ,
                          hy_dZ, T(1), 1);
-      dim3 ga((unsigned)(map / TILE), (unsigned)(map / TILE));
+      dim3 ga((unsigned)(map / TILE), (unsigned)(map / HB_RT));
       hipLaunchKernelGGL((k_kernel_backward<T>), ga, dim3(NTHREADS), 0, st(), (const T*)g.Za, D, (const int64_t*)nullptr, ma,
                          (const T*)g.Za, D, ma, D, (const T*)g.scales, g.k.kind, kvar(g), (const T*)g.invDa, map,
                          hy_pvar, hy_pscale, hy_pZ, map);
@@ -3643,6 +3651,7 @@ struct Svgp : SvgpBase {
     AGPCHK(timing_end(chol_use_dag(ctx, mp / TILE, Bq / TILE + 1) ? 1 : chol_launch_count(mp / TILE, Bq / TILE + 1)));
     g.la_state = 1;
     g.xa_valid = with_x != 0;
+    if (with_x) g.xa_epoch += 1;
     return AGP_OK;
   }
 
@@ -3762,8 +3771,10 @@ struct Svgp : SvgpBase {
     AGPCHK(xtx_padded<T>(ctx, g.Xa, mp, mp, g.Sigma, mp));
     // mu = Sigma eta1 as the reference writes it (global_update!, analyticVI.jl:229-246).  Until round 4 this was Xa' (Xa eta1) from
     // the factorisation's [eta1'] row: a copy and a 16-workgroup triangular mat-vec (4.8 + 15.6 us at m = 1024 against 7.0)
-    hipLaunchKernelGGL((k_symv<T>), grid1(mp * 64), dim3(256), 0, st(), (const T*)g.Sigma, mp, mp, (const T*)g.eta1, g.mu);
+    hipLaunchKernelGGL((k_symv_trmv<T>), grid1(2 * mp * 64), dim3(256), 0, st(), (const T*)g.Sigma, (const T*)g.Xa, mp, mp,
+                       (const T*)g.eta1, g.mu, g.v);
     LAUNCHCHK(ctx);
+    g.v_epoch = g.xa_epoch;
     g.post_valid = true;
     return AGP_OK;
   }

@@ -314,11 +314,16 @@ __device__ __forceinline__ void kernel_base_dbase(int kind, T d2, T& base, T& db
 //   dscale_d += (2/s_d) sum_ij c_ij t_ijd^2         c = G * variance * phi'(d2) ,  t = s_d (x_d - z_d)
 //   dZ[j][d] += -2 s_d sum_i c_ij t_ijd               (gradient w.r.t. the SECOND argument z_j)
 // Partials (deterministic two-stage reduction):  pvar[tile], pscale[tile][D], pZ[tile row][p][D].
-// grid = (ceil(p/64), ceil(n/64)).  D <= HB_MAXD.
+// grid = (ceil(p/64), ceil(n/RT)) (RT rows of X per workgroup, see below).  D <= HB_MAXD.
 // ---------------------------------------------------------------------------------------------------
 constexpr int HB_MAXD = 64;
 
-template <typename T>
+// RT: rows of X per workgroup (the tile is RT x 64), grid = (ceil(p / 64), ceil(n / RT)).  RT = 32 -- twice the workgroups, two per
+// CU, for a launch that looked bound by the latency of its phases at one wave per SIMD -- was measured in round 4: 23.6 + 20.0 ->
+// 21.6 + 19.5 us for the two passes at m = B = 1024, and the reduction behind them 10.0 -> 17.7 us (twice the partial sums): the
+// pass is bound by its LDS traffic (nine ds_read per row of C in pass 2), not by occupancy.  64 it stays.
+constexpr int HB_RT = 64;
+template <typename T, int RT = HB_RT>
 __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restrict__ X, int64_t ldx,
                                                               const int64_t* __restrict__ idx, int64_t n,
                                                               const T* __restrict__ Y, int64_t ldy, int64_t p, int64_t D,
@@ -327,28 +332,30 @@ __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restric
                                                               double* __restrict__ pvar, double* __restrict__ pscale,
                                                               T* __restrict__ pZ, int64_t p_pad) {
   if (variance < T(0)) variance = scales[D];  // device-resident kernel parameters (see k_kernelmatrix)
-  __shared__ T xs[TILE][KM_DC + 1];
+  static_assert(RT == 32 || RT == 64, "k_kernel_backward: 32 or 64 rows per workgroup");
+  constexpr int NA = RT / 16;  // row groups of 16 per thread
+  __shared__ T xs[RT][KM_DC + 1];
   __shared__ T ys[TILE][KM_DC + 1];
-  __shared__ T Cs[TILE][TILE + 1];  // c_ij of the tile (pass 2 contracts it against the staged coordinates)
-  __shared__ T rows[TILE];
+  __shared__ T Cs[RT][TILE + 1];  // c_ij of the tile (pass 2 contracts it against the staged coordinates)
+  __shared__ T rows[RT];
   __shared__ double red[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ty = tid >> 4, tx = tid & 15;
-  const int64_t i0 = blockIdx.y * (int64_t)TILE, j0 = blockIdx.x * (int64_t)TILE;
+  const int64_t i0 = blockIdx.y * (int64_t)RT, j0 = blockIdx.x * (int64_t)TILE;
   const int64_t tile = blockIdx.y * (int64_t)gridDim.x + blockIdx.x;
-  T acc[4][4];
+  T acc[NA][4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = T(0);
   // a thread stages one dimension of NST rows; the row indices are resolved once (the gather's index loads used to sit in front of
   // every coordinate load: at one wave per SIMD the two dependent round trips per element were most of the kernel's time)
-  constexpr int NST = TILE * KM_DC / NTHREADS;
-  static_assert(NTHREADS % KM_DC == 0 && TILE * KM_DC % NTHREADS == 0, "k_kernel_backward: staging layout");
+  constexpr int NST = TILE * KM_DC / NTHREADS, NSX = RT * KM_DC / NTHREADS;
+  static_assert(NTHREADS % KM_DC == 0 && TILE * KM_DC % NTHREADS == 0 && RT * KM_DC % NTHREADS == 0, "k_kernel_backward: staging layout");
   const int sd = tid % KM_DC, sr0 = tid / KM_DC;
-  int64_t xrow[NST];
+  int64_t xrow[NSX];
 #pragma unroll
-  for (int q = 0; q < NST; ++q) {
+  for (int q = 0; q < NSX; ++q) {
     const int64_t gi = i0 + sr0 + q * (NTHREADS / KM_DC);
     xrow[q] = gi < n ? (idx ? idx[gi] : gi) : (int64_t)-1;
   }
@@ -356,19 +363,18 @@ __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restric
     const int64_t gd = d0 + sd;
     const bool dok = gd < D;
     const T sc = (scales && dok) ? scales[gd] : T(1);
-    T xv[NST], yv[NST];
+    T xv[NSX], yv[NST];
+#pragma unroll
+    for (int q = 0; q < NSX; ++q) xv[q] = (dok && xrow[q] >= 0) ? X[xrow[q] * ldx + gd] : T(0);
 #pragma unroll
     for (int q = 0; q < NST; ++q) {
       const int64_t gj = j0 + sr0 + q * (NTHREADS / KM_DC);
-      xv[q] = (dok && xrow[q] >= 0) ? X[xrow[q] * ldx + gd] : T(0);
       yv[q] = (dok && gj < p) ? Y[gj * ldy + gd] : T(0);
     }
 #pragma unroll
-    for (int q = 0; q < NST; ++q) {
-      const int r = sr0 + q * (NTHREADS / KM_DC);
-      xs[r][sd] = xv[q] * sc;
-      ys[r][sd] = yv[q] * sc;
-    }
+    for (int q = 0; q < NSX; ++q) xs[sr0 + q * (NTHREADS / KM_DC)][sd] = xv[q] * sc;
+#pragma unroll
+    for (int q = 0; q < NST; ++q) ys[sr0 + q * (NTHREADS / KM_DC)][sd] = yv[q] * sc;
   };
   // pass 1: squared distances
   for (int64_t d0 = 0; d0 < D; d0 += KM_DC) {
@@ -376,13 +382,13 @@ __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restric
     __syncthreads();
 #pragma unroll 8
     for (int d = 0; d < KM_DC; ++d) {
-      T xv[4], yv[4];
+      T xv[NA], yv[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) xv[a] = xs[ty + 16 * a][d];
+      for (int a = 0; a < NA; ++a) xv[a] = xs[ty + 16 * a][d];
 #pragma unroll
       for (int b = 0; b < 4; ++b) yv[b] = ys[tx + 16 * b][d];
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           T df = xv[a] - yv[b];
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restric
   // c_ij = G_ij * variance * phi'(d2) ; dvar partial
   double dv = 0.0;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       int64_t gi = i0 + ty + 16 * a, gj = j0 + tx + 16 * b;
@@ -412,11 +418,11 @@ __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restric
   //   sum_ij c_ij t_ijd^2     = sum_i rowsum_i xs_id^2 - 2 sum_j ys_jd (C'xs)_jd + sum_j colsum_j ys_jd^2   (combined in double)
   // thread (j = lane, dg = wave) owns (C'xs)_{j, 8 dg .. 8 dg + 7} of the staged chunk.
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) Cs[ty + 16 * a][tx + 16 * b] = acc[a][b];
   __syncthreads();
-  if (tid < TILE) {
+  if (tid < RT) {
     T s = T(0);
 #pragma unroll 8
     for (int j = 0; j < TILE; ++j) s += Cs[tid][j];
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restric
   }
   T cols = T(0);
 #pragma unroll 8
-  for (int i = 0; i < TILE; ++i) cols += Cs[i][lane];
+  for (int i = 0; i < RT; ++i) cols += Cs[i][lane];
   constexpr int DPT = KM_DC / 4;  // dimensions per thread
   for (int64_t d0 = 0; d0 < D; d0 += KM_DC) {
     if (D > KM_DC) {  // (one chunk: pass 1 left it staged)
@@ -436,18 +442,19 @@ __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restric
 #pragma unroll
     for (int q = 0; q < DPT; ++q) zs[q] = T(0);
 #pragma unroll 4
-    for (int i = 0; i < TILE; ++i) {
+    for (int i = 0; i < RT; ++i) {
       const T c = Cs[i][lane];
 #pragma unroll
       for (int q = 0; q < DPT; ++q) zs[q] += c * xs[i][wave * DPT + q];
     }
-    const T rw = rows[lane];
+    const bool rl = lane < RT;  // the row-sum term lives on the tile's RT rows
+    const T rw = rl ? rows[lane] : T(0);
 #pragma unroll
     for (int q = 0; q < DPT; ++q) {
       const int d = wave * DPT + q;
       const int64_t gd = d0 + d, gj = j0 + lane;
       const T sc = (scales && gd < D) ? scales[gd] : T(1);
-      const double xv = (double)xs[lane][d], yv = (double)ys[lane][d];
+      const double xv = rl ? (double)xs[lane][d] : 0.0, yv = (double)ys[lane][d];
       double ss = (double)rw * xv * xv - 2.0 * yv * (double)zs[q] + (double)cols * yv * yv;
       for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
       if (gd < D) {

@@ -517,6 +517,25 @@ __global__ void k_trmv_lower(const T* __restrict__ X, int64_t ld, int64_t n, con
   if (lane == 0) y[row] = s;
 }
 
+// ys = S x for symmetric dense S (waves 0 .. n - 1, like k_symv) and yt = X x for lower-triangular X (waves n .. 2 n - 1, like
+// k_trmv_lower) in ONE launch: mu = Sigma eta1 and v = Xa eta1 behind a factorisation with its inverse (materialize), so that the
+// next step with that inverse finds v ready instead of launching k_trmv_lower itself
+template <typename T>
+__global__ void k_symv_trmv(const T* __restrict__ S, const T* __restrict__ X, int64_t ld, int64_t n, const T* __restrict__ x,
+                            T* __restrict__ ys, T* __restrict__ yt) {
+  const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (w >= 2 * n) return;
+  const bool tri = w >= n;
+  const int64_t row = tri ? w - n : w;
+  const T* M = tri ? X : S;
+  const int64_t kend = tri ? row + 1 : n;
+  T s = T(0);
+  for (int64_t k = lane; k < kend; k += 64) s += M[row * ld + k] * x[k];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if (lane == 0) (tri ? yt : ys)[row] = s;
+}
+
 // y[j] = sum_{k >= j} X[k][j] x[k]   (transpose of the above: mu = X' v).  One workgroup per 64 columns, 16 row groups of
 // 64 lanes (coalesced 512-byte rows); the 16 partial sums are combined in a fixed order through LDS.  blockDim = 1024.
 template <typename T>

@@ -2865,7 +2865,8 @@ struct Svgp : SvgpBase {
     if (gk_fused) {
       AGPCHK((gemm_nt<T, EPI_STORE>(ctx, g.Cmat, mp, Tw2, mp, mp, mp, mp, 0, Tw, mp, nullptr, 0, nullptr, nullptr, nullptr,
                                     0)));  // C (K^-1 Sigma)' = C Sigma K^-1
-      hipLaunchKernelGGL((k_hyper_gK_fused<T>), grid2(mp, mp), blk2, 0, st(), m, mp, (const T*)Tw, (const T*)g.Cmat,
+      hipLaunchKernelGGL((k_hyper_gK_fused<T>), dim3((unsigned)(mp / 32), (unsigned)(mp / 32)), dim3(256), 0, st(), m, mp,
+                         (const T*)Tw, (const T*)g.Cmat,
                          (const T*)g.Kinv, (const T*)g.apred, (const T*)g.kinv_mu0, (const T*)hy_upart, (int)(Bq / TILE), mp, rho,
                          Tw2);
     } else {

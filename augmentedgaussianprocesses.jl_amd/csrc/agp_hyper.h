@@ -139,38 +139,46 @@ __global__ __launch_bounds__(256) void k_hyper_hk_tile(int64_t B, int64_t ld, T 
 //   G_K = -1/2 sym2(kappa' H) - 1/2 (K^-1 - K^-1 M) + 1/2 at at'
 //       = TM + TM' - C - K^-1/4 - rho/2 (u a' + a u') + 1/2 at at' ,   TM = C M
 // instead of the two products kappa' H (2 B m^2) and K^-1 (Sigma K^-1).  Valid m x m block; zero in the padding.
+// 32 x 32 output tiles, 256 threads (32 x 8): the transposed tile of TM travels through LDS (read directly, TM[j][i] cost the
+// launch 4 us of 32-byte segments); grid = (mp / 32, mp / 32).
 template <typename T>
-__global__ void k_hyper_gK_fused(int64_t m, int64_t mp, const T* __restrict__ TM, const T* __restrict__ C,
-                                 const T* __restrict__ Kinv, const T* __restrict__ a, const T* __restrict__ a2,
-                                 const T* __restrict__ upart, int nchunk, int64_t ldu, T rho, T* __restrict__ out) {
-  __shared__ T ui[16], uj[16], up[8][32];
-  const int64_t i = blockIdx.y * (int64_t)blockDim.y + threadIdx.y;
-  const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const int t = threadIdx.y * 16 + threadIdx.x;
-  {  // u of the block's 16 rows and 16 columns: eight threads per entry fetch the tile-row partials side by side (a single thread
-     // walking all of them was 10 us of dependent loads), added in a fixed order
-    const int el = t & 31, cg = t >> 5;
-    const int64_t e = el < 16 ? blockIdx.y * (int64_t)16 + el : blockIdx.x * (int64_t)16 + (el - 16);
+__global__ __launch_bounds__(256) void k_hyper_gK_fused(int64_t m, int64_t mp, const T* __restrict__ TM, const T* __restrict__ C,
+                                                        const T* __restrict__ Kinv, const T* __restrict__ a,
+                                                        const T* __restrict__ a2, const T* __restrict__ upart, int nchunk,
+                                                        int64_t ldu, T rho, T* __restrict__ out) {
+  __shared__ T tt[32][33];
+  __shared__ T ui[32], uj[32], up[4][64];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, t = threadIdx.x;
+  const int64_t i0 = blockIdx.y * (int64_t)32, j0 = blockIdx.x * (int64_t)32;
+  {  // u of the tile's 32 rows and 32 columns: four threads per entry fetch the tile-row partials side by side, fixed order
+    const int el = t & 63, cg = t >> 6;
+    const int64_t e = el < 32 ? i0 + el : j0 + (el - 32);
     T s = T(0);
-    if (e < mp)
-      for (int c = cg; c < nchunk; c += 8) s += upart[c * ldu + e];
+    for (int c = cg; c < nchunk; c += 4) s += upart[c * ldu + e];
     up[cg][el] = s;
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) tt[ty + 8 * q][tx] = TM[(j0 + ty + 8 * q) * mp + i0 + tx];  // tile (j0.., i0..): TM[j][i]
   __syncthreads();
-  if (t < 32) {
-    const T s = ((up[0][t] + up[1][t]) + (up[2][t] + up[3][t])) + ((up[4][t] + up[5][t]) + (up[6][t] + up[7][t]));
-    (t < 16 ? ui[t] : uj[t - 16]) = s;
+  if (t < 64) {
+    const T s = (up[0][t] + up[1][t]) + (up[2][t] + up[3][t]);
+    (t < 32 ? ui[t] : uj[t - 32]) = s;
   }
   __syncthreads();
-  if (i >= mp || j >= mp) return;
-  T v = T(0);
-  if (i < m && j < m) {
-    const T ai = a[i], aj = a[j];
-    const T ati = ai - (a2 ? a2[i] : T(0)), atj = aj - (a2 ? a2[j] : T(0));
-    v = TM[i * mp + j] + TM[j * mp + i] - C[i * mp + j] - T(0.25) * Kinv[i * mp + j] -
-        T(0.5) * rho * (ui[threadIdx.y] * aj + ai * uj[threadIdx.x]) + T(0.5) * ati * atj;
+  const int64_t j = j0 + tx;
+  const T aj = a[j], atj = aj - (a2 ? a2[j] : T(0)), ujv = uj[tx];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = ty + 8 * q;
+    const int64_t i = i0 + r;
+    T v = T(0);
+    if (i < m && j < m) {
+      const T ai = a[i], ati = ai - (a2 ? a2[i] : T(0));
+      v = TM[i * mp + j] + tt[tx][r] - C[i * mp + j] - T(0.25) * Kinv[i * mp + j] - T(0.5) * rho * (ui[r] * aj + ai * ujv) +
+          T(0.5) * ati * atj;
+    }
+    out[i * mp + j] = v;
   }
-  out[i * mp + j] = v;
 }
 
 // mean_f = kappa mu (one wave per row) and, in the same launch, k_hyper_gvec's modes 0 - 2 from it
@@ -562,9 +570,21 @@ __global__ void k_hyper_reduce2(int64_t D, double* __restrict__ out, int64_t p, 
   const int64_t e = ((int64_t)blockIdx.x - (D + 1)) * (int64_t)blockDim.x + threadIdx.x;
   if (e >= p * D) return;
   const int64_t j = e / D, d = e % D;
+  // (the loads of a set are independent: issued in groups of four, added in row-tile order as two k_hyper_reduce launches did)
   T a = T(0), b = T(0);
-  for (int64_t r = 0; r < nrow1; ++r) a += pZ1[(r * p_pad + j) * D + d];
-  for (int64_t r = 0; r < nrow2; ++r) b += pZ2[(r * p_pad + j) * D + d];
+  int64_t r = 0;
+  for (; r + 4 <= nrow1; r += 4) {
+    const T x0 = pZ1[(r * p_pad + j) * D + d], x1 = pZ1[((r + 1) * p_pad + j) * D + d];
+    const T x2 = pZ1[((r + 2) * p_pad + j) * D + d], x3 = pZ1[((r + 3) * p_pad + j) * D + d];
+    a = (((a + x0) + x1) + x2) + x3;
+  }
+  for (; r < nrow1; ++r) a += pZ1[(r * p_pad + j) * D + d];
+  for (r = 0; r + 4 <= nrow2; r += 4) {
+    const T x0 = pZ2[(r * p_pad + j) * D + d], x1 = pZ2[((r + 1) * p_pad + j) * D + d];
+    const T x2 = pZ2[((r + 2) * p_pad + j) * D + d], x3 = pZ2[((r + 3) * p_pad + j) * D + d];
+    b = (((b + x0) + x1) + x2) + x3;
+  }
+  for (; r < nrow2; ++r) b += pZ2[(r * p_pad + j) * D + d];
   dZ[e] = (T(0) + T(1) * a) + T(2) * b;
 }
 

@@ -2065,6 +2065,8 @@ struct Svgp : SvgpBase {
         LAUNCHCHK(ctx);
       }
       g.K_stale = false;
+      g.C_valid = false;  // (C = kappa' diag(w) kappa + K^-1 / 4 of a step under the kernel matrices before this refresh)
+      if (tw2_kis_of == (int)(&g - lat.data())) tw2_kis_of = -1;
       // (under AGP_FLAG_STALE_K a full-batch run keeps the step's kernel matrices across the refresh of the fresh set)
       if (!(g.stale_on && !desc.stochastic)) g.kappa_valid = false;
       g.pred_valid = g.predvar_valid = false;
@@ -3769,6 +3771,7 @@ struct Svgp : SvgpBase {
   agp_status materialize(Latent& g) {
     if (g.post_valid) return AGP_OK;
     if (!(g.la_state == 1 && g.xa_valid)) AGPCHK(aug_factor(g, 0, 1));
+    if (tw2_kis_of == (int)(&g - lat.data())) tw2_kis_of = -1;  // K^-1 Sigma in the scratch belongs to the Sigma before this one
     AGPCHK(xtx_padded<T>(ctx, g.Xa, mp, mp, g.Sigma, mp));
     // mu = Sigma eta1 as the reference writes it (global_update!, analyticVI.jl:229-246).  Until round 4 this was Xa' (Xa eta1) from
     // the factorisation's [eta1'] row: a copy and a 16-workgroup triangular mat-vec (4.8 + 15.6 us at m = 1024 against 7.0)

@@ -536,41 +536,7 @@ __global__ void k_symv_trmv(const T* __restrict__ S, const T* __restrict__ X, in
   if (lane == 0) (tri ? yt : ys)[row] = s;
 }
 
-// y[j] = sum_{k >= j} X[k][j] x[k]   (transpose of the above: mu = X' v).  One workgroup per 64 columns, 16 row groups of
-// 64 lanes (coalesced 512-byte rows); the 16 partial sums are combined in a fixed order through LDS.  blockDim = 1024.
-template <typename T>
-__global__ __launch_bounds__(1024) void k_trmv_lower_t(const T* __restrict__ X, int64_t ld, int64_t n,
-                                                        const T* __restrict__ x, T* __restrict__ y) {
-  __shared__ T part[16][64];
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int64_t j = blockIdx.x * 64 + col;
-  T s = T(0);
-  if (j < n) {
-    // four independent accumulators: the loop is a chain of dependent global loads otherwise (64 of them for the first
-    // column block at n = 1024: 21 us; 15.6 us like this)
-    T s1 = T(0), s2 = T(0), s3 = T(0);
-    int64_t k = blockIdx.x * 64 + grp;
-    for (; k + 48 < n; k += 64) {
-      const T a0 = X[k * ld + j], a1 = X[(k + 16) * ld + j], a2 = X[(k + 32) * ld + j], a3 = X[(k + 48) * ld + j];
-      const T x0 = x[k], x1 = x[k + 16], x2 = x[k + 32], x3 = x[k + 48];
-      s += (k >= j) ? a0 * x0 : T(0);
-      s1 += (k + 16 >= j) ? a1 * x1 : T(0);
-      s2 += (k + 32 >= j) ? a2 * x2 : T(0);
-      s3 += (k + 48 >= j) ? a3 * x3 : T(0);
-    }
-    for (; k < n; k += 16)
-      if (k >= j) s += X[k * ld + j] * x[k];
-    s = (s + s1) + (s2 + s3);
-  }
-  part[grp][col] = s;
-  __syncthreads();
-  if (grp == 0 && j < n) {
-    T t = T(0);
-#pragma unroll
-    for (int g = 0; g < 16; ++g) t += part[g][col];
-    y[j] = t;
-  }
-}
+// (round 4: mu = Sigma eta1 replaced the transposed triangular mat-vec mu = Xa' v, k_trmv_lower_t, which is gone)
 
 // y[i] = sum_j M[i][j] x[j], i < rows (one wave per row)
 template <typename T>

@@ -64,7 +64,6 @@ struct agp_ctx {
   // releases them with (signal memory) and the event this context's stream waits on behind every split launch
   hipStream_t chain_stream = nullptr;
   int32_t* chain_go = nullptr;
-  hipEvent_t chain_done = nullptr;   // (only with AGP_CHAIN_JOIN=1: an event join behind every split launch, for A/B measurements)
   int32_t* chain_ctr = nullptr;      // device word: chain workgroups that have exited (DagSync::done); chain_exits = what it will reach
   int32_t chain_exits = 0;
   int chain_state = 0;  // 0 not tried, 1 usable, -1 not available (the two streams do not run kernels side by side) / switched off
@@ -225,11 +224,7 @@ static bool chol_use_dag(const agp_ctx* c, int64_t nt, int64_t ne = 0, int64_t n
     return e ? (e[0] == '0' ? 0 : 1) : -1;
   }();
   if (c->dag_off) return false;  // a lost dependency was seen on this context (two processes sharing the device): stay safe
-  static const int64_t col_tiles = []() {
-    const char* e = getenv("AGP_DAG_MAX_COLUMN_TILES");
-    return e ? (int64_t)atoll(e) : DAG_MAX_COLUMN_TILES;
-  }();
-  if (nb * (nt + ne + 1) > col_tiles) return false;
+  if (nb * (nt + ne + 1) > DAG_MAX_COLUMN_TILES) return false;
   return v < 0 ? nt <= DAG_MAX_NT : v == 1;
 }
 
@@ -472,11 +467,7 @@ static bool chain_split_wanted(int64_t tiles, bool with_prologue = false, bool f
   // per CU whatever the registers), and the measured case lost (C2: 0.3167 ms split, 0.3103 ms merged).  In fp32 the same tile
   // kernel fits two workgroups per CU (68 KB, 128 VGPRs) and wins: m = 1024, B = 2048 fp32 0.325 -> 0.270 ms per step.
   if (with_prologue && f64 && v < 0) return false;
-  static const int64_t min_tiles = []() {
-    const char* e = getenv("AGP_CHAIN_SPLIT_MIN_TILES");
-    return e ? (int64_t)atoll(e) : (int64_t)600;
-  }();
-  return v < 0 ? tiles >= min_tiles : v == 1;
+  return v < 0 ? tiles >= 600 : v == 1;
 }
 // the chain stream, its release word and the proof that kernels of the two streams run at the same time (k_handshake: where
 // dispatches are serialised -- rocprofv3 --pmc, AMD_SERIALIZE_KERNEL -- a chain kernel polling for the tile kernel behind it in
@@ -492,7 +483,6 @@ static bool chain_split_ready(agp_ctx* c) {
     return false;
   }
   bool ok = hipExtMallocWithFlags((void**)&c->chain_go, 8, hipMallocSignalMemory) == hipSuccess && hipMemset(c->chain_go, 0, 8) == hipSuccess &&
-            hipEventCreateWithFlags(&c->chain_done, hipEventDisableTiming) == hipSuccess &&
             hipMalloc((void**)&c->chain_ctr, sizeof(int32_t)) == hipSuccess && hipMemset(c->chain_ctr, 0, sizeof(int32_t)) == hipSuccess;
   int32_t* hs = nullptr;
   ok = ok && hipMalloc((void**)&hs, 4 * sizeof(int32_t)) == hipSuccess && hipMemset(hs, 0, 4 * sizeof(int32_t)) == hipSuccess;
@@ -513,20 +503,9 @@ static bool chain_split_ready(agp_ctx* c) {
 // chain writes nothing (its diagonal factors are write-through stores issued before that publish), so whatever follows on this
 // context's stream -- and a host synchronisation of it -- sees a finished factorisation.  The one exception, an aborted launch whose
 // chain is still inside a tile factorisation, is handled where it matters: the fallback waits for the chain workgroups' exit count
-// (DagSync::done, SafeSrc::chain_done).  An event join (record on the chain stream, wait on this one) was the first version and
-// DEADLOCKED with the host several steps ahead, the look-ahead on and the prologue inside the split launch (fp32, m = 1024,
-// B = 2048; not with the host synchronising every step, not without the look-ahead, not with a ring of distinct events either):
-// AGP_CHAIN_JOIN=1 brings it back for A/B measurements only.
-static agp_status chain_split_join(agp_ctx* c) {
-  static const bool on = []() {
-    const char* e = getenv("AGP_CHAIN_JOIN");
-    return e && e[0] == '1';
-  }();
-  if (!on) return AGP_OK;
-  HIPCHK(c, hipEventRecord(c->chain_done, c->chain_stream));
-  HIPCHK(c, hipStreamWaitEvent(c->stream, c->chain_done, 0));
-  return AGP_OK;
-}
+// (DagSync::done, SafeSrc::chain_done).  (An event join -- record on the chain stream, wait on this one -- was the first version and
+// DEADLOCKED with the host several steps ahead, the look-ahead on and the prologue inside the split launch; removed in round 5,
+// the account is in docs/DESIGN_LOG.md.)
 // what a split launch hands its kernels / its fallback about the chain kernel (nb chain workgroups)
 static void chain_split_arm(agp_ctx* c, DagSync& ds, int nb) {
   ds.go = c->chain_go;
@@ -562,57 +541,27 @@ struct ProHost {
 // k-slices per block column of the prologue's product: a tile of block column c has to be there when the chain reaches the
 // column (about tau * c after the start, tau = 17.8 us f64 / 14 us f32 per block column), a 64-row chunk of the product costs a
 // workgroup about tc = 2.7 / 1.6 us; columns 0 and 1 feed the chain at once and are split as far as it pays (8).
-// AGP_PRO_KS="8,8,4,2,1" overrides (the last entry repeats).
 static void pro_ks_table(int64_t nt, int64_t nq, bool f64, unsigned char* ks, unsigned char* kf) {
-  static const std::vector<int> env = []() {
-    std::vector<int> v;
-    if (const char* e = getenv("AGP_PRO_KS")) {
-      for (const char* p = e; *p;) {
-        v.push_back(atoi(p));
-        while (*p && *p != ',') ++p;
-        if (*p == ',') ++p;
-      }
-    }
-    return v;
-  }();
   const double tc = f64 ? 2.7 : 1.6, tau = f64 ? 17.8 : 14.0;
   for (int64_t c = 0; c < nt && c < 32; ++c) {
     int want;
-    if (!env.empty()) want = env[std::min<size_t>((size_t)c, env.size() - 1)];
-    else if (c == 0) want = 8;
+    if (c == 0) want = 8;
     else if (c == 1) want = f64 ? 4 : 8;
     else want = (int)std::ceil((double)nq * (tc + 0.3) / (tau * (double)c - 12.0));
     want = std::max(1, std::min<int>(want, (int)std::min<int64_t>(8, nq)));
-    ks[c] = (unsigned char)want;
-  }
-  // the tiles next to the diagonal (ProArgs::kf): the same split as their column unless AGP_PRO_KF says otherwise
-  static const std::vector<int> envf = []() {
-    std::vector<int> v;
-    if (const char* e = getenv("AGP_PRO_KF")) {
-      for (const char* p = e; *p;) {
-        v.push_back(atoi(p));
-        while (*p && *p != ',') ++p;
-        if (*p == ',') ++p;
-      }
-    }
-    return v;
-  }();
-  for (int64_t c = 0; c < nt && c < 32; ++c) {
-    int want = envf.empty() ? (int)ks[c] : envf[std::min<size_t>((size_t)c, envf.size() - 1)];
-    want = std::max<int>(want, (int)ks[c]);
-    kf[c] = (unsigned char)std::max(1, std::min<int>(want, (int)std::min<int64_t>(8, nq)));
+    // the tiles next to the diagonal (ProArgs::kf) take the same split as their column (a finer one was measured at 32 block
+    // columns, docs/DESIGN_LOG.md, and not adopted)
+    ks[c] = kf[c] = (unsigned char)want;
   }
 }
-static bool dag_trace_on() {
-  static const bool on = getenv("AGP_DAG_TRACE") != nullptr;
+// test hook (AGP_DAG_TEST_ABORT=1): pretend every task-graph launch of a CAVI step lost a dependency, so that the in-stream
+// fallback runs behind each of them
+static bool dag_test_abort() {
+  static const bool on = []() {
+    const char* e = getenv("AGP_DAG_TEST_ABORT");
+    return e && e[0] == '1';
+  }();
   return on;
-}
-static bool dag_fused_on() {
-  static const bool fused = []() {
-    const char* e = getenv("AGP_CHOL_DAG_FUSED");
-    return !(e && e[0] == '0');
-  }();
-  return fused;
 }
 
 template <typename T>
@@ -632,7 +581,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
   const int64_t nt = n / TILE;
   const bool use_dag = chol_use_dag(c, nt, ne);
   bool split_used = false;  // the launch went out as chain kernel + tile kernel: its fallback waits for the chain's exit count
-  if (pro && !(use_dag && X && dag_fused_on() && !dag_trace_on() && !want_l && nt <= 32)) {
+  if (pro && !(use_dag && X && !want_l && nt <= 32)) {
     c->err = "potrf_fused: a pending natural-gradient step can only ride on the CAVI step's task-graph launch";
     return AGP_ERR_INVALID;
   }
@@ -665,14 +614,8 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     T* H = nullptr;
     const int hs = pro ? c->h_step_set : 0;
     AGPCHK(dag_handover_acquire<T>(c, hstride, hs, &H));
-    unsigned long long* trace = nullptr;
-    static const char* trace_path = getenv("AGP_DAG_TRACE");  // development aid: per-tile timestamps of one launch
-    if (trace_path && ne > 0) {
-      if (hipMalloc((void**)&trace, (size_t)ntiles * 8 * 8) != hipSuccess) trace = nullptr;
-      if (trace) (void)hipMemsetAsync(trace, 0, (size_t)ntiles * 8 * 8, c->stream);
-    }
-    const bool fused = dag_fused_on();
-    const bool step_inst = fused && !trace && nx == 0 && !do_x && !want_l;
+    unsigned long long* const trace = nullptr;  // (per-tile timestamps: the TRACE instantiation of k_chol_dag, a development aid)
+    const bool step_inst = nx == 0 && !do_x && !want_l;
     DagSync ds{};
     if (ssync) {
       if (step_inst) {
@@ -685,11 +628,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     one.X[0] = X;
     one.Dg[0] = Dg;
     one.E[0] = E;
-    if (fused && trace)
-      hipLaunchKernelGGL((k_chol_dag<T, true, false, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1,
-                         (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
-                         (int)(do_x && nx == 0) | (want_l ? 2 : 0), DagSync{});
-    else if (fused && !trace && pro) {  // ... with the pending natural-gradient step as its prologue (the CAVI step's launch, or --
+    if (pro) {  // ... with the pending natural-gradient step as its prologue (the CAVI step's launch, or --
                                         // hyper-parameter iteration -- the factorisation of the updated -2 eta2 with its inverse)
       pa.kap = pro->kap;
       pa.ldk = pro->ldk;
@@ -717,19 +656,8 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
         pa.nfill = 64;
         c->h_dirty[other].on = false;
       }
-      // development aids: AGP_PRO_TRACE=<file> dumps the prologue's wall-clock stamps of the 50th launch; AGP_PRO_LDS_PAD=<bytes>
-      // of dynamic LDS per workgroup (f32: two workgroups share a CU unless padded beyond 80 KB)
-      static const char* pro_trace_path = getenv("AGP_PRO_TRACE");
-      static const unsigned lds_pad = []() {
-        const char* e = getenv("AGP_PRO_LDS_PAD");
-        return e ? (unsigned)atoi(e) : 0u;
-      }();
-      static int pro_launches = 0;
-      unsigned long long* ptrace = nullptr;
-      if (pro_trace_path && ++pro_launches == 50) {
-        if (hipMalloc((void**)&ptrace, 2048 * 8) != hipSuccess) ptrace = nullptr;
-        if (ptrace) (void)hipMemsetAsync(ptrace, 0, 2048 * 8, c->stream);
-      }
+      unsigned long long* const ptrace = nullptr;  // (wall-clock stamps of the prologue, PRO_TS in agp_chol.h: a development aid)
+      constexpr unsigned lds_pad = 0;
       if (step_inst && chain_split_wanted(ntiles + nhelp, true, sizeof(T) == 8) && chain_split_ready(c)) {  // chain kernel + tile kernel (k_chol_dag, ROLE)
         chain_split_arm(c, ds, 1);
         split_used = true;
@@ -740,7 +668,6 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
                            dim3(CHOL_THREADS), lds_pad, c->stream, one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid,
                            c->dag_flags, c->dag_epoch, ptrace, H, hstride, nx, erow, 0, ds, pa, epi ? *epi : EpiArgs<T>{});
         LAUNCHCHK(c);
-        AGPCHK(chain_split_join(c));
       } else if (step_inst)
         hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, true>), dim3((unsigned)(ntiles + nhelp + pa.nfill)),
                            dim3(CHOL_THREADS), lds_pad, c->stream, one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid,
@@ -750,17 +677,6 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
                            dim3(CHOL_THREADS), lds_pad, c->stream, one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid,
                            c->dag_flags, c->dag_epoch, ptrace, H, hstride, nx, erow, (int)(do_x && nx == 0) | (want_l ? 2 : 0),
                            DagSync{}, pa, EpiArgs<T>{});
-      if (ptrace) {
-        std::vector<unsigned long long> hq(2048);
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipMemcpy(hq.data(), ptrace, 2048 * 8, hipMemcpyDeviceToHost);
-        (void)hipFree(ptrace);
-        if (FILE* f = fopen(pro_trace_path, "w")) {
-          for (size_t i = 0; i < hq.size(); ++i)
-            if (hq[i]) fprintf(f, "%zu %llu\n", i, hq[i]);
-          fclose(f);
-        }
-      }
       c->h_step_set = other;
     } else if (step_inst && chain_split_wanted(ntiles) && chain_split_ready(c)) {
       // ... as two kernels: the chain workgroup on its own stream (enqueued first), every other tile on this one
@@ -773,25 +689,17 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
                          one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx,
                          erow, 0, ds);
       LAUNCHCHK(c);
-      AGPCHK(chain_split_join(c));
     } else if (step_inst)  // the CAVI step's launch: specialised instantiation
       hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1,
                          (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
                          0, ds);
-    else if (fused)
-      hipLaunchKernelGGL((k_chol_dag<T, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0, ld,
-                         ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
-                         (int)(do_x && nx == 0) | (want_l ? 2 : 0), DagSync{});
     else
-      hipLaunchKernelGGL((k_chol_dag<T, false>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0, ld,
+      hipLaunchKernelGGL((k_chol_dag<T, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0, ld,
                          ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
                          (int)(do_x && nx == 0) | (want_l ? 2 : 0), DagSync{});
     LAUNCHCHK(c);
     AGPCHK(dag_handover_release<T>(c, hused, hstride, 1, hs));
-    static const bool test_abort = []() {  // test hook: pretend every task-graph launch of a CAVI step lost a dependency
-      const char* e = getenv("AGP_DAG_TEST_ABORT");
-      return e && e[0] == '1';
-    }();
+    const bool test_abort = dag_test_abort();
     if (safe) {
       safe->chain_done = split_used ? c->chain_ctr : nullptr;
       safe->chain_want = c->chain_exits;
@@ -800,18 +708,6 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       if (test_abort) hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, c->stream, info_dev, -1);
       if (can_defer) *defer_safe = true;
       else AGPCHK(launch_chol_safe<T>(c, one, *safe, 1, ld, ldx, lde, ne, nt, info_dev, nvalid));
-    }
-    if (trace) {
-      std::vector<unsigned long long> h((size_t)ntiles * 8);
-      (void)hipStreamSynchronize(c->stream);
-      (void)hipMemcpy(h.data(), trace, h.size() * 8, hipMemcpyDeviceToHost);
-      (void)hipFree(trace);
-      FILE* f = fopen(trace_path, "w");
-      if (f) {
-        fprintf(f, "%lld %lld\n", (long long)nt, (long long)ne);
-        for (size_t i = 0; i < h.size(); ++i) fprintf(f, "%llu\n", h[i]);
-        fclose(f);
-      }
     }
     return AGP_OK;  // X = L^-1 came out of the same launch
   }
@@ -884,7 +780,6 @@ static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, in
                        c->stream, bt, nb, fstride, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch,
                        (unsigned long long*)nullptr, H, hstride, (int64_t)0, (const T*)nullptr, 0, ds);
     LAUNCHCHK(c);
-    AGPCHK(chain_split_join(c));
   } else
     hipLaunchKernelGGL((k_chol_dag<T, true, true, false, true>), dim3((unsigned)(ntiles * nb)), dim3(CHOL_THREADS), 0, c->stream, bt, nb, fstride, ld,
                        ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, (unsigned long long*)nullptr, H, hstride,
@@ -894,11 +789,7 @@ static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, in
   if (safe) {
     safe->chain_done = split_used ? c->chain_ctr : nullptr;
     safe->chain_want = c->chain_exits;
-    static const bool test_abort = []() {
-      const char* e = getenv("AGP_DAG_TEST_ABORT");
-      return e && e[0] == '1';
-    }();
-    if (test_abort) hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, c->stream, info_dev, -1);
+    if (dag_test_abort()) hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, c->stream, info_dev, -1);
     AGPCHK(launch_chol_safe<T>(c, bt, *safe, nb, ld, ldx, lde, ne, nt, info_dev, nvalid));
   }
   return AGP_OK;
@@ -917,33 +808,9 @@ static agp_status potrf_fused_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, 
 // Up to this many C tiles a GEMM / symmetric-product launch uses two k-groups per workgroup (512 threads, two waves per SIMD):
 // one four-wave workgroup reaches about half of a CU's MFMA rate, and up to ~4 workgroups per CU the second k-group is worth
 // more than the extra tiles in flight (measured, step times with 320 -> 1100: fp32 m = B = 2048 0.821 -> 0.789 ms, fp64 m = B =
-// 1536 0.703 -> 0.687 ms, 2048 1.37 -> 1.33 ms; C2's 256 / 136 tiles were below the old limit already).  AGP_KG2_LIMIT overrides.
-static int64_t kg2_limit() {
-  static const int64_t v = []() {
-    const char* e = getenv("AGP_KG2_LIMIT");
-    return e ? (int64_t)atoll(e) : (int64_t)1100;
-  }();
-  return v;
-}
-static int64_t syrk_kg2_limit() {  // (AGP_SYRK_KG2_LIMIT: the symmetric products alone, for A/B measurements)
-  static const int64_t v = []() {
-    const char* e = getenv("AGP_SYRK_KG2_LIMIT");
-    return e ? (int64_t)atoll(e) : kg2_limit();
-  }();
-  return v;
-}
-// Tail split of a symmetric-product launch (syrk_tn_body, agp_linalg.h): T tile workgroups (all latents together) on n CUs.
-// Co-resident workgroups share their CU's MFMA pipes, so by the arithmetic a launch is as long as the CU with the most tiles: the
-// remainder R = T mod n of T / n whole rounds is cut into n / R k-slices per tile, one piece per CU, dispatched behind the full tiles.
-// OFF unless AGP_SYRK_SPLIT=1 (2: also print the plan).  Measured in round 4 and NOT adopted: C3 (528 fp32 tiles = 2 rounds + 16
-// tiles in 16 slices) k_syrk_tn<float> 141 -> 144 us plus the finishing launch, step 0.668 -> 0.707 ms; C4 (8 x 136 tiles = 4
-// rounds + 64 tiles in 4 slices) step 1.108 -> 1.131 ms.  Neither launch is bound by its tail: the fp32 product moves 16 flop per
-// operand byte through the L2 (267 MB of fabric traffic at C3) and the C4 launch shares the chip with two look-ahead streams.
-// (A first version counted rounds of occupancy x CUs slots instead of CUs: the same result.)
-struct SyrkSplit {
-  int64_t per_latent = 0;  // tiles of every latent that are split
-  int P = 1;
-};
+// 1536 0.703 -> 0.687 ms, 2048 1.37 -> 1.33 ms; C2's 256 / 136 tiles were below the old limit already).
+static constexpr int64_t kg2_limit() { return 1100; }
+static constexpr int64_t syrk_kg2_limit() { return kg2_limit(); }
 static int ctx_cus(agp_ctx* c) {
   if (c->n_cu <= 0) {
     int v = 0;
@@ -951,38 +818,6 @@ static int ctx_cus(agp_ctx* c) {
     c->n_cu = v;
   }
   return c->n_cu;
-}
-static SyrkSplit syrk_split_plan(agp_ctx* c, const void* kernel, int threads, int64_t tiles_per_latent, int nl, int64_t nslab) {
-  static const bool on = [] {
-    const char* e = getenv("AGP_SYRK_SPLIT");
-    return e && (e[0] == '1' || e[0] == '2');
-  }();
-  SyrkSplit sp;
-  if (!on) return sp;
-  int occ = 0;
-  const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, 0);
-  static const bool verbose = [] {
-    const char* e = getenv("AGP_SYRK_SPLIT");
-    return e && e[0] == '2';
-  }();
-  if (verbose) fprintf(stderr, "[agp] syrk_split_plan: occupancy query %d -> %d per CU, %d CUs, %lld tiles x %d\n", (int)oe, occ,
-                       ctx_cus(c), (long long)tiles_per_latent, nl);
-  if (oe != hipSuccess || occ <= 0) return sp;
-  // The unit that matters is the CU, not the slot: co-resident workgroups share their CU's MFMA pipes, so a launch is as long as the
-  // CU with the most tiles.  T tiles on n CUs: T / n whole rounds of one tile per CU, and the remainder R = T mod n as n / R slices
-  // each -- one piece per CU, dispatched behind the full tiles.  (Slots only matter when a round does not fit into them.)
-  const int64_t ncu = ctx_cus(c), T = tiles_per_latent * nl;
-  if (T <= ncu || T / ncu > (int64_t)occ * 4) return sp;
-  const int64_t R = T % ncu;
-  if (R == 0 || 2 * R > ncu) return sp;
-  const int64_t per = (R + nl - 1) / nl;  // per latent (rounded up: a few more pieces than CUs)
-  if (per >= tiles_per_latent) return sp;
-  int64_t P = ncu / (per * nl);
-  P = std::min<int64_t>(P, std::min<int64_t>(32, nslab / 2));  // at least two slabs per piece
-  if (P < 2) return sp;
-  sp.per_latent = per;
-  sp.P = (int)P;
-  return sp;
 }
 static agp_status ensure_bal_ws(agp_ctx* c, size_t need) {
   if (c->bal_bytes < need) {
@@ -1021,41 +856,21 @@ static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_
     c->h_dirty[0].on = false;
   }
   // up to 160 tiles (C2: 136 on 256 CUs, one workgroup per CU) four k-groups: 16 waves per CU instead of 8 -- 58 -> 52 us at C2
-  // (step 0.379 -> 0.3735 ms); AGP_SYRK_KG4=0 switches it off
-  static const bool kg4 = []() {
-    const char* e = getenv("AGP_SYRK_KG4");
-    return !(e && e[0] == '0');
-  }();
-  const int kg = (kg4 && tiles <= 160 && Kdim >= 8 * BK) ? 4 : (tiles <= syrk_kg2_limit() && Kdim >= 4 * BK) ? 2 : 1;
-  // tail split (syrk_tn_body): the remainder tiles of the last round as k-slices behind the full tiles, finished by a second launch
-  SyrkSplit sp;
-  if (!lower_a && out != nullptr && kg != 4)
-    sp = syrk_split_plan(c, kg == 2 ? (const void*)&k_syrk_tn<T, MODE, 2> : (const void*)&k_syrk_tn<T, MODE, 1>, kg * NTHREADS, tiles,
-                         1, Kdim / BkOf<T>::v);
-  const int64_t nfull = tiles - sp.per_latent, npiece = sp.per_latent * sp.P;
-  if (npiece) AGPCHK(ensure_bal_ws(c, sizeof(T) * (size_t)npiece * TILE * TILE));
-  T* ws = npiece ? (T*)c->bal_ws : (T*)nullptr;
-  const int64_t grid = nfull + npiece + nrider + nfill;
+  // (step 0.379 -> 0.3735 ms)
+  const int kg = (tiles <= 160 && Kdim >= 8 * BK) ? 4 : (tiles <= syrk_kg2_limit() && Kdim >= 4 * BK) ? 2 : 1;
+  const int64_t grid = tiles + nrider + nfill;
   if (kg == 4)
     hipLaunchKernelGGL((k_syrk_tn<T, MODE, 4>), dim3((unsigned)grid), dim3(4 * NTHREADS), 0, c->stream, A, lda, Kdim, w,
                        lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0, nrider, fillp, fused_used, fstride,
-                       fnb, nfull, sp.P, ws);
+                       fnb);
   else if (kg == 2)
     hipLaunchKernelGGL((k_syrk_tn<T, MODE, 2>), dim3((unsigned)grid), dim3(2 * NTHREADS), 0, c->stream, A, lda, Kdim, w,
                        lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0, nrider, fillp, fused_used, fstride,
-                       fnb, nfull, sp.P, ws);
+                       fnb);
   else
     hipLaunchKernelGGL((k_syrk_tn<T, MODE, 1>), dim3((unsigned)grid), dim3(NTHREADS), 0, c->stream, A, lda, Kdim, w,
                        lower_a, out, ldo, eta2, Kinv, ldm, lr, tiles, rvec, eta1, kinv_mu0, nrider, fillp, fused_used, fstride,
-                       fnb, nfull, sp.P, ws);
-  if (npiece) {
-    SyrkBatch<T> b{};
-    b.out[0] = out;
-    b.eta2[0] = eta2;
-    b.Kinv[0] = Kinv;
-    hipLaunchKernelGGL((k_syrk_split_finish<T, MODE>), dim3((unsigned)sp.per_latent, 1), dim3(NTHREADS), 0, c->stream, b, ldo, ldm,
-                       lr, tiles, nfull, sp.P, (const T*)ws);
-  }
+                       fnb);
   LAUNCHCHK(c);
   return AGP_OK;
 }
@@ -1063,24 +878,16 @@ static agp_status syrk_tn(agp_ctx* c, const T* A, int64_t lda, int64_t n, int64_
 // out = X' X for lower-triangular X  (A^-1 from its inverse Cholesky factor): the symmetric product with the k range of every
 // tile starting at its first row, k-groups chosen like everywhere else (it ran with one k-group on 136 tiles: 60 us at m = 1024)
 // Round 4: from 8 block rows on, the balanced form (k_xtx_bal: units of at most ch k-blocks, partial tiles added by the last arriver
-// in unit order): 42 -> ~15 us at m = 1024.  AGP_XTX_BALANCED=0 keeps the one-workgroup-per-tile product; AGP_XTX_CH sets ch.
+// in unit order): 42 -> ~15 us at m = 1024 (below 8 block rows the one-workgroup-per-tile product stays).
 // (Dg ...: log det from the diagonal factors rides on the reduction launch; *rider_done says whether it did)
 template <typename T>
 static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* out, int64_t ldo, const T* Dg = nullptr,
                              int64_t nvalid = 0, double* ld_out = nullptr, int32_t* status = nullptr, bool* rider_done = nullptr) {
   if (rider_done) *rider_done = false;
-  static const int bal_env = [] {
-    const char* e = getenv("AGP_XTX_BALANCED");
-    return e ? atoi(e) : 1;
-  }();
-  static const int ch_env = [] {
-    const char* e = getenv("AGP_XTX_CH");
-    return e ? std::max(1, atoi(e)) : 0;
-  }();
   const int64_t nt = n / TILE;
-  if (!bal_env || nt < 8)
+  if (nt < 8)
     return syrk_tn<T, SY_STORE>(c, X, ld, n, n, (const T*)nullptr, 1, out, ldo, (T*)nullptr, (const T*)nullptr, (int64_t)0, T(0));
-  const int ch = (int)std::max<int64_t>(ch_env ? ch_env : 2, (nt + XTX_MAXU - 1) / XTX_MAXU);  // at most XTX_MAXU units per tile
+  const int ch = (int)std::max<int64_t>(2, (nt + XTX_MAXU - 1) / XTX_MAXU);  // at most XTX_MAXU units per tile
   const int64_t nunits = xtx_bal_units(nt, ch), ntri = nt * (nt + 1) / 2;
   AGPCHK(ensure_bal_ws(c, sizeof(T) * (size_t)nunits * TILE * TILE));
   T* fillp = nullptr;
@@ -1094,15 +901,7 @@ static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* o
     nfill = 96;
     c->h_dirty[0].on = false;
   }
-  static const int kg_env = [] {
-    const char* e = getenv("AGP_XTX_KG");
-    return e ? atoi(e) : 1;
-  }();
-  if (kg_env == 2)
-    hipLaunchKernelGGL((k_xtx_bal<T, 2>), dim3((unsigned)(nunits + nfill)), dim3(2 * NTHREADS), 0, c->stream, X, ld, n, out, ldo,
-                       (T*)c->bal_ws, ch, nunits, fillp, fused_used, fstride, fnb);
-  else
-    hipLaunchKernelGGL((k_xtx_bal<T, 1>), dim3((unsigned)(nunits + nfill)), dim3(NTHREADS), 0, c->stream, X, ld, n, out, ldo,
+  hipLaunchKernelGGL((k_xtx_bal<T, 1>), dim3((unsigned)(nunits + nfill)), dim3(NTHREADS), 0, c->stream, X, ld, n, out, ldo,
                        (T*)c->bal_ws, ch, nunits, fillp, fused_used, fstride, fnb);
   const bool rider = Dg != nullptr && ld_out != nullptr;
   hipLaunchKernelGGL((k_xtx_bal_reduce<T>), dim3((unsigned)(ntri + (rider ? 1 : 0))), dim3(NTHREADS), 0, c->stream, n, out, ldo,
@@ -1621,11 +1420,7 @@ struct Svgp : SvgpBase {
     // only where the launch is not bound by workgroup slots: at 32 block columns (C3) the task graph already queues 1584 tile
     // workgroups through 256 slots, and the product's 27 ms of CU time inside it costs more than the kernel of its own (measured:
     // 0.70 -> 0.86-0.96 ms per step with any k-split table)
-    static const int64_t max_nt = []() {
-      const char* e = getenv("AGP_PRO_MAX_NT");
-      return e ? (int64_t)atoll(e) : (int64_t)16;
-    }();
-    if (mp / TILE > max_nt) return false;
+    if (mp / TILE > 16) return false;
     const int k = lp.kind;
     return k == AGP_LIK_GAUSSIAN || k == AGP_LIK_LOGISTIC || k == AGP_LIK_STUDENTT || k == AGP_LIK_LAPLACE ||
            k == AGP_LIK_BAYESIANSVM || k == AGP_LIK_NEGBINOMIAL || k == AGP_LIK_POISSON;
@@ -1655,8 +1450,7 @@ struct Svgp : SvgpBase {
     return AGP_OK;
   }
   agp_status step_finish() override {
-    if (pro_allowed() && chol_use_dag(ctx, mp / TILE, rup64(B_last) / TILE + 1, 1) && mp / TILE <= 32 && dag_fused_on() &&
-        !dag_trace_on()) {
+    if (pro_allowed() && chol_use_dag(ctx, mp / TILE, rup64(B_last) / TILE + 1, 1) && mp / TILE <= 32) {
       Latent& g = lat[0];
       g.C_valid = false;
       pend.on = true;
@@ -1686,33 +1480,9 @@ struct Svgp : SvgpBase {
   int64_t B_last = 0, ldx_last = 0;
   double rho_last = 1.0;
 
-  // (st_over: the hyper-gradient puts its small launches on a side stream next to the main stream's products, hypergrad)
-  hipStream_t st_over = nullptr;
-  hipStream_t st() { return st_over ? st_over : ctx->stream; }
-  struct StreamOver {  // scope guard: st() returns `s` until the guard goes
-    hipStream_t& slot;
-    StreamOver(hipStream_t& sl, hipStream_t s) : slot(sl) { slot = s; }
-    ~StreamOver() { slot = nullptr; }
-  };
-  // side stream of the hyper-gradient (round 4) and its fork / join events.  OFF unless AGP_HYPER_SIDE=1: measured at C2, the two
-  // fork / join pairs hide 46 us of small launches behind the products and still lengthen the iteration (1063 -> 1077 us) -- every
-  // cross-stream event costs the waiting stream 7 - 12 us here, and the kernels that share the chip slow one another down
-  // (the backward pass 24 -> 54 us next to a product)
-  hipStream_t hy_side = nullptr;
-  hipEvent_t hy_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  int hy_side_state = 0;  // 0 not tried, 1 usable, -1 off
-  bool hy_side_ready() {
-    if (hy_side_state == 0) {
-      hy_side_state = -1;
-      const char* e = getenv("AGP_HYPER_SIDE");
-      if (e && e[0] == '1' && hipStreamCreateWithFlags(&hy_side, hipStreamNonBlocking) == hipSuccess) {
-        bool ok = true;
-        for (auto& ev : hy_ev) ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
-        if (ok) hy_side_state = 1;
-      }
-    }
-    return hy_side_state == 1;
-  }
+  hipStream_t st() { return ctx->stream; }
+  // (round 4 measured the hyper-gradient's small launches on a side stream next to the products: 1063 -> 1077 us, every cross-stream
+  //  event costs the waiting stream 7 - 12 us; removed in round 5, docs/DESIGN_LOG.md)
 
   agp_status init() override {
     m = desc.m;
@@ -1848,12 +1618,6 @@ struct Svgp : SvgpBase {
       if (pf_join[q]) dcheck(hipEventDestroy(pf_join[q]), __LINE__);
     }
     if (pf_fork) dcheck(hipEventDestroy(pf_fork), __LINE__);
-    if (hy_side) {
-      (void)hipStreamSynchronize(hy_side);
-      dcheck(hipStreamDestroy(hy_side), __LINE__);
-    }
-    for (auto& ev : hy_ev)
-      if (ev) dcheck(hipEventDestroy(ev), __LINE__);
     if (elbo_pin) {
       dcheck(hipHostFree(elbo_pin), __LINE__);
       for (auto& e : elbo_ev)
@@ -2296,11 +2060,7 @@ struct Svgp : SvgpBase {
     const bool prefetched = pf_valid && !fresh && x == pf_x && idx == pf_idx && B == pf_B && ldx == pf_ldx;
     // how many problems one task-graph launch may take (0: none fits, plain launches)
     int dag_nb = 0;
-    static const int max_nb = []() {
-      const char* e = getenv("AGP_DAG_MAX_NB");
-      return e ? std::max(1, std::min(atoi(e), (int)CHOL_MAXB)) : DAG_MAX_NB;
-    }();
-    for (int q = max_nb; q >= 1 && !dag_nb; --q)
+    for (int q = DAG_MAX_NB; q >= 1 && !dag_nb; --q)
       if (chol_use_dag(ctx, mp / TILE, Bq / TILE + 1, q)) dag_nb = q;
     // single latent on the task graph: the launch itself tells the look-ahead stream that the step
     // before has released its kappa buffers (DagSync) -- no event record on this stream
@@ -2324,17 +2084,13 @@ struct Svgp : SvgpBase {
     bool use_pro = false;
     if (pend.on || pendp.on) {
       use_pro = !fresh && nl == 1 && dag_nb > 0 && (prefetched || (reuse && lat[0].kappa_valid)) && pro_allowed() &&
-                mp / TILE <= 32 && dag_fused_on() && !dag_trace_on() && (pendp.on || pend.Bq >= TILE);
+                mp / TILE <= 32 && (pendp.on || pend.Bq >= TILE);
       if (!use_pro) AGPCHK(flush());
     }
     // the row statistics of this step as the epilogue of its task-graph launch, the launch's fallback deferred to the next step
     const bool use_epi = use_pro && in_cavi_step && epi_allowed();
     if (prefetched) {  // kappa of this minibatch was produced on the prefetch stream: adopt those buffers
-      static const bool pf_poll = []() {  // AGP_PF_POLL=0: wait for the look-ahead with an event (A/B measurements)
-        const char* e = getenv("AGP_PF_POLL");
-        return !(e && e[0] == '0');
-      }();
-      if (sig_state == 1 && pf_poll) {
+      if (sig_state == 1) {  // (the look-ahead's completion word is polled in-stream; without signal memory: an event wait)
         if (sdef.on) {  // the previous step's deferred fallback launch carries this step's wait for its look-ahead
           AGPCHK(run_deferred_safe((const int32_t*)sig[1], pf_seq));
         } else {
@@ -2445,11 +2201,7 @@ struct Svgp : SvgpBase {
           src.eta2[q] = g.eta2;
         }
         if (nb == 1) {  // also writes the [eta1' ; 0] block when it falls back to per-column launches
-          static const bool merge_ok = []() {  // AGP_MERGE_SAFE=0: keep k_chol_safe a launch of its own (A/B measurements)
-            const char* e = getenv("AGP_MERGE_SAFE");
-            return !(e && e[0] == '0');
-          }();
-          bool defer = nl == 1 && merge_ok;  // single latent: the row-statistics launch below carries the fallback (k_safe_rowstats)
+          bool defer = nl == 1;  // single latent: the row-statistics launch below carries the fallback (k_safe_rowstats)
           ProHost<T> ph{};
           if (use_pro) {
             Latent& g0 = lat[0];
@@ -2708,21 +2460,13 @@ struct Svgp : SvgpBase {
     const T rho = (T)rho_last;
     // round 4: H = G_kappa K^-1 comes from ONE product, kappa (Sigma K^-1), with the K^-1 Sigma that is formed on the way to Apred
     // (k_hyper_hk) -- not kappa Sigma followed by (.) K^-1.  The heteroscedastic model needs kappa Sigma itself (var_f under the
-    // current posterior) and keeps the two products; AGP_HYPER_TWO_PRODUCTS=1 forces them (A/B).
-    static const bool two_products_env = [] {
-      const char* e = getenv("AGP_HYPER_TWO_PRODUCTS");
-      return e && atoi(e) != 0;
-    }();
-    const bool one_product = lp.kind != AGP_LIK_HETEROSCEDASTIC && !two_products_env;
+    // current posterior) and keeps the two products.
+    const bool one_product = lp.kind != AGP_LIK_HETEROSCEDASTIC;
     // ... and G_K from ONE more, C (Sigma K^-1), when the factorisation launch inside materialize() took the pending natural-gradient
     // step as its prologue and left C = kappa' diag(w) kappa + K^-1 / 4 behind (aug_factor, k_hyper_gK_fused): no kappa' H, no Apred
     AGPCHK(refresh_K());
     AGPCHK(materialize(g));
     const bool gk_fused = one_product && g.C_valid && g.C_kap == g.kappa && !g.stale_on && !(g.on && !g.on_first);
-    // ... and with the small launches next to the products instead of between them: K^-1 mu, mean_f / g_mu / g_sigma run on a side
-    // stream while the main stream forms K^-1 Sigma and kappa (Sigma K^-1); the backward pass through K_nm and its reduction run
-    // there while the main stream forms C (Sigma K^-1) and G_K.  Two fork / join pairs of events; everything the side stream does
-    // is joined before this function returns.
     n_hgrad += 1;
     n_gk_fused += gk_fused ? 1 : 0;
     // K^-1 mu rides on the mean_f / g_mu / g_sigma launch (k_hyper_muf_gvec) when that launch exists and nothing else needs it first
@@ -2738,15 +2482,7 @@ struct Svgp : SvgpBase {
       g.pred_valid = true;  // (ensure_pred below then skips its own launch)
       pred_guard.flag = &g.pred_valid;
     }
-    const bool side = gk_fused && !mo && hy_side_ready();
-    if (side) {
-      HIPCHK(ctx, hipEventRecord(hy_ev[0], ctx->stream));
-      HIPCHK(ctx, hipStreamWaitEvent(hy_side, hy_ev[0], 0));
-    }
-    {
-      StreamOver so(st_over, side ? hy_side : (hipStream_t) nullptr);
-      AGPCHK(ensure_pred(g, !gk_fused));  // Sigma, mu, K^-1 mu (, Apred = K^-1 - K^-1 Sigma K^-1)
-    }
+    AGPCHK(ensure_pred(g, !gk_fused));  // Sigma, mu, K^-1 mu (, Apred = K^-1 - K^-1 Sigma K^-1)
     // AGP_FLAG_STALE_K: the step's kappa mixes the new Knm with the frozen inv(K); the differentiated ELBO recomputes the
     // kernel matrices (ELBO.jl:15-21), so the gradient takes kappa = Knm K^-1 with the FRESH inverse
     if (g.stale_on && lp.kind == AGP_LIK_HETEROSCEDASTIC) {
@@ -2816,7 +2552,6 @@ struct Svgp : SvgpBase {
                            kap, (const T*)(Kt + l * Bp), pw0);
       }
       if (one_product) {
-        StreamOver so(st_over, side ? hy_side : (hipStream_t) nullptr);
         hipLaunchKernelGGL((k_hyper_muf_gvec<T>), grid1((B + (fuse_a ? mp : 0)) * 64), dim3(256), 0, st(), B, mp, mp, rho, gmode,
                            kap, (const T*)g.mu, (const T*)(rbuf + l * Bp), (const T*)(theta + l * Bp), (const T*)y_last, idx_last,
                            hy_muf, hy_gmu, hy_gs, fuse_a ? (const T*)g.Kinv : (const T*)nullptr, g.apred);
@@ -2837,10 +2572,6 @@ struct Svgp : SvgpBase {
       }
       AGPCHK((gemm_nt<T, EPI_STORE>(ctx, kap, mp, Tw2, mp, Bq, mp, mp, 0, hyH1, mp, nullptr, 0, nullptr, nullptr, nullptr,
                                     0)));  // kappa (K^-1 Sigma)' = kappa Sigma K^-1
-      if (side) {  // join: K^-1 mu, g_mu, g_sigma
-        HIPCHK(ctx, hipEventRecord(hy_ev[1], hy_side));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, hy_ev[1], 0));
-      }
       if (gk_fused) {
         if (!hy_upart) AGPCHK(dmalloc(ctx, &hy_upart, (Bp / TILE) * mp));
         hipLaunchKernelGGL((k_hyper_hk_tile<T>), dim3((unsigned)(mp / TILE), (unsigned)(Bq / TILE)), dim3(256), 0, st(), B, mp, rho,
@@ -2851,10 +2582,6 @@ struct Svgp : SvgpBase {
                            (const T*)hy_gs, (const T*)g.apred, (const T*)hyH1, kap, hyH2, hyH3);
       }
       LAUNCHCHK(ctx);
-      if (side) {  // fork: the backward pass through K_nm needs G_Knm only
-        HIPCHK(ctx, hipEventRecord(hy_ev[2], ctx->stream));
-        HIPCHK(ctx, hipStreamWaitEvent(hy_side, hy_ev[2], 0));
-      }
     } else {
       hipLaunchKernelGGL((k_hyper_gkappa<T>), grid2(Bq, mp), blk2, 0, st(), B, Bq, mp, mp, rho, (const T*)hy_gmu,
                          (const T*)hy_gs, (const T*)g.mu, knm, hyH1);
@@ -2888,7 +2615,6 @@ struct Svgp : SvgpBase {
     const bool online_x = g.on && !g.on_first;
     const bool one_reduce = !online_x;
     {
-      StreamOver so(st_over, side ? hy_side : (hipStream_t) nullptr);
       dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / HB_RT));
       const int64_t tiles = (int64_t)gk.x * gk.y;
       hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)x_last, ldx_last, idx_last, B,
@@ -2898,10 +2624,6 @@ struct Svgp : SvgpBase {
         hipLaunchKernelGGL((k_hyper_reduce<T>), dim3((unsigned)(D + 1 + (m * D + 255) / 256)), dim3(256), 0, st(), tiles, D,
                            (const double*)hy_pvar, (const double*)hy_pscale, hy_g, 1.0, 1, (int64_t)gk.y, m, mp, (const T*)hy_pZ,
                            hy_dZ, T(1), (const T*)hy_gs, B, (double)rho);
-    }
-    if (side) {  // join: the second backward pass reuses the partial-sum buffers and accumulates into the gradient
-      HIPCHK(ctx, hipEventRecord(hy_ev[3], hy_side));
-      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, hy_ev[3], 0));
     }
     if (online_x && bs_world > 1) {
       ctx->err = "hyper-gradient of a streaming (online) model on a batch-sharded handle is not wired";
@@ -3305,11 +3027,10 @@ struct Svgp : SvgpBase {
         // one latent: lowest priority -- the look-ahead GEMM must not take CUs from the latency-bound factorisation chain (C2 0.309
         // -> 0.336 ms with the highest).  Several latents: highest -- the batched task graph holds every CU with mostly waiting
         // workgroups for 0.6 ms and nl look-ahead pairs have to get through next to it; a starved look-ahead is what the main stream
-        // then waits for (C4, 8 latents: 1.34 -> 1.21 ms).  AGP_PF_PRIORITY=l|n|h overrides.
+        // then waits for (C4, 8 latents: 1.34 -> 1.21 ms).
         int lo = 0, hi = 0;
         HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        int pr = nl > 1 ? hi : lo;
-        if (const char* e = getenv("AGP_PF_PRIORITY")) pr = e[0] == 'h' ? hi : e[0] == 'n' ? (lo + hi) / 2 : lo;
+        const int pr = nl > 1 ? hi : lo;
         HIPCHK(ctx, hipStreamCreateWithPriority(&pf_stream, hipStreamNonBlocking, pr));
       }
       HIPCHK(ctx, hipEventCreateWithFlags(&pf_done, hipEventDisableTiming));
@@ -3367,19 +3088,15 @@ struct Svgp : SvgpBase {
     // several latents (round 4): their (K_nm, kappa) pairs are independent, and one in-order stream runs them as 2 nl kernels of
     // exactly one workgroup per CU each, next to a task graph that holds most CUs -- every kernel boundary drains.  They are spread
     // over two streams (fork / join by events on the look-ahead's own streams, none on the step's); more streams take too much of
-    // the chip from the task graph.  AGP_PF_STREAMS=1..4 overrides.
-    static const int pf_ways = []() {
-      const char* e = getenv("AGP_PF_STREAMS");
-      return e ? std::max(1, std::min(atoi(e), PF_SIDE + 1)) : 2;  // measured at C4 (8 latents): 1 stream 1.186, 2: 1.088, 3: 1.41, 4: 1.34 ms
-    }();
+    // the chip from the task graph (measured at C4, 8 latents: 1 stream 1.186, 2: 1.088, 3: 1.41, 4: 1.34 ms).
+    constexpr int pf_ways = 2;
     // (only next to the batched task graph: at C5 -- blocked factorisation, GEMMs of 4096 tiles -- two streams cost 13.5 -> 14.5 ms)
     const int ways = (nl > 1 && chol_use_dag(ctx, mp / TILE, Bq / TILE + 1, 2)) ? std::min<int>(pf_ways, nl) : 1;
     if (ways > 1) {
       if (!pf_side[0]) {
         int lo = 0, hi = 0;
         HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        int pr = hi;
-        if (const char* e = getenv("AGP_PF_PRIORITY")) pr = e[0] == 'h' ? hi : e[0] == 'n' ? (lo + hi) / 2 : lo;
+        const int pr = hi;
         for (int q = 0; q < PF_SIDE; ++q) {
           HIPCHK(ctx, hipStreamCreateWithPriority(&pf_side[q], hipStreamNonBlocking, pr));
           HIPCHK(ctx, hipEventCreateWithFlags(&pf_join[q], hipEventDisableTiming));
@@ -3439,24 +3156,55 @@ struct Svgp : SvgpBase {
     *n = B_last;
     return AGP_OK;
   }
+  // k_elbo_terms is one instantiation per likelihood (no scratch under the 1024-thread register budget)
+  agp_status launch_elbo_terms(int64_t B, int nlat, const LikParams<T>& lk, int lat_off, int add_global, const T* yv,
+                               const int32_t* ycls, const int64_t* idx, const T* mf, const T* vf, const T* cv, const T* thv,
+                               const T* gv, const T* av, const T* bv, double* outp, int64_t ystr) {
+#define AGP_ELBO_CASE(K)                                                                                                        \
+  case K:                                                                                                                       \
+    hipLaunchKernelGGL((k_elbo_terms<T, K>), dim3(1), dim3(1024), 0, st(), B, nlat, Bp, lk, desc.elbo_mode, lat_off, add_global, \
+                       yv, ycls, idx, mf, vf, cv, thv, gv, av, bv, outp, ystr, (const T*)lam_dev, (int)shard_once);              \
+    break;
+    switch (lk.kind) {
+      AGP_ELBO_CASE(LIK_GAUSSIAN)
+      AGP_ELBO_CASE(LIK_LOGISTIC)
+      AGP_ELBO_CASE(LIK_STUDENTT)
+      AGP_ELBO_CASE(LIK_LSM)
+      AGP_ELBO_CASE(LIK_LAPLACE)
+      AGP_ELBO_CASE(LIK_BSVM)
+      AGP_ELBO_CASE(LIK_POISSON)
+      AGP_ELBO_CASE(LIK_NEGBIN)
+      AGP_ELBO_CASE(LIK_HETERO)
+      default:
+        ctx->err = "ELBO data terms: unknown likelihood kind";
+        return AGP_ERR_INVALID;
+    }
+#undef AGP_ELBO_CASE
+    LAUNCHCHK(ctx);
+    return AGP_OK;
+  }
   bool lsm_finished = false;  // k_lsm_fused has written theta, r, w of this step already
   agp_status lsm_local_all() override {
     if (lp.kind != AGP_LIK_LOGISTICSOFTMAX) return AGP_OK;
-    static const bool fuse = []() {
-      const char* e = getenv("AGP_LSM_FUSED");
-      return !(e && e[0] == '0');
-    }();
-    if (!fuse || nl > LSM_FUSED_MAXL) {
+    if (nl > LSM_FUSED_MAXL) {
       for (int it = 0; it < 2; ++it) {  // logisticsoftmax.jl:65
         AGPCHK(lsm_gamma());
         AGPCHK(lsm_alpha());
       }
       return AGP_OK;
     }
-    // 64 threads per workgroup: a 1024-point minibatch spreads over 16 CUs instead of 4 (the kernel is latency, not bandwidth)
-    hipLaunchKernelGGL((k_lsm_fused<T>), dim3((unsigned)((B_last + 63) / 64)), dim3(64), 0, st(), B_last, nl, Bp,
-                       desc.latent_offset, (T)rho_last, (const int32_t*)y_last, idx_last, (const T*)muf, (const T*)cbuf, alpha,
-                       (const T*)beta, gamma, gsum, theta, rbuf, wbuf, (int)desc.lik.n_class, flags_dev);
+    // one lane per (point, latent), LG = 2^ceil(log2 nl) lanes per point, 64 threads per workgroup: the 8 x 1024 values of a C4
+    // update spread over 128 workgroups (the kernel is latency, not bandwidth)
+#define AGP_LSM_LAUNCH(LG)                                                                                                   \
+  hipLaunchKernelGGL((k_lsm_fused<T, LG>), dim3((unsigned)((B_last * LG + 63) / 64)), dim3(64), 0, st(), B_last, nl, Bp,      \
+                     desc.latent_offset, (T)rho_last, (const int32_t*)y_last, idx_last, (const T*)muf, (const T*)cbuf, alpha, \
+                     (const T*)beta, gamma, gsum, theta, rbuf, wbuf, (int)desc.lik.n_class, flags_dev)
+    if (nl <= 1) AGP_LSM_LAUNCH(1);
+    else if (nl <= 2) AGP_LSM_LAUNCH(2);
+    else if (nl <= 4) AGP_LSM_LAUNCH(4);
+    else if (nl <= 8) AGP_LSM_LAUNCH(8);
+    else AGP_LSM_LAUNCH(16);
+#undef AGP_LSM_LAUNCH
     LAUNCHCHK(ctx);
     lsm_finished = true;
     return AGP_OK;
@@ -3542,22 +3290,13 @@ struct Svgp : SvgpBase {
         ctx->h_dirty[0].on = false;
       }
       const bool kg2 = tiles * nl <= kg2_limit() && Bq >= 4 * BK;
-      // tail split over all latents' tiles (syrk_tn_body): every latent cuts its last tiles into k-slices, one more launch finishes
-      const SyrkSplit sp = syrk_split_plan(ctx, kg2 ? (const void*)&k_syrk_eta_batch<T, 2> : (const void*)&k_syrk_eta_batch<T, 1>,
-                                           (kg2 ? 2 : 1) * NTHREADS, tiles, nl, Bq / BkOf<T>::v);
-      const int64_t nfull = tiles - sp.per_latent, npiece = sp.per_latent * sp.P;
-      if (npiece) AGPCHK(ensure_bal_ws(ctx, sizeof(T) * (size_t)npiece * nl * TILE * TILE));
-      T* ws = npiece ? (T*)ctx->bal_ws : (T*)nullptr;
-      dim3 grid((unsigned)(nfull + npiece + nrider + nfill), (unsigned)nl);
+      dim3 grid((unsigned)(tiles + nrider + nfill), (unsigned)nl);
       if (kg2)
         hipLaunchKernelGGL((k_syrk_eta_batch<T, 2>), grid, dim3(2 * NTHREADS), 0, st(), b, mp, Bq, mp, mp, lr, tiles, nrider, fillp,
-                           fused_used, fstride, fnb, nfull, sp.P, ws);
+                           fused_used, fstride, fnb);
       else
         hipLaunchKernelGGL((k_syrk_eta_batch<T, 1>), grid, dim3(NTHREADS), 0, st(), b, mp, Bq, mp, mp, lr, tiles, nrider, fillp,
-                           fused_used, fstride, fnb, nfull, sp.P, ws);
-      if (npiece)
-        hipLaunchKernelGGL((k_syrk_split_finish<T, SY_ETA2>), dim3((unsigned)sp.per_latent, (unsigned)nl), dim3(NTHREADS), 0, st(), b,
-                           mp, mp, lr, tiles, nfull, sp.P, (const T*)ws);
+                           fused_used, fstride, fnb);
       LAUNCHCHK(ctx);
       return AGP_OK;
     }
@@ -3604,7 +3343,7 @@ struct Svgp : SvgpBase {
     ProHost<T> ph{};
     bool use_pro = false;
     if (pend.on) {
-      use_pro = nl == 1 && pro_allowed() && chol_use_dag(ctx, mp / TILE, Bq / TILE + 1) && dag_fused_on() && !dag_trace_on() &&
+      use_pro = nl == 1 && pro_allowed() && chol_use_dag(ctx, mp / TILE, Bq / TILE + 1) &&
                 pend.Bq >= TILE && mp / TILE > 1;
       if (!use_pro) AGPCHK(flush());
     }
@@ -3836,12 +3575,10 @@ struct Svgp : SvgpBase {
                            (const T*)y, ystride, idx, mf, vf, mo_mixm, mo_mixv, mo_th, mo_cc, rbuf, wbuf, 0, qlo, nl);
       for (int t = 0; t < nT; ++t) {
         LikParams<T> lt{mocfg.kind[t], mocfg.p0[t], mocfg.p1[t]};
-        hipLaunchKernelGGL((k_elbo_terms<T>), dim3(1), dim3(1024), 0, st(), B, 1, Bp, lt, desc.elbo_mode, 0, 0,
-                           (const T*)y + t, (const int32_t*)nullptr, idx,
-                           (const T*)(mo_mixm + (int64_t)t * Bp), (const T*)(mo_mixv + (int64_t)t * Bp),
-                           (const T*)(mo_cc + (int64_t)t * Bp), (const T*)(mo_th + (int64_t)t * Bp), (const T*)nullptr,
-                           (const T*)nullptr, (const T*)nullptr, scal_dev + 8 + 2 * t, (int64_t)nT, (const T*)lam_dev,
-                           (int)shard_once);
+        AGPCHK(launch_elbo_terms(B, 1, lt, 0, 0, (const T*)y + t, (const int32_t*)nullptr, idx,
+                                 (const T*)(mo_mixm + (int64_t)t * Bp), (const T*)(mo_mixv + (int64_t)t * Bp),
+                                 (const T*)(mo_cc + (int64_t)t * Bp), (const T*)(mo_th + (int64_t)t * Bp), (const T*)nullptr,
+                                 (const T*)nullptr, (const T*)nullptr, scal_dev + 8 + 2 * t, (int64_t)nT));
       }
       LAUNCHCHK(ctx);
       std::vector<double> ht(2 * nT);
@@ -3854,11 +3591,9 @@ struct Svgp : SvgpBase {
       }
       if (fresh) HIPCHK(ctx, hipMemcpyAsync(mo_th, mo_th_save, sizeof(T) * MO_MAXT * Bp, hipMemcpyDeviceToDevice, st()));
     } else {
-      hipLaunchKernelGGL((k_elbo_terms<T>), dim3(1), dim3(1024), 0, st(), B, nl, Bp, lp, desc.elbo_mode,
-                         desc.latent_offset, (int)(desc.latent_offset == 0), (const T*)y, (const int32_t*)y, idx, mf, vf,
-                         (const T*)cbuf, (const T*)theta, (const T*)gamma, (const T*)alpha, (const T*)beta, scal_dev,
-                         (int64_t)1, (const T*)lam_dev, (int)shard_once);
-      LAUNCHCHK(ctx);
+      AGPCHK(launch_elbo_terms(B, nl, lp, desc.latent_offset, (int)(desc.latent_offset == 0), (const T*)y, (const int32_t*)y, idx,
+                               (const T*)mf, (const T*)vf, (const T*)cbuf, (const T*)theta, (const T*)gamma, (const T*)alpha,
+                               (const T*)beta, scal_dev, (int64_t)1));
     }
     if (fresh && lsm)
       HIPCHK(ctx, hipMemcpyAsync(alpha, alpha_save, sizeof(T) * Bp, hipMemcpyDeviceToDevice, st()));
@@ -4439,11 +4174,16 @@ struct Svgp : SvgpBase {
 
   // ---- multi-GPU drivers behind the ABI (include/agp_hip.h "multi-GPU") -----------------------
   agp_status comm_sum(agp_comm* cm, void* buf, int64_t count) {
-    static const bool force = []() {  // AGP_FORCE_SPLIT=1 (diagnostic): issue the collective of a one-rank communicator too
+    return comm_sum_typed(cm, buf, count, sizeof(T) == 8 ? AGP_F64 : AGP_F32, force_split());
+  }
+  // AGP_FORCE_SPLIT=1 (diagnostic): take the phase-split batch-parallel path (statistics -> all-reduce -> eta step) with a one-rank
+  // communicator too, and issue its collective, so that its cost next to the fused step can be measured on a single GPU
+  static bool force_split() {
+    static const bool on = []() {
       const char* e = getenv("AGP_FORCE_SPLIT");
       return e && e[0] == '1';
     }();
-    return comm_sum_typed(cm, buf, count, sizeof(T) == 8 ? AGP_F64 : AGP_F32, force);
+    return on;
   }
   agp_status comm_sum_typed(agp_comm* cm, void* buf, int64_t count, int dtype, bool force = false) {
     // (AGP_ALLOW_PARTIAL_SHARD=1: bench.py times ONE rank's share of the 16-latent model on a one-GPU box -- the other latents'
@@ -4465,13 +4205,11 @@ struct Svgp : SvgpBase {
     return agp_comm_allreduce(cm, buf, count, dtype);
   }
 
-  // block-column groups of the packed statistics for AGP_SPLIT_OVERLAP: AGP_SPLIT_OVERLAP_GROUPS (default 4, at most 8) groups of
-  // about equal tile count; group 0 also carries t (it sits in front of block column 0 in `stats`)
+  // block-column groups of the packed statistics for AGP_SPLIT_OVERLAP: four groups of about equal tile count (8 groups with a
+  // 112 us train measured the same step time); group 0 also carries t (it sits in front of block column 0 in `stats`)
   agp_status overlap_groups() {
     const int64_t nt = mp / TILE;
-    int want = 4;
-    if (const char* e = getenv("AGP_SPLIT_OVERLAP_GROUPS")) want = atoi(e);
-    want = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, 8), nt));
+    const int want = (int)std::max<int64_t>(1, std::min<int64_t>(4, nt));
     if (!arrive_dev) {
       HIPCHK(ctx, hipMalloc((void**)&arrive_dev, 8 * ARRIVE_STRIDE * sizeof(int32_t)));
       HIPCHK(ctx, hipMemsetAsync(arrive_dev, 0, 8 * ARRIVE_STRIDE * sizeof(int32_t), st()));
@@ -4501,13 +4239,7 @@ struct Svgp : SvgpBase {
   agp_status cavi_step_multi(agp_comm* cm, int mode, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B,
                              double rho) override {
     if (mode != AGP_SHARD_LATENT && mode != AGP_SHARD_BATCH) return AGP_ERR_INVALID;
-    // AGP_FORCE_SPLIT=1 (diagnostic): take the phase-split path (statistics -> all-reduce -> eta step) with a one-rank
-    // communicator too, so that its cost next to the fused step can be measured on a single GPU
-    static const bool force_split = []() {
-      const char* e = getenv("AGP_FORCE_SPLIT");
-      return e && e[0] == '1';
-    }();
-    const bool multi = cm && (cm->world > 1 || (force_split && mode == AGP_SHARD_BATCH));
+    const bool multi = cm && (cm->world > 1 || (force_split() && mode == AGP_SHARD_BATCH));
     adopt_batch_shard(cm, mode);
     const bool lam_lik = lp.kind == AGP_LIK_POISSON || lp.kind == AGP_LIK_HETEROSCEDASTIC ||
                          (lp.kind == AGP_LIK_GAUSSIAN && lp.noise_dev);  // likelihood state re-estimated from whole-minibatch sums
@@ -4530,7 +4262,7 @@ struct Svgp : SvgpBase {
       return !(e && e[0] == '0');
     }();
     const bool merge = split_merged && multi && mode == AGP_SHARD_BATCH && !lam_lik && nl == 1 && pro_allowed() &&
-                       chol_use_dag(ctx, mp / TILE, rup64(B) / TILE + 1, 1) && dag_fused_on() && !dag_trace_on();
+                       chol_use_dag(ctx, mp / TILE, rup64(B) / TILE + 1, 1);
     in_cavi_step = merge;
     const agp_status sl = step_local(x, ldx, y, idx, B, rho, false);
     in_cavi_step = false;
@@ -4538,7 +4270,7 @@ struct Svgp : SvgpBase {
     AGPCHK(sl);
     AGPCHK(run_deferred_safe());  // (the launch's fallback: the packed product below needs this step's r, w now)
     if (multi && lam_lik) {
-      AGPCHK(comm_sum_typed(cm, scal_dev + 60, 3, AGP_F64, force_split));
+      AGPCHK(comm_sum_typed(cm, scal_dev + 60, 3, AGP_F64, force_split()));
       AGPCHK(lambda_finish_reduced());
     }
     const bool lsm = lp.kind == AGP_LIK_LOGISTICSOFTMAX;
@@ -4797,7 +4529,6 @@ agp_status agp_ctx_destroy(agp_ctx* ctx) {
   }
   if (ctx->chain_go) (void)hipFree(ctx->chain_go);
   if (ctx->chain_ctr) (void)hipFree(ctx->chain_ctr);
-  if (ctx->chain_done) (void)hipEventDestroy(ctx->chain_done);
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -5045,7 +4776,6 @@ static agp_status bb_diag_bench(agp_ctx* ctx, int blocks, int reps, double* us) 
         e2m = std::max(e2m, std::abs(s2 - (i == j ? 1.0 : 0.0)));
         if (j > i) e3m = std::max(e3m, std::abs((double)Lh[i * TILE + j]) + std::abs((double)Xh[i * TILE + j]));
       }
-    if (getenv("AGP_DIAG_VERBOSE")) fprintf(stderr, "[diag_bench var=%d] |LL'-A|=%.3e |XL-I|=%.3e upper=%.3e\n", VAR, e1m, e2m, e3m);
     const double tol = sizeof(T) == 8 ? 1e-12 : 1e-4;
     if (!(e1m < tol) || !(e2m < tol) || e3m != 0.0) {
       ctx->err = "diag_bench residual check failed";

@@ -174,9 +174,10 @@ __global__ void k_scale_rows(const T* __restrict__ Y, int64_t ldy, int64_t p, in
 // SPEC 1: row-dot only (streaming prediction: no matrix output, not symmetric); SPEC 2: store only (Knm of the step: not
 // symmetric, no row-dot); SPEC 0: everything at run time.  The specialised forms drop the unused code and its registers.
 // (SPEC 3 keeps the symmetric / diagonal logic and spilled 14 registers under the 128-VGPR cap; a K_ZZ launch is one workgroup per CU
-//  anyway, so it is compiled for two)
+//  anyway, so it is compiled for two.  Round 5: the same for the general form SPEC 0 -- set-up launches, the ABI's agp_kernelmatrix,
+//  full predictive covariances --, whose fp64 instantiations carried 160 - 188 bytes of scratch per lane under that cap)
 template <typename T, int KIND, int SPEC = 0>
-__global__ __launch_bounds__(NTHREADS, (SPEC == 3 ? 2 : 4)) void k_kernelmatrix_mma(const T* __restrict__ X, int64_t ldx,
+__global__ __launch_bounds__(NTHREADS, ((SPEC == 3 || SPEC == 0) ? 2 : 4)) void k_kernelmatrix_mma(const T* __restrict__ X, int64_t ldx,
                                                                const int64_t* __restrict__ idx, int64_t n,
                                                                const T* __restrict__ Ysc, const T* __restrict__ yng,
                                                                int64_t p, int64_t D, int Dp, const T* __restrict__ scales,
@@ -383,6 +384,23 @@ __device__ __forceinline__ double digamma_d(double x) {
                        f * (-1.0 / 252.0 +
                             f * (1.0 / 240.0 + f * (-1.0 / 132.0 + f * (691.0 / 32760.0 + f * (-1.0 / 12.0)))))));
   return r + log(x) - 0.5 / x + t;
+}
+
+// log Gamma(x), x > 0: upward recurrence to x >= 10 (the product of the skipped factors, one log), then Stirling's series
+// (|abs err| < 2e-15 there; the last term kept is 1/(156 x^13) < 7e-16).  The device library's lgamma needs more than the 128
+// registers a 1024-thread workgroup has: the three ELBO kernels that call it per data point carried ~300 bytes of scratch per lane.
+__device__ __forceinline__ double lgamma_pos_d(double x) {
+  double p = 1.0;
+  while (x < 10.0) {
+    p *= x;
+    x += 1.0;
+  }
+  const double f = 1.0 / (x * x);
+  const double t = (1.0 / 12.0 +
+                    f * (-1.0 / 360.0 +
+                         f * (1.0 / 1260.0 +
+                              f * (-1.0 / 1680.0 + f * (1.0 / 1188.0 + f * (-691.0 / 360360.0 + f * (1.0 / 156.0))))))) / x;
+  return (x - 0.5) * log(x) - x + 0.91893853320467274178 + t - log(p);
 }
 
 // E[omega] for PG(1, c): tanh(c/2)/(2c), series 1/4 - c^2/48 near 0   (src/likelihood/logistic.jl:47-49)
@@ -810,56 +828,55 @@ __global__ void k_lsm_finish(int64_t B, int nl, int64_t ldb, int latent_offset, 
 
 // The whole local update of a handle that holds ALL latents of the model -- two rounds of (gamma, alpha) and the final theta, r, w
 // (k_lsm_gamma, k_lsm_alpha, k_lsm_gamma, k_lsm_alpha, k_lsm_finish) -- in one launch: the fixed point is per data point, and five
-// launches of four workgroups each cost the 8-class step ~55 us of an in-order queue.  Same operations in the same order per point
-// and latent as the separate kernels (which the latent-parallel driver keeps: its sum over latents crosses ranks), so the results
-// are bitwise the same.
+// launches of four workgroups each cost the 8-class step ~55 us of an in-order queue.
+// Round 5: one LANE per (point, latent) -- LG = the power of two >= nl consecutive lanes own one point -- instead of one lane per
+// point walking its latents out of per-thread arrays (196 - 668 bytes of scratch per lane, four workgroups for the whole C4 update,
+// 41 us): every lane evaluates its own gamma_k, the sum over the latents is taken with shuffles IN LATENT ORDER (k = 0, 1, ...), so
+// it is the sum k_lsm_gamma forms -- the same operations in the same order per point and latent as the separate kernels (which the
+// latent-parallel driver keeps: its sum over latents crosses ranks): bitwise the same results.  psi(alpha) is evaluated by every
+// lane of a point (same argument, same value).
 constexpr int LSM_FUSED_MAXL = 16;
-template <typename T>
-__global__ void k_lsm_fused(int64_t B, int nl, int64_t ldb, int latent_offset, T rho, const int32_t* __restrict__ ycls,
-                            const int64_t* __restrict__ idx, const T* __restrict__ muf, const T* __restrict__ c,
-                            T* __restrict__ alpha, const T* __restrict__ beta, T* __restrict__ gamma, T* __restrict__ gsum,
-                            T* __restrict__ theta, T* __restrict__ r, T* __restrict__ w, int n_class, int* __restrict__ flags) {
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= B) return;
-  double hm[LSM_FUSED_MAXL], hc[LSM_FUSED_MAXL];
-  T cc[LSM_FUSED_MAXL], gam[LSM_FUSED_MAXL];
-#pragma unroll
-  for (int k = 0; k < LSM_FUSED_MAXL; ++k)
-    if (k < nl) {
-      cc[k] = c[k * ldb + i];
-      hm[k] = -0.5 * (double)muf[k * ldb + i];
-      hc[k] = 0.5 * (double)cc[k];
-    }
-  T a = alpha[i], gs = T(0);
+template <typename T, int LG>
+__global__ void __launch_bounds__(256)
+k_lsm_fused(int64_t B, int nl, int64_t ldb, int latent_offset, T rho, const int32_t* __restrict__ ycls,
+            const int64_t* __restrict__ idx, const T* __restrict__ muf, const T* __restrict__ c, T* __restrict__ alpha,
+            const T* __restrict__ beta, T* __restrict__ gamma, T* __restrict__ gsum, T* __restrict__ theta, T* __restrict__ r,
+            T* __restrict__ w, int n_class, int* __restrict__ flags) {
+  static_assert(LG >= 1 && LG <= LSM_FUSED_MAXL && (LG & (LG - 1)) == 0, "lanes per point: a power of two <= 16");
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t i_raw = t / LG;
+  const int k = (int)(t % LG);
+  const bool pt = i_raw < B;            // every lane stays in the shuffles; lanes beyond B / nl compute on clamped operands
+  const bool on = pt && k < nl;
+  const int64_t i = pt ? i_raw : B - 1;
+  const int kk = k < nl ? k : nl - 1;
+  const int lane = threadIdx.x & 63, base = lane & ~(LG - 1);
+  const T cc = c[kk * ldb + i];
+  const double hm = -0.5 * (double)muf[kk * ldb + i], hc = 0.5 * (double)cc;
+  T a = alpha[i], gs = T(0), gam = T(0);
   const double b2 = 2.0 * (double)beta[i];
   for (int it = 0; it < 2; ++it) {  // logisticsoftmax.jl:65
     const double epsi = exp(digamma_d((double)a));
+    const double g = epsi * safe_expcosh_d(hm, hc) / b2;
+    gam = (T)g;
     double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < LSM_FUSED_MAXL; ++k)
-      if (k < nl) {
-        const double g = epsi * safe_expcosh_d(hm[k], hc[k]) / b2;
-        gam[k] = (T)g;
-        s += g;
-      }
+    for (int q = 0; q < nl; ++q) s += __shfl(g, base + q);  // latent order: the sum of k_lsm_gamma
     gs = (T)s;
     a = T(1) + gs;
   }
-  alpha[i] = a;
-  gsum[i] = gs;
+  if (!on) return;
   const int cls = ycls[idx ? idx[i] : i];
-  if (cls < 0 || cls >= n_class) atomicOr(flags, FLAG_BAD_LABEL);
-#pragma unroll
-  for (int k = 0; k < LSM_FUSED_MAXL; ++k)
-    if (k < nl) {
-      const T yk = (cls == latent_offset + k) ? T(1) : T(0);
-      const T g = gam[k];
-      const T th = (yk + g) * theta_pg<T>(cc[k]);
-      gamma[k * ldb + i] = g;
-      theta[k * ldb + i] = th;
-      r[k * ldb + i] = rho * (yk - g) / T(2);
-      w[k * ldb + i] = rho * th / T(2);
-    }
+  if (k == 0) {
+    alpha[i] = a;
+    gsum[i] = gs;
+    if (cls < 0 || cls >= n_class) atomicOr(flags, FLAG_BAD_LABEL);
+  }
+  const T yk = (cls == latent_offset + k) ? T(1) : T(0);
+  const T th = (yk + gam) * theta_pg<T>(cc);
+  gamma[k * ldb + i] = gam;
+  theta[k * ldb + i] = th;
+  r[k * ldb + i] = rho * (yk - gam) / T(2);
+  w[k * ldb + i] = rho * th / T(2);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -887,7 +904,8 @@ __device__ __forceinline__ T lik_g1(int kind, T p0, T yi, T thv) {
 // mixed mean_f / var_f (lines 24-45), per-task local updates, mixed gradients (lines 48-84):
 //   r_q = rho sum_t A_tq (g1_t - 2 g2_t (m_t - A_tq mu_q)) ; w_q = rho sum_t A_tq^2 g2_t
 template <typename T>
-__global__ void k_mo_local(int64_t B, int Q, int64_t ldb, MoCfg<T> cfg, const T* __restrict__ A, T rho,
+__global__ void __launch_bounds__(256)  // (launched with 256 threads; the default 1024-thread budget of 128 registers spilled 716 B per lane in fp32)
+k_mo_local(int64_t B, int Q, int64_t ldb, MoCfg<T> cfg, const T* __restrict__ A, T rho,
                            const T* __restrict__ y, int64_t ystride, const int64_t* __restrict__ idx,
                            const T* __restrict__ muf, const T* __restrict__ varf, T* __restrict__ mixm,
                            T* __restrict__ mixv, T* __restrict__ th, T* __restrict__ cc, T* __restrict__ r,
@@ -1194,21 +1212,41 @@ __global__ void k_copy2d(const T* __restrict__ src, int64_t lds, int64_t rs, int
 // LogisticSoftMax: sums over the nl local latents; the GammaEntropy term and nothing else is global and is added
 // only when add_global != 0 (latent_offset == 0 rank).  elbo_ref != 0 reproduces logistic.jl:82 (dot(theta, mu)).
 // ---------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void k_elbo_terms(int64_t B, int nl, int64_t ldb, LikParams<T> lp, int elbo_ref, int latent_offset,
-                             int add_global, const T* __restrict__ y, const int32_t* __restrict__ ycls,
-                             const int64_t* __restrict__ idx, const T* __restrict__ muf, const T* __restrict__ varf,
-                             const T* __restrict__ c, const T* __restrict__ theta, const T* __restrict__ gamma,
-                             const T* __restrict__ alpha, const T* __restrict__ beta, double* __restrict__ out,
-                             int64_t ystr, const T* __restrict__ lam, int once) {
+// Round 5: one instantiation per likelihood (KIND) -- the single kernel with every likelihood's branch in its loop body compiled to
+// 636 bytes of scratch per lane (lgamma + digamma + nine branches under a 1024-thread register budget); per-launch constants
+// (lgamma / digamma of the Student-t shape parameters, logs of fixed parameters) are hoisted out of the loop over the points.
+template <typename T, int KIND>
+__global__ void __launch_bounds__(1024)
+k_elbo_terms(int64_t B, int nl, int64_t ldb, LikParams<T> lp, int elbo_ref, int latent_offset, int add_global,
+             const T* __restrict__ y, const int32_t* __restrict__ ycls, const int64_t* __restrict__ idx,
+             const T* __restrict__ muf, const T* __restrict__ varf, const T* __restrict__ c, const T* __restrict__ theta,
+             const T* __restrict__ gamma, const T* __restrict__ alpha, const T* __restrict__ beta, double* __restrict__ out,
+             int64_t ystr, const T* __restrict__ lam, int once) {
   // once = 0 on the minibatch shards of a batch-parallel run other than the first: the reference's once-per-evaluation terms
   // (not sums over points) must enter the all-reduced ELBO a single time
   __shared__ double red[16];
   double e = 0.0, kl = 0.0;
-  const double LOG2 = 0.69314718055994530942, LOG2PI = 1.83787706640934548356, LOGPI = 1.14472988584940017414;
-  const double lamv = (lp.kind == LIK_POISSON || lp.kind == LIK_HETERO) ? (double)lam[0] : 1.0;
+  constexpr double LOG2 = 0.69314718055994530942, LOG2PI = 1.83787706640934548356, LOGPI = 1.14472988584940017414;
+  const double lamv = (KIND == LIK_POISSON || KIND == LIK_HETERO) ? (double)lam[0] : 1.0;
+  // per-launch constants
+  double k0 = 0.0, k1 = 0.0, k2 = 0.0, k3 = 0.0;
+  if constexpr (KIND == LIK_STUDENTT) {
+    const double nu = (double)lp.p0, sig = (double)lp.p1;
+    const double al = 0.5 * (nu + 1.0), alp = 0.5 * nu, bp = alp * sig * sig;
+    k0 = -0.5 * log(2.0 * 3.14159265358979323846 * sig * sig);
+    k1 = digamma_d(al);
+    k2 = (al - alp) * k1 - lgamma(al) + lgamma(alp);
+    k3 = log(bp);
+  } else if constexpr (KIND == LIK_GAUSSIAN) {
+    k0 = lp.noise_dev ? (double)lam[0] : (double)lp.p0;
+    k1 = log(k0);
+  } else if constexpr (KIND == LIK_NEGBIN) {
+    k0 = lgamma((double)lp.p0);
+  } else if constexpr (KIND == LIK_POISSON || KIND == LIK_HETERO) {
+    k0 = log(lamv);
+  }
   for (int64_t i = threadIdx.x; i < B; i += blockDim.x) {
-    if (lp.kind == LIK_LSM) {
+    if constexpr (KIND == LIK_LSM) {
       int cls = ycls[idx ? idx[i] : i];
       double a = (double)alpha[i], b = (double)beta[i];
       double psi = digamma_d(a);
@@ -1221,28 +1259,27 @@ __global__ void k_elbo_terms(int64_t B, int nl, int64_t ldb, LikParams<T> lp, in
         kl += (yk + g) * logcosh_d(0.5 * cc) - 0.5 * cc * cc * th;          // PolyaGammaKL
         kl += lam0 - g + (g > 0.0 ? g * log(g) : 0.0) - g * psil;           // PoissonKL
       }
-      if (add_global) kl += -a - lgamma(a) - (1.0 - a) * psi;               // GammaEntropy (sum parts)
-    } else if (lp.kind == LIK_HETERO) {  // heteroscedastic.jl:142-179 ; layout as in k_hetero_local
+      if (add_global) kl += -a - lgamma_pos_d(a) - (1.0 - a) * psi;               // GammaEntropy (sum parts)
+    } else if constexpr (KIND == LIK_HETERO) {  // heteroscedastic.jl:142-179 ; layout as in k_hetero_local
       double yi = (double)y[(idx ? idx[i] : i) * ystr];
       double m0 = (double)muf[i], s0 = (double)varf[i], m1 = (double)muf[ldb + i], s1 = (double)varf[ldb + i];
       double g = (double)gamma[i], th = (double)theta[ldb + i], cc = (double)c[ldb + i];
       double lam0 = lamv * ((yi - m0) * (yi - m0) + s0) / 2.0;
-      e += 0.5 * log(lamv) - log(2.0 * sqrt(2.0 * 3.14159265358979323846));
+      e += 0.5 * k0 - log(2.0 * sqrt(2.0 * 3.14159265358979323846));
       e += 0.5 * (m1 * (0.5 - g) - m1 * m1 * th - s1 * th);
       e -= lam0 - g + (g > 0.0 ? g * log(g) : 0.0) - g * log(lam0);  // PoissonKL(gamma, lam0, log lam0)
       kl += (0.5 + g) * logcosh_d(0.5 * cc) - 0.5 * cc * cc * th;
     } else {
       double yi = (double)y[(idx ? idx[i] : i) * ystr];
       double mu = (double)muf[i], s = (double)varf[i];
-      if (lp.kind == LIK_GAUSSIAN) {
-        double s2 = lp.noise_dev ? (double)lam[0] : (double)lp.p0;
-        e += -0.5 * (LOG2PI + log(s2) + ((yi - mu) * (yi - mu) + s) / s2);
-      } else if (lp.kind == LIK_LOGISTIC) {
+      if constexpr (KIND == LIK_GAUSSIAN) {
+        e += -0.5 * (LOG2PI + k1 + ((yi - mu) * (yi - mu) + s) / k0);
+      } else if constexpr (KIND == LIK_LOGISTIC) {
         double th = (double)theta[i], cc = (double)c[i];
         double quad = elbo_ref ? th * mu : th * mu * mu;
         e += -0.5 * LOG2 + 0.5 * (mu * yi - th * s - quad);
         kl += logcosh_d(0.5 * cc) - 0.5 * cc * cc * th;
-      } else if (lp.kind == LIK_LAPLACE) {
+      } else if constexpr (KIND == LIK_LAPLACE) {
         // laplace.jl:93-123 ; GIGEntropy (KLdivergences.jl:105-113) at p = 1/2 in closed form:
         //   log(2 K_1/2(s)) = log2 + (log(pi/2) - log s)/2 - s ;  s (K_3/2 + K_-1/2) / (2 K_1/2) = s + 1/2
         // elbo_ref keeps the reference's scalar-iteration quirks: log(a) counted once, log(2 K_p) of the first point only
@@ -1255,34 +1292,35 @@ __global__ void k_elbo_terms(int64_t B, int nl, int64_t ldb, LikParams<T> lp, in
         else ent += 0.5 * log(a) + l2k;
         double expo = -log(2.0 * be * be) - 0.5 * (a * b + b * b * sqrt(a)) / (a * b * b * be * be);
         kl += ent - expo;
-      } else if (lp.kind == LIK_BSVM) {  // bayesiansvm.jl:71-92 ; elbo_ref: + theta (1 - y mu)^2 as written in line 81
+      } else if constexpr (KIND == LIK_BSVM) {  // bayesiansvm.jl:71-92 ; elbo_ref: + theta (1 - y mu)^2 as written in line 81
         double th = (double)theta[i], cc = (double)c[i], d = 1.0 - yi * mu, sc = sqrt(cc);
         e += -0.5 * LOG2 + mu * yi - 0.5 * th * s + (elbo_ref ? th * d * d : -0.5 * th * d * d);
         kl += 0.5 * log(cc) + (LOG2 + 0.5 * (LOGPI - LOG2 - log(sc)) - sc) - 0.5 * sc;
-      } else if (lp.kind == LIK_POISSON) {  // poisson.jl:106-132
+      } else if constexpr (KIND == LIK_POISSON) {  // poisson.jl:106-132
         double th = (double)theta[i], cc = (double)c[i], g = (double)gamma[i];
-        e += 0.5 * (mu * (yi - g) - th * mu * mu - th * s) + yi * log(lamv) - lgamma(yi + 1.0) - LOG2 * (yi + g);
-        kl += lamv - (1.0 + log(lamv)) * g + (g > 0.0 ? g * log(g) : 0.0);      // PoissonKL(gamma, lambda)
+        e += 0.5 * (mu * (yi - g) - th * mu * mu - th * s) + yi * k0 - lgamma_pos_d(yi + 1.0) - LOG2 * (yi + g);
+        kl += lamv - (1.0 + k0) * g + (g > 0.0 ? g * log(g) : 0.0);             // PoissonKL(gamma, lambda)
         kl += (yi + g) * logcosh_d(0.5 * cc) - 0.5 * cc * cc * th;              // PolyaGammaKL(y + gamma, c, theta)
-      } else if (lp.kind == LIK_NEGBIN) {  // negativebinomial.jl:103-131 ; elbo_ref: dot(theta, mu) as written in line 125
+      } else if constexpr (KIND == LIK_NEGBIN) {  // negativebinomial.jl:103-131 ; elbo_ref: dot(theta, mu) as written in line 125
         double th = (double)theta[i], cc = (double)c[i], rr = (double)lp.p0;
-        e += lgamma(yi + rr) - lgamma(yi + 1.0) - lgamma(rr) - LOG2 * (yi + rr);
+        e += lgamma_pos_d(yi + rr) - lgamma_pos_d(yi + 1.0) - k0 - LOG2 * (yi + rr);
         e += 0.5 * mu * (yi - rr) - 0.5 * (elbo_ref ? th * mu : th * mu * mu) - 0.5 * th * s;
         kl += (yi + rr) * logcosh_d(0.5 * cc) - 0.5 * cc * cc * th;
-      } else {
-        double nu = (double)lp.p0, sig = (double)lp.p1;
-        double al = 0.5 * (nu + 1.0), alp = 0.5 * nu, bp = alp * sig * sig;
+      } else {  // Student-t, studentt.jl:103-127
+        static_assert(KIND == LIK_STUDENTT, "k_elbo_terms: unknown likelihood");
+        const double nu = (double)lp.p0, sig = (double)lp.p1;
+        const double al = 0.5 * (nu + 1.0), alp = 0.5 * nu, bp = alp * sig * sig;
         double th = (double)theta[i], cc = (double)c[i];
-        e += -0.5 * log(2.0 * 3.14159265358979323846 * sig * sig) - (log(cc) - digamma_d(al)) -
-             0.5 * (th * s + th * mu * mu - 2.0 * th * mu * yi + th * yi * yi);
-        kl += (al - alp) * digamma_d(al) - lgamma(al) + lgamma(alp) + alp * (log(cc) - log(bp)) + al * (bp - cc) / cc;
+        const double lc = log(cc);
+        e += k0 - (lc - k1) - 0.5 * (th * s + th * mu * mu - 2.0 * th * mu * yi + th * yi * yi);
+        kl += k2 + alp * (lc - k3) + al * (bp - cc) / cc;
       }
     }
   }
   e = block_sum<double>(e, red);
   kl = block_sum<double>(kl, red);
   if (threadIdx.x == 0) {
-    if (lp.kind == LIK_LSM && add_global && once) kl += log((double)beta[0]);  // sum(log, first(beta)) (Q16)
+    if (KIND == LIK_LSM && add_global && once) kl += log((double)beta[0]);  // sum(log, first(beta)) (Q16)
     out[0] = e;
     out[1] = kl;
   }

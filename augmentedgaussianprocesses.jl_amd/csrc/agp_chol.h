@@ -1434,8 +1434,13 @@ struct ChainPrefetch {
   bool coh = false;  // the chain runs as a kernel of its own: its plain stores would only become visible when THAT kernel ends
   T v[TILE * TILE / 256];
   __device__ __forceinline__ void operator()(int round) {
-    const int t = (int)threadIdx.x - 256;
+    int t = (int)threadIdx.x - 256;
     if (t < 0) return;
+    // (opaque to the optimiser: otherwise the LDS offsets (e >> 6) * LDP + (e & 63) of all sixteen e = t + 256 q are hoisted out of
+    //  the chain's loop and live through every tile factorisation -- the launch with prologue and identity rows, at the 256-register
+    //  cap of a 512-thread workgroup, spilled two of them to scratch)
+    // fp64 only: the fp32 launches are far from their cap, and their register allocation is left as it was.
+    if (sizeof(T) == 8) asm volatile("" : "+v"(t));
     if (round < 2) {  // L_{k-1,k-1} -> Dg, off the critical path (plain stores, read by later kernels only)
       if (dgsrc) {
 #pragma unroll

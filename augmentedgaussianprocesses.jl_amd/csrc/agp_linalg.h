@@ -120,7 +120,7 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_gemm_nt_eminus_sym(const T* _
 //              xGMI; nt = ldo / 64)
 enum { SY_STORE = 0, SY_ETA2 = 1, SY_PACK = 2 };
 
-// what a finished tile (ta, tb) of S does, by mode (shared by the product kernels and by k_syrk_split_finish)
+// what a finished tile (ta, tb) of S does, by mode
 template <typename T, int MODE>
 __device__ __forceinline__ void syrk_epilogue(Acc<T>& acc, int64_t ta, int64_t tb, T* __restrict__ out, int64_t ldo,
                                               T* __restrict__ eta2, const T* __restrict__ Kinv, int64_t ldm, T lr) {
@@ -155,23 +155,17 @@ __device__ __forceinline__ void syrk_epilogue(Acc<T>& acc, int64_t ta, int64_t t
   }
 }
 
-// Tail split (round 4).  A launch of ntri tiles on S workgroup slots runs ceil(ntri / S) rounds and the last one may be nearly
-// empty: 528 tiles on 512 slots (C3: m = 2048 fp32, two 512-thread workgroups per CU) take two rounds for 1.03 rounds of work --
-// the 138 us of k_syrk_tn<float> at C3.  The host therefore gives the LAST ntri - nfull tiles (the remainder of ntri / S) to P
-// workgroups each, a slice of the k range per workgroup, placed behind the full tiles in the grid: they are dispatched as the
-// full tiles of the last round retire and fill the tail.  Their partial tiles go to `ws` (thread-major, piece by piece) and a
-// second, small launch (k_syrk_split_finish) adds them in piece order and applies the mode's epilogue.
-//   workgroups [0, nfull): full tiles | [nfull, nfull + (ntri - nfull) P): pieces | riders | hand-over refill
+// workgroups of a launch: [0, ntri): lower tiles | riders (eta1 step) | hand-over refill.  (A tail split of multi-round launches --
+// the remainder tiles of the last round as k-slices behind the full tiles, finished by a second launch -- was built and measured in
+// round 4 and removed in round 5: C3 141 -> 144 us + the finishing launch; docs/DESIGN_LOG.md section 12.)
 template <typename T, int MODE, int KG = 1>
 __device__ __forceinline__ void syrk_tn_body(const T* __restrict__ A, int64_t lda, int64_t Kdim, const T* __restrict__ w,
                                              int lower_a, T* __restrict__ out, int64_t ldo, T* __restrict__ eta2,
                                              const T* __restrict__ Kinv, int64_t ldm, T lr, int64_t ntri_,
                                              const T* __restrict__ rvec, T* __restrict__ eta1,
                                              const T* __restrict__ kinv_mu0, int64_t nrider, T* __restrict__ fillp,
-                                             int64_t fill_used, int64_t fill_stride, int fill_nb, T* smem, int64_t nfull = -1,
-                                             int P = 1, T* __restrict__ ws = nullptr) {
-  if (nfull < 0) nfull = ntri_;
-  const int64_t ntri = nfull + (ntri_ - nfull) * P;  // tile workgroups of this launch (full tiles + pieces)
+                                             int64_t fill_used, int64_t fill_stride, int fill_nb, T* smem) {
+  const int64_t ntri = ntri_;
   if (fillp && (int64_t)blockIdx.x >= ntri + nrider) {
     // second kind of rider: refill the hand-over slots the factorisation before this launch wrote (agp_chol.h, "self-validating
     // hand-over") with the sentinel, in the shadow of the tile workgroups -- half the chip is idle during this launch anyway
@@ -208,32 +202,13 @@ __device__ __forceinline__ void syrk_tn_body(const T* __restrict__ A, int64_t ld
   // (launch order = row-major triangle order.  An XCD-aware order -- contiguous id ranges per XCD over 4 x 4 blocks of tiles --
   // was measured: 25 % less fabric traffic, but the f32 m = 2048 product got 9 % SLOWER and f64 m = 1024 did not move; the
   // operands sit in the Infinity Cache either way, and with the plain order all XCDs stream the same panels at the same time)
-  const bool piece = (int64_t)blockIdx.x >= nfull;
-  const int64_t pj = piece ? (int64_t)blockIdx.x - nfull : 0;  // piece pj % P of split tile pj / P
   int64_t ta, tb;
-  tri_index(piece ? nfull + pj / P : (int64_t)blockIdx.x, ta, tb);
+  tri_index((int64_t)blockIdx.x, ta, tb);
   const int64_t a0 = ta * TILE, b0 = tb * TILE;
   Acc<T> acc;
   acc.zero();
-  int64_t kBegin = lower_a ? a0 : 0, kEnd = Kdim;
-  if (piece) {  // slice pj % P of the tile's slabs (whole slabs; the last slices may be empty)
-    constexpr int BKT = BkOf<T>::v;
-    const int64_t nslab = (Kdim - kBegin) / BKT, per = (nslab + P - 1) / P, s0 = (pj % P) * per;
-    kEnd = kBegin + ((s0 + per < nslab) ? (s0 + per) : nslab) * BKT;
-    kBegin += (s0 < nslab ? s0 : nslab) * BKT;
-  }
-  gemm_tile<T, RC, RC, KG>(A + a0, lda, A + b0, lda, kBegin, kEnd, w, acc, smem);
+  gemm_tile<T, RC, RC, KG>(A + a0, lda, A + b0, lda, lower_a ? a0 : 0, Kdim, w, acc, smem);
   if (KG > 1 && threadIdx.x >= NTHREADS) return;
-  if (piece) {
-    T* wp = ws + pj * (TILE * TILE);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) wp[((mi * 2 + ni) * 4 + q) * NTHREADS + threadIdx.x] = acc.a[mi][ni][q];
-    return;
-  }
   syrk_epilogue<T, MODE>(acc, ta, tb, out, ldo, eta2, Kinv, ldm, lr);
 }
 
@@ -245,14 +220,13 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_syrk_tn(const T* __restrict__
                                                       const T* __restrict__ rvec = nullptr, T* __restrict__ eta1 = nullptr,
                                                       const T* __restrict__ kinv_mu0 = nullptr, int64_t nrider = 0,
                                                       T* __restrict__ fillp = nullptr, int64_t fill_used = 0,
-                                                      int64_t fill_stride = 0, int fill_nb = 0, int64_t nfull = -1, int P = 1,
-                                                      T* __restrict__ ws = nullptr) {
+                                                      int64_t fill_stride = 0, int fill_nb = 0) {
   // KG = 4 in f64 takes ALL of gfx950's 160 KB of LDS (4 x 40 KB staging areas): nothing else in this kernel may be __shared__,
   // and the instantiation does not exist for smaller-LDS targets
   static_assert((size_t)KG * smem_elems<T>() * sizeof(T) <= 160 * 1024, "k_syrk_tn: staging areas exceed the 160 KB LDS of gfx950");
   __shared__ __attribute__((aligned(16))) T smem[KG * smem_elems<T>()];
   syrk_tn_body<T, MODE, KG>(A, lda, Kdim, w, lower_a, out, ldo, eta2, Kinv, ldm, lr, ntri, rvec, eta1, kinv_mu0, nrider, fillp,
-                            fill_used, fill_stride, fill_nb, smem, nfull, P, ws);
+                            fill_used, fill_stride, fill_nb, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -396,42 +370,14 @@ template <typename T, int KG>
 __global__ __launch_bounds__(NTHREADS * KG) void k_syrk_eta_batch(SyrkBatch<T> b, int64_t lda, int64_t Kdim, int64_t ldo,
                                                              int64_t ldm, T lr, int64_t ntri, int64_t nrider,
                                                              T* __restrict__ fillp, int64_t fill_used,
-                                                             int64_t fill_stride, int fill_nb, int64_t nfull = -1, int P = 1,
-                                                             T* __restrict__ ws = nullptr) {
+                                                             int64_t fill_stride, int fill_nb) {
   __shared__ __attribute__((aligned(16))) T smem[KG * smem_elems<T>()];
   const int q = blockIdx.y;
   // the hand-over refill riders exist once (in the slice of latent 0)
-  const int64_t nwg = nfull < 0 ? ntri : nfull + (ntri - nfull) * P;
-  if (q != 0 && (int64_t)blockIdx.x >= nwg + nrider) return;
-  // (every latent splits its own last ntri - nfull tiles; its pieces live at ws + q (ntri - nfull) P tiles)
+  if (q != 0 && (int64_t)blockIdx.x >= ntri + nrider) return;
   syrk_tn_body<T, SY_ETA2, KG>(b.A[q], lda, Kdim, b.w[q], 0, b.out[q], ldo, b.eta2[q], b.Kinv[q], ldm, lr, ntri, b.rvec[q],
                                b.eta1[q], b.kinv_mu0[q], nrider, q == 0 ? fillp : (T*)nullptr, fill_used, fill_stride, fill_nb,
-                               smem, nfull, P, ws ? ws + (int64_t)q * (ntri - nfull) * P * (TILE * TILE) : (T*)nullptr);
-}
-
-// second launch of a split product: workgroup (j, q) adds the P partial tiles of latent q's split tile nfull + j in piece order and
-// applies the mode's epilogue.  grid = (ntri - nfull, n_latent), 256 threads.
-template <typename T, int MODE>
-__global__ __launch_bounds__(NTHREADS) void k_syrk_split_finish(SyrkBatch<T> b, int64_t ldo, int64_t ldm, T lr, int64_t ntri,
-                                                                int64_t nfull, int P, const T* __restrict__ ws) {
-  const int q = blockIdx.y;
-  int64_t ta, tb;
-  tri_index(nfull + blockIdx.x, ta, tb);
-  const T* w0 = ws + (((int64_t)q * (ntri - nfull) + blockIdx.x) * P) * (TILE * TILE) + threadIdx.x;
-  Acc<T> acc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    T v = T(0);
-    int p = 0;
-    for (; p + 4 <= P; p += 4) {  // four loads in flight, added in piece order
-      const T x0 = w0[(int64_t)p * (TILE * TILE) + e * NTHREADS], x1 = w0[(int64_t)(p + 1) * (TILE * TILE) + e * NTHREADS];
-      const T x2 = w0[(int64_t)(p + 2) * (TILE * TILE) + e * NTHREADS], x3 = w0[(int64_t)(p + 3) * (TILE * TILE) + e * NTHREADS];
-      v = (((v + x0) + x1) + x2) + x3;
-    }
-    for (; p < P; ++p) v += w0[(int64_t)p * (TILE * TILE) + e * NTHREADS];
-    acc.a[e >> 3][(e >> 2) & 1][e & 3] = v;
-  }
-  syrk_epilogue<T, MODE>(acc, ta, tb, b.out[q], ldo, b.eta2[q], b.Kinv[q], ldm, lr);
+                               smem);
 }
 
 // eta2 step from an already reduced statistic S (batch-parallel multi-GPU path: S was all-reduced), stored as packed lower

@@ -199,6 +199,29 @@ def _hyper_products(m, B):
             "list": [r[0] for r in rows]}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it (the shape of the driver's N = 1 command): re-run this script under
+    torch.distributed.run, one rank per GPU of this node, rendezvous on 127.0.0.1.  Rank 0's JSON line goes to our stdout, every
+    rank's stderr to ours; returns the launcher's exit code."""
+    import socket
+    import subprocess
+
+    if os.environ.get("AGP_BENCH_SHARE_GPU") != "1":
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"[bench] --gpus {n} but this node shows {have} GPU(s)", file=sys.stderr)
+            return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] starting", n, "ranks:", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     # c5 on one GPU times the share of ONE rank of the 8-GPU run (a latent slice without its communicator): the library refuses
     # that by default (the mixes are partial), the benchmark asks for it explicitly
@@ -207,9 +230,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU) and hand over to them
+        raise SystemExit(launch_ranks(a.gpus))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N ...` (starts its own "
+                         "ranks) or `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
+                         "--master-port P bench.py --gpus N ...`")
     # test hook: AGP_BENCH_SHARE_GPU=1 maps every rank to GPU 0 and uses gloo + the callback transport, so the N > 1 code path
     # can be exercised on a single-GPU box (never set by the driver; numbers from such a run are meaningless)
     share = os.environ.get("AGP_BENCH_SHARE_GPU") == "1"
@@ -560,9 +587,17 @@ def main():
         out["value_definition"] = ("batch-parallel weak scaling: one step consumes the global minibatch of B x n_gpus points and counts "
                                    "as n_gpus minibatch-iterations; global steps/s = value / n_gpus" if mode == "batch" else
                                    "latent-parallel: one step of the whole model (all latents) counts as one iteration")
+        # how many ranks the communicator of the data path really spans: every rank contributes 1.0 to a one-element all-reduce
+        # issued through that very communicator (agp_comm_allreduce), outside the timed region
+        one = torch.ones(1, dtype=torch.float64, device=dev)
+        comm.all_reduce(one)
+        torch.cuda.synchronize()
         out["collective"] = {
+            "issuer": coll,
             "issued_by": coll,
+            "ranks_seen": int(round(float(one.item()))),
             "calls_per_step": round(ncalls / max(steps, 1), 2),
+            "bytes_per_step": int(nbytes / max(steps, 1)),
             "bytes_allreduced_per_step_per_rank": int(nbytes / max(steps, 1)),
             "us_per_step": round(cms * 1e3 / max(steps, 1), 2),
             "us_per_call": round(cms * 1e3 / max(ncalls, 1), 2),

@@ -24,3 +24,31 @@ def test_bench_line_with_short_runs(built, steps, warmup):
         assert k in d["roofline"]
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
     assert d["ms_per_step_with_hyper_update"] > 0 and d["hyper_roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("config,extra", [("c2", []), ("c4", ["--m", "256", "--batch", "256", "--N", "20000"])])
+def test_bench_starts_its_own_ranks(built, config, extra):
+    """`python bench.py --gpus 2` -- the shape of the driver's command, no launcher around it -- starts two ranks itself
+    (torch.distributed.run, 127.0.0.1) and rank 0 prints the ONE line.  AGP_BENCH_SHARE_GPU=1 puts both ranks on GPU 0 (gloo + the
+    callback transport): the N > 1 code path of bench.py through agp_svgp_cavi_step_multi, batch-parallel (c2: the packed
+    statistic of analyticVI.jl:168,179 all-reduced, with the split-overlap A/B) and latent-parallel (c4)."""
+    env = dict(os.environ, AGP_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--config", config,
+                        "--no-cpu-baseline", "--no-elbo-tol", "--no-extras"] + extra, capture_output=True, text=True, timeout=1500,
+                       cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["metric"] == "cavi_iters_per_sec" and d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    c = d["collective"]
+    assert c["ranks_seen"] == 2 and c["issuer"] and c["us_per_call"] >= 0
+    if config == "c2":
+        assert d["scaling"] == "weak" and d["config"]["global_batch"] == 2048
+        mp = 1024
+        assert c["bytes_per_step"] == 8 * (mp + (mp // 64) * (mp // 64 + 1) // 2 * 4096) and c["calls_per_step"] == 1
+        assert c["split_overlap_ab"]["AGP_SPLIT_OVERLAP"] == 1 and c["split_overlap_ab"]["ms_per_step"] > 0
+    else:
+        assert d["scaling"] == "strong" and c["calls_per_step"] == 2  # sum_k gamma_k twice per step (logisticsoftmax.jl:65-72)

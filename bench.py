@@ -200,9 +200,10 @@ def _hyper_products(m, B):
 
 
 def launch_ranks(n):
-    """`python bench.py --gpus N` without a launcher around it (the shape of the driver's N = 1 command): re-run this script under
-    torch.distributed.run, one rank per GPU of this node, rendezvous on 127.0.0.1.  Rank 0's JSON line goes to our stdout, every
-    rank's stderr to ours; returns the launcher's exit code."""
+    """`python bench.py --gpus N` without a launcher around it (the shape of the driver's N = 1 command): start the N ranks
+    ourselves, one process per GPU of this node, with the environment torch.distributed.run would give them (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT).  Rank 0's stdout (the ONE JSON line) is ours, the other ranks'
+    stdout and every rank's stderr go to our stderr.  Returns the first non-zero exit code (the other ranks are then stopped)."""
     import socket
     import subprocess
 
@@ -214,12 +215,30 @@ def launch_ranks(n):
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    print("[bench] starting", n, "ranks:", " ".join(cmd), file=sys.stderr, flush=True)
-    return subprocess.run(cmd, env=env).returncode
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] starting {n} ranks (MASTER_ADDR=127.0.0.1 MASTER_PORT={port}):", " ".join(cmd), file=sys.stderr, flush=True)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", "1")             # (what torch.distributed.run sets for more than one rank)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            st = procs[r].poll()
+            if st is None:
+                continue
+            alive.discard(r)
+            if st != 0 and rc == 0:
+                rc = st
+                print(f"[bench] rank {r} exited with code {st}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in alive:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
 
 
 def main():
@@ -236,7 +255,8 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N ...` (starts its own "
                          "ranks) or `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
-                         "--master-port P bench.py --gpus N ...`")
+                         "--master-port P bench.py --gpus N ...` (script options spelled out in full: the launcher's argument "
+                         "parser claims abbreviations such as --m)")
     # test hook: AGP_BENCH_SHARE_GPU=1 maps every rank to GPU 0 and uses gloo + the callback transport, so the N > 1 code path
     # can be exercised on a single-GPU box (never set by the driver; numbers from such a run are meaningless)
     share = os.environ.get("AGP_BENCH_SHARE_GPU") == "1"

@@ -29,7 +29,7 @@ def test_bench_line_with_short_runs(built, steps, warmup):
 @pytest.mark.parametrize("config,extra", [("c2", []), ("c4", ["--m", "256", "--batch", "256", "--N", "20000"])])
 def test_bench_starts_its_own_ranks(built, config, extra):
     """`python bench.py --gpus 2` -- the shape of the driver's command, no launcher around it -- starts two ranks itself
-    (torch.distributed.run, 127.0.0.1) and rank 0 prints the ONE line.  AGP_BENCH_SHARE_GPU=1 puts both ranks on GPU 0 (gloo + the
+    (one process per GPU, rendezvous on 127.0.0.1) and rank 0 prints the ONE line.  AGP_BENCH_SHARE_GPU=1 puts both ranks on GPU 0 (gloo + the
     callback transport): the N > 1 code path of bench.py through agp_svgp_cavi_step_multi, batch-parallel (c2: the packed
     statistic of analyticVI.jl:168,179 all-reduced, with the split-overlap A/B) and latent-parallel (c4)."""
     env = dict(os.environ, AGP_BENCH_SHARE_GPU="1")
@@ -52,3 +52,24 @@ def test_bench_starts_its_own_ranks(built, config, extra):
         assert c["split_overlap_ab"]["AGP_SPLIT_OVERLAP"] == 1 and c["split_overlap_ab"]["ms_per_step"] > 0
     else:
         assert d["scaling"] == "strong" and c["calls_per_step"] == 2  # sum_k gamma_k twice per step (logisticsoftmax.jl:65-72)
+
+
+def test_bench_under_the_drivers_launcher_command(built):
+    """The driver's N > 1 form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port
+    P bench.py --gpus N --steps K --warmup W` (both ranks on GPU 0 here: AGP_BENCH_SHARE_GPU=1)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, AGP_BENCH_SHARE_GPU="1", AGP_BENCH_NO_OVERLAP_AB="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["collective"]["ranks_seen"] == 2

@@ -659,6 +659,14 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       unsigned long long* const ptrace = nullptr;  // (wall-clock stamps of the prologue, PRO_TS in agp_chol.h: a development aid)
       constexpr unsigned lds_pad = 0;
       if (step_inst && chain_split_wanted(ntiles + nhelp, true, sizeof(T) == 8) && chain_split_ready(c)) {  // chain kernel + tile kernel (k_chol_dag, ROLE)
+        // No event joins the chain stream behind a split launch (see chain_split_arm): correct only as long as the chain kernel
+        // stores nothing after its last publish.  C = S + K^-1 / 4 (ProArgs::Cout) is a plain store of tile (0, 0)'s workgroup --
+        // in a split launch that would be the chain kernel, whose plain stores only become visible when THAT kernel ends.  Cout
+        // exists for launches with the inverse (do_x), which never split; enforced here rather than assumed.
+        if (pa.Cout) {
+          c->err = "potrf_fused: C = S + K^-1/4 (ProArgs::Cout) cannot ride on a split (chain kernel + tile kernel) launch";
+          return AGP_ERR_INVALID;
+        }
         chain_split_arm(c, ds, 1);
         split_used = true;
         hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, true, 1>), dim3(1), dim3(CHOL_THREADS), 0, c->chain_stream, one, 1,
@@ -3670,12 +3678,18 @@ struct Svgp : SvgpBase {
       HIPCHK(ctx, hipHostMalloc((void**)&elbo_pin, sizeof(double) * ELBO_RING, hipHostMallocMapped));
       for (auto& e : elbo_ev) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    const int slot = elbo_next;
-    if (elbo_open[slot]) {
-      ctx->err = "agp_svgp_elbo_enqueue: more than 8 evaluations in flight (fetch the older tickets first)";
+    // any closed slot will do (tickets may be fetched out of order), searched from the one after the last ticket handed out
+    int slot = -1;
+    for (int q = 0; q < ELBO_RING && slot < 0; ++q)
+      if (!elbo_open[(elbo_next + q) % ELBO_RING]) slot = (elbo_next + q) % ELBO_RING;
+    if (slot < 0) {
+      ctx->err = "agp_svgp_elbo_enqueue: 8 evaluations in flight, none fetched (agp_svgp_elbo_fetch closes a ticket)";
       return AGP_ERR_INVALID;
     }
-    elbo_async = slot;
+    // a batch-sharded handle's ELBO is a sum over the ranks (agp_svgp_elbo_multi): its local terms are what agp_svgp_elbo_terms
+    // reports after a SYNCHRONOUS evaluation -- the enqueued form would leave them stale
+    const bool force_sync = bs_world > 1;
+    elbo_async = force_sync ? -1 : slot;
     elbo_async_used = false;
     double v = 0.0;
     const agp_status st_ = elbo(x, ldx, y, idx, B, rho, fresh, &v);

@@ -1725,7 +1725,17 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
     if (threadIdx.x == 0) {
       wait_ok = 1;
       long spins = 0;
-      while (sync.go && __hip_atomic_load(sync.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != sync.go_val) {
+      // ordered compare, not equality: the release word is one per context and every split launch stores its own sequence number
+      // into it.  A chain kernel that is dispatched late (its launch was aborted and the fallback has run, the next tile kernel has
+      // already stored go_val + 1) must not wait for a value that has come and gone -- it would spin for a minute and latch -1 on a
+      // launch that has nothing to do with it.  If the word has moved PAST go_val this launch is over: count out, do no work.
+      while (sync.go) {
+        const int32_t d = (int32_t)(__hip_atomic_load(sync.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - sync.go_val);
+        if (d == 0) break;
+        if (d > 0) {  // a later launch has been released already
+          wait_ok = 0;
+          break;
+        }
         __builtin_amdgcn_s_sleep(4);
         if (++spins > (1L << 26)) {  // about a minute: the tile kernel never started.  Treated like a lost dependency: the latch
           atomicExch(info, -1);      // sends the launch to the in-stream fallback (the tiles, should they still come, give up on

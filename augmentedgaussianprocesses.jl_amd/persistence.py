@@ -121,6 +121,13 @@ def save_trained_model(filename: str, model: SVGP) -> None:
         arrays[f"eta1_{l}"], arrays[f"eta2_{l}"], arrays[f"Z_{l}"] = e1, e2, model.Zs[l]
     if mo:
         arrays["A"] = model.get_A()
+    if model.k_opt is not None:
+        # moments / velocity and step count of every latent's kernel-parameter optimiser (agp_svgp_hyper_opt_state): a resumed run
+        # continues the optimiser instead of taking a bias-corrected first step again
+        for l in range(model.n_latent):
+            km, kv, ks = (C.c_double * (1 + model.D))(), (C.c_double * (1 + model.D))(), C.c_int32()
+            model._chk(capi.lib().agp_svgp_hyper_opt_state(model._h, l, 0, km, kv, C.byref(ks)))
+            arrays[f"kopt_m_{l}"], arrays[f"kopt_v_{l}"], arrays[f"kopt_t_{l}"] = np.array(km[:]), np.array(kv[:]), np.array(ks.value)
     if isinstance(model.likelihood, LK.LogisticSoftMaxLikelihood) and inf.batchsize > 0:
         # carried between minibatches; exported by capacity (it is state, not a view of the last batch)
         arrays["lsm_alpha"] = model.get_matrix(capi.VEC_ALPHA, 0, min(int(inf.batchsize), model._max_batch))
@@ -130,7 +137,14 @@ def save_trained_model(filename: str, model: SVGP) -> None:
 
 
 def load_trained_model(filename: str, *, device=None):
-    """load_trained_model(filename) -> the model with its posterior restored on the device (ready to predict or train on)."""
+    """load_trained_model(filename) -> the model with its posterior restored on the device (ready to predict or train on).
+
+    What a resumed `train!(model, ...; state=...)` continues and what restarts: the natural parameters, kernels, inducing points,
+    the Robbins-Monro counter, likelihood state (lambda, LogisticSoftMax alpha), mixing weights and the moments + step count of
+    the kernel-parameter optimisers are restored -- the kernel parameters move on as if the run had never stopped.  The device
+    state of the Z optimiser, of `GaussianLikelihood(opt_noise=...)` and of `Aoptimiser` RESTARTS (zero moments, step 0): their
+    first step after a reload is a bias-corrected first ADAM step, so the inducing points / noise / mixing weights of a resumed
+    run differ from an uninterrupted one at the size of one optimiser step."""
     import ctypes as C
 
     from . import capi
@@ -156,6 +170,12 @@ def load_trained_model(filename: str, *, device=None):
     for l in range(nl):
         model.set_state(l, g[f"eta1_{l}"], g[f"eta2_{l}"])
     model._chk(capi.lib().agp_svgp_set_opt_state(h, int(g["n_opt"])))
+    for l in range(nl):
+        if f"kopt_m_{l}" in g.files and model.k_opt is not None:
+            km = (C.c_double * (1 + model.D))(*[float(v) for v in g[f"kopt_m_{l}"]])
+            kv = (C.c_double * (1 + model.D))(*[float(v) for v in g[f"kopt_v_{l}"]])
+            ks = C.c_int32(int(g[f"kopt_t_{l}"]))
+            model._chk(capi.lib().agp_svgp_hyper_opt_state(h, l, 1, km, kv, C.byref(ks)))
     lik = model.likelihood
     if hasattr(lik, "lam") and not isinstance(lik, list):
         model._chk(capi.lib().agp_svgp_set_lik_param(h, float(lik.lam)))

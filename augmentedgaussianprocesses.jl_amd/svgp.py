@@ -342,6 +342,17 @@ class SVGP:
     def _pre_destroy(self):
         self._pull_hypers()
         self._pull_lik_state()
+        self._close_tickets()
+
+    def _close_tickets(self):
+        """objective_enqueue tickets belong to the device handle: before it is re-created (a larger batch than ever before) every
+        open one is fetched, so that objective_fetch still returns its value afterwards (found by the ADVICE r04 review: the
+        library's slot numbers of a destroyed handle answered AGP_ERR_INVALID)."""
+        for tk, slot in list(getattr(self, "_tickets", {}).items()):
+            if isinstance(slot, int):
+                out, ready = C.c_double(), C.c_int32()
+                self._chk(capi.lib().agp_svgp_elbo_fetch(self._h, slot, 1, C.byref(out), C.byref(ready)))
+                self._tickets[tk] = float(out.value)
 
     def _pull_lik_state(self):
         """λ of PoissonLikelihood / HeteroscedasticLikelihood lives on the device while training; mirror it back"""
@@ -698,14 +709,32 @@ def objective_enqueue(model: SVGP) -> int:
     idx_ptr = getattr(model, "_last_idx", None)
     model._chk(L.agp_svgp_elbo_enqueue(model._h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(yd.data_ptr()), idx_ptr,
                                        model.inference.batchsize, model.inference.rho, 0, C.byref(t)))
-    return t.value
+    # tickets are the mirror's own numbers: ticket -> the library's slot of the current handle, or the value itself once the
+    # handle it belonged to has been re-created (_close_tickets)
+    if not hasattr(model, "_tickets"):
+        model._tickets, model._next_ticket = {}, 0
+    tk = model._next_ticket
+    model._next_ticket += 1
+    model._tickets[tk] = int(t.value)
+    return tk
 
 
 def objective_fetch(model: SVGP, ticket: int, wait: bool = True):
-    """the value of an `objective_enqueue` ticket; with wait=False: None while it has not arrived yet"""
+    """the value of an `objective_enqueue` ticket; with wait=False: None while it has not arrived yet.  Tickets may be fetched in
+    any order; one that outlived its device handle (the model was re-created for a larger batch in between) still has its value."""
+    tickets = getattr(model, "_tickets", {})
+    if ticket not in tickets:
+        raise KeyError(f"objective_fetch: ticket {ticket} is not open (already fetched, or not from this model)")
+    slot = tickets[ticket]
+    if isinstance(slot, float):
+        del tickets[ticket]
+        return slot
     out, ready = C.c_double(), C.c_int32()
-    model._chk(capi.lib().agp_svgp_elbo_fetch(model._h, int(ticket), 1 if wait else 0, C.byref(out), C.byref(ready)))
-    return out.value if ready.value else None
+    model._chk(capi.lib().agp_svgp_elbo_fetch(model._h, slot, 1 if wait else 0, C.byref(out), C.byref(ready)))
+    if not ready.value:
+        return None
+    del tickets[ticket]
+    return out.value
 
 
 def ELBO(model: SVGP, X, y, *, obsdim: int = 1, rho: Optional[float] = None) -> float:

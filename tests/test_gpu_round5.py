@@ -108,3 +108,72 @@ def test_device_logisticsoftmax_fixed_point_is_stationary_for_the_augmented_boun
     assert np.max(np.abs(g["gamma"])) < 1e-6 and np.max(np.abs(g["alpha"])) < 1e-6 and np.max(np.abs(g["c"])) < 1e-6
     assert np.max(np.abs(g["beta"])) < 1e-6
     assert AGP.objective(ma) == pytest.approx(val - N * Kc * np.log(2.0) + (N - 1) * np.log(Kc), rel=1e-8)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# ADVICE r04
+def _toy(rng, N=400, D=3, m=24):
+    X = rng.random((N, D))
+    f = np.sin(4 * X[:, 0]) + X[:, 1] - 0.8 * X[:, 2]
+    Z = X[rng.permutation(N)[:m]].copy()
+    return X, f, Z
+
+
+def test_resumed_run_continues_the_kernel_optimiser(mods, tmp_path):
+    """save_trained_model now carries the moments and step count of the kernel-parameter optimisers (agp_svgp_hyper_opt_state): a run
+    saved after 6 iterations, reloaded and continued lands on the kernel parameters of the run that simply went on (Z is fixed
+    here: the Z optimiser's device state restarts on reload, as the docstring says).  With restarted ADAM moments the first step
+    after the reload is a full-size bias-corrected step: the variances would differ in the second digit."""
+    AGP, R, capi, torch = mods
+    rng = np.random.default_rng(18)
+    X, f, Z = _toy(rng, N=300, m=16)
+    y = (f + 0.2 * rng.standard_normal(len(f)) > 0).astype(int)
+    B = 60
+    idx = [rng.choice(len(X), B, replace=False) for _ in range(12)]
+
+    def model():
+        return AGP.SVGP(1.2 * (AGP.SqExponentialKernel() @ AGP.ARDTransform(np.array([2.0, 3.0, 1.5]))), AGP.LogisticLikelihood(),
+                        AGP.AnalyticSVI(B), Z, optimiser=AGP.ADAM(0.05), Zoptimiser=False)
+
+    # (two train! calls of 6 iterations in both runs: the last iteration of a call takes no hyper step, training.jl:65-69, so a
+    #  12-iteration call is a different trajectory by design)
+    ma = model()
+    AGP.train_(ma, X, y, 6, idx_stream=idx[:6])
+    AGP.save_trained_model(str(tmp_path / "r.npz"), ma)
+    mc = AGP.load_trained_model(str(tmp_path / "r.npz"))
+    AGP.train_(ma, X, y, 6, idx_stream=idx[6:], state=True)
+    AGP.train_(mc, X, y, 6, idx_stream=idx[6:], state=True)
+    ma._pull_hypers(), mc._pull_hypers()
+    assert abs(ma.kernels[0].variance - 1.2) > 1e-2  # the optimiser did move the parameters
+    assert mc.kernels[0].variance == pytest.approx(ma.kernels[0].variance, rel=1e-8)
+    assert _rel(mc.kernels[0].scales(3), ma.kernels[0].scales(3)) < 1e-8
+    mu_a, mu_c = ma.get_state(0)[0], mc.get_state(0)[0]
+    assert _rel(mu_c, mu_a) < 1e-7
+
+
+def test_elbo_tickets_out_of_order_and_across_a_handle_recreation(mods):
+    """agp_svgp_elbo_enqueue takes any closed slot of its ring (tickets fetched out of order used to block it with "more than 8
+    in flight"), and a ticket that outlives its device handle -- the mirror re-creates the handle when a larger batch is asked for --
+    still has its value."""
+    AGP, R, capi, torch = mods
+    rng = np.random.default_rng(19)
+    X, f, Z = _toy(rng)
+    y = (f > 0).astype(int)
+    B = 64
+    idx = [rng.choice(len(X), B, replace=False) for _ in range(4)]
+    m = AGP.SVGP(AGP.SqExponentialKernel() @ AGP.ScaleTransform(2.0), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z, optimiser=False)
+    AGP.train_(m, X, y, 4, idx_stream=idx)
+    ref = AGP.objective(m)
+    tk = [AGP.objective_enqueue(m) for _ in range(8)]
+    for t in (tk[3], tk[6], tk[0]):  # out of order
+        assert AGP.objective_fetch(m, t) == pytest.approx(ref, rel=1e-12)
+    tk2 = [AGP.objective_enqueue(m) for _ in range(3)]  # three slots were closed: three more fit
+    with pytest.raises(Exception):
+        AGP.objective_enqueue(m)  # ... and a ninth open ticket does not
+    # a prediction on more points than the handle's batch capacity re-creates the handle: the open tickets keep their values
+    keep = [tk[1], tk2[0]]
+    m._ensure_handle(4 * B)
+    for t in keep:
+        assert AGP.objective_fetch(m, t) == pytest.approx(ref, rel=1e-12)
+    with pytest.raises(KeyError):
+        AGP.objective_fetch(m, tk[3])  # fetched already

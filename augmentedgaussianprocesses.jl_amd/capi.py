@@ -141,6 +141,7 @@ SYMBOLS = {
     "agp_comm_allreduce": (_I32, [_VP, _VP, _I64, _I32]),
     "agp_comm_timing": (_I32, [_VP, _I32]),
     "agp_comm_stats": (_I32, [_VP, _PI64, _PI64, _PDBL]),
+    "agp_comm_standin_allreduce": (_I32, [_VP, _I64, _I32, _VP, _I32, _I32, _DBL, _VP]),
     "agp_svgp_cavi_step_multi": (_I32, [_VP, _VP, _I32, _VP, _I64, _VP, _VP, _I64, _DBL]),
     "agp_svgp_elbo_multi": (_I32, [_VP, _VP, _I32, _PDBL]),
     "agp_svgp_hyper_step_multi": (_I32, [_VP, _VP, _I32]),

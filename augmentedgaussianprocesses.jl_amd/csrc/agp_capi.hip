@@ -5502,7 +5502,62 @@ static agp_status comm_allreduce_groups(agp_comm* cm, void* base, int esz, const
   return AGP_OK;
 }
 
+// ---- stand-in for an xGMI ring all-reduce on a one-GPU box (diagnostic; agp_comm_standin_allreduce) -------------------------------
+// RCCL's ring kernel is a handful of workgroups ("channels") that pass chunks to one another through flags: it only finishes when all
+// of them are RESIDENT at the same time.  A sleep kernel in the collective's place does not exercise that; this one does: n_wg
+// workgroups meet at a grid barrier (every one must have a CU), move the buffer through their registers chunk by chunk (sum over one
+// rank = the values they found), meet again, and do not return before min_us have passed.  The barrier counter only grows (two
+// arrivals per workgroup and launch): launches on one stream are ordered, which is how the callback transport uses it.  The spins
+// are bounded (about a second): a stand-in that cannot become resident reports it through `stuck` instead of hanging the device.
+__device__ unsigned long long g_standin_bar;
+__global__ void k_standin_allreduce(unsigned long long* __restrict__ buf8, int64_t n8, unsigned long long base, double min_us,
+                                    int32_t* __restrict__ stuck) {
+  const unsigned long long t0 = wall_clock64();  // 100 MHz constant clock
+  const unsigned long long n_wg = gridDim.x;
+  __shared__ int ok;
+  auto meet = [&](unsigned long long target) {
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(&g_standin_bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      long spins = 0;
+      ok = 1;
+      while (__hip_atomic_load(&g_standin_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1L << 22)) {
+          ok = 0;
+          if (stuck) atomicAdd(stuck, 1);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    return ok != 0;
+  };
+  const bool all_here = meet(base + n_wg);
+  if (all_here)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)n_wg * blockDim.x) {
+      const unsigned long long v = __hip_atomic_load(buf8 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(buf8 + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  (void)meet(base + 2 * n_wg);
+  if (threadIdx.x == 0)
+    while ((double)(wall_clock64() - t0) * 0.01 < min_us) __builtin_amdgcn_s_sleep(16);
+}
+static unsigned long long g_standin_launches = 0;
+
 extern "C" {
+
+agp_status agp_comm_standin_allreduce(void* buf, int64_t count, int32_t dtype, void* stream, int32_t n_wg, int32_t n_threads,
+                                      double min_us, int32_t* stuck_dev) {
+  if (!buf || count <= 0 || (dtype != AGP_F64 && dtype != AGP_F32) || n_wg < 1 || n_wg > 64 || n_threads < 64 || n_threads > 1024)
+    return AGP_ERR_INVALID;
+  const int64_t n8 = count * (dtype == AGP_F64 ? 8 : 4) / 8;  // whole 8-byte words (a trailing float stays where it is)
+  const unsigned long long base = g_standin_launches * 2ull * (unsigned long long)n_wg;
+  // (the counter's base assumes one n_wg per process: the stand-in is a diagnostic of ONE configuration per run)
+  g_standin_launches += 1;
+  hipLaunchKernelGGL(k_standin_allreduce, dim3((unsigned)n_wg), dim3((unsigned)n_threads), 0, (hipStream_t)stream,
+                     (unsigned long long*)buf, n8, base, min_us, stuck_dev);
+  return hipGetLastError() == hipSuccess ? AGP_OK : AGP_ERR_HIP;
+}
 
 agp_status agp_comm_allreduce(agp_comm* cm, void* buf, int64_t count, int32_t dtype) {
   if (!cm || !buf || count <= 0 || (dtype != AGP_F64 && dtype != AGP_F32)) return AGP_ERR_INVALID;

@@ -339,10 +339,24 @@ def main():
             mp_ = (m + 63) // 64 * 64
             full_count = mp_ + (mp_ // 64) * (mp_ // 64 + 1) // 2 * 4096
             exts = {}
+            # AGP_BENCH_FAKE_RESIDENT=<workgroups>x<threads> (e.g. 16x512): instead of a sleep kernel, a stand-in that occupies the
+            # chip the way RCCL's ring kernel does -- that many workgroups which must ALL be resident to finish (grid barrier, the
+            # range moved through their registers, grid barrier; agp_comm_standin_allreduce), lasting at least the same time
+            resident = os.environ.get("AGP_BENCH_FAKE_RESIDENT", "")
+            res_wg, res_thr = (int(v) for v in resident.split("x")) if resident else (0, 0)
+            stuck = torch.zeros(1, dtype=torch.int32, device=dev) if resident else None
+            cfg["_standin_stuck"] = stuck
 
             def _fake(ptr, count, dtype, stream):
                 try:
                     us = fake_us if count >= full_count else max(lat_us, fake_us * count / full_count)
+                    if resident:
+                        st_ = L.agp_comm_standin_allreduce(C.c_void_p(ptr), count, dtype,
+                                                           C.c_void_p(stream if stream is not None else torch.cuda.current_stream().cuda_stream),
+                                                           res_wg, res_thr, float(us), C.c_void_p(stuck.data_ptr()))
+                        if st_ != 0:
+                            raise RuntimeError(f"agp_comm_standin_allreduce -> {st_}")
+                        return
                     cyc = int(us * 1700)
                     if stream is None:  # the ctx runs on the default stream, which is torch's current one here
                         torch.cuda._sleep(cyc)
@@ -356,7 +370,9 @@ def main():
                     raise
 
             comm = P.Comm.from_callback(model, 0, 1, _fake)
-            coll = f"callback: ~{fake_us:.0f} us sleep kernel per call (AGP_BENCH_FAKE_ALLREDUCE_US)"
+            coll = (f"callback: resident stand-in, {res_wg} workgroups x {res_thr} threads, >= {fake_us:.0f} us per whole statistic "
+                    "(AGP_BENCH_FAKE_RESIDENT)" if resident else
+                    f"callback: ~{fake_us:.0f} us sleep kernel per call (AGP_BENCH_FAKE_ALLREDUCE_US)")
         else:
             comm = P.Comm.rccl(model, 0, 1, P.Comm.unique_id())
             coll = "rccl via agp_comm (one rank, AGP_FORCE_SPLIT)"
@@ -464,6 +480,9 @@ def main():
                           "bytes_allreduced_per_step_per_rank": int(nb_ab / max(steps, 1)),
                           "note": "same loop, same index stream, variable flipped; the headline line above ran with AGP_SPLIT_OVERLAP="
                                   + (keep or "0") + "; with the flag on, one call is the train of column groups on the communicator's stream"}
+        except Exception as ex:  # the A/B must never cost the headline line (it runs behind the timed region, last GPU work of N > 1)
+            overlap_ab = {"AGP_SPLIT_OVERLAP": int(flipped), "error": repr(ex)[:300]}
+            print("[bench] split-overlap A/B failed on rank", rank, ":", repr(ex), file=sys.stderr)
         finally:
             if keep is None:
                 os.environ.pop("AGP_SPLIT_OVERLAP", None)
@@ -623,6 +642,8 @@ def main():
             "us_per_call": round(cms * 1e3 / max(ncalls, 1), 2),
             "timing": "HIP events on the ctx stream around every 4th collective (rank 0), scaled to all of them",
         }
+        if cfg.get("_standin_stuck") is not None:
+            out["collective"]["standin_workgroups_that_gave_up_waiting"] = int(cfg["_standin_stuck"].item())
         if tied:
             out["collective"]["tied_Z_hyper_step_every"] = cfg["hyper_every"]
         if overlap_ab is not None:

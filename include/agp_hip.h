@@ -465,6 +465,13 @@ agp_status agp_comm_allreduce(agp_comm* comm, void* buf, int64_t count, int32_t 
  * collective, n > 1 every n-th one (the two event records cost the stream ~20 us each time); the sum is scaled to all calls. */
 agp_status agp_comm_timing(agp_comm* comm, int32_t on);
 agp_status agp_comm_stats(agp_comm* comm, int64_t* n_calls_host, int64_t* bytes_host, double* ms_host);
+/* Diagnostic (one-GPU boxes): a stand-in for an xGMI ring all-reduce that occupies the chip the way RCCL's ring kernel does -- n_wg
+ * workgroups of n_threads that must ALL be resident to finish (grid barrier, the buffer moved through their registers, grid
+ * barrier), lasting at least min_us.  Sum over one rank: the buffer keeps its values.  Enqueued on `stream` (a hipStream_t; the
+ * stream an agp_allreduce_fn callback is handed).  stuck_dev (nullable, device int32): incremented by every workgroup whose bounded
+ * wait for the others ran out (~1 s) -- the stand-in then gives up instead of hanging the device.  One n_wg per process. */
+agp_status agp_comm_standin_allreduce(void* buf, int64_t count, int32_t dtype, void* stream, int32_t n_wg, int32_t n_threads,
+                                      double min_us, int32_t* stuck_dev);
 
 /* update_parameters!(model, state, x, y) (src/training/training.jl:140-158) of a sharded model: agp_svgp_cavi_step with the
  * exchange points above carried out on `comm`.  comm == NULL or world == 1 degenerates to the single-GPU step through the

@@ -314,6 +314,25 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_safe_rowstats(CholBatch<T> bt,
   }
 }
 
+// The same for the launch behind materialize() (the factorisation of -2 eta2 with its inverse and Sigma = X' X, round 5): the
+// fallback, then mu = Sigma eta1 and v = X eta1 wave by wave (k_symv_trmv's rows) -- one launch less in the hyper-parameter iteration.
+template <typename T>
+__global__ __launch_bounds__(CHOL_THREADS) void k_safe_symv_trmv(CholBatch<T> bt, SafeSrc<T> src, int64_t ld, int64_t ldx, int64_t lde,
+                                                                 int64_t ne, int64_t nt, int32_t* __restrict__ info, int64_t nvalid,
+                                                                 unsigned* __restrict__ bar, int32_t* __restrict__ retries,
+                                                                 const T* __restrict__ S, const T* __restrict__ X, int64_t ldm,
+                                                                 int64_t n, const T* __restrict__ x, T* __restrict__ ys,
+                                                                 T* __restrict__ yt) {
+  __shared__ __attribute__((aligned(16))) T sm[3 * TILE * LDP];
+  __shared__ __attribute__((aligned(16))) T sc[SC_ELEMS];
+  __shared__ T piv[TILE];
+  (void)chol_safe_body<T>(bt, src, 1, ld, ldx, lde, ne, nt, info, nvalid, bar, retries, sm, sc, piv);
+  // (after a fallback its last grid barrier has made X and Sigma visible to every workgroup)
+  const int64_t wpb = CHOL_THREADS / 64, nwave = (int64_t)gridDim.x * wpb;
+  for (int64_t w = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); w < 2 * n; w += nwave)
+    symv_trmv_row<T>(w, threadIdx.x & 63, S, X, ldm, n, x, ys, yt);
+}
+
 // Factorisation by plain launches (matrices beyond the task graph, and the task graph's fallback).  From 8 block columns on it is
 // blocked (agp_chol.h, k_chol_panel): groups of G block columns -- the G x G diagonal block by G small launches, the rows below it
 // by one panel-solve launch, everything to the right by one trailing launch per group; the part of the trailing update that the
@@ -568,7 +587,12 @@ template <typename T>
 static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int64_t ldx, T* Dg, T* E, int64_t lde,
                               int64_t ne, int do_x, int32_t* info_dev, int64_t nvalid, const T* erow = nullptr,
                               bool want_l = true, SafeSrc<T>* safe = nullptr, bool* defer_safe = nullptr,
-                              StepSync* ssync = nullptr, const ProHost<T>* pro = nullptr, const EpiArgs<T>* epi = nullptr) {
+                              StepSync* ssync = nullptr, const ProHost<T>* pro = nullptr, const EpiArgs<T>* epi = nullptr,
+                              T* Pout = nullptr, bool* p_done = nullptr, double* ld_out = nullptr, int32_t* ld_status = nullptr) {
+  // Pout (with do_x; leading dimension ldx): P = X' X is wanted next -- K^-1 at a kernel refresh, Sigma for the hyper-gradient.  On
+  // the task graph it is formed by product workgroups at the end of the same launch (ProdArgs, agp_chol.h) and *p_done says so;
+  // otherwise the caller forms it (xtx_padded)
+  if (p_done) *p_done = false;
   // ssync (CAVI step next to a look-ahead stream): the step's task-graph instantiation stores its `started` number (`used` is set)
   // defer_safe (in: the caller can run the fallback itself, k_safe_rowstats; out: whether it has to -- the task graph was used)
   const bool can_defer = defer_safe && *defer_safe;
@@ -612,8 +636,36 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
     const int64_t hstride = ((2 * nt + ne) * nt + 3 * nt + nhelp) * TILE * TILE;
     const int64_t hused = (3 * nt + (nt + ne + nx) * nt + nhelp) * TILE * TILE;
     T* H = nullptr;
-    const int hs = pro ? c->h_step_set : 0;
+    const bool with_p = Pout != nullptr && nx > 0 && p_done != nullptr;
+    const int64_t nprod = with_p ? nt * (nt + 1) / 2 : 0;
+    // launches with a prologue alternate between the two hand-over sets and refill each other's; so do the launches with product
+    // workgroups (the symmetric-product launches whose riders refilled set 0 behind them are gone from their path)
+    const int hs = (pro || with_p) ? c->h_step_set : 0;
     AGPCHK(dag_handover_acquire<T>(c, hstride, hs, &H));
+    ProdArgs<T> pd{};
+    if (with_p) {
+      pd.out = Pout;
+      pd.ld = ldx;
+      pd.ld_out = ld_out;  // (log det of the factor rides on the last product workgroup)
+      pd.status = ld_status;
+      if (!pro) {
+        const int other = hs ^ 1;
+        if (c->hset[other] && c->h_dirty[other].on && c->h_dirty[other].nb == 1 && c->htype == (int)sizeof(T)) {
+          pd.fill = (T*)c->hset[other];
+          pd.fill_n = c->h_dirty[other].used;
+          c->h_dirty[other].on = false;
+        }
+        c->h_step_set = other;
+      }
+      if (safe) {
+        safe->pout = Pout;
+        safe->ldpo = ldx;
+        safe->ld_out = ld_out;
+        safe->ld_status = ld_status;
+        safe->ld_n = nvalid;
+      }
+      *p_done = true;
+    }
     unsigned long long* const trace = nullptr;  // (per-tile timestamps: the TRACE instantiation of k_chol_dag, a development aid)
     const bool step_inst = nx == 0 && !do_x && !want_l;
     DagSync ds{};
@@ -680,11 +732,13 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
         hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, true>), dim3((unsigned)(ntiles + nhelp + pa.nfill)),
                            dim3(CHOL_THREADS), lds_pad, c->stream, one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid,
                            c->dag_flags, c->dag_epoch, ptrace, H, hstride, nx, erow, 0, ds, pa, epi ? *epi : EpiArgs<T>{});
-      else
-        hipLaunchKernelGGL((k_chol_dag<T, true, false, false, false, true>), dim3((unsigned)(ntiles + nhelp + pa.nfill)),
+      else {
+        pd.base = ntiles + nhelp + pa.nfill;
+        hipLaunchKernelGGL((k_chol_dag<T, true, false, false, false, true>), dim3((unsigned)(ntiles + nhelp + pa.nfill + nprod)),
                            dim3(CHOL_THREADS), lds_pad, c->stream, one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid,
                            c->dag_flags, c->dag_epoch, ptrace, H, hstride, nx, erow, (int)(do_x && nx == 0) | (want_l ? 2 : 0),
-                           DagSync{}, pa, EpiArgs<T>{});
+                           DagSync{}, pa, EpiArgs<T>{}, pd);
+      }
       c->h_step_set = other;
     } else if (step_inst && chain_split_wanted(ntiles) && chain_split_ready(c)) {
       // ... as two kernels: the chain workgroup on its own stream (enqueued first), every other tile on this one
@@ -701,10 +755,12 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1,
                          (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
                          0, ds);
-    else
-      hipLaunchKernelGGL((k_chol_dag<T, true>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0, ld,
-                         ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
-                         (int)(do_x && nx == 0) | (want_l ? 2 : 0), DagSync{});
+    else {
+      pd.base = ntiles;
+      hipLaunchKernelGGL((k_chol_dag<T, true>), dim3((unsigned)(ntiles + nprod)), dim3(CHOL_THREADS), 0, c->stream, one, 1, (int64_t)0,
+                         ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
+                         (int)(do_x && nx == 0) | (want_l ? 2 : 0), DagSync{}, ProArgs<T>{}, EpiArgs<T>{}, pd);
+    }
     LAUNCHCHK(c);
     AGPCHK(dag_handover_release<T>(c, hused, hstride, 1, hs));
     const bool test_abort = dag_test_abort();
@@ -922,15 +978,16 @@ static agp_status xtx_padded(agp_ctx* c, const T* X, int64_t ld, int64_t n, T* o
 template <typename T, int EPI>
 static agp_status gemm_nt(agp_ctx* c, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                           int tri_b, T* C, int64_t ldc, const T* E, int64_t lde, const T* v, T* p0, T* p1,
-                          int64_t ldp) {
+                          int64_t ldp, const HkArgs<T>* hk = nullptr) {
   dim3 g((unsigned)(N / TILE), (unsigned)(M / TILE));
+  const HkArgs<T> hka = hk ? *hk : HkArgs<T>{};  // (EPI_HK only)
   // fewer tiles than ~1.25 waves of CUs: two k-groups per workgroup (2 waves per SIMD) instead of idle SIMD slots
   if ((N / TILE) * (M / TILE) <= kg2_limit() && K >= 4 * BK)
     hipLaunchKernelGGL((k_gemm_nt<T, EPI, 2>), g, dim3(2 * NTHREADS), 0, c->stream, A, lda, B, ldb, K, tri_b, C, ldc, E,
-                       lde, v, p0, p1, ldp);
+                       lde, v, p0, p1, ldp, hka);
   else
     hipLaunchKernelGGL((k_gemm_nt<T, EPI, 1>), g, dim3(NTHREADS), 0, c->stream, A, lda, B, ldb, K, tri_b, C, ldc, E, lde,
-                       v, p0, p1, ldp);
+                       v, p0, p1, ldp, hka);
   LAUNCHCHK(c);
   return AGP_OK;
 }
@@ -1230,6 +1287,7 @@ struct Svgp : SvgpBase {
     // v = Xa eta1 formed by materialize() next to mu belongs to the inverse with this number (aug_factor counts them): a step that
     // takes W, v from the inverse uses it instead of launching the triangular mat-vec itself
     int64_t xa_epoch = 0, v_epoch = -1;
+    int64_t sigma_epoch = -1;  // xa_epoch of the inverse whose Sigma = Xa' Xa the factorisation launch itself has left in Sigma (ProdArgs)
     bool v_ready = false;
     double half_logdetK = 0.0;
     bool logdet_pending = false;  // half_logdetK still sits in logdetK_dev (asynchronous K refresh)
@@ -1262,7 +1320,7 @@ struct Svgp : SvgpBase {
   T *hyKap = nullptr, *hyKnm = nullptr;  // kappa (Knm) under the fresh inv(K) (kernel) for the hyper-gradient, AGP_FLAG_STALE_K
   T* hy_pZ2 = nullptr;
   double *hy_pvar2 = nullptr, *hy_pscale2 = nullptr;
-  T* hy_upart = nullptr;                 // per tile row: partial column sums of kappa' g_mu (k_hyper_hk_tile -> k_hyper_gK_fused)
+  T* hy_upart = nullptr;                 // two per tile row: partial column sums of kappa' g_mu (k_gemm_nt<EPI_HK> -> k_hyper_gK_fused)
   T *hyH1 = nullptr, *hyH2 = nullptr, *hyH3 = nullptr, *hy_gmu = nullptr, *hy_gs = nullptr, *hy_muf = nullptr,
     *hy_pZ = nullptr, *hy_dZ = nullptr;
   double *hy_pvar = nullptr, *hy_pscale = nullptr, *hy_g = nullptr;
@@ -1803,11 +1861,14 @@ struct Svgp : SvgpBase {
         src.kkind = g.k.kind;
         src.kvariance = kvar(g);
         src.kjitter = (T)jitter;
-        AGPCHK(potrf_fused<T>(ctx, g.L, mp, mp, g.Xk, mp, g.DgK, (T*)nullptr, 0, 0, 1, infoK_dev, m, (const T*)nullptr, true, &src));
         if (!logdetK_dev) AGPCHK(dmalloc(ctx, &logdetK_dev, nl));
         const int li = (int)(&g - lat.data());
-        bool ld_done = false;
-        AGPCHK(xtx_padded<T>(ctx, g.Xk, mp, mp, g.Kinv, mp, (const T*)g.DgK, m, logdetK_dev + li, info_dev, &ld_done));
+        bool kinv_done = false;  // K^-1 = X' X (and log det K) by product workgroups of the same launch (task graph), else below
+        AGPCHK(potrf_fused<T>(ctx, g.L, mp, mp, g.Xk, mp, g.DgK, (T*)nullptr, 0, 0, 1, infoK_dev, m, (const T*)nullptr, true, &src,
+                              nullptr, nullptr, nullptr, nullptr, g.Kinv, &kinv_done, logdetK_dev + li, info_dev));
+        bool ld_done = kinv_done;
+        if (!kinv_done)
+          AGPCHK(xtx_padded<T>(ctx, g.Xk, mp, mp, g.Kinv, mp, (const T*)g.DgK, m, logdetK_dev + li, info_dev, &ld_done));
         if (!ld_done)
           hipLaunchKernelGGL((k_logdiag_sum<T>), dim3(1), dim3(1024), 0, st(), (const T*)g.DgK, m, logdetK_dev + li, info_dev);
         LAUNCHCHK(ctx);
@@ -2578,14 +2639,20 @@ struct Svgp : SvgpBase {
                                       nullptr, 0)));
         tw2_kis_of = l;
       }
-      AGPCHK((gemm_nt<T, EPI_STORE>(ctx, kap, mp, Tw2, mp, Bq, mp, mp, 0, hyH1, mp, nullptr, 0, nullptr, nullptr, nullptr,
-                                    0)));  // kappa (K^-1 Sigma)' = kappa Sigma K^-1
       if (gk_fused) {
-        if (!hy_upart) AGPCHK(dmalloc(ctx, &hy_upart, (Bp / TILE) * mp));
-        hipLaunchKernelGGL((k_hyper_hk_tile<T>), dim3((unsigned)(mp / TILE), (unsigned)(Bq / TILE)), dim3(256), 0, st(), B, mp, rho,
-                           (const T*)hy_gmu, (const T*)hy_gs, (const T*)g.apred, (const T*)hyH1, kap, (T*)nullptr, hyH3, hy_upart,
-                           mp);
+        // kappa (K^-1 Sigma)' = kappa Sigma K^-1 with the element-wise pass behind it as the product's epilogue (EPI_HK): G_Knm and
+        // the partial column sums of u = kappa' g_mu, two rows of partials per tile row (T1 itself is never stored)
+        if (!hy_upart) AGPCHK(dmalloc(ctx, &hy_upart, 2 * (Bp / TILE) * mp));
+        HkArgs<T> hk{};
+        hk.gmu = hy_gmu;
+        hk.gs = hy_gs;
+        hk.rho = rho;
+        hk.B = B;
+        AGPCHK((gemm_nt<T, EPI_HK>(ctx, kap, mp, Tw2, mp, Bq, mp, mp, 0, (T*)nullptr, mp, kap, mp, (const T*)g.apred, hy_upart, hyH3,
+                                   mp, &hk)));
       } else {
+        AGPCHK((gemm_nt<T, EPI_STORE>(ctx, kap, mp, Tw2, mp, Bq, mp, mp, 0, hyH1, mp, nullptr, 0, nullptr, nullptr, nullptr,
+                                      0)));  // kappa (K^-1 Sigma)' = kappa Sigma K^-1
         hipLaunchKernelGGL((k_hyper_hk<T>), grid2(Bq, mp), blk2, 0, st(), B, Bq, mp, mp, rho, (const T*)hy_gmu,
                            (const T*)hy_gs, (const T*)g.apred, (const T*)hyH1, kap, hyH2, hyH3);
       }
@@ -2604,7 +2671,7 @@ struct Svgp : SvgpBase {
                                     0)));  // C (K^-1 Sigma)' = C Sigma K^-1
       hipLaunchKernelGGL((k_hyper_gK_fused<T>), dim3((unsigned)(mp / 32), (unsigned)(mp / 32)), dim3(256), 0, st(), m, mp,
                          (const T*)Tw, (const T*)g.Cmat,
-                         (const T*)g.Kinv, (const T*)g.apred, (const T*)g.kinv_mu0, (const T*)hy_upart, (int)(Bq / TILE), mp, rho,
+                         (const T*)g.Kinv, (const T*)g.apred, (const T*)g.kinv_mu0, (const T*)hy_upart, (int)(2 * (Bq / TILE)), mp, rho,
                          Tw2);
     } else {
       dim3 gt((unsigned)(mp / TILE), (unsigned)(mp / TILE));
@@ -2622,14 +2689,13 @@ struct Svgp : SvgpBase {
     // (k_hyper_reduce2, second set of partial sums).
     const bool online_x = g.on && !g.on_first;
     const bool one_reduce = !online_x;
-    {
+    if (!one_reduce) {  // (one_reduce: this pass shares the launch of the pass through K_ZZ below, k_kernel_backward2)
       dim3 gk((unsigned)(mp / TILE), (unsigned)(Bq / HB_RT));
       const int64_t tiles = (int64_t)gk.x * gk.y;
       hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)x_last, ldx_last, idx_last, B,
                          (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, kvar(g), (const T*)hyH3, mp,
                          hy_pvar, hy_pscale, hy_pZ, mp);
-      if (!one_reduce)
-        hipLaunchKernelGGL((k_hyper_reduce<T>), dim3((unsigned)(D + 1 + (m * D + 255) / 256)), dim3(256), 0, st(), tiles, D,
+      hipLaunchKernelGGL((k_hyper_reduce<T>), dim3((unsigned)(D + 1 + (m * D + 255) / 256)), dim3(256), 0, st(), tiles, D,
                            (const double*)hy_pvar, (const double*)hy_pscale, hy_g, 1.0, 1, (int64_t)gk.y, m, mp, (const T*)hy_pZ,
                            hy_dZ, T(1), (const T*)hy_gs, B, (double)rho);
     }
@@ -2675,10 +2741,27 @@ struct Svgp : SvgpBase {
     {
       dim3 gk((unsigned)(mp / TILE), (unsigned)(mp / HB_RT));
       const int64_t tiles = (int64_t)gk.x * gk.y;
-      hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)g.Z, D, (const int64_t*)nullptr,
-                         m, (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, kvar(g), (const T*)Tw2, mp,
-                         one_reduce ? hy_pvar2 : hy_pvar, one_reduce ? hy_pscale2 : hy_pscale, one_reduce ? hy_pZ2 : hy_pZ, mp);
-      if (one_reduce)
+      if (one_reduce) {
+        KbPass<T> pa{(const T*)x_last, ldx_last, idx_last, B, (const T*)hyH3, mp, hy_pvar, hy_pscale, hy_pZ};
+        KbPass<T> pb{(const T*)g.Z, D, (const int64_t*)nullptr, m, (const T*)Tw2, mp, hy_pvar2, hy_pscale2, hy_pZ2};
+        const int64_t ny1 = Bq / HB_RT;
+        hipLaunchKernelGGL((k_kernel_backward2<T>), dim3(gk.x, (unsigned)(ny1 + gk.y)), dim3(NTHREADS), 0, st(), pa, pb, ny1,
+                           (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, kvar(g), mp);
+      } else
+        hipLaunchKernelGGL((k_kernel_backward<T>), gk, dim3(NTHREADS), 0, st(), (const T*)g.Z, D, (const int64_t*)nullptr,
+                           m, (const T*)g.Z, D, m, D, (const T*)g.scales, g.k.kind, kvar(g), (const T*)Tw2, mp, hy_pvar, hy_pscale,
+                           hy_pZ, mp);
+      if (one_reduce && hy_grad_on_device_only && hy_k && hy_z && D + 1 <= 256) {
+        // the training loop's hyper step: the reduction rides on the optimiser launch (k_hyper_reduce2_adam, hyper_apply_one)
+        red_def.on = true;
+        red_def.latent = l;
+        red_def.nt1 = (int64_t)(mp / TILE) * (Bq / HB_RT);
+        red_def.nrow1 = (int64_t)(Bq / HB_RT);
+        red_def.nt2 = tiles;
+        red_def.nrow2 = (int64_t)gk.y;
+        red_def.B = B;
+        red_def.rho = (double)rho;
+      } else if (one_reduce)
         hipLaunchKernelGGL((k_hyper_reduce2<T>), dim3((unsigned)(D + 1 + (m * D + 255) / 256)), dim3(256), 0, st(), D, hy_g, m, mp,
                            hy_dZ, (int64_t)(mp / TILE) * (Bq / HB_RT), (const double*)hy_pvar, (const double*)hy_pscale,
                            (int64_t)(Bq / HB_RT), (const T*)hy_pZ, tiles, (const double*)hy_pvar2, (const double*)hy_pscale2,
@@ -2721,6 +2804,12 @@ struct Svgp : SvgpBase {
   }
   std::vector<double> hy_last;
   bool hy_grad_on_device_only = false;  // set around hypergrad() by hyper_step(): no download, no synchronisation
+  struct RedDeferred {  // the gradient's final reduction, left to the optimiser launch (k_hyper_reduce2_adam)
+    bool on = false;
+    int latent = -1;
+    int64_t nt1 = 0, nrow1 = 0, nt2 = 0, nrow2 = 0, B = 0;
+    double rho = 0.0;
+  } red_def;
 
   // ADAM moments of the kernel-parameter optimiser (1 + D entries: variance, scales; a ScaleTransform uses entry 1 only).  They
   // live on the device (Latent::kadam); this call copies them out / in (handle re-creation, the online model's chain of handles,
@@ -2765,6 +2854,35 @@ struct Svgp : SvgpBase {
   // parameters goes stale until somebody asks for it (params_to_host).
   agp_status hyper_apply_one(int l, const std::vector<double>* hg_host, const T* dZ_dev) {
     Latent& g = lat[l];
+    const bool red_here = red_def.on && red_def.latent == l && !hg_host && dZ_dev == (const T*)hy_dZ;
+    if (red_def.on && !red_here) {
+      ctx->err = "hyper step: a deferred gradient reduction was not taken by its optimiser launch";
+      red_def.on = false;
+      return AGP_ERR_INVALID;
+    }
+    if (red_here) {  // reduction of both backward passes + both optimiser steps: ONE launch
+      red_def.on = false;
+      AGPCHK(hyper_alloc());
+      AGPCHK(ensure_kadam(g));
+      if (!g.z_am) {
+        AGPCHK(dmalloc(ctx, &g.z_am, m * D));
+        AGPCHK(dmalloc(ctx, &g.z_av, m * D));
+        HIPCHK(ctx, hipMemsetAsync(g.z_am, 0, sizeof(double) * m * D, st()));
+        HIPCHK(ctx, hipMemsetAsync(g.z_av, 0, sizeof(double) * m * D, st()));
+      }
+      g.k_step += 1;
+      g.z_step += 1;
+      const int64_t nzb = (m * D + HYPER_RA_THREADS - 1) / HYPER_RA_THREADS;
+      hipLaunchKernelGGL((k_hyper_reduce2_adam<T>), dim3((unsigned)(nzb + 1)), dim3(HYPER_RA_THREADS), 0, st(), D, hy_g, m, mp, hy_dZ, red_def.nt1,
+                         (const double*)hy_pvar, (const double*)hy_pscale, red_def.nrow1, (const T*)hy_pZ, red_def.nt2,
+                         (const double*)hy_pvar2, (const double*)hy_pscale2, red_def.nrow2, (const T*)hy_pZ2, (const T*)hy_gs, red_def.B,
+                         red_def.rho, g.Z, g.z_am, g.z_av, g.z_step, hy_zeta, hy_zrule, hy_zrho, g.k.ard ? 1 : 0,
+                         g.k.has_variance ? 1 : 0, g.k.has_transform ? 1 : 0, g.scales, g.kadam, g.kadam + (1 + D), g.k_step, hy_keta,
+                         hy_krule, hy_krho, hy_b1, hy_b2, hy_eps);
+      LAUNCHCHK(ctx);
+      g.host_params_stale = true;
+      return AGP_OK;
+    }
     if (hy_k && hy_z && dZ_dev && D + 1 <= 256) {  // both steps in one launch (k_adam_z_and_params)
       AGPCHK(hyper_alloc());
       AGPCHK(ensure_kadam(g));
@@ -3342,7 +3460,14 @@ struct Svgp : SvgpBase {
   // Augmented Cholesky of -2*eta2 with the extension rows [kappa (Bq rows, already in Wbuf) ; eta1'] :
   //   Wbuf <- [kappa L^-T ; (L^-1 eta1)']   i.e. W and v of mean_f = W v, var_f = rowsum(W^2) + K~.
   // with_x additionally forms Xa = L^-1 (needed only for Sigma / mu export, ELBO and prediction).
-  agp_status aug_factor(Latent& g, int64_t Bq, int with_x) {
+  // tail (materialize): the caller's next launch carries the task graph's fallback itself (k_safe_symv_trmv) -- filled when it has to
+  struct SafeTail {
+    bool on = false;
+    CholBatch<T> bt{};
+    SafeSrc<T> src{};
+    int64_t ne = 0, nt = 0;
+  };
+  agp_status aug_factor(Latent& g, int64_t Bq, int with_x, SafeTail* tail = nullptr) {
     // a pending natural-gradient step (only the hyper step's wrapper leaves one: every other entry point has flushed) rides on this
     // launch as its prologue -- the hyper-parameter iteration's "eta step, then factor the new -2 eta2 with its inverse" in ONE launch
     AGPCHK(run_deferred_safe());
@@ -3388,8 +3513,25 @@ struct Svgp : SvgpBase {
     // (SafeSrc::want_x), so that no host check -- no stream synchronisation -- sits behind the launch (round 3: the hyper-parameter
     // iteration used to wait here once per step)
     src.want_x = with_x ? 1 : 0;
+    // with_x: Sigma = Xa' Xa is what every caller forms next -- product workgroups at the end of the same task-graph launch do it
+    bool sigma_done = false;
+    bool defer = tail != nullptr;
     AGPCHK(potrf_fused<T>(ctx, g.La, mp, mp, g.Xa, mp, g.DgA, g.Wbuf, mp, Bq / TILE + 1, with_x, info_dev, m,
-                          (const T*)g.eta1, false, &src, nullptr, nullptr, use_pro ? &ph : nullptr));
+                          (const T*)g.eta1, false, &src, tail ? &defer : nullptr, nullptr, use_pro ? &ph : nullptr,
+                          (const EpiArgs<T>*)nullptr, with_x ? g.Sigma : (T*)nullptr, &sigma_done));
+    if (tail) {
+      tail->on = defer;
+      if (defer) {
+        tail->bt = CholBatch<T>{};
+        tail->bt.A[0] = g.La;
+        tail->bt.X[0] = g.Xa;
+        tail->bt.Dg[0] = g.DgA;
+        tail->bt.E[0] = g.Wbuf;
+        tail->src = src;
+        tail->ne = Bq / TILE + 1;
+        tail->nt = mp / TILE;
+      }
+    }
     if (use_pro) {  // taken by the launch (a refused launch leaves it pending for flush())
       pend.on = false;
       n_prologue += 1;
@@ -3402,6 +3544,7 @@ struct Svgp : SvgpBase {
     g.la_state = 1;
     g.xa_valid = with_x != 0;
     if (with_x) g.xa_epoch += 1;
+    g.sigma_epoch = sigma_done ? g.xa_epoch : -1;
     return AGP_OK;
   }
 
@@ -3449,6 +3592,8 @@ struct Svgp : SvgpBase {
         rel_pending = true;
         rel_slot = step_parity ^ 1;
       } else {
+        // (the step's deferred fallback, if it re-runs, rewrites the step's Wbuf and reads its pk: before the event releases them)
+        AGPCHK(run_deferred_safe());
         slot_kind[step_parity ^ 1] = 0;
         HIPCHK(ctx, hipEventRecord(step_done[step_parity ^ 1], st()));
       }
@@ -3517,13 +3662,28 @@ struct Svgp : SvgpBase {
   // Sigma = Xa' Xa ; mu = Xa' v   with Xa = chol(-2 eta2)^-1, v = Xa eta1     (inference.jl:25-28)
   agp_status materialize(Latent& g) {
     if (g.post_valid) return AGP_OK;
-    if (!(g.la_state == 1 && g.xa_valid)) AGPCHK(aug_factor(g, 0, 1));
+    SafeTail tail;
+    if (!(g.la_state == 1 && g.xa_valid)) AGPCHK(aug_factor(g, 0, 1, &tail));
     if (tw2_kis_of == (int)(&g - lat.data())) tw2_kis_of = -1;  // K^-1 Sigma in the scratch belongs to the Sigma before this one
-    AGPCHK(xtx_padded<T>(ctx, g.Xa, mp, mp, g.Sigma, mp));
+    if (g.sigma_epoch != g.xa_epoch) {  // (else: left by the launch itself)
+      if (tail.on) {
+        AGPCHK(launch_chol_safe<T>(ctx, tail.bt, tail.src, 1, mp, mp, mp, tail.ne, tail.nt, info_dev, m));
+        tail.on = false;
+      }
+      AGPCHK(xtx_padded<T>(ctx, g.Xa, mp, mp, g.Sigma, mp));
+    }
     // mu = Sigma eta1 as the reference writes it (global_update!, analyticVI.jl:229-246).  Until round 4 this was Xa' (Xa eta1) from
     // the factorisation's [eta1'] row: a copy and a 16-workgroup triangular mat-vec (4.8 + 15.6 us at m = 1024 against 7.0)
-    hipLaunchKernelGGL((k_symv_trmv<T>), grid1(2 * mp * 64), dim3(256), 0, st(), (const T*)g.Sigma, (const T*)g.Xa, mp, mp,
-                       (const T*)g.eta1, g.mu, g.v);
+    if (tail.on) {  // the task graph's fallback rides on this launch
+      AGPCHK(ensure_safe_words<T>(ctx));
+      const int64_t most = std::max<int64_t>(tail.nt + tail.ne + tail.nt * (tail.nt + 1) / 2 + tail.ne * tail.nt, (2 * mp + 7) / 8);
+      const unsigned g1 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(safe_grid_cap(ctx), most));
+      hipLaunchKernelGGL((k_safe_symv_trmv<T>), dim3(g1), dim3(CHOL_THREADS), 0, st(), tail.bt, tail.src, mp, mp, mp, tail.ne, tail.nt,
+                         info_dev, m, ctx->safe_bar, ctx->safe_retries, (const T*)g.Sigma, (const T*)g.Xa, mp, mp, (const T*)g.eta1,
+                         g.mu, g.v);
+    } else
+      hipLaunchKernelGGL((k_symv_trmv<T>), grid1(2 * mp * 64), dim3(256), 0, st(), (const T*)g.Sigma, (const T*)g.Xa, mp, mp,
+                         (const T*)g.eta1, g.mu, g.v);
     LAUNCHCHK(ctx);
     g.v_epoch = g.xa_epoch;
     g.post_valid = true;
@@ -3968,16 +4128,17 @@ struct Svgp : SvgpBase {
     const int64_t CH = pred_chunk;
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
-      if (!need_var) {
+      if (!need_var && kmm_usable(D)) {
         // means only: ONE launch over all test points, every workgroup carries its 64 rows through all inducing-point tiles with
-        // the row-dot against K^-1 mu in registers -- K*m and per-tile partial sums never reach memory (predictions.jl:33-34)
+        // the row-dot against K^-1 mu in registers -- K*m and per-tile partial sums never reach memory (predictions.jl:33-34).
+        // (The VALU kernel -- D beyond the MFMA kernel's limit -- leaves one slice per column tile, which the caller's output
+        // has no room for: it takes the chunked form below.)
         const int slices = launch_kernelmatrix<T>(ctx, st(), (const T*)xt, ldx, (const int64_t*)nullptr, nt, (const T*)g.Z, D, m, D,
                                                   (const T*)g.scales, g.k.kind, kvar(g), (T*)nullptr, mp, nt, mp, 0, T(0),
                                                   (const T*)g.apred, (T*)mu_out + (int64_t)l * nt, nt, 1, (const T*)g.Zsc,
                                                   (const T*)g.zn);
         LAUNCHCHK(ctx);
         if (slices == 1) continue;
-        // (D beyond the MFMA kernel's limit: the VALU kernel left one slice per column tile -- redo chunked below)
       }
       for (int64_t s = 0; s < nt; s += CH) {
         const int64_t nc = (nt - s) < CH ? (nt - s) : CH;

@@ -1045,6 +1045,12 @@ struct SafeSrc {
   // split launch (k_chol_dag ROLE 1 / 2): the chain kernel(s) of the launch have counted themselves out when *chain_done >= chain_want
   const int32_t* chain_done = nullptr;
   int32_t chain_want = 0;
+  // the launch also delivers P = X' X (ProdArgs): the fallback forms it from its own X (problem 0; leading dimension ldpo)
+  T* pout = nullptr;
+  int64_t ldpo = 0;
+  double* ld_out = nullptr;      // ... and log det of the factor over the first ld_n rows (ProdArgs::ld_out), with its status words
+  int32_t* ld_status = nullptr;
+  int64_t ld_n = 0;
 };
 
 // the kernel functions of agp_cavi.h restated for the fallback (agp_chol.h is included first): base(d2), d2 = squared scaled distance
@@ -1161,6 +1167,29 @@ __device__ __forceinline__ bool chol_safe_body(const CholBatch<T>& bt, const Saf
       }
     }
     grid_barrier(bar, ++phase * nwg);
+    if (src.pout) {  // P = X' X, one thread per lower element, k ascending (X is lower triangular: the sum starts at row i)
+      const T* X = bt.X[0];
+      for (int64_t e = g0; e < n * n; e += gsz) {
+        const int64_t i = e / n, j = e % n;
+        if (j > i) continue;
+        T sacc = T(0);
+        for (int64_t k = i; k < n; ++k) sacc += X[k * ldx + i] * X[k * ldx + j];
+        src.pout[i * src.ldpo + j] = sacc;
+        src.pout[j * src.ldpo + i] = sacc;
+      }
+      if (src.ld_out && blockIdx.x == 0) {  // log det from the diagonal factors (as k_logdiag_sum reads them)
+        const T* Dg = bt.Dg[0];
+        double lsum = 0.0;
+        for (int64_t i = threadIdx.x; i < src.ld_n; i += CHOL_THREADS) lsum += log((double)Dg[(i / TILE) * TILE * TILE + (i % TILE) * (TILE + 1)]);
+        lsum = block_sum<double>(lsum, reinterpret_cast<double*>(sc));
+        if (threadIdx.x == 0) {
+          src.ld_out[0] = lsum;
+          int32_t* st_ = src.ld_status;
+          if (st_ && st_[1] != 0 && st_[3] == 0) st_[3] = (st_[0] != 0 || st_[2] != 0) ? 2 : 1;
+        }
+      }
+      grid_barrier(bar, ++phase * nwg);
+    }
   }
   // leave the barrier words at zero for the next use: arrivals are counted on a second word, the last one to arrive resets both
   if (threadIdx.x == 0) {
@@ -1676,6 +1705,34 @@ template <typename T, int ROLE, bool PRO>
 constexpr int dag_min_waves() {
   return ROLE != 2 ? 1 : PRO ? (sizeof(T) == 8 ? 2 : 4) : (sizeof(T) == 8 ? AGP_TILES_WAVES_F64 : AGP_TILES_WAVES_F32);
 }
+// ---- P = X' X as SINK work of the launch that produces X = L^-1 (round 5) ------------------------------------
+// A launch with the nt identity block rows (nx = nt) leaves X in the hand-over slots of those rows: slot (nt + ne + i, k) holds
+// E(i, k) = X(k, i)' once block column k has been processed.  Both consumers of such a launch need X' X next -- K^-1 = X' X at a
+// kernel refresh, Sigma = Xa' Xa for the hyper-gradient -- and until round 4 that was two more launches (k_xtx_bal 20.7 us +
+// k_xtx_bal_reduce 8.7 us, twice per hyper-on iteration) BEHIND a launch in which 255 CUs wait for the chain.  Now the launch ends
+// with nt (nt + 1) / 2 PRODUCT workgroups, one per lower tile (i, j):
+//     P(i, j) = sum_{k >= i} E(i, k) E(j, k)'                         (k ascending: fixed order, bitwise reproducible)
+// They are the LAST workgroups of the grid: they only get a slot when everything else has been dispatched, by which time most of
+// their operands are there; each waits for the flags of its two operand tiles like any tile workgroup (abortable), and what they
+// wait for has lower workgroup indices (the dispatch-order argument is untouched).  The tile is stored to `out` in both
+// triangles (diagonal tiles: the lower half is the truth).  Before it starts, a product workgroup also stores its share of the
+// sentinels of the OTHER hand-over set (fill): the launches whose riders did that (k_xtx_bal, k_syrk_tn) are gone from this path.
+// If the launch is aborted the in-stream fallback forms P itself (SafeSrc::pout).
+template <typename T>
+struct ProdArgs {
+  T* out = nullptr;     // n x n, leading dimension ld; nullptr: no product workgroups
+  int64_t ld = 0;
+  int64_t base = 0;     // index of the first product workgroup in the grid
+  T* fill = nullptr;    // (nullable) hand-over set to refill with the sentinel
+  int64_t fill_n = 0;
+  // (nullable) log det of the factored matrix' Cholesky factor, sum_i log L_ii over the first nvalid rows, by the LAST product
+  // workgroup: it has waited for the last block column, so every X_k = L_kk^-1 sits in its hand-over slot, and the diagonal of a
+  // triangular inverse is the reciprocal of the factor's (the launch behind a kernel refresh that did this, k_logdiag_sum /
+  // k_xtx_bal_reduce's rider, is gone).  status: the [info | infoK | flags | orderK] words of k_logdiag_sum, same bookkeeping.
+  double* ld_out = nullptr;
+  int32_t* status = nullptr;
+};
+
 template <typename T, bool FUSED, bool BATCH = false, bool TRACE = false, bool STEP = false, bool PRO = false, int ROLE = 0>
 __global__ __launch_bounds__(CHOL_THREADS, (dag_min_waves<T, ROLE, PRO>()))
 void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ldx,
@@ -1683,7 +1740,8 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
                                                            int32_t* __restrict__ info, int64_t nvalid, int32_t* flags,
                                                            int32_t epoch, unsigned long long* trace, T* H, int64_t hstride,
                                                            int64_t nx_, const T* __restrict__ erow, int opts, DagSync sync,
-                                                           ProArgs<T> pro = ProArgs<T>{}, EpiArgs<T> epi = EpiArgs<T>{}) {
+                                                           ProArgs<T> pro = ProArgs<T>{}, EpiArgs<T> epi = EpiArgs<T>{},
+                                                           ProdArgs<T> prod = ProdArgs<T>{}) {
   static_assert(!PRO || (FUSED && !BATCH), "the prologue exists for single-problem launches with a chain workgroup only");
   static_assert(ROLE == 0 || (FUSED && STEP && !TRACE), "the split launch exists for the CAVI step's launches");
   // opts bit 0: the chain also stores X_k to its real home (a single block column wanting its inverse: no identity rows run)
@@ -1759,7 +1817,10 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
   int64_t b = bidx, c = 0;
   bool helper = false;
   int64_t hbase = 0;  // PRO: helper slots of the columns before c
-  if (PRO && ROLE == 1) {
+  const bool is_prod = !BATCH && !STEP && ROLE != 1 && prod.out != nullptr && bidx >= prod.base;  // P = X' X tile (see ProdArgs)
+  if (is_prod) {
+    b = 0;  // (decoded below, once the flag pointers are in place)
+  } else if (PRO && ROLE == 1) {
     // the chain kernel: tile (0, 0), whose place in the tile kernel comes right after the helpers of block column 0 (hbase = 0)
   } else if (PRO) {
     for (;;) {
@@ -1826,6 +1887,62 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
   if (TRACE && tid == 0) trace[bidx * 8 + (slot)] = wall_clock64()
 #define DAG_TRC(col, slot) \
   if (TRACE && tid == 0) trace[chain_slot(col, nt, ne, nx) * 8 + (slot)] = wall_clock64()
+  if (is_prod) {
+    const int64_t pidx = bidx - prod.base, nprod = nt * (nt + 1) / 2;
+    if (prod.fill) {  // this workgroup's share of the other hand-over set's sentinels (fire-and-forget)
+      const T sv = __builtin_bit_cast(T, Sent<T>::bits);
+      for (int64_t i = pidx * CHOL_THREADS + tid; i < prod.fill_n; i += nprod * CHOL_THREADS) prod.fill[i] = sv;
+    }
+    int64_t pi, pj;
+    tri_index(pidx, pi, pj);  // lower tile (pi, pj), pj <= pi
+    const bool pdiag = pi == pj;
+    const int64_t Ri = nt + ne + pi, Rj = nt + ne + pj;
+    Acc8<T> pacc;
+    pacc.zero();
+    for (int64_t k = pi; k < nt; ++k) {
+      if (!dag_wait(ready + (Ri * nt + k) * DAG_FS, pdiag ? nullptr : ready + (Rj * nt + k) * DAG_FS, epoch, abortf, info, &wait_ok))
+        return;
+      if (pdiag) load_tile_lds_hv<T>(HL + (Ri * nt + k) * SLOT, bufA);
+      else load_tiles_lds_hv2<T>(HL + (Ri * nt + k) * SLOT, bufA, HL + (Rj * nt + k) * SLOT, bufB);
+      __syncthreads();
+      mma8<T>(bufA, pdiag ? bufA : bufB, pacc);
+      __syncthreads();
+    }
+    const int64_t i0 = pi * TILE, j0 = pj * TILE;
+    if (pdiag) {  // the lower half is the truth, the upper half its mirror image
+      acc8_foreach<T>(pacc, [&](int r, int cc, T& val) { bufA[r * LDP + cc] = val; });
+      __syncthreads();
+      acc8_foreach<T>(pacc, [&](int r, int cc, T& val) {
+        prod.out[(i0 + r) * prod.ld + i0 + cc] = cc > r ? bufA[cc * LDP + r] : val;
+      });
+    } else {
+      acc8_foreach<T>(pacc, [&](int r, int cc, T& val) {
+        prod.out[(i0 + r) * prod.ld + j0 + cc] = val;
+        prod.out[(j0 + cc) * prod.ld + i0 + r] = val;
+      });
+    }
+    if (prod.ld_out && pidx == nprod - 1) {  // tile (nt - 1, nt - 1): every xready flag is up
+      __syncthreads();
+      double lsum = 0.0;
+      for (int64_t i = tid; i < nvalid; i += CHOL_THREADS) {
+        const T* px = HX + (i / TILE) * SLOT + (i % TILE) * (TILE + 1);
+        const T xv = hv_settle<T>(px, __hip_atomic_load(px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        lsum -= log((double)xv);
+      }
+      lsum = block_sum<double>(lsum, reinterpret_cast<double*>(sc));
+      if (tid == 0) {
+        prod.ld_out[0] = lsum;
+        int32_t* st_ = prod.status;
+        if (st_) {
+          const int32_t i0_ = __hip_atomic_load(st_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int32_t i1_ = __hip_atomic_load(st_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int32_t i2_ = __hip_atomic_load(st_ + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (i1_ != 0 && st_[3] == 0) st_[3] = (i0_ != 0 || i2_ != 0) ? 2 : 1;
+        }
+      }
+    }
+    return;
+  }
   DAG_TR(0);
   const bool chain = FUSED && c == 0 && b == 0;  // (PRO: no longer workgroup 0 -- the helpers of column 0 come first)
   if (STEP && !BATCH && sync.started && chain && tid == 0 && ROLE != 1)

@@ -101,37 +101,8 @@ __global__ void k_hyper_hk(int64_t B, int64_t rows, int64_t cols, int64_t ld, T 
   Gknm[i * ld + j] = g;
 }
 
-// The same on 64 x 64 tiles (grid = (cols / 64, rows / 64), 256 threads) with the column sums  u = kappa' g_mu  on the way:
-// upart[tile row][col] = sum over the tile's rows of g_mu_i kappa_ij (fixed order; the consumer, k_hyper_gK_fused, adds the tile
-// rows).  H is optional (the fused G_K does not need it).
-template <typename T>
-__global__ __launch_bounds__(256) void k_hyper_hk_tile(int64_t B, int64_t ld, T rho, const T* __restrict__ gmu,
-                                                       const T* __restrict__ gs, const T* __restrict__ a,
-                                                       const T* __restrict__ T1, const T* __restrict__ kappa,
-                                                       T* __restrict__ H, T* __restrict__ Gknm, T* __restrict__ upart,
-                                                       int64_t ldu) {
-  __shared__ T red[4][64];
-  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int64_t j = blockIdx.x * (int64_t)64 + col, i0 = blockIdx.y * (int64_t)64 + rg * 16;
-  const T aj = a[j];
-  T u = T(0);
-#pragma unroll 4
-  for (int q = 0; q < 16; ++q) {
-    const int64_t i = i0 + q;
-    T h = T(0), g = T(0);
-    if (i < B) {
-      const T k = kappa[i * ld + j], s = rho * gs[i], gm = gmu[i];
-      h = rho * gm * aj + s * (T(2) * T1[i * ld + j] - k);
-      g = h - s * k;
-      u += gm * k;
-    }
-    if (H) H[i * ld + j] = h;
-    Gknm[i * ld + j] = g;
-  }
-  red[rg][col] = u;
-  __syncthreads();
-  if (rg == 0) upart[blockIdx.y * ldu + j] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-}
+// (round 5: the tile form of this pass, k_hyper_hk_tile, which also left the partial column sums of u = kappa' g_mu for the fused G_K,
+//  is the epilogue of the product in front of it now: k_gemm_nt<EPI_HK>, agp_linalg.h)
 
 // G_K from ONE m^3 product (round 4).  With S = kappa' diag(w) kappa of the step (w = rho grad_E_Sigma = -rho g_s), C = S + K^-1/4
 // (left by the prologue of the factorisation launch, ProArgs::Cout), M = Sigma K^-1, a = K^-1 mu, at = a - K^-1 mu0, u = kappa' g_mu:
@@ -331,14 +302,13 @@ constexpr int HB_MAXD = 64;
 // 21.6 + 19.5 us for the two passes at m = B = 1024, and the reduction behind them 10.0 -> 17.7 us (twice the partial sums): the
 // pass is bound by its LDS traffic (nine ds_read per row of C in pass 2), not by occupancy.  64 it stays.
 constexpr int HB_RT = 64;
+// (by: the workgroup's row block -- the y index of a launch of its own, or its offset inside a launch that carries two passes)
 template <typename T, int RT = HB_RT>
-__global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restrict__ X, int64_t ldx,
-                                                              const int64_t* __restrict__ idx, int64_t n,
-                                                              const T* __restrict__ Y, int64_t ldy, int64_t p, int64_t D,
-                                                              const T* __restrict__ scales, int kind, T variance,
-                                                              const T* __restrict__ G, int64_t ldg,
-                                                              double* __restrict__ pvar, double* __restrict__ pscale,
-                                                              T* __restrict__ pZ, int64_t p_pad) {
+__device__ __forceinline__ void kernel_backward_body(const T* __restrict__ X, int64_t ldx, const int64_t* __restrict__ idx, int64_t n,
+                                                     const T* __restrict__ Y, int64_t ldy, int64_t p, int64_t D,
+                                                     const T* __restrict__ scales, int kind, T variance,
+                                                     const T* __restrict__ G, int64_t ldg, double* __restrict__ pvar,
+                                                     double* __restrict__ pscale, T* __restrict__ pZ, int64_t p_pad, int64_t by) {
   if (variance < T(0)) variance = scales[D];  // device-resident kernel parameters (see k_kernelmatrix)
   static_assert(RT == 32 || RT == 64, "k_kernel_backward: 32 or 64 rows per workgroup");
   constexpr int NA = RT / 16;  // row groups of 16 per thread
@@ -349,8 +319,8 @@ __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restric
   __shared__ double red[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ty = tid >> 4, tx = tid & 15;
-  const int64_t i0 = blockIdx.y * (int64_t)RT, j0 = blockIdx.x * (int64_t)TILE;
-  const int64_t tile = blockIdx.y * (int64_t)gridDim.x + blockIdx.x;
+  const int64_t i0 = by * (int64_t)RT, j0 = blockIdx.x * (int64_t)TILE;
+  const int64_t tile = by * (int64_t)gridDim.x + blockIdx.x;
   T acc[NA][4];
 #pragma unroll
   for (int a = 0; a < NA; ++a)
@@ -466,11 +436,47 @@ __global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restric
       double ss = (double)rw * xv * xv - 2.0 * yv * (double)zs[q] + (double)cols * yv * yv;
       for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
       if (gd < D) {
-        if (gj < p_pad) pZ[(blockIdx.y * p_pad + gj) * D + gd] = T(-2) * sc * (zs[q] - cols * ys[lane][d]);
+        if (gj < p_pad) pZ[(by * p_pad + gj) * D + gd] = T(-2) * sc * (zs[q] - cols * ys[lane][d]);
         if (lane == 0) pscale[tile * D + gd] = 2.0 / (double)sc * ss;
       }
     }
   }
+}
+template <typename T, int RT = HB_RT>
+__global__ __launch_bounds__(NTHREADS) void k_kernel_backward(const T* __restrict__ X, int64_t ldx,
+                                                              const int64_t* __restrict__ idx, int64_t n,
+                                                              const T* __restrict__ Y, int64_t ldy, int64_t p, int64_t D,
+                                                              const T* __restrict__ scales, int kind, T variance,
+                                                              const T* __restrict__ G, int64_t ldg,
+                                                              double* __restrict__ pvar, double* __restrict__ pscale,
+                                                              T* __restrict__ pZ, int64_t p_pad) {
+  kernel_backward_body<T, RT>(X, ldx, idx, n, Y, ldy, p, D, scales, kind, variance, G, ldg, pvar, pscale, pZ, p_pad,
+                              (int64_t)blockIdx.y);
+}
+// The backward passes through K_nm = k(x, Z) and K_ZZ = k(Z, Z) of one gradient evaluation in ONE launch (round 5): they are
+// independent (both read a finished G), each is 256 workgroups of one wave per SIMD at m = B = 1024 and bound by the latency of
+// its phases -- side by side they overlap (24.4 + 20.1 us as two launches).  Row blocks [0, ny1): first pass; the rest: second.
+// Same second argument Y (the inducing points) and kernel; each pass writes its own partial sums, exactly as on its own.
+template <typename T>
+struct KbPass {
+  const T* X;
+  int64_t ldx;
+  const int64_t* idx;
+  int64_t n;
+  const T* G;
+  int64_t ldg;
+  double* pvar;
+  double* pscale;
+  T* pZ;
+};
+template <typename T, int RT = HB_RT>
+__global__ __launch_bounds__(NTHREADS) void k_kernel_backward2(KbPass<T> a, KbPass<T> b, int64_t ny1, const T* __restrict__ Y,
+                                                               int64_t ldy, int64_t p, int64_t D, const T* __restrict__ scales,
+                                                               int kind, T variance, int64_t p_pad) {
+  const bool second = (int64_t)blockIdx.y >= ny1;  // (uniform: the selects below are scalar)
+  kernel_backward_body<T, RT>(second ? b.X : a.X, second ? b.ldx : a.ldx, second ? b.idx : a.idx, second ? b.n : a.n, Y, ldy, p, D,
+                              scales, kind, variance, second ? b.G : a.G, second ? b.ldg : a.ldg, second ? b.pvar : a.pvar,
+                              second ? b.pscale : a.pscale, second ? b.pZ : a.pZ, p_pad, (int64_t)blockIdx.y - (second ? ny1 : 0));
 }
 
 // out[0] += wgt * sum pvar ; out[1 + d] += wgt * sum_tiles pscale[tile][d] : one workgroup per output, fixed-order tree
@@ -647,6 +653,117 @@ __global__ void k_adam_z_and_params(int64_t nz, int64_t nzb, T* __restrict__ z, 
     else
       for (int d = 0; d < D; ++d) params[d] = (T)np_;
   }
+}
+
+// k_hyper_reduce2 + k_adam_z_and_params in ONE launch (round 5): the hyper step of the training loop never looks at the gradient
+// between the two, and every kernel costs the in-order queue ~5 us.  Same arithmetic in the same order as the two kernels -- the
+// scalar reductions reproduce block_sum's order (thread-strided partial sums, halving shuffles per wave, waves added in order)
+// with one WAVE standing in for the 256-thread workgroup, so that hypergrad + hyper_apply (the split a tied-Z driver all-reduces
+// in between) stays bit-identical to hyper_step.
+//   workgroup 0: the D + 1 kernel-parameter gradients (waves take them in turn), out[0 .. D], then the parameters' optimiser step;
+//   workgroups 1 ..: elements of Z -- reduce dZ[e] from both sets of partial sums, store it, take its optimiser step.
+// emulation of block_sum<double> over two sequences f1(t), t < n1, and f2(t), t < n2 (t = thread index of a 256-thread workgroup) by
+// one wave; the first element of every virtual thread is fetched before any arithmetic (the usual case, n <= 256, is then ONE round
+// of eight independent loads -- a wave that takes several gradients in turn pays a memory latency per round, not per load)
+template <typename F1, typename F2>
+__device__ __forceinline__ void wave_as_block_sum2(int64_t n1, F1 f1, int64_t n2, F2 f2, double& r1, double& r2) {
+  const int lane = threadIdx.x & 63;
+  double s1[4], s2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {  // virtual wave q of the 256-thread workgroup: threads 64 q .. 64 q + 63
+    s1[q] = lane + 64 * q < n1 ? f1(lane + 64 * q) : 0.0;
+    s2[q] = lane + 64 * q < n2 ? f2(lane + 64 * q) : 0.0;
+  }
+  double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    double a = 0.0 + s1[q], b = 0.0 + s2[q];
+    for (int64_t t = lane + 64 * q + 256; t < n1; t += 256) a += f1(t);
+    for (int64_t t = lane + 64 * q + 256; t < n2; t += 256) b += f2(t);
+    for (int o = 32; o > 0; o >>= 1) {
+      a += __shfl_down(a, o);
+      b += __shfl_down(b, o);
+    }
+    t1 += __shfl(a, 0);
+    t2 += __shfl(b, 0);
+  }
+  r1 = t1;
+  r2 = t2;
+}
+constexpr int HYPER_RA_THREADS = 1024;  // workgroup 0 takes the D + 1 scalar gradients wave by wave: 16 waves
+template <typename T>
+__global__ __launch_bounds__(HYPER_RA_THREADS) void k_hyper_reduce2_adam(
+    int64_t D, double* __restrict__ out, int64_t p, int64_t p_pad, T* __restrict__ dZ, int64_t ntiles1, const double* __restrict__ pvar1,
+    const double* __restrict__ pscale1, int64_t nrow1, const T* __restrict__ pZ1, int64_t ntiles2, const double* __restrict__ pvar2,
+    const double* __restrict__ pscale2, int64_t nrow2, const T* __restrict__ pZ2, const T* __restrict__ xkd, int64_t Bkd, double wgt_kd,
+    // optimiser state (k_adam_z_and_params)
+    T* __restrict__ z, double* __restrict__ zm, double* __restrict__ zv, int zstep, double zeta, int zrule, double zrho, int ard,
+    int has_variance, int has_transform, T* __restrict__ params, double* __restrict__ am, double* __restrict__ av, int kstep, double keta,
+    int krule, double krho, double b1, double b2, double eps) {
+  if (blockIdx.x == 0) {
+    __shared__ double gsh[257];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+    for (int d = wave; d <= (int)D; d += nwave) {
+      double s1, s2, extra = 0.0, unused;
+      wave_as_block_sum2(
+          ntiles1, [&](int64_t t) { return d == 0 ? pvar1[t] : pscale1[t * D + d - 1]; }, ntiles2,
+          [&](int64_t t) { return d == 0 ? pvar2[t] : pscale2[t * D + d - 1]; }, s1, s2);
+      if (d == 0 && xkd) {
+        wave_as_block_sum2(Bkd, [&](int64_t i) { return (double)xkd[i]; }, 0, [&](int64_t) { return 0.0; }, extra, unused);
+        extra *= wgt_kd;
+      }
+      const double gd = ((0.0 + 1.0 * s1 + extra)) + 1.0 * s2;
+      if (lane == 0) {
+        out[d] = gd;
+        gsh[d] = gd;
+      }
+    }
+    __syncthreads();
+    const int np = 1 + (ard ? (int)D : 1);
+    const int j = threadIdx.x;
+    if (j >= np) return;
+    const double pj = j == 0 ? (double)params[D] : (double)params[ard ? j - 1 : 0];
+    double gl;
+    if (j == 0) {
+      gl = has_variance ? pj * gsh[0] : 0.0;
+    } else if (ard) {
+      gl = has_transform ? pj * gsh[j] : 0.0;
+    } else {
+      double sgm = 0.0;
+      for (int d = 0; d < (int)D; ++d) sgm += gsh[1 + d];
+      gl = has_transform ? pj * sgm : 0.0;
+    }
+    const double np_ = exp(log(pj) + opt_rule_delta(krule, gl, am + j, av + j, kstep, keta, b1, b2, eps, krho));
+    if (j == 0) {
+      if (has_variance) params[D] = (T)np_;
+      else am[0] = av[0] = 0.0;
+    } else if (has_transform) {
+      if (ard) params[j - 1] = (T)np_;
+      else
+        for (int d = 0; d < (int)D; ++d) params[d] = (T)np_;
+    }
+    return;
+  }
+  const int64_t e = ((int64_t)blockIdx.x - 1) * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= p * D) return;
+  const int64_t j = e / D, d = e % D;
+  T a = T(0), b = T(0);
+  int64_t r = 0;
+  for (; r + 4 <= nrow1; r += 4) {
+    const T x0 = pZ1[(r * p_pad + j) * D + d], x1 = pZ1[((r + 1) * p_pad + j) * D + d];
+    const T x2 = pZ1[((r + 2) * p_pad + j) * D + d], x3 = pZ1[((r + 3) * p_pad + j) * D + d];
+    a = (((a + x0) + x1) + x2) + x3;
+  }
+  for (; r < nrow1; ++r) a += pZ1[(r * p_pad + j) * D + d];
+  for (r = 0; r + 4 <= nrow2; r += 4) {
+    const T x0 = pZ2[(r * p_pad + j) * D + d], x1 = pZ2[((r + 1) * p_pad + j) * D + d];
+    const T x2 = pZ2[((r + 2) * p_pad + j) * D + d], x3 = pZ2[((r + 3) * p_pad + j) * D + d];
+    b = (((b + x0) + x1) + x2) + x3;
+  }
+  for (; r < nrow2; ++r) b += pZ2[(r * p_pad + j) * D + d];
+  const T gz = (T(0) + T(1) * a) + T(2) * b;
+  dZ[e] = gz;
+  z[e] = (T)((double)z[e] + opt_rule_delta(zrule, (double)gz, zm + e, zv + e, zstep, zeta, b1, b2, eps, zrho));
 }
 
 // C(M x N) = A(K x M)^T B(K x N)  (both operands row-contiguous; general, non-symmetric).  grid = (N/64, M/64)

@@ -23,14 +23,26 @@ namespace agp {
 // Partial slices: slice = blockIdx.x*2 + wn, each of length ldp; the consumer sums slices in fixed order
 // (deterministic, no atomics).
 // ---------------------------------------------------------------------------------------------------
-enum { EPI_STORE = 0, EPI_KAPPA = 1, EPI_W = 2, EPI_ROWDOT = 3, EPI_EMINUS = 4 };
+//   EPI_HK      no C    ; the hyper-gradient's element-wise pass behind T1 = kappa (Sigma K^-1) (k_hyper_hk, agp_hyper.h) as the
+//               epilogue of that product (round 5: one launch and 16 MB of T1 traffic less per hyper-on iteration):
+//                 h = rho g_mu_i a_j + rho g_s_i (2 T1_ij - kappa_ij) ;  G_Knm_ij = h - rho g_s_i kappa_ij   -> part1 (ld = ldc)
+//                 upart[2 (tile row) + row wave][j] = sum over that wave's 32 rows of g_mu_i kappa_ij          -> part0 (ld = ldp)
+//               E = kappa, v = a = K^-1 mu; rows >= hk.B give zeros
+enum { EPI_STORE = 0, EPI_KAPPA = 1, EPI_W = 2, EPI_ROWDOT = 3, EPI_EMINUS = 4, EPI_HK = 5 };
+template <typename T>
+struct HkArgs {
+  const T* gmu = nullptr;
+  const T* gs = nullptr;
+  T rho = T(0);
+  int64_t B = 0;
+};
 
 template <typename T, int EPI, int KG = 1>
 __global__ __launch_bounds__(NTHREADS * KG) void k_gemm_nt(const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
                                                       int64_t ldb, int64_t K, int tri_b, T* __restrict__ C,
                                                       int64_t ldc, const T* __restrict__ E, int64_t lde,
                                                       const T* __restrict__ v, T* __restrict__ part0,
-                                                      T* __restrict__ part1, int64_t ldp) {
+                                                      T* __restrict__ part1, int64_t ldp, HkArgs<T> hk = HkArgs<T>{}) {
   __shared__ __attribute__((aligned(16))) T smem[KG * smem_elems<T>()];
   int64_t bn, bm;  // XCD-aware: every XCD works on a compact block of C tiles (agp_chol.h, xcd_contiguous)
 #ifndef AGP_GEMM_XCD
@@ -60,6 +72,38 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_gemm_nt(const T* __restrict__
   }
   if (EPI == EPI_EMINUS) {
     acc_foreach<T>(acc, [&](int r, int c, T val) { C[(r0 + r) * ldc + c0 + c] = E[(r0 + r) * lde + c0 + c] - val; });
+  }
+  if (EPI == EPI_HK) {
+    // this thread's values of a column: rows (lane >> 4) + 4 r + 16 mi of its wave's 32; column sums: over r and mi in the thread, then
+    // over the four lanes that share a column (xor 16, 32) -- a fixed order
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, wm = wave >> 1, wn = wave & 1;
+    T ucol[2] = {T(0), T(0)};
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * 32 + mi * 16 + Mfma<T>::row(lane, r), col = wn * 32 + ni * 16 + (lane & 15);
+          const int64_t i = r0 + row, j = c0 + col;
+          T g = T(0);
+          if (i < hk.B) {
+            const T k = E[i * lde + j], sg = hk.rho * hk.gs[i], gm = hk.gmu[i];
+            const T h = hk.rho * gm * v[j] + sg * (T(2) * acc.a[mi][ni][r] - k);
+            g = h - sg * k;
+            ucol[ni] += gm * k;
+          }
+          part1[i * ldc + j] = g;
+        }
+    // one row of partial sums per (tile row, row wave): 2 M / 64 rows of `part0`, which the consumer adds in order (no barrier here:
+    // with two k-groups half of the workgroup has left already)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      T u = ucol[ni];
+      u += __shfl_xor(u, 16);
+      u += __shfl_xor(u, 32);
+      if (lane < 16) part0[(bm * 2 + wm) * ldp + c0 + wn * 32 + ni * 16 + lane] = u;
+    }
   }
   if (EPI == EPI_KAPPA || EPI == EPI_ROWDOT || EPI == EPI_W) {
     const int wn = (threadIdx.x >> 6) & 1;
@@ -467,11 +511,8 @@ __global__ void k_trmv_lower(const T* __restrict__ X, int64_t ld, int64_t n, con
 // k_trmv_lower) in ONE launch: mu = Sigma eta1 and v = Xa eta1 behind a factorisation with its inverse (materialize), so that the
 // next step with that inverse finds v ready instead of launching k_trmv_lower itself
 template <typename T>
-__global__ void k_symv_trmv(const T* __restrict__ S, const T* __restrict__ X, int64_t ld, int64_t n, const T* __restrict__ x,
-                            T* __restrict__ ys, T* __restrict__ yt) {
-  const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (w >= 2 * n) return;
+__device__ __forceinline__ void symv_trmv_row(int64_t w, int lane, const T* __restrict__ S, const T* __restrict__ X, int64_t ld,
+                                              int64_t n, const T* __restrict__ x, T* __restrict__ ys, T* __restrict__ yt) {
   const bool tri = w >= n;
   const int64_t row = tri ? w - n : w;
   const T* M = tri ? X : S;
@@ -480,6 +521,13 @@ __global__ void k_symv_trmv(const T* __restrict__ S, const T* __restrict__ X, in
   for (int64_t k = lane; k < kend; k += 64) s += M[row * ld + k] * x[k];
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
   if (lane == 0) (tri ? yt : ys)[row] = s;
+}
+template <typename T>
+__global__ void k_symv_trmv(const T* __restrict__ S, const T* __restrict__ X, int64_t ld, int64_t n, const T* __restrict__ x,
+                            T* __restrict__ ys, T* __restrict__ yt) {
+  const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w >= 2 * n) return;
+  symv_trmv_row<T>(w, threadIdx.x & 63, S, X, ld, n, x, ys, yt);
 }
 
 // (round 4: mu = Sigma eta1 replaced the transposed triangular mat-vec mu = Xa' v, k_trmv_lower_t, which is gone)

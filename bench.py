@@ -179,6 +179,48 @@ def build_model(AGP, cfg, ell, Z, B_local, rank, world, dev_index, mode):
     raise ValueError(lik)
 
 
+def _pmc_traffic(cfg_name, kernel_name, step_inst):
+    """traffic (bytes per launch) of `kernel_name` from profiles/r05_<cfg>_pmc_hbm_bytes.json (older rounds' files as fall-backs):
+    -> {"traffic": .., "traffic_source": .., "traffic_kernel": ..} or {} when no file lists the kernel"""
+    names = [f"r05_{cfg_name}_pmc_hbm_bytes.json"]
+    names += {"c2": ["r04_pmc_hbm_bytes.json", "r03_pmc_hbm_bytes.json"], "c3": ["r04_c3_pmc_hbm_bytes.json", "r03_c3_pmc_hbm_bytes.json"],
+              "c5": ["r02_c5_pmc_hbm_bytes.json"]}.get(cfg_name, [])
+    # rocprofv3 prints every template argument: match on the kernel's name and its leading arguments
+    base = kernel_name.split(" (")[0].split(", ...")[0].rstrip(">")
+    stem = base.split("<")[0]
+    for pf in names:
+        try:
+            with open(os.path.join(ROOT, "profiles", pf)) as fh:
+                pm = json.load(fh)
+        except Exception:
+            continue
+        keys = [k for k in pm["kernels"] if k.startswith(base)] or ([k for k in pm["kernels"] if k.startswith(stem + "<")] if "blocked" not in base else [])
+        if "blocked" in kernel_name:  # the blocked factorisation: its three kernels together, per step launch count unknown here: per kernel
+            parts = {k: pm["kernels"][k]["hbm_bytes_per_launch_corrected"] for k in pm["kernels"]
+                     if k.startswith(("k_chol_step<", "k_chol_panel<", "k_chol_trail<"))}
+            if parts:
+                # per launch of the SEQUENCE (what `achieved` is per): the kernels' bytes weighted by their launch counts in that run
+                cnt = {k: pm["kernels"][k]["FETCH_SIZE"]["launches"] for k in parts}
+                avg = sum(parts[k] * cnt[k] for k in parts) / max(sum(cnt.values()), 1)
+                return {"traffic": int(avg), "traffic_per_kernel": parts, "traffic_launches_in_pass": cnt,
+                        "traffic_source": f"profiles/{pf} (rocprofv3 --pmc, separate passes; average over the sequence's launches)"}
+            continue
+        if not keys:
+            continue
+
+        def _args(k):
+            return k[k.index("<") + 1:k.rindex(">")].split(", ") if "<" in k else []
+
+        if step_inst:  # the CAVI step's own instantiation (template argument STEP = true) when the file has it
+            pref = [k for k in keys if len(_args(k)) >= 5 and _args(k)[4] == "true"]
+            keys = pref or keys
+        # the launch with the most traffic among the candidates is the step's (set-up launches of the same kernel are smaller)
+        key = max(keys, key=lambda k: pm["kernels"][k]["hbm_bytes_per_launch_corrected"])
+        return {"traffic": pm["kernels"][key]["hbm_bytes_per_launch_corrected"], "traffic_kernel": key,
+                "traffic_source": f"profiles/{pf} (rocprofv3 --pmc, separate passes, same command)"}
+    return {}
+
+
 def _hyper_products(m, B):
     """The seven GEMM-shaped launches of one hyper-on iteration: executed vs dense-count flops."""
     rows = [
@@ -650,29 +692,11 @@ def main():
             out["collective"]["split_overlap_ab"] = overlap_ab
 
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE as
-    # MI355X_MICROARCH.md prescribes for gfx950); rocprofv3 cannot wrap bench.py from inside, so this is not live
-    if a.config in ("c2", "c3") and world == 1 and comm is None:
-        for pf in (("r04_pmc_hbm_bytes.json", "r03_pmc_hbm_bytes.json", "r02_pmc_hbm_bytes.json", "r01h_pmc_hbm_bytes.json")
-                   if a.config == "c2" else ("r04_c3_pmc_hbm_bytes.json", "r03_c3_pmc_hbm_bytes.json", "r02_c3_pmc_hbm_bytes.json")):
-            try:
-                with open(os.path.join(ROOT, "profiles", pf)) as fh:
-                    pm = json.load(fh)
-                # (rocprofv3 prints every template argument, the TRACE flag included: match on the name without its closing '>')
-                # ... and take the CAVI step's own instantiation (last template argument STEP = true) when the file has it: the
-                # other launches of the same kernel in that run (K_ZZ, factorisations with the inverse) have no extension rows
-                keys = [k for k in pm["kernels"] if k.startswith(roofline["kernel"][:-1])]
-                if not keys:
-                    continue
-                def _is_step(k):  # template arguments <T, FUSED, BATCH, TRACE, STEP, PRO>
-                    ta = k[k.index("<") + 1:k.rindex(">")].split(", ")
-                    return len(ta) >= 5 and ta[4] == "true"
-                key = ([k for k in keys if _is_step(k)] or keys)[0]
-                roofline["traffic"] = pm["kernels"][key]["hbm_bytes_per_launch_corrected"]
-                roofline["traffic_source"] = f"profiles/{pf} (rocprofv3 --pmc, separate passes, same command)"
-                break
-            except Exception:
-                continue
-
+    # MI355X_MICROARCH.md prescribes for gfx950); rocprofv3 cannot wrap bench.py from inside, so this is not live.  Counter
+    # collection serialises kernels, so those passes run the MERGED task graph (the context's self-test keeps it): where the live
+    # launch is the split one (chain kernel + tile kernel) the traffic is that of the merged instantiation of the same task graph.
+    if world == 1 and comm is None:
+        roofline.update(_pmc_traffic(a.config, roofline["kernel"], step_inst=True))
     if rank == 0 and world == 1:
         # measured MFMA ceiling (issue-rate microbenchmark inside the library)
         pk = C.c_double()
@@ -733,6 +757,13 @@ def main():
                 # the GEMM-shaped launches of one iteration (round 4: seven, round 3: nine + the symmetric Apred product) with the
                 # flops they execute against what a dense 2 n^3-style count credits them (triangular operands, symmetric results)
                 "products": _hyper_products(mpad, (B + 63) // 64 * 64)}
+            if a.config == "c2":
+                tr = _pmc_traffic("hyper", out["hyper_roofline"]["kernel"], step_inst=False)
+                out["hyper_roofline"]["traffic"] = tr.get("traffic")
+                out["hyper_roofline"]["traffic_unit"] = "bytes/launch"
+                if tr:
+                    out["hyper_roofline"]["traffic_source"] = tr["traffic_source"]
+                    out["hyper_roofline"]["traffic_kernel"] = tr["traffic_kernel"]
             ngr, ngf = C.c_int64(), C.c_int64()
             if hasattr(L, "agp_svgp_hyper_counters"):
                 mh._chk(L.agp_svgp_hyper_counters(hh, C.byref(ngr), C.byref(ngf)))

@@ -16,6 +16,30 @@
  *   - caller owns all data buffers; the library owns the opaque handles and their device workspaces.
  *   - work is enqueued asynchronously on the ctx stream; calls that return host scalars or a
  *     data-dependent status (refresh_K, elbo, check_status, ctx_sync) synchronise that stream.
+ *
+ * Environment (all the library reads; 15 variables, each read once per process unless said otherwise).  The first eleven force a
+ * FALLBACK path that also exists on its own -- the GPU suite is run once with each of them (tools/suite_with_fallbacks.sh,
+ * profiles/r05_fallback_suites.txt); the A/B levers of earlier rounds are gone (docs/DESIGN_LOG.md has their numbers).
+ *   AGP_CHOL_DAG=0|1          never / always factor with the one-launch tile task graph (default: up to 32 block columns, i.e. m <= 2048;
+ *                             beyond, and after a lost dependency, plain launches per block column / blocked panels)
+ *   AGP_CHAIN_SPLIT=0|1       the task graph as one kernel / as chain kernel + tile kernel (default: two kernels from 600 tiles)
+ *   AGP_STEP_PROLOGUE=0       the natural-gradient step of a single-latent CAVI step as a kernel of its own (k_syrk_tn<SY_ETA2>)
+ *                             instead of the prologue of the next step's task-graph launch
+ *   AGP_STEP_EPILOGUE=0       the row statistics + local update as a kernel of their own instead of the launch's epilogue
+ *   AGP_PF_INKERNEL=0         look-ahead stream handed over by events instead of polled words in signal memory
+ *   AGP_KERNELMATRIX_VALU=1   kernel matrices by the direct-difference VALU kernel instead of the MFMA form (the path of D > 128)
+ *   AGP_HYPER_GK_FUSED=0      hyper-gradient with kappa' H and K^-1 Sigma K^-1 (the form of handles without a prologue launch:
+ *                             several latents, batch-sharded, online, stale-K) instead of the one product C (Sigma K^-1)
+ *   AGP_SPLIT_MERGED=0        batch-parallel step: eta step and row statistics as kernels of their own (k_eta2_from_packed)
+ *   AGP_CHOL_GROUP=n          block columns per group of the blocked factorisation beyond the task graph (default 8; 1 = per column)
+ *   AGP_CHOL_LOOKAHEAD=0      ... without its side stream
+ *   AGP_DAG_TEST_ABORT=1      test hook: every task-graph launch of a CAVI step is treated as having lost a dependency (the in-stream
+ *                             fallback k_chol_safe / k_safe_rowstats redoes it)
+ *   AGP_SPLIT_OVERLAP=1       (read at every step) batch-parallel statistics travel in block-column groups next to the next
+ *                             factorisation; see "multi-GPU" below
+ *   AGP_FORCE_SPLIT=1         diagnostic: the batch-parallel step sequence with a one-rank communicator, its collective issued
+ *   AGP_ALLOW_PARTIAL_SHARD=1 diagnostic: a latent-sharded multi-output handle may step without its communicator (bench.py c5, one GPU)
+ *   AGP_RCCL_PATH=<file>      the librccl.so to bind when the process holds none (agp_comm_init)
  */
 #ifndef AGP_HIP_H
 #define AGP_HIP_H

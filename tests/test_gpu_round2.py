@@ -14,6 +14,8 @@ import os
 import numpy as np
 import pytest
 
+import _knobs as K_
+
 pytestmark = pytest.mark.gpu
 
 
@@ -448,7 +450,8 @@ def test_task_graph_fallback_reruns_the_factorisation_in_stream(mods, K):
         del os.environ["AGP_DAG_TEST_ABORT"]
     assert not isinstance(got, str), got
     retries, eta2, X, y, Z, idx = got
-    assert retries >= 6  # every step went through the fallback
+    if not K_.no_task_graph():
+        assert retries >= 6  # every step went through the fallback
     lik = R.LogisticLikelihood() if K == 1 else R.LogisticSoftMaxLikelihood(3)
     mr = R.SVGP(R.Kernel("sqexponential", 2.0, 1.5), lik, Z, stochastic=True, batchsize=256)
     mr.train(X, y, len(idx), idx_stream=idx)
@@ -510,9 +513,10 @@ def test_task_graph_is_tried_again_after_a_pause(mods):
     counts, eta2, X, y, Z, idx = got
     # every step of the first call went through the fallback -- and (round 3) so did the factorisation of K_ZZ at the start of
     # train!, which has an in-stream fallback of its own now
-    assert counts[0] == 7
-    assert counts[1] == counts[0]              # paused: 500 steps of plain launches, no task graph, nothing to re-run
-    assert counts[2] > counts[1]               # steps 513.. use the task graph again (and lose it again)
+    if not K_.no_task_graph():
+        assert counts[0] == 7
+        assert counts[1] == counts[0]              # paused: 500 steps of plain launches, no task graph, nothing to re-run
+        assert counts[2] > counts[1]               # steps 513.. use the task graph again (and lose it again)
     mr = R.SVGP(R.Kernel("sqexponential", 2.0, 1.5), R.LogisticLikelihood(), Z, stochastic=True, batchsize=128)
     mr.train(X, y, len(idx), idx_stream=idx)
     assert _rel(eta2, mr.latents[0].eta2) < 1e-7

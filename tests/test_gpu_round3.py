@@ -18,6 +18,8 @@ import os
 import numpy as np
 import pytest
 
+import _knobs as KN
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -555,7 +557,8 @@ def test_fallback_of_launches_with_the_inverse_matches_oracle(mods):
         del os.environ["AGP_DAG_TEST_ABORT"]
     assert not isinstance(got, str), got
     retries, eta2, Sig, (var, sc), Zf, X, y, Z, idx = got
-    assert retries >= 10  # steps, materialisations and kernel refreshes all went through their fallbacks
+    if not KN.no_task_graph():
+        assert retries >= 10  # steps, materialisations and kernel refreshes all went through their fallbacks
     mr = R.SVGP(R.Kernel("sqexponential", 2.0, 1.5), R.LogisticLikelihood(), Z, stochastic=True, batchsize=256, k_opt=R.Adam(0.01),
                 z_opt=R.Adam(0.001))
     mr.train(X, y, len(idx), idx_stream=idx)
@@ -622,7 +625,9 @@ def test_pending_step_is_invisible_through_the_abi(mods, likname, T):
     mr.train(X, y, iters, idx_stream=idx, callback=cbr)
     n, npro = C.c_int64(), C.c_int64()
     assert capi.lib().agp_svgp_step_counters(ma._h, C.byref(n), C.byref(npro)) == 0
-    assert n.value == iters and npro.value >= iters - 6  # the scheduling really was in use (the four peeks above flushed theirs)
+    assert n.value == iters
+    if not KN.no_prologue():
+        assert npro.value >= iters - 6  # the scheduling really was in use (the four peeks above flushed theirs)
     assert _rel(seen[3][1], ref[3]) < tol
     assert abs(seen[5][1] - ref[5]) < max(tol, 1e-8) * abs(ref[5]) * (1 if T == np.float64 else 10)
     # (the prediction inside train! uses the K of the last refresh, like the reference's state.kernel_matrices)
@@ -667,7 +672,8 @@ def test_ragged_and_changing_minibatch_sizes_with_a_pending_step(mods):
     assert L.agp_svgp_check_status(h) == 0
     n, npro = C.c_int64(), C.c_int64()
     assert L.agp_svgp_step_counters(h, C.byref(n), C.byref(npro)) == 0
-    assert npro.value >= 6  # the steps that follow a minibatch of at least one tile took it as their prologue
+    if not KN.no_prologue():
+        assert npro.value >= 6  # the steps that follow a minibatch of at least one tile took it as their prologue
     mr.train(X, y, len(Bs), idx_stream=idx, fresh_state=False)
     g = mr.latents[0]
     mu, Sig, e1, e2 = ma.get_state(0)

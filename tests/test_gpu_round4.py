@@ -14,6 +14,8 @@ import warnings
 import numpy as np
 import pytest
 
+import _knobs as KN
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -508,6 +510,8 @@ def test_split_overlap_gates_really_wait_and_change_nothing(mods):
     launch do wait at their arrival gates while the later column groups are still "travelling".  One rank: the sum is the input, so
     the final state must be bit-identical with and without the flag, the statistics must have gone out as 4 ranges per step, and
     every step after the first must have ridden on its successor's launch."""
+    if KN.no_prologue() or KN.forced("AGP_SPLIT_MERGED"):
+        pytest.skip("the pending step on the reduced statistics (the path under test) is switched off by the environment")
     outs = []
     for ov in ("0", "1"):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg_overlap.py"), "80", "60"], cwd=ROOT, capture_output=True, text=True,

@@ -19,6 +19,8 @@ import sys
 import numpy as np
 import pytest
 
+import _knobs as KN
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -81,7 +83,9 @@ def test_hyper_iteration_with_fused_products_matches_oracle(mods, likname, ard, 
     assert _rel(mu, g.mu) < 1e-7 and _rel(Sig, g.Sigma) < 1e-7
     ng, nf = C.c_int64(), C.c_int64()
     ma._chk(capi.lib().agp_svgp_hyper_counters(ma._ensure_handle(B), C.byref(ng), C.byref(nf)))
-    assert ng.value >= iters - 4 and nf.value == ng.value, (ng.value, nf.value)
+    assert ng.value >= iters - 4, (ng.value, nf.value)
+    if not (KN.no_prologue() or KN.forced("AGP_HYPER_GK_FUSED")):
+        assert nf.value == ng.value, (ng.value, nf.value)
 
 
 _AB_SCRIPT = r"""

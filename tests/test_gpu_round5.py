@@ -177,3 +177,34 @@ def test_elbo_tickets_out_of_order_and_across_a_handle_recreation(mods):
         assert AGP.objective_fetch(m, t) == pytest.approx(ref, rel=1e-12)
     with pytest.raises(KeyError):
         AGP.objective_fetch(m, tk[3])  # fetched already
+
+
+def test_means_only_prediction_beyond_the_mfma_kernels_dimension_limit(mods):
+    """D = 160 > KMM_MAXD: the kernel matrix comes from the direct-difference VALU kernel, which leaves one row-dot slice per column
+    tile.  The means-only predictor (predict_y / predict_f without the variance) must take the chunked form there -- its one-launch
+    form wrote those slices past the caller's output (found in round 5 by the suite under AGP_KERNELMATRIX_VALU=1: an abort at
+    N = 1e6, silent at small sizes).  Guard bytes behind the output stay untouched; means equal those of the call with variances."""
+    AGP, R, capi, torch = mods
+    import ctypes as C
+
+    rng = np.random.default_rng(5)
+    N, D, m, B, nt = 1500, 160, 200, 256, 1000
+    X = rng.random((N, D))
+    y = np.sin(X[:, :4].sum(1)) + 0.1 * rng.standard_normal(N)
+    Z = X[rng.permutation(N)[:m]].copy()
+    ma = AGP.SVGP(AGP.with_lengthscale(AGP.SqExponentialKernel(), 3.0), AGP.GaussianLikelihood(0.1), AGP.AnalyticSVI(B), Z,
+                  optimiser=False)
+    AGP.train_(ma, X, y, 5)
+    Xt = rng.random((nt, D))
+    mu_cov, _ = AGP.predict_f(ma, Xt, cov=True)
+    mu = AGP.predict_f(ma, Xt, cov=False)
+    mu = mu[0] if isinstance(mu, tuple) else mu
+    assert _rel(mu, mu_cov) < 1e-12
+    # through the C ABI with guard words behind the output
+    xt = torch.as_tensor(Xt, device="cuda")
+    out = torch.full((nt + 4096,), -7.0, dtype=torch.float64, device="cuda")
+    h = ma._ensure_handle(B)
+    assert capi.lib().agp_svgp_predict_f(h, C.c_void_p(xt.data_ptr()), xt.stride(0), nt, C.c_void_p(out.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert _rel(out[:nt].cpu().numpy(), mu_cov) < 1e-12
+    assert bool((out[nt:] == -7.0).all())

@@ -485,7 +485,12 @@ static bool chain_split_wanted(int64_t tiles, bool with_prologue = false, bool f
   // fp64 launches with the prologue stay merged unless forced: their tile workgroups stage four LDS tiles (135 KB: one workgroup
   // per CU whatever the registers), and the measured case lost (C2: 0.3167 ms split, 0.3103 ms merged).  In fp32 the same tile
   // kernel fits two workgroups per CU (68 KB, 128 VGPRs) and wins: m = 1024, B = 2048 fp32 0.325 -> 0.270 ms per step.
-  if (with_prologue && f64 && v < 0) return false;
+  // Round 5: also in fp32 (m = 1024, B = 2048: 0.325 -> 0.270 ms per step when split).  Launches with the prologue and the epilogue
+  // follow each other with nothing in between, and about one split launch in 10 000 of that form lost a dependency on its own
+  // (stress of docs/DESIGN_LOG.md section 14: the run then goes through the fallback -- correct, but milliseconds, and no longer the
+  // bitwise trajectory of the merged launch).  Until that is understood the split form of these launches is opt-in.
+  (void)f64;
+  if (with_prologue && v < 0) return false;
   return v < 0 ? tiles >= 600 : v == 1;
 }
 // the chain stream, its release word and the proof that kernels of the two streams run at the same time (k_handshake: where
@@ -1126,6 +1131,9 @@ struct SvgpBase {
   virtual agp_status lsm_gsum_ptr(void** p, int64_t* n) = 0;
   virtual agp_status step_stats(bool fused) = 0;
   virtual agp_status stats_ptr(void** p, int64_t* n) = 0;
+#ifdef AGP_DEBUG_PTRS  // (development builds only: device addresses of the step's state, tools/tmp)
+  virtual void* debug_ptr(int what) { (void)what; return nullptr; }
+#endif
   virtual agp_status step_global(bool fused) = 0;
   // tail of agp_svgp_cavi_step: the fused natural-gradient step now, or left pending for the next step's task-graph launch
   virtual agp_status step_finish() = 0;
@@ -3448,6 +3456,23 @@ struct Svgp : SvgpBase {
     *n = (int64_t)nl * stats_stride();
     return AGP_OK;
   }
+#ifdef AGP_DEBUG_PTRS
+  void* debug_ptr(int what) override {
+    Latent& g = lat[0];
+    switch (what) {
+      case 0: return g.eta2;
+      case 1: return g.eta1;
+      case 2: return wbuf;
+      case 3: return rbuf;
+      case 4: return wbuf2;
+      case 5: return rbuf2;
+      case 6: return g.kappa;
+      case 7: return g.Wbuf;
+      case 8: return theta;
+      default: return nullptr;
+    }
+  }
+#endif
 
   // AGP_HYPER_GK_FUSED=0: the hyper-gradient forms G_K from kappa' H and Apred as before round 4 (A/B, tests)
   static bool gk_fused_on() {
@@ -5364,6 +5389,9 @@ agp_status agp_svgp_step_stats(agp_svgp* h) {
   HCHKF(h);
   return h->impl->step_stats(false);
 }
+#ifdef AGP_DEBUG_PTRS
+void* agp_debug_ptr(agp_svgp* h, int what) { return (h && h->impl) ? h->impl->debug_ptr(what) : nullptr; }
+#endif
 agp_status agp_svgp_stats_ptr(agp_svgp* h, void** ptr, int64_t* count) {
   HCHKF(h);
   return h->impl->stats_ptr(ptr, count);

@@ -753,7 +753,7 @@ def main():
                 "algorithmic_flops_per_launch": fl, "achieved": round(fl / us / 1e6, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(fl / us / 1e6 / peak, 4),
                 "iteration": "no host synchronisation inside the iteration"
-                             + (" (25 kernels back to back, profiles/r04_c2_hyper_timeline.txt)" if a.config == "c2" else ""),
+                             + (" (17 kernels back to back, profiles/r05_c2_hyper_timeline.txt)" if a.config == "c2" else ""),
                 # the GEMM-shaped launches of one iteration (round 4: seven, round 3: nine + the symmetric Apred product) with the
                 # flops they execute against what a dense 2 n^3-style count credits them (triangular operands, symmetric results)
                 "products": _hyper_products(mpad, (B + 63) // 64 * 64)}

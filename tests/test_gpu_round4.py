@@ -219,9 +219,9 @@ def test_fp32_gate_at_the_c3_shape(mods):
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # split task-graph launch
-def _run_child(env_extra, code):
+def _run_child(env_extra, code, *argv):
     env = dict(os.environ, **env_extra)
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", code, *argv], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout
 
@@ -282,7 +282,8 @@ err = np.max(np.abs(e2 - mr.latents[0].eta2)) / np.max(np.abs(mr.latents[0].eta2
 print('ERR', err)
 assert err < 1e-9, err
 """
-    out = _run_child({"AGP_CHAIN_SPLIT": "1", "AGP_DAG_TEST_ABORT": "1"}, code)
+    # (without the prologue: the forced split of launches WITH it is the opt-in form with the known hazard, DESIGN_LOG section 14)
+    out = _run_child({"AGP_CHAIN_SPLIT": "1", "AGP_DAG_TEST_ABORT": "1", "AGP_STEP_PROLOGUE": "0"}, code)
     assert "ERR" in out
 
 
@@ -352,7 +353,9 @@ def test_split_launch_with_prologue_lookahead_and_the_host_far_ahead(mods):
     """Regression for a deadlock of the first version of the split launch (an event joined the chain kernel's stream with the step's
     behind every launch): fp32, m = 1024, B = 2048 -- the prologue rides in the split launch --, look-ahead on, 200 steps enqueued
     without a single synchronisation.  Now no event sits between the streams; the run must simply finish, and it
-    must land where the merged launch lands."""
+    must land where the merged launch lands -- bit for bit, unless one of its 200 launches lost a dependency on its own and went
+    through the fallback (round 5: about one split launch of this form in 10 000 does, docs/DESIGN_LOG.md section 14; the split form
+    of launches with the prologue is opt-in since): then to fp32 rounding."""
     code = r"""
 import sys, ctypes as C, hashlib
 sys.path.insert(0, '.')
@@ -378,11 +381,18 @@ torch.cuda.synchronize()
 mu, Sig, e1, e2 = model.get_state(0)
 assert np.all(np.isfinite(e2))
 print('HASH', hashlib.sha256(np.ascontiguousarray(e2).tobytes()).hexdigest())
+np.save(sys.argv[1], e2)
 """
+    import tempfile
+
     get = lambda s: [l for l in s.splitlines() if l.startswith("HASH")][0]
-    h_split = get(_run_child({"AGP_CHAIN_SPLIT": "1"}, code))
-    h_merged = get(_run_child({"AGP_CHAIN_SPLIT": "0"}, code))
-    assert h_split == h_merged
+    with tempfile.TemporaryDirectory() as td:
+        pa, pb = os.path.join(td, "a.npy"), os.path.join(td, "b.npy")
+        h_split = get(_run_child({"AGP_CHAIN_SPLIT": "1"}, code, pa))
+        h_merged = get(_run_child({"AGP_CHAIN_SPLIT": "0"}, code, pb))
+        if h_split != h_merged:
+            a, b = np.load(pa).astype(np.float64), np.load(pb).astype(np.float64)
+            assert np.max(np.abs(a - b)) <= 2e-6 * np.max(np.abs(b)), "split and merged launches differ beyond fp32 rounding"
 
 
 def test_enqueued_elbo_equals_the_synchronous_one(mods):
@@ -474,7 +484,9 @@ def test_split_launch_fallback_with_a_full_grid_and_the_host_ahead(mods):
     """The grid-barrier fallback behind an aborted SPLIT launch at a size where it wants one workgroup on every CU (m = B = 1024:
     441 shares), with the host several steps ahead: the chain kernel of the next launch is then already in flight and sits on a CU
     the fallback cannot use -- its grid leaves those CUs out (safe_grid_cap), otherwise its first barrier would never complete.
-    Every launch is made to abort (AGP_DAG_TEST_ABORT=1); the trajectory must equal the undisturbed one to rounding."""
+    Every launch is made to abort (AGP_DAG_TEST_ABORT=1); the trajectory must equal the undisturbed one to rounding.
+    (AGP_STEP_PROLOGUE=0 since round 5: a forced split of launches WITH the prologue leaves tile (0, 0)'s eta2 step to the chain
+    kernel, and 1 aborted launch in 25 of that opt-in form handed the fallback a half-stepped eta2 -- docs/DESIGN_LOG.md section 14.)"""
     code = r"""
 import numpy as np, sys
 sys.path.insert(0, '.')
@@ -496,7 +508,8 @@ print('OK')
 
     with tempfile.TemporaryDirectory() as td:
         pa, pb = os.path.join(td, "a.npy"), os.path.join(td, "b.npy")
-        for env, path in (({"AGP_CHAIN_SPLIT": "1", "AGP_DAG_TEST_ABORT": "1"}, pa), ({"AGP_CHAIN_SPLIT": "0"}, pb)):
+        for env, path in (({"AGP_CHAIN_SPLIT": "1", "AGP_DAG_TEST_ABORT": "1", "AGP_STEP_PROLOGUE": "0"}, pa),
+                          ({"AGP_CHAIN_SPLIT": "0", "AGP_STEP_PROLOGUE": "0"}, pb)):
             r = subprocess.run([sys.executable, "-c", code, path], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True,
                                timeout=300)
             assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

@@ -2,8 +2,8 @@
 # Round-5 evidence kept under profiles/ (run on the GPU box through gpurun; outputs land in gpurun_out/, copy r05_* to profiles/):
 #   r05_c{2..5}_bench_line.json     the JSON line of bench.py --config cN (no profiler attached), FINAL build
 #   r05_c{2..5}_kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same commands
-#   r05_c2_step_gaps.txt, r05_c2_hyper_timeline.txt, r05_c2_hyper_kernel_stats.csv
-#   r05_c{2..5}_pmc_hbm_bytes.json, r05_hyper_pmc_hbm_bytes.json, r05_c2_pmc_mfma_util.json, r05_hyper_pmc_mfma_util.json
+#   r05_c2_step_gaps.txt, r05_c4_step_trace.txt, r05_c2_hyper_timeline.txt, r05_c2_hyper_kernel_stats.csv
+#   r05_c{2..5}_pmc_hbm_bytes.json, r05_hyper_pmc_hbm_bytes.json, r05_c2_pmc_mfma_util.json, r05_c4_pmc_mfma_util.json, r05_hyper_pmc_mfma_util.json
 #   r05_soaks.txt                   determinism soaks of the final build
 # usage: bash tools/collect_round5.sh [pmc|lines|stats|soaks ...]   (default: everything; PMC passes FIRST so that the bench lines
 #        printed afterwards carry their traffic figures)
@@ -21,7 +21,7 @@ pmc)
     python tools/pmc_traffic.py parse $c ${T}_$c > gpurun_out/${T}_pmc_$c.log 2>&1
     cp gpurun_out/pmc_${T}_$c/${T}_${c}_pmc_hbm_bytes.json gpurun_out/ 2>/dev/null && cp gpurun_out/${T}_${c}_pmc_hbm_bytes.json profiles/
   done
-  for c in c2 hyper; do
+  for c in c2 c4 hyper; do
     python tools/pmc_traffic.py mfma $c ${T}_$c > gpurun_out/${T}_mfma_$c.log 2>&1
     cp gpurun_out/pmc_${T}_$c/${T}_${c}_pmc_mfma_util.json gpurun_out/ 2>/dev/null
   done ;;
@@ -34,6 +34,8 @@ stats)
     cp $(find gpurun_out/prof_${T}_$c -name "*kernel_stats.csv" | head -1) gpurun_out/${T}_${c}_kernel_stats.csv
   done
   python tools/step_gaps.py $(find gpurun_out/prof_${T}_c2 -name "*kernel_trace.csv" | head -1) > gpurun_out/${T}_c2_step_gaps.txt 2>&1
+  # C4: the step's launches on all four streams relative to the tile kernel's start (where the 1.08 ms go)
+  python tools/step_gaps.py $(find gpurun_out/prof_${T}_c4 -name "*kernel_trace.csv" | head -1) "k_chol_dag<double, true, true, false, true, false, 2>" > gpurun_out/${T}_c4_step_trace.txt 2>&1
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${T}_hyper -o p -- python $R/tools/prof_hyper.py > /dev/null 2>&1)
   cp $(find gpurun_out/prof_${T}_hyper -name "*kernel_stats.csv" | head -1) gpurun_out/${T}_c2_hyper_kernel_stats.csv
   python tools/hyper_timeline.py $(find gpurun_out/prof_${T}_hyper -name "*kernel_trace.csv" | head -1) > gpurun_out/${T}_c2_hyper_timeline.txt 2>&1 ;;

@@ -127,7 +127,9 @@ def test_pre_round4_hyper_paths_stay_on_the_same_trajectory(mods, tmp_path):
     # factorisation algorithm: the fused G_K must still find a complete C
     for other in ("old", "abort"):
         for key in ("var", "sc", "Z", "mu", "e2"):
-            assert _rel(outs[other][key], outs["new"][key]) < (1e-9 if other != "abort" else 1e-8), (other, key)
+            # (3e-9: the two gradient forms differ by rounding, and after 30 optimiser steps Z sits 1.2e-9 apart when the kernel
+            #  matrices come from the direct-difference VALU kernel -- AGP_KERNELMATRIX_VALU=1 --, 4e-10 with the MFMA kernel)
+            assert _rel(outs[other][key], outs["new"][key]) < (3e-9 if other != "abort" else 1e-8), (other, key)
         # predictive variances k** - k*' (K^-1 - K^-1 Sigma K^-1) k* cancel against K^-1 of a kernel matrix with jitter 1e-8: a
         # different summation order inside X'X shows at 1e-6 of the variance (measured 9.6e-7)
         assert _rel(outs[other]["pred"], outs["new"]["pred"]) < 1e-5, other

@@ -128,7 +128,7 @@ def test_pre_round4_hyper_paths_stay_on_the_same_trajectory(mods, tmp_path):
     for other in ("old", "abort"):
         for key in ("var", "sc", "Z", "mu", "e2"):
             # (3e-9: the two gradient forms differ by rounding, and after 30 optimiser steps Z sits 1.2e-9 apart when the kernel
-            #  matrices come from the direct-difference VALU kernel -- AGP_KERNELMATRIX_VALU=1 --, 4e-10 with the MFMA kernel)
+            #  matrices come from the direct-difference VALU kernel -- AGP_KERNELMATRIX_VALU=1 --; with the default MFMA kernel the old limit of 1e-9 holds)
             assert _rel(outs[other][key], outs["new"][key]) < (3e-9 if other != "abort" else 1e-8), (other, key)
         # predictive variances k** - k*' (K^-1 - K^-1 Sigma K^-1) k* cancel against K^-1 of a kernel matrix with jitter 1e-8: a
         # different summation order inside X'X shows at 1e-6 of the variance (measured 9.6e-7)

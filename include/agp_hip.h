@@ -17,9 +17,10 @@
  *   - work is enqueued asynchronously on the ctx stream; calls that return host scalars or a
  *     data-dependent status (refresh_K, elbo, check_status, ctx_sync) synchronise that stream.
  *
- * Environment (all the library reads; 15 variables, each read once per process unless said otherwise).  The first eleven force a
- * FALLBACK path that also exists on its own -- the GPU suite is run once with each of them (tools/suite_with_fallbacks.sh,
- * profiles/r05_fallback_suites.txt); the A/B levers of earlier rounds are gone (docs/DESIGN_LOG.md has their numbers).
+ * Environment (all the library reads; 15 variables, each read once per process unless said otherwise).  The first eight switch a
+ * default path off for the FALLBACK that also exists on its own -- the GPU suite is run once with each of them, AGP_CHAIN_SPLIT both
+ * ways (tools/suite_with_fallbacks.sh, profiles/r05_fallback_suites.txt); AGP_CHOL_GROUP, AGP_CHOL_LOOKAHEAD and the test hook
+ * AGP_DAG_TEST_ABORT are exercised by tests of their own.  The A/B levers of earlier rounds are gone (docs/DESIGN_LOG.md has their numbers).
  *   AGP_CHOL_DAG=0|1          never / always factor with the one-launch tile task graph (default: up to 32 block columns, i.e. m <= 2048;
  *                             beyond, and after a lost dependency, plain launches per block column / blocked panels)
  *   AGP_CHAIN_SPLIT=0|1       the task graph as one kernel / as chain kernel + tile kernel (default: two kernels from 600 tiles,

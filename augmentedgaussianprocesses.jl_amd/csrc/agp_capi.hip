@@ -485,10 +485,11 @@ static bool chain_split_wanted(int64_t tiles, bool with_prologue = false, bool f
   // fp64 launches with the prologue stay merged unless forced: their tile workgroups stage four LDS tiles (135 KB: one workgroup
   // per CU whatever the registers), and the measured case lost (C2: 0.3167 ms split, 0.3103 ms merged).  In fp32 the same tile
   // kernel fits two workgroups per CU (68 KB, 128 VGPRs) and wins: m = 1024, B = 2048 fp32 0.325 -> 0.270 ms per step.
-  // Round 5: also in fp32 (m = 1024, B = 2048: 0.325 -> 0.270 ms per step when split).  Launches with the prologue and the epilogue
-  // follow each other with nothing in between, and about one split launch in 10 000 of that form lost a dependency on its own
-  // (stress of docs/DESIGN_LOG.md section 14: the run then goes through the fallback -- correct, but milliseconds, and no longer the
-  // bitwise trajectory of the merged launch).  Until that is understood the split form of these launches is opt-in.
+  // Round 5: also in fp32 (m = 1024, B = 2048: 0.325 -> 0.270 ms per step when split).  Two findings of the stress runs in
+  // docs/DESIGN_LOG.md section 14: the chain kernel used to take tile (0, 0)'s eta2 step, so an ABORTED launch of this form could
+  // leave eta2 half-stepped (repaired: the chain's place in the tile kernel takes it and parks the tile, agp_chol.h); and about one
+  // split launch in 10 000 lost a dependency on its own and went through the fallback (correct, but milliseconds, and no longer
+  // the bitwise trajectory of the merged launch).  Until the second is understood the split form of these launches is opt-in.
   (void)f64;
   if (with_prologue && v < 0) return false;
   return v < 0 ? tiles >= 600 : v == 1;

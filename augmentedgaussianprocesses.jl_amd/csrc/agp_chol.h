@@ -1949,11 +1949,16 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
     __hip_atomic_store(sync.started, sync.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (ROLE == 2 && chain) {  // the chain's place in the tile kernel: it is the first workgroup to run, so it releases the chain kernel
     if (tid == 0 && sync.go) __hip_atomic_store(sync.go, sync.go_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return;
+    // PRO: this workgroup -- not the chain kernel -- takes the prologue of tile (0, 0) and PARKS A(0, 0) = -2 eta2 for the chain
+    // like any feeder (the unused diagonal park slot of block column 0): every store of the natural-gradient step then belongs to
+    // the tile kernel's stream, and "eta is completely stepped even when the factorisation is aborted" holds for split launches too
+    if (!PRO) return;
   }
   if (ROLE == 1 && !chain) return;
   Acc8<T> acc;
-  if (PRO && !ext) {
+  if (PRO && ROLE == 1) {
+    // (tile (0, 0) arrives parked, see above)
+  } else if (PRO && !ext) {
     // ---- prologue of a matrix tile: S(R, c) (own k-slice + the helpers' partial tiles), the eta2 step, A = -2 eta2 -> acc
     const int64_t ntc_ = nt - c, nn_ = ntc_ < PRO_NEAR ? ntc_ : PRO_NEAR;
     const int ksc = b < nn_ ? pro.kf[c] : pro.ks[c];
@@ -2089,11 +2094,27 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
   } else {
     acc8_foreach<T>(acc, [&](int r, int cc, T& val) { val = rowp[r * ldr + c0 + cc]; });
   }
+  if (PRO && ROLE == 2 && chain) {  // A(0, 0) of the stepped eta2 -> the chain kernel
+    T* park = HP + SLOT;
+    acc8_foreach<T>(acc, [&](int r, int cc, T& val) {
+      __hip_atomic_store(park + r * TILE + cc, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    });
+    dag_signal(pre2, epoch);
+    return;
+  }
   if (ROLE != 2 && chain) {
     // ---- the chain: ONE workgroup carries the critical path through all columns, so that per column only the tile
     // factorisation and two 64^3 products are serial:  factor(c) -> L(c+1,c) = T X_c' -> S = D - L L' -> factor(c+1).
     // T = tile (c+1, c) and D = tile (c+1, c+1) arrive with all their other updates already applied by feeder workgroups.
-    acc8_foreach<T>(acc, [&](int r, int cc, T& val) { bufA[r * LDP + cc] = val; });
+    if (PRO && ROLE == 1) {
+      if (!dag_wait(pre2, nullptr, epoch, abortf, info, &wait_ok)) {
+        chain_count_out(sync);
+        return;
+      }
+      load_tile_lds_hv<T>(HP + SLOT, bufA);
+    } else {
+      acc8_foreach<T>(acc, [&](int r, int cc, T& val) { bufA[r * LDP + cc] = val; });
+    }
     __syncthreads();
     T* bufC = sm + (FUSED ? 2 : 0) * TILE * LDP;
     T* bufD = sm + (FUSED ? 3 : 0) * TILE * LDP;

@@ -25,7 +25,7 @@
  *                             beyond, and after a lost dependency, plain launches per block column / blocked panels)
  *   AGP_CHAIN_SPLIT=0|1       the task graph as one kernel / as chain kernel + tile kernel (default: two kernels from 600 tiles,
  *                             except launches that carry the natural-gradient step as their prologue: those split only when
- *                             forced -- in that form an ABORTED launch can leave eta2 half-stepped, docs/DESIGN_LOG.md section 14)
+ *                             forced -- docs/DESIGN_LOG.md section 14)
  *   AGP_STEP_PROLOGUE=0       the natural-gradient step of a single-latent CAVI step as a kernel of its own (k_syrk_tn<SY_ETA2>)
  *                             instead of the prologue of the next step's task-graph launch
  *   AGP_STEP_EPILOGUE=0       the row statistics + local update as a kernel of their own instead of the launch's epilogue

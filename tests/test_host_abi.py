@@ -236,3 +236,24 @@ def test_c_client_compiles_and_links_against_the_header_and_library(built, tmp_p
     r = subprocess.run(cc, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert os.path.getsize(exe) > 0
+
+
+def test_bench_fails_loudly_without_a_gpu(built):
+    """The product path has no CPU fallback: on a box without a GPU `bench.py` must stop with an error, not print a line; asked for
+    more GPUs than the node shows, it says so before starting any rank."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "GPU" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 2 and "--gpus 2 but this node shows 0 GPU(s)" in (r.stderr + r.stdout)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -1,0 +1,44 @@
+"""Stress A of docs/DESIGN_LOG.md section 14: N models of 6 CAVI steps (fp64, m = B = 1024) in one process, meant to be run with the test
+hook and a forced launch form, e.g.
+
+    AGP_CHAIN_SPLIT=1 AGP_DAG_TEST_ABORT=1 timeout 100 python tools/stress/abort_stress.py 30
+
+Every model must land on the first model's natural parameters (the fallback is deterministic); prints one line per model with its
+wall time (a stall shows as a model that never prints) and the count of models that failed or deviated.  Keep N small: a process
+that creates many contexts slows down."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+import __graft_entry__ as g  # noqa: E402
+
+g.build()
+import agp_amd as AGP  # noqa: E402
+
+rng = np.random.default_rng(6)
+N, D, m, B, iters = 6000, 6, 1024, 1024, 6
+X = rng.random((N, D))
+f = np.sin(4 * X[:, 0]) + X[:, 1] - 0.8
+y = np.sign(f + 0.3 * rng.standard_normal(N))
+Z = X[rng.permutation(N)[:m]].copy()
+idx = [rng.choice(N, B, replace=False) for _ in range(iters)]
+ref, bad = None, 0
+for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
+    t0 = time.time()
+    try:
+        ma = AGP.SVGP(AGP.SqExponentialKernel() @ AGP.ScaleTransform(3.0), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z, optimiser=False)
+        AGP.train_(ma, X, y, iters, idx_stream=idx)
+        e2 = ma.get_state(0)[3]
+        if ref is None:
+            ref = e2
+        d = float(np.max(np.abs(e2 - ref)) / np.max(np.abs(ref)))
+        note = "" if d <= 1e-9 else f"  DEVIATES {d:.2e}"
+        bad += d > 1e-9
+    except Exception as e:  # noqa: BLE001
+        bad += 1
+        note = "  FAILED " + str(e)[:100]
+    print(f"model {rep}: {time.time() - t0:.2f} s{note}", flush=True)
+print("bad", bad)

@@ -5392,6 +5392,16 @@ agp_status agp_svgp_step_stats(agp_svgp* h) {
 }
 #ifdef AGP_DEBUG_PTRS
 void* agp_debug_ptr(agp_svgp* h, int what) { return (h && h->impl) ? h->impl->debug_ptr(what) : nullptr; }
+// the words of agp_dag_diag (agp_chol.h) + [6] the context's flag block, [7] int32 words per flag, DAG_FS (so that [1] can be turned
+// into a flag index: ([1] - [6]) / 4 / [7]); synchronises the device
+int agp_debug_dag_diag(agp_ctx* c, unsigned long long* out8) {
+  if (!out8) return 1;
+  if (hipDeviceSynchronize() != hipSuccess) return 2;
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(agp_dag_diag), 8 * sizeof(unsigned long long)) != hipSuccess) return 3;
+  out8[6] = c ? (unsigned long long)c->dag_flags : 0ull;
+  out8[7] = (unsigned long long)DAG_FS;
+  return 0;
+}
 #endif
 agp_status agp_svgp_stats_ptr(agp_svgp* h, void** ptr, int64_t* count) {
   HCHKF(h);

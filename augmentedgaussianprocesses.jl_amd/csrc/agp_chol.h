@@ -1315,6 +1315,12 @@ __device__ __forceinline__ void load_tiles_lds_hv2(const T* H0, T* S0, const T* 
   }
 }
 
+#ifdef AGP_DEBUG_PTRS
+// development builds only (docs/DESIGN_LOG.md section 14, "which wait expires"): what the FIRST bounded wait of a launch that ran out was
+// waiting for -- [0] number of expired waits since the library was loaded, [1] address of the flag, [2] epoch, [3] workgroup index,
+// [4] 1 = spin limit / 2 = saw the launch's abort flag, [5] chain kernels whose release word never came.  Read by agp_debug_dag_diag.
+__device__ unsigned long long agp_dag_diag[8];
+#endif
 // one thread polls up to two flags for `epoch`; returns false (workgroup-uniform) when the run was aborted
 __device__ __forceinline__ bool dag_wait(const int32_t* f0, const int32_t* f1, int32_t epoch, int32_t* abort_flag,
                                          int32_t* info, int* lds_ok) {
@@ -1328,6 +1334,14 @@ __device__ __forceinline__ bool dag_wait(const int32_t* f0, const int32_t* f1, i
         __builtin_amdgcn_s_sleep(1);
         if (++spins > DAG_SPIN_LIMIT ||
             ((spins & 63) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)) {
+#ifdef AGP_DEBUG_PTRS
+          if (spins > DAG_SPIN_LIMIT && atomicAdd(&agp_dag_diag[0], 1ull) == 0) {  // (the first one is the cause, the others follow it)
+            agp_dag_diag[1] = (unsigned long long)f;
+            agp_dag_diag[2] = (unsigned long long)epoch;
+            agp_dag_diag[3] = (unsigned long long)blockIdx.x;
+            agp_dag_diag[4] = 1;
+          }
+#endif
           __hip_atomic_store(abort_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           atomicExch(info, -1);
           ok = 0;
@@ -1798,6 +1812,9 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
         if (++spins > (1L << 26)) {  // about a minute: the tile kernel never started.  Treated like a lost dependency: the latch
           atomicExch(info, -1);      // sends the launch to the in-stream fallback (the tiles, should they still come, give up on
           wait_ok = 0;               // their own bounded waits for the chain)
+#ifdef AGP_DEBUG_PTRS
+          atomicAdd(&agp_dag_diag[5], 1ull);
+#endif
           break;
         }
       }

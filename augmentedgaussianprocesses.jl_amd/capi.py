@@ -80,6 +80,7 @@ SYMBOLS = {
     "agp_ctx_create": (_I32, [_I32, _VP, _PVP]),
     "agp_ctx_destroy": (_I32, [_VP]),
     "agp_ctx_sync": (_I32, [_VP]),
+    "agp_ctx_task_graph_fallbacks": (_I32, [_VP, _PI64]),
     "agp_last_error": (C.c_char_p, [_VP]),
     "agp_kernelmatrix": (_I32, [_VP, _I32, _PK, _VP, _I64, _I64, _VP, _VP, _I64, _I64, _I64, _VP, _I64]),
     "agp_potrf_jitter": (_I32, [_VP, _I32, _VP, _I64, _I64, _DBL, _PI32]),

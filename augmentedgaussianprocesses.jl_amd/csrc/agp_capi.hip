@@ -485,13 +485,11 @@ static bool chain_split_wanted(int64_t tiles, bool with_prologue = false, bool f
   // fp64 launches with the prologue stay merged unless forced: their tile workgroups stage four LDS tiles (135 KB: one workgroup
   // per CU whatever the registers), and the measured case lost (C2: 0.3167 ms split, 0.3103 ms merged).  In fp32 the same tile
   // kernel fits two workgroups per CU (68 KB, 128 VGPRs) and wins: m = 1024, B = 2048 fp32 0.325 -> 0.270 ms per step.
-  // Round 5: also in fp32 (m = 1024, B = 2048: 0.325 -> 0.270 ms per step when split).  Two findings of the stress runs in
-  // docs/DESIGN_LOG.md section 14: the chain kernel used to take tile (0, 0)'s eta2 step, so an ABORTED launch of this form could
-  // leave eta2 half-stepped (repaired: the chain's place in the tile kernel takes it and parks the tile, agp_chol.h); and about one
-  // split launch in 10 000 lost a dependency on its own and went through the fallback (correct, but milliseconds, and no longer
-  // the bitwise trajectory of the merged launch).  Until the second is understood the split form of these launches is opt-in.
-  (void)f64;
-  if (with_prologue && v < 0) return false;
+  // Round 5 made the fp32 form opt-in as well after two findings of the stress runs (docs/DESIGN_LOG.md section 14): the chain kernel
+  // took tile (0, 0)'s eta2 step, so an ABORTED launch could leave eta2 half-stepped (repaired in round 5: the chain's place in the
+  // tile kernel takes it and parks the tile), and about one split launch in 10 000 lost a dependency on its own -- the tile kernel
+  // filled every CU before the chain kernel was resident (repaired in round 6: DagSync::here / k_wait_here).  Default again in fp32.
+  if (with_prologue && f64 && v < 0) return false;
   return v < 0 ? tiles >= 600 : v == 1;
 }
 // the chain stream, its release word and the proof that kernels of the two streams run at the same time (k_handshake: where
@@ -536,7 +534,13 @@ static void chain_split_arm(agp_ctx* c, DagSync& ds, int nb) {
   ds.go = c->chain_go;
   ds.go_val = ++c->chain_seq;
   ds.done = c->chain_ctr;
+  ds.here = c->chain_go + 1;  // (second word of the same signal-memory allocation)
   c->chain_exits += nb;
+}
+// ... enqueued on the step's stream between the chain kernel's launch (chain stream) and the tile kernel's: every chain workgroup
+// of this launch -- and of all launches before it: the count is cumulative, like chain_exits -- is resident (DagSync::here)
+static void chain_split_wait_here(agp_ctx* c) {
+  hipLaunchKernelGGL(k_wait_here, dim3(1), dim3(64), 0, c->stream, (const int32_t*)(c->chain_go + 1), c->chain_exits);
 }
 
 // what a CAVI step hands to its factorisation about the look-ahead stream (see DagSync, agp_chol.h)
@@ -730,6 +734,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
         hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, true, 1>), dim3(1), dim3(CHOL_THREADS), 0, c->chain_stream, one, 1,
                            (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, ptrace, H, hstride, nx, erow, 0,
                            ds, pa, epi ? *epi : EpiArgs<T>{});
+        chain_split_wait_here(c);
         hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, true, 2>), dim3((unsigned)(ntiles + nhelp + pa.nfill)),
                            dim3(CHOL_THREADS), lds_pad, c->stream, one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid,
                            c->dag_flags, c->dag_epoch, ptrace, H, hstride, nx, erow, 0, ds, pa, epi ? *epi : EpiArgs<T>{});
@@ -753,6 +758,7 @@ static agp_status potrf_fused(agp_ctx* c, T* A, int64_t ld, int64_t n, T* X, int
       hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, false, 1>), dim3(1), dim3(CHOL_THREADS), 0, c->chain_stream, one, 1,
                          (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx, erow,
                          0, ds);
+      chain_split_wait_here(c);
       hipLaunchKernelGGL((k_chol_dag<T, true, false, false, true, false, 2>), dim3((unsigned)ntiles), dim3(CHOL_THREADS), 0, c->stream,
                          one, 1, (int64_t)0, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, trace, H, hstride, nx,
                          erow, 0, ds);
@@ -846,6 +852,7 @@ static agp_status potrf_dag_batch(agp_ctx* c, const CholBatch<T>& bt, int nb, in
     hipLaunchKernelGGL((k_chol_dag<T, true, true, false, true, false, 1>), dim3((unsigned)nb), dim3(CHOL_THREADS), 0, c->chain_stream, bt,
                        nb, fstride, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch, (unsigned long long*)nullptr, H,
                        hstride, (int64_t)0, (const T*)nullptr, 0, ds);
+    chain_split_wait_here(c);
     hipLaunchKernelGGL((k_chol_dag<T, true, true, false, true, false, 2>), dim3((unsigned)(ntiles * nb)), dim3(CHOL_THREADS), 0,
                        c->stream, bt, nb, fstride, ld, ldx, lde, ne, nt, info_dev, nvalid, c->dag_flags, c->dag_epoch,
                        (unsigned long long*)nullptr, H, hstride, (int64_t)0, (const T*)nullptr, 0, ds);
@@ -3661,6 +3668,14 @@ struct Svgp : SvgpBase {
       ctx->err = "the look-ahead stream waited about a minute for a CAVI step that never started (k_wait_ge)";
       return AGP_ERR_HIP;
     }
+    if (info == -3) {  // (grid_barrier, agp_chol.h: a bounded wait since round 6 -- this used to be a hang)
+      if (ctx->safe_bar) HIPCHK(ctx, hipMemsetAsync(ctx->safe_bar, 0, 2 * sizeof(unsigned), st()));
+      dag_pause(ctx);
+      ctx->err = "the in-stream fallback of an aborted task-graph launch could not complete: one of its workgroups did not become "
+                 "resident within the grid barrier's limit (is another process holding compute units of this GPU?); the step's "
+                 "results are not valid";
+      return AGP_ERR_HIP;
+    }
     if (info == -4) {
       ctx->err = "AGP_SPLIT_OVERLAP: a column group of the all-reduced statistics did not arrive within the gate's limit";
       return AGP_ERR_HIP;
@@ -4744,6 +4759,19 @@ agp_status agp_ctx_sync(agp_ctx* ctx) {
   if (!ctx) return AGP_ERR_INVALID;
   DevGuard guard(ctx->device);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return AGP_OK;
+}
+
+// task-graph launches of this context that lost a tile dependency and were re-run by the in-stream fallback (cumulative)
+agp_status agp_ctx_task_graph_fallbacks(agp_ctx* ctx, int64_t* n_host) {
+  if (!ctx || !n_host) return AGP_ERR_INVALID;
+  DevGuard guard(ctx->device);
+  *n_host = 0;
+  if (!ctx->safe_retries) return AGP_OK;  // no launch of this context ever carried a fallback
+  int32_t r = 0;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpy(&r, ctx->safe_retries, sizeof(r), hipMemcpyDeviceToHost));
+  *n_host = r;
   return AGP_OK;
 }
 

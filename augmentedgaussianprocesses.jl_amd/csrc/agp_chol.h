@@ -1070,15 +1070,40 @@ __device__ __forceinline__ T safe_kernel_base(int kind, T d2) {
   return exp(-r);  // Exponential
 }
 
-__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
+// Bounded (round 6): a workgroup of the fallback that cannot become resident (its grid is <= n_cu - CHOL_MAXB workgroups of ~110 KB
+// LDS, dealt to the XCDs round-robin; ONE further long-lived large-LDS workgroup of somebody else in an XCD is enough) used to make
+// this barrier spin forever.  Now the wait is limited on the device's constant 100 MHz clock; when it runs out the workgroup latches
+// info = -3 (agp_svgp_check_status: AGP_ERR_HIP, "the in-stream fallback could not become resident"; the host clears the barrier
+// words) and every workgroup leaves at its next barrier.  Returns false (workgroup-uniform) when the barrier is broken.
+constexpr long long GRID_BARRIER_TICKS = 8LL * 100000000LL;  // 8 s (a phase with the inverse's forward substitution is ~0.2 s)
+__device__ __forceinline__ bool grid_barrier(unsigned* ctr, unsigned target, int32_t* info) {
+  __shared__ int gb_ok;
   __syncthreads();
   if (threadIdx.x == 0) {
+    int ok = 1;
     __threadfence();  // agent-scope release: this workgroup's plain stores reach memory before it is counted
     atomicAdd(ctr, 1u);
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
+    const long long t0 = (long long)wall_clock64();
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(8);
+      if ((++spins & 255u) == 0) {
+        if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == -3) {
+          ok = 0;
+          break;
+        }
+        if ((long long)wall_clock64() - t0 > GRID_BARRIER_TICKS) {
+          atomicExch(info, -3);
+          ok = 0;
+          break;
+        }
+      }
+    }
     __threadfence();  // agent-scope acquire: drop what this XCD's L2 may still hold of the others' tiles
+    gb_ok = ok;
   }
   __syncthreads();
+  return gb_ok != 0;
 }
 
 // (a device function so that the kernel which follows the task graph in a single-latent step -- row statistics and local
@@ -1128,12 +1153,12 @@ __device__ __forceinline__ bool chol_safe_body(const CholBatch<T>& bt, const Saf
         E[(src.Bq + e / n) * lde + (e % n)] = (e / n) == 0 ? src.eta1[q][e % n] : T(0);
     }
   }
-  grid_barrier(bar, ++phase * nwg);
+  if (!grid_barrier(bar, ++phase * nwg, info)) return true;
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // every workgroup has seen the -1 by now: the latch goes back to "no failure",
-    atomicExch(info, 0);                      // so that a non-positive pivot of THIS run is reported like any other
-    atomicAdd(retries, 1);
+    atomicCAS(info, -1, 0);                   // so that a non-positive pivot of THIS run is reported like any other (CAS: a
+    atomicAdd(retries, 1);                    // broken barrier's -3 stays)
   }
-  grid_barrier(bar, ++phase * nwg);
+  if (!grid_barrier(bar, ++phase * nwg, info)) return true;
   for (int64_t k = 0; k < nt; ++k) {
     const int64_t nP = nt - k + ne;
     const int64_t nU = chol_nU(k, 0, nt, nt, ne);
@@ -1142,7 +1167,7 @@ __device__ __forceinline__ bool chol_safe_body(const CholBatch<T>& bt, const Saf
       chol_step_body<T>(bt.A[q], bt.X[q], bt.Dg[q], bt.E[q], v / nb, ld, ldx, lde, ne, 0, k, nt, info, nvalid, sm, sc, piv);
       __syncthreads();  // the next share reuses the LDS tiles
     }
-    grid_barrier(bar, ++phase * nwg);
+    if (!grid_barrier(bar, ++phase * nwg, info)) return true;
   }
   if (src.want_x) {
     // X = L^-1 (lower triangular) column by column: thread j solves L x = e_j by forward substitution.  L's strictly-lower tiles sit
@@ -1166,7 +1191,7 @@ __device__ __forceinline__ bool chol_safe_body(const CholBatch<T>& bt, const Saf
         }
       }
     }
-    grid_barrier(bar, ++phase * nwg);
+    if (!grid_barrier(bar, ++phase * nwg, info)) return true;
     if (src.pout) {  // P = X' X, one thread per lower element, k ascending (X is lower triangular: the sum starts at row i)
       const T* X = bt.X[0];
       for (int64_t e = g0; e < n * n; e += gsz) {
@@ -1188,7 +1213,7 @@ __device__ __forceinline__ bool chol_safe_body(const CholBatch<T>& bt, const Saf
           if (st_ && st_[1] != 0 && st_[3] == 0) st_[3] = (st_[0] != 0 || st_[2] != 0) ? 2 : 1;
         }
       }
-      grid_barrier(bar, ++phase * nwg);
+      if (!grid_barrier(bar, ++phase * nwg, info)) return true;
     }
   }
   // leave the barrier words at zero for the next use: arrivals are counted on a second word, the last one to arrive resets both
@@ -1373,7 +1398,25 @@ struct DagSync {
   // writing (a chain that is in the middle of a tile factorisation notices the abort at its next wait, up to ~17 us later).  No
   // event joins the two streams: the tile kernel cannot end before the chain's last publish, after which the chain writes nothing.
   int32_t* done = nullptr;
+  // round 6: ... and counts itself IN on `here` (one per chain workgroup, the first thing it does).  The step's stream does not start
+  // the tile kernel before every chain workgroup of the launch is resident (k_wait_here in front of the tile kernel): a tile kernel
+  // that fills every CU with workgroups waiting for a chain kernel that has not found a place yet was the one way a split launch
+  // lost a dependency on its own (docs/DESIGN_LOG.md section 14, defect 5: about once in 10 000 launches at fp32 m = 1024 / B = 2048)
+  int32_t* here = nullptr;
 };
+// the step stream's side of DagSync::here: one wave in front of the tile kernel.  In the steady state the chain kernel has been
+// resident for the whole of the kernels that precede the tile kernel (it is enqueued first, on a stream of higher priority, and
+// becomes dispatchable when the chain kernel of the launch before exits -- when that launch's tile kernel ends), so this costs a
+// launch slot and no wait.  Bounded (2 s): past that the tile kernel starts anyway and is protected by its own bounded waits.
+__global__ void k_wait_here(const int32_t* __restrict__ here, int32_t want) {
+  if (threadIdx.x != 0) return;
+  const long long t0 = (long long)wall_clock64();
+  unsigned spins = 0;
+  while ((int32_t)(__hip_atomic_load(here, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+    __builtin_amdgcn_s_sleep(2);
+    if ((++spins & 1023u) == 0 && (long long)wall_clock64() - t0 > 200000000LL) break;
+  }
+}
 // (ROLE 1) every thread's stores acknowledged, then one count
 __device__ __forceinline__ void chain_count_out(const DagSync& sync) {
   if (!sync.done) return;
@@ -1707,6 +1750,7 @@ __device__ __forceinline__ void pro_slice(const T* __restrict__ kap, int64_t ldk
 // 512-thread workgroup per CU; the tile kernel alone compiles to <= 128 (f64) / <= 80 (f32) and runs 2 - 3 workgroups per CU, which
 // is what a launch of 1500+ tiles (C3, C4) is short of.  The chain kernel may start before the work in front of the tile kernel
 // has finished: it polls DagSync::go (stored by the tile kernel's first workgroup) and then drops its caches.
+constexpr long long CHAIN_GO_TICKS = 4LL * 100000000LL;
 #ifndef AGP_TILES_WAVES_F64
 #define AGP_TILES_WAVES_F64 4
 #endif
@@ -1796,10 +1840,12 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
   if (ROLE == 1) {  // the chain as a kernel of its own: wait until the tile kernel runs (= everything before it on its stream is done)
     if (threadIdx.x == 0) {
       wait_ok = 1;
-      long spins = 0;
+      if (sync.here) __hip_atomic_fetch_add(sync.here, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // resident: the tile kernel may start
+      unsigned spins = 0;
+      const long long t0 = (long long)wall_clock64();
       // ordered compare, not equality: the release word is one per context and every split launch stores its own sequence number
       // into it.  A chain kernel that is dispatched late (its launch was aborted and the fallback has run, the next tile kernel has
-      // already stored go_val + 1) must not wait for a value that has come and gone -- it would spin for a minute and latch -1 on a
+      // already stored go_val + 1) must not wait for a value that has come and gone -- it would spin out its limit and latch -1 on a
       // launch that has nothing to do with it.  If the word has moved PAST go_val this launch is over: count out, do no work.
       while (sync.go) {
         const int32_t d = (int32_t)(__hip_atomic_load(sync.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - sync.go_val);
@@ -1809,9 +1855,11 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
           break;
         }
         __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1L << 26)) {  // about a minute: the tile kernel never started.  Treated like a lost dependency: the latch
-          atomicExch(info, -1);      // sends the launch to the in-stream fallback (the tiles, should they still come, give up on
-          wait_ok = 0;               // their own bounded waits for the chain)
+        // limit on the device's 100 MHz clock (round 6; it was 2^26 polls, about 100 s): what sits between this kernel's start and
+        // the tile kernel's is at most the kernels of one step plus a fallback with the inverse (~0.2 s); CHAIN_GO_TICKS = 4 s
+        if ((++spins & 1023u) == 0 && (long long)wall_clock64() - t0 > CHAIN_GO_TICKS) {  // the tile kernel never started.  Treated
+          atomicExch(info, -1);      // like a lost dependency: the latch sends the launch to the in-stream fallback (the tiles, should
+          wait_ok = 0;               // they still come, give up on their own bounded waits for the chain)
 #ifdef AGP_DEBUG_PTRS
           atomicAdd(&agp_dag_diag[5], 1ull);
 #endif

@@ -294,6 +294,12 @@ def main():
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU) and hand over to them
         raise SystemExit(launch_ranks(a.gpus))
+    # Nothing but the ONE JSON line on stdout: gloo ("[Gloo] Rank 0 is connected ..."), RCCL's banner and anything else a library
+    # prints through C stdio or fd 1 goes to stderr for the whole run -- fd 1 is pointed at fd 2 here and the saved descriptor is
+    # used for the line alone (round 6)
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != a.gpus:
         raise SystemExit(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N ...` (starts its own "
                          "ranks) or `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
@@ -451,6 +457,8 @@ def main():
     for i in range(warm):
         step(i)
     model._chk(L.agp_svgp_check_status(h))  # (also takes the natural-gradient step the last warm-up iteration left pending)
+    fb0 = C.c_int64(0)
+    model._chk(L.agp_ctx_task_graph_fallbacks(model._ctx, C.byref(fb0)))
     cnt0 = (C.c_int64(), C.c_int64())
     model._chk(L.agp_svgp_step_counters(h, C.byref(cnt0[0]), C.byref(cnt0[1])))
     # HIP events around the dominant kernel sequence of every 4th step (every step at c5): bracketing every step costs the C2
@@ -476,6 +484,15 @@ def main():
     t1 = time.perf_counter()
     dt = t1 - t0
     host_enqueue_ms_per_step = (t_enq - t0) * 1e3 / max(steps, 1)
+    # task-graph launches of the timed region that lost a tile dependency and were re-run by the in-stream fallback (0 on a GPU the
+    # process has to itself; a non-zero count = steps that took milliseconds, include/agp_hip.h agp_ctx_task_graph_fallbacks)
+    fb1 = C.c_int64(0)
+    model._chk(L.agp_ctx_task_graph_fallbacks(model._ctx, C.byref(fb1)))
+    task_graph_fallbacks = int(fb1.value - fb0.value)
+    if dist is not None:
+        tfb = torch.tensor([task_graph_fallbacks], dtype=torch.int64, device="cpu" if share else dev)
+        dist.all_reduce(tfb, op=dist.ReduceOp.SUM)
+        task_graph_fallbacks = int(tfb.item())
     nl, kms = C.c_int64(), C.c_double()
     model._chk(L.agp_svgp_timing_read(h, C.byref(nl), C.byref(kms)))
     model._chk(L.agp_svgp_timing_enable(h, 0))
@@ -647,6 +664,7 @@ def main():
         "warmup": warm,
         "ms_per_step": round(dt / steps * 1e3, 4),
         "host_enqueue_ms_per_step": round(host_enqueue_ms_per_step, 4),
+        "task_graph_fallbacks": task_graph_fallbacks,
         "higher_is_better": True,
         "scaling": scaling,
         "vs_baseline": None,
@@ -943,7 +961,7 @@ def main():
     flush_c_stdio()
     out.pop("_elbo_ctx", None)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.destroy()
     if dist is not None:

@@ -166,6 +166,11 @@ int32_t agp_version(void);
 agp_status agp_ctx_create(int32_t device, void* hip_stream, agp_ctx** out);
 agp_status agp_ctx_destroy(agp_ctx* ctx);
 agp_status agp_ctx_sync(agp_ctx* ctx);
+/* Diagnostics (round 6): how many task-graph factorisation launches of this context lost a tile dependency and were re-run by their
+ * in-stream fallback (k_chol_safe / k_safe_rowstats) since the context was created.  0 on a GPU this process has to itself -- a
+ * non-zero count means steps that cost milliseconds instead of 0.3 and a trajectory that is correct to rounding but no longer the
+ * bitwise one; bench.py prints it as `task_graph_fallbacks`.  Synchronises the context's stream. */
+agp_status agp_ctx_task_graph_fallbacks(agp_ctx* ctx, int64_t* n_host);
 const char* agp_last_error(agp_ctx* ctx);
 
 /* ---- building blocks (unit parity) ---------------------------------------------------------------- */

@@ -355,9 +355,10 @@ def test_split_launch_with_prologue_lookahead_and_the_host_far_ahead(mods):
     """Regression for a deadlock of the first version of the split launch (an event joined the chain kernel's stream with the step's
     behind every launch): fp32, m = 1024, B = 2048 -- the prologue rides in the split launch --, look-ahead on, 200 steps enqueued
     without a single synchronisation.  Now no event sits between the streams; the run must simply finish, and it
-    must land where the merged launch lands -- bit for bit, unless one of its 200 launches lost a dependency on its own and went
-    through the fallback (round 5: about one split launch of this form in 10 000 does, docs/DESIGN_LOG.md section 14; the split form
-    of launches with the prologue is opt-in since): then to fp32 rounding."""
+    must land where the merged launch lands -- BIT FOR BIT -- without a single launch having gone through the fallback.  (Round 5
+    accepted fp32 rounding here: about one split launch in 10 000 lost a dependency on its own -- the tile kernel filled every CU
+    before the chain kernel was resident.  Round 6: the step's stream waits for the chain kernel's "here" count in front of the tile
+    kernel, DagSync::here / k_wait_here, and this is the default form of the fp32 launch again.)"""
     code = r"""
 import sys, ctypes as C, hashlib
 sys.path.insert(0, '.')
@@ -382,19 +383,17 @@ for i in range(steps):
 torch.cuda.synchronize()
 mu, Sig, e1, e2 = model.get_state(0)
 assert np.all(np.isfinite(e2))
+nfb = C.c_int64(-1)
+assert L.agp_ctx_task_graph_fallbacks(model._ctx, C.byref(nfb)) == 0
+print('FALLBACKS', nfb.value)
 print('HASH', hashlib.sha256(np.ascontiguousarray(e2).tobytes()).hexdigest())
-np.save(sys.argv[1], e2)
 """
-    import tempfile
-
-    get = lambda s: [l for l in s.splitlines() if l.startswith("HASH")][0]
-    with tempfile.TemporaryDirectory() as td:
-        pa, pb = os.path.join(td, "a.npy"), os.path.join(td, "b.npy")
-        h_split = get(_run_child({"AGP_CHAIN_SPLIT": "1"}, code, pa))
-        h_merged = get(_run_child({"AGP_CHAIN_SPLIT": "0"}, code, pb))
-        if h_split != h_merged:
-            a, b = np.load(pa).astype(np.float64), np.load(pb).astype(np.float64)
-            assert np.max(np.abs(a - b)) <= 2e-6 * np.max(np.abs(b)), "split and merged launches differ beyond fp32 rounding"
+    get = lambda s, key="HASH": [l for l in s.splitlines() if l.startswith(key)][0]
+    out_default = _run_child({}, code)  # fp32 launches with the prologue split by default (from 600 tiles)
+    out_split = _run_child({"AGP_CHAIN_SPLIT": "1"}, code)
+    out_merged = _run_child({"AGP_CHAIN_SPLIT": "0"}, code)
+    assert get(out_split, "FALLBACKS") == get(out_merged, "FALLBACKS") == get(out_default, "FALLBACKS") == "FALLBACKS 0"
+    assert get(out_split) == get(out_merged) == get(out_default), "split and merged launches must be bitwise identical"
 
 
 def test_enqueued_elbo_equals_the_synchronous_one(mods):

@@ -18,6 +18,7 @@ from collections import Counter
 cnt = Counter()
 ref = None
 diffs = []
+fallbacks = 0
 for rep in range(reps):
     model = AGP.SVGP(AGP.with_lengthscale(AGP.Matern52Kernel(), 1.0), AGP.StudentTLikelihood(3.0), AGP.AnalyticSVI(B), Z, optimiser=False, T=np.float32)
     AGP.train_(model, X, y, 1, idx_stream=idx[:1])
@@ -29,6 +30,9 @@ for rep in range(reps):
         assert L.agp_svgp_cavi_step(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(yd.data_ptr()), C.c_void_p(ia[j].data_ptr()), B, N / B) == 0
         L.agp_svgp_prefetch(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(ia[(j + 1) % 32].data_ptr()), B)
     torch.cuda.synchronize()
+    nfb = C.c_int64(0)
+    L.agp_ctx_task_graph_fallbacks(model._ctx, C.byref(nfb))
+    fallbacks += nfb.value
     try:
         e2 = model.get_state(0)[3]
         cnt[hashlib.sha256(np.ascontiguousarray(e2).tobytes()).hexdigest()[:10]] += 1
@@ -40,4 +44,5 @@ for rep in range(reps):
     except Exception as e:
         cnt["EXC " + str(e)[:60]] += 1
     del model
-print(os.environ.get("AGP_HIP_LIB", "default")[-12:], os.environ.get("AGP_CHAIN_SPLIT"), dict(cnt), diffs[:12])
+print(os.environ.get("AGP_HIP_LIB", "default")[-12:], "AGP_CHAIN_SPLIT", os.environ.get("AGP_CHAIN_SPLIT"), "AGP_STEP_PROLOGUE",
+      os.environ.get("AGP_STEP_PROLOGUE"), "runs", reps, "launches", reps * steps, "task_graph_fallbacks", fallbacks, dict(cnt), diffs[:12])

@@ -42,6 +42,7 @@ from .svgp import (  # noqa: F401
     objective,
     objective_enqueue,
     objective_fetch,
+    SideObjective,
     predict_f,
     predict_y,
     proba_y,

@@ -257,7 +257,17 @@ static agp_status ensure_safe_words(agp_ctx* c) {
 // NEXT split launch may be sitting on: with the host ahead, that kernel is already in flight on its own stream, polls for a tile
 // kernel that is enqueued BEHIND the fallback, and holds most of its CU's LDS while it does (a fallback workgroup cannot share the
 // CU).  A fallback grid of n_cu workgroups would then wait at its first barrier for a workgroup that can never be placed.
-static int64_t safe_grid_cap(const agp_ctx* c) { return std::max<int64_t>(1, (int64_t)c->n_cu - (c->chain_state == 1 ? CHOL_MAXB : 0)); }
+static int64_t safe_grid_cap(const agp_ctx* c) {
+  // test hook (AGP_DAG_TEST_OVERSUBSCRIBE=1, with AGP_DAG_TEST_ABORT=1): a fallback grid that CANNOT be resident at once (four
+  // workgroups of ~110 KB LDS per CU), i.e. the situation the bounded grid barrier exists for -- the step must end in status -3
+  // (AGP_ERR_HIP from agp_svgp_check_status) after the barrier's limit instead of hanging (tests/test_gpu_round6.py)
+  static const bool over = []() {
+    const char* e = getenv("AGP_DAG_TEST_OVERSUBSCRIBE");
+    return e && e[0] == '1';
+  }();
+  if (over) return 4 * (int64_t)c->n_cu;
+  return std::max<int64_t>(1, (int64_t)c->n_cu - (c->chain_state == 1 ? CHOL_MAXB : 0));
+}
 // the fallback behind a task-graph launch (see k_chol_safe): one launch that returns at once unless the latch reads -1
 template <typename T>
 static agp_status launch_chol_safe(agp_ctx* c, const CholBatch<T>& bt, const SafeSrc<T>& src, int nb, int64_t ld, int64_t ldx,
@@ -2996,6 +3006,9 @@ struct Svgp : SvgpBase {
       hy_grad_on_device_only = true;
       const agp_status hs = hypergrad(l, nullptr, nullptr, nullptr);
       hy_grad_on_device_only = false;
+      //  hypergrad() marks the reduction as deferred BEFORE its last fallible calls (the online model's extra passes, a
+      // launch check, a copy): an error exit must not leave the mark behind for the next, unrelated hyper_apply to trip over
+      if (hs != AGP_OK) red_def.on = false;
       AGPCHK(hs);
       AGPCHK(hyper_apply_one(l, nullptr, (const T*)hy_dZ));
     }

@@ -22,20 +22,75 @@ enum {
 };
 enum { FLAG_NEG_KTILDE = 1, FLAG_BAD_LABEL = 2 };
 
+// ---------------------------------------------------------------------------------------------------
+// exp for the kernel functions (round 6).  Every kernel of the path evaluates exp at a NON-POSITIVE argument
+// (-d2/2, -sqrt(5) r, -sqrt(3) r, -r), N m times per streaming prediction: 1.07e9 values at C2.  The device library's exp costs a
+// lane ~36 VALU instructions there (its polynomial as v_mov_b64 + v_fmac pairs, overflow / underflow / NaN selects); this one 17:
+//   n = rint(x log2 e) ; r = x - n ln2 (two-constant Cody-Waite, exact for |n| < 2^20) ; e^r by its degree-11 Taylor polynomial on
+//   |r| <= ln2 / 2 (truncation 6.3e-15 relative, Horner with the coefficients as SGPR operands of v_fma_f64) ; v_ldexp_f64.
+// Arguments below -750 are clamped there (the result is exactly 0 through v_ldexp's denormal handling -- the padded "far" inducing
+// points of the online model rely on exact zeros); a NaN argument gives a finite value like the d2 > 0 ? d2 : 0 in front of every
+// call always did.  Max relative error against exp over [-745, 0]: 9e-15 (the truncation at |r| = ln2 / 2; tests/test_gpu_round6.py).
+// fp32: v_exp_f32 with log2 e folded into the argument (1.5 ulp of the instruction + the argument's rounding, |x| 2^-24 relative).
+// ---------------------------------------------------------------------------------------------------
+struct ExpScalePlain {  // e^x, x <= 0
+  static constexpr double ct = 1.44269504088896338700e+00;    // n = rint(ct x)
+  static constexpr double chi = -6.93147180369123816490e-01;  // r = x + n chi + n clo
+  static constexpr double clo = -1.90821492927058770002e-10;
+  static constexpr double lim = -750.0;                       // clamp (towards zero) of x
+  static constexpr double sc = 1.0;                           // polynomial variable is sc * r
+};
+struct ExpScaleHalfNeg {  // e^(-u/2), u >= 0: the squared-exponential kernel straight from the squared distance
+  static constexpr double ct = -0.5 * 1.44269504088896338700e+00;
+  static constexpr double chi = 2.0 * 6.93147180369123816490e-01;
+  static constexpr double clo = 2.0 * 1.90821492927058770002e-10;
+  static constexpr double lim = 1500.0;
+  static constexpr double sc = -0.5;
+};
+template <typename S>
+__device__ __forceinline__ double exp_core_d(double x) {
+  // (the caller has clamped x into [lim, 0] resp. [0, lim])
+  const double n = __builtin_rint(x * S::ct);
+  double r = __builtin_fma(n, S::chi, x);
+  r = __builtin_fma(n, S::clo, r);
+  // p(r) = sum_k (sc r)^k / k!, k = 0 .. 11
+  constexpr double s1 = S::sc, s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1, s6 = s3 * s3, s7 = s6 * s1, s8 = s4 * s4,
+                   s9 = s8 * s1, s10 = s5 * s5, s11 = s10 * s1;
+  // ONE asm statement for the Horner chain: between separate asm statements the compiler puts an s_nop each, and left to itself it
+  // keeps the coefficients in VGPRs and emits v_mov_b64 + v_fmac_f64 pairs (9 more VALU instructions per value)
+  double p;
+  const double p0 = s11 / 39916800.0;  // (a VGPR operand that stays live across the values of a tile: VOP3 takes one SGPR source)
+  asm("v_fma_f64 %0, %13, %1, %2\n\tv_fma_f64 %0, %0, %1, %3\n\tv_fma_f64 %0, %0, %1, %4\n\tv_fma_f64 %0, %0, %1, %5\n\t"
+      "v_fma_f64 %0, %0, %1, %6\n\tv_fma_f64 %0, %0, %1, %7\n\tv_fma_f64 %0, %0, %1, %8\n\tv_fma_f64 %0, %0, %1, %9\n\t"
+      "v_fma_f64 %0, %0, %1, %10\n\tv_fma_f64 %0, %0, %1, %11\n\tv_fma_f64 %0, %0, %1, %12"
+      : "=&v"(p)
+      : "v"(r), "s"(s10 / 3628800.0), "s"(s9 / 362880.0), "s"(s8 / 40320.0), "s"(s7 / 5040.0), "s"(s6 / 720.0), "s"(s5 / 120.0),
+        "s"(s4 / 24.0), "s"(s3 / 6.0), "s"(s2 / 2.0), "s"(s1), "s"(1.0), "v"(p0));
+  return __builtin_amdgcn_ldexp(p, (int)n);
+}
+// e^x for x <= 0 (x > 0 is not an error but loses the clamp's protection against overflow of the exponent: not used that way)
+__device__ __forceinline__ double exp_nonpos(double x) { return exp_core_d<ExpScalePlain>(__builtin_fmax(x, ExpScalePlain::lim)); }
+__device__ __forceinline__ float exp_nonpos(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896338700f); }
+// e^(-u/2) for u >= 0 (negative or NaN u: treated as 0, like kernel_base's own clamp)
+__device__ __forceinline__ double exp_mhalf(double u) {
+  return exp_core_d<ExpScaleHalfNeg>(__builtin_fmin(__builtin_fmax(u, 0.0), ExpScaleHalfNeg::lim));
+}
+__device__ __forceinline__ float exp_mhalf(float u) { return __builtin_amdgcn_exp2f(__builtin_fmaxf(u, 0.0f) * (-0.5f * 1.44269504088896338700f)); }
+
 template <typename T>
 __device__ __forceinline__ T kernel_base(int kind, T d2) {
+  if (kind == K_SQEXP) return exp_mhalf(d2);
   d2 = d2 > T(0) ? d2 : T(0);
-  if (kind == K_SQEXP) return exp(T(-0.5) * d2);
   T d = sqrt(d2);
   if (kind == K_MATERN52) {
     const T s5 = T(2.23606797749978969641);
-    return (T(1) + s5 * d + T(5) * d2 / T(3)) * exp(-s5 * d);
+    return (T(1) + s5 * d + T(5) * d2 / T(3)) * exp_nonpos(-s5 * d);
   }
   if (kind == K_MATERN32) {
     const T s3 = T(1.73205080756887729353);
-    return (T(1) + s3 * d) * exp(-s3 * d);
+    return (T(1) + s3 * d) * exp_nonpos(-s3 * d);
   }
-  return exp(-d);
+  return exp_nonpos(-d);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -308,6 +363,29 @@ __global__ __launch_bounds__(NTHREADS, ((SPEC == 3 || SPEC == 0) ? 2 : 4)) void 
       ynv[ni] = ynb[cl_[ni]];
       al[ni] = (alpha != nullptr && cok[ni]) ? alpha[gj] : T(0);
     }
+    if constexpr (SPEC == 1 && KIND == K_SQEXP && sizeof(T) == 8) {
+      // Streaming prediction with the squared-exponential kernel in fp64 (round 6): branch-free, 21 VALU instructions per kernel value
+      // (s2, d2, two clamps, the 17 of exp_mhalf, the row-dot FMA) where the general form below spends ~48 and a branch.  No masks:
+      // rows beyond n are zero rows of Xs (finite values, never stored), columns beyond p have alpha = 0.  No direct-difference
+      // repair of (nearly) coincident points either: the GEMM form leaves d2 an absolute error of a few ulp(|x|^2 + |y|^2), which
+      // this kernel function turns into HALF that as a relative error of its value -- it is the first-order kernels below (sqrt at
+      // d2 -> 0) that need the repair.  The variance is folded into alpha.
+      T alv[2];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) alv[ni] = variance * al[ni];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const T xnv = xn[wm * 32 + mi * 16 + Mfma<T>::row(lane, r)];
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const T d2 = __builtin_fma(T(-2), acc[mi][ni][r], xnv + ynv[ni]);
+            rs[mi][r] = __builtin_fma(exp_mhalf(d2), alv[ni], rs[mi][r]);
+          }
+        }
+      continue;
+    }
     const int64_t dgi = sym ? (j0 - i0) : (int64_t)1 << 40;  // gi == gj  <=>  rl - cl == j0 - i0 (only tiles on the diagonal can hit)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -373,6 +451,7 @@ inline size_t kmm_smem_bytes(int Dp) {
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double digamma_d(double x) {
   // psi(x), x > 0 : upward recurrence to x >= 10, then the asymptotic series (|err| < 1e-15 relative)
+  if (!(x > 0.0)) return __builtin_nan("");  // (same domain guard as lgamma_pos_d: the loop below would not end for x = -inf)
   double r = 0.0;
   while (x < 10.0) {
     r -= 1.0 / x;
@@ -390,6 +469,10 @@ __device__ __forceinline__ double digamma_d(double x) {
 // (|abs err| < 2e-15 there; the last term kept is 1/(156 x^13) < 7e-16).  The device library's lgamma needs more than the 128
 // registers a 1024-thread workgroup has: the three ELBO kernels that call it per data point carried ~300 bytes of scratch per lane.
 __device__ __forceinline__ double lgamma_pos_d(double x) {
+  // domain guard: the recurrence below walks up to x >= 10 one step at a time -- x = -inf would never get there and a
+  // hugely negative x (a bad count label handed through the C ABI) would keep the ELBO kernel's one workgroup, and its stream,
+  // busy for |x| iterations.  Outside x > 0 (and for NaN) the answer is NaN, as the library's lgamma reports poles / bad input.
+  if (!(x > 0.0) || x == __builtin_inf()) return x == __builtin_inf() ? x : __builtin_nan("");
   double p = 1.0;
   while (x < 10.0) {
     p *= x;

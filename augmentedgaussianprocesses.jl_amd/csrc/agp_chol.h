@@ -1883,6 +1883,11 @@ void k_chol_dag(CholBatch<T> bt, int nb, int64_t fstride, int64_t ld, int64_t ld
   bool helper = false;
   int64_t hbase = 0;  // PRO: helper slots of the columns before c
   const bool is_prod = !BATCH && !STEP && ROLE != 1 && prod.out != nullptr && bidx >= prod.base;  // P = X' X tile (see ProdArgs)
+  //  the host clears the dirty mark of the OTHER hand-over set when it enqueues a launch with product workgroups and no
+  // prologue, trusting THESE workgroups to refill it (prod.fill, first thing they do below).  That holds only while no exit can
+  // precede the fill for an is_prod workgroup -- true for ROLE 0 (the chain-kernel exits above are ROLE 1, the STEP forms have no
+  // product workgroups); the hand-over validates itself by sentinels, so a missed refill would be accepted as data, not reported
+  static_assert(ROLE == 0 || STEP, "product workgroups (ProdArgs) must reach their sentinel refill unconditionally: ROLE 0 only");
   if (is_prod) {
     b = 0;  // (decoded below, once the flag pointers are in place)
   } else if (PRO && ROLE == 1) {

@@ -108,6 +108,9 @@ def save_trained_model(filename: str, model: SVGP) -> None:
         "k_opt": _opt_spec(model.k_opt), "z_opt": _opt_spec(model.z_opt),
         "atfrequency": model.atfrequency, "mean": model.mean if np.isscalar(model.mean) or model.mean is None else None,
         "jitter": getattr(model, "jitter", None), "stale_K": bool(getattr(model, "reference_compat_stale_K", False)),
+        # the mixing weights' optimiser of a multi-output model (update_A!, single_and_multi_output_utils.jl:87-118): without it a
+        # reloaded model silently froze A; its moments restart, like the Z optimiser's
+        "a_opt": _opt_spec(getattr(model, "A_opt", None)) if mo else None,
     }
     import ctypes as C
 
@@ -162,7 +165,9 @@ def load_trained_model(filename: str, *, device=None):
               jitter=meta.get("jitter"), reference_compat_stale_K=meta.get("stale_K", False))
     if meta["class"] == "MOSVGP":
         kw.pop("jitter"), kw.pop("reference_compat_stale_K")  # (not constructor arguments of the multi-output model)
-        model = MOSVGP(kernels, [_lik_from(d) for d in meta["likelihood"]], inf, Zs, A=g["A"], Aoptimiser=False, **kw)
+        # (files written before round 6 carry no "a_opt": the model's default ADAM(0.01), MOSVGP.jl:42, as for a fresh model)
+        a_opt = _opt_from(meta["a_opt"]) if "a_opt" in meta else None
+        model = MOSVGP(kernels, [_lik_from(d) for d in meta["likelihood"]], inf, Zs, A=g["A"], Aoptimiser=a_opt, **kw)
     else:
         model = SVGP(kernels, _lik_from(meta["likelihood"]), inf, Zs, **kw)
     inf.n_iter = meta["n_iter"]

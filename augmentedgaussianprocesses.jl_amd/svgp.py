@@ -737,6 +737,87 @@ def objective_fetch(model: SVGP, ticket: int, wait: bool = True):
     return out.value
 
 
+class SideObjective:
+    """Convergence monitoring NEXT TO the training stream (round 6).
+
+    `objective` / `objective_enqueue` evaluate the ELBO in line on the model's own stream: at C2 a check on a fixed 8192-point
+    batch costs the training loop 0.87 ms (kernel matrices of the evaluation batch, local update, the factorisation of -2 eta2 with
+    its inverse, the ELBO's reductions) between two 0.31 ms steps.  A check needs nothing of the training state but a SNAPSHOT of
+    (eta1, eta2): this object owns a shadow model -- same kernels, inducing points, likelihood and prior mean on a context and
+    stream of its own, its K_ZZ factored once -- and a ring of snapshot buffers.  `enqueue` copies (eta1, eta2) out of the training
+    handle on the training stream (two device copies; agp_svgp_get_state), lets the side stream wait for them with an event, and
+    there installs them (agp_svgp_set_state: the same factorisation launch `objective` uses) and enqueues the evaluation
+    (agp_svgp_elbo_enqueue, fresh local variables: ELBO(model, X, y) of src/functions/ELBO.jl:32-47 with rho explicit).  The
+    training stream goes straight on to its next steps; the steps are bound by one workgroup's dependent chain while ~250 CUs
+    idle, which is where the evaluation runs.  `fetch` returns the value (tickets in any order).
+
+    The values are bit-identical to `ELBO(model, X[idx], y[idx], rho=rho)` evaluated in line at the same point of the training
+    sequence (tests/test_gpu_round6.py).  Models whose kernels / inducing points move (hyper-parameter optimisation on) are
+    refused: the shadow's K_ZZ is factored once.  Reference: the monitoring this replaces is `objective(model, state, y)` in
+    train!'s progress reporting, src/training/training.jl:71-90, and the ELBO itself, src/inference/analyticVI.jl:255-274."""
+
+    def __init__(self, model: SVGP, max_eval_batch: int, ring: int = 4):
+        if isinstance(model, MOSVGP) or model.n_latent != 1:
+            raise NotImplementedError("SideObjective: single-latent SVGP models")
+        if model.k_opt is not None or model.z_opt is not None:
+            raise NotImplementedError("SideObjective: kernels and inducing points must be fixed (optimiser=False, Zoptimiser=False)")
+        if model._h is None:
+            raise RuntimeError("SideObjective: the model has no device state yet (train it for at least one step, or bind data)")
+        torch = _torch()
+        self.model = model
+        dev = model._dev()
+        self.stream = torch.cuda.Stream(device=dev)
+        import copy
+
+        with torch.cuda.stream(self.stream):  # (the shadow's context takes torch's current stream: the side stream)
+            inf = AnalyticSVI(int(max_eval_batch)) if model.inference.stoch else AnalyticVI()
+            self.shadow = SVGP(copy.deepcopy(model.kernels[0]), copy.deepcopy(model.likelihood), inf, model.Zs[0], optimiser=False,
+                               Zoptimiser=False, mean=model.mean, T=model.T.type, device=dev.index, elbo_mode=model.elbo_mode,
+                               jitter=model.jitter)
+            self.h = self.shadow._ensure_handle(int(max_eval_batch))
+            self.shadow._chk(capi.lib().agp_svgp_refresh_K(self.h))
+        self.stream.synchronize()
+        m = model.m
+        self._ring = [(torch.empty(m, dtype=model.tdtype, device=dev), torch.empty(m, m, dtype=model.tdtype, device=dev),
+                       torch.cuda.Event(), torch.cuda.Event()) for _ in range(int(ring))]
+        self._n = 0
+        self._tickets = {}
+
+    def enqueue(self, Xd, yd, idx_dev, B: int, rho: float) -> int:
+        """Snapshot the training model's (eta1, eta2) now (in stream order) and evaluate ELBO on rows idx_dev[0..B) of the device
+        arrays (Xd, yd) on the side stream.  Returns a ticket."""
+        torch = _torch()
+        L = capi.lib()
+        mdl = self.model
+        e1, e2, ev_snap, ev_used = self._ring[self._n % len(self._ring)]
+        main = torch.cuda.current_stream(mdl._dev())
+        if self._n >= len(self._ring):
+            main.wait_event(ev_used)  # the side stream has installed the snapshot this slot held (set_state copies it out)
+        mdl._chk(L.agp_svgp_get_state(mdl._h, 0, None, None, C.c_void_p(e1.data_ptr()), C.c_void_p(e2.data_ptr())))
+        ev_snap.record(main)
+        t = C.c_int32()
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev_snap)
+            self.shadow._chk(L.agp_svgp_set_state(self.h, 0, C.c_void_p(e1.data_ptr()), C.c_void_p(e2.data_ptr())))
+            ev_used.record(self.stream)
+            self.shadow._chk(L.agp_svgp_elbo_enqueue(self.h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(yd.data_ptr()),
+                                                     C.c_void_p(idx_dev.data_ptr()) if idx_dev is not None else None, int(B),
+                                                     float(rho), 1, C.byref(t)))
+        tk = self._n
+        self._n += 1
+        self._tickets[tk] = int(t.value)
+        return tk
+
+    def fetch(self, ticket: int, wait: bool = True):
+        slot = self._tickets[ticket]
+        out, ready = C.c_double(), C.c_int32()
+        self.shadow._chk(capi.lib().agp_svgp_elbo_fetch(self.h, slot, 1 if wait else 0, C.byref(out), C.byref(ready)))
+        if not ready.value:
+            return None
+        del self._tickets[ticket]
+        return out.value
+
+
 def ELBO(model: SVGP, X, y, *, obsdim: int = 1, rho: Optional[float] = None) -> float:
     """External ELBO(model, X, y) (src/functions/ELBO.jl:28-47): fresh local variables on (X, y), one local update.
     rho defaults to the reference's behaviour (the ρ left by the last train!, Appendix A Q13); pass rho=1 for the

@@ -799,6 +799,45 @@ def main():
         out["predict_f_mean_all_N"] = {"seconds": round(tp, 4), "points_per_s": round(N / tp, 1),
                                        "hbm_GBps_algorithmic": round((N * D * es + N * es) / tp / 1e9, 2),
                                        "algorithmic_TFLOPs": round(N * m * (3 * D + 14) / tp / 1e12, 2)}
+        # round 6: what bounds the streaming predictor (SURVEY 8d called it the HBM-bound measurement; it is not: N D + N elements of
+        # traffic against N m kernel values).  1.5 s of back-to-back predictions with the engine clock and socket power sampled.
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from clock_sampler import ClockSampler
+
+            smp = ClockSampler(local_rank, 20.0).start()
+            tps, reps = time.perf_counter(), 0
+            while time.perf_counter() - tps < 1.5:
+                for _ in range(20):
+                    model._chk(L.agp_svgp_predict_f(h, xp, ld, N, C.c_void_p(mu_out.data_ptr()), None))
+                torch.cuda.synchronize()
+                reps += 20
+            tpl = (time.perf_counter() - tps) / reps
+            clk = smp.stop()
+            nval = float(N) * m
+            # executed per kernel value: the cross term on the MFMA pipe (2 D flops) + the VALU instructions of the epilogue
+            # (fp64 squared-exponential: 22, of which 16 are FMAs -- s2, d2, two clamps, exp_mhalf's 17, the row-dot FMA; the
+            # general path ~48: csrc/agp_cavi.h); every fraction against the datasheet peaks
+            valu_per_value = 22 if (not f32 and cfg["kernel"] == "sqexp") else 48
+            vpeak = peak  # the VALU's FMA rate equals the MFMA rate in fp64 (78.6 TF); fp32: quoted against the MFMA peak as well
+            out["predict_roofline"] = {
+                "kernel": f"k_kernelmatrix_mma<{tname}, {'K_SQEXP' if cfg['kernel'] == 'sqexp' else 'K_MATERN52'}, 1> (streaming: K_*m never stored)",
+                "seconds_per_pass": round(tpl, 5), "kernel_values_per_s": round(nval / tpl, 1), "exp_per_s": round(nval / tpl, 1),
+                "bound": "valu + mfma issue (neither HBM nor a single pipe)",
+                "hbm": {"achieved": round((N * D * es + N * es) / tpl / 1e9, 1), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round((N * D * es + N * es) / tpl / 1e9 / 8000.0, 4)},
+                "mfma": {"achieved": round(2.0 * nval * D / tpl / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(2.0 * nval * D / tpl / 1e12 / peak, 4), "what": "cross term x.z of the squared distances"},
+                "valu": {"instructions_per_value": valu_per_value, "achieved": round(2.0 * valu_per_value * nval / tpl / 1e12, 2),
+                         "peak": vpeak, "unit": "TFLOP/s (every VALU instruction counted as an FMA)",
+                         "frac": round(2.0 * valu_per_value * nval / tpl / 1e12 / vpeak, 4)},
+                "combined_frac_of_one_pipe": round((2.0 * nval * D + 2.0 * valu_per_value * nval) / tpl / 1e12 / peak, 4),
+                "clock_power_during_the_loop": clk,
+                "note": "MFMA and VALU work of different waves overlap; their sum runs at about the rate the register-only MFMA loop "
+                        "sustains under the socket power limit (mfma_sustained) -- DESIGN.md section 4",
+            }
+        except Exception as ex:
+            out["predict_roofline"] = {"error": repr(ex)}
 
     # ---- time to ELBO tolerance (build-defined, SURVEY.md 8d: the reference has no stopping rule) ----
     if not a.no_elbo_tol and rank == 0 and world == 1 and single_latent:
@@ -830,6 +869,13 @@ def main():
         # its decision comes one check (ten iterations, ~3 ms at C2) after the check that satisfies it, and the reported time is
         # the wall-clock at which the host HAS that value.  AGP_BENCH_ELBO_SYNC=1 restores the synchronous evaluation.
         elbo_sync = os.environ.get("AGP_BENCH_ELBO_SYNC") == "1"
+        # round 6: the checks run NEXT TO the training stream (agp_amd.SideObjective: a snapshot of (eta1, eta2) by two device
+        # copies on the training stream, the evaluation -- kernel matrices of the 8192 points, local update, factorisation of -2 eta2
+        # with its inverse, the ELBO's reductions -- on a side stream with a shadow handle of its own, bit-identical values,
+        # tests/test_gpu_round6.py).  In line a check cost the loop 0.87 ms between two 0.31 ms steps, 190 times.
+        # AGP_BENCH_ELBO_INLINE=1 restores the in-line enqueued evaluation of rounds 4-5.
+        elbo_side = (not elbo_sync) and os.environ.get("AGP_BENCH_ELBO_INLINE") != "1"
+        side = AGP.SideObjective(model2, EVAL, ring=4) if elbo_side else None
         tk, pending_tk, rdy = C.c_int32(), None, C.c_int32()
         while it < max_it and (hit["raw"] is None or hit["smoothed"] is None or hit["reach"] is None) and \
                 (time.perf_counter() - ts) < t_cap:
@@ -843,6 +889,12 @@ def main():
             if elbo_sync:
                 model2._chk(L.agp_svgp_elbo(h2, xp, ld, yp, C.c_void_p(eval_idx.data_ptr()), EVAL, rho_e, 1, C.byref(e)))
                 it_of_value = it
+            elif elbo_side:
+                prev, pending_tk = pending_tk, (side.enqueue(eng._X, eng._y, eval_idx, EVAL, rho_e), it)
+                if prev is None:
+                    continue
+                e.value = side.fetch(prev[0])
+                it_of_value = prev[1]
             else:
                 model2._chk(L.agp_svgp_elbo_enqueue(h2, xp, ld, yp, C.c_void_p(eval_idx.data_ptr()), EVAL, rho_e, 1, C.byref(tk)))
                 prev, pending_tk = pending_tk, (tk.value, it)
@@ -864,7 +916,10 @@ def main():
                 if abs(m1 - m0) / abs(m1) < 1e-3:
                     hit["smoothed"] = (now, it_of_value, hist[-1])
         if pending_tk is not None:  # close the last ticket
-            model2._chk(L.agp_svgp_elbo_fetch(h2, pending_tk[0], 1, C.byref(e), C.byref(rdy)))
+            if elbo_side:
+                side.fetch(pending_tk[0])
+            else:
+                model2._chk(L.agp_svgp_elbo_fetch(h2, pending_tk[0], 1, C.byref(e), C.byref(rdy)))
         torch.cuda.synchronize()
         # contracted rule: |ELBO_t - ELBO_{t-10}| / |ELBO_t| < 1e-4 for 3 consecutive checks
         out["time_to_elbo_tol_s"] = round(hit["raw"][0], 4) if hit["raw"] else None
@@ -873,9 +928,11 @@ def main():
         out["elbo_tol_rule"] = ("SURVEY 8d: ELBO (corrected, fresh local variables) on a fixed 8192-point batch every 10 iterations; stop "
                                 "when |ELBO_t - ELBO_{t-10}| / |ELBO_t| < 1e-4 for 3 consecutive checks; wall-clock includes the "
                                 f"ELBO evaluations; null = not reached within {it} iterations / {t_cap:.0f} s"
-                                + ("" if elbo_sync else "; evaluations enqueued in the stream and read one check later "
-                                   "(agp_svgp_elbo_enqueue / _fetch): reported seconds = when the host has the deciding value, "
+                                + ("" if elbo_sync else "; evaluations " + ("on a side stream from a snapshot of (eta1, eta2) "
+                                   "(agp_amd.SideObjective, bit-identical values)" if elbo_side else "enqueued in the training stream")
+                                   + " and read one check later: reported seconds = when the host has the deciding value, "
                                    "reported iterations = the iteration that value belongs to"))
+        out["elbo_checks"] = "side stream (SideObjective)" if elbo_side else ("synchronous" if elbo_sync else "in-line, enqueued")
         if len(hist) > 20:  # what the rule is up against: the spread of consecutive checks at the end of the run
             d = np.abs(np.diff(hist[-101:])) / np.abs(np.asarray(hist[-100:] if len(hist) > 100 else hist[1:]))
             out["elbo_check_noise_floor"] = {"median_rel_change_of_consecutive_checks": float(np.median(d)),

@@ -17,15 +17,17 @@
  *   - work is enqueued asynchronously on the ctx stream; calls that return host scalars or a
  *     data-dependent status (refresh_K, elbo, check_status, ctx_sync) synchronise that stream.
  *
- * Environment (all the library reads; 15 variables, each read once per process unless said otherwise).  The first eight switch a
+ * Environment (all the library reads; 16 variables, each read once per process unless said otherwise).  The first eight switch a
  * default path off for the FALLBACK that also exists on its own -- the GPU suite is run once with each of them, AGP_CHAIN_SPLIT both
  * ways (tools/suite_with_fallbacks.sh, profiles/r05_fallback_suites.txt); AGP_CHOL_GROUP, AGP_CHOL_LOOKAHEAD and the test hook
  * AGP_DAG_TEST_ABORT are exercised by tests of their own.  The A/B levers of earlier rounds are gone (docs/DESIGN_LOG.md has their numbers).
  *   AGP_CHOL_DAG=0|1          never / always factor with the one-launch tile task graph (default: up to 32 block columns, i.e. m <= 2048;
  *                             beyond, and after a lost dependency, plain launches per block column / blocked panels)
  *   AGP_CHAIN_SPLIT=0|1       the task graph as one kernel / as chain kernel + tile kernel (default: two kernels from 600 tiles,
- *                             except launches that carry the natural-gradient step as their prologue: those split only when
- *                             forced -- docs/DESIGN_LOG.md section 14)
+ *                             except fp64 launches that carry the natural-gradient step as their prologue: those split only when
+ *                             forced.  Round 6: the step's stream starts the tile kernel only when every chain workgroup of the
+ *                             launch is resident -- DagSync::here, k_wait_here -- which removed the one way a split launch lost a
+ *                             dependency on its own, docs/DESIGN_LOG.md sections 14 and 15)
  *   AGP_STEP_PROLOGUE=0       the natural-gradient step of a single-latent CAVI step as a kernel of its own (k_syrk_tn<SY_ETA2>)
  *                             instead of the prologue of the next step's task-graph launch
  *   AGP_STEP_EPILOGUE=0       the row statistics + local update as a kernel of their own instead of the launch's epilogue
@@ -38,6 +40,8 @@
  *   AGP_CHOL_LOOKAHEAD=0      ... without its side stream
  *   AGP_DAG_TEST_ABORT=1      test hook: every task-graph launch of a CAVI step is treated as having lost a dependency (the in-stream
  *                             fallback k_chol_safe / k_safe_rowstats redoes it)
+ *   AGP_DAG_TEST_OVERSUBSCRIBE=1  test hook (with AGP_DAG_TEST_ABORT=1): the fallback's grid is made too large to be resident at once, so
+ *                             its grid barrier runs into its limit (8 s) and the step ends in status -3 / AGP_ERR_HIP instead of a hang
  *   AGP_SPLIT_OVERLAP=1       (read at every step) batch-parallel statistics travel in block-column groups next to the next
  *                             factorisation; see "multi-GPU" below
  *   AGP_FORCE_SPLIT=1         diagnostic: the batch-parallel step sequence with a one-rank communicator, its collective issued

@@ -333,3 +333,141 @@ def test_logisticsoftmax_fixed_point_is_stationary_for_the_augmented_bound_of_th
     assert max(np.max(np.abs(x)) for x in g2["mu"]) > 1e-2 and np.max(np.abs(g2["gamma"])) > 1e-2
     # the value: reference constants accounted for
     assert mdl.elbo(yt) == pytest.approx(val - N * Kc * np.log(2.0) + (N - 1) * np.log(Kc), rel=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: pins for the likelihoods of SURVEY 8f-2 and for the multi-output mixing that do not pass through the
+# oracle's own formulas.
+#   * BayesianSVM (bayesiansvm.jl:43-67): the pseudo-likelihood exp(-2 max(1 - y f, 0)) as the location-scale mixture of Polson &
+#     Scott (2011) / Wenzel et al. (2017): L(y | f) = int (2 pi lam)^-1/2 exp(-(1 + lam - y f)^2 / (2 lam)) dlam.  With the optimal
+#     q(lam) = GIG(1/2, 1, c), c = E(1 - y f)^2, the integral int (2 pi lam)^-1/2 exp(-(c / lam + lam) / 2) dlam = exp(-sqrt c)
+#     collapses the bound to  -sqrt(c) - (1 - y E f)  per point.
+#   * NegBinomial (negativebinomial.jl:69-99): sigma(f)^y sigma(-f)^r with a Polya-Gamma variable of shape b = y + r.  The JJ / PG
+#     collapsed bound is  (y - r) E f / 2 + b [log sigma(c) - c / 2], c = sqrt(E f^2)  (its stationarity gives grad_E_Sigma =
+#     b tanh(c/2) / (4 c) = E[omega] / 2).  The reference writes theta = (r + y) tanh(c/2) / c and grad_E_Sigma = theta / 2, i.e. TWICE
+#     that (negativebinomial.jl:78,97-99 -- its comment says "E[omega]"; the logistic model's theta = tanh(c/2) / (2c) IS E[omega]).
+#     Its updates are therefore the exact coordinate ascent of the bound with the Polya-Gamma part DOUBLED,
+#     (y - r) E f / 2 + 2 b [log sigma(c) - c / 2]: the test shows that the restated fixed point maximises that functional to 2e-6
+#     and is measurably NOT the maximiser of the literature's bound.  Mirrored, like the other quirks of SURVEY Appendix A; the same
+#     factor sits in the Poisson model's theta (poisson.jl:75), whose gamma and lambda updates follow the undoubled bound, so that
+#     model's fixed point maximises no single functional and is pinned by its identities only (test_oracle_kat.py).
+#   * multi-output mixing (single_and_multi_output_utils.jl:24-118): the data term of every admissible task likelihood is
+#     E log p(y_t | f_t, omega) = g1 . E f_t - g2 . E f_t^2 + const with f_t = sum_q A_tq f_q; torch.autograd of that expression
+#     in A against the restated update_A! gradient.
+def test_bayesiansvm_cavi_fixed_point_maximises_the_collapsed_scale_mixture_bound():
+    import torch
+
+    rng = np.random.default_rng(61)
+    X, f, Z = _toy_sparse(rng)
+    y = np.where(f + 0.3 * rng.standard_normal(len(f)) > 0, 1.0, -1.0)
+    kern = R.Kernel("sqexponential", 2.0, 1.5)
+    mdl = R.SVGP(kern, R.BayesianSVM(), Z, stochastic=False)
+    mdl.train(X, y, 800, labels_treated=True)
+    g = mdl.latents[0]
+    K, kappa, Kt = _sparse_pieces(kern, X, Z, mdl.jitter)
+
+    def svm(mf, vf, yy):
+        return -torch.sqrt((1.0 - yy * mf) ** 2 + vf) - (1.0 - yy * mf)
+
+    mu, Sig, val = _maximise_collapsed_bound(svm, K, kappa, Kt, y, 0.9 * g.mu, np.linalg.cholesky(1.1 * g.Sigma))
+    assert np.max(np.abs(mu - g.mu)) < 2e-6 * np.max(np.abs(g.mu))
+    assert np.max(np.abs(Sig - g.Sigma)) < 2e-6 * np.max(np.abs(g.Sigma))
+    # (the reference's ELBO for this likelihood is NOT that bound's value: it subtracts the GIG entropy as if it were a KL term,
+    #  bayesiansvm.jl:85-92 -- mirrored by the oracle and the device; the fixed point, which the updates alone decide, is what is pinned)
+    assert np.isfinite(val) and np.isfinite(mdl.elbo(y))
+
+
+def test_negbinomial_fixed_point_maximises_the_bound_with_a_doubled_polya_gamma_part():
+    import torch
+
+    rng = np.random.default_rng(62)
+    X, f, Z = _toy_sparse(rng)
+    r = 4.0
+    y = rng.negative_binomial(int(r), 1.0 / (1.0 + np.exp(0.7 * f))).astype(np.float64)
+    kern = R.Kernel("sqexponential", 2.0, 1.2)
+    mdl = R.SVGP(kern, R.NegBinomialLikelihood(r), Z, stochastic=False)
+    mdl.train(X, y, 800, labels_treated=True)
+    g = mdl.latents[0]
+    K, kappa, Kt = _sparse_pieces(kern, X, Z, mdl.jitter)
+
+    def bound(scale):
+        def h(mf, vf, yy):
+            c = torch.sqrt(mf ** 2 + vf)
+            return 0.5 * (yy - r) * mf + scale * (yy + r) * (torch.nn.functional.logsigmoid(c) - 0.5 * c)
+        return h
+
+    mu2, Sig2, _ = _maximise_collapsed_bound(bound(2.0), K, kappa, Kt, y, 0.9 * g.mu, np.linalg.cholesky(1.1 * g.Sigma))
+    assert np.max(np.abs(mu2 - g.mu)) < 2e-6 * np.max(np.abs(g.mu))
+    assert np.max(np.abs(Sig2 - g.Sigma)) < 2e-6 * np.max(np.abs(g.Sigma))
+    mu1, Sig1, _ = _maximise_collapsed_bound(bound(1.0), K, kappa, Kt, y, 0.9 * g.mu, np.linalg.cholesky(1.1 * g.Sigma))
+    # ... and not the literature's: the posterior variances of the reference's fixed point are too small by a visible margin
+    assert np.max(np.abs(np.diag(Sig1) - np.diag(g.Sigma))) > 0.05 * np.max(np.diag(g.Sigma))
+    assert np.all(np.diag(Sig1) > np.diag(g.Sigma))
+
+
+def _mo_toy(rng, liks):
+    N, D, m, Q = 80, 2, 6, 3
+    X = rng.random((N, D))
+    fs = [np.sin(4 * X[:, 0]), X[:, 1] - 0.5, np.cos(3 * X[:, 0] * X[:, 1])]
+    ys = []
+    for t, l in enumerate(liks):
+        ys.append(fs[t] + 0.1 * rng.standard_normal(N) if l.name in ("gaussian", "studentt", "laplace")
+                  else np.sign(fs[t] + 0.1 * rng.standard_normal(N)))
+    A = rng.standard_normal((len(liks), Q))
+    A /= np.linalg.norm(A, axis=1, keepdims=True)
+    Zs = [X[rng.permutation(N)[:m]].copy() for _ in range(Q)]
+    return X, ys, A, Zs
+
+
+def test_multioutput_mixing_gradient_is_what_autograd_gives():
+    """update_A! (single_and_multi_output_utils.jl:87-118) against torch.autograd of the data term written from the likelihoods'
+    expec_loglikelihood with the mixed moments E f_t = sum_q A_tq E f_q, Var f_t = sum_q A_tq^2 Var f_q (:24-45), local variables
+    held fixed -- for a Gaussian, a logistic (corrected ELBO) and a Student-t task."""
+    import torch
+
+    rng = np.random.default_rng(63)
+    liks = [R.GaussianLikelihood(0.2), R.LogisticLikelihood(), R.StudentTLikelihood(4.0, 0.8)]
+    X, ys, A, Zs = _mo_toy(rng, liks)
+    eta = 0.05
+    mdl = R.MOSVGP(R.Kernel("sqexponential", 3.0, 1.0), liks, Zs, A.copy(), stochastic=False, A_opt=R.Adam(eta))
+    mdl.train(X, ys, 3)  # some posterior, local variables of the last step in place
+    A0 = mdl.A.copy()
+    mu_q, var_q = mdl.lat_mean_var()
+    Mq = torch.tensor(np.stack(mu_q), dtype=torch.float64)
+    Vq = torch.tensor(np.stack(var_q), dtype=torch.float64)
+    At = torch.tensor(A0, dtype=torch.float64, requires_grad=True)
+    total = 0.0
+    for t, lik in enumerate(liks):
+        mf = At[t] @ Mq
+        vf = (At[t] ** 2) @ Vq
+        yt = torch.tensor(ys[t], dtype=torch.float64)
+        lv = mdl.local_vars[t]
+        if lik.name == "gaussian":     # gaussian.jl:82-93
+            total = total - 0.5 * (((yt - mf) ** 2).sum() + vf.sum()) / lik.sigma2
+        elif lik.name == "logistic":   # logistic.jl:73-84 (corrected: theta . mu^2)
+            th = torch.tensor(lv["theta"], dtype=torch.float64)
+            total = total + 0.5 * ((mf * yt).sum() - (th * vf).sum() - (th * mf * mf).sum())
+        else:                           # studentt.jl:103-119
+            th = torch.tensor(lv["theta"], dtype=torch.float64)
+            total = total - 0.5 * (th * (vf + mf * mf - 2.0 * mf * yt + yt * yt)).sum()
+    total.backward()
+    G = At.grad.numpy()
+    # the oracle's step: ADAM's first step from zero moments moves each entry by eta * sign(grad) (bias-corrected m / sqrt(v) = +-1), then
+    # the rows are normalised -- so compare the gradient through the restated formula directly
+    for t, lik in enumerate(liks):
+        gmu = R.grad_E_mu(lik, ys[t], mdl.local_vars[t])[0]
+        gS = R.grad_E_Sigma(lik, ys[t], mdl.local_vars[t])[0]
+        for q in range(mdl.Q):
+            others = sum(A0[t, qq] * mu_q[qq] for qq in range(mdl.Q) if qq != q)
+            dA = np.dot(gmu, mu_q[q]) - 2.0 * np.dot(gS, mu_q[q] * others) - 2.0 * A0[t, q] * np.dot(gS, mu_q[q] ** 2 + var_q[q])
+            assert dA == pytest.approx(G[t, q], rel=1e-10, abs=1e-12)
+    # and update_A! itself takes exactly that gradient: one more call moves A by ADAM(dA) and renormalises
+    import copy
+
+    st = copy.deepcopy(mdl.A_state)
+    mdl.update_A(ys)
+    opt = R.Adam(eta)
+    for t in range(len(liks)):
+        _, delta = opt.apply(st[t], G[t])
+        row = A0[t] + delta
+        assert np.allclose(mdl.A[t], row / np.linalg.norm(row), rtol=1e-12, atol=1e-14)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Register / scratch / LDS table of every kernel in libagp_hip.so, from the compiler's own remarks.
 
-    python tools/kernel_resources.py [--out profiles/r05_kernel_resources.txt] [--remarks FILE]
+    python tools/kernel_resources.py [--out profiles/r06_kernel_resources.txt] [--remarks FILE]
 
 Compiles csrc/agp_capi.hip with build()'s exact flags plus -Rpass-analysis=kernel-resource-usage (cross-compiles for gfx950
 without a GPU, ~80 s), demangles the kernel names (llvm-cxxfilt) and writes one row per kernel:
@@ -125,7 +125,7 @@ def read_table(path):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_kernel_resources.txt"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_kernel_resources.txt"))
     ap.add_argument("--remarks", default=None)
     a = ap.parse_args()
     text = open(a.remarks).read() if a.remarks else compile_remarks()

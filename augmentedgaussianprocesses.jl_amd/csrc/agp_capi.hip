@@ -1004,6 +1004,22 @@ static agp_status gemm_nt(agp_ctx* c, const T* A, int64_t lda, const T* B, int64
                           int64_t ldp, const HkArgs<T>* hk = nullptr) {
   dim3 g((unsigned)(N / TILE), (unsigned)(M / TILE));
   const HkArgs<T> hka = hk ? *hk : HkArgs<T>{};  // (EPI_HK only)
+  // round 6: 128 x 64 C tiles (k_gemm_nt_tall) for the large fp64 products -- more 64-tiles than two k-groups are used for (C5's
+  // 4096-tile kappa GEMM).  AGP_GEMM_TALL=0 / 1 forces (1: wherever the shape allows, M a multiple of 128).
+  if constexpr (EPI == EPI_STORE || EPI == EPI_KAPPA) {
+    static const int tall = []() {
+      const char* e = getenv("AGP_GEMM_TALL");
+      return e ? (e[0] == '0' ? 0 : 1) : -1;
+    }();
+    const bool big = (N / TILE) * (M / TILE) > kg2_limit();
+    if (M % (2 * TILE) == 0 && K >= BK && (tall == 1 || (tall < 0 && big && sizeof(T) == 8))) {
+      dim3 gt((unsigned)(N / TILE), (unsigned)(M / (2 * TILE)));
+      hipLaunchKernelGGL((k_gemm_nt_tall<T, EPI>), gt, dim3(NTHREADS), 0, c->stream, A, lda, B, ldb, K, tri_b, C, ldc, E, lde, p0, p1,
+                         ldp);
+      LAUNCHCHK(c);
+      return AGP_OK;
+    }
+  }
   // fewer tiles than ~1.25 waves of CUs: two k-groups per workgroup (2 waves per SIMD) instead of idle SIMD slots
   if ((N / TILE) * (M / TILE) <= kg2_limit() && K >= 4 * BK)
     hipLaunchKernelGGL((k_gemm_nt<T, EPI, 2>), g, dim3(2 * NTHREADS), 0, c->stream, A, lda, B, ldb, K, tri_b, C, ldc, E,

@@ -230,9 +230,11 @@ __global__ void k_scale_rows(const T* __restrict__ Y, int64_t ldy, int64_t p, in
 // symmetric, no row-dot); SPEC 0: everything at run time.  The specialised forms drop the unused code and its registers.
 // (SPEC 3 keeps the symmetric / diagonal logic and spilled 14 registers under the 128-VGPR cap; a K_ZZ launch is one workgroup per CU
 //  anyway, so it is compiled for two.  Round 5: the same for the general form SPEC 0 -- set-up launches, the ABI's agp_kernelmatrix,
-//  full predictive covariances --, whose fp64 instantiations carried 160 - 188 bytes of scratch per lane under that cap)
+//  full predictive covariances --, whose fp64 instantiations carried 160 - 188 bytes of scratch per lane under that cap.
+//  Round 6: the fp64 forms of the first-order kernels keep eight column slots per lane in the 4x4x4 accumulator layout and spilled 12
+//  bytes under the 128-VGPR cap: three workgroups per CU for them)
 template <typename T, int KIND, int SPEC = 0>
-__global__ __launch_bounds__(NTHREADS, ((SPEC == 3 || SPEC == 0) ? 2 : 4)) void k_kernelmatrix_mma(const T* __restrict__ X, int64_t ldx,
+__global__ __launch_bounds__(NTHREADS, ((SPEC == 3 || SPEC == 0) ? 2 : (sizeof(T) == 8 && KIND != K_SQEXP) ? 3 : 4)) void k_kernelmatrix_mma(const T* __restrict__ X, int64_t ldx,
                                                                const int64_t* __restrict__ idx, int64_t n,
                                                                const T* __restrict__ Ysc, const T* __restrict__ yng,
                                                                int64_t p, int64_t D, int Dp, const T* __restrict__ scales,
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(NTHREADS, ((SPEC == 3 || SPEC == 0) ? 2 : 4)) void 
                                                                const T* __restrict__ alpha_, T* __restrict__ part,
                                                                int64_t ldp, int64_t ctiles) {
   if (variance < T(0)) variance = scales[D];  // device-resident kernel parameters (see k_kernelmatrix)
+  constexpr bool L4 = use_mfma4<T>();  // (AGP_F64_MFMA4 builds) fp64: 4x4x4 MFMA form and its accumulator layout (see the epilogue)
   T* __restrict__ out = SPEC == 1 ? nullptr : out_;
   const int sym = SPEC == 3 ? 1 : SPEC != 0 ? 0 : sym_;  // SPEC 3 (round 4): K_ZZ of a refresh -- store only, symmetric, no row-dot
   const T* __restrict__ alpha = (SPEC == 2 || SPEC == 3) ? nullptr : alpha_;
@@ -343,26 +346,42 @@ __global__ __launch_bounds__(NTHREADS, ((SPEC == 3 || SPEC == 0) ? 2 : 4)) void 
     for (int kk = 0; kk < Dp / 4; ++kk) {
       const T a0 = pa[kk * 4], a1 = pa[16 * LDX + kk * 4];
       const T b0 = pb[kk * 4], b1 = pb[16 * LDX + kk * 4];
-      acc[0][0] = Mfma<T>::mma(a0, b0, acc[0][0]);
-      acc[0][1] = Mfma<T>::mma(a0, b1, acc[0][1]);
-      acc[1][0] = Mfma<T>::mma(a1, b0, acc[1][0]);
-      acc[1][1] = Mfma<T>::mma(a1, b1, acc[1][1]);
+      if constexpr (L4) {  // fp64: the 4-block 4x4x4 MFMA (agp_device.h, mma_slab): same operand registers, B rotated block-wise
+        const double b01 = dpp_ror<12>(b0), b02 = dpp_ror<8>(b0), b03 = dpp_ror<4>(b0);
+        const double b11 = dpp_ror<12>(b1), b12 = dpp_ror<8>(b1), b13 = dpp_ror<4>(b1);
+        acc[0][0] = mma4x4(a0, b0, b01, b02, b03, acc[0][0]);
+        acc[0][1] = mma4x4(a0, b1, b11, b12, b13, acc[0][1]);
+        acc[1][0] = mma4x4(a1, b0, b01, b02, b03, acc[1][0]);
+        acc[1][1] = mma4x4(a1, b1, b11, b12, b13, acc[1][1]);
+      } else {
+        acc[0][0] = Mfma<T>::mma(a0, b0, acc[0][0]);
+        acc[0][1] = Mfma<T>::mma(a0, b1, acc[0][1]);
+        acc[1][0] = Mfma<T>::mma(a1, b0, acc[1][0]);
+        acc[1][1] = Mfma<T>::mma(a1, b1, acc[1][1]);
+      }
     }
-    // epilogue.  Everything that depends on the column only (two columns per lane and tile) or on the row only is taken out of the
-    // element loop: PMC showed ~96 VALU instructions per kernel value with the bounds checks, the 64-bit index arithmetic and the
-    // alpha loads inside it -- the VALU, not the MFMA or the exp, bounded the streaming predictor.
-    int cl_[2];
-    bool cok[2], cout_[2];
-    T ynv[2], al[2];
+    // epilogue.  Everything that depends on the column only or on the row only is taken out of the element loop: PMC showed ~96 VALU
+    // instructions per kernel value with the bounds checks, the 64-bit index arithmetic and the alpha loads inside it -- the VALU,
+    // not the MFMA or the exp, bounded the streaming predictor.
+    // Accumulator layouts: element r of acc[mi][ni] is (row rowof(mi, r), column colof(ni, r)) of the 64 x 64 tile.  fp32 (16x16x4):
+    // four rows, one column per lane; fp64 (4x4x4, round 6): ONE row, four columns per lane (NQ = 4 column slots per ni).
+    constexpr int NQ = L4 ? 4 : 1;
+    auto rowof = [&](int mi, int r) { return wm * 32 + mi * 16 + (L4 ? g4_row(lane) : Mfma<T>::row(lane, r)); };
+    auto colof = [&](int ni, int q) { return wn * 32 + ni * 16 + (L4 ? g4_col(lane, q) : (lane & 15)); };
+    int cl_[2][NQ];
+    bool cok[2][NQ], cout_[2][NQ];
+    T ynv[2][NQ], al[2][NQ];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      cl_[ni] = wn * 32 + ni * 16 + (lane & 15);
-      const int64_t gj = j0 + cl_[ni];
-      cok[ni] = gj < p;
-      cout_[ni] = out != nullptr && gj < p_out;
-      ynv[ni] = ynb[cl_[ni]];
-      al[ni] = (alpha != nullptr && cok[ni]) ? alpha[gj] : T(0);
-    }
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        cl_[ni][q] = colof(ni, q);
+        const int64_t gj = j0 + cl_[ni][q];
+        cok[ni][q] = gj < p;
+        cout_[ni][q] = out != nullptr && gj < p_out;
+        ynv[ni][q] = ynb[cl_[ni][q]];
+        al[ni][q] = (alpha != nullptr && cok[ni][q]) ? alpha[gj] : T(0);
+      }
     if constexpr (SPEC == 1 && KIND == K_SQEXP && sizeof(T) == 8) {
       // Streaming prediction with the squared-exponential kernel in fp64 (round 6): branch-free, 21 VALU instructions per kernel value
       // (s2, d2, two clamps, the 17 of exp_mhalf, the row-dot FMA) where the general form below spends ~48 and a branch.  No masks:
@@ -370,18 +389,20 @@ __global__ __launch_bounds__(NTHREADS, ((SPEC == 3 || SPEC == 0) ? 2 : 4)) void 
       // repair of (nearly) coincident points either: the GEMM form leaves d2 an absolute error of a few ulp(|x|^2 + |y|^2), which
       // this kernel function turns into HALF that as a relative error of its value -- it is the first-order kernels below (sqrt at
       // d2 -> 0) that need the repair.  The variance is folded into alpha.
-      T alv[2];
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) alv[ni] = variance * al[ni];
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) al[ni][q] *= variance;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const T xnv = xn[wm * 32 + mi * 16 + Mfma<T>::row(lane, r)];
+          const T xnv = xn[rowof(mi, r)];  // (4x4x4 layout: the same row for every r)
+          const int q = L4 ? r : 0;
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
-            const T d2 = __builtin_fma(T(-2), acc[mi][ni][r], xnv + ynv[ni]);
-            rs[mi][r] = __builtin_fma(exp_mhalf(d2), alv[ni], rs[mi][r]);
+            const T d2 = __builtin_fma(T(-2), acc[mi][ni][r], xnv + ynv[ni][q]);
+            rs[mi][L4 ? 0 : r] = __builtin_fma(exp_mhalf(d2), al[ni][q], rs[mi][L4 ? 0 : r]);
           }
         }
       continue;
@@ -391,18 +412,19 @@ __global__ __launch_bounds__(NTHREADS, ((SPEC == 3 || SPEC == 0) ? 2 : 4)) void 
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int rl = wm * 32 + mi * 16 + Mfma<T>::row(lane, r);
+        const int rl = rowof(mi, r);
+        const int q = L4 ? r : 0;
         const int64_t gi = i0 + rl;
         const bool rok = gi < n, rout = gi < n_out;
         const T xnv = xn[rl];
         T* orow = out ? out + gi * ldo + j0 : nullptr;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          const int cl = cl_[ni];
+          const int cl = cl_[ni][q];
           const bool diag = sym && (int64_t)(rl - cl) == dgi;
           T val = T(0);
-          if (rok && cok[ni]) {
-            const T s2 = xnv + ynv[ni];
+          if (rok && cok[ni][q]) {
+            const T s2 = xnv + ynv[ni][q];
             T d2 = s2 - T(2) * acc[mi][ni][r];
             if (diag) {
               // the point against itself: the direct differences below would give exactly 0 -- but through a 32-deep rolled loop that
@@ -423,19 +445,29 @@ __global__ __launch_bounds__(NTHREADS, ((SPEC == 3 || SPEC == 0) ? 2 : 4)) void 
           } else if (diag) {
             val = T(1);
           }
-          if (cout_[ni] && rout) orow[cl] = val;
-          rs[mi][r] += val * al[ni];
+          if (cout_[ni][q] && rout) orow[cl] = val;
+          rs[mi][L4 ? 0 : r] += val * al[ni][q];
         }
       }
   }
   if (alpha) {
+    if constexpr (L4) {  // one row per lane and mi: the four lanes that share it differ in lane & 3
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const T s = row16_sum(rs[mi][r]);
-        if ((lane & 15) == 0) red[wn * TILE + wm * 32 + mi * 16 + Mfma<T>::row(lane, r)] = s;
+      for (int mi = 0; mi < 2; ++mi) {
+        T sv = rs[mi][0];
+        sv += __shfl_xor(sv, 1);
+        sv += __shfl_xor(sv, 2);
+        if ((lane & 3) == 0) red[wn * TILE + wm * 32 + mi * 16 + g4_row(lane)] = sv;
       }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const T sv = row16_sum(rs[mi][r]);
+          if ((lane & 15) == 0) red[wn * TILE + wm * 32 + mi * 16 + Mfma<T>::row(lane, r)] = sv;
+        }
+    }
     __syncthreads();
     if (tid < TILE && i0 + tid < n_out) part[blockIdx.x * ldp + i0 + tid] = red[tid] + red[TILE + tid];
   }

@@ -123,6 +123,47 @@ __global__ __launch_bounds__(NTHREADS * KG) void k_gemm_nt(const T* __restrict__
   }
 }
 
+// The same product on 128 x 64 C tiles (gemm_tile_tall, agp_device.h): EPI_STORE and EPI_KAPPA only, M a multiple of 128.
+// grid = (N / 64, M / 128).  The K~ partial slices keep their layout (slice = 2 bn + wn, one value per row).
+template <typename T, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void k_gemm_nt_tall(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
+                                                              int64_t K, int tri_b, T* __restrict__ C, int64_t ldc,
+                                                              const T* __restrict__ E, int64_t lde, T* __restrict__ part0,
+                                                              T* __restrict__ part1, int64_t ldp) {
+  static_assert(EPI == EPI_STORE || EPI == EPI_KAPPA, "tall tiles: plain store and the kappa epilogue");
+  __shared__ __attribute__((aligned(16))) T smem[TallSlab<T>::SMEM];
+  int64_t bn, bm;
+  banded_tile(xcd_contiguous((int64_t)blockIdx.x + (int64_t)blockIdx.y * gridDim.x, (int64_t)gridDim.x * gridDim.y),
+              (int64_t)gridDim.x, (int64_t)gridDim.y, bm, bn);
+  const int64_t r0 = bm * 2 * TILE, c0 = bn * TILE;
+  AccTall<T> acc;
+  acc.zero();
+  const int64_t kEnd = tri_b ? ((c0 + TILE) < K ? (c0 + TILE) : K) : K;
+  gemm_tile_tall<T>(A + r0 * lda, lda, B + c0 * ldb, ldb, 0, kEnd, acc, smem);
+  acc_foreach_tall<T>(acc, [&](int r, int c, T val) {
+    C[(r0 + r) * ldc + c0 + c] = val;
+    if (EPI == EPI_KAPPA && part1) part1[(r0 + r) * ldc + c0 + c] = val;
+  });
+  if (EPI == EPI_KAPPA) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    T* p0 = part0 + (bn * 2 + wn) * ldp;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * 64 + mi * 16 + Mfma<T>::row(lane, r);
+        T s0 = T(0);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int col = wn * 32 + ni * 16 + (lane & 15);
+          s0 += acc.a[mi][ni][r] * E[(r0 + row) * lde + c0 + col];  // (the order of acc_row_reduce: ni ascending, then the 16 lanes)
+        }
+        s0 = row16_sum(s0);
+        if ((lane & 15) == 0) p0[r0 + row] = s0;
+      }
+  }
+}
+
 // C = E - A B^T for a result known to be SYMMETRIC (A = K^-1 - K^-1 (Sigma K^-1): predictions.jl:38 and the hyper-gradient's G_K):
 // only the nt (nt + 1) / 2 lower tiles are formed -- half the flops of k_gemm_nt<EPI_EMINUS> -- and mirrored on the way out
 // (diagonal tiles: the lower half is the truth).  grid = nt (nt + 1) / 2, row-major triangle order.

@@ -82,12 +82,14 @@ def test_kernel_exponential_over_the_whole_argument_range(mods, kind):
     arg = {0: lambda t: t * t / 2, 1: lambda t: 5 ** 0.5 * t, 2: lambda t: 3 ** 0.5 * t, 3: lambda t: t}[kind]
     for g, w, t in zip(got, want, d):
         wf = float(w)
-        if wf > 1e-290:
+        if wf >= 1e-290:  # relative
             worst = max(worst, abs(float((mpf(float(g)) - w) / w)) / (3e-14 + 8 * 2.2e-16 * arg(t)))
-        elif wf == 0.0 or wf < 1e-323:
+        elif wf == 0.0:  # below half the smallest denormal: exactly zero
             assert g == 0.0, (t, g)
-        else:  # denormal range: absolute
-            assert abs(g - wf) <= 1e-300, (t, g, wf)
+        else:
+            # the exponential itself is (nearly) denormal here: it carries few bits, and the Matern kernels multiply it by a
+            # polynomial of ~1e5 afterwards -- absolute, at the size of that product's last bit
+            assert abs(g - wf) <= 1e-9 * wf + 1e-315, (t, g, wf)
     assert worst <= 1.0, worst  # (in units of the tolerance above)
     assert got[0] == 1.0
     L.agp_ctx_destroy(ctx)
@@ -224,7 +226,8 @@ def test_side_stream_objective_is_bitwise_the_inline_one(mods, m, B, EVAL, dtype
     def make():
         mdl = AGP.SVGP(AGP.SqExponentialKernel() @ AGP.ScaleTransform(3.0), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z,
                        optimiser=False, T=T)
-        AGP.train_(mdl, X, y, 1, idx_stream=[idx[0]])  # binds the data, creates the handle
+        mdl._ensure_handle(max(EVAL, B))  # (capacity for the in-line evaluation on EVAL points)
+        AGP.train_(mdl, X, y, 1, idx_stream=[idx[0]])  # binds the data
         return mdl
 
     def steps(mdl, i0, i1):

@@ -3201,7 +3201,10 @@ struct Svgp : SvgpBase {
         // then waits for (C4, 8 latents: 1.34 -> 1.21 ms).
         int lo = 0, hi = 0;
         HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        const int pr = nl > 1 ? hi : lo;
+        int pr = nl > 1 ? hi : lo;
+#ifdef AGP_DEV_KNOBS  // (development builds: A/B of the look-ahead's priority, round 6 -- C3 experiment)
+        if (const char* e = getenv("AGP_DEV_PF_PRIO")) pr = e[0] == 'h' ? hi : e[0] == 'n' ? 0 : lo;
+#endif
         HIPCHK(ctx, hipStreamCreateWithPriority(&pf_stream, hipStreamNonBlocking, pr));
       }
       HIPCHK(ctx, hipEventCreateWithFlags(&pf_done, hipEventDisableTiming));

@@ -751,12 +751,13 @@ class SideObjective:
     training stream goes straight on to its next steps; the steps are bound by one workgroup's dependent chain while ~250 CUs
     idle, which is where the evaluation runs.  `fetch` returns the value (tickets in any order).
 
-    The values are bit-identical to `ELBO(model, X[idx], y[idx], rho=rho)` evaluated in line at the same point of the training
-    sequence (tests/test_gpu_round6.py).  Models whose kernels / inducing points move (hyper-parameter optimisation on) are
+    The values equal `ELBO(model, X[idx], y[idx], rho=rho)` evaluated in line at the same point of the training sequence to a few
+    ulp (the two handles form Sigma = Xa' Xa by different kernels), and taking the snapshot leaves the training trajectory
+    bit-identical (tests/test_gpu_round6.py).  Models whose kernels / inducing points move (hyper-parameter optimisation on) are
     refused: the shadow's K_ZZ is factored once.  Reference: the monitoring this replaces is `objective(model, state, y)` in
     train!'s progress reporting, src/training/training.jl:71-90, and the ELBO itself, src/inference/analyticVI.jl:255-274."""
 
-    def __init__(self, model: SVGP, max_eval_batch: int, ring: int = 4):
+    def __init__(self, model: SVGP, max_eval_batch: int, ring: int = 4, priority: Optional[int] = None):
         if isinstance(model, MOSVGP) or model.n_latent != 1:
             raise NotImplementedError("SideObjective: single-latent SVGP models")
         if model.k_opt is not None or model.z_opt is not None:
@@ -766,7 +767,9 @@ class SideObjective:
         torch = _torch()
         self.model = model
         dev = model._dev()
-        self.stream = torch.cuda.Stream(device=dev)
+        # priority of the side stream (None: the default): a check is ~34 GF of MFMA work at C2; whether it runs NEXT TO the training
+        # steps or between them is the dispatcher's decision, see DESIGN.md section 10
+        self.stream = torch.cuda.Stream(device=dev) if priority is None else torch.cuda.Stream(device=dev, priority=int(priority))
         import copy
 
         with torch.cuda.stream(self.stream):  # (the shadow's context takes torch's current stream: the side stream)

@@ -180,9 +180,9 @@ def build_model(AGP, cfg, ell, Z, B_local, rank, world, dev_index, mode):
 
 
 def _pmc_traffic(cfg_name, kernel_name, step_inst):
-    """traffic (bytes per launch) of `kernel_name` from profiles/r05_<cfg>_pmc_hbm_bytes.json (older rounds' files as fall-backs):
+    """traffic (bytes per launch) of `kernel_name` from profiles/r06_<cfg>_pmc_hbm_bytes.json (older rounds' files as fall-backs):
     -> {"traffic": .., "traffic_source": .., "traffic_kernel": ..} or {} when no file lists the kernel"""
-    names = [f"r05_{cfg_name}_pmc_hbm_bytes.json"]
+    names = [f"r06_{cfg_name}_pmc_hbm_bytes.json", f"r05_{cfg_name}_pmc_hbm_bytes.json"]
     names += {"c2": ["r04_pmc_hbm_bytes.json", "r03_pmc_hbm_bytes.json"], "c3": ["r04_c3_pmc_hbm_bytes.json", "r03_c3_pmc_hbm_bytes.json"],
               "c5": ["r02_c5_pmc_hbm_bytes.json"]}.get(cfg_name, [])
     # rocprofv3 prints every template argument: match on the kernel's name and its leading arguments
@@ -771,7 +771,7 @@ def main():
                 "algorithmic_flops_per_launch": fl, "achieved": round(fl / us / 1e6, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(fl / us / 1e6 / peak, 4),
                 "iteration": "no host synchronisation inside the iteration"
-                             + (" (17 kernels back to back, profiles/r05_c2_hyper_timeline.txt)" if a.config == "c2" else ""),
+                             + (" (17 kernels back to back, profiles/r06_c2_hyper_timeline.txt)" if a.config == "c2" else ""),
                 # the GEMM-shaped launches of one iteration (round 4: seven, round 3: nine + the symmetric Apred product) with the
                 # flops they execute against what a dense 2 n^3-style count credits them (triangular operands, symmetric results)
                 "products": _hyper_products(mpad, (B + 63) // 64 * 64)}
@@ -871,11 +871,12 @@ def main():
         elbo_sync = os.environ.get("AGP_BENCH_ELBO_SYNC") == "1"
         # round 6: the checks run NEXT TO the training stream (agp_amd.SideObjective: a snapshot of (eta1, eta2) by two device
         # copies on the training stream, the evaluation -- kernel matrices of the 8192 points, local update, factorisation of -2 eta2
-        # with its inverse, the ELBO's reductions -- on a side stream with a shadow handle of its own, bit-identical values,
+        # with its inverse, the ELBO's reductions -- on a side stream with a shadow handle of its own, values equal to a few ulp,
         # tests/test_gpu_round6.py).  In line a check cost the loop 0.87 ms between two 0.31 ms steps, 190 times.
         # AGP_BENCH_ELBO_INLINE=1 restores the in-line enqueued evaluation of rounds 4-5.
         elbo_side = (not elbo_sync) and os.environ.get("AGP_BENCH_ELBO_INLINE") != "1"
-        side = AGP.SideObjective(model2, EVAL, ring=4) if elbo_side else None
+        side_prio = os.environ.get("AGP_BENCH_SIDE_PRIORITY")  # (development: -1 = high, 0 = normal; unset = the default stream priority)
+        side = AGP.SideObjective(model2, EVAL, ring=4, priority=None if side_prio is None else int(side_prio)) if elbo_side else None
         tk, pending_tk, rdy = C.c_int32(), None, C.c_int32()
         while it < max_it and (hit["raw"] is None or hit["smoothed"] is None or hit["reach"] is None) and \
                 (time.perf_counter() - ts) < t_cap:
@@ -929,7 +930,7 @@ def main():
                                 "when |ELBO_t - ELBO_{t-10}| / |ELBO_t| < 1e-4 for 3 consecutive checks; wall-clock includes the "
                                 f"ELBO evaluations; null = not reached within {it} iterations / {t_cap:.0f} s"
                                 + ("" if elbo_sync else "; evaluations " + ("on a side stream from a snapshot of (eta1, eta2) "
-                                   "(agp_amd.SideObjective, bit-identical values)" if elbo_side else "enqueued in the training stream")
+                                   "(agp_amd.SideObjective)" if elbo_side else "enqueued in the training stream")
                                    + " and read one check later: reported seconds = when the host has the deciding value, "
                                    "reported iterations = the iteration that value belongs to"))
         out["elbo_checks"] = "side stream (SideObjective)" if elbo_side else ("synchronous" if elbo_sync else "in-line, enqueued")

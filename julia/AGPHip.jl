@@ -36,6 +36,7 @@ using LinearAlgebra
 using StatsBase: sample, Weights
 using Random
 using Optimisers
+import ProgressMeter                      # (a dependency of the reference: train!'s progress reporting, training.jl:46,71-90)
 const AGP = AugmentedGaussianProcesses
 
 import AugmentedGaussianProcesses: train!, predict_f, predict_y, proba_y, ELBO, objective
@@ -469,7 +470,28 @@ function train!(hm::HipModel{T}, X::AbstractArray, y, iterations::Int=100; callb
         end
         return device_indices(idx)
     end
+    if AGP.verbose(model) > 0   # training.jl:35-38
+        @info "Starting training $model with $N samples, $(size(hm.Xd, 1)) features and $(length(model.f)) latent GP" *
+              (length(model.f) > 1 ? "s" : "")
+    end
     local_iter = 1
+    # progress reporting of the reference (training.jl:46,71-90): ProgressMeter with (:iter, :ELBO); the ELBO is
+    # `objective(model, state, y)` on the kernel matrices / local variables of the step just taken -- verbose == 2: every 10th
+    # iteration, verbose > 2: every iteration.  On the device the value is ENQUEUED behind the step (agp_svgp_elbo_enqueue) and shown
+    # one report later, so that reporting never makes the host wait for the stream inside the loop.
+    prog = AGP.verbose(model) > 1 ? ProgressMeter.Progress(iterations; dt=0.2, desc="Training Progress: ") : nothing
+    pending_elbo = nothing   # (ticket, iteration it belongs to)
+    function report(it)
+        prog === nothing && return
+        (AGP.verbose(model) > 2 || it % 10 == 0) || return
+        tk = objective_enqueue(hm)
+        if pending_elbo !== nothing
+            elbo = objective_fetch(hm, pending_elbo[1])
+            AGP.verbose(model) == 2 && ProgressMeter.update!(prog, pending_elbo[2] - 1)
+            ProgressMeter.next!(prog; showvalues=[(:iter, pending_elbo[2]), (:ELBO, elbo)])
+        end
+        pending_elbo = (tk, it)
+    end
     idd = draw(1)
     while true
         stepped = false   # this iteration's variational update has been enqueued (the device's own counters have moved on)
@@ -488,6 +510,7 @@ function train!(hm::HipModel{T}, X::AbstractArray, y, iterations::Int=100; callb
         (nxt === nothing || hyper_now) || prefetch!(hm, nxt)
         callback === nothing || callback(hm, hm, AGP.n_iter(model))
         hyper_now && update_hyperparameters!(hm)
+        report(local_iter)
         local_iter += 1
         inf.n_iter += 1
         (local_iter <= iterations) || break
@@ -508,6 +531,7 @@ function train!(hm::HipModel{T}, X::AbstractArray, y, iterations::Int=100; callb
             end
         end
     end
+    pending_elbo === nothing || objective_fetch(hm, pending_elbo[1])   # (close the last report's ticket)
     if AGP.verbose(model) > 0   # training.jl:103-105
         @info "Training ended after $(local_iter - 1) iterations. Total number of iterations $(AGP.n_iter(model))"
     end
@@ -555,6 +579,81 @@ function objective_fetch(hm::HipModel, ticket::Integer; wait::Bool=true)
                         hm.h, ticket, wait ? 1 : 0, out, ready))
     return ready[] == 1 ? out[] : nothing
 end
+
+"""
+    task_graph_fallbacks(hm) -> Int
+
+How many factorisation launches of this model's context lost a tile dependency and were re-run by their in-stream fallback since the
+context was created (`agp_ctx_task_graph_fallbacks`, round 6): 0 on a GPU the process has to itself.  Synchronises the stream.
+"""
+function task_graph_fallbacks(hm::HipModel)
+    n = Ref{Int64}(0)
+    check(hm.ctx, ccall((:agp_ctx_task_graph_fallbacks, libagp), Int32, (Ptr{Cvoid}, Ref{Int64}), hm.ctx, n))
+    return Int(n[])
+end
+
+"""
+    SideObjective(hm::HipModel, max_eval_batch; ring=4)
+    ticket = enqueue!(side, idx::ROCVector{Int64}, ρ)     # snapshot of (η₁, η₂) now, ELBO(model, X[idx], y[idx]) on the side stream
+    value  = fetch(side, ticket; wait=true)
+
+Convergence monitoring NEXT TO the training stream (round 6; the Python mirror's `agp_amd.SideObjective`, same three ABI calls): a
+shadow `HipModel` of a deep copy of the reference model on a HIP stream and context of its own, its K_ZZ factored once; `enqueue!`
+copies (η₁, η₂) out of the training handle on the training stream (`agp_svgp_get_state`, two device copies), makes the side stream wait
+for them (`AMDGPU.HIP` event), installs them there (`agp_svgp_set_state`) and enqueues the evaluation (`agp_svgp_elbo_enqueue`, fresh
+local variables: `ELBO(model, X, y)` of src/functions/ELBO.jl:32-47 with ρ explicit).  Replaces the in-line `objective(model, state, y)`
+of `train!`'s progress reporting (src/training/training.jl:71-90) where the host must not wait and the training stream must not carry
+the evaluation.  Kernels and inducing points must be fixed (`optimiser=false, Zoptimiser=false`): the shadow's K_ZZ is factored once.
+The values equal the in-line evaluation's to a few ulp; the training trajectory is bit-identical with and without the snapshots.
+"""
+mutable struct SideObjective{T}
+    hm::HipModel{T}
+    shadow::HipModel{T}
+    stream::AMDGPU.HIPStream
+    ring::Vector{Tuple{ROCVector{T},ROCMatrix{T},AMDGPU.HIP.HIPEvent,AMDGPU.HIP.HIPEvent}}
+    n::Int
+end
+
+function SideObjective(hm::HipModel{T}, max_eval_batch::Int; ring::Int=4) where {T}
+    (length(hm.model.f) == 1 && !is_mo(hm)) || error("SideObjective: single-latent SVGP models")
+    all(gp -> AGP.opt(gp) === nothing && AGP.Zopt(gp) === nothing, hm.model.f) ||
+        error("SideObjective: kernels and inducing points must be fixed (optimiser=false, Zoptimiser=false)")
+    hm.h != C_NULL || error("SideObjective: the model has no device state yet")
+    stream = AMDGPU.HIPStream()
+    shadow = HipModel(deepcopy(hm.model))
+    AMDGPU.stream!(stream) do                                  # the shadow's context takes AMDGPU.jl's current stream: the side stream
+        shadow.X, shadow.y, shadow.N = hm.X, hm.y, hm.N        # (the same device data: read-only on both sides)
+        ensure_handle!(shadow, max_eval_batch)
+        check(shadow.ctx, ccall((:agp_svgp_refresh_K, libagp), Int32, (Ptr{Cvoid},), shadow.h))
+    end
+    AMDGPU.synchronize(stream)
+    m = AGP.dim(hm.model.f[1])
+    slots = [(ROCVector{T}(undef, m), ROCMatrix{T}(undef, m, m), AMDGPU.HIP.HIPEvent(stream), AMDGPU.HIP.HIPEvent(stream)) for _ in 1:ring]
+    return SideObjective{T}(hm, shadow, stream, slots, 0)
+end
+
+function enqueue!(side::SideObjective{T}, idx::ROCVector{Int64}, ρ::Real) where {T}
+    hm, sh = side.hm, side.shadow
+    e1, e2, ev_snap, ev_used = side.ring[side.n % length(side.ring) + 1]
+    main = AMDGPU.stream()
+    side.n >= length(side.ring) && AMDGPU.HIP.wait(ev_used, main)   # the side stream has installed what this slot held
+    check(hm.ctx, ccall((:agp_svgp_get_state, libagp), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                        hm.h, 0, C_NULL, C_NULL, pointer(e1), pointer(e2)))
+    AMDGPU.HIP.record(ev_snap, main)
+    tk = Ref{Int32}()
+    AMDGPU.stream!(side.stream) do
+        AMDGPU.HIP.wait(ev_snap, side.stream)
+        check(sh.ctx, ccall((:agp_svgp_set_state, libagp), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}), sh.h, 0, pointer(e1), pointer(e2)))
+        AMDGPU.HIP.record(ev_used, side.stream)
+        check(sh.ctx, ccall((:agp_svgp_elbo_enqueue, libagp), Int32,
+                            (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int64, Float64, Int32, Ref{Int32}),
+                            sh.h, pointer(hm.X), size(hm.X, 1), pointer(hm.y), pointer(idx), length(idx), Float64(ρ), 1, tk))
+    end
+    side.n += 1
+    return tk[]
+end
+
+Base.fetch(side::SideObjective, ticket::Integer; wait::Bool=true) = objective_fetch(side.shadow, ticket; wait)
 
 # external ELBO(model, X, y) (src/functions/ELBO.jl:28-47): kernel matrices recomputed on (X, y), fresh local variables, one local
 # update.  The reference keeps ρ = N/B of the last train! here (Appendix A Q13); pass ρ = 1 for the properly scaled value.

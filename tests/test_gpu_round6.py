@@ -207,11 +207,14 @@ def test_reloaded_multioutput_model_keeps_optimising_its_mixing_weights(mods, tm
 
 
 @pytest.mark.parametrize("m,B,EVAL,dtype", [(64, 128, 512, "f64"), (1024, 1024, 2048, "f64"), (256, 256, 1024, "f32")])
-def test_side_stream_objective_is_bitwise_the_inline_one(mods, m, B, EVAL, dtype):
+def test_side_stream_objective_equals_the_inline_one(mods, m, B, EVAL, dtype):
     """SideObjective (round 6): the ELBO check of a training loop evaluated on a side stream from a snapshot of (eta1, eta2), next to
     the steps that follow, against agp_svgp_elbo (fresh local variables) evaluated in line on the training handle at the same
-    points of the same run -- every value bit-identical, the trajectories bit-identical, and the side evaluations really in flight
-    while training continues (tickets fetched two checks later)."""
+    points of the same run.  The TRAJECTORIES are bit-identical (the snapshot perturbs nothing); the VALUES agree to rounding -- a few
+    ulp, not bitwise: the shadow handle forms Sigma = Xa' Xa with the product workgroups inside its factorisation launch
+    (agp_svgp_set_state -> refactor), the in-line evaluation on a handle in the middle of training with the stand-alone balanced
+    product, and the two add in different orders.  The side evaluations are really in flight while training continues (tickets
+    fetched two checks later)."""
     AGP, R, capi, torch = mods
     L = capi.lib()
     rng = np.random.default_rng(21)
@@ -260,7 +263,8 @@ def test_side_stream_objective_is_bitwise_the_inline_one(mods, m, B, EVAL, dtype
             got.append(side.fetch(tickets.pop(0)))
     got += [side.fetch(t) for t in tickets]
     assert len(got) == len(inline) and all(np.isfinite(got))
-    assert [np.float64(v).tobytes() for v in got] == [np.float64(v).tobytes() for v in inline], (got, inline)
+    tol = 1e-13 if dtype == "f64" else 1e-6
+    assert np.allclose(got, inline, rtol=tol, atol=0), (got, inline)
     assert np.array_equal(ma.get_state(0)[3], mb.get_state(0)[3])
     # and the values are the oracle's ELBO of that posterior (rtol: fp32 states are compared in double)
     assert inline[-1] < 0 and abs(inline[-1] - inline[-2]) < abs(inline[0])

@@ -2,7 +2,7 @@
 
   python tools/pmc_traffic.py collect [config] [tag]  # two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over a short bench.py run
   python tools/pmc_traffic.py parse   [config] [tag]  # -> gpurun_out/pmc_<tag>/<tag>_pmc_hbm_bytes.json  (copy it to profiles/)
-  config: c2 (default) | c3 | c4 | c5 (bench.py --config) | hyper (tools/prof_hyper.py: the hyper-on iteration); tag: default r05_<config>
+  config: c2 (default) | c3 | c4 | c5 (bench.py --config) | hyper (tools/prof_hyper.py: the hyper-on iteration); tag: default r06_<config>
 
 Units / corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): the counters are in KB and
 FETCH_SIZE reports half of the bytes actually fetched on gfx950, so bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  The
@@ -19,7 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = sys.argv[2] if len(sys.argv) > 2 else "c2"
-TAG = sys.argv[3] if len(sys.argv) > 3 else f"r05_{CFG}"
+TAG = sys.argv[3] if len(sys.argv) > 3 else f"r06_{CFG}"
 OUT = os.path.join(ROOT, "gpurun_out", f"pmc_{TAG}")
 CMD = ["python", os.path.join(ROOT, "bench.py"), "--config", CFG, "--no-cpu-baseline", "--no-elbo-tol", "--steps",
        "10" if CFG == "c5" else "40", "--warmup", "4" if CFG == "c5" else "10"]

@@ -40,5 +40,16 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
     except Exception as e:  # noqa: BLE001
         bad += 1
         note = "  FAILED " + str(e)[:100]
-    print(f"model {rep}: {time.time() - t0:.2f} s{note}", flush=True)
+    extra = ""
+    if os.environ.get("AGP_STRESS_DIAG") == "1":  # a -DAGP_DEBUG_PTRS build: which bounded wait of the task graph ran out, if any
+        import ctypes as C
+
+        from agp_amd import capi
+
+        dbg = C.CDLL(capi.LIB_PATH)
+        dbg.agp_debug_dag_diag.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+        out = (C.c_ulonglong * 8)()
+        dbg.agp_debug_dag_diag(ma._ctx, out)
+        extra = f"  [diag: expired waits {int(out[0])}, kind {int(out[4])}, workgroup {int(out[3])}, chain release never came {int(out[5])}]"
+    print(f"model {rep}: {time.time() - t0:.2f} s{note}{extra}", flush=True)
 print("bad", bad)

@@ -17,6 +17,9 @@ from agp_amd import capi  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 m, B, D, N, steps = 1024, 2048, 16, 50000, 200
+if len(sys.argv) > 2:  # round 6: any shape, e.g. `... split_which_wait.py 10 2048 2048 32 20000` = the C3 soak's shape
+    m, B, D, steps = (int(v) for v in sys.argv[2:6])
+    N = 200000
 rng = np.random.default_rng(0)
 X = rng.random((N, D))
 y = np.sin(X @ rng.standard_normal(D)) + 0.1 * rng.standard_normal(N)
@@ -38,6 +41,9 @@ for rep in range(reps):
         L.agp_svgp_prefetch(h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(ia[(j + 1) % 32].data_ptr()), B)
     out = (C.c_ulonglong * 8)()
     assert dbg.agp_debug_dag_diag(model._ctx, out) == 0
+    nfb = C.c_int64(0)
+    L.agp_ctx_task_graph_fallbacks(model._ctx, C.byref(nfb))
+    print(f"run {rep}: {steps} steps, task_graph_fallbacks {nfb.value}, expired waits {int(out[0])}, chain release never came {int(out[5])}", flush=True)
     if out[0] or out[5]:
         fi = (int(out[1]) - int(out[6])) // 4 // int(out[7]) if out[1] else -1
         ntile = (nt + ne) * nt

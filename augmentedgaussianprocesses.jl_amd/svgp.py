@@ -752,8 +752,8 @@ class SideObjective:
     idle, which is where the evaluation runs.  `fetch` returns the value (tickets in any order).
 
     The values equal `ELBO(model, X[idx], y[idx], rho=rho)` evaluated in line at the same point of the training sequence to a few
-    ulp (the two handles form Sigma = Xa' Xa by different kernels), and taking the snapshot leaves the training trajectory
-    bit-identical (tests/test_gpu_round6.py).  Models whose kernels / inducing points move (hyper-parameter optimisation on) are
+    ulp (the two handles form Sigma = Xa' Xa by different kernels); the training trajectory with snapshots equals the one without to
+    rounding (a snapshot takes the pending natural-gradient step with the stand-alone kernel; tests/test_gpu_round6.py).  Models whose kernels / inducing points move (hyper-parameter optimisation on) are
     refused: the shadow's K_ZZ is factored once.  Reference: the monitoring this replaces is `objective(model, state, y)` in
     train!'s progress reporting, src/training/training.jl:71-90, and the ELBO itself, src/inference/analyticVI.jl:255-274."""
 

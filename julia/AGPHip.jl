@@ -604,7 +604,7 @@ for them (`AMDGPU.HIP` event), installs them there (`agp_svgp_set_state`) and en
 local variables: `ELBO(model, X, y)` of src/functions/ELBO.jl:32-47 with ρ explicit).  Replaces the in-line `objective(model, state, y)`
 of `train!`'s progress reporting (src/training/training.jl:71-90) where the host must not wait and the training stream must not carry
 the evaluation.  Kernels and inducing points must be fixed (`optimiser=false, Zoptimiser=false`): the shadow's K_ZZ is factored once.
-The values equal the in-line evaluation's to a few ulp; the training trajectory is bit-identical with and without the snapshots.
+The values equal the in-line evaluation's to a few ulp; the training trajectory with snapshots equals the one without to rounding.
 """
 mutable struct SideObjective{T}
     hm::HipModel{T}

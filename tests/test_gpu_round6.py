@@ -210,8 +210,7 @@ def test_reloaded_multioutput_model_keeps_optimising_its_mixing_weights(mods, tm
 def test_side_stream_objective_equals_the_inline_one(mods, m, B, EVAL, dtype):
     """SideObjective (round 6): the ELBO check of a training loop evaluated on a side stream from a snapshot of (eta1, eta2), next to
     the steps that follow, against agp_svgp_elbo (fresh local variables) evaluated in line on the training handle at the same
-    points of the same run.  The TRAJECTORIES are bit-identical (the snapshot perturbs nothing); the VALUES agree to rounding -- a few
-    ulp, not bitwise: the shadow handle forms Sigma = Xa' Xa with the product workgroups inside its factorisation launch
+    points of the same run.  Trajectories and values agree to rounding -- the values to a few ulp, not bitwise: the shadow handle forms Sigma = Xa' Xa with the product workgroups inside its factorisation launch
     (agp_svgp_set_state -> refactor), the in-line evaluation on a handle in the middle of training with the stand-alone balanced
     product, and the two add in different orders.  The side evaluations are really in flight while training continues (tickets
     fetched two checks later)."""
@@ -263,9 +262,17 @@ def test_side_stream_objective_equals_the_inline_one(mods, m, B, EVAL, dtype):
             got.append(side.fetch(tickets.pop(0)))
     got += [side.fetch(t) for t in tickets]
     assert len(got) == len(inline) and all(np.isfinite(got))
-    tol = 1e-13 if dtype == "f64" else 1e-6
-    assert np.allclose(got, inline, rtol=tol, atol=0), (got, inline)
-    assert np.array_equal(ma.get_state(0)[3], mb.get_state(0)[3])
+    # (the ELBO is a difference of terms of size ~N: the agreement is relative to those, not to a value that happens to be near zero)
+    tol = 1e-12 if dtype == "f64" else 1e-5
+    assert np.allclose(got, inline, rtol=tol, atol=tol * N), (got, inline)
+    # the trajectories of the three runs -- in-line checks (A), side-stream checks (B), no checks at all (C) -- agree to rounding: a
+    # check takes the pending natural-gradient step with the stand-alone kernel instead of the next launch's prologue, and an in-line
+    # evaluation also leaves the factorisation of -2 eta2 with its inverse behind for the next step (other summation orders)
+    mc = make()
+    steps(mc, 1, iters)
+    e2b, e2c, e2a = mb.get_state(0)[3], mc.get_state(0)[3], ma.get_state(0)[3]
+    tolt = (1e-9 if dtype == "f64" else 1e-3) * np.max(np.abs(e2c))
+    assert np.max(np.abs(e2b - e2c)) <= tolt and np.max(np.abs(e2a - e2c)) <= tolt
     # and the values are the oracle's ELBO of that posterior (rtol: fp32 states are compared in double)
     assert inline[-1] < 0 and abs(inline[-1] - inline[-2]) < abs(inline[0])
 

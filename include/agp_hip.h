@@ -17,7 +17,7 @@
  *   - work is enqueued asynchronously on the ctx stream; calls that return host scalars or a
  *     data-dependent status (refresh_K, elbo, check_status, ctx_sync) synchronise that stream.
  *
- * Environment (all the library reads; 16 variables, each read once per process unless said otherwise).  The first eight switch a
+ * Environment (all the library reads; 17 variables, each read once per process unless said otherwise).  The first eight switch a
  * default path off for the FALLBACK that also exists on its own -- the GPU suite is run once with each of them, AGP_CHAIN_SPLIT both
  * ways (tools/suite_with_fallbacks.sh, profiles/r05_fallback_suites.txt); AGP_CHOL_GROUP, AGP_CHOL_LOOKAHEAD and the test hook
  * AGP_DAG_TEST_ABORT are exercised by tests of their own.  The A/B levers of earlier rounds are gone (docs/DESIGN_LOG.md has their numbers).
@@ -36,6 +36,8 @@
  *   AGP_HYPER_GK_FUSED=0      hyper-gradient with kappa' H and K^-1 Sigma K^-1 (the form of handles without a prologue launch:
  *                             several latents, batch-sharded, online, stale-K) instead of the one product C (Sigma K^-1)
  *   AGP_SPLIT_MERGED=0        batch-parallel step: eta step and row statistics as kernels of their own (k_eta2_from_packed)
+ *   AGP_GEMM_TALL=0|1         (round 6) never / wherever the shape allows: the kappa-type products on 128 x 64 C tiles (k_gemm_nt_tall) instead of
+ *                             64 x 64 ones (default: fp64 products of more than 1100 64-tiles, i.e. C5's kappa GEMM)
  *   AGP_CHOL_GROUP=n          block columns per group of the blocked factorisation beyond the task graph (default 8; 1 = per column)
  *   AGP_CHOL_LOOKAHEAD=0      ... without its side stream
  *   AGP_DAG_TEST_ABORT=1      test hook: every task-graph launch of a CAVI step is treated as having lost a dependency (the in-stream

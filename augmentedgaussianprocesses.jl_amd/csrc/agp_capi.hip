@@ -1315,6 +1315,7 @@ struct Svgp : SvgpBase {
     const T* C_kap = nullptr;  // the kappa buffer it was formed from
     T* apred = nullptr;   // K^-1 mu
     bool K_stale = true, post_valid = false, pred_valid = false, predvar_valid = false, kappa_valid = false;
+    bool kappa_eval = false;  // kappa / Knm / pk hold the kernel matrices of the last FRESH evaluation batch (ev_x ..., round 6)
     bool keep_last = false;  // this step reuses kappa / K~ of the previous full-batch step
     bool via_inverse = false;  // this step gets W, v from the available inverse factor instead of a new factorisation
     // hyper-parameter optimiser state (ADAM): kernel parameters on the host, Z on the device
@@ -1583,6 +1584,15 @@ struct Svgp : SvgpBase {
   }
   // last step
   const void* x_last = nullptr;
+  // identity of the batch of the last fresh evaluation (ELBO(model, X, y), ELBO.jl:32-47) whose kappa is still in the buffers: a
+  // handle that only evaluates -- the shadow handle of a SideObjective, same points every check, kernels and Z fixed -- recomputes
+  // neither K_nm nor kappa = K_nm K^-1 (17 GF at 8192 x 1024) per check.  Same contract as the full-batch kappa cache: pointer
+  // identity; a host that rewrites X / idx in place says so (agp_svgp_invalidate_data).  Any training step, K refresh, set_Z /
+  // set_kernel clears it.
+  const void* ev_x = nullptr;
+  const int64_t* ev_idx = nullptr;
+  int64_t ev_B = 0, ev_ldx = 0;
+  bool eval_cache_ok = false;
   const void* y_last = nullptr;
   const int64_t* idx_last = nullptr;
   int64_t B_last = 0, ldx_last = 0;
@@ -1826,7 +1836,7 @@ struct Svgp : SvgpBase {
     g.k.has_transform = k->has_transform != 0 || k->ard != 0;
     for (int64_t d = 0; d < D; ++d) g.k.scales[d] = k->ard ? k->ard_scales_host[d] : k->scale;
     g.K_stale = true;
-    g.kappa_valid = false;
+    g.kappa_valid = g.kappa_eval = false;
     g.zsc_valid = false;
     pf_valid = false;
     g.pred_valid = g.predvar_valid = false;
@@ -1839,7 +1849,7 @@ struct Svgp : SvgpBase {
     HIPCHK(ctx, hipMemcpy2DAsync(g.Z, sizeof(T) * D, z, sizeof(T) * ldz, sizeof(T) * D, m, hipMemcpyDeviceToDevice,
                                  st()));
     g.K_stale = true;
-    g.kappa_valid = false;
+    g.kappa_valid = g.kappa_eval = false;
     g.zsc_valid = false;
     pf_valid = false;
     g.pred_valid = g.predvar_valid = false;
@@ -1943,6 +1953,7 @@ struct Svgp : SvgpBase {
       g.C_valid = false;  // (C = kappa' diag(w) kappa + K^-1 / 4 of a step under the kernel matrices before this refresh)
       if (tw2_kis_of == (int)(&g - lat.data())) tw2_kis_of = -1;
       // (under AGP_FLAG_STALE_K a full-batch run keeps the step's kernel matrices across the refresh of the fresh set)
+      g.kappa_eval = false;
       if (!(g.stale_on && !desc.stochastic)) g.kappa_valid = false;
       g.pred_valid = g.predvar_valid = false;
     }
@@ -2168,6 +2179,9 @@ struct Svgp : SvgpBase {
     const int64_t Bq = rup64(B);
     const int ns = (int)(2 * mp / TILE);
     const bool reuse = !desc.stochastic && !fresh && x == x_last && idx == idx_last && B == B_last && ldx == ldx_last;
+    const bool reuse_eval = fresh && eval_cache_ok && x == ev_x && idx == ev_idx && B == ev_B && ldx == ev_ldx;
+    if (!fresh)
+      for (auto& g : lat) g.kappa_eval = false;  // (a training step takes the buffers)
     const bool prefetched = pf_valid && !fresh && x == pf_x && idx == pf_idx && B == pf_B && ldx == pf_ldx;
     // how many problems one task-graph launch may take (0: none fits, plain launches)
     int dag_nb = 0;
@@ -2231,7 +2245,7 @@ struct Svgp : SvgpBase {
     bool merged_safe = false;
     for (int l = 0; l < nl; ++l) {
       Latent& g = lat[l];
-      const bool keep = reuse && g.kappa_valid;
+      const bool keep = (reuse && g.kappa_valid) || (reuse_eval && g.kappa_eval);
       g.keep_last = keep;
       if (prefetched) {
         // nothing to compute
@@ -2245,7 +2259,8 @@ struct Svgp : SvgpBase {
         AGPCHK((gemm_nt<T, EPI_KAPPA>(ctx, g.Knm, mp, kinv_kappa(g), mp, Bq, mp, mp, 0, g.kappa, mp, g.Knm, mp, nullptr,
                                       g.pk, g.Wbuf, ldp)));
         g.kappa_valid = !desc.stochastic && !fresh;
-      } else {
+        g.kappa_eval = fresh && eval_cache_ok;
+      } else if (!(g.la_state == 1 && g.xa_valid)) {  // (W = kappa Xa' below writes Wbuf itself)
         HIPCHK(ctx, hipMemcpyAsync(g.Wbuf, g.kappa, sizeof(T) * Bq * mp, hipMemcpyDeviceToDevice, st()));
       }
       // When the factor of the CURRENT -2*eta2 and its inverse X_a are still around (a materialize() since the last
@@ -2495,6 +2510,12 @@ struct Svgp : SvgpBase {
     B_last = B;
     ldx_last = ldx;
     rho_last = rho;
+    if (fresh) {  // (whose kappa the buffers hold now: see ev_x)
+      ev_x = x;
+      ev_idx = idx;
+      ev_B = B;
+      ev_ldx = ldx;
+    }
     if (lp.kind == AGP_LIK_MULTIOUTPUT) {
       if (!mo) {
         ctx->err = "multi-output handle: call agp_svgp_set_multioutput first";
@@ -3001,6 +3022,7 @@ struct Svgp : SvgpBase {
       g.K_stale = true;  // (the kernel parameters were stepped in place on the device: nothing to upload)
       g.zsc_valid = false;
       // (the reference's full-batch path keeps its kernel matrices across a hyper step, training.jl:196-204)
+      g.kappa_eval = false;
       if (!(g.stale_on && !desc.stochastic)) g.kappa_valid = false;
       g.pred_valid = g.predvar_valid = false;
     }
@@ -3788,7 +3810,10 @@ struct Svgp : SvgpBase {
       // the Gaussian KL below needs Sigma, mu anyway: factor -2*eta2 WITH its inverse first, so that the local step on the
       // evaluation batch (and the next training step) take W, v from the inverse instead of two more factorisation chains
       for (auto& g : lat) AGPCHK(materialize(g));
-      AGPCHK(step_local(x, ldx, y, idx, B, rho, true));
+      eval_cache_ok = true;  // (only this caller: the online model's fresh local steps see new data behind the same pointers)
+      const agp_status sl = step_local(x, ldx, y, idx, B, rho, true);
+      eval_cache_ok = false;
+      AGPCHK(sl);
       if (lsm) {
         for (int it = 0; it < 2; ++it) {
           AGPCHK(lsm_gamma());
@@ -3796,7 +3821,7 @@ struct Svgp : SvgpBase {
         }
         AGPCHK(lsm_finish());
       }
-      for (auto& g : lat) g.kappa_valid = false;
+      for (auto& g : lat) g.kappa_valid = false;  // (the training step's kappa is gone; the evaluation batch's stays: kappa_eval)
       mf = muf;
       vf = varf;
     } else {
@@ -4045,7 +4070,7 @@ struct Svgp : SvgpBase {
   }
   // the caller refilled / mutated X (or y) in place: nothing cached from it may be reused (AnalyticVI kappa cache, look-ahead)
   agp_status invalidate_data() override {
-    for (auto& g : lat) g.kappa_valid = false;
+    for (auto& g : lat) g.kappa_valid = g.kappa_eval = false;
     pf_valid = false;
     x_last = nullptr;
     idx_last = nullptr;

@@ -358,7 +358,10 @@ agp_status agp_svgp_check_status(agp_svgp* h);
  *   fresh_local = 0 : on the kernel matrices and local variables left by the last cavi_step (x, y, idx, B
  *                     must be that step's) -- `objective(model, state, y)` of training.jl:76
  *   fresh_local = 1 : external ELBO(model, X, y) of src/functions/ELBO.jl:32-47 : recompute kappa on this
- *                     batch, re-initialise local variables, one local update, then the ELBO; rho explicit. */
+ *                     batch, re-initialise local variables, one local update, then the ELBO; rho explicit.
+ *                     Round 6: when the SAME batch (pointer identity of x and idx, same B / ldx) is evaluated again with no training
+ *                     step, kernel / Z change or agp_svgp_invalidate_data in between -- a handle used for monitoring only -- K_nm and
+ *                     kappa of that batch are kept, like the full-batch kappa cache of the step. */
 agp_status agp_svgp_elbo(agp_svgp* h, const void* x, int64_t ldx, const void* y, const int64_t* idx, int64_t B,
                          double rho, int32_t fresh_local, double* elbo_host);
 /* The same evaluation WITHOUT a host round trip (convergence monitoring: `objective(model, state, y)` every few iterations of

@@ -152,6 +152,14 @@ def _child(env_extra, code, timeout=300):
 
 
 def test_fallback_counter_behind_the_abi(mods):
+    import _knobs
+
+    if _knobs.no_task_graph():
+        pytest.skip("AGP_CHOL_DAG=0: no task-graph launches, hence nothing for the fallback to re-run")
+    _fallback_counter_body()
+
+
+def _fallback_counter_body():
     """agp_ctx_task_graph_fallbacks: 0 for a run on a GPU the process has to itself, the number of re-run launches under the test
     hook that aborts every task-graph launch of a CAVI step (bench.py prints the same count as `task_graph_fallbacks`)."""
     out = _child({}, _FB_CODE)
@@ -162,6 +170,14 @@ def test_fallback_counter_behind_the_abi(mods):
 
 
 def test_an_oversubscribed_fallback_ends_in_an_error_status_not_in_a_hang(mods):
+    import _knobs
+
+    if _knobs.no_task_graph():
+        pytest.skip("AGP_CHOL_DAG=0: no task-graph launches, hence no in-stream fallback")
+    _oversubscribed_body()
+
+
+def _oversubscribed_body():
     """The in-stream fallback separates its phases by grid barriers and relies on all of its workgroups being resident.  Until round 5
     a workgroup that could not get a compute unit made the others spin forever (docs/DESIGN_LOG.md section 14, "the one unbounded
     wait"); now the barrier is limited on the device's 100 MHz clock (8 s) and latches status -3.  The hook makes the fallback's
@@ -309,3 +325,58 @@ def test_device_fixed_points_of_the_8f2_likelihoods_maximise_their_collapsed_bou
     K, kappa, Kt = _sparse_pieces(kern, X, Z, 1e-4)
     mu, Sig, val = _maximise_collapsed_bound(term, K, kappa, Kt, np.asarray(y, dtype=np.float64), 0.9 * mu_d, np.linalg.cholesky(1.1 * Sig_d))
     assert np.max(np.abs(mu_d - mu)) < 2e-6 * np.max(np.abs(mu)) and np.max(np.abs(Sig_d - Sig)) < 2e-6 * np.max(np.abs(Sig))
+
+
+def test_evaluation_batch_kappa_cache_and_its_invalidation(mods):
+    """Round 6: a handle that evaluates ELBO(model, X[idx], y[idx]) (fresh local variables) again and again on the SAME batch -- the
+    shadow handle of a SideObjective -- keeps K_nm and kappa = K_nm K^-1 of that batch between the calls (pointer identity, like the
+    full-batch kappa cache).  The cached evaluation equals the uncached one of a new handle in the same state; another index buffer,
+    agp_svgp_invalidate_data after an in-place change of X, a new kernel and a training step in between all recompute."""
+    AGP, R, capi, torch = mods
+    L = capi.lib()
+    rng = np.random.default_rng(5)
+    N, D, m, B, EVAL = 3000, 4, 64, 128, 512
+    X = rng.random((N, D))
+    y = np.sign(np.sin(4 * X[:, 0]) + X[:, 1] - 0.8 + 0.3 * rng.standard_normal(N))
+    Z = X[rng.permutation(N)[:m]].copy()
+    idx = [rng.choice(N, B, replace=False) for _ in range(6)]
+    ia = torch.as_tensor(rng.choice(N, EVAL, replace=False).astype(np.int64), device="cuda")
+    ib = torch.as_tensor(rng.choice(N, EVAL, replace=False).astype(np.int64), device="cuda")
+
+    def make(scale=3.0):
+        mdl = AGP.SVGP(AGP.SqExponentialKernel() @ AGP.ScaleTransform(scale), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z, optimiser=False)
+        mdl._ensure_handle(EVAL)
+        AGP.train_(mdl, X, y, 3, idx_stream=idx[:3])
+        return mdl
+
+    def elbo(mdl, it):
+        Xd, yd, _ = mdl._data
+        e = C.c_double()
+        mdl._chk(L.agp_svgp_elbo(mdl._h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(yd.data_ptr()), C.c_void_p(it.data_ptr()),
+                                 EVAL, N / EVAL, 1, C.byref(e)))
+        return e.value
+
+    a = make()
+    v1 = elbo(a, ia)
+    v1b = elbo(a, ia)                       # cached kappa, same state
+    assert v1b == pytest.approx(v1, rel=1e-13)
+    # another state through set_state (what the shadow handle of a SideObjective sees), cached kappa against a new handle
+    b = make()
+    AGP.train_(b, X, y, 3, idx_stream=idx[3:])
+    mu, Sig, e1, e2 = b.get_state(0)
+    a.set_state(0, e1, e2)
+    v2 = elbo(a, ia)
+    assert v2 == pytest.approx(elbo(b, ia), rel=1e-12) and abs(v2 - v1) > 1e-6 * abs(v1)
+    # another index buffer: recomputed
+    assert elbo(a, ib) == pytest.approx(elbo(b, ib), rel=1e-12)
+    # in-place change of the data + agp_svgp_invalidate_data
+    Xd, yd, _ = a._data
+    v_before = elbo(a, ia)
+    Xd[ia[:50]] += 0.05
+    a._chk(L.agp_svgp_invalidate_data(a._h))
+    v_after = elbo(a, ia)
+    assert abs(v_after - v_before) > 1e-8 * abs(v_before)
+    Xb = b._data[0]
+    Xb[ia[:50]] += 0.05
+    b._chk(L.agp_svgp_invalidate_data(b._h))
+    assert v_after == pytest.approx(elbo(b, ia), rel=1e-12)

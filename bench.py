@@ -878,6 +878,7 @@ def main():
         side_prio = os.environ.get("AGP_BENCH_SIDE_PRIORITY")  # (development: -1 = high, 0 = normal; unset = the default stream priority)
         side = AGP.SideObjective(model2, EVAL, ring=4, priority=None if side_prio is None else int(side_prio)) if elbo_side else None
         tk, pending_tk, rdy = C.c_int32(), None, C.c_int32()
+        side_q, side_lag = [], max(1, min(3, int(os.environ.get("AGP_BENCH_ELBO_LAG", "1"))))
         while it < max_it and (hit["raw"] is None or hit["smoothed"] is None or hit["reach"] is None) and \
                 (time.perf_counter() - ts) < t_cap:
             for _ in range(10):
@@ -891,9 +892,13 @@ def main():
                 model2._chk(L.agp_svgp_elbo(h2, xp, ld, yp, C.c_void_p(eval_idx.data_ptr()), EVAL, rho_e, 1, C.byref(e)))
                 it_of_value = it
             elif elbo_side:
-                prev, pending_tk = pending_tk, (side.enqueue(eng._X, eng._y, eval_idx, EVAL, rho_e), it)
-                if prev is None:
+                # (side_q: tickets in flight, oldest first; a value is read `side_lag` checks after it was enqueued -- with one check
+                #  of lag the host can wait for a side stream that shares the chip with ten training steps; SideObjective's ring
+                #  holds four snapshots)
+                side_q.append((side.enqueue(eng._X, eng._y, eval_idx, EVAL, rho_e), it))
+                if len(side_q) <= side_lag:
                     continue
+                prev = side_q.pop(0)
                 e.value = side.fetch(prev[0])
                 it_of_value = prev[1]
             else:
@@ -916,9 +921,11 @@ def main():
                 m1, m0 = sum(hist[-10:]) / 10.0, sum(hist[-20:-10]) / 10.0
                 if abs(m1 - m0) / abs(m1) < 1e-3:
                     hit["smoothed"] = (now, it_of_value, hist[-1])
+        for tq in side_q:  # close the tickets still open
+            side.fetch(tq[0])
         if pending_tk is not None:  # close the last ticket
             if elbo_side:
-                side.fetch(pending_tk[0])
+                pass
             else:
                 model2._chk(L.agp_svgp_elbo_fetch(h2, pending_tk[0], 1, C.byref(e), C.byref(rdy)))
         torch.cuda.synchronize()

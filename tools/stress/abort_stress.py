@@ -30,7 +30,24 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
     t0 = time.time()
     try:
         ma = AGP.SVGP(AGP.SqExponentialKernel() @ AGP.ScaleTransform(3.0), AGP.LogisticLikelihood(), AGP.AnalyticSVI(B), Z, optimiser=False)
-        AGP.train_(ma, X, y, iters, idx_stream=idx)
+        if os.environ.get("AGP_STRESS_NO_LOOKAHEAD") == "1":
+            # the same six steps through the raw ABI WITHOUT agp_svgp_prefetch: no look-ahead stream, kappa computed in line
+            import ctypes as C
+
+            import torch
+
+            from agp_amd import capi
+
+            L = capi.lib()
+            AGP.train_(ma, X, y, 1, idx_stream=idx[:1])
+            Xd, yd, _ = ma._data
+            ia = torch.as_tensor(np.stack(idx), device="cuda")
+            for i in range(1, iters):
+                assert L.agp_svgp_cavi_step(ma._h, C.c_void_p(Xd.data_ptr()), Xd.stride(0), C.c_void_p(yd.data_ptr()),
+                                            C.c_void_p(ia[i].data_ptr()), B, N / B) == 0
+            ma._chk(L.agp_svgp_check_status(ma._h))
+        else:
+            AGP.train_(ma, X, y, iters, idx_stream=idx)
         e2 = ma.get_state(0)[3]
         if ref is None:
             ref = e2

@@ -819,6 +819,18 @@ def main():
             # (fp64 squared-exponential: 22, of which 16 are FMAs -- s2, d2, two clamps, exp_mhalf's 17, the row-dot FMA; the
             # general path ~48: csrc/agp_cavi.h); every fraction against the datasheet peaks
             valu_per_value = 22 if (not f32 and cfg["kernel"] == "sqexp") else 48
+            # ... and the kernel's TOTAL VALU instructions per value from the committed counter pass of the same kernel (SQ_INSTS_VALU
+            # minus SQ_INSTS_MFMA, profiles/r06_predict_pmc.json: the epilogue + the per-tile copy / address work amortised over a
+            # lane's 16 values), which is what the VALU share below is computed from when the file covers this kernel
+            valu_total, valu_src = float(valu_per_value), "ISA count of the epilogue only"
+            try:
+                with open(os.path.join(ROOT, "profiles", "r06_predict_pmc.json")) as fh:
+                    pm = json.load(fh)
+                if not f32 and cfg["kernel"] == "sqexp" and pm["m"] == m:
+                    valu_total = float(pm["derived"]["non_mfma_valu_per_kernel_value_lanes"])
+                    valu_src = "profiles/r06_predict_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_MFMA, tools/pmc_predict.py)"
+            except Exception:
+                pass
             vpeak = peak  # the VALU's FMA rate equals the MFMA rate in fp64 (78.6 TF); fp32: quoted against the MFMA peak as well
             out["predict_roofline"] = {
                 "kernel": f"k_kernelmatrix_mma<{tname}, {'K_SQEXP' if cfg['kernel'] == 'sqexp' else 'K_MATERN52'}, 1> (streaming: K_*m never stored)",
@@ -828,14 +840,22 @@ def main():
                         "unit": "GB/s", "frac": round((N * D * es + N * es) / tpl / 1e9 / 8000.0, 4)},
                 "mfma": {"achieved": round(2.0 * nval * D / tpl / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(2.0 * nval * D / tpl / 1e12 / peak, 4), "what": "cross term x.z of the squared distances"},
-                "valu": {"instructions_per_value": valu_per_value, "achieved": round(2.0 * valu_per_value * nval / tpl / 1e12, 2),
+                "valu": {"instructions_per_value": valu_per_value, "instructions_per_value_total": valu_total,
+                         "instructions_per_value_total_source": valu_src,
+                         "achieved": round(2.0 * valu_total * nval / tpl / 1e12, 2),
                          "peak": vpeak, "unit": "TFLOP/s (every VALU instruction counted as an FMA)",
-                         "frac": round(2.0 * valu_per_value * nval / tpl / 1e12 / vpeak, 4)},
-                "combined_frac_of_one_pipe": round((2.0 * nval * D + 2.0 * valu_per_value * nval) / tpl / 1e12 / peak, 4),
+                         "frac": round(2.0 * valu_total * nval / tpl / 1e12 / vpeak, 4)},
+                "combined_frac_of_one_pipe": round((2.0 * nval * D + 2.0 * valu_total * nval) / tpl / 1e12 / peak, 4),
                 "clock_power_during_the_loop": clk,
                 "note": "MFMA and VALU work of different waves overlap; their sum runs at about the rate the register-only MFMA loop "
                         "sustains under the socket power limit (mfma_sustained) -- DESIGN.md section 4",
             }
+            try:  # fabric bytes per pass from the same counter file (FETCH_SIZE x 2 + WRITE_SIZE, separate passes)
+                if valu_src.startswith("profiles/"):
+                    out["predict_roofline"]["hbm"]["traffic"] = pm["derived"]["fabric_bytes_per_launch_corrected"]
+                    out["predict_roofline"]["hbm"]["algorithmic_bytes"] = int(N * D * es + N * es)
+            except Exception:
+                pass
         except Exception as ex:
             out["predict_roofline"] = {"error": repr(ex)}
 

@@ -30,5 +30,5 @@ def test_committed_bench_line(cfg):
     if cfg == "c2":  # the headline configuration carries the second half of the metric and the round's new objects
         assert d["time_to_elbo_tol_reachable"]["seconds"] < 0.72 and d["time_to_elbo_tol_reachable"]["iters"] == 1900
         p = d["predict_roofline"]
-        assert p["seconds_per_pass"] < 2.2e-3 and p["valu"]["instructions_per_value"] == 22
+        assert p["seconds_per_pass"] < 2.2e-3 and p["valu"]["instructions_per_value"] == 22 and 30 < p["valu"]["instructions_per_value_total"] < 40
         assert 0 < p["hbm"]["frac"] < 0.05 and 0.3 < p["mfma"]["frac"] < 0.6
